@@ -1,0 +1,81 @@
+"""CPU: the oracle (oracle/fvgn_oracle.py) reproduces the golden vectors produced by the reference itself
+(tests/golden/make_golden.py).  Tolerance: 1e-5 relative fp32 (BASELINE.json north_star); the generator log
+(tests/golden/make_golden.log) shows the forward agreeing bit-for-bit in the build container."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import cases
+from oracle import fvgn_oracle as O
+
+TOL = 1e-5
+
+
+def _rel(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return np.abs(a - b).max() / (np.abs(b).max() + 1e-30)
+
+
+@pytest.mark.parametrize("name", list(cases.CASES))
+def test_oracle_matches_reference_golden(name, golden_dir):
+    fx = np.load(os.path.join(golden_dir, f"{name}.npz"))
+    graphs = cases.make_graphs(name)
+    P = O.init_parameters(cases.WEIGHT_SEED)
+    names = list(P)
+    assert names == list(fx["param_names"])
+    # inputs regenerated identically (fingerprints committed with the golden vectors)
+    assert _rel(cases.fingerprint(graphs[0].x.numpy()), fx["in.x"]) < 1e-12
+    assert _rel(cases.fingerprint(graphs[0].edge_index.numpy()), fx["in.edge_index"]) == 0
+    assert _rel(cases.fingerprint(graphs[1].face_node_x.numpy()), fx["in.face_node_x"]) == 0
+    assert _rel(cases.fingerprint(graphs[1].A_node_to_node.numpy()), fx["in.A"]) < 1e-12
+    w = np.stack([cases.fingerprint(P[k].numpy()) for k in names])
+    assert _rel(w, fx["in.weights"]) < 1e-12
+
+    buffers = O.new_normalizer_buffers()
+    Pg = {k: v.detach().requires_grad_(True) for k, v in P.items()}
+    out, inter = O.model_forward(Pg, buffers, graphs, return_intermediates=True)
+    loss = O.training_loss(out)
+    for key, val in (("loss_cont", out[0]), ("loss_mom_x", out[1]), ("loss_mom_y", out[2]), ("loss_press", out[3]),
+                     ("uvp_node", out[4]), ("uvp_cell", out[5]), ("x_norm", graphs[0].x),
+                     ("edge_attr", graphs[0].edge_attr), ("dec", inter["dec"])):
+        assert _rel(val.detach().numpy(), fx[key]) < TOL, key
+    assert abs(float(loss) - float(fx["loss"])) < TOL * abs(float(fx["loss"]))
+    for k in inter:
+        if "tap_fp." + k in fx:
+            assert _rel(cases.fingerprint(inter[k].detach().numpy())[:2], fx["tap_fp." + k][:2]) < TOL, k
+
+    grads = dict(zip(names, torch.autograd.grad(loss, [Pg[k] for k in names], allow_unused=True)))
+    gfp = fx["grad_fp"]
+    gscale = np.nanmax(gfp[:, 1])  # largest gradient L2 norm in the model: noise floor for ~zero gradients
+    for i, k in enumerate(names):
+        if np.isnan(gfp[i, 0]):
+            assert grads[k] is None, k  # ln_1 / Attn.temperature are unused
+            continue
+        mine = cases.fingerprint(grads[k].numpy())
+        assert abs(mine[1] - gfp[i, 1]) < 1e-4 * gfp[i, 1] + 1e-7 * gscale, k
+    for k in fx.files:
+        if k.startswith("grad."):
+            g = grads[k[5:]].numpy()
+            assert np.abs(g - fx[k]).max() < 1e-4 * np.abs(fx[k]).max() + 1e-7 * gscale, k
+    # Normalizer buffers after one accumulation (utils/normalization.py:52-66)
+    assert _rel(buffers["acc_count"].numpy(), fx["norm.acc_count"]) < 1e-6
+    assert _rel(buffers["acc_sum"].numpy(), fx["norm.acc_sum"]) < 1e-5
+    assert _rel(buffers["acc_sum_squared"].numpy(), fx["norm.acc_sum_squared"]) < 1e-5
+
+
+def test_wlsq_known_answer(golden_dir):
+    """The reference's only known-answer material (grad_rec_acc_test.py:87-181): WLSQ gradient of the analytic field."""
+    import math
+    fx = np.load(os.path.join(golden_dir, "wlsq_analytic.npz"))
+    meshes, _ = cases.make_meshes("cyl_cavity_b2")
+    m = meshes[0]
+    pos = torch.from_numpy(m["node|pos"]).float()
+    x, y = pos[:, 0:1], pos[:, 1:2]
+    phi = (1.0 + 0.01 * torch.sin(5 * math.pi * x) + 0.01 * torch.sin(5 * math.pi * y)
+           + 0.01 * torch.cos(5 * math.pi * x * y))
+    t = lambda k: torch.from_numpy(m[k])
+    g = O.node_based_WLSQ(phi, t("face_node_x"), t("support_edge"), t("A_node_to_node"),
+                          t("single_B_node_to_node"), t("extra_B_node_to_node"))
+    assert _rel(g.numpy(), fx["grad"]) < TOL
