@@ -1,0 +1,459 @@
+// Row-tile fused GEMM chain on fp32 MFMA (gfx950).  See include/gfv.h for the contract.
+//
+// One workgroup = 4 waves = a tile of 64 rows; wave w owns rows 16w..16w+15 of the tile for the whole chain, so
+// the activation tile in LDS is wave-private (no workgroup barrier on it) and LayerNorm / row ops are wave-local.
+// Only the weight stream is shared: W is streamed from L2 through a double-buffered LDS stage in 32-wide k
+// slices ([128 n][32 k], row stride 36 floats), one barrier per slice, next slice prefetched to registers while
+// the current one feeds the MFMAs.
+//
+// MFMA: v_mfma_f32_16x16x4_f32, exact fp32.  Each wave computes 16 rows x 128 columns = 8 accumulator tiles.
+// Operand trick: the k index inside a 16-wide k step is permuted consistently for A and B (lane group q takes
+// k = 4q..4q+3), so every lane fetches its four A (and four B) values of four consecutive MFMAs with ONE
+// ds_read_b128 from row-major [row][k] / [n][k] images - nn.Linear's [out,in] weight layout is read as stored.
+#include "gfv_common.h"
+#include "../../include/gfv.h"
+
+namespace {
+
+constexpr int BM = 64;
+constexpr int LDX = 132;   // activation tile row stride (floats): 128 + 4 -> rows start 4 banks apart
+constexpr int WK = 32;     // k slice of the weight stage
+constexpr int LDW = 36;    // weight stage row stride
+constexpr int LDO = 132;   // output staging row stride
+constexpr int XS_FLOATS = BM * LDX;
+constexpr int WS_FLOATS = 128 * LDW;
+constexpr int OS_FLOATS = 4 * 4 * LDO;  // per wave 4 rows
+constexpr int LDS_FLOATS = XS_FLOATS + 2 * WS_FLOATS + OS_FLOATS;
+
+struct Ctx {
+  int tid, wave, lane, nl, q, rr, c4;
+  int row0;  // first global row of the tile
+  int M;
+};
+
+__device__ __forceinline__ void wave_lds_sync() {
+  // LDS traffic of one wave is processed in order; make prior ds ops complete and stop compiler reordering.
+  __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+  __builtin_amdgcn_wave_barrier();
+}
+
+// ---- weight slice: global -> registers -> LDS ------------------------------------------------------------
+struct WSlice {
+  const float* W;  // base of the layer's weight
+  int ldw;         // = K of the layer
+  int n0;          // first output row of this pass
+  int N;           // valid output rows of the layer
+  int kcol;        // first weight column of the slice
+  int kvalid;      // number of valid columns from kcol (may be <= 0 .. WK)
+  int vec;         // float4 loads allowed
+};
+
+__device__ __forceinline__ void wslice_load(const WSlice& s, const Ctx& c, float4 (&reg)[4]) {
+  const int c4 = c.tid & 7;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int n = (c.tid >> 3) + 32 * p;
+    const int gn = s.n0 + n;
+    const int k = 4 * c4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (gn < s.N) {
+      const float* src = s.W + (size_t)gn * s.ldw + s.kcol + k;
+      if (s.vec) {
+        if (k < s.kvalid) v = *reinterpret_cast<const float4*>(src);
+      } else {
+        if (k + 0 < s.kvalid) v.x = src[0];
+        if (k + 1 < s.kvalid) v.y = src[1];
+        if (k + 2 < s.kvalid) v.z = src[2];
+        if (k + 3 < s.kvalid) v.w = src[3];
+      }
+    }
+    reg[p] = v;
+  }
+}
+
+__device__ __forceinline__ void wslice_store(float* Wb, const Ctx& c, const float4 (&reg)[4]) {
+  const int c4 = c.tid & 7;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int n = (c.tid >> 3) + 32 * p;
+    *reinterpret_cast<float4*>(&Wb[n * LDW + 4 * c4]) = reg[p];
+  }
+}
+
+// one 32-wide k slice: acc[t] += X[wave rows][kx0..kx0+ksteps*16) * Wb^T
+__device__ __forceinline__ void mma_slice(floatx4 (&acc)[8], const float* Xs, const float* Wb, const Ctx& c, int kx0,
+                                         int ksteps, int ntiles) {
+  const float* xrow = Xs + (c.wave * 16 + c.nl) * LDX + kx0 + 4 * c.q;
+  const float* wrow = Wb + c.nl * LDW + 4 * c.q;
+  for (int ks = 0; ks < ksteps; ++ks) {
+    const float4 a = *reinterpret_cast<const float4*>(xrow + 16 * ks);
+    if (ntiles == 8) {
+      float4 b[8];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) b[t] = *reinterpret_cast<const float4*>(wrow + t * 16 * LDW + 16 * ks);
+#pragma unroll
+      for (int t = 0; t < 8; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b[t].x, acc[t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < 8; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b[t].y, acc[t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < 8; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b[t].z, acc[t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < 8; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b[t].w, acc[t], 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        if (t < ntiles) {
+          const float4 b = *reinterpret_cast<const float4*>(wrow + t * 16 * LDW + 16 * ks);
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc[t], 0, 0, 0);
+        }
+      }
+    }
+  }
+}
+
+// ---- row helpers in the "coalesced" layout: a row of 128 floats = 32 lanes x float4 --------------------------
+__device__ __forceinline__ float4 f4_add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float f4_sum(float4 a) { return (a.x + a.y) + (a.z + a.w); }
+
+__device__ __forceinline__ void row_stats(const float4 v, float& mean, float& rstd) {
+  mean = gfv_half_sum(f4_sum(v)) * (1.0f / 128.0f);
+  const float dx = v.x - mean, dy = v.y - mean, dz = v.z - mean, dw = v.w - mean;
+  const float var = gfv_half_sum((dx * dx + dy * dy) + (dz * dz + dw * dw)) * (1.0f / 128.0f);
+  rstd = rsqrtf(var + 1e-5f);  // nn.LayerNorm eps (EPD.py:32)
+}
+
+__device__ __forceinline__ float4 row_layernorm(const float4 v, const float4 g, const float4 b) {
+  float mean, rstd;
+  row_stats(v, mean, rstd);
+  return make_float4((v.x - mean) * rstd * g.x + b.x, (v.y - mean) * rstd * g.y + b.y,
+                     (v.z - mean) * rstd * g.z + b.z, (v.w - mean) * rstd * g.w + b.w);
+}
+
+// LayerNorm backward for one row: y = LN input row, go = grad wrt LN output; returns grad wrt LN input and
+// accumulates the lane's 4 columns of dgamma / dbeta.
+__device__ __forceinline__ float4 row_layernorm_bwd(const float4 y, const float4 go, const float4 g, float4& dgam,
+                                                    float4& dbet) {
+  float mean, rstd;
+  row_stats(y, mean, rstd);
+  const float4 xh = make_float4((y.x - mean) * rstd, (y.y - mean) * rstd, (y.z - mean) * rstd, (y.w - mean) * rstd);
+  const float4 gg = make_float4(go.x * g.x, go.y * g.y, go.z * g.z, go.w * g.w);
+  const float m1 = gfv_half_sum(f4_sum(gg)) * (1.0f / 128.0f);
+  const float m2 = gfv_half_sum((gg.x * xh.x + gg.y * xh.y) + (gg.z * xh.z + gg.w * xh.w)) * (1.0f / 128.0f);
+  dgam.x += go.x * xh.x; dgam.y += go.y * xh.y; dgam.z += go.z * xh.z; dgam.w += go.w * xh.w;
+  dbet.x += go.x; dbet.y += go.y; dbet.z += go.z; dbet.w += go.w;
+  return make_float4(rstd * (gg.x - m1 - xh.x * m2), rstd * (gg.y - m1 - xh.y * m2), rstd * (gg.z - m1 - xh.z * m2),
+                     rstd * (gg.w - m1 - xh.w * m2));
+}
+
+__device__ __forceinline__ float4 load_row4(const float* base, size_t row, int ld, int col, int width, bool vec) {
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float* p = base + row * (size_t)ld + col;
+  if (vec) {
+    if (col < width) v = *reinterpret_cast<const float4*>(p);
+  } else {
+    if (col + 0 < width) v.x = p[0];
+    if (col + 1 < width) v.y = p[1];
+    if (col + 2 < width) v.z = p[2];
+    if (col + 3 < width) v.w = p[3];
+  }
+  return v;
+}
+
+__device__ __forceinline__ void store_row4(float* base, size_t row, int ld, int col, int width, bool vec, float4 v) {
+  float* p = base + row * (size_t)ld + col;
+  if (vec) {
+    if (col < width) *reinterpret_cast<float4*>(p) = v;
+  } else {
+    if (col + 0 < width) p[0] = v.x;
+    if (col + 1 < width) p[1] = v.y;
+    if (col + 2 < width) p[2] = v.z;
+    if (col + 3 < width) p[3] = v.w;
+  }
+}
+
+// ---- stage one input segment (<=128 columns) of the tile into the wave's rows of Xs ---------------------------
+__device__ void stage_input(const gfv_rowtile_args_t& A, int si, float* Xs, const Ctx& c, float4& dgam, float4& dbet) {
+  const gfv_seg_t& s = A.seg[si];
+  const bool vec = ((s.width & 3) == 0) && ((s.ld & 3) == 0);
+  const int col = 4 * c.c4;
+  float4 gam = make_float4(1.f, 1.f, 1.f, 1.f), bet = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (A.in_op == GFV_IN_LN || A.in_op == GFV_IN_LNBWD) {
+    gam = *reinterpret_cast<const float4*>(A.in_gamma + col);
+    if (A.in_op == GFV_IN_LN) bet = *reinterpret_cast<const float4*>(A.in_beta + col);
+  }
+#pragma unroll 2
+  for (int p = 0; p < 8; ++p) {
+    const int r = c.wave * 16 + c.rr + 2 * p;
+    const int m = c.row0 + r;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (m < c.M) {
+      const size_t srow = s.idx ? (size_t)s.idx[m] : (size_t)m;
+      v = load_row4(s.ptr, srow, s.ld, col, s.width, vec);
+      if (si == 0 && A.in_add) v = f4_add(v, load_row4(A.in_add, srow, s.ld, col, s.width, vec));
+      if (si == 0 && A.gadd) {
+        const int node = (col < 64) ? A.gadd_s[m] : A.gadd_r[m];
+        v = f4_add(v, *reinterpret_cast<const float4*>(A.gadd + (size_t)node * 64 + (col & 63)));
+      }
+    }
+    if (A.in_op == GFV_IN_GELU) {
+      v = make_float4(gfv_gelu(v.x), gfv_gelu(v.y), gfv_gelu(v.z), gfv_gelu(v.w));
+    } else if (A.in_op == GFV_IN_LN) {
+      v = row_layernorm(v, gam, bet);
+    } else if (A.in_op == GFV_IN_LNBWD) {
+      float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (m < c.M) y = *reinterpret_cast<const float4*>(A.in_aux + (size_t)m * 128 + col);
+      v = row_layernorm_bwd(y, v, gam, dgam, dbet);
+    }
+    if (m >= c.M) v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (si == 0 && A.in_save && m < c.M) *reinterpret_cast<float4*>(A.in_save + (size_t)m * 128 + col) = v;
+    *reinterpret_cast<float4*>(&Xs[r * LDX + col]) = v;
+  }
+}
+
+// write the accumulators of the wave's 16x128 slab into its rows of Xs
+__device__ __forceinline__ void acc_to_xs(const floatx4 (&acc)[8], float* Xs, const Ctx& c) {
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) Xs[(c.wave * 16 + 4 * c.q + reg) * LDX + 16 * t + c.nl] = acc[t][reg];
+  }
+}
+
+// intermediate epilogue: element op in the coalesced layout, result stays in Xs as the next layer's input
+__device__ void mid_epilogue(const gfv_layer_t& L, float* Xs, const Ctx& c) {
+  const int col = 4 * c.c4;
+  float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (L.bias && L.op != GFV_OP_MUL_DGELU) bias = *reinterpret_cast<const float4*>(L.bias + col);
+#pragma unroll 2
+  for (int p = 0; p < 8; ++p) {
+    const int r = c.wave * 16 + c.rr + 2 * p;
+    const int m = c.row0 + r;
+    float4 v = f4_add(*reinterpret_cast<const float4*>(&Xs[r * LDX + col]), bias);
+    if (L.op == GFV_OP_BIAS_GELU) {
+      if (L.save && m < c.M) *reinterpret_cast<float4*>(L.save + (size_t)m * 128 + col) = v;
+      v = make_float4(gfv_gelu(v.x), gfv_gelu(v.y), gfv_gelu(v.z), gfv_gelu(v.w));
+    } else if (L.op == GFV_OP_MUL_DGELU) {
+      float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (m < c.M) z = *reinterpret_cast<const float4*>(L.aux + (size_t)m * 128 + col);
+      v = make_float4(v.x * gfv_dgelu(z.x), v.y * gfv_dgelu(z.y), v.z * gfv_dgelu(z.z), v.w * gfv_dgelu(z.w));
+      if (L.save && m < c.M) *reinterpret_cast<float4*>(L.save + (size_t)m * 128 + col) = v;
+    }
+    *reinterpret_cast<float4*>(&Xs[r * LDX + col]) = v;
+  }
+}
+
+// final epilogue for one 128-wide output chunk: 4 rounds of 4 rows through the wave's staging buffer
+__device__ void final_epilogue(const gfv_rowtile_args_t& A, const gfv_layer_t& L, int chunk, const floatx4 (&acc)[8],
+                               float* Os, const Ctx& c, float4& dgam, float4& dbet) {
+  float* os = Os + c.wave * 4 * LDO;
+  const int ncol = L.N - 128 * chunk;
+  const int width = ncol < 128 ? ncol : 128;
+  const int old = A.out_ld[chunk];
+  const bool ovec = ((width & 3) == 0) && ((old & 3) == 0);
+  const int col = 4 * c.c4;
+  float* out = A.out[chunk];
+  const float* res = A.res[chunk];
+  const int rld = A.res_ld[chunk];
+  float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (L.bias) bias = load_row4(L.bias, 0, 0, 128 * chunk + col, L.N, (L.N & 3) == 0);
+  float4 gam = make_float4(1.f, 1.f, 1.f, 1.f), bet = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (A.fin_op != GFV_FIN_PLAIN) {
+    gam = *reinterpret_cast<const float4*>(A.fin_gamma + col);
+    if (A.fin_op == GFV_FIN_LN) bet = *reinterpret_cast<const float4*>(A.fin_beta + col);
+  }
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg) {
+    // rows {reg, 4+reg, 8+reg, 12+reg} of the wave's slab -> staging rows 0..3 (index q)
+#pragma unroll
+    for (int t = 0; t < 8; ++t) os[c.q * LDO + 16 * t + c.nl] = acc[t][reg];
+    wave_lds_sync();
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int sr = c.rr + 2 * p;  // staging row = q index
+      const int r = c.wave * 16 + 4 * sr + reg;
+      const int m = c.row0 + r;
+      float4 v = f4_add(*reinterpret_cast<const float4*>(&os[sr * LDO + col]), bias);
+      const bool live = m < c.M;
+      if (L.op == GFV_OP_MUL_DGELU) {
+        float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (live) z = load_row4(L.aux, (size_t)m, L.N, 128 * chunk + col, L.N, true);
+        v = make_float4(v.x * gfv_dgelu(z.x), v.y * gfv_dgelu(z.y), v.z * gfv_dgelu(z.z), v.w * gfv_dgelu(z.w));
+      }
+      if (A.fin_op == GFV_FIN_LN) {
+        if (A.fin_presave && live) *reinterpret_cast<float4*>(A.fin_presave + (size_t)m * 128 + col) = v;
+        v = row_layernorm(v, gam, bet);
+      } else if (A.fin_op == GFV_FIN_LNBWD) {
+        float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (live) y = *reinterpret_cast<const float4*>(A.fin_aux + (size_t)m * 128 + col);
+        if (!live) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        v = row_layernorm_bwd(y, v, gam, dgam, dbet);
+      }
+      if (live) {
+        if (chunk == 0 && A.out_nores) *reinterpret_cast<float4*>(A.out_nores + (size_t)m * 128 + col) = v;
+        if (res) v = f4_add(v, load_row4(res, (size_t)m, rld, col, width, ovec && ((rld & 3) == 0)));
+        store_row4(out, (size_t)m, old, col, width, ovec, v);
+      }
+    }
+    wave_lds_sync();
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void rowtile_chain_kernel(const gfv_rowtile_args_t A) {
+  __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
+  float* Xs = lds;
+  float* Wb0 = lds + XS_FLOATS;
+  float* Wb1 = Wb0 + WS_FLOATS;
+  float* Os = Wb1 + WS_FLOATS;
+
+  Ctx c;
+  c.tid = threadIdx.x;
+  c.wave = c.tid >> 6;
+  c.lane = c.tid & 63;
+  c.nl = c.lane & 15;
+  c.q = c.lane >> 4;
+  c.rr = c.lane >> 5;
+  c.c4 = c.lane & 31;
+  c.row0 = blockIdx.x * BM;
+  c.M = A.M;
+
+  float4 dgam = make_float4(0.f, 0.f, 0.f, 0.f), dbet = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 wreg[4];
+  int wbuf = 0;
+
+  // flat weight-slice sequence: (layer, pass, input chunk, k slice)
+  auto make_slice = [&](int layer, int pass, int chunk, int ks) {
+    WSlice s;
+    const gfv_layer_t& L = A.layer[layer];
+    s.W = L.W;
+    s.ldw = L.K;
+    s.n0 = 128 * pass;
+    s.N = L.N;
+    int koff = 0, width = 128;
+    if (layer == 0) {
+      for (int i = 0; i < chunk; ++i) koff += A.seg[i].width;
+      width = A.seg[chunk].width;
+    }
+    s.kcol = koff + ks;
+    s.kvalid = width - ks;
+    s.vec = ((L.K & 3) == 0) && ((koff & 3) == 0) && ((width & 3) == 0);
+    return s;
+  };
+
+  {
+    WSlice s0 = make_slice(0, 0, 0, 0);
+    wslice_load(s0, c, wreg);
+    wslice_store(Wb0, c, wreg);
+  }
+  __syncthreads();
+
+  for (int layer = 0; layer < A.nlayers; ++layer) {
+    const gfv_layer_t& L = A.layer[layer];
+    const bool last = (layer == A.nlayers - 1);
+    const int npass = last ? (L.N + 127) / 128 : 1;
+    const int nchunk = (layer == 0) ? A.nseg : 1;
+    for (int pass = 0; pass < npass; ++pass) {
+      floatx4 acc[8];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) acc[t] = floatx4{0.f, 0.f, 0.f, 0.f};
+      const int nrem = L.N - 128 * pass;
+      const int ntiles = nrem >= 128 ? 8 : (nrem + 15) / 16;
+      for (int chunk = 0; chunk < nchunk; ++chunk) {
+        int width = 128;
+        if (layer == 0) {
+          width = A.seg[chunk].width;
+          if (nchunk > 1 || pass == 0) {
+            wave_lds_sync();
+            stage_input(A, chunk, Xs, c, dgam, dbet);
+            wave_lds_sync();
+          }
+        }
+        const int kpad = (width + 15) & ~15;
+        for (int ks = 0; ks < kpad; ks += WK) {
+          // locate the next slice in the flat sequence
+          int nl_ = layer, np_ = pass, nc_ = chunk, nk_ = ks + WK;
+          bool have_next = true;
+          if (nk_ >= kpad) {
+            nk_ = 0;
+            nc_ = chunk + 1;
+            if (nc_ >= nchunk) {
+              nc_ = 0;
+              np_ = pass + 1;
+              if (np_ >= npass) {
+                np_ = 0;
+                nl_ = layer + 1;
+                if (nl_ >= A.nlayers) have_next = false;
+              }
+            }
+          }
+          if (have_next) {
+            WSlice sn = make_slice(nl_, np_, nc_, nk_);
+            wslice_load(sn, c, wreg);
+          }
+          const int ksteps = (kpad - ks) >= WK ? 2 : 1;
+          mma_slice(acc, Xs, wbuf ? Wb1 : Wb0, c, ks, ksteps, ntiles);
+          if (have_next) wslice_store(wbuf ? Wb0 : Wb1, c, wreg);
+          __syncthreads();
+          wbuf ^= 1;
+        }
+      }
+      if (!last) {
+        wave_lds_sync();
+        acc_to_xs(acc, Xs, c);
+        wave_lds_sync();
+        mid_epilogue(L, Xs, c);
+        wave_lds_sync();
+      } else {
+        final_epilogue(A, L, pass, acc, Os, c, dgam, dbet);
+      }
+    }
+  }
+
+  if (A.ln_partial) {
+    // (dgamma, dbeta) of the tile: lane halves -> waves -> global partial row
+    dgam.x += __shfl_xor(dgam.x, 32, 64); dgam.y += __shfl_xor(dgam.y, 32, 64);
+    dgam.z += __shfl_xor(dgam.z, 32, 64); dgam.w += __shfl_xor(dgam.w, 32, 64);
+    dbet.x += __shfl_xor(dbet.x, 32, 64); dbet.y += __shfl_xor(dbet.y, 32, 64);
+    dbet.z += __shfl_xor(dbet.z, 32, 64); dbet.w += __shfl_xor(dbet.w, 32, 64);
+    __syncthreads();
+    float* red = Xs;  // [4 waves][2][128]
+    if (c.lane < 32) {
+      *reinterpret_cast<float4*>(&red[(c.wave * 2 + 0) * 128 + 4 * c.c4]) = dgam;
+      *reinterpret_cast<float4*>(&red[(c.wave * 2 + 1) * 128 + 4 * c.c4]) = dbet;
+    }
+    __syncthreads();
+    const int j = c.tid;  // 0..255 = [2][128]
+    const float s = red[j] + red[256 + j] + red[512 + j] + red[768 + j];
+    A.ln_partial[(size_t)blockIdx.x * 256 + j] = s;
+  }
+}
+
+}  // namespace
+
+extern "C" int gfv_rowtile_tiles(int32_t M) { return (M + BM - 1) / BM; }
+
+extern "C" int gfv_rowtile_chain(const gfv_rowtile_args_t* args, void* stream) {
+  if (!args || args->M < 0 || args->nlayers < 1 || args->nlayers > 3 || args->nseg < 1 || args->nseg > 3) return GFV_ERR_ARG;
+  if (args->M == 0) return GFV_OK;
+  for (int i = 0; i < args->nseg; ++i)
+    if (args->seg[i].width < 1 || args->seg[i].width > 128) return GFV_ERR_ARG;
+  for (int l = 0; l + 1 < args->nlayers; ++l)
+    if (args->layer[l].N != 128 || args->layer[l + 1].K != 128) return GFV_ERR_ARG;
+  int k0 = 0;
+  for (int i = 0; i < args->nseg; ++i) k0 += args->seg[i].width;
+  if (k0 != args->layer[0].K) return GFV_ERR_ARG;
+  const gfv_layer_t& last = args->layer[args->nlayers - 1];
+  if (last.N > 384 || last.N < 1) return GFV_ERR_ARG;
+  if (last.N > 128 && (last.N & 15)) return GFV_ERR_ARG;
+  if ((args->fin_op != GFV_FIN_PLAIN || args->in_op == GFV_IN_LN || args->in_op == GFV_IN_LNBWD) &&
+      (args->fin_op != GFV_FIN_PLAIN ? last.N != 128 : false))
+    return GFV_ERR_ARG;
+  if ((args->in_op == GFV_IN_LN || args->in_op == GFV_IN_LNBWD) && (args->nseg != 1 || args->seg[0].width != 128))
+    return GFV_ERR_ARG;
+  const int tiles = (args->M + BM - 1) / BM;
+  hipLaunchKernelGGL(rowtile_chain_kernel, dim3(tiles), dim3(256), 0, (hipStream_t)stream, *args);
+  GFV_CHECK_LAUNCH();
+  return GFV_OK;
+}

@@ -1,0 +1,209 @@
+// Atomics-free segmented (CSR) gather-reduce and its companions (gfx950, wave64).  Contract: include/gfv.h.
+//
+// out[r,:] = scale[r] * sum_{k in row r} src[col[k],:]
+//
+// A destination row is owned by a sub-wave of LPR = F/4 lanes (each lane one float4 = 16 B, so a row is read in
+// full 64..512-byte segments); a wave carries 64/LPR rows at a time and every (row, lane) walks its CSR
+// segment with 4 gathers in flight.  No atomics, fixed summation order (deterministic), one coalesced write per
+// destination row.  Rows are node/cell features that stay L2/MALL resident between kernels; indices are int32.
+#include "gfv_common.h"
+#include "../../include/gfv.h"
+
+namespace {
+
+template <int LPR>
+__global__ __launch_bounds__(256) void seg_gather_sum_vec(const float* __restrict__ src, const int* __restrict__ rowptr,
+                                                          const int* __restrict__ col, const float* __restrict__ scale,
+                                                          const float* __restrict__ src_scale,
+                                                          float* __restrict__ out, int n_rows, int accumulate) {
+  constexpr int F = LPR * 4;
+  constexpr int ROWS_PER_BLOCK = 256 / LPR;
+  const int sub = threadIdx.x / LPR;
+  const int l = threadIdx.x % LPR;
+  for (int r = blockIdx.x * ROWS_PER_BLOCK + sub; r < n_rows; r += gridDim.x * ROWS_PER_BLOCK) {
+    const int beg = rowptr[r], end = rowptr[r + 1];
+    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
+    int k = beg;
+    for (; k + 4 <= end; k += 4) {
+      const int c0 = col[k], c1 = col[k + 1], c2 = col[k + 2], c3 = col[k + 3];
+      float4 v0 = *reinterpret_cast<const float4*>(src + (size_t)c0 * F + 4 * l);
+      float4 v1 = *reinterpret_cast<const float4*>(src + (size_t)c1 * F + 4 * l);
+      float4 v2 = *reinterpret_cast<const float4*>(src + (size_t)c2 * F + 4 * l);
+      float4 v3 = *reinterpret_cast<const float4*>(src + (size_t)c3 * F + 4 * l);
+      if (src_scale) {
+        const float s0 = src_scale[c0], s1 = src_scale[c1], s2 = src_scale[c2], s3 = src_scale[c3];
+        v0.x *= s0; v0.y *= s0; v0.z *= s0; v0.w *= s0;
+        v1.x *= s1; v1.y *= s1; v1.z *= s1; v1.w *= s1;
+        v2.x *= s2; v2.y *= s2; v2.z *= s2; v2.w *= s2;
+        v3.x *= s3; v3.y *= s3; v3.z *= s3; v3.w *= s3;
+      }
+      a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+      a1.x += v1.x; a1.y += v1.y; a1.z += v1.z; a1.w += v1.w;
+      a2.x += v2.x; a2.y += v2.y; a2.z += v2.z; a2.w += v2.w;
+      a3.x += v3.x; a3.y += v3.y; a3.z += v3.z; a3.w += v3.w;
+    }
+    for (; k < end; ++k) {
+      const int c0 = col[k];
+      float4 v0 = *reinterpret_cast<const float4*>(src + (size_t)c0 * F + 4 * l);
+      if (src_scale) {
+        const float s0 = src_scale[c0];
+        v0.x *= s0; v0.y *= s0; v0.z *= s0; v0.w *= s0;
+      }
+      a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+    }
+    float4 s = make_float4((a0.x + a1.x) + (a2.x + a3.x), (a0.y + a1.y) + (a2.y + a3.y),
+                           (a0.z + a1.z) + (a2.z + a3.z), (a0.w + a1.w) + (a2.w + a3.w));
+    if (scale) {
+      const float sc = scale[r];
+      s.x *= sc; s.y *= sc; s.z *= sc; s.w *= sc;
+    }
+    float4* o = reinterpret_cast<float4*>(out + (size_t)r * F + 4 * l);
+    if (accumulate) {
+      const float4 p = *o;
+      s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
+    }
+    *o = s;
+  }
+}
+
+__global__ __launch_bounds__(256) void seg_gather_sum_scalar(const float* __restrict__ src, const int* __restrict__ rowptr,
+                                                             const int* __restrict__ col, const float* __restrict__ scale,
+                                                             const float* __restrict__ src_scale,
+                                                             float* __restrict__ out, int n_rows, int F, int accumulate) {
+  const long total = (long)n_rows * F;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int r = (int)(i / F), f = (int)(i % F);
+    float s = 0.f;
+    for (int k = rowptr[r]; k < rowptr[r + 1]; ++k) {
+      const int c = col[k];
+      const float v = src[(size_t)c * F + f];
+      s += src_scale ? v * src_scale[c] : v;
+    }
+    if (scale) s *= scale[r];
+    if (accumulate) s += out[i];
+    out[i] = s;
+  }
+}
+
+template <int LPR>
+__global__ __launch_bounds__(256) void gather_pair_kernel(const float* __restrict__ a, const int* __restrict__ s,
+                                                          const int* __restrict__ r, const float* __restrict__ base,
+                                                          float* __restrict__ out, int n_edges) {
+  // out row = 2F floats = 2*LPR float4; lanes [0,LPR) copy a[s[e]], lanes [LPR,2LPR) copy a[r[e]]
+  constexpr int F = LPR * 4;
+  constexpr int LANES = 2 * LPR;
+  constexpr int EPB = 256 / LANES;
+  const int sub = threadIdx.x / LANES, l = threadIdx.x % LANES;
+  for (int e = blockIdx.x * EPB + sub; e < n_edges; e += gridDim.x * EPB) {
+    const int node = (l < LPR) ? s[e] : r[e];
+    float4 v = *reinterpret_cast<const float4*>(a + (size_t)node * F + 4 * (l % LPR));
+    if (base) {
+      const float4 b = *reinterpret_cast<const float4*>(base + (size_t)e * 2 * F + 4 * l);
+      v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+    }
+    *reinterpret_cast<float4*>(out + (size_t)e * 2 * F + 4 * l) = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial, int n_chunks, int n,
+                                                              float* __restrict__ out, int accumulate) {
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int c = 0;
+    for (; c + 4 <= n_chunks; c += 4) {
+      s0 += partial[(size_t)c * n + j];
+      s1 += partial[(size_t)(c + 1) * n + j];
+      s2 += partial[(size_t)(c + 2) * n + j];
+      s3 += partial[(size_t)(c + 3) * n + j];
+    }
+    for (; c < n_chunks; ++c) s0 += partial[(size_t)c * n + j];
+    float s = (s0 + s1) + (s2 + s3);
+    if (accumulate) s += out[j];
+    out[j] = s;
+  }
+}
+
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int rows,
+                                                        int cols) {
+  __shared__ float tile[32][33];
+  const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int j = ty; j < 32; j += 8) {
+    const int r = by + j, c = bx + tx;
+    tile[j][tx] = (r < rows && c < cols) ? in[(size_t)r * cols + c] : 0.f;
+  }
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8) {
+    const int c = bx + j, r = by + tx;  // out[c][r]
+    if (c < cols && r < rows) out[(size_t)c * rows + r] = tile[tx][j];
+  }
+}
+
+inline int grid_for(long work_items, int per_block) {
+  long g = (work_items + per_block - 1) / per_block;
+  if (g > 256L * 16) g = 256L * 16;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+}  // namespace
+
+extern "C" int gfv_seg_gather_sum(const float* src, const int32_t* rowptr, const int32_t* col, const float* scale,
+                                  const float* src_scale, float* out, int32_t n_rows, int32_t F, int32_t accumulate, void* stream) {
+  if (n_rows < 0 || F < 1) return GFV_ERR_ARG;
+  if (n_rows == 0) return GFV_OK;
+  hipStream_t st = (hipStream_t)stream;
+#define LAUNCH_VEC(LPR)                                                                                       \
+  hipLaunchKernelGGL((seg_gather_sum_vec<LPR>), dim3(grid_for(n_rows, 256 / LPR)), dim3(256), 0, st, src,     \
+                     rowptr, col, scale, src_scale, out, n_rows, accumulate)
+  switch (F) {
+    case 4: LAUNCH_VEC(1); break;
+    case 8: LAUNCH_VEC(2); break;
+    case 16: LAUNCH_VEC(4); break;
+    case 32: LAUNCH_VEC(8); break;
+    case 64: LAUNCH_VEC(16); break;
+    case 128: LAUNCH_VEC(32); break;
+    case 256: LAUNCH_VEC(64); break;
+    default:
+      hipLaunchKernelGGL(seg_gather_sum_scalar, dim3(grid_for((long)n_rows * F, 256)), dim3(256), 0, st, src, rowptr,
+                         col, scale, src_scale, out, n_rows, F, accumulate);
+  }
+#undef LAUNCH_VEC
+  GFV_CHECK_LAUNCH();
+  return GFV_OK;
+}
+
+extern "C" int gfv_gather_pair(const float* a, const int32_t* s, const int32_t* r, const float* base, float* out,
+                               int32_t n_edges, int32_t F, void* stream) {
+  if (n_edges < 0) return GFV_ERR_ARG;
+  if (n_edges == 0) return GFV_OK;
+  hipStream_t st = (hipStream_t)stream;
+  if (F == 64) {
+    hipLaunchKernelGGL((gather_pair_kernel<16>), dim3(grid_for(n_edges, 8)), dim3(256), 0, st, a, s, r, base, out, n_edges);
+  } else if (F == 128) {
+    hipLaunchKernelGGL((gather_pair_kernel<32>), dim3(grid_for(n_edges, 4)), dim3(256), 0, st, a, s, r, base, out, n_edges);
+  } else {
+    return GFV_ERR_ARG;
+  }
+  GFV_CHECK_LAUNCH();
+  return GFV_OK;
+}
+
+extern "C" int gfv_reduce_partials(const float* partial, int32_t n_chunks, int32_t n, float* out, int32_t accumulate,
+                                   void* stream) {
+  if (n <= 0) return GFV_OK;
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, partial,
+                     n_chunks, n, out, accumulate);
+  GFV_CHECK_LAUNCH();
+  return GFV_OK;
+}
+
+extern "C" int gfv_transpose(const float* in, float* out, int32_t rows, int32_t cols, void* stream) {
+  if (rows <= 0 || cols <= 0) return GFV_ERR_ARG;
+  hipLaunchKernelGGL(transpose_kernel, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(256), 0, (hipStream_t)stream, in,
+                     out, rows, cols);
+  GFV_CHECK_LAUNCH();
+  return GFV_OK;
+}
+
+extern "C" int gfv_abi_version(void) { return GFV_ABI_VERSION; }

@@ -1,0 +1,118 @@
+"""ctypes binding of libgfv.so (the C ABI declared in include/gfv.h).
+
+Plumbing only: converts torch CUDA tensors to raw device pointers and launches on torch's current HIP stream.
+There is NO fallback: if the shared library is missing or a call fails, this raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libgfv.so")
+
+c_float_p = C.c_void_p
+c_int_p = C.c_void_p
+
+OP_NONE, OP_BIAS_GELU, OP_MUL_DGELU = 0, 1, 2
+IN_NONE, IN_GELU, IN_LN, IN_LNBWD = 0, 1, 2, 3
+FIN_PLAIN, FIN_LN, FIN_LNBWD = 0, 1, 2
+
+
+class Seg(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("idx", C.c_void_p), ("width", C.c_int32), ("ld", C.c_int32)]
+
+
+class Layer(C.Structure):
+    _fields_ = [("W", C.c_void_p), ("bias", C.c_void_p), ("K", C.c_int32), ("N", C.c_int32), ("op", C.c_int32),
+                ("pad_", C.c_int32), ("save", C.c_void_p), ("aux", C.c_void_p)]
+
+
+class RowtileArgs(C.Structure):
+    _fields_ = [
+        ("M", C.c_int32), ("nseg", C.c_int32), ("seg", Seg * 3), ("in_add", C.c_void_p), ("in_op", C.c_int32),
+        ("nlayers", C.c_int32), ("in_gamma", C.c_void_p), ("in_beta", C.c_void_p), ("in_aux", C.c_void_p),
+        ("gadd", C.c_void_p), ("gadd_s", C.c_void_p), ("gadd_r", C.c_void_p), ("in_save", C.c_void_p),
+        ("ln_partial", C.c_void_p), ("layer", Layer * 3), ("fin_op", C.c_int32), ("pad_", C.c_int32),
+        ("fin_gamma", C.c_void_p), ("fin_beta", C.c_void_p), ("fin_aux", C.c_void_p), ("fin_presave", C.c_void_p),
+        ("res", C.c_void_p * 3), ("res_ld", C.c_int32 * 3), ("out_ld", C.c_int32 * 3), ("out", C.c_void_p * 3),
+        ("out_nores", C.c_void_p),
+    ]
+
+
+_lib = None
+
+_SIGNATURES = {
+    "gfv_abi_version": (C.c_int, []),
+    "gfv_seg_gather_sum": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                     C.c_int32, C.c_int32, C.c_void_p]),
+    "gfv_gather_pair": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
+                                  C.c_void_p]),
+    "gfv_rowtile_tiles": (C.c_int, [C.c_int32]),
+    "gfv_rowtile_chain": (C.c_int, [C.POINTER(RowtileArgs), C.c_void_p]),
+    "gfv_dw_chunks": (C.c_int, [C.c_int32]),
+    "gfv_linear_dw_workspace_floats": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
+    "gfv_linear_dw": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(Seg), C.c_int32, C.c_void_p, C.c_int32,
+                                C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
+    "gfv_linear_dw_ex": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(Seg), C.c_int32, C.c_void_p, C.c_int32,
+                                   C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
+                                   C.c_int32, C.c_void_p]),
+    "gfv_reduce_partials": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
+    "gfv_transpose": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+}
+
+
+def declared_symbols():
+    return list(_SIGNATURES)
+
+
+def register(name, restype, argtypes):
+    _SIGNATURES[name] = (restype, argtypes)
+    if _lib is not None:
+        fn = getattr(_lib, name)
+        fn.restype, fn.argtypes = restype, argtypes
+
+
+def load():
+    """Load libgfv.so or raise.  No CPU / PyTorch fallback exists for the product path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"libgfv.so not found at {LIB_PATH}: build it with `python gen-fvgn-steady_amd/gfv/build.py` "
+            "(hipcc --offload-arch=gfx950). The HIP extension is mandatory; there is no fallback path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in _SIGNATURES.items():
+        fn = getattr(lib, name)  # raises AttributeError if the symbol is missing
+        fn.restype, fn.argtypes = restype, argtypes
+    _lib = lib
+    return lib
+
+
+def stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    if t is None:
+        return None
+    assert t.is_cuda, "libgfv works on device memory only"
+    return t.data_ptr()
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"libgfv: {what} failed with code {rc}")
+
+
+def f32c(t):
+    assert t.dtype == torch.float32 and t.is_contiguous(), (t.dtype, t.is_contiguous())
+    return t
+
+
+def i32c(t):
+    assert t.dtype == torch.int32 and t.is_contiguous()
+    return t

@@ -1,0 +1,148 @@
+"""Thin tensor-level wrappers over the C ABI (no autograd here; see gfv/functions.py).
+
+Every function launches hand-written HIP kernels from libgfv.so on torch's current stream.  PyTorch is used only
+for device memory (output allocation)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import lib as L
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def seg_gather_sum(src, rowptr, col, n_rows, scale=None, src_scale=None, out=None, accumulate=False):
+    """out[r] = scale[r] * sum_{k in row r} src_scale[col[k]] * src[col[k]]   (src [n_src, F] contiguous fp32)."""
+    lib = L.load()
+    F = src.shape[-1]
+    L.f32c(src)
+    if out is None:
+        assert not accumulate
+        out = torch.empty((n_rows, F), dtype=torch.float32, device=src.device)
+    rc = lib.gfv_seg_gather_sum(_p(src), _p(L.i32c(rowptr)), _p(L.i32c(col)), _p(scale), _p(src_scale), _p(out),
+                                n_rows, F, 1 if accumulate else 0, L.stream_ptr())
+    L.check(rc, "gfv_seg_gather_sum")
+    return out
+
+
+def gather_pair(a, s, r, base=None, out=None):
+    lib = L.load()
+    F = a.shape[-1]
+    E = s.shape[0]
+    if out is None:
+        out = torch.empty((E, 2 * F), dtype=torch.float32, device=a.device)
+    rc = lib.gfv_gather_pair(_p(L.f32c(a)), _p(L.i32c(s)), _p(L.i32c(r)), _p(base), _p(out), E, F, L.stream_ptr())
+    L.check(rc, "gfv_gather_pair")
+    return out
+
+
+def transpose(w, out=None):
+    lib = L.load()
+    rows, cols = w.shape
+    if out is None:
+        out = torch.empty((cols, rows), dtype=torch.float32, device=w.device)
+    rc = lib.gfv_transpose(_p(L.f32c(w)), _p(out), rows, cols, L.stream_ptr())
+    L.check(rc, "gfv_transpose")
+    return out
+
+
+def reduce_partials(partial, n_chunks, n, out=None, accumulate=False):
+    lib = L.load()
+    if out is None:
+        out = torch.empty((n,), dtype=torch.float32, device=partial.device)
+    rc = lib.gfv_reduce_partials(_p(partial), n_chunks, n, _p(out), 1 if accumulate else 0, L.stream_ptr())
+    L.check(rc, "gfv_reduce_partials")
+    return out
+
+
+def rowtile_tiles(M):
+    return (M + 63) // 64
+
+
+class Seg:
+    """Input segment: rows of `t` (optionally gathered by int32 `idx`), `width` valid columns, row stride `ld`."""
+
+    def __init__(self, t, idx=None, width=None, ld=None, offset=0):
+        self.t, self.idx = t, idx
+        self.width = t.shape[-1] if width is None else width
+        self.ld = t.stride(0) if ld is None else ld
+        self.offset = offset  # column offset (floats) into the row
+
+    def fill(self, cs):
+        cs.ptr = self.t.data_ptr() + 4 * self.offset
+        cs.idx = _p(self.idx)
+        cs.width = self.width
+        cs.ld = self.ld
+
+
+class LayerSpec:
+    def __init__(self, W, bias=None, op=L.OP_NONE, save=None, aux=None):
+        self.W, self.bias, self.op, self.save, self.aux = W, bias, op, save, aux
+
+
+def rowtile_chain(M, segs, layers, outs, *, in_add=None, in_op=L.IN_NONE, in_gamma=None, in_beta=None, in_aux=None,
+                  gadd=None, gadd_s=None, gadd_r=None, in_save=None, ln_partial=None, fin_op=L.FIN_PLAIN,
+                  fin_gamma=None, fin_beta=None, fin_aux=None, fin_presave=None, res=None, out_nores=None):
+    """Launch the fused row-tile GEMM chain.  outs / res: list (per 128-wide chunk of the last layer) of
+    (tensor, ld) or tensors; see include/gfv.h for the semantics of every field."""
+    lib = L.load()
+    a = L.RowtileArgs()
+    a.M = M
+    a.nseg = len(segs)
+    for i, s in enumerate(segs):
+        s.fill(a.seg[i])
+    a.in_add = _p(in_add)
+    a.in_op = in_op
+    a.nlayers = len(layers)
+    a.in_gamma, a.in_beta, a.in_aux = _p(in_gamma), _p(in_beta), _p(in_aux)
+    a.gadd, a.gadd_s, a.gadd_r = _p(gadd), _p(gadd_s), _p(gadd_r)
+    a.in_save, a.ln_partial = _p(in_save), _p(ln_partial)
+    for i, ly in enumerate(layers):
+        cl = a.layer[i]
+        cl.W, cl.bias = _p(ly.W), _p(ly.bias)
+        cl.N, cl.K = ly.W.shape[0], ly.W.shape[1]
+        cl.op = ly.op
+        cl.save, cl.aux = _p(ly.save), _p(ly.aux)
+    a.fin_op = fin_op
+    a.fin_gamma, a.fin_beta, a.fin_aux, a.fin_presave = _p(fin_gamma), _p(fin_beta), _p(fin_aux), _p(fin_presave)
+    for i, o in enumerate(outs):
+        t, ld = o if isinstance(o, tuple) else (o, o.stride(0))
+        a.out[i] = t.data_ptr() if torch.is_tensor(t) else t
+        a.out_ld[i] = ld
+    if res is not None:
+        for i, o in enumerate(res):
+            if o is None:
+                continue
+            t, ld = o if isinstance(o, tuple) else (o, o.stride(0))
+            a.res[i] = t.data_ptr() if torch.is_tensor(t) else t
+            a.res_ld[i] = ld
+    a.out_nores = _p(out_nores)
+    rc = lib.gfv_rowtile_chain(C.byref(a), L.stream_ptr())
+    L.check(rc, "gfv_rowtile_chain")
+
+
+def linear_dw(G, n_out, segs, M, *, ldg=None, in_add=None, a_op=0, a_gamma=None, a_beta=None, dW=None, db=None,
+              want_db=True, accumulate=False, workspace=None, g_offset=0):
+    """dW[n,k] = sum_m G[m,n] A[m,k]; db[n] = sum_m G[m,n].  Returns (dW [n_out,K], db [n_out] or None)."""
+    lib = L.load()
+    K = sum(s.width for s in segs)
+    dev = G.device
+    if dW is None:
+        dW = torch.empty((n_out, K), dtype=torch.float32, device=dev)
+    if db is None and want_db:
+        db = torch.empty((n_out,), dtype=torch.float32, device=dev)
+    need = lib.gfv_linear_dw_workspace_floats(M, n_out, K)
+    if workspace is None or workspace.numel() < need:
+        workspace = torch.empty((max(need, 1),), dtype=torch.float32, device=dev)
+    cs = (L.Seg * 3)()
+    for i, s in enumerate(segs):
+        s.fill(cs[i])
+    ldg = G.stride(0) if ldg is None else ldg
+    rc = lib.gfv_linear_dw_ex(G.data_ptr() + 4 * g_offset, ldg, n_out, cs, len(segs), _p(in_add), a_op, _p(a_gamma),
+                              _p(a_beta), M, _p(dW), 0, _p(db), _p(workspace), 1 if accumulate else 0, L.stream_ptr())
+    L.check(rc, "gfv_linear_dw_ex")
+    return dW, db

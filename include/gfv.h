@@ -1,0 +1,129 @@
+/* libgfv - C ABI of the MI355X-native (gfx950) Gen-FVGN hot path.
+ *
+ * Every entry point is `extern "C"`, takes plain device pointers + sizes + a hipStream_t (as void*), allocates
+ * nothing, keeps no global state, is asynchronous on the given stream and returns 0 (GFV_OK) or a negative
+ * error code.  All floating point data is fp32, all index data int32 (plans are narrowed from the reference's
+ * int64 once per mesh batch).
+ *
+ * What each entry replaces in the reference (paths relative to /root/reference/src) is cited per function; the
+ * reference has no native code of its own: these replace the third-party CUDA kernels it reaches through
+ * torch_scatter / ATen / cuBLAS / Inductor.
+ */
+#ifndef GFV_H_
+#define GFV_H_
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GFV_ABI_VERSION 1
+int gfv_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Segmented (CSR) gather-reduce:  out[r,:] = scale[r] * sum_{k in [rowptr[r],rowptr[r+1])} src[col[k],:]
+ * Atomics-free wavefront segmented reduce.  Replaces torch_scatter.scatter_add / scatter_mean and the fused
+ * "gather then scatter" pairs at FVMmodel/Models/FVGN/blocks.py:35-51,92-99 and the index_put_ backward of
+ * the gathers at blocks.py:101-102.  src is [n_src, F] row-major (ld = F), F in {4,8,...,256} multiple of 4,
+ * or any F through the scalar path.  scale (per destination row) and src_scale (per source row, applied to
+ * each gathered row) may be NULL.  `accumulate` != 0 adds into out.
+ * ---------------------------------------------------------------------------------------------------------- */
+int gfv_seg_gather_sum(const float* src, const int32_t* rowptr, const int32_t* col, const float* scale,
+                       const float* src_scale, float* out, int32_t n_rows, int32_t F, int32_t accumulate, void* stream);
+
+/* out[e, 0:F] = a[s[e], :], out[e, F:2F] = a[r[e], :]  (+ base[e,:] if base != NULL).  Adjoint of the
+ * chunked edge->node scatter at blocks.py:34-42. */
+int gfv_gather_pair(const float* a, const int32_t* s, const int32_t* r, const float* base, float* out,
+                    int32_t n_edges, int32_t F, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Row-tile fused GEMM chain on fp32 MFMA (v_mfma_f32_16x16x4_f32): up to three Linear layers applied to a tile
+ * of 64 rows that stays in LDS, with gather/concat/LayerNorm prologues and bias/GELU/LayerNorm/residual
+ * epilogues.  Forward and the dX-chain of the backward are the same kernel with different element ops.
+ * Replaces nn.Linear/GELU/LayerNorm inside build_mlp (FVMmodel/Models/FVGN/EPD.py:10-63), the concat + MLP of
+ * EdgeBlock/NodeBlock (blocks.py:54,101-111) and the Linear layers of the Transolver block
+ * (FVMmodel/Models/GraphTransolver/GraphTransolver.py:54-59,95,98-128,163-169).
+ * ---------------------------------------------------------------------------------------------------------- */
+typedef struct {
+  const float* ptr;   /* [rows, ld] */
+  const int32_t* idx; /* optional row gather index [M]; NULL = identity */
+  int32_t width;      /* valid columns (<= 128); zero padded to a multiple of 16 inside the kernel */
+  int32_t ld;         /* row stride in floats */
+} gfv_seg_t;
+
+enum {                /* per-layer element op applied to the accumulator */
+  GFV_OP_NONE = 0,      /* v = acc + bias                                   */
+  GFV_OP_BIAS_GELU = 1, /* v = acc + bias; save v; next input = gelu(v)     */
+  GFV_OP_MUL_DGELU = 2  /* v = acc * gelu'(aux); save v; next input = v     */
+};
+enum { GFV_IN_NONE = 0, GFV_IN_GELU = 1, GFV_IN_LN = 2, GFV_IN_LNBWD = 3 };
+enum { GFV_FIN_PLAIN = 0, GFV_FIN_LN = 1, GFV_FIN_LNBWD = 2 };
+
+typedef struct {
+  const float* W;     /* [N, K] row-major: nn.Linear weight (forward) or its transpose (dX chain) */
+  const float* bias;  /* [N] or NULL */
+  int32_t K, N;       /* K = input width, N = output width (128 for inner layers; last layer: <= 384) */
+  int32_t op;
+  int32_t pad_;
+  float* save;        /* optional [M, N] */
+  const float* aux;   /* [M, N] for GFV_OP_MUL_DGELU */
+} gfv_layer_t;
+
+typedef struct {
+  int32_t M;
+  int32_t nseg;
+  gfv_seg_t seg[3];       /* input row m = concat_i seg[i][idx_i[m], 0:width_i] */
+  const float* in_add;    /* optional: seg[0] row += in_add row (same idx / ld as seg[0]) */
+  int32_t in_op;
+  int32_t nlayers;
+  const float* in_gamma;  /* GFV_IN_LN / GFV_IN_LNBWD */
+  const float* in_beta;
+  const float* in_aux;    /* GFV_IN_LNBWD: the pre-LayerNorm values y [M,128] */
+  const float* gadd;      /* optional [*,64]: input row m += [gadd[gadd_s[m]] | gadd[gadd_r[m]]] (before in_op) */
+  const int32_t* gadd_s;
+  const int32_t* gadd_r;
+  float* in_save;         /* optional [M,128]: result of the prologue */
+  float* ln_partial;      /* GFV_IN_LNBWD / GFV_FIN_LNBWD: [n_tiles, 2, 128] per-tile (dgamma, dbeta) partial sums */
+  gfv_layer_t layer[3];
+  int32_t fin_op;
+  int32_t pad_;
+  const float* fin_gamma;
+  const float* fin_beta;
+  const float* fin_aux;   /* GFV_FIN_LNBWD: the LayerNorm input rows [M,128] */
+  float* fin_presave;     /* GFV_FIN_LN: pre-LayerNorm values [M,128] */
+  const float* res[3];    /* optional addend per 128-wide output chunk */
+  int32_t res_ld[3];
+  int32_t out_ld[3];
+  float* out[3];          /* output pointer per 128-wide chunk of the last layer */
+  float* out_nores;       /* optional [M,128]: chunk 0 result BEFORE the residual addend (EdgeBlock output e') */
+} gfv_rowtile_args_t;
+
+int gfv_rowtile_tiles(int32_t M); /* number of 64-row tiles = rows of ln_partial */
+int gfv_rowtile_chain(const gfv_rowtile_args_t* args, void* stream);
+
+/* Weight gradient of a Linear layer: dW[n,k] = sum_m G[m,n] * A[m,k], db[n] = sum_m G[m,n] (two-stage,
+ * deterministic).  A is assembled like the forward input (segments, gather, optional GELU of a saved
+ * pre-activation).  partial: workspace [gfv_dw_chunks(M), N(=128), Kpad] (+ N floats per chunk for db).
+ * Replaces the autograd mm/addmm wgrad of nn.Linear (pre_train_Adam.py:188). */
+int gfv_dw_chunks(int32_t M);
+int gfv_linear_dw(const float* G, int32_t ldg, int32_t n_out, const gfv_seg_t* segs, int32_t nseg,
+                  const float* in_add, int32_t a_gelu, int32_t M, float* dW, float* db, float* workspace,
+                  int32_t accumulate, void* stream);
+size_t gfv_linear_dw_workspace_floats(int32_t M, int32_t n_out, int32_t K);
+/* same, with the input-row op spelled out: a_op 0 none, 1 GELU, 2 LayerNorm(a_gamma, a_beta) (single 128-wide segment) */
+int gfv_linear_dw_ex(const float* G, int32_t ldg, int32_t n_out, const gfv_seg_t* segs, int32_t nseg,
+                     const float* in_add, int32_t a_op, const float* a_gamma, const float* a_beta, int32_t M,
+                     float* dW, int32_t reserved, float* db, float* workspace, int32_t accumulate, void* stream);
+
+/* out[j] (+)= sum_c partial[c, j]  (c < n_chunks, j < n) */
+int gfv_reduce_partials(const float* partial, int32_t n_chunks, int32_t n, float* out, int32_t accumulate,
+                        void* stream);
+
+/* out = in^T for a [rows, cols] fp32 matrix (weights for the dX chain). */
+int gfv_transpose(const float* in, float* out, int32_t rows, int32_t cols, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GFV_H_ */
