@@ -1,0 +1,599 @@
+// Finite-volume discretisation kernels (gfx950): WLSQ gradient reconstruction, node->face / node->cell
+// interpolation, conserved-form flux assembly, per-graph residual norms, cell->node smoothing, and the adjoint of
+// each.  Contract: include/gfv.h.  Reference: FVMmodel/FVdiscretization/{FVscheme,FVgrad,FVInterpolation}.py,
+// formulas restated in SURVEY.md 8(a-16).
+//
+// All of this is HBM/L2-bound index work on 7-channel fields: every kernel is a CSR-ordered gather (node-, face- or
+// cell-parallel) with no atomics, so results are deterministic; plans (CSR tables, permuted moment vectors,
+// normalised 5x5 matrices) are built once per mesh batch.
+#include "gfv_common.h"
+#include "../../include/gfv.h"
+
+namespace {
+
+enum { NT_NORMAL = 0, NT_INFLOW = 1, NT_OUTFLOW = 2, NT_WALL = 3, NT_PRESS = 4, NT_INWALL = 5 };
+
+// ---- phi = [uvp_new | uv_hat | uv_old] from the decoder output ---------------------------------------------------
+// uvp_new = BC(10*tanh(dec/10))  (importer.py:187-189), uv_hat per integrator (importer.py:192-201)
+__global__ __launch_bounds__(256) void phi_fwd_kernel(const float* __restrict__ dec, const float* __restrict__ y,
+                                                      const int* __restrict__ node_type, const float* __restrict__ uv_old,
+                                                      float* __restrict__ phi, int N, int mode) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= N) return;
+  const int nt = node_type[i];
+  float u = tanhf(dec[3 * i] / 10.f) * 10.f, v = tanhf(dec[3 * i + 1] / 10.f) * 10.f, p = tanhf(dec[3 * i + 2] / 10.f) * 10.f;
+  if (nt == NT_WALL || nt == NT_INFLOW || nt == NT_PRESS || nt == NT_INWALL) { u = y[2 * i]; v = y[2 * i + 1]; }
+  if (nt == NT_PRESS) p = 0.f;
+  const float uo = uv_old[2 * i], vo = uv_old[2 * i + 1];
+  float uh, vh;
+  if (mode == 0) { uh = uo; vh = vo; }
+  else if (mode == 1) { uh = u; vh = v; }
+  else { uh = (uo + u) / 2.0f; vh = (vo + v) / 2.0f; }
+  float4* o = reinterpret_cast<float4*>(phi + (size_t)i * 8);
+  o[0] = make_float4(u, v, p, uh);
+  o[1] = make_float4(vh, uo, vo, 0.f);
+}
+
+__global__ __launch_bounds__(256) void phi_bwd_kernel(const float* __restrict__ gphi, const float* __restrict__ dec,
+                                                      const int* __restrict__ node_type, float* __restrict__ gdec, int N,
+                                                      int mode) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= N) return;
+  const float4 a = *reinterpret_cast<const float4*>(gphi + (size_t)i * 8);
+  const float4 b = *reinterpret_cast<const float4*>(gphi + (size_t)i * 8 + 4);
+  const float ch = (mode == 0) ? 0.f : (mode == 1 ? 1.f : 0.5f);
+  float gu = a.x + ch * a.w, gv = a.y + ch * b.x, gp = a.z;
+  const int nt = node_type[i];
+  if (nt == NT_WALL || nt == NT_INFLOW || nt == NT_PRESS || nt == NT_INWALL) { gu = 0.f; gv = 0.f; }
+  if (nt == NT_PRESS) gp = 0.f;
+  const float t0 = tanhf(dec[3 * i] / 10.f), t1 = tanhf(dec[3 * i + 1] / 10.f), t2 = tanhf(dec[3 * i + 2] / 10.f);
+  gdec[3 * i] = gu * (1.f - t0 * t0);
+  gdec[3 * i + 1] = gv * (1.f - t1 * t1);
+  gdec[3 * i + 2] = gp * (1.f - t2 * t2);
+}
+
+// ---- 5x5 LU with partial pivoting (LAPACK getf2 order), solve and transpose-solve ---------------------------------
+struct LU5 {
+  float a[5][5];
+  int piv[5];
+};
+
+__device__ __forceinline__ void lu5_factor(LU5& m) {
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    int p = k;
+    float mx = fabsf(m.a[k][k]);
+#pragma unroll
+    for (int r = k + 1; r < 5; ++r) {
+      const float v = fabsf(m.a[r][k]);
+      if (v > mx) { mx = v; p = r; }
+    }
+    m.piv[k] = p;
+    if (p != k) {
+#pragma unroll
+      for (int c = 0; c < 5; ++c) { const float t = m.a[k][c]; m.a[k][c] = m.a[p][c]; m.a[p][c] = t; }
+    }
+    const float inv = 1.0f / m.a[k][k];
+#pragma unroll
+    for (int r = k + 1; r < 5; ++r) {
+      m.a[r][k] *= inv;
+#pragma unroll
+      for (int c = k + 1; c < 5; ++c) m.a[r][c] -= m.a[r][k] * m.a[k][c];
+    }
+  }
+}
+
+__device__ __forceinline__ void lu5_solve(const LU5& m, float (&b)[5]) {
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    const int p = m.piv[k];
+    if (p != k) { const float t = b[k]; b[k] = b[p]; b[p] = t; }
+  }
+#pragma unroll
+  for (int k = 0; k < 5; ++k)
+#pragma unroll
+    for (int r = k + 1; r < 5; ++r) b[r] -= m.a[r][k] * b[k];
+#pragma unroll
+  for (int k = 4; k >= 0; --k) {
+    b[k] /= m.a[k][k];
+#pragma unroll
+    for (int r = 0; r < k; ++r) b[r] -= m.a[r][k] * b[k];
+  }
+}
+
+// solve A^T x = b with A = P^T L U
+__device__ __forceinline__ void lu5_solve_t(const LU5& m, float (&b)[5]) {
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {  // U^T w = b
+#pragma unroll
+    for (int r = 0; r < k; ++r) b[k] -= m.a[r][k] * b[r];
+    b[k] /= m.a[k][k];
+  }
+#pragma unroll
+  for (int k = 4; k >= 0; --k)  // L^T mu = w (unit diagonal)
+#pragma unroll
+    for (int r = k + 1; r < 5; ++r) b[k] -= m.a[r][k] * b[r];
+#pragma unroll
+  for (int k = 4; k >= 0; --k) {  // x = P^T mu
+    const int p = m.piv[k];
+    if (p != k) { const float t = b[k]; b[k] = b[p]; b[p] = t; }
+  }
+}
+
+__device__ __forceinline__ void load_An(const float* An, int i, LU5& m) {
+  const float* p = An + (size_t)i * 25;
+#pragma unroll
+  for (int r = 0; r < 5; ++r)
+#pragma unroll
+    for (int c = 0; c < 5; ++c) m.a[r][c] = p[5 * r + c];
+}
+
+// WLSQ forward (FVgrad.py:295-359): lane (node i, channel c), 8 lanes per node
+__global__ __launch_bounds__(256) void wlsq_fwd_kernel(const float* __restrict__ phi, const int* __restrict__ rowptr,
+                                                       const int* __restrict__ outn, const float* __restrict__ Bp,
+                                                       const float* __restrict__ An, const float* __restrict__ rn,
+                                                       float* __restrict__ grad, int N) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  const int i = t >> 3, c = t & 7;
+  if (i >= N) return;
+  float rhs[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+  if (c < 7) {
+    const float pi = phi[(size_t)i * 8 + c];
+    const int beg = rowptr[i], end = rowptr[i + 1];
+    for (int k = beg; k < end; ++k) {
+      const float d = phi[(size_t)outn[k] * 8 + c] - pi;
+      const float* b = Bp + (size_t)k * 5;
+#pragma unroll
+      for (int j = 0; j < 5; ++j) rhs[j] += b[j] * d;
+    }
+    LU5 m;
+    load_An(An, i, m);
+#pragma unroll
+    for (int j = 0; j < 5; ++j) rhs[j] = rhs[j] / rn[(size_t)i * 5 + j];
+    lu5_factor(m);
+    lu5_solve(m, rhs);
+    grad[(size_t)i * 16 + 2 * c] = rhs[0];
+    grad[(size_t)i * 16 + 2 * c + 1] = rhs[1];
+  } else {
+    grad[(size_t)i * 16 + 14] = 0.f;
+    grad[(size_t)i * 16 + 15] = 0.f;
+  }
+}
+
+// WLSQ backward, stage 1: g_rhs[i,c,:] = (A_n^-T [g_grad[i,c,0:2],0,0,0]) / rn
+__global__ __launch_bounds__(256) void wlsq_bwd_solve_kernel(const float* __restrict__ ggrad, const float* __restrict__ An,
+                                                             const float* __restrict__ rn, float* __restrict__ grhs, int N) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  const int i = t >> 3, c = t & 7;
+  if (i >= N) return;
+  float b[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+  if (c < 5) {  // channels 5,6 (uv_old) carry no gradient
+    b[0] = ggrad[(size_t)i * 16 + 2 * c];
+    b[1] = ggrad[(size_t)i * 16 + 2 * c + 1];
+    LU5 m;
+    load_An(An, i, m);
+    lu5_factor(m);
+    lu5_solve_t(m, b);
+#pragma unroll
+    for (int j = 0; j < 5; ++j) b[j] = b[j] / rn[(size_t)i * 5 + j];
+  }
+#pragma unroll
+  for (int j = 0; j < 5; ++j) grhs[((size_t)i * 8 + c) * 5 + j] = b[j];
+}
+
+// stage 2: g_phi[j,c] += sum_{d: out_d = j} B_d . g_rhs[in_d,c,:]  -  sumB[j] . g_rhs[j,c,:]
+__global__ __launch_bounds__(256) void wlsq_bwd_gather_kernel(const float* __restrict__ grhs, const int* __restrict__ rowptr_o,
+                                                              const int* __restrict__ inn, const float* __restrict__ Bo,
+                                                              const float* __restrict__ sumB, float* __restrict__ gphi,
+                                                              int N) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  const int j = t >> 3, c = t & 7;
+  if (j >= N || c >= 5) return;
+  float s = 0.f;
+  const int beg = rowptr_o[j], end = rowptr_o[j + 1];
+  for (int k = beg; k < end; ++k) {
+    const float* g = grhs + ((size_t)inn[k] * 8 + c) * 5;
+    const float* b = Bo + (size_t)k * 5;
+    s += (b[0] * g[0] + b[1] * g[1]) + (b[2] * g[2] + b[3] * g[3]) + b[4] * g[4];
+  }
+  const float* g = grhs + ((size_t)j * 8 + c) * 5;
+  const float* sb = sumB + (size_t)j * 5;
+  s -= (sb[0] * g[0] + sb[1] * g[1]) + (sb[2] * g[2] + sb[3] * g[3]) + sb[4] * g[4];
+  gphi[(size_t)j * 8 + c] += s;
+}
+
+// ---- node -> face (FVInterpolation.py:111-185) + face BC (FVscheme.py:32-48) ------------------------------------------
+// Ff[f] = { phi_f[0..4], grad_f[c][a] (c<5, a<2) at 5+2c+a, pad }
+__global__ __launch_bounds__(256) void face_fwd_kernel(const float* __restrict__ phi, const float* __restrict__ grad,
+                                                       const int* __restrict__ es, const int* __restrict__ er,
+                                                       const float* __restrict__ pos, const float* __restrict__ fpos,
+                                                       const int* __restrict__ ftype, const float* __restrict__ y,
+                                                       float* __restrict__ Ff, int E) {
+  const int f = blockIdx.x * 256 + threadIdx.x;
+  if (f >= E) return;
+  const int s = es[f], r = er[f];
+  const float fx = fpos[2 * f], fy = fpos[2 * f + 1];
+  const float rsx = fx - pos[2 * s], rsy = fy - pos[2 * s + 1];
+  const float rrx = fx - pos[2 * r], rry = fy - pos[2 * r + 1];
+  float out[16];
+#pragma unroll
+  for (int c = 0; c < 5; ++c) {
+    const float gsx = grad[(size_t)s * 16 + 2 * c], gsy = grad[(size_t)s * 16 + 2 * c + 1];
+    const float grx = grad[(size_t)r * 16 + 2 * c], gry = grad[(size_t)r * 16 + 2 * c + 1];
+    const float vs = phi[(size_t)s * 8 + c] + (rsx * gsx + rsy * gsy);
+    const float vr = phi[(size_t)r * 8 + c] + (rrx * grx + rry * gry);
+    out[c] = (vs + vr) / 2.0f;
+    out[5 + 2 * c] = (gsx + grx) / 2.0f;
+    out[5 + 2 * c + 1] = (gsy + gry) / 2.0f;
+  }
+  out[15] = 0.f;
+  const int ft = ftype[f];
+  if (ft == NT_INFLOW) {
+    const float yu = (y[2 * s] + y[2 * r]) / 2.f, yv = (y[2 * s + 1] + y[2 * r + 1]) / 2.f;
+    out[0] = yu; out[1] = yv; out[3] = yu; out[4] = yv;
+  } else if (ft == NT_WALL) {
+    out[0] = 0.f; out[1] = 0.f; out[3] = 0.f; out[4] = 0.f;
+  }
+  float4* o = reinterpret_cast<float4*>(Ff + (size_t)f * 16);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) o[j] = make_float4(out[4 * j], out[4 * j + 1], out[4 * j + 2], out[4 * j + 3]);
+}
+
+// ---- cells: node->cell mean (FVInterpolation.py:36-109), fluxes and residuals (FVscheme.py:145-250) --------------------
+struct CellArgs {
+  const float* phi;      // [N,8]
+  const float* grad;     // [N,16]
+  const float* Ff;       // [E,16]
+  const float* pos;      // [N,2]
+  const int* crow;       // [C+1]
+  const int* kface;      // [Sg]
+  const int* knode;      // [Sg]
+  const float* kS;       // [Sg,2] surface vectors
+  const int* ftype;      // [E]
+  const float* centroid; // [C,2]
+  const float* area;     // [C]
+  const int* cbatch;     // [C]
+  const float* theta;    // [B,9]
+  const float* dt;       // [B]
+  const float* uvp_dim;  // [B,3]
+  const float* sigma;    // [B,3]
+  float* phic;           // [C,8]
+  float* cres;           // [C,4] = (div, Rx, Ry, lp2)
+  float* uvp_cell;       // [C,3] dimensional cell output
+  int C;
+};
+
+__global__ __launch_bounds__(256) void cell_fwd_kernel(const CellArgs A) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= A.C) return;
+  const int b = A.cbatch[c];
+  const float* th = A.theta + (size_t)b * 9;
+  const float th0 = th[0], th2 = th[2], th3 = th[3], th4 = th[4], th5 = th[5];
+  const float cx = A.centroid[2 * c], cy = A.centroid[2 * c + 1];
+  const float area = A.area[c];
+  float pc[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  float div = 0.f, Jx = 0.f, Jy = 0.f, lp2 = 0.f;
+  const int beg = A.crow[c], end = A.crow[c + 1];
+  for (int k = beg; k < end; ++k) {
+    const int n = A.knode[k], f = A.kface[k];
+    const float rx = cx - A.pos[2 * n], ry = cy - A.pos[2 * n + 1];
+#pragma unroll
+    for (int ch = 0; ch < 7; ++ch)
+      pc[ch] += A.phi[(size_t)n * 8 + ch] + (rx * A.grad[(size_t)n * 16 + 2 * ch] + ry * A.grad[(size_t)n * 16 + 2 * ch + 1]);
+    const float Sx = A.kS[2 * k], Sy = A.kS[2 * k + 1];
+    const float4* fp = reinterpret_cast<const float4*>(A.Ff + (size_t)f * 16);
+    const float4 f0 = fp[0], f1 = fp[1], f2 = fp[2], f3 = fp[3];
+    // f0 = (u, v, p, uh)  f1 = (vh, gu_x, gu_y, gv_x)  f2 = (gv_y, gp_x, gp_y, guh_x)  f3 = (guh_y, gvh_x, gvh_y, pad)
+    const float u = f0.x, v = f0.y, p = f0.z, uh = f0.w, vh = f1.x;
+    div += u * Sx + v * Sy;
+    const float m00 = (uh * uh) * th2 + p * th3 - f2.w * th4;
+    const float m01 = (uh * vh) * th2 + 0.f * th3 - f3.x * th4;
+    const float m10 = (vh * uh) * th2 + 0.f * th3 - f3.y * th4;
+    const float m11 = (vh * vh) * th2 + p * th3 - f3.z * th4;
+    Jx += m00 * Sx + m01 * Sy;
+    Jy += m10 * Sx + m11 * Sy;
+    if (A.ftype[f] == NT_OUTFLOW) {
+      const float l0 = th4 * (f1.y * Sx + f1.z * Sy) - p * Sx;
+      const float l1 = th4 * (f1.w * Sx + f2.x * Sy) - p * Sy;
+      lp2 += l0 * l0 + l1 * l1;
+    }
+  }
+  const float cnt = fmaxf((float)(end - beg), 1.f);
+#pragma unroll
+  for (int ch = 0; ch < 7; ++ch) pc[ch] = pc[ch] / cnt;
+  const float dtb = A.dt[b];
+  const float ux = ((pc[0] - pc[5]) / dtb) * area, uy = ((pc[1] - pc[6]) / dtb) * area;
+  const float src = th5 * area;
+  const float Rx = th0 * ux + (Jx - src), Ry = th0 * uy + (Jy - src);
+  float4* o = reinterpret_cast<float4*>(A.phic + (size_t)c * 8);
+  o[0] = make_float4(pc[0], pc[1], pc[2], pc[3]);
+  o[1] = make_float4(pc[4], pc[5], pc[6], 0.f);
+  *reinterpret_cast<float4*>(A.cres + (size_t)c * 4) = make_float4(div, Rx, Ry, lp2);
+  if (A.uvp_cell) {
+    const float* ud = A.uvp_dim + (size_t)b * 3;
+    const float* sg = A.sigma + (size_t)b * 3;
+    A.uvp_cell[3 * c] = pc[0] * ud[0] * sg[0];
+    A.uvp_cell[3 * c + 1] = pc[1] * ud[1] * sg[1];
+    A.uvp_cell[3 * c + 2] = pc[2] * ud[2] * sg[2];
+  }
+}
+
+// per-graph sums of squares -> the four residual losses (FVscheme.py:158-164,184-188,243-250)
+__global__ __launch_bounds__(256) void graph_loss_kernel(const float* __restrict__ cres, const int* __restrict__ gcell_ptr,
+                                                         const float* __restrict__ theta, const float* __restrict__ sigma,
+                                                         float* __restrict__ sums, float* __restrict__ losses) {
+  __shared__ float red[4][256];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  for (int c = gcell_ptr[b] + tid; c < gcell_ptr[b + 1]; c += 256) {
+    const float4 v = *reinterpret_cast<const float4*>(cres + (size_t)c * 4);
+    s0 += v.x * v.x; s1 += v.y * v.y; s2 += v.z * v.z; s3 += v.w;
+  }
+  red[0][tid] = s0; red[1][tid] = s1; red[2][tid] = s2; red[3][tid] = s3;
+  __syncthreads();
+  for (int o = 128; o >= 1; o >>= 1) {
+    if (tid < o) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) red[j][tid] += red[j][tid + o];
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    const float S0 = red[0][0], S1 = red[1][0], S2 = red[2][0], S3 = red[3][0];
+    sums[4 * b] = S0; sums[4 * b + 1] = S1; sums[4 * b + 2] = S2; sums[4 * b + 3] = S3;
+    losses[4 * b] = sqrtf(S0) * theta[(size_t)b * 9 + 1];
+    losses[4 * b + 1] = sqrtf(S1) * sigma[(size_t)b * 3];
+    losses[4 * b + 2] = sqrtf(S2) * sigma[(size_t)b * 3 + 1];
+    losses[4 * b + 3] = sqrtf(S3);
+  }
+}
+
+// cell -> node inverse-distance smoothing (FVInterpolation.py:218-265), Dirichlet overwrite (importer.py:223) and
+// re-dimensionalisation (importer.py:228-229)
+__global__ __launch_bounds__(256) void cell_to_node_kernel(const float* __restrict__ phic, const int* __restrict__ nrow,
+                                                           const int* __restrict__ ncell, const float* __restrict__ pos,
+                                                           const float* __restrict__ centroid, const int* __restrict__ node_type,
+                                                           const float* __restrict__ y, const int* __restrict__ nbatch,
+                                                           const float* __restrict__ uvp_dim, const float* __restrict__ sigma,
+                                                           const float* __restrict__ phi, int smooth, float* __restrict__ out,
+                                                           int N) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= N) return;
+  float u, v, p;
+  if (smooth) {
+    const float px = pos[2 * i], py = pos[2 * i + 1];
+    float su = 0.f, sv = 0.f, sp = 0.f, sw = 0.f;
+    for (int k = nrow[i]; k < nrow[i + 1]; ++k) {
+      const int c = ncell[k];
+      const float dx = px - centroid[2 * c], dy = py - centroid[2 * c + 1];
+      const float w = 1.0f / sqrtf(dx * dx + dy * dy);
+      su += phic[(size_t)c * 8] * w; sv += phic[(size_t)c * 8 + 1] * w; sp += phic[(size_t)c * 8 + 2] * w; sw += w;
+    }
+    u = su / sw; v = sv / sw; p = sp / sw;
+  } else {
+    u = phi[(size_t)i * 8]; v = phi[(size_t)i * 8 + 1]; p = phi[(size_t)i * 8 + 2];
+  }
+  const int nt = node_type[i];
+  if (nt == NT_WALL || nt == NT_INFLOW || nt == NT_PRESS || nt == NT_INWALL) { u = y[2 * i]; v = y[2 * i + 1]; }
+  if (nt == NT_PRESS) p = 0.f;
+  const int b = nbatch[i];
+  out[3 * i] = u * uvp_dim[3 * b] * sigma[3 * b];
+  out[3 * i + 1] = v * uvp_dim[3 * b + 1] * sigma[3 * b + 1];
+  out[3 * i + 2] = p * uvp_dim[3 * b + 2] * sigma[3 * b + 2];
+}
+
+// ---- backward ---------------------------------------------------------------------------------------------------
+// per cell: gc = (g_div, g_Rx, g_Ry, coef_lp) from the loss gradients
+__global__ __launch_bounds__(256) void cell_bwd_kernel(const float* __restrict__ cres, const float* __restrict__ sums,
+                                                       const float* __restrict__ gloss, const int* __restrict__ cbatch,
+                                                       const float* __restrict__ theta, const float* __restrict__ sigma,
+                                                       float* __restrict__ gc, int C) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const int b = cbatch[c];
+  const float4 r = *reinterpret_cast<const float4*>(cres + (size_t)c * 4);
+  const float S0 = sums[4 * b], S1 = sums[4 * b + 1], S2 = sums[4 * b + 2], S3 = sums[4 * b + 3];
+  const float g0 = S0 > 0.f ? gloss[4 * b] * theta[(size_t)b * 9 + 1] * r.x / sqrtf(S0) : 0.f;
+  const float g1 = S1 > 0.f ? gloss[4 * b + 1] * sigma[(size_t)b * 3] * r.y / sqrtf(S1) : 0.f;
+  const float g2 = S2 > 0.f ? gloss[4 * b + 2] * sigma[(size_t)b * 3 + 1] * r.z / sqrtf(S2) : 0.f;
+  const float g3 = S3 > 0.f ? gloss[4 * b + 3] / sqrtf(S3) : 0.f;
+  *reinterpret_cast<float4*>(gc + (size_t)c * 4) = make_float4(g0, g1, g2, g3);
+}
+
+// per face: gradient of everything the adjacent cells did with the face values -> gFf [E,16]
+__global__ __launch_bounds__(256) void face_bwd_kernel(const float* __restrict__ Ff, const float* __restrict__ gc,
+                                                       const int* __restrict__ frow, const int* __restrict__ fk,
+                                                       const int* __restrict__ kcell, const float* __restrict__ kS,
+                                                       const int* __restrict__ ftype, const int* __restrict__ cbatch,
+                                                       const float* __restrict__ theta, float* __restrict__ gFf, int E) {
+  const int f = blockIdx.x * 256 + threadIdx.x;
+  if (f >= E) return;
+  const float4* fp = reinterpret_cast<const float4*>(Ff + (size_t)f * 16);
+  const float4 f0 = fp[0], f1 = fp[1], f2 = fp[2];
+  const float p = f0.z, uh = f0.w, vh = f1.x;
+  const int ft = ftype[f];
+  float g[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) g[j] = 0.f;
+  for (int q = frow[f]; q < frow[f + 1]; ++q) {
+    const int k = fk[q];
+    const int c = kcell[k];
+    const float* th = theta + (size_t)cbatch[c] * 9;
+    const float th2 = th[2], th3 = th[3], th4 = th[4];
+    const float Sx = kS[2 * k], Sy = kS[2 * k + 1];
+    const float4 gcv = *reinterpret_cast<const float4*>(gc + (size_t)c * 4);
+    const float gd = gcv.x, gx = gcv.y, gy = gcv.z;
+    g[0] += gd * Sx;
+    g[1] += gd * Sy;
+    const float uS = uh * Sx + vh * Sy, gU = gx * uh + gy * vh, gS = gx * Sx + gy * Sy;
+    g[3] += th2 * (gx * uS + gU * Sx);
+    g[4] += th2 * (gy * uS + gU * Sy);
+    g[2] += th3 * gS;
+    g[5 + 6] -= th4 * gx * Sx;  // d/d grad(u_hat)_x
+    g[5 + 7] -= th4 * gx * Sy;
+    g[5 + 8] -= th4 * gy * Sx;
+    g[5 + 9] -= th4 * gy * Sy;
+    if (ft == NT_OUTFLOW) {
+      const float l0 = th4 * (f1.y * Sx + f1.z * Sy) - p * Sx;
+      const float l1 = th4 * (f1.w * Sx + f2.x * Sy) - p * Sy;
+      const float gl0 = gcv.w * l0, gl1 = gcv.w * l1;
+      g[5 + 0] += th4 * gl0 * Sx;
+      g[5 + 1] += th4 * gl0 * Sy;
+      g[5 + 2] += th4 * gl1 * Sx;
+      g[5 + 3] += th4 * gl1 * Sy;
+      g[2] -= gl0 * Sx + gl1 * Sy;
+    }
+  }
+  if (ft == NT_INFLOW || ft == NT_WALL) { g[0] = 0.f; g[1] = 0.f; g[3] = 0.f; g[4] = 0.f; }
+  float4* o = reinterpret_cast<float4*>(gFf + (size_t)f * 16);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) o[j] = make_float4(g[4 * j], g[4 * j + 1], g[4 * j + 2], g[4 * j + 3]);
+}
+
+// per node: adjoint of node->face and node->cell interpolation -> g_phi [N,8], g_grad [N,16]
+struct NodeBwdArgs {
+  const float* gFf;      // [E,16]
+  const float* gc;       // [C,4]
+  const int* nfrow;      // [N+1] node -> incident faces
+  const int* nfcol2;     // [2E]  2*face + side
+  const int* nrow;       // [N+1] node -> incident (cell, node) incidences
+  const int* ncell;      // [Sg]  cell of each incidence
+  const float* pos;      // [N,2]
+  const float* fpos;     // [E,2]
+  const float* centroid; // [C,2]
+  const int* crow;       // [C+1] (for the incidence count of a cell)
+  const float* area;
+  const int* cbatch;
+  const float* theta;
+  const float* dt;
+  float* gphi;           // [N,8]
+  float* ggrad;          // [N,16]
+  int N;
+};
+
+__global__ __launch_bounds__(256) void node_bwd_kernel(const NodeBwdArgs A) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= A.N) return;
+  const float px = A.pos[2 * i], py = A.pos[2 * i + 1];
+  float gp[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+  float gg[10];
+#pragma unroll
+  for (int j = 0; j < 10; ++j) gg[j] = 0.f;
+  for (int k = A.nfrow[i]; k < A.nfrow[i + 1]; ++k) {
+    const int f = A.nfcol2[k] >> 1;
+    const float rx = A.fpos[2 * f] - px, ry = A.fpos[2 * f + 1] - py;
+    const float4* gpn = reinterpret_cast<const float4*>(A.gFf + (size_t)f * 16);
+    const float4 a0 = gpn[0], a1 = gpn[1], a2 = gpn[2], a3 = gpn[3];
+    const float v[16] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, a2.x, a2.y, a2.z, a2.w, a3.x, a3.y, a3.z, a3.w};
+#pragma unroll
+    for (int c = 0; c < 5; ++c) {
+      const float h = 0.5f * v[c];
+      gp[c] += h;
+      gg[2 * c] += h * rx + 0.5f * v[5 + 2 * c];
+      gg[2 * c + 1] += h * ry + 0.5f * v[5 + 2 * c + 1];
+    }
+  }
+  for (int k = A.nrow[i]; k < A.nrow[i + 1]; ++k) {
+    const int c = A.ncell[k];
+    const int b = A.cbatch[c];
+    const float cnt = fmaxf((float)(A.crow[c + 1] - A.crow[c]), 1.f);
+    const float coef = A.theta[(size_t)b * 9] * A.area[c] / A.dt[b] / cnt;
+    const float gx = A.gc[(size_t)c * 4 + 1] * coef, gy = A.gc[(size_t)c * 4 + 2] * coef;
+    const float rx = A.centroid[2 * c] - px, ry = A.centroid[2 * c + 1] - py;
+    gp[0] += gx; gp[1] += gy;
+    gg[0] += gx * rx; gg[1] += gx * ry;
+    gg[2] += gy * rx; gg[3] += gy * ry;
+  }
+  float4* o = reinterpret_cast<float4*>(A.gphi + (size_t)i * 8);
+  o[0] = make_float4(gp[0], gp[1], gp[2], gp[3]);
+  o[1] = make_float4(gp[4], 0.f, 0.f, 0.f);
+  float4* og = reinterpret_cast<float4*>(A.ggrad + (size_t)i * 16);
+  og[0] = make_float4(gg[0], gg[1], gg[2], gg[3]);
+  og[1] = make_float4(gg[4], gg[5], gg[6], gg[7]);
+  og[2] = make_float4(gg[8], gg[9], 0.f, 0.f);
+  og[3] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+}  // namespace
+
+#define LAUNCH1D(kernel, n, stream, ...)                                                                    \
+  do {                                                                                                      \
+    if ((n) > 0) {                                                                                          \
+      hipLaunchKernelGGL(kernel, dim3(gfv_div_up((n), 256)), dim3(256), 0, (hipStream_t)(stream), __VA_ARGS__); \
+      GFV_CHECK_LAUNCH();                                                                                   \
+    }                                                                                                       \
+  } while (0)
+
+extern "C" int gfv_phi_fwd(const float* dec, const float* y, const int32_t* node_type, const float* uv_old, float* phi,
+                           int32_t N, int32_t mode, void* stream) {
+  LAUNCH1D(phi_fwd_kernel, N, stream, dec, y, node_type, uv_old, phi, N, mode);
+  return GFV_OK;
+}
+
+extern "C" int gfv_phi_bwd(const float* gphi, const float* dec, const int32_t* node_type, float* gdec, int32_t N,
+                           int32_t mode, void* stream) {
+  LAUNCH1D(phi_bwd_kernel, N, stream, gphi, dec, node_type, gdec, N, mode);
+  return GFV_OK;
+}
+
+extern "C" int gfv_wlsq_fwd(const float* phi, const int32_t* rowptr, const int32_t* outn, const float* Bp, const float* An,
+                            const float* rn, float* grad, int32_t N, void* stream) {
+  LAUNCH1D(wlsq_fwd_kernel, (long)N * 8, stream, phi, rowptr, outn, Bp, An, rn, grad, N);
+  return GFV_OK;
+}
+
+extern "C" int gfv_wlsq_bwd(const float* ggrad, const float* An, const float* rn, const int32_t* rowptr_o,
+                            const int32_t* inn, const float* Bo, const float* sumB, float* grhs_ws, float* gphi, int32_t N,
+                            void* stream) {
+  LAUNCH1D(wlsq_bwd_solve_kernel, (long)N * 8, stream, ggrad, An, rn, grhs_ws, N);
+  LAUNCH1D(wlsq_bwd_gather_kernel, (long)N * 8, stream, grhs_ws, rowptr_o, inn, Bo, sumB, gphi, N);
+  return GFV_OK;
+}
+
+extern "C" int gfv_face_fwd(const float* phi, const float* grad, const int32_t* es, const int32_t* er, const float* pos,
+                            const float* fpos, const int32_t* ftype, const float* y, float* Ff, int32_t E, void* stream) {
+  LAUNCH1D(face_fwd_kernel, E, stream, phi, grad, es, er, pos, fpos, ftype, y, Ff, E);
+  return GFV_OK;
+}
+
+extern "C" int gfv_cell_fwd(const float* phi, const float* grad, const float* Ff, const float* pos, const int32_t* crow,
+                            const int32_t* kface, const int32_t* knode, const float* kS, const int32_t* ftype,
+                            const float* centroid, const float* area, const int32_t* cbatch, const float* theta,
+                            const float* dt, const float* uvp_dim, const float* sigma, float* phic, float* cres,
+                            float* uvp_cell, int32_t C, void* stream) {
+  CellArgs a{phi, grad, Ff, pos, crow, kface, knode, kS, ftype, centroid, area, cbatch, theta, dt, uvp_dim, sigma,
+             phic, cres, uvp_cell, C};
+  LAUNCH1D(cell_fwd_kernel, C, stream, a);
+  return GFV_OK;
+}
+
+extern "C" int gfv_graph_loss(const float* cres, const int32_t* gcell_ptr, const float* theta, const float* sigma,
+                              float* sums, float* losses, int32_t B, void* stream) {
+  if (B <= 0) return GFV_OK;
+  hipLaunchKernelGGL(graph_loss_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, cres, gcell_ptr, theta, sigma, sums,
+                     losses);
+  GFV_CHECK_LAUNCH();
+  return GFV_OK;
+}
+
+extern "C" int gfv_cell_to_node(const float* phic, const int32_t* nrow, const int32_t* ncell, const float* pos,
+                                const float* centroid, const int32_t* node_type, const float* y, const int32_t* nbatch,
+                                const float* uvp_dim, const float* sigma, const float* phi, int32_t smooth, float* out,
+                                int32_t N, void* stream) {
+  LAUNCH1D(cell_to_node_kernel, N, stream, phic, nrow, ncell, pos, centroid, node_type, y, nbatch, uvp_dim, sigma, phi,
+           smooth, out, N);
+  return GFV_OK;
+}
+
+extern "C" int gfv_fvm_bwd(const float* cres, const float* sums, const float* gloss, const float* Ff, const int32_t* cbatch,
+                           const float* theta, const float* sigma, const float* dt, const int32_t* frow, const int32_t* fk,
+                           const int32_t* kcell, const float* kS, const int32_t* ftype, const int32_t* nfrow,
+                           const int32_t* nfcol2, const int32_t* nrow, const int32_t* ncell, const int32_t* crow,
+                           const float* pos, const float* fpos, const float* centroid, const float* area, float* gc_ws,
+                           float* gFf_ws, float* gphi, float* ggrad, int32_t N, int32_t E, int32_t C, void* stream) {
+  LAUNCH1D(cell_bwd_kernel, C, stream, cres, sums, gloss, cbatch, theta, sigma, gc_ws, C);
+  LAUNCH1D(face_bwd_kernel, E, stream, Ff, gc_ws, frow, fk, kcell, kS, ftype, cbatch, theta, gFf_ws, E);
+  NodeBwdArgs a{gFf_ws, gc_ws, nfrow, nfcol2, nrow, ncell, pos, fpos, centroid, crow, area, cbatch, theta, dt, gphi, ggrad, N};
+  LAUNCH1D(node_bwd_kernel, N, stream, a);
+  return GFV_OK;
+}

@@ -1,0 +1,239 @@
+// Input normalisation, relative edge features and the fused Adam step (gfx950).  Contract: include/gfv.h.
+// Reference: FVMmodel/importer.py:54-93,114-130,166-178; utils/normalization.py:32-85; torch.optim.Adam defaults
+// (pre_train_Adam.py:79,191).  All HBM-bound elementwise / small-reduction work.
+#include "gfv_common.h"
+#include "../../include/gfv.h"
+
+namespace {
+
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  const int tid = threadIdx.x;
+  v = gfv_wave_sum(v);
+  __syncthreads();
+  if ((tid & 63) == 0) red[tid >> 6] = v;
+  __syncthreads();
+  float s = 0.f;
+  for (int i = 0; i < (int)(blockDim.x >> 6); ++i) s += red[i];
+  return s;
+}
+
+// per graph: mean and population std of x[:,0:3] (importer.py:80-93), two passes like the reference
+__global__ __launch_bounds__(256) void graph_norm_stats_kernel(const float* __restrict__ x, int ldx,
+                                                               const int* __restrict__ gnode_ptr, float* __restrict__ stats) {
+  __shared__ float red[4];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int beg = gnode_ptr[b], end = gnode_ptr[b + 1];
+  const float cnt = fmaxf((float)(end - beg), 1.f);
+  float mean[3];
+  for (int c = 0; c < 3; ++c) {
+    float s = 0.f;
+    for (int i = beg + tid; i < end; i += 256) s += x[(size_t)i * ldx + c];
+    mean[c] = block_sum(s, red) / cnt;
+  }
+  for (int c = 0; c < 3; ++c) {
+    float s = 0.f;
+    for (int i = beg + tid; i < end; i += 256) {
+      const float d = x[(size_t)i * ldx + c] - mean[c];
+      s += d * d;
+    }
+    const float var = block_sum(s, red) / cnt;
+    if (tid == 0) {
+      stats[6 * b + c] = mean[c];
+      stats[6 * b + 3 + c] = sqrtf(var);
+    }
+  }
+}
+
+// column sums / sums of squares of x[:, 3:12] -> per-block partials [nblocks][18]
+__global__ __launch_bounds__(256) void normalizer_partial_kernel(const float* __restrict__ x, int ldx, int N,
+                                                                 float* __restrict__ partial) {
+  __shared__ float red[4];
+  const int tid = threadIdx.x;
+  float s[9], q[9];
+#pragma unroll
+  for (int c = 0; c < 9; ++c) { s[c] = 0.f; q[c] = 0.f; }
+  for (int i = blockIdx.x * 256 + tid; i < N; i += gridDim.x * 256) {
+#pragma unroll
+    for (int c = 0; c < 9; ++c) {
+      const float v = x[(size_t)i * ldx + 3 + c];
+      s[c] += v; q[c] += v * v;
+    }
+  }
+  for (int c = 0; c < 9; ++c) {
+    const float a = block_sum(s[c], red);
+    const float b = block_sum(q[c], red);
+    if (tid == 0) { partial[blockIdx.x * 18 + c] = a; partial[blockIdx.x * 18 + 9 + c] = b; }
+  }
+}
+
+// fold partials into the running buffers and derive mean / std (normalization.py:52-85)
+__global__ void normalizer_finalize_kernel(const float* __restrict__ partial, int nblocks, float n_rows, int accumulate,
+                                           float* acc_count, float* num_acc, float* acc_sum, float* acc_sq,
+                                           float* __restrict__ mean_std) {
+  const int c = threadIdx.x;
+  if (c >= 9) return;
+  if (accumulate) {
+    float a = 0.f, b = 0.f;
+    for (int i = 0; i < nblocks; ++i) { a += partial[i * 18 + c]; b += partial[i * 18 + 9 + c]; }
+    acc_sum[c] += a;
+    acc_sq[c] += b;
+  }
+  const float cnt_new = accumulate ? (*acc_count + n_rows) : *acc_count;
+  const float safe = fmaxf(cnt_new, 1.0f);
+  const float mean = acc_sum[c] / safe;
+  float sd = sqrtf(acc_sq[c] / safe - mean * mean);
+  if (sd < 1e-8f || !(sd == sd)) sd = (sd == sd) ? 1.0f : sd;
+  mean_std[c] = mean;
+  mean_std[9 + c] = sd;
+  __syncthreads();
+  if (c == 0 && accumulate) { *acc_count = cnt_new; *num_acc = *num_acc + 1.0f; }
+}
+
+// uv_old, per-graph standardisation of x[:,0:3], running-stat normalisation of x[:,3:12]; in place on x
+__global__ __launch_bounds__(256) void node_prep_kernel(float* __restrict__ x, int ldx, const int* __restrict__ batch,
+                                                        const float* __restrict__ stats, const float* __restrict__ uvp_dim,
+                                                        const float* __restrict__ mean_std, int norm_global,
+                                                        float* __restrict__ uv_old, int N) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= N) return;
+  const int b = batch[i];
+  float* xr = x + (size_t)i * ldx;
+  uv_old[2 * i] = xr[0] / uvp_dim[3 * b];
+  uv_old[2 * i + 1] = xr[1] / uvp_dim[3 * b + 1];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) xr[c] = (xr[c] - stats[6 * b + c]) / (stats[6 * b + 3 + c] + 1e-8f);
+  if (norm_global) {
+#pragma unroll
+    for (int c = 0; c < 9; ++c) xr[3 + c] = (xr[3 + c] - mean_std[c]) / mean_std[9 + c];
+  }
+}
+
+// edge_attr = [x_s - x_r (12) | pos_s - pos_r (2) | norm (1)] (importer.py:54-78); padded [E,16] + optional packed [E,15]
+__global__ __launch_bounds__(256) void edge_attr_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ pos,
+                                                        const int* __restrict__ es, const int* __restrict__ er,
+                                                        float* __restrict__ out16, float* __restrict__ out15, int E) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= E) return;
+  const int s = es[e], r = er[e];
+  float v[16];
+#pragma unroll
+  for (int c = 0; c < 12; ++c) v[c] = x[(size_t)s * ldx + c] - x[(size_t)r * ldx + c];
+  const float dx = pos[2 * s] - pos[2 * r], dy = pos[2 * s + 1] - pos[2 * r + 1];
+  v[12] = dx; v[13] = dy; v[14] = sqrtf(dx * dx + dy * dy); v[15] = 0.f;
+  float4* o = reinterpret_cast<float4*>(out16 + (size_t)e * 16);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) o[j] = make_float4(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
+  if (out15) {
+#pragma unroll
+    for (int c = 0; c < 15; ++c) out15[(size_t)e * 15 + c] = v[c];
+  }
+}
+
+__global__ void adam_tick_kernel(float* step) { *step = *step + 1.0f; }
+
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, long n, const float* __restrict__ step, float lr,
+                                                   float b1, float b2, float eps, float grad_scale) {
+  const float t = *step;
+  const float bc1 = 1.0f - powf(b1, t), bc2 = 1.0f - powf(b2, t);
+  const float step_size = lr / bc1, bc2_sqrt = sqrtf(bc2);
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float gi = g[i] * grad_scale;
+    const float mi = m[i] * b1 + (1.0f - b1) * gi;
+    const float vi = v[i] * b2 + (1.0f - b2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] = p[i] - step_size * (mi / denom);
+  }
+}
+
+// loss = mean_b log(w_p*L_p + w_c*L_c + w_m*L_mx + w_m*L_my) (pre_train_Adam.py:177-184) and its gradient wrt the
+// four per-graph residuals; losses layout [B,4] = (cont, momx, momy, press)
+__global__ void train_loss_kernel(const float* __restrict__ losses, int B, float wc, float wm, float wp,
+                                  float* __restrict__ loss, float* __restrict__ gloss) {
+  __shared__ float red[64];
+  const int tid = threadIdx.x;
+  float s = 0.f;
+  for (int b = tid; b < B; b += 64) {
+    const float tot = wp * losses[4 * b + 3] + wc * losses[4 * b] + wm * losses[4 * b + 1] + wm * losses[4 * b + 2];
+    s += logf(tot);
+    const float inv = 1.0f / (tot * (float)B);
+    gloss[4 * b] = wc * inv; gloss[4 * b + 1] = wm * inv; gloss[4 * b + 2] = wm * inv; gloss[4 * b + 3] = wp * inv;
+  }
+  red[tid] = s;
+  __syncthreads();
+  if (tid == 0) {
+    float a = 0.f;
+    for (int i = 0; i < 64; ++i) a += red[i];
+    *loss = a / (float)B;
+  }
+}
+
+inline int cap_grid(long n) {
+  long g = (n + 255) / 256;
+  if (g > 4096) g = 4096;
+  return (int)(g < 1 ? 1 : g);
+}
+
+}  // namespace
+
+extern "C" int gfv_graph_norm_stats(const float* x, int32_t ldx, const int32_t* gnode_ptr, int32_t B, float* stats,
+                                    void* stream) {
+  if (B <= 0) return GFV_OK;
+  hipLaunchKernelGGL(graph_norm_stats_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, x, ldx, gnode_ptr, stats);
+  GFV_CHECK_LAUNCH();
+  return GFV_OK;
+}
+
+extern "C" int gfv_normalizer_blocks(int32_t N) { int g = (N + 255) / 256; return g > 512 ? 512 : (g < 1 ? 1 : g); }
+
+extern "C" int gfv_normalizer_update(const float* x, int32_t ldx, int32_t N, int32_t accumulate, float* acc_count,
+                                     float* num_acc, float* acc_sum, float* acc_sq, float* partial_ws, float* mean_std,
+                                     void* stream) {
+  const int nb = gfv_normalizer_blocks(N);
+  if (accumulate && N > 0) {
+    hipLaunchKernelGGL(normalizer_partial_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, x, ldx, N, partial_ws);
+    GFV_CHECK_LAUNCH();
+  }
+  hipLaunchKernelGGL(normalizer_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, partial_ws, nb, (float)N,
+                     accumulate, acc_count, num_acc, acc_sum, acc_sq, mean_std);
+  GFV_CHECK_LAUNCH();
+  return GFV_OK;
+}
+
+extern "C" int gfv_node_prep(float* x, int32_t ldx, const int32_t* batch, const float* stats, const float* uvp_dim,
+                             const float* mean_std, int32_t norm_global, float* uv_old, int32_t N, void* stream) {
+  if (N <= 0) return GFV_OK;
+  hipLaunchKernelGGL(node_prep_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, ldx, batch, stats,
+                     uvp_dim, mean_std, norm_global, uv_old, N);
+  GFV_CHECK_LAUNCH();
+  return GFV_OK;
+}
+
+extern "C" int gfv_edge_attr(const float* x, int32_t ldx, const float* pos, const int32_t* es, const int32_t* er,
+                             float* out16, float* out15, int32_t E, void* stream) {
+  if (E <= 0) return GFV_OK;
+  hipLaunchKernelGGL(edge_attr_kernel, dim3((E + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, ldx, pos, es, er,
+                     out16, out15, E);
+  GFV_CHECK_LAUNCH();
+  return GFV_OK;
+}
+
+extern "C" int gfv_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float* step, float lr, float beta1,
+                             float beta2, float eps, float grad_scale, void* stream) {
+  if (n <= 0) return GFV_OK;
+  hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step);
+  hipLaunchKernelGGL(adam_kernel, dim3(cap_grid(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long)n, step, lr,
+                     beta1, beta2, eps, grad_scale);
+  GFV_CHECK_LAUNCH();
+  return GFV_OK;
+}
+
+extern "C" int gfv_train_loss(const float* losses, int32_t B, float w_cont, float w_mom, float w_press, float* loss,
+                              float* gloss, void* stream) {
+  if (B <= 0) return GFV_ERR_ARG;
+  hipLaunchKernelGGL(train_loss_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, losses, B, w_cont, w_mom, w_press, loss,
+                     gloss);
+  GFV_CHECK_LAUNCH();
+  return GFV_OK;
+}

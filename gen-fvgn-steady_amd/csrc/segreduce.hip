@@ -123,14 +123,14 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
   }
 }
 
-__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int rows,
-                                                        int cols) {
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, int ld_in, float* __restrict__ out,
+                                                        int rows, int cols) {
   __shared__ float tile[32][33];
   const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
   for (int j = ty; j < 32; j += 8) {
     const int r = by + j, c = bx + tx;
-    tile[j][tx] = (r < rows && c < cols) ? in[(size_t)r * cols + c] : 0.f;
+    tile[j][tx] = (r < rows && c < cols) ? in[(size_t)r * ld_in + c] : 0.f;
   }
   __syncthreads();
   for (int j = ty; j < 32; j += 8) {
@@ -198,10 +198,10 @@ extern "C" int gfv_reduce_partials(const float* partial, int32_t n_chunks, int32
   return GFV_OK;
 }
 
-extern "C" int gfv_transpose(const float* in, float* out, int32_t rows, int32_t cols, void* stream) {
+extern "C" int gfv_transpose(const float* in, int32_t ld_in, float* out, int32_t rows, int32_t cols, void* stream) {
   if (rows <= 0 || cols <= 0) return GFV_ERR_ARG;
   hipLaunchKernelGGL(transpose_kernel, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(256), 0, (hipStream_t)stream, in,
-                     out, rows, cols);
+                     ld_in, out, rows, cols);
   GFV_CHECK_LAUNCH();
   return GFV_OK;
 }

@@ -1,0 +1,505 @@
+// Transolver "physics attention" over per-graph slice tokens (gfx950).  Contract: include/gfv.h.
+// Reference: FVMmodel/Models/GraphTransolver/GraphTransolver.py:48-95 (Graph_Physics_Attention_1D.graph_forward).
+//
+// Fixed geometry of the reference's block: H = 8 heads, D = 16 dims per head, G = 32 slices (TransFVGN_v2.py:28-35).
+// The reference materialises [N,8,32,16] products twice per forward (28 % of its CPU time); here the per-node
+// work stays in registers and only w [N,8,32] and the per-graph tokens [B,8,32,16] touch memory.
+#include "gfv_common.h"
+#include "../../include/gfv.h"
+
+namespace {
+
+constexpr int H = 8, D = 16, G = 32;
+
+// ---- w = softmax((x_mid . Ws^T + bs) / T_h) ---------------------------------------------------------------
+// one thread per (node, head); a block covers 32 nodes.  Results are staged through LDS for row-contiguous stores.
+__global__ __launch_bounds__(256) void slice_softmax_fwd_kernel(const float* __restrict__ xmid, const float* __restrict__ Ws,
+                                                                const float* __restrict__ bs, const float* __restrict__ temp,
+                                                                float* __restrict__ w, int N) {
+  __shared__ float sW[G * D];
+  __shared__ float sB[G];
+  __shared__ float stage[256 * (G + 1)];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < G * D; i += 256) sW[i] = Ws[i];
+  if (tid < G) sB[tid] = bs[tid];
+  __syncthreads();
+  const long row0 = (long)blockIdx.x * 256;  // (n,h) row index
+  const long row = row0 + tid;
+  const long nrows = (long)N * H;
+  if (row < nrows) {
+    const int h = (int)(row & (H - 1));
+    float x[D];
+    const float4* xp = reinterpret_cast<const float4*>(xmid + row * D);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float4 v = xp[i];
+      x[4 * i] = v.x; x[4 * i + 1] = v.y; x[4 * i + 2] = v.z; x[4 * i + 3] = v.w;
+    }
+    const float invT = 1.0f / temp[h];
+    float l[G];
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      float s = 0.f;
+#pragma unroll
+      for (int c = 0; c < D; ++c) s += x[c] * sW[g * D + c];
+      s = (s + sB[g]) * invT;
+      l[g] = s;
+      mx = fmaxf(mx, s);
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      l[g] = __expf(l[g] - mx);
+      sum += l[g];
+    }
+    const float inv = 1.0f / sum;
+#pragma unroll
+    for (int g = 0; g < G; ++g) stage[tid * (G + 1) + g] = l[g] * inv;
+  }
+  __syncthreads();
+  // coalesced store of the block's 256 x 32 floats
+  for (int i = tid; i < 256 * G; i += 256) {
+    const long r = row0 + i / G;
+    if (r < nrows) w[r * G + (i % G)] = stage[(i / G) * (G + 1) + (i % G)];
+  }
+}
+
+// backward of the slice softmax.  gw = dL/dw.  Outputs g_xmid [N,128] and per-block partials of
+// (dWs [32,16], dbs [32], dT [8]) = 552 floats per block.
+__global__ __launch_bounds__(256) void slice_softmax_bwd_kernel(const float* __restrict__ xmid, const float* __restrict__ Ws,
+                                                                const float* __restrict__ bs, const float* __restrict__ temp,
+                                                                const float* __restrict__ w, const float* __restrict__ gw,
+                                                                float* __restrict__ gxmid, float* __restrict__ partial, int N) {
+  __shared__ float sW[G * D];
+  __shared__ float sB[G];
+  __shared__ float sGL[256 * (G + 1)];  // d logits (pre-temperature) per row
+  __shared__ float sX[256 * (D + 1)];
+  __shared__ float sT[256];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < G * D; i += 256) sW[i] = Ws[i];
+  if (tid < G) sB[tid] = bs[tid];
+  __syncthreads();
+  const long row = (long)blockIdx.x * 256 + tid;
+  const long nrows = (long)N * H;
+  float dT = 0.f;
+  if (row < nrows) {
+    const int h = (int)(row & (H - 1));
+    const float invT = 1.0f / temp[h];
+    float x[D];
+    const float4* xp = reinterpret_cast<const float4*>(xmid + row * D);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float4 v = xp[i];
+      x[4 * i] = v.x; x[4 * i + 1] = v.y; x[4 * i + 2] = v.z; x[4 * i + 3] = v.w;
+    }
+    float wv[G], gv[G];
+    const float4* wp = reinterpret_cast<const float4*>(w + row * G);
+    const float4* gp = reinterpret_cast<const float4*>(gw + row * G);
+    float dot = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float4 a = wp[i], b = gp[i];
+      wv[4 * i] = a.x; wv[4 * i + 1] = a.y; wv[4 * i + 2] = a.z; wv[4 * i + 3] = a.w;
+      gv[4 * i] = b.x; gv[4 * i + 1] = b.y; gv[4 * i + 2] = b.z; gv[4 * i + 3] = b.w;
+      dot += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+    }
+    float gx[D];
+#pragma unroll
+    for (int c = 0; c < D; ++c) gx[c] = 0.f;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const float gz = wv[g] * (gv[g] - dot);  // grad wrt z = logit / T
+      float lg = 0.f;
+#pragma unroll
+      for (int c = 0; c < D; ++c) lg += x[c] * sW[g * D + c];
+      lg += sB[g];
+      dT -= gz * lg * invT * invT;
+      const float gl = gz * invT;  // grad wrt the raw logit
+      sGL[tid * (G + 1) + g] = gl;
+#pragma unroll
+      for (int c = 0; c < D; ++c) gx[c] += gl * sW[g * D + c];
+    }
+    float4* op = reinterpret_cast<float4*>(gxmid + row * D);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) op[i] = make_float4(gx[4 * i], gx[4 * i + 1], gx[4 * i + 2], gx[4 * i + 3]);
+#pragma unroll
+    for (int c = 0; c < D; ++c) sX[tid * (D + 1) + c] = x[c];
+  } else {
+#pragma unroll
+    for (int g = 0; g < G; ++g) sGL[tid * (G + 1) + g] = 0.f;
+#pragma unroll
+    for (int c = 0; c < D; ++c) sX[tid * (D + 1) + c] = 0.f;
+  }
+  sT[tid] = dT;
+  __syncthreads();
+  // dWs[g][c] = sum_rows GL[row][g] * X[row][c]: 512 outputs, 2 per thread
+  float* out = partial + (size_t)blockIdx.x * 552;
+#pragma unroll
+  for (int o = 0; o < 2; ++o) {
+    const int idx = tid + 256 * o;
+    const int g = idx / D, c = idx % D;
+    float s = 0.f;
+    for (int r = 0; r < 256; ++r) s += sGL[r * (G + 1) + g] * sX[r * (D + 1) + c];
+    out[idx] = s;
+  }
+  if (tid < G) {
+    float s = 0.f;
+    for (int r = 0; r < 256; ++r) s += sGL[r * (G + 1) + tid];
+    out[512 + tid] = s;
+  }
+  if (tid < H) {
+    float s = 0.f;
+    for (int r = tid; r < 256; r += H) s += sT[r];  // rows of head h are r = h mod 8 (block base is a multiple of 8)
+    out[544 + tid] = s;
+  }
+}
+
+// ---- per-chunk partial slice tokens:  T[h][g][c] = sum_n w[n,h,g] * a[n,h,c],  Nrm[h][g] = sum_n w[n,h,g] ------------
+// chunk = contiguous node range inside one graph.  thread t <-> (h = t/32, g = t%32), 16 accumulators + norm.
+__global__ __launch_bounds__(256) void slice_token_partial_kernel(const float* __restrict__ w, const float* __restrict__ a,
+                                                                  const int* __restrict__ chunk_beg,
+                                                                  const int* __restrict__ chunk_end,
+                                                                  float* __restrict__ partial) {
+  const int tid = threadIdx.x, h = tid >> 5;
+  const int beg = chunk_beg[blockIdx.x], end = chunk_end[blockIdx.x];
+  float acc[D];
+#pragma unroll
+  for (int c = 0; c < D; ++c) acc[c] = 0.f;
+  float nrm = 0.f;
+  for (int n = beg; n < end; ++n) {
+    const float wv = w[(size_t)n * 256 + tid];
+    const float4* ap = reinterpret_cast<const float4*>(a + (size_t)n * 128 + h * D);
+    nrm += wv;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float4 v = ap[i];
+      acc[4 * i] += wv * v.x; acc[4 * i + 1] += wv * v.y; acc[4 * i + 2] += wv * v.z; acc[4 * i + 3] += wv * v.w;
+    }
+  }
+  float* out = partial + ((size_t)blockIdx.x * 256 + tid) * 17;
+#pragma unroll
+  for (int c = 0; c < D; ++c) out[c] = acc[c];
+  out[16] = nrm;
+}
+
+// ---- attention among the 32 slice tokens of one (graph, head) ---------------------------------------------------
+struct AttnFwdArgs {
+  const float* partial;      // [nchunks][256][17]
+  const int* gchunk_ptr;     // [B+1] chunk range of each graph
+  const float *Wq, *Wk, *Wv; // [16,16]
+  float* token;              // [B,8,32,16] normalised slice tokens
+  float* norm;               // [B,8,32]
+  float* attn;               // [B,8,32,32]
+  float* out_token;          // [B,8,32,16]
+};
+
+__global__ __launch_bounds__(256) void slice_attention_fwd_kernel(const AttnFwdArgs A) {
+  __shared__ float sTok[G][D + 1], sQ[G][D + 1], sK[G][D + 1], sV[G][D + 1], sA[G][G + 1], sNrm[G];
+  __shared__ float sWq[D * D], sWk[D * D], sWv[D * D];
+  const int b = blockIdx.x, h = blockIdx.y, tid = threadIdx.x;
+  const int bh = b * H + h;
+  sWq[tid] = A.Wq[tid]; sWk[tid] = A.Wk[tid]; sWv[tid] = A.Wv[tid];
+  // reduce chunk partials (fixed order): 512 token values + 32 norms
+  const int c0 = A.gchunk_ptr[b], c1 = A.gchunk_ptr[b + 1];
+  for (int idx = tid; idx < G * 17; idx += 256) {
+    const int g = idx / 17, c = idx % 17;
+    float s = 0.f;
+    for (int ch = c0; ch < c1; ++ch) s += A.partial[((size_t)ch * 256 + h * G + g) * 17 + c];
+    if (c < D) sTok[g][c] = s; else sNrm[g] = s;
+  }
+  __syncthreads();
+  for (int idx = tid; idx < G * D; idx += 256) {
+    const int g = idx / D, c = idx % D;
+    const float t = sTok[g][c] / (sNrm[g] + 1e-5f);  // GraphTransolver.py:74
+    A.token[(size_t)bh * G * D + idx] = t;
+  }
+  if (tid < G) A.norm[bh * G + tid] = sNrm[tid];
+  __syncthreads();
+  for (int idx = tid; idx < G * D; idx += 256) {
+    const int g = idx / D, c = idx % D;
+    sTok[g][c] = sTok[g][c] / (sNrm[g] + 1e-5f);
+  }
+  __syncthreads();
+  for (int idx = tid; idx < G * D; idx += 256) {
+    const int g = idx / D, j = idx % D;
+    float q = 0.f, k = 0.f, v = 0.f;
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+      const float t = sTok[g][c];
+      q += t * sWq[j * D + c]; k += t * sWk[j * D + c]; v += t * sWv[j * D + c];
+    }
+    sQ[g][j] = q; sK[g][j] = k; sV[g][j] = v;
+  }
+  __syncthreads();
+  for (int idx = tid; idx < G * G; idx += 256) {
+    const int i = idx / G, j = idx % G;
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < D; ++c) s += sQ[i][c] * sK[j][c];
+    sA[i][j] = s * 0.25f;  // dim_head ** -0.5, GraphTransolver.py:31,80
+  }
+  __syncthreads();
+  if (tid < G) {
+    float mx = -3.0e38f;
+    for (int j = 0; j < G; ++j) mx = fmaxf(mx, sA[tid][j]);
+    float sum = 0.f;
+    for (int j = 0; j < G; ++j) { const float e = __expf(sA[tid][j] - mx); sA[tid][j] = e; sum += e; }
+    const float inv = 1.0f / sum;
+    for (int j = 0; j < G; ++j) sA[tid][j] *= inv;
+  }
+  __syncthreads();
+  for (int idx = tid; idx < G * G; idx += 256) A.attn[(size_t)bh * G * G + idx] = sA[idx / G][idx % G];
+  for (int idx = tid; idx < G * D; idx += 256) {
+    const int i = idx / D, c = idx % D;
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < G; ++j) s += sA[i][j] * sV[j][c];
+    A.out_token[(size_t)bh * G * D + idx] = s;
+  }
+}
+
+struct AttnBwdArgs {
+  const float* gpartial;   // [nchunks][256][17] partial sums of w^T g_out_x (slot 16 unused)
+  const int* gchunk_ptr;
+  const float *Wq, *Wk, *Wv;
+  const float* token;      // normalised tokens (saved)
+  const float* norm;
+  const float* attn;
+  float* g_raw;            // [B,8,32,16] grad wrt the un-normalised token sums
+  float* g_norm;           // [B,8,32]    grad wrt slice_norm
+  float* dW_partial;       // [B*8][3][16][16]
+};
+
+__global__ __launch_bounds__(256) void slice_attention_bwd_kernel(const AttnBwdArgs A) {
+  __shared__ float sTok[G][D + 1], sQ[G][D + 1], sK[G][D + 1], sV[G][D + 1], sA[G][G + 1], sGO[G][D + 1];
+  __shared__ float sGA[G][G + 1], sGQ[G][D + 1], sGK[G][D + 1], sGV[G][D + 1], sGT[G][D + 1];
+  __shared__ float sWq[D * D], sWk[D * D], sWv[D * D];
+  const int b = blockIdx.x, h = blockIdx.y, tid = threadIdx.x;
+  const int bh = b * H + h;
+  sWq[tid] = A.Wq[tid]; sWk[tid] = A.Wk[tid]; sWv[tid] = A.Wv[tid];
+  const int c0 = A.gchunk_ptr[b], c1 = A.gchunk_ptr[b + 1];
+  for (int idx = tid; idx < G * D; idx += 256) {
+    const int g = idx / D, c = idx % D;
+    float s = 0.f;
+    for (int ch = c0; ch < c1; ++ch) s += A.gpartial[((size_t)ch * 256 + h * G + g) * 17 + c];
+    sGO[g][c] = s;  // grad wrt out_token
+    sTok[g][c] = A.token[(size_t)bh * G * D + idx];
+  }
+  for (int idx = tid; idx < G * G; idx += 256) sA[idx / G][idx % G] = A.attn[(size_t)bh * G * G + idx];
+  __syncthreads();
+  for (int idx = tid; idx < G * D; idx += 256) {
+    const int g = idx / D, j = idx % D;
+    float q = 0.f, k = 0.f, v = 0.f;
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+      const float t = sTok[g][c];
+      q += t * sWq[j * D + c]; k += t * sWk[j * D + c]; v += t * sWv[j * D + c];
+    }
+    sQ[g][j] = q; sK[g][j] = k; sV[g][j] = v;
+  }
+  __syncthreads();
+  // out = attn @ V:  gV = attn^T gO ; gAttn = gO V^T
+  for (int idx = tid; idx < G * D; idx += 256) {
+    const int j = idx / D, c = idx % D;
+    float s = 0.f;
+    for (int i = 0; i < G; ++i) s += sA[i][j] * sGO[i][c];
+    sGV[j][c] = s;
+  }
+  for (int idx = tid; idx < G * G; idx += 256) {
+    const int i = idx / G, j = idx % G;
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < D; ++c) s += sGO[i][c] * sV[j][c];
+    sGA[i][j] = s;
+  }
+  __syncthreads();
+  if (tid < G) {  // softmax backward per row, then the 1/sqrt(D) scale
+    float dot = 0.f;
+    for (int j = 0; j < G; ++j) dot += sA[tid][j] * sGA[tid][j];
+    for (int j = 0; j < G; ++j) sGA[tid][j] = sA[tid][j] * (sGA[tid][j] - dot) * 0.25f;
+  }
+  __syncthreads();
+  for (int idx = tid; idx < G * D; idx += 256) {
+    const int i = idx / D, c = idx % D;
+    float gq = 0.f, gk = 0.f;
+    for (int j = 0; j < G; ++j) {
+      gq += sGA[i][j] * sK[j][c];
+      gk += sGA[j][i] * sQ[j][c];
+    }
+    sGQ[i][c] = gq; sGK[i][c] = gk;
+  }
+  __syncthreads();
+  // q = tok Wq^T ...: g_tok = gQ Wq + gK Wk + gV Wv ; dWq[j][c] = sum_g gQ[g][j] tok[g][c]
+  for (int idx = tid; idx < G * D; idx += 256) {
+    const int g = idx / D, c = idx % D;
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < D; ++j) s += sGQ[g][j] * sWq[j * D + c] + sGK[g][j] * sWk[j * D + c] + sGV[g][j] * sWv[j * D + c];
+    sGT[g][c] = s;
+  }
+  {
+    const int j = tid / D, c = tid % D;
+    float dq = 0.f, dk = 0.f, dv = 0.f;
+    for (int g = 0; g < G; ++g) {
+      const float t = sTok[g][c];
+      dq += sGQ[g][j] * t; dk += sGK[g][j] * t; dv += sGV[g][j] * t;
+    }
+    float* o = A.dW_partial + (size_t)bh * 3 * D * D;
+    o[tid] = dq; o[D * D + tid] = dk; o[2 * D * D + tid] = dv;
+  }
+  __syncthreads();
+  // token = raw / (norm + eps):  g_raw = g_tok / (norm+eps) ; g_norm = -sum_c g_tok * token / (norm+eps)
+  for (int idx = tid; idx < G * D; idx += 256) {
+    const int g = idx / D, c = idx % D;
+    A.g_raw[(size_t)bh * G * D + idx] = sGT[g][c] / (A.norm[bh * G + g] + 1e-5f);
+  }
+  if (tid < G) {
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < D; ++c) s += sGT[tid][c] * sTok[tid][c];
+    A.g_norm[bh * G + tid] = -s / (A.norm[bh * G + tid] + 1e-5f);
+  }
+}
+
+// ---- de-slice:  out[n,h,c] = sum_g w[n,h,g] * T[b(n),h,g,c]    (thread per (n,h)) ------------------------------------
+__global__ __launch_bounds__(256) void deslice_kernel(const float* __restrict__ w, const float* __restrict__ T,
+                                                      const int* __restrict__ batch, float* __restrict__ out, int N,
+                                                      int accumulate) {
+  const long row = (long)blockIdx.x * 256 + threadIdx.x;
+  if (row >= (long)N * H) return;
+  const int n = (int)(row >> 3), h = (int)(row & 7);
+  const float* Tp = T + ((size_t)batch[n] * H + h) * G * D;
+  float acc[D];
+#pragma unroll
+  for (int c = 0; c < D; ++c) acc[c] = 0.f;
+  const float4* wp = reinterpret_cast<const float4*>(w + row * G);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const float4 wv = wp[i];
+    const float ww[4] = {wv.x, wv.y, wv.z, wv.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float4* tp = reinterpret_cast<const float4*>(Tp + (4 * i + k) * D);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float4 t = tp[j];
+        acc[4 * j] += ww[k] * t.x; acc[4 * j + 1] += ww[k] * t.y; acc[4 * j + 2] += ww[k] * t.z; acc[4 * j + 3] += ww[k] * t.w;
+      }
+    }
+  }
+  float4* op = reinterpret_cast<float4*>(out + row * D);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    float4 v = make_float4(acc[4 * j], acc[4 * j + 1], acc[4 * j + 2], acc[4 * j + 3]);
+    if (accumulate) { const float4 p = op[j]; v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w; }
+    op[j] = v;
+  }
+}
+
+// ---- gw[n,h,g] (+)= sum_c a[n,h,c] * T[b(n),h,g,c] (+ add[b(n),h,g]) --------------------------------------------------
+__global__ __launch_bounds__(256) void slice_gw_kernel(const float* __restrict__ a, const float* __restrict__ T,
+                                                       const float* __restrict__ add, const int* __restrict__ batch,
+                                                       float* __restrict__ gw, int N, int accumulate) {
+  const long row = (long)blockIdx.x * 256 + threadIdx.x;
+  if (row >= (long)N * H) return;
+  const int n = (int)(row >> 3), h = (int)(row & 7);
+  const size_t bh = (size_t)batch[n] * H + h;
+  const float* Tp = T + bh * G * D;
+  float x[D];
+  const float4* ap = reinterpret_cast<const float4*>(a + row * D);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float4 v = ap[i];
+    x[4 * i] = v.x; x[4 * i + 1] = v.y; x[4 * i + 2] = v.z; x[4 * i + 3] = v.w;
+  }
+  float4* op = reinterpret_cast<float4*>(gw + row * G);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    float r[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float4* tp = reinterpret_cast<const float4*>(Tp + (4 * i + k) * D);
+      float s = add ? add[bh * G + 4 * i + k] : 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float4 t = tp[j];
+        s += x[4 * j] * t.x + x[4 * j + 1] * t.y + x[4 * j + 2] * t.z + x[4 * j + 3] * t.w;
+      }
+      r[k] = s;
+    }
+    float4 v = make_float4(r[0], r[1], r[2], r[3]);
+    if (accumulate) { const float4 p = op[i]; v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w; }
+    op[i] = v;
+  }
+}
+
+}  // namespace
+
+extern "C" int gfv_slice_softmax_fwd(const float* xmid, const float* Ws, const float* bs, const float* temp, float* w,
+                                     int32_t N, void* stream) {
+  if (N <= 0) return N == 0 ? GFV_OK : GFV_ERR_ARG;
+  hipLaunchKernelGGL(slice_softmax_fwd_kernel, dim3(gfv_div_up((long)N * H, 256)), dim3(256), 0, (hipStream_t)stream,
+                     xmid, Ws, bs, temp, w, N);
+  GFV_CHECK_LAUNCH();
+  return GFV_OK;
+}
+
+extern "C" int gfv_slice_softmax_bwd_blocks(int32_t N) { return gfv_div_up((long)N * H, 256); }
+
+extern "C" int gfv_slice_softmax_bwd(const float* xmid, const float* Ws, const float* bs, const float* temp,
+                                     const float* w, const float* gw, float* gxmid, float* partial, int32_t N,
+                                     void* stream) {
+  if (N <= 0) return N == 0 ? GFV_OK : GFV_ERR_ARG;
+  hipLaunchKernelGGL(slice_softmax_bwd_kernel, dim3(gfv_div_up((long)N * H, 256)), dim3(256), 0, (hipStream_t)stream,
+                     xmid, Ws, bs, temp, w, gw, gxmid, partial, N);
+  GFV_CHECK_LAUNCH();
+  return GFV_OK;
+}
+
+extern "C" int gfv_slice_token_partial(const float* w, const float* a, const int32_t* chunk_beg, const int32_t* chunk_end,
+                                       int32_t n_chunks, float* partial, void* stream) {
+  if (n_chunks <= 0) return n_chunks == 0 ? GFV_OK : GFV_ERR_ARG;
+  hipLaunchKernelGGL(slice_token_partial_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, w, a, chunk_beg,
+                     chunk_end, partial);
+  GFV_CHECK_LAUNCH();
+  return GFV_OK;
+}
+
+extern "C" int gfv_slice_attention_fwd(const float* partial, const int32_t* gchunk_ptr, int32_t B, const float* Wq,
+                                       const float* Wk, const float* Wv, float* token, float* norm, float* attn,
+                                       float* out_token, void* stream) {
+  if (B <= 0) return B == 0 ? GFV_OK : GFV_ERR_ARG;
+  AttnFwdArgs a{partial, gchunk_ptr, Wq, Wk, Wv, token, norm, attn, out_token};
+  hipLaunchKernelGGL(slice_attention_fwd_kernel, dim3(B, H), dim3(256), 0, (hipStream_t)stream, a);
+  GFV_CHECK_LAUNCH();
+  return GFV_OK;
+}
+
+extern "C" int gfv_slice_attention_bwd(const float* gpartial, const int32_t* gchunk_ptr, int32_t B, const float* Wq,
+                                       const float* Wk, const float* Wv, const float* token, const float* norm,
+                                       const float* attn, float* g_raw, float* g_norm, float* dW_partial, void* stream) {
+  if (B <= 0) return B == 0 ? GFV_OK : GFV_ERR_ARG;
+  AttnBwdArgs a{gpartial, gchunk_ptr, Wq, Wk, Wv, token, norm, attn, g_raw, g_norm, dW_partial};
+  hipLaunchKernelGGL(slice_attention_bwd_kernel, dim3(B, H), dim3(256), 0, (hipStream_t)stream, a);
+  GFV_CHECK_LAUNCH();
+  return GFV_OK;
+}
+
+extern "C" int gfv_deslice(const float* w, const float* T, const int32_t* batch, float* out, int32_t N, int32_t accumulate,
+                           void* stream) {
+  if (N <= 0) return N == 0 ? GFV_OK : GFV_ERR_ARG;
+  hipLaunchKernelGGL(deslice_kernel, dim3(gfv_div_up((long)N * H, 256)), dim3(256), 0, (hipStream_t)stream, w, T, batch,
+                     out, N, accumulate);
+  GFV_CHECK_LAUNCH();
+  return GFV_OK;
+}
+
+extern "C" int gfv_slice_gw(const float* a, const float* T, const float* add, const int32_t* batch, float* gw, int32_t N,
+                            int32_t accumulate, void* stream) {
+  if (N <= 0) return N == 0 ? GFV_OK : GFV_ERR_ARG;
+  hipLaunchKernelGGL(slice_gw_kernel, dim3(gfv_div_up((long)N * H, 256)), dim3(256), 0, (hipStream_t)stream, a, T, add,
+                     batch, gw, N, accumulate);
+  GFV_CHECK_LAUNCH();
+  return GFV_OK;
+}

@@ -1,0 +1,420 @@
+"""Hand-orchestrated forward / backward of the Gen-FVGN hot path on the HIP kernels of libgfv.
+
+This is the host side of SURVEY.md 8 rows a-1 ... a-14: a fixed sequence of C-ABI launches per training step with
+explicitly managed saved tensors (no autograd tape inside).  `FVMmodel.importer.NNmodel` wraps it in ONE
+torch.autograd.Function so the reference's drivers (`loss.backward(); optimizer.step()`) work unchanged, and
+`gfv.trainer.TrainStep` drives it directly (flat gradient buffer, fused Adam, hipGraph capture).
+
+Parameters are addressed by the reference's state_dict names.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import lib as L
+from . import ops
+from .ops import LayerSpec, Seg
+
+_MODE = {"explicit": 0, "implicit": 1, "imex": 2}
+
+
+def _empty(dev, *shape):
+    return torch.empty(shape, dtype=torch.float32, device=dev)
+
+
+class Engine:
+    def __init__(self, message_passing_num=3, integrator="imex", ncn_smooth=True, net="TransFVGN_v2"):
+        self.mp = message_passing_num
+        self.mode = _MODE[integrator]
+        self.smooth = 1 if ncn_smooth else 0
+        self.n_proc = 2 if net in ("TransFVGN_v2", "TransFVGN") else 1
+        self.net = net
+
+    # ------------------------------------------------------------------------------------------------------------
+    # fused 3-layer MLP (EPD.py:10-63)
+    # ------------------------------------------------------------------------------------------------------------
+    @staticmethod
+    def _mlp_names(prefix, ln):
+        lin = prefix + ".0" if ln else prefix
+        return [f"{lin}.0.weight", f"{lin}.0.bias", f"{lin}.2.weight", f"{lin}.2.bias", f"{lin}.4.weight",
+                f"{lin}.4.bias"] + ([f"{prefix}.1.weight", f"{prefix}.1.bias"] if ln else [])
+
+    def mlp3_fwd(self, P, prefix, M, segs, *, ln=True, res=None, in_add=None, want_nores=False, keep=True):
+        names = self._mlp_names(prefix, ln)
+        W1, b1, W2, b2, W3, b3 = (P[n] for n in names[:6])
+        dev = W1.device
+        nout = W3.shape[0]
+        z1 = _empty(dev, M, 128) if keep else None
+        z2 = _empty(dev, M, 128) if keep else None
+        y3 = _empty(dev, M, 128) if (keep and ln) else None
+        out = _empty(dev, M, nout)
+        nores = _empty(dev, M, 128) if want_nores else None
+        ops.rowtile_chain(
+            M, segs,
+            [LayerSpec(W1, b1, L.OP_BIAS_GELU, save=z1), LayerSpec(W2, b2, L.OP_BIAS_GELU, save=z2), LayerSpec(W3, b3)],
+            [out], in_add=in_add, fin_op=L.FIN_LN if ln else L.FIN_PLAIN,
+            fin_gamma=P[names[6]] if ln else None, fin_beta=P[names[7]] if ln else None, fin_presave=y3,
+            res=[res] if res is not None else None, out_nores=nores)
+        saved = dict(z1=z1, z2=z2, y3=y3, segs=segs, in_add=in_add, M=M, ln=ln, prefix=prefix)
+        return out, nores, saved
+
+    def mlp3_bwd(self, P, sv, G, grads, *, outs=None, res=None, gadd=None, W1t=None, g_ld=None):
+        """G: grad wrt the MLP output (after LayerNorm, before the residual) [M, nout].  outs: per 128-chunk of the
+        (possibly permuted) input, or None when the input needs no gradient (encoders)."""
+        prefix, M, ln = sv["prefix"], sv["M"], sv["ln"]
+        names = self._mlp_names(prefix, ln)
+        W1, W2, W3 = P[names[0]], P[names[2]], P[names[4]]
+        dev = W1.device
+        nout = W3.shape[0]
+        W3t, W2t = ops.transpose(W3), ops.transpose(W2)
+        gz2, gz1 = _empty(dev, M, 128), _empty(dev, M, 128)
+        tiles = ops.rowtile_tiles(M)
+        part = _empty(dev, tiles, 2, 128) if ln else None
+        g3 = _empty(dev, M, 128) if ln else G
+        gseg = Seg(G, width=nout, ld=G.stride(0) if g_ld is None else g_ld)
+        kw = dict(in_op=L.IN_LNBWD, in_gamma=P[names[6]], in_aux=sv["y3"], in_save=g3, ln_partial=part) if ln else {}
+        if gadd is not None:
+            kw.update(gadd=gadd[0], gadd_s=gadd[1], gadd_r=gadd[2])
+        if outs is not None:
+            if W1t is None:
+                W1t = ops.transpose(W1)
+            ops.rowtile_chain(M, [gseg],
+                              [LayerSpec(W3t, None, L.OP_MUL_DGELU, save=gz2, aux=sv["z2"]),
+                               LayerSpec(W2t, None, L.OP_MUL_DGELU, save=gz1, aux=sv["z1"]), LayerSpec(W1t)],
+                              outs, res=res, **kw)
+        else:
+            ops.rowtile_chain(M, [gseg],
+                              [LayerSpec(W3t, None, L.OP_MUL_DGELU, save=gz2, aux=sv["z2"]),
+                               LayerSpec(W2t, None, L.OP_MUL_DGELU, aux=sv["z1"])], [gz1], **kw)
+        self._dw(grads, names[4], names[5], g3, nout, [Seg(sv["z2"])], M, a_op=1,
+                 ldg=(G.stride(0) if g_ld is None else g_ld) if not ln else None)
+        self._dw(grads, names[2], names[3], gz2, 128, [Seg(sv["z1"])], M, a_op=1)
+        self._dw(grads, names[0], names[1], gz1, 128, sv["segs"], M, in_add=sv["in_add"])
+        if ln:
+            gb = ops.reduce_partials(part, tiles, 256)
+            self._put(grads, names[6], gb[:128])
+            self._put(grads, names[7], gb[128:])
+
+    @staticmethod
+    def _put(grads, name, value):
+        dst = grads.get(name)
+        if dst is None:
+            grads[name] = value
+        else:
+            dst.copy_(value.reshape(dst.shape))
+
+    def _dw(self, grads, wname, bname, G, n_out, segs, M, *, a_op=0, a_gamma=None, a_beta=None, in_add=None, ldg=None,
+            g_offset=0, row0=0):
+        """dW rows [row0, row0+n_out) of parameter `wname` (and its bias) from G."""
+        K = sum(s.width for s in segs)
+        dst = grads.get(wname)
+        dev = G.device
+        if dst is None:
+            raise KeyError(wname)
+        dW = dst[row0:row0 + n_out]
+        db = grads[bname][row0:row0 + n_out] if bname is not None else None
+        assert dW.is_contiguous() and dW.shape[1] == K, (wname, dW.shape, K)
+        ops.linear_dw(G, n_out, segs, M, ldg=ldg, in_add=in_add, a_op=a_op, a_gamma=a_gamma, a_beta=a_beta, dW=dW, db=db,
+                      want_db=bname is not None, g_offset=g_offset)
+
+    # ------------------------------------------------------------------------------------------------------------
+    # GnBlock (EPD.py:177-195, blocks.py)
+    # ------------------------------------------------------------------------------------------------------------
+    def gn_fwd(self, P, prefix, x, e, pl):
+        N, E = pl.N, pl.E
+        nb = ops.seg_gather_sum(x, pl.n_rowptr, pl.n_col_node, N)
+        e_out, e_new, sv_e = self.mlp3_fwd(P, f"{prefix}.eb_module.net", E, [Seg(nb, pl.es), Seg(nb, pl.er), Seg(e)],
+                                           res=e, want_nores=True)
+        agg = ops.seg_gather_sum(e_new.view(2 * E, 64), pl.n_rowptr, pl.n_col_edge2, N)
+        nbm = ops.seg_gather_sum(agg, pl.n_rowptr, pl.n_col_node, N, scale=pl.inv_deg)
+        x_out, _, sv_n = self.mlp3_fwd(P, f"{prefix}.nb_module.net", N, [Seg(nbm), Seg(x)], res=x)
+        return x_out, e_out, dict(sv_e=sv_e, sv_n=sv_n, prefix=prefix)
+
+    def gn_bwd(self, P, sv, g_x_out, g_e_out, grads, pl):
+        N, E = pl.N, pl.E
+        dev = g_x_out.device
+        prefix = sv["prefix"]
+        W1n = P[f"{prefix}.nb_module.net.0.0.weight"]                      # [128, 64 + 128]
+        W1t = _empty(dev, 192, 128)
+        ops.transpose(W1n, out=W1t[0:128], col0=64, ncols=128)             # rows for x first, then nbm
+        ops.transpose(W1n, out=W1t[128:192], col0=0, ncols=64)
+        g_x_in, g_nbm = _empty(dev, N, 128), _empty(dev, N, 64)
+        self.mlp3_bwd(P, sv["sv_n"], g_x_out, grads, outs=[g_x_in, (g_nbm, 64)], res=[g_x_out, None], W1t=W1t)
+        g_agg = ops.seg_gather_sum(g_nbm, pl.n_rowptr, pl.n_col_node, N, src_scale=pl.inv_deg)
+        gnb2, g_e_in = _empty(dev, E, 256), _empty(dev, E, 128)
+        self.mlp3_bwd(P, sv["sv_e"], g_e_out, grads, outs=[(gnb2, 256), (gnb2.data_ptr() + 512, 256), g_e_in],
+                      res=[None, None, g_e_out], gadd=(g_agg, pl.es, pl.er))
+        g_nb = ops.seg_gather_sum(gnb2.view(2 * E, 128), pl.n_rowptr, pl.n_col_edge2, N)
+        ops.seg_gather_sum(g_nb, pl.n_rowptr, pl.n_col_node, N, out=g_x_in, accumulate=True)
+        return g_x_in, g_e_in
+
+    # ------------------------------------------------------------------------------------------------------------
+    # Transolver block (GraphTransolver.py:48-95,163-169)
+    # ------------------------------------------------------------------------------------------------------------
+    def trans_fwd(self, P, prefix, xg, emb, pl):
+        lib = L.load()
+        st = L.stream_ptr()
+        N, B = pl.N, pl.B
+        dev = xg.device
+        a = f"{prefix}.Attn"
+        fx_in, fx_mid, x_mid = _empty(dev, N, 128), _empty(dev, N, 128), _empty(dev, N, 128)
+        ops.rowtile_chain(N, [Seg(xg)], [LayerSpec(P[f"{a}.in_project_fx.weight"], P[f"{a}.in_project_fx.bias"])],
+                          [fx_mid], in_add=emb, in_save=fx_in)
+        ops.rowtile_chain(N, [Seg(fx_in)], [LayerSpec(P[f"{a}.in_project_x.weight"], P[f"{a}.in_project_x.bias"])],
+                          [x_mid])
+        w = _empty(dev, N, 256)
+        temp = P[f"{a}.graph_temperature"]
+        L.check(lib.gfv_slice_softmax_fwd(x_mid.data_ptr(), P[f"{a}.in_project_slice.weight"].data_ptr(),
+                                          P[f"{a}.in_project_slice.bias"].data_ptr(), temp.data_ptr(), w.data_ptr(), N,
+                                          st), "slice_softmax_fwd")
+        partial = _empty(dev, pl.n_chunks, 256, 17)
+        L.check(lib.gfv_slice_token_partial(w.data_ptr(), fx_mid.data_ptr(), pl.chunk_beg.data_ptr(),
+                                            pl.chunk_end.data_ptr(), pl.n_chunks, partial.data_ptr(), st), "token_partial")
+        token, norm = _empty(dev, B, 8, 32, 16), _empty(dev, B, 8, 32)
+        attn, out_token = _empty(dev, B, 8, 32, 32), _empty(dev, B, 8, 32, 16)
+        L.check(lib.gfv_slice_attention_fwd(partial.data_ptr(), pl.gchunk_ptr.data_ptr(), B, P[f"{a}.to_q.weight"].data_ptr(),
+                                            P[f"{a}.to_k.weight"].data_ptr(), P[f"{a}.to_v.weight"].data_ptr(),
+                                            token.data_ptr(), norm.data_ptr(), attn.data_ptr(), out_token.data_ptr(), st),
+                "slice_attention_fwd")
+        out_x = _empty(dev, N, 128)
+        L.check(lib.gfv_deslice(w.data_ptr(), out_token.data_ptr(), pl.batch.data_ptr(), out_x.data_ptr(), N, 0, st),
+                "deslice")
+        fx1 = _empty(dev, N, 128)
+        ops.rowtile_chain(N, [Seg(out_x)], [LayerSpec(P[f"{a}.to_out.0.weight"], P[f"{a}.to_out.0.bias"])], [fx1],
+                          res=[fx_in])
+        z = _empty(dev, N, 256)
+        ops.rowtile_chain(N, [Seg(fx1)],
+                          [LayerSpec(P[f"{prefix}.mlp.linear_pre.0.weight"], P[f"{prefix}.mlp.linear_pre.0.bias"])],
+                          [(z, 256), (z.data_ptr() + 512, 256)], in_op=L.IN_LN, in_gamma=P[f"{prefix}.ln_2.weight"],
+                          in_beta=P[f"{prefix}.ln_2.bias"])
+        out = _empty(dev, N, 128)
+        ops.rowtile_chain(N, [Seg(z, width=128, ld=256), Seg(z, width=128, ld=256, offset=128)],
+                          [LayerSpec(P[f"{prefix}.mlp.linear_post.weight"], P[f"{prefix}.mlp.linear_post.bias"])], [out],
+                          in_op=L.IN_GELU, res=[fx1])
+        sv = dict(prefix=prefix, fx_in=fx_in, fx_mid=fx_mid, x_mid=x_mid, w=w, token=token, norm=norm, attn=attn,
+                  out_token=out_token, out_x=out_x, fx1=fx1, z=z)
+        return out, sv
+
+    def trans_bwd(self, P, sv, g_out, grads, pl):
+        lib = L.load()
+        st = L.stream_ptr()
+        N, B = pl.N, pl.B
+        dev = g_out.device
+        prefix = sv["prefix"]
+        a = f"{prefix}.Attn"
+        z, fx1, fx_in = sv["z"], sv["fx1"], sv["fx_in"]
+        zsegs = [Seg(z, width=128, ld=256), Seg(z, width=128, ld=256, offset=128)]
+        # linear_post
+        Wpost, Wpre = P[f"{prefix}.mlp.linear_post.weight"], P[f"{prefix}.mlp.linear_pre.0.weight"]
+        g_z = _empty(dev, N, 256)
+        ops.rowtile_chain(N, [Seg(g_out)], [LayerSpec(ops.transpose(Wpost), None, L.OP_MUL_DGELU, aux=z)],
+                          [(g_z, 256), (g_z.data_ptr() + 512, 256)])
+        self._dw(grads, f"{prefix}.mlp.linear_post.weight", f"{prefix}.mlp.linear_post.bias", g_out, 128, zsegs, N, a_op=1)
+        # linear_pre behind LayerNorm ln_2
+        tiles = ops.rowtile_tiles(N)
+        part = _empty(dev, tiles, 2, 128)
+        g_fx1 = _empty(dev, N, 128)
+        gam2, bet2 = P[f"{prefix}.ln_2.weight"], P[f"{prefix}.ln_2.bias"]
+        ops.rowtile_chain(N, [Seg(g_z, width=128, ld=256), Seg(g_z, width=128, ld=256, offset=128)],
+                          [LayerSpec(ops.transpose(Wpre))], [g_fx1], fin_op=L.FIN_LNBWD, fin_gamma=gam2, fin_aux=fx1,
+                          ln_partial=part, res=[g_out])
+        for h in range(2):
+            self._dw(grads, f"{prefix}.mlp.linear_pre.0.weight", f"{prefix}.mlp.linear_pre.0.bias", g_z, 128, [Seg(fx1)], N,
+                     a_op=2, a_gamma=gam2, a_beta=bet2, ldg=256, g_offset=128 * h, row0=128 * h)
+        gb = ops.reduce_partials(part, tiles, 256)
+        self._put(grads, f"{prefix}.ln_2.weight", gb[:128])
+        self._put(grads, f"{prefix}.ln_2.bias", gb[128:])
+        # to_out
+        g_out_x = _empty(dev, N, 128)
+        ops.rowtile_chain(N, [Seg(g_fx1)], [LayerSpec(ops.transpose(P[f"{a}.to_out.0.weight"]))], [g_out_x])
+        self._dw(grads, f"{a}.to_out.0.weight", f"{a}.to_out.0.bias", g_fx1, 128, [Seg(sv["out_x"])], N)
+        # de-slice / attention / slice
+        w, batch = sv["w"], pl.batch
+        gw = _empty(dev, N, 256)
+        L.check(lib.gfv_slice_gw(g_out_x.data_ptr(), sv["out_token"].data_ptr(), None, batch.data_ptr(), gw.data_ptr(), N,
+                                 0, st), "slice_gw")
+        gpartial = _empty(dev, pl.n_chunks, 256, 17)
+        L.check(lib.gfv_slice_token_partial(w.data_ptr(), g_out_x.data_ptr(), pl.chunk_beg.data_ptr(),
+                                            pl.chunk_end.data_ptr(), pl.n_chunks, gpartial.data_ptr(), st), "token_partial")
+        g_raw, g_norm = _empty(dev, B, 8, 32, 16), _empty(dev, B, 8, 32)
+        dwp = _empty(dev, B * 8, 3, 16, 16)
+        L.check(lib.gfv_slice_attention_bwd(gpartial.data_ptr(), pl.gchunk_ptr.data_ptr(), B,
+                                            P[f"{a}.to_q.weight"].data_ptr(), P[f"{a}.to_k.weight"].data_ptr(),
+                                            P[f"{a}.to_v.weight"].data_ptr(), sv["token"].data_ptr(), sv["norm"].data_ptr(),
+                                            sv["attn"].data_ptr(), g_raw.data_ptr(), g_norm.data_ptr(), dwp.data_ptr(), st),
+                "slice_attention_bwd")
+        dqkv = ops.reduce_partials(dwp, B * 8, 768)
+        self._put(grads, f"{a}.to_q.weight", dqkv[0:256])
+        self._put(grads, f"{a}.to_k.weight", dqkv[256:512])
+        self._put(grads, f"{a}.to_v.weight", dqkv[512:768])
+        g_fx_mid = _empty(dev, N, 128)
+        L.check(lib.gfv_deslice(w.data_ptr(), g_raw.data_ptr(), batch.data_ptr(), g_fx_mid.data_ptr(), N, 0, st), "deslice")
+        L.check(lib.gfv_slice_gw(sv["fx_mid"].data_ptr(), g_raw.data_ptr(), g_norm.data_ptr(), batch.data_ptr(),
+                                 gw.data_ptr(), N, 1, st), "slice_gw")
+        nblk = lib.gfv_slice_softmax_bwd_blocks(N)
+        sp = _empty(dev, nblk, 552)
+        g_x_mid = _empty(dev, N, 128)
+        temp = P[f"{a}.graph_temperature"]
+        L.check(lib.gfv_slice_softmax_bwd(sv["x_mid"].data_ptr(), P[f"{a}.in_project_slice.weight"].data_ptr(),
+                                          P[f"{a}.in_project_slice.bias"].data_ptr(), temp.data_ptr(), w.data_ptr(),
+                                          gw.data_ptr(), g_x_mid.data_ptr(), sp.data_ptr(), N, st), "slice_softmax_bwd")
+        ds = ops.reduce_partials(sp, nblk, 552)
+        self._put(grads, f"{a}.in_project_slice.weight", ds[0:512])
+        self._put(grads, f"{a}.in_project_slice.bias", ds[512:544])
+        self._put(grads, f"{a}.graph_temperature", ds[544:552])
+        # projections; fx_in also feeds the to_out residual
+        t1, g_fx_in = _empty(dev, N, 128), _empty(dev, N, 128)
+        ops.rowtile_chain(N, [Seg(g_fx_mid)], [LayerSpec(ops.transpose(P[f"{a}.in_project_fx.weight"]))], [t1], res=[g_fx1])
+        ops.rowtile_chain(N, [Seg(g_x_mid)], [LayerSpec(ops.transpose(P[f"{a}.in_project_x.weight"]))], [g_fx_in], res=[t1])
+        self._dw(grads, f"{a}.in_project_fx.weight", f"{a}.in_project_fx.bias", g_fx_mid, 128, [Seg(fx_in)], N)
+        self._dw(grads, f"{a}.in_project_x.weight", f"{a}.in_project_x.bias", g_x_mid, 128, [Seg(fx_in)], N)
+        return g_fx_in
+
+    # ------------------------------------------------------------------------------------------------------------
+    # finite-volume integrator (FVscheme.py:618-724 -> conserved_form :50-274)
+    # ------------------------------------------------------------------------------------------------------------
+    def fvm_fwd(self, dec, uv_old, pl, want_outputs=True):
+        lib = L.load()
+        st = L.stream_ptr()
+        N, E, C, B = pl.N, pl.E, pl.C, pl.B
+        dev = dec.device
+        phi, grad = _empty(dev, N, 8), _empty(dev, N, 16)
+        L.check(lib.gfv_phi_fwd(dec.data_ptr(), pl.y.data_ptr(), pl.node_type.data_ptr(), uv_old.data_ptr(), phi.data_ptr(),
+                                N, self.mode, st), "phi_fwd")
+        L.check(lib.gfv_wlsq_fwd(phi.data_ptr(), pl.x_rowptr.data_ptr(), pl.x_out.data_ptr(), pl.x_B.data_ptr(),
+                                 pl.An.data_ptr(), pl.rn.data_ptr(), grad.data_ptr(), N, st), "wlsq_fwd")
+        Ff = _empty(dev, E, 16)
+        L.check(lib.gfv_face_fwd(phi.data_ptr(), grad.data_ptr(), pl.es.data_ptr(), pl.er.data_ptr(), pl.pos.data_ptr(),
+                                 pl.fpos.data_ptr(), pl.ftype.data_ptr(), pl.y.data_ptr(), Ff.data_ptr(), E, st), "face_fwd")
+        phic, cres = _empty(dev, C, 8), _empty(dev, C, 4)
+        uvp_cell = _empty(dev, C, 3) if want_outputs else None
+        L.check(lib.gfv_cell_fwd(phi.data_ptr(), grad.data_ptr(), Ff.data_ptr(), pl.pos.data_ptr(), pl.crow.data_ptr(),
+                                 pl.kface.data_ptr(), pl.knode.data_ptr(), pl.kS.data_ptr(), pl.ftype.data_ptr(),
+                                 pl.centroid.data_ptr(), pl.area.data_ptr(), pl.cbatch.data_ptr(), pl.theta.data_ptr(),
+                                 pl.dt.data_ptr(), pl.uvp_dim.data_ptr(), pl.sigma.data_ptr(), phic.data_ptr(),
+                                 cres.data_ptr(), None if uvp_cell is None else uvp_cell.data_ptr(), C, st), "cell_fwd")
+        sums, losses = _empty(dev, B, 4), _empty(dev, B, 4)
+        L.check(lib.gfv_graph_loss(cres.data_ptr(), pl.gcell_ptr.data_ptr(), pl.theta.data_ptr(), pl.sigma.data_ptr(),
+                                   sums.data_ptr(), losses.data_ptr(), B, st), "graph_loss")
+        uvp_node = None
+        if want_outputs:
+            uvp_node = _empty(dev, N, 3)
+            L.check(lib.gfv_cell_to_node(phic.data_ptr(), pl.nrow.data_ptr(), pl.ncell.data_ptr(), pl.pos.data_ptr(),
+                                         pl.centroid.data_ptr(), pl.node_type.data_ptr(), pl.y.data_ptr(),
+                                         pl.batch.data_ptr(), pl.uvp_dim.data_ptr(), pl.sigma.data_ptr(), phi.data_ptr(),
+                                         self.smooth, uvp_node.data_ptr(), N, st), "cell_to_node")
+        sv = dict(dec=dec, Ff=Ff, cres=cres, sums=sums, phi=phi, grad=grad, phic=phic)
+        return losses, uvp_node, uvp_cell, sv
+
+    def fvm_bwd(self, sv, gloss, pl):
+        lib = L.load()
+        st = L.stream_ptr()
+        N, E, C = pl.N, pl.E, pl.C
+        dev = gloss.device
+        gc, gFf = _empty(dev, C, 4), _empty(dev, E, 16)
+        gphi, ggrad = _empty(dev, N, 8), _empty(dev, N, 16)
+        L.check(lib.gfv_fvm_bwd(sv["cres"].data_ptr(), sv["sums"].data_ptr(), gloss.data_ptr(), sv["Ff"].data_ptr(),
+                                pl.cbatch.data_ptr(), pl.theta.data_ptr(), pl.sigma.data_ptr(), pl.dt.data_ptr(),
+                                pl.frow.data_ptr(), pl.fk.data_ptr(), pl.kcell.data_ptr(), pl.kS.data_ptr(),
+                                pl.ftype.data_ptr(), pl.n_rowptr.data_ptr(), pl.n_col_edge2.data_ptr(), pl.nrow.data_ptr(),
+                                pl.ncell.data_ptr(), pl.crow.data_ptr(), pl.pos.data_ptr(), pl.fpos.data_ptr(),
+                                pl.centroid.data_ptr(), pl.area.data_ptr(), gc.data_ptr(), gFf.data_ptr(), gphi.data_ptr(),
+                                ggrad.data_ptr(), N, E, C, st), "fvm_bwd")
+        grhs = _empty(dev, N, 8, 5)
+        L.check(lib.gfv_wlsq_bwd(ggrad.data_ptr(), pl.An.data_ptr(), pl.rn.data_ptr(), pl.xo_rowptr.data_ptr(),
+                                 pl.xo_in.data_ptr(), pl.xo_B.data_ptr(), pl.sumB.data_ptr(), grhs.data_ptr(),
+                                 gphi.data_ptr(), N, st), "wlsq_bwd")
+        gdec = _empty(dev, N, 3)
+        L.check(lib.gfv_phi_bwd(gphi.data_ptr(), sv["dec"].data_ptr(), pl.node_type.data_ptr(), gdec.data_ptr(), N,
+                                self.mode, st), "phi_bwd")
+        return gdec
+
+    # ------------------------------------------------------------------------------------------------------------
+    # input preparation (importer.py:166-178)
+    # ------------------------------------------------------------------------------------------------------------
+    def prep_fwd(self, x, buffers, pl, norm_global, accumulate, want_edge_attr15=True):
+        """In place on x [N,12]; returns (uv_old [N,2], edge_attr16 [E,16], edge_attr15 [E,15] or None)."""
+        lib = L.load()
+        st = L.stream_ptr()
+        N, E, B = pl.N, pl.E, pl.B
+        dev = x.device
+        assert x.is_contiguous() and x.shape[1] == 12
+        stats = _empty(dev, B, 6)
+        L.check(lib.gfv_graph_norm_stats(x.data_ptr(), 12, pl.gnode_ptr.data_ptr(), B, stats.data_ptr(), st), "norm_stats")
+        mean_std = _empty(dev, 18)
+        if norm_global:
+            nb = lib.gfv_normalizer_blocks(N)
+            pws = _empty(dev, nb, 18)
+            L.check(lib.gfv_normalizer_update(x.data_ptr(), 12, N, 1 if accumulate else 0, buffers["acc_count"].data_ptr(),
+                                              buffers["num_accumulations"].data_ptr(), buffers["acc_sum"].data_ptr(),
+                                              buffers["acc_sum_squared"].data_ptr(), pws.data_ptr(), mean_std.data_ptr(),
+                                              st), "normalizer_update")
+        uv_old = _empty(dev, N, 2)
+        L.check(lib.gfv_node_prep(x.data_ptr(), 12, pl.batch.data_ptr(), stats.data_ptr(), pl.uvp_dim.data_ptr(),
+                                  mean_std.data_ptr(), 1 if norm_global else 0, uv_old.data_ptr(), N, st), "node_prep")
+        ea16 = _empty(dev, E, 16)
+        ea15 = _empty(dev, E, 15) if want_edge_attr15 else None
+        L.check(lib.gfv_edge_attr(x.data_ptr(), 12, pl.pos.data_ptr(), pl.es.data_ptr(), pl.er.data_ptr(), ea16.data_ptr(),
+                                  None if ea15 is None else ea15.data_ptr(), E, st), "edge_attr")
+        return uv_old, ea16, ea15
+
+    # ------------------------------------------------------------------------------------------------------------
+    # simulator (TransFVGN_v2.py:54-105 / EPD.py:222-270)
+    # ------------------------------------------------------------------------------------------------------------
+    def simulator_fwd(self, P, x, ea16, pl, prefix="simulator"):
+        N, E = pl.N, pl.E
+        xn, _, sv_nenc = self.mlp3_fwd(P, f"{prefix}.encoder.nb_encoder", N, [Seg(x, width=12, ld=12)])
+        en, _, sv_eenc = self.mlp3_fwd(P, f"{prefix}.encoder.eb_encoder", E, [Seg(ea16, width=15, ld=16)])
+        procs = []
+        if self.net == "EPD":
+            blocks = []
+            for ig in range(self.mp):
+                xn, en, sv = self.gn_fwd(P, f"{prefix}.GN_block_list.{ig}", xn, en, pl)
+                blocks.append(sv)
+            procs.append(dict(blocks=blocks, trans=None))
+        else:
+            for ip in range(self.n_proc):
+                emb = xn
+                blocks = []
+                for ig in range(self.mp):
+                    xn, en, sv = self.gn_fwd(P, f"{prefix}.processpr_list.{ip}.GN_block_list.{ig}", xn, en, pl)
+                    blocks.append(sv)
+                xn, svt = self.trans_fwd(P, f"{prefix}.processpr_list.{ip}.TransBlock", xn, emb, pl)
+                procs.append(dict(blocks=blocks, trans=svt))
+        dec, _, sv_dec = self.mlp3_fwd(P, f"{prefix}.decoder.node_decode_module", N, [Seg(xn)], ln=False)
+        return dec, dict(sv_nenc=sv_nenc, sv_eenc=sv_eenc, procs=procs, sv_dec=sv_dec)
+
+    def simulator_bwd(self, P, sv, g_dec, grads, pl):
+        N, E = pl.N, pl.E
+        dev = g_dec.device
+        g_x = _empty(dev, N, 128)
+        self.mlp3_bwd(P, sv["sv_dec"], g_dec, grads, outs=[g_x])
+        g_e = None
+        for proc in reversed(sv["procs"]):
+            g_emb = None
+            if proc["trans"] is not None:
+                g_x = self.trans_bwd(P, proc["trans"], g_x, grads, pl)   # grad wrt (x_GN + emb)
+                g_emb = g_x
+            for blk in reversed(proc["blocks"]):
+                if g_e is None:
+                    g_e = torch.zeros((E, 128), dtype=torch.float32, device=dev)  # last block's edges feed nothing
+                g_x, g_e = self.gn_bwd(P, blk, g_x, g_e, grads, pl)
+            if g_emb is not None:
+                g_x = g_x + g_emb  # the processor input also entered the Transolver residual (TransFVGN_v2.py:46-49)
+        self.mlp3_bwd(P, sv["sv_nenc"], g_x, grads)
+        self.mlp3_bwd(P, sv["sv_eenc"], g_e, grads)
+
+    # ------------------------------------------------------------------------------------------------------------
+    # whole model (importer.py:156-240)
+    # ------------------------------------------------------------------------------------------------------------
+    def forward(self, P, buffers, x, pl, *, norm_global=True, accumulate=True, want_outputs=True, want_edge_attr15=True):
+        uv_old, ea16, ea15 = self.prep_fwd(x, buffers, pl, norm_global, accumulate, want_edge_attr15)
+        dec, sv_sim = self.simulator_fwd(P, x, ea16, pl)
+        losses, uvp_node, uvp_cell, sv_fvm = self.fvm_fwd(dec, uv_old, pl, want_outputs)
+        return losses, uvp_node, uvp_cell, ea15, dict(sim=sv_sim, fvm=sv_fvm)
+
+    def backward(self, P, ctx, gloss, grads, pl):
+        """gloss [B,4] = dL/d(cont, mom_x, mom_y, press); fills `grads` (name -> preallocated tensor)."""
+        g_dec = self.fvm_bwd(ctx["fvm"], gloss, pl)
+        self.simulator_bwd(P, ctx["sim"], g_dec, grads, pl)
+        return grads

@@ -40,12 +40,14 @@ def gather_pair(a, s, r, base=None, out=None):
     return out
 
 
-def transpose(w, out=None):
+def transpose(w, out=None, col0=0, ncols=None):
+    """out [ncols, rows] = w[:, col0:col0+ncols]^T   (w contiguous [rows, cols])."""
     lib = L.load()
     rows, cols = w.shape
+    ncols = cols - col0 if ncols is None else ncols
     if out is None:
-        out = torch.empty((cols, rows), dtype=torch.float32, device=w.device)
-    rc = lib.gfv_transpose(_p(L.f32c(w)), _p(out), rows, cols, L.stream_ptr())
+        out = torch.empty((ncols, rows), dtype=torch.float32, device=w.device)
+    rc = lib.gfv_transpose(L.f32c(w).data_ptr() + 4 * col0, cols, _p(out), rows, ncols, L.stream_ptr())
     L.check(rc, "gfv_transpose")
     return out
 

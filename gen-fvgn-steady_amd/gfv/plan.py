@@ -1,0 +1,197 @@
+"""Per-batch mesh plan: CSR tables, permuted WLSQ moments and narrowed (int32) indices on the device.
+
+Built ONCE per batch of graphs with torch tensor ops on the batch's own device (host-side plumbing, not the per-step
+hot path) and cached on ``graph_node._gfv_plan``.  Everything the HIP kernels index with lives here, so the hot
+path has no host synchronisation (the reference syncs on ``mask.any()``, ``batch.max()+1``: FVscheme.py:148,162,
+GraphTransolver.py:51).
+
+Index conventions follow SURVEY.md 8(a-0): two-way node adjacency = "all forward edges, then all reverse edges"
+(blocks.py:25-31), directed WLSQ stencil = [fx, fx.flip(0), support_edge] (FVgrad.py:264-271), reverse-direction
+moment vectors with the odd-order terms negated (FVgrad.py:299-312).  Stable sorts keep the reference's summation
+order inside every segment.
+"""
+from __future__ import annotations
+
+import torch
+
+SLICE_CHUNK = 128  # nodes per partial-token chunk
+
+
+def _csr(index, n_rows):
+    order = torch.argsort(index, stable=True)
+    counts = torch.bincount(index, minlength=n_rows)
+    rowptr = torch.zeros(n_rows + 1, dtype=torch.int64, device=index.device)
+    rowptr[1:] = torch.cumsum(counts, 0)
+    return rowptr.to(torch.int32), order
+
+
+def _ptr_from_batch(batch, B):
+    counts = torch.bincount(batch, minlength=B)
+    ptr = torch.zeros(B + 1, dtype=torch.int64, device=batch.device)
+    ptr[1:] = torch.cumsum(counts, 0)
+    return ptr
+
+
+class MeshPlan:
+    pass
+
+
+def _gnn_part(p, edge_index, N):
+    """Two-way node adjacency in CSR order of the receiving node (blocks.py:24-31,82-90)."""
+    dev = edge_index.device
+    E = edge_index.shape[1]
+    i32 = lambda t: t.to(torch.int32).contiguous()
+    p.N, p.E, p.device = N, E, dev
+    s, r = edge_index[0], edge_index[1]
+    p.es, p.er = i32(s), i32(r)
+    indeg = torch.cat((s, r))
+    other = torch.cat((r, s))
+    ar = torch.arange(E, device=dev)
+    eid2 = torch.cat((2 * ar, 2 * ar + 1))
+    p.n_rowptr, order = _csr(indeg, N)
+    p.n_col_node = i32(other[order])
+    p.n_col_edge2 = i32(eid2[order])
+    deg = torch.bincount(indeg, minlength=N).to(torch.float32)
+    p.inv_deg = (1.0 / deg.clamp(min=1.0)).contiguous()
+    return p
+
+
+def _batch_part(p, nb, B=None):
+    """Per-graph node ranges and the node chunks of the slice-token reduction (GraphTransolver.py:64-73)."""
+    dev = nb.device
+    if B is None:
+        B = int(nb.max().item()) + 1 if nb.numel() else 0
+    p.B = B
+    p.N = int(nb.shape[0])
+    p.batch = nb.to(torch.int32).contiguous()
+    gnode_ptr = _ptr_from_batch(nb, B)
+    p.gnode_ptr = gnode_ptr.to(torch.int32).contiguous()
+    gp = gnode_ptr.tolist()
+    cb, ce, gcp = [], [], [0]
+    for b in range(B):
+        for st in range(gp[b], gp[b + 1], SLICE_CHUNK):
+            cb.append(st)
+            ce.append(min(st + SLICE_CHUNK, gp[b + 1]))
+        gcp.append(len(cb))
+    p.chunk_beg = torch.tensor(cb, dtype=torch.int32, device=dev)
+    p.chunk_end = torch.tensor(ce, dtype=torch.int32, device=dev)
+    p.gchunk_ptr = torch.tensor(gcp, dtype=torch.int32, device=dev)
+    p.n_chunks = len(cb)
+    return p
+
+
+def build_gnn_plan(graph_node):
+    """GNN-only plan for the stand-alone block operators, cached on the graph object."""
+    key = (graph_node.edge_index.data_ptr(), int(graph_node.x.shape[0]))
+    cached = getattr(graph_node, "_gfv_gnn_plan", None)
+    if cached is not None and cached[0] == key:
+        return cached[1]
+    full = getattr(graph_node, "_gfv_plan", None)
+    p = full[1] if full is not None else _gnn_part(MeshPlan(), graph_node.edge_index, int(graph_node.x.shape[0]))
+    try:
+        graph_node._gfv_gnn_plan = (key, p)
+    except AttributeError:
+        pass
+    return p
+
+
+_batch_plan_cache = {}
+
+
+def build_batch_plan(batch, plan=None):
+    key = (batch.data_ptr(), int(batch.shape[0]), str(batch.device))
+    if plan is None:
+        hit = _batch_plan_cache.get(key)
+        if hit is not None:
+            return hit
+        plan = MeshPlan()
+    if not hasattr(plan, "chunk_beg"):
+        _batch_part(plan, batch.reshape(-1))
+    if len(_batch_plan_cache) > 64:
+        _batch_plan_cache.clear()
+    _batch_plan_cache[key] = plan
+    return plan
+
+
+def build_plan(graph_node, graph_node_x, graph_edge, graph_cell, graph_Index):
+    p = MeshPlan()
+    dev = graph_node.x.device
+    i32 = lambda t: t.to(torch.int32).contiguous()
+    f32 = lambda t: t.to(torch.float32).contiguous()
+    N = graph_node.x.shape[0]
+    E = graph_node.edge_index.shape[1]
+    C = graph_cell.pos.shape[0]
+    B = int(graph_Index.theta_PDE.shape[0])
+    p.N, p.E, p.C, p.B, p.device = N, E, C, B, dev
+    _gnn_part(p, graph_node.edge_index, N)
+    _batch_part(p, graph_node.batch.reshape(-1), B)
+
+    # ---- node data ---------------------------------------------------------------------------------------------
+    p.node_type = i32(graph_node.node_type.reshape(-1))
+    p.y = f32(graph_node.y[:, 0:2])
+    p.pos = f32(graph_node.pos)
+
+    # ---- WLSQ stencil --------------------------------------------------------------------------------------------
+    fx = graph_node_x.face_node_x
+    sup = graph_node_x.support_edge
+    out_idx = torch.cat((fx[0], fx[1], sup[0]))
+    in_idx = torch.cat((fx[1], fx[0], sup[1]))
+    B1 = graph_node_x.single_B_node_to_node.reshape(-1, 5)
+    Brev = B1.clone()
+    Brev[:, 0:2] *= -1
+    Bfull = torch.cat((B1, Brev, graph_node_x.extra_B_node_to_node.reshape(-1, 5)), 0).to(torch.float32)
+    p.x_rowptr, o_in = _csr(in_idx, N)
+    p.x_out = i32(out_idx[o_in])
+    p.x_B = Bfull[o_in].contiguous()
+    p.xo_rowptr, o_out = _csr(out_idx, N)
+    p.xo_in = i32(in_idx[o_out])
+    p.xo_B = Bfull[o_out].contiguous()
+    p.sumB = torch.zeros((N, 5), dtype=torch.float32, device=dev).index_add_(0, in_idx, Bfull).contiguous()
+    A = graph_node_x.A_node_to_node.to(torch.float32)
+    row_norms = torch.norm(A, p=2, dim=2, keepdim=True)          # FVgrad.py:335
+    p.rn = (row_norms + 1e-8).reshape(N, 5).contiguous()
+    p.An = (A / (row_norms + 1e-8)).reshape(N, 25).contiguous()  # FVgrad.py:336
+    p.S = int(in_idx.shape[0])
+
+    # ---- faces -------------------------------------------------------------------------------------------------
+    p.ftype = i32(graph_edge.face_type.reshape(-1))
+    p.fpos = f32(graph_edge.pos)
+    face_area = graph_edge.face_area.to(torch.float32).reshape(-1, 1)
+
+    # ---- cells: (cell, face, node) incidences -----------------------------------------------------------------
+    cells_node, cells_face, cells_index = graph_node.face, graph_edge.face, graph_cell.face
+    Svec = graph_cell.cells_face_unv.to(torch.float32).reshape(-1, 2) * face_area[cells_face]  # FVscheme.py:89
+    p.crow, oc = _csr(cells_index, C)
+    kface, knode, kcell = cells_face[oc], cells_node[oc], cells_index[oc]
+    p.kface, p.knode, p.kcell = i32(kface), i32(knode), i32(kcell)
+    p.kS = Svec[oc].contiguous()
+    p.frow, of = _csr(kface, E)
+    p.fk = i32(of)
+    p.nrow, on = _csr(knode, N)
+    p.ncell = i32(kcell[on])
+    p.Sg = int(cells_index.shape[0])
+    p.centroid = f32(graph_cell.pos)
+    p.area = f32(graph_cell.cells_area.reshape(-1))
+    cbatch = graph_cell.batch
+    p.cbatch = i32(cbatch)
+    p.gcell_ptr = i32(_ptr_from_batch(cbatch, B))
+
+    # ---- per-graph scalars ----------------------------------------------------------------------------------------
+    p.theta = f32(graph_Index.theta_PDE)
+    p.sigma = f32(graph_Index.sigma)
+    p.uvp_dim = f32(graph_Index.uvp_dim)
+    p.dt = f32(graph_Index.dt_graph.reshape(-1))
+    return p
+
+
+def get_plan(graphs):
+    """Plan cached on graph_node (keyed by the identity of its index tensors)."""
+    graph_node = graphs[0]
+    key = (graph_node.edge_index.data_ptr(), graph_node.face.data_ptr(), graphs[1].face_node_x.data_ptr(),
+           graph_node.x.shape[0], str(graph_node.x.device))
+    cached = getattr(graph_node, "_gfv_plan", None)
+    if cached is not None and cached[0] == key:
+        return cached[1]
+    plan = build_plan(*graphs)
+    graph_node._gfv_plan = (key, plan)
+    return plan

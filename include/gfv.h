@@ -120,8 +120,93 @@ int gfv_linear_dw_ex(const float* G, int32_t ldg, int32_t n_out, const gfv_seg_t
 int gfv_reduce_partials(const float* partial, int32_t n_chunks, int32_t n, float* out, int32_t accumulate,
                         void* stream);
 
-/* out = in^T for a [rows, cols] fp32 matrix (weights for the dX chain). */
-int gfv_transpose(const float* in, float* out, int32_t rows, int32_t cols, void* stream);
+/* out [cols, rows] = in^T for a [rows, cols] fp32 matrix with row stride ld_in (weights for the dX chain). */
+int gfv_transpose(const float* in, int32_t ld_in, float* out, int32_t rows, int32_t cols, void* stream);
+
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Transolver physics attention (H=8 heads, D=16, G=32 slices).  Replaces
+ * FVMmodel/Models/GraphTransolver/GraphTransolver.py:61-95 (softmax slice weights, scatter_add slice tokens over
+ * `batch`, 32x32 attention per (graph, head), de-slice) without materialising [N,8,32,16].
+ * Layouts: xmid/fx/out_x [N,128] = [N,8,16]; w, gw [N,8,32]; tokens [B,8,32,16]; norm [B,8,32]; attn [B,8,32,32].
+ * Node chunks: contiguous node ranges inside one graph (chunk_beg/chunk_end [n_chunks]; gchunk_ptr [B+1]).
+ * ---------------------------------------------------------------------------------------------------------- */
+int gfv_slice_softmax_fwd(const float* xmid, const float* Ws, const float* bs, const float* temp, float* w, int32_t N,
+                          void* stream);
+int gfv_slice_softmax_bwd_blocks(int32_t N); /* rows of `partial` ([blocks][552] = dWs 512 | dbs 32 | dT 8) */
+int gfv_slice_softmax_bwd(const float* xmid, const float* Ws, const float* bs, const float* temp, const float* w,
+                          const float* gw, float* gxmid, float* partial, int32_t N, void* stream);
+/* partial[chunk][h*32+g][0:16] = sum_n w[n,h,g] a[n,h,:], [16] = sum_n w[n,h,g] */
+int gfv_slice_token_partial(const float* w, const float* a, const int32_t* chunk_beg, const int32_t* chunk_end,
+                            int32_t n_chunks, float* partial, void* stream);
+int gfv_slice_attention_fwd(const float* partial, const int32_t* gchunk_ptr, int32_t B, const float* Wq, const float* Wk,
+                            const float* Wv, float* token, float* norm, float* attn, float* out_token, void* stream);
+/* dW_partial [B*8][3][16][16] (q,k,v), reduce with gfv_reduce_partials */
+int gfv_slice_attention_bwd(const float* gpartial, const int32_t* gchunk_ptr, int32_t B, const float* Wq, const float* Wk,
+                            const float* Wv, const float* token, const float* norm, const float* attn, float* g_raw,
+                            float* g_norm, float* dW_partial, void* stream);
+/* out[n,h,:] (+)= sum_g w[n,h,g] T[batch[n],h,g,:] */
+int gfv_deslice(const float* w, const float* T, const int32_t* batch, float* out, int32_t N, int32_t accumulate,
+                void* stream);
+/* gw[n,h,g] (+)= sum_c a[n,h,c] T[batch[n],h,g,c] + add[batch[n],h,g] */
+int gfv_slice_gw(const float* a, const float* T, const float* add, const int32_t* batch, float* gw, int32_t N,
+                 int32_t accumulate, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Finite-volume discretisation (conserved form).  Replaces FVMmodel/FVdiscretization/FVscheme.py:618-724,50-274,
+ * FVgrad.py:235-367 (precomputed-moments branch), FVInterpolation.py:36-185,218-265 and the clamp / Dirichlet /
+ * integrator mixing of FVMmodel/importer.py:187-201,223-231.  Padded layouts: phi [N,8] = (u,v,p,uh,vh,uo,vo,0),
+ * grad [N,16] = d(phi_c)/d(x,y) at 2c+a, Ff [E,16] = (phi_f[0:5], grad_f[c][a] at 5+2c+a), cres [C,4] =
+ * (div, Rx, Ry, sum |lp|^2), losses [B,4] = (cont, mom_x, mom_y, press).  mode: 0 explicit, 1 implicit, 2 imex.
+ * ---------------------------------------------------------------------------------------------------------- */
+int gfv_phi_fwd(const float* dec, const float* y, const int32_t* node_type, const float* uv_old, float* phi, int32_t N,
+                int32_t mode, void* stream);
+int gfv_phi_bwd(const float* gphi, const float* dec, const int32_t* node_type, float* gdec, int32_t N, int32_t mode,
+                void* stream);
+/* rowptr/outn/Bp: directed stencil in CSR order of the receiving node, Bp [S,5] permuted moment vectors;
+ * An [N,25] row-normalised moment matrix, rn [N,5] = row norm + 1e-8 */
+int gfv_wlsq_fwd(const float* phi, const int32_t* rowptr, const int32_t* outn, const float* Bp, const float* An,
+                 const float* rn, float* grad, int32_t N, void* stream);
+/* adjoint; rowptr_o/inn/Bo: the same stencil in CSR order of the SENDING node, sumB [N,5]; grhs_ws [N,8,5];
+ * adds into gphi */
+int gfv_wlsq_bwd(const float* ggrad, const float* An, const float* rn, const int32_t* rowptr_o, const int32_t* inn,
+                 const float* Bo, const float* sumB, float* grhs_ws, float* gphi, int32_t N, void* stream);
+int gfv_face_fwd(const float* phi, const float* grad, const int32_t* es, const int32_t* er, const float* pos,
+                 const float* fpos, const int32_t* ftype, const float* y, float* Ff, int32_t E, void* stream);
+int gfv_cell_fwd(const float* phi, const float* grad, const float* Ff, const float* pos, const int32_t* crow,
+                 const int32_t* kface, const int32_t* knode, const float* kS, const int32_t* ftype, const float* centroid,
+                 const float* area, const int32_t* cbatch, const float* theta, const float* dt, const float* uvp_dim,
+                 const float* sigma, float* phic, float* cres, float* uvp_cell, int32_t C, void* stream);
+int gfv_graph_loss(const float* cres, const int32_t* gcell_ptr, const float* theta, const float* sigma, float* sums,
+                   float* losses, int32_t B, void* stream);
+int gfv_cell_to_node(const float* phic, const int32_t* nrow, const int32_t* ncell, const float* pos, const float* centroid,
+                     const int32_t* node_type, const float* y, const int32_t* nbatch, const float* uvp_dim,
+                     const float* sigma, const float* phi, int32_t smooth, float* out, int32_t N, void* stream);
+/* adjoint of face_fwd + cell_fwd + graph_loss: gloss [B,4] -> gphi [N,8], ggrad [N,16] (overwritten) */
+int gfv_fvm_bwd(const float* cres, const float* sums, const float* gloss, const float* Ff, const int32_t* cbatch,
+                const float* theta, const float* sigma, const float* dt, const int32_t* frow, const int32_t* fk,
+                const int32_t* kcell, const float* kS, const int32_t* ftype, const int32_t* nfrow, const int32_t* nfcol2,
+                const int32_t* nrow, const int32_t* ncell, const int32_t* crow, const float* pos, const float* fpos,
+                const float* centroid, const float* area, float* gc_ws, float* gFf_ws, float* gphi, float* ggrad,
+                int32_t N, int32_t E, int32_t C, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Input normalisation / edge features / optimiser.  Replace FVMmodel/importer.py:54-93,114-130,166-178,
+ * utils/normalization.py:32-85, torch.optim.Adam (pre_train_Adam.py:79,191) and the loss of
+ * pre_train_Adam.py:177-184.
+ * ---------------------------------------------------------------------------------------------------------- */
+int gfv_graph_norm_stats(const float* x, int32_t ldx, const int32_t* gnode_ptr, int32_t B, float* stats, void* stream);
+int gfv_normalizer_blocks(int32_t N);
+int gfv_normalizer_update(const float* x, int32_t ldx, int32_t N, int32_t accumulate, float* acc_count, float* num_acc,
+                          float* acc_sum, float* acc_sq, float* partial_ws, float* mean_std, void* stream);
+int gfv_node_prep(float* x, int32_t ldx, const int32_t* batch, const float* stats, const float* uvp_dim,
+                  const float* mean_std, int32_t norm_global, float* uv_old, int32_t N, void* stream);
+int gfv_edge_attr(const float* x, int32_t ldx, const float* pos, const int32_t* es, const int32_t* er, float* out16,
+                  float* out15, int32_t E, void* stream);
+int gfv_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float* step, float lr, float beta1, float beta2,
+                  float eps, float grad_scale, void* stream);
+int gfv_train_loss(const float* losses, int32_t B, float w_cont, float w_mom, float w_press, float* loss, float* gloss,
+                   void* stream);
 
 #ifdef __cplusplus
 }
