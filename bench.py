@@ -1,0 +1,209 @@
+#!/usr/bin/env python3
+"""Headline benchmark: training iterations / second of the Gen-FVGN hot path (forward + loss + backward + Adam,
+batch resident on the device) on the synthetic ~50k-cell cylinder mesh (BASELINE.json metric / configs[2]).
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One process per GPU; every rank owns `--meshes-per-gpu` meshes (weak scaling, graphs sharded by rank) and
+the flat fp32 gradient (4.7 MB) is all-reduced with RCCL before the fused Adam step.  Rank 0 prints ONE JSON line.
+`roofline` is measured live with HIP events around every launch of the dominant kernel (an instrumented pass of
+the same step); `cpu_baseline` times the oracle (oracle/fvgn_oracle.py, the CPU restatement pinned to the reference)
+on the host cores for a bounded number of steps of the same workload.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "gen-fvgn-steady_amd"))
+
+import numpy as np
+import torch
+
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, exact fp32
+PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec
+
+
+def build_workload(cells, meshes, rank, device):
+    from gfv import meshgen
+    from gfv.graph import build_batch
+    nx, ny = meshgen.cylinder_grid_for_cells(cells)
+    ms, fs = [], []
+    for i in range(meshes):
+        raw = meshgen.raw_tri_channel_cylinder(nx=nx, ny=ny, jitter=0.2, seed=1234 + rank * meshes + i)
+        m = meshgen.finish_mesh(raw)
+        ms.append(m)
+        fs.append(meshgen.random_fields(m, seed=1 + rank * meshes + i))
+    graphs = build_batch(ms, fs, device="cpu")
+    sizes = dict(N=int(graphs[0].x.shape[0]), E=int(graphs[0].edge_index.shape[1]), C=int(graphs[3].pos.shape[0]),
+                 Sigma=int(graphs[0].face.shape[0]), Ex=int(graphs[1].face_node_x.shape[1]), B=meshes)
+    return graphs, sizes
+
+
+def algorithmic_step_flops(sz, mp=3):
+    # forward FLOPs per node / per edge (H=128, TransFVGN_v2), step = 3x forward
+    return 3.0 * (1330944.0 * sz["N"] + 1052416.0 * sz["E"])
+
+
+def cpu_baseline(graphs_cpu, budget_s, max_steps=3):
+    from oracle import fvgn_oracle as O
+    torch.manual_seed(0)
+    P = O.init_parameters(0, perturb=False)
+    buffers = O.new_normalizer_buffers()
+    state = {}
+    x0 = graphs_cpu[0].x.clone()
+    times = []
+    t_begin = time.time()
+    for i in range(max_steps + 1):
+        graphs_cpu[0].x = x0.clone()
+        t0 = time.time()
+        O.train_step(P, buffers, graphs_cpu, state)
+        dt = time.time() - t0
+        if i > 0:
+            times.append(dt)
+        if time.time() - t_begin > budget_s and times:
+            break
+    return float(np.median(times)), len(times)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--cells", type=int, default=50000)
+    ap.add_argument("--meshes-per-gpu", type=int, default=1)
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
+    ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU work for the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--profile-steps", type=int, default=3)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("launch with torch.distributed.run for --gpus > 1 (one process per GPU)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    from gfv import lib as L
+    from gfv.params import default_params
+    from gfv.trainer import TrainStep
+    from FVMmodel.importer import NNmodel
+    lib = L.load()
+
+    graphs_cpu, sz = build_workload(args.cells, args.meshes_per_gpu, rank, device)
+    graphs = tuple(g.clone().to(device) for g in graphs_cpu)
+    torch.manual_seed(0)  # identical initial weights on every rank (data parallel replicas)
+    model = NNmodel(default_params()).to(device)
+    ts = TrainStep(model, graphs, world_size=world, use_graph=not args.no_graph)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        ts.step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ts.step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    final_loss = float(ts.loss.item())
+
+    # ---- roofline leg: same step, eager, HIP events around every launch of the main kernels -----------------
+    roof, roof_all = None, []
+    if rank == 0:
+        ts_use_graph = ts.use_graph
+        ts.use_graph = False
+        lib.gfv_profile_reset()
+        lib.gfv_profile_enable(1)
+        for _ in range(max(1, args.profile_steps)):
+            ts.step()
+        torch.cuda.synchronize()
+        lib.gfv_profile_enable(0)
+        out = (ctypes.c_double * 4)()
+        spec = {1: ("rowtile_chain_kernel", "mfma"), 2: ("linear_dw_kernel", "mfma"), 3: ("seg_gather_sum_vec", "hbm")}
+        for kind, (kname, bound) in spec.items():
+            lib.gfv_profile_collect(kind, out)
+            n, ms, fl, by = out[0], out[1], out[2], out[3]
+            if n == 0:
+                continue
+            if bound == "mfma":
+                ach, peak, unit = fl / (ms * 1e-3) / 1e12, PEAK_F32_MFMA_TFLOPS, "TFLOP/s"
+            else:
+                ach, peak, unit = by / (ms * 1e-3) / 1e9, PEAK_HBM_GBS, "GB/s"
+            roof_all.append({"kernel": kname, "bound": bound, "achieved": round(ach, 3), "peak": peak, "unit": unit,
+                             "frac": round(ach / peak, 4), "traffic": None, "launches_per_step": n / args.profile_steps,
+                             "avg_launch_us": round(1e3 * ms / n, 2), "ms_per_step": round(ms / args.profile_steps, 4)})
+        lib.gfv_profile_reset()
+        ts.use_graph = ts_use_graph
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            traffic = json.load(open(pmc))
+            for r in roof_all:
+                r["traffic"] = traffic.get(r["kernel"])
+        if roof_all:
+            roof = max(roof_all, key=lambda r: r["ms_per_step"])
+
+    if world > 1:
+        dist.barrier()
+
+    cpu = None
+    if rank == 0 and world == 1 and args.cpu_budget > 0:
+        ncores = os.cpu_count() or 1
+        torch.set_num_threads(ncores)
+        sec, nst = cpu_baseline(graphs_cpu, args.cpu_budget)
+        cpu = {"value": round(args.meshes_per_gpu / sec, 5), "unit": "train-iters/s", "cores": torch.get_num_threads(),
+               "kind": "port", "sample": f"{nst} timed steps (after 1 warm-up) of the same {sz['C']}-cell mesh batch, "
+               f"oracle/fvgn_oracle.py fp32 eager PyTorch, median {sec:.3f} s/step"}
+
+    if rank == 0:
+        total_meshes = world * args.meshes_per_gpu
+        value = total_meshes * args.steps / elapsed
+        line = {
+            "metric": "training iters/sec, 50k-cell cylinder mesh (fwd + loss + bwd + Adam, batch resident in HBM)",
+            "value": round(value, 3), "unit": "mesh-train-iters/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "cylinder_flow tri mesh, TransFVGN_v2 (hidden 128, mp 3), 2nd-order WLSQ, conserved form",
+                       "cells": sz["C"], "nodes": sz["N"], "faces": sz["E"], "meshes_per_gpu": args.meshes_per_gpu,
+                       "global_batch": total_meshes, "parallelism": f"dp{world}", "hip_graph": not args.no_graph,
+                       "final_loss": round(final_loss, 6)},
+            "roofline": ({k: roof[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")} | {"kernel": roof["kernel"]})
+            if roof else None,
+            "roofline_kernels": roof_all,
+            "algorithmic_step_tflops": round(algorithmic_step_flops(sz) / 1e12, 4),
+            "step_mfma_frac": round(algorithmic_step_flops(sz) * total_meshes / world / (elapsed / args.steps) / 1e12
+                                    / PEAK_F32_MFMA_TFLOPS, 4),
+            "cpu_baseline": cpu,
+        }
+        if cpu:
+            line["gpu_over_cpu"] = round(value / cpu["value"], 1)
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -8,6 +8,7 @@
 // accumulator tiles each).  Slab partials go to a workspace and are summed by gfv_reduce_partials in a fixed
 // order (no float atomics -> deterministic).
 #include "gfv_common.h"
+#include "gfv_prof.h"
 #include "../../include/gfv.h"
 
 namespace {
@@ -194,7 +195,10 @@ extern "C" int gfv_linear_dw_ex(const float* G, int32_t ldg, int32_t n_out, cons
   if (chunks == 0) return GFV_OK;
   a.ws_dw = workspace;
   a.ws_db = db ? workspace + (size_t)chunks * n_out * K : nullptr;
+  void* tok = gfv_prof_begin(GFV_K_DW, 2.0 * M * (double)n_out * K,
+                             4.0 * M * ((double)n_out + K) + 4.0 * (double)chunks * n_out * K, (hipStream_t)stream);
   hipLaunchKernelGGL(linear_dw_kernel, dim3(chunks, nseg), dim3(256), 0, (hipStream_t)stream, a);
+  gfv_prof_end(tok, (hipStream_t)stream);
   GFV_CHECK_LAUNCH();
   int rc = gfv_reduce_partials(a.ws_dw, chunks, n_out * K, dW, accumulate, stream);
   if (rc) return rc;

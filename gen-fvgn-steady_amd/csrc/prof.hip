@@ -1,0 +1,54 @@
+// Optional per-launch timing with HIP events, on the stream the kernels are launched on (bench.py roofline leg).
+// Disabled by default: zero overhead on the product path.  Not thread safe (one stream, one host thread).
+#include "gfv_common.h"
+#include "gfv_prof.h"
+#include <vector>
+
+namespace {
+struct Rec { int kind; double flops, bytes; hipEvent_t a, b; };
+bool g_on = false;
+std::vector<Rec> g_recs;
+}  // namespace
+
+bool gfv_prof_enabled() { return g_on; }
+
+void* gfv_prof_begin(int kind, double flops, double bytes, hipStream_t st) {
+  if (!g_on) return nullptr;
+  Rec r{kind, flops, bytes, nullptr, nullptr};
+  hipEventCreate(&r.a);
+  hipEventCreate(&r.b);
+  hipEventRecord(r.a, st);
+  g_recs.push_back(r);
+  return (void*)(g_recs.size());
+}
+
+void gfv_prof_end(void* tok, hipStream_t st) {
+  if (!tok) return;
+  Rec& r = g_recs[(size_t)tok - 1];
+  hipEventRecord(r.b, st);
+}
+
+extern "C" int gfv_profile_enable(int on) {
+  g_on = on != 0;
+  return 0;
+}
+
+// Sums over all recorded launches of `kind`; synchronises on the recorded events.  out = {count, ms, flops, bytes}
+extern "C" int gfv_profile_collect(int kind, double* out) {
+  double n = 0, ms = 0, fl = 0, by = 0;
+  for (auto& r : g_recs) {
+    if (r.kind != kind) continue;
+    float t = 0.f;
+    hipEventSynchronize(r.b);
+    hipEventElapsedTime(&t, r.a, r.b);
+    n += 1; ms += t; fl += r.flops; by += r.bytes;
+  }
+  out[0] = n; out[1] = ms; out[2] = fl; out[3] = by;
+  return 0;
+}
+
+extern "C" int gfv_profile_reset(void) {
+  for (auto& r : g_recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
+  g_recs.clear();
+  return 0;
+}

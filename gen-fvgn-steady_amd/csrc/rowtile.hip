@@ -11,6 +11,7 @@
 // k = 4q..4q+3), so every lane fetches its four A (and four B) values of four consecutive MFMAs with ONE
 // ds_read_b128 from row-major [row][k] / [n][k] images - nn.Linear's [out,in] weight layout is read as stored.
 #include "gfv_common.h"
+#include "gfv_prof.h"
 #include "../../include/gfv.h"
 
 namespace {
@@ -453,7 +454,27 @@ extern "C" int gfv_rowtile_chain(const gfv_rowtile_args_t* args, void* stream) {
   if ((args->in_op == GFV_IN_LN || args->in_op == GFV_IN_LNBWD) && (args->nseg != 1 || args->seg[0].width != 128))
     return GFV_ERR_ARG;
   const int tiles = (args->M + BM - 1) / BM;
+  void* tok = nullptr;
+  if (gfv_prof_enabled()) {
+    // algorithmic work: 2*M*K*N flops per layer; bytes: every input row read once, every output/saved row written once
+    double fl = 0, by = 0;
+    for (int l = 0; l < args->nlayers; ++l) {
+      fl += 2.0 * args->M * (double)args->layer[l].K * args->layer[l].N;
+      by += 4.0 * ((double)args->layer[l].K * args->layer[l].N + args->layer[l].N);
+      if (args->layer[l].save) by += 4.0 * args->M * args->layer[l].N;
+      if (args->layer[l].aux) by += 4.0 * args->M * args->layer[l].N;
+    }
+    by += 4.0 * args->M * (double)args->layer[0].K + 4.0 * args->M * (double)last.N;
+    for (int i = 0; i < args->nseg; ++i) if (args->seg[i].idx) by += 4.0 * args->M;
+    if (args->in_aux || args->fin_aux) by += 4.0 * args->M * 128.0;
+    if (args->in_save) by += 4.0 * args->M * 128.0;
+    if (args->fin_presave) by += 4.0 * args->M * 128.0;
+    if (args->out_nores) by += 4.0 * args->M * 128.0;
+    for (int c = 0; c < 3; ++c) if (args->res[c]) by += 4.0 * args->M * 128.0;
+    tok = gfv_prof_begin(GFV_K_ROWTILE, fl, by, (hipStream_t)stream);
+  }
   hipLaunchKernelGGL(rowtile_chain_kernel, dim3(tiles), dim3(256), 0, (hipStream_t)stream, *args);
+  gfv_prof_end(tok, (hipStream_t)stream);
   GFV_CHECK_LAUNCH();
   return GFV_OK;
 }

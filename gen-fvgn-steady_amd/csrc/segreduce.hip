@@ -7,6 +7,7 @@
 // segment with 4 gathers in flight.  No atomics, fixed summation order (deterministic), one coalesced write per
 // destination row.  Rows are node/cell features that stay L2/MALL resident between kernels; indices are int32.
 #include "gfv_common.h"
+#include "gfv_prof.h"
 #include "../../include/gfv.h"
 
 namespace {
@@ -148,11 +149,29 @@ inline int grid_for(long work_items, int per_block) {
 
 }  // namespace
 
+extern "C" int gfv_seg_gather_sum_nnz(const float* src, const int32_t* rowptr, const int32_t* col, const float* scale,
+                                      const float* src_scale, float* out, int32_t n_rows, int32_t F, int32_t accumulate,
+                                      int64_t nnz_hint, void* stream);
+
 extern "C" int gfv_seg_gather_sum(const float* src, const int32_t* rowptr, const int32_t* col, const float* scale,
                                   const float* src_scale, float* out, int32_t n_rows, int32_t F, int32_t accumulate, void* stream) {
+  return gfv_seg_gather_sum_nnz(src, rowptr, col, scale, src_scale, out, n_rows, F, accumulate, -1, stream);
+}
+
+// nnz_hint: number of gathered rows (for the algorithmic-byte count of the profiler only; -1 = unknown)
+extern "C" int gfv_seg_gather_sum_nnz(const float* src, const int32_t* rowptr, const int32_t* col, const float* scale,
+                                      const float* src_scale, float* out, int32_t n_rows, int32_t F, int32_t accumulate,
+                                      int64_t nnz_hint, void* stream) {
   if (n_rows < 0 || F < 1) return GFV_ERR_ARG;
   if (n_rows == 0) return GFV_OK;
   hipStream_t st = (hipStream_t)stream;
+  void* tok = nullptr;
+  if (gfv_prof_enabled() && nnz_hint >= 0) {
+    // 4*M*F (gathered rows) + w*M (indices) + 4*R*F (output rows), M = nnz, w = 4
+    const double by = 4.0 * (double)nnz_hint * F + 4.0 * (double)nnz_hint + 4.0 * (double)n_rows * F * (accumulate ? 2 : 1) +
+                      4.0 * (double)n_rows;
+    tok = gfv_prof_begin(GFV_K_SEG, (double)nnz_hint * F, by, st);
+  }
 #define LAUNCH_VEC(LPR)                                                                                       \
   hipLaunchKernelGGL((seg_gather_sum_vec<LPR>), dim3(grid_for(n_rows, 256 / LPR)), dim3(256), 0, st, src,     \
                      rowptr, col, scale, src_scale, out, n_rows, accumulate)
@@ -169,6 +188,7 @@ extern "C" int gfv_seg_gather_sum(const float* src, const int32_t* rowptr, const
                          col, scale, src_scale, out, n_rows, F, accumulate);
   }
 #undef LAUNCH_VEC
+  gfv_prof_end(tok, st);
   GFV_CHECK_LAUNCH();
   return GFV_OK;
 }

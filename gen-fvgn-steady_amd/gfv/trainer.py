@@ -1,0 +1,138 @@
+"""Training-step driver: forward + loss + backward (+ RCCL gradient all-reduce) + fused Adam on the HIP engine.
+
+Reproduces the call sequence of the reference's drivers for ONE batch kept on the device
+(solve_with_grad_GPU.py:133-181: restore `x` from a backup and re-arm the norm flags every inner step;
+pre_train_Adam.py:158-191: zero_grad, forward, `mean(log(weighted residuals))`, backward, Adam), without the autograd
+tape: parameters, gradients and Adam moments live in flat fp32 buffers, so the optimiser is one kernel and the
+data-parallel exchange is ONE all-reduce of 4.7 MB.  The fixed launch sequence can be captured into
+a hipGraph (torch.cuda.CUDAGraph) to remove host launch overhead.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import lib as L
+from .functions import unused_param_names
+from .plan import get_plan
+
+
+class TrainStep:
+    def __init__(self, model, graphs, *, lr=None, betas=(0.9, 0.999), eps=1e-8, loss_weights=None, world_size=1,
+                 process_group=None, use_graph=False, want_outputs=True):
+        self.model = model
+        self.graphs = graphs
+        self.plan = get_plan(graphs)
+        self.engine = model.engine()
+        p = model.params
+        self.lr = p.lr if lr is None else lr
+        self.betas, self.eps = betas, eps
+        self.w_cont, self.w_mom, self.w_press = loss_weights or (p.loss_cont, p.loss_mom, p.loss_press)
+        self.world_size, self.pg = world_size, process_group
+        self.use_graph = use_graph
+        self.want_outputs = want_outputs
+        dev = graphs[0].x.device
+        self.dev = dev
+
+        # flat parameter / gradient / moment buffers; the module's parameters become views of the flat buffer
+        names, tensors = model.param_names_tensors()
+        total = sum((t.numel() + 3) // 4 * 4 for t in tensors)
+        self.flat_p = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat_g = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat_m = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat_v = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.step_t = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.P, self.G = {}, {}
+        skip = unused_param_names(names)
+        off = 0
+        for n, t in zip(names, tensors):
+            k = t.numel()
+            # keep every tensor 16-byte aligned inside the flat buffer (float4 loads in the kernels)
+            view = self.flat_p[off:off + k].view(t.shape)
+            view.copy_(t.data)
+            t.data = view
+            self.P[n] = view
+            if n not in skip:
+                self.G[n] = self.flat_g[off:off + k].view(t.shape)
+            off += (k + 3) // 4 * 4
+        assert all(v.data_ptr() % 16 == 0 for v in self.P.values())
+        self.n_params = total
+        self.x = graphs[0].x
+        self.x_backup = self.x.clone()
+        B = self.plan.B
+        self.loss = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.gloss = torch.zeros((B, 4), dtype=torch.float32, device=dev)
+        self.losses = None
+        self.uvp_node = None
+        self._graphs = {}
+
+    # one un-captured step body ------------------------------------------------------------------------------
+    def _body(self, accumulate, with_adam=True):
+        lib = L.load()
+        st = L.stream_ptr()
+        self.x.copy_(self.x_backup)  # solve_with_grad_GPU.py:143 (fresh, un-normalised node state every step)
+        losses, uvp_node, uvp_cell, _, ctx = self.engine.forward(
+            self.P, self.model.node_norm.buffers_dict(), self.x, self.plan, norm_global=True, accumulate=accumulate,
+            want_outputs=self.want_outputs, want_edge_attr15=False)
+        L.check(lib.gfv_train_loss(losses.data_ptr(), self.plan.B, self.w_cont, self.w_mom, self.w_press,
+                                   self.loss.data_ptr(), self.gloss.data_ptr(), st), "train_loss")
+        self.engine.backward(self.P, ctx, self.gloss, self.G, self.plan)
+        self.losses, self.uvp_node, self.uvp_cell = losses, uvp_node, uvp_cell
+        if with_adam:
+            self._adam()
+
+    def _adam(self):
+        lib = L.load()
+        L.check(lib.gfv_adam_step(self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.flat_m.data_ptr(),
+                                  self.flat_v.data_ptr(), self.n_params, self.step_t.data_ptr(), self.lr, self.betas[0],
+                                  self.betas[1], self.eps, 1.0 / self.world_size, L.stream_ptr()), "adam_step")
+
+    def _allreduce(self):
+        import torch.distributed as dist
+        dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM, group=self.pg)
+
+    def step(self):
+        """One training iteration.  Returns the (device) scalar loss tensor of this rank's batch."""
+        acc = self.model.node_norm.should_accumulate()
+        dist_on = self.world_size > 1
+        if not self.use_graph:
+            self._body(acc, with_adam=not dist_on)
+            if dist_on:
+                self._allreduce()
+                self._adam()
+        else:
+            key = (acc, dist_on)
+            g = self._graphs.get(key)
+            if g is None:
+                # warm the allocator on a side stream, then capture (PyTorch CUDA-graph recipe)
+                s = torch.cuda.Stream()
+                s.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(s):
+                    self._snapshot()
+                    self._body(acc, with_adam=not dist_on)
+                    self._restore()
+                torch.cuda.current_stream().wait_stream(s)
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._body(acc, with_adam=not dist_on)
+                self._graphs[key] = g
+                self._restore()  # capture does not execute; state is as before this step
+            g.replay()
+            if dist_on:
+                self._allreduce()
+                self._adam()
+        if acc:
+            self.model.node_norm.note_accumulated()
+        return self.loss
+
+    # state snapshot so the capture warm-up does not advance training ---------------------------------------
+    def _snapshot(self):
+        nb = self.model.node_norm
+        self._snap = (self.flat_p.clone(), self.flat_m.clone(), self.flat_v.clone(), self.step_t.clone(),
+                      nb.acc_count.clone(), nb.num_accumulations.clone(), nb.acc_sum.clone(), nb.acc_sum_squared.clone())
+
+    def _restore(self):
+        nb = self.model.node_norm
+        for dst, src in zip((self.flat_p, self.flat_m, self.flat_v, self.step_t, nb.acc_count, nb.num_accumulations,
+                             nb.acc_sum, nb.acc_sum_squared), self._snap):
+            dst.copy_(src)

@@ -32,6 +32,11 @@ int gfv_abi_version(void);
 int gfv_seg_gather_sum(const float* src, const int32_t* rowptr, const int32_t* col, const float* scale,
                        const float* src_scale, float* out, int32_t n_rows, int32_t F, int32_t accumulate, void* stream);
 
+/* same; nnz_hint = rowptr[n_rows] if the caller knows it (only used for the profiler's algorithmic-byte count) */
+int gfv_seg_gather_sum_nnz(const float* src, const int32_t* rowptr, const int32_t* col, const float* scale,
+                           const float* src_scale, float* out, int32_t n_rows, int32_t F, int32_t accumulate,
+                           int64_t nnz_hint, void* stream);
+
 /* out[e, 0:F] = a[s[e], :], out[e, F:2F] = a[r[e], :]  (+ base[e,:] if base != NULL).  Adjoint of the
  * chunked edge->node scatter at blocks.py:34-42. */
 int gfv_gather_pair(const float* a, const int32_t* s, const int32_t* r, const float* base, float* out,
@@ -207,6 +212,15 @@ int gfv_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float
                   float eps, float grad_scale, void* stream);
 int gfv_train_loss(const float* losses, int32_t B, float w_cont, float w_mom, float w_press, float* loss, float* gloss,
                    void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Optional per-launch HIP-event timing of the main kernels on their own stream (bench.py roofline leg).
+ * kind: 1 row-tile chain, 2 weight gradient, 3 segmented reduce.  out = {launches, total ms, algorithmic flops,
+ * algorithmic bytes} summed since the last reset.  Off by default.
+ * ---------------------------------------------------------------------------------------------------------- */
+int gfv_profile_enable(int on);
+int gfv_profile_collect(int kind, double* out);
+int gfv_profile_reset(void);
 
 #ifdef __cplusplus
 }
