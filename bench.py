@@ -64,7 +64,7 @@ def cpu_baseline(graphs_cpu, budget_s, max_steps=3):
     for i in range(max_steps + 1):
         graphs_cpu[0].x = x0.clone()
         t0 = time.time()
-        O.train_step(P, buffers, graphs_cpu, state)
+        O.train_step(P, buffers, graphs_cpu, state, hyper={"dataset_size": 1})
         dt = time.time() - t0
         if i > 0:
             times.append(dt)
@@ -108,7 +108,9 @@ def main():
     graphs_cpu, sz = build_workload(args.cells, args.meshes_per_gpu, rank, device)
     graphs = tuple(g.clone().to(device) for g in graphs_cpu)
     torch.manual_seed(0)  # identical initial weights on every rank (data parallel replicas)
-    model = NNmodel(default_params()).to(device)
+    # dataset_size=1: the solve-script regime (solve_with_grad_GPU.py), where the online Normalizer never accumulates
+    # and is the identity (utils/normalization.py:39); a single mesh has constant conditioning columns.
+    model = NNmodel(default_params(dataset_size=1)).to(device)
     ts = TrainStep(model, graphs, world_size=world, use_graph=not args.no_graph)
 
     def barrier():
@@ -171,7 +173,9 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and args.cpu_budget > 0:
-        ncores = os.cpu_count() or 1
+        # 16 threads is the fastest setting for this launch-bound eager workload on the GPU box's host
+        # (measured 8/16/32/64/256 threads: 4.3 / 3.5 / 3.6 / 5.2 / 188 s per step); override with GFV_CPU_THREADS
+        ncores = int(os.environ.get("GFV_CPU_THREADS", min(16, os.cpu_count() or 1)))
         torch.set_num_threads(ncores)
         sec, nst = cpu_baseline(graphs_cpu, args.cpu_budget)
         cpu = {"value": round(args.meshes_per_gpu / sec, 5), "unit": "train-iters/s", "cores": torch.get_num_threads(),

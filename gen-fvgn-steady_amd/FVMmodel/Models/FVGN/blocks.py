@@ -34,13 +34,13 @@ class _EdgeBlockFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         P, pl = ctx.P, ctx.plan
-        grads = {n: torch.empty_like(P[n]) for n in ctx.names}
+        grads = GF._alloc_grads(ctx.names, [P[n] for n in ctx.names])
         gnb2 = torch.empty((pl.E, 256), device=g.device)
         ge = torch.empty((pl.E, 128), device=g.device)
         ctx.engine.mlp3_bwd(P, ctx.sv, g.contiguous(), grads, outs=[(gnb2, 256), (gnb2.data_ptr() + 512, 256), ge])
         g_nb = ops.seg_gather_sum(gnb2.view(2 * pl.E, 128), pl.n_rowptr, pl.n_col_edge2, pl.N)
         gx = ops.seg_gather_sum(g_nb, pl.n_rowptr, pl.n_col_node, pl.N)
-        return (None, None, None, gx, ge) + tuple(grads[n] for n in ctx.names)
+        return (None, None, None, gx, ge) + tuple(grads.view(n) for n in ctx.names)
 
 
 class _NodeBlockFn(torch.autograd.Function):
@@ -59,7 +59,7 @@ class _NodeBlockFn(torch.autograd.Function):
     def backward(ctx, g):
         P, pl = ctx.P, ctx.plan
         dev = g.device
-        grads = {n: torch.empty_like(P[n]) for n in ctx.names}
+        grads = GF._alloc_grads(ctx.names, [P[n] for n in ctx.names])
         W1 = P["blk.net.0.0.weight"]
         W1t = torch.empty((192, 128), device=dev)
         ops.transpose(W1, out=W1t[0:128], col0=64, ncols=128)
@@ -68,7 +68,7 @@ class _NodeBlockFn(torch.autograd.Function):
         ctx.engine.mlp3_bwd(P, ctx.sv, g.contiguous(), grads, outs=[gx, (gnbm, 64)], W1t=W1t)
         g_agg = ops.seg_gather_sum(gnbm, pl.n_rowptr, pl.n_col_node, pl.N, src_scale=pl.inv_deg)
         ge = ops.gather_pair(g_agg, pl.es, pl.er)
-        return (None, None, None, gx, ge) + tuple(grads[n] for n in ctx.names)
+        return (None, None, None, gx, ge) + tuple(grads.view(n) for n in ctx.names)
 
 
 def _graph_plan(graph_node):

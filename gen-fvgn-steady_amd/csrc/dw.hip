@@ -1,34 +1,30 @@
-// Weight gradient of a Linear layer on fp32 MFMA (gfx950):  dW[n,k] = sum_m G[m,n] * A[m,k],  db[n] = sum_m G[m,n].
-// Contract: include/gfv.h (gfv_linear_dw).
+// Weight gradients of Linear layers on fp32 MFMA (gfx950):  dW[n,k] = sum_m G[m,n] * A[m,k],  db[n] = sum_m G[m,n].
+// Contract: include/gfv.h (gfv_dw_multi / gfv_linear_dw).
 //
-// Both operands have the contraction index m as their row index in memory, so tiles of 32 rows of G and A are
-// staged row-major in LDS ([m][128], row stride 144 floats: the four k-groups of an MFMA operand fetch land on
-// disjoint bank quarters) and each MFMA operand is one ds_read_b32 per lane.  A workgroup owns a 512-row slab of
-// m and the full 128 x (<=128) output block of one input segment; its 4 waves own the 64x64 quadrants (16
-// accumulator tiles each).  Slab partials go to a workspace and are summed by gfv_reduce_partials in a fixed
-// order (no float atomics -> deterministic).
+// A launch carries up to 6 independent 128 x (<=128) output tiles (all weight gradients of one fused MLP: the
+// input segments of layer 1, layer 2, layer 3) so small row counts still fill the chip; blockIdx.y selects the tile,
+// blockIdx.x a slab of rows.  Both operands have the contraction index m as their row index in memory, so slabs of
+// 32 rows of G and A are staged row-major in LDS ([m][128], row stride 144 floats: the four k-groups of an MFMA
+// operand fetch land on disjoint bank quarters), double buffered, and every MFMA operand is one ds_read_b32 per
+// lane.  The 4 waves own the 64x64 quadrants of the tile (16 accumulator tiles each).  Slab partials are written
+// to a workspace laid out like the parameter block ([slab][W1|b1|W2|b2|W3|b3]) and summed in a fixed order by
+// gfv_reduce_partials: no float atomics, deterministic.
 #include "gfv_common.h"
 #include "gfv_prof.h"
 #include "../../include/gfv.h"
 
 namespace {
 
-constexpr int RCH = 512;  // rows of m per workgroup
 constexpr int SUB = 32;   // rows per staged sub-tile
 constexpr int LDT = 144;
 
-struct DwArgs {
-  const float* G;
-  int ldg, n_out;
-  gfv_seg_t seg[3];
-  int nseg;
-  const float* in_add;
-  int a_op;  // 0 none, 1 gelu, 2 layernorm(gamma,beta)
-  const float* a_gamma;
-  const float* a_beta;
-  int M, Ktot;
-  float* ws_dw;  // [chunks][n_out*Ktot]
-  float* ws_db;  // [chunks][n_out] or NULL
+struct DwLaunch {
+  gfv_dw_tile_t tile[6];
+  int ntiles;
+  int M;
+  int rows_per_slab;  // multiple of 32
+  long ws_stride;     // floats per slab in the workspace
+  float* ws;
 };
 
 __device__ __forceinline__ float4 ld4(const float* base, size_t row, int ld, int col, int width, bool vec) {
@@ -45,25 +41,23 @@ __device__ __forceinline__ float4 ld4(const float* base, size_t row, int ld, int
   return v;
 }
 
-__global__ __launch_bounds__(256, 2) void linear_dw_kernel(const DwArgs A) {
-  __shared__ __attribute__((aligned(16))) float Gs[SUB * LDT];
-  __shared__ __attribute__((aligned(16))) float As[SUB * LDT];
+template <bool FULL>
+__device__ __forceinline__ void dw_body(const DwLaunch& A, const gfv_dw_tile_t& T, float* lds) {
+  float* Gs0 = lds;
+  float* As0 = lds + SUB * LDT;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, nl = lane & 15, q = lane >> 4;
   const int wn = wave >> 1, wk = wave & 1;
-  const int chunk = blockIdx.x, si = blockIdx.y;
-  const gfv_seg_t seg = A.seg[si];
-  int koff = 0;
-  for (int i = 0; i < si; ++i) koff += A.seg[i].width;
-  const int kpad = (seg.width + 15) & ~15;
-  const int npad = (A.n_out + 15) & ~15;
-  const bool gvec = ((A.ldg & 3) == 0) && ((A.n_out & 3) == 0);
-  const bool avec = ((seg.ld & 3) == 0) && ((seg.width & 3) == 0);
+  const int slab = blockIdx.x;
+  const int kpad = FULL ? 128 : ((T.width + 15) & ~15);
+  const int npad = FULL ? 128 : ((T.n_out + 15) & ~15);
+  const bool gvec = FULL || (((T.ldg & 3) == 0) && ((T.n_out & 3) == 0));
+  const bool avec = FULL || (((T.ld & 3) == 0) && ((T.width & 3) == 0));
   const int c4 = tid & 31, rg = tid >> 5;  // staging: row group 0..7, float4 column
   const int col = 4 * c4;
   float4 gam = make_float4(1.f, 1.f, 1.f, 1.f), bet = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (A.a_op == 2) {
-    gam = *reinterpret_cast<const float4*>(A.a_gamma + col);
-    bet = *reinterpret_cast<const float4*>(A.a_beta + col);
+  if (T.a_op == 2) {
+    gam = *reinterpret_cast<const float4*>(T.a_gamma + col);
+    bet = *reinterpret_cast<const float4*>(T.a_beta + col);
   }
 
   floatx4 acc[4][4];
@@ -73,8 +67,8 @@ __global__ __launch_bounds__(256, 2) void linear_dw_kernel(const DwArgs A) {
     for (int j = 0; j < 4; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
   float4 dbacc = make_float4(0.f, 0.f, 0.f, 0.f);
 
-  const int m_beg = chunk * RCH;
-  const int m_end = min(m_beg + RCH, A.M);
+  const int m_beg = slab * A.rows_per_slab;
+  const int m_end = min(m_beg + A.rows_per_slab, A.M);
   float4 greg[4], areg[4];
 
   auto load_sub = [&](int m0) {
@@ -83,17 +77,17 @@ __global__ __launch_bounds__(256, 2) void linear_dw_kernel(const DwArgs A) {
       const int m = m0 + rg + 8 * p;
       float4 g = make_float4(0.f, 0.f, 0.f, 0.f), a = g;
       if (m < m_end) {
-        g = ld4(A.G, (size_t)m, A.ldg, col, A.n_out, gvec);
-        const size_t srow = seg.idx ? (size_t)seg.idx[m] : (size_t)m;
-        a = ld4(seg.ptr, srow, seg.ld, col, seg.width, avec);
-        if (si == 0 && A.in_add) {
-          const float4 b = ld4(A.in_add, srow, seg.ld, col, seg.width, avec);
+        g = ld4(T.G, (size_t)m, T.ldg, col, FULL ? 128 : T.n_out, gvec);
+        const size_t srow = T.idx ? (size_t)T.idx[m] : (size_t)m;
+        a = ld4(T.A, srow, T.ld, col, FULL ? 128 : T.width, avec);
+        if (T.in_add) {
+          const float4 b = ld4(T.in_add, srow, T.ld, col, FULL ? 128 : T.width, avec);
           a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
         }
       }
-      if (A.a_op == 1) {
+      if (T.a_op == 1) {
         a = make_float4(gfv_gelu(a.x), gfv_gelu(a.y), gfv_gelu(a.z), gfv_gelu(a.w));
-      } else if (A.a_op == 2) {
+      } else if (T.a_op == 2) {
         // row LayerNorm (eps 1e-5); the 32 lanes that share a row are an aligned half wave
         const float mean = gfv_half_sum((a.x + a.y) + (a.z + a.w)) * (1.0f / 128.0f);
         const float dx = a.x - mean, dy = a.y - mean, dz = a.z - mean, dw = a.w - mean;
@@ -107,19 +101,29 @@ __global__ __launch_bounds__(256, 2) void linear_dw_kernel(const DwArgs A) {
       areg[p] = a;
     }
   };
-
-  if (m_beg < m_end) load_sub(m_beg);
-  for (int m0 = m_beg; m0 < m_end; m0 += SUB) {
-    __syncthreads();  // previous sub-tile fully consumed
+  auto store_sub = [&](int buf) {
+    float* Gs = Gs0 + buf * 2 * SUB * LDT;
+    float* As = As0 + buf * 2 * SUB * LDT;
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
       *reinterpret_cast<float4*>(&Gs[(rg + 8 * p) * LDT + col]) = greg[p];
       *reinterpret_cast<float4*>(&As[(rg + 8 * p) * LDT + col]) = areg[p];
       dbacc.x += greg[p].x; dbacc.y += greg[p].y; dbacc.z += greg[p].z; dbacc.w += greg[p].w;
     }
-    __syncthreads();
-    if (m0 + SUB < m_end) load_sub(m0 + SUB);
-#pragma unroll 2
+  };
+
+  int buf = 0;
+  if (m_beg < m_end) {
+    load_sub(m_beg);
+    store_sub(0);
+  }
+  __syncthreads();
+  for (int m0 = m_beg; m0 < m_end; m0 += SUB) {
+    const bool more = m0 + SUB < m_end;
+    if (more) load_sub(m0 + SUB);
+    const float* Gs = Gs0 + buf * 2 * SUB * LDT;
+    const float* As = As0 + buf * 2 * SUB * LDT;
+#pragma unroll
     for (int ms = 0; ms < SUB / 4; ++ms) {
       const float* grow = &Gs[(4 * ms + q) * LDT + 64 * wn + nl];
       const float* arow = &As[(4 * ms + q) * LDT + 64 * wk + nl];
@@ -128,17 +132,26 @@ __global__ __launch_bounds__(256, 2) void linear_dw_kernel(const DwArgs A) {
       for (int i = 0; i < 4; ++i) g[i] = grow[16 * i];
 #pragma unroll
       for (int j = 0; j < 4; ++j) a[j] = arow[16 * j];
+      if (FULL) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          if (64 * wn + 16 * i < npad && 64 * wk + 16 * j < kpad)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(g[i], a[j], acc[i][j], 0, 0, 0);
-        }
+          for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(g[i], a[j], acc[i][j], 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (64 * wn + 16 * i < npad && 64 * wk + 16 * j < kpad)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(g[i], a[j], acc[i][j], 0, 0, 0);
+      }
     }
+    if (more) store_sub(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
   }
 
-  float* ws = A.ws_dw + (size_t)chunk * A.n_out * A.Ktot;
+  float* ws = A.ws + (size_t)slab * A.ws_stride + T.out_off;
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -147,62 +160,115 @@ __global__ __launch_bounds__(256, 2) void linear_dw_kernel(const DwArgs A) {
       for (int reg = 0; reg < 4; ++reg) {
         const int n = 64 * wn + 16 * i + 4 * q + reg;
         const int k = 64 * wk + 16 * j + nl;
-        if (n < A.n_out && k < seg.width) ws[(size_t)n * A.Ktot + koff + k] = acc[i][j][reg];
+        if (FULL || (n < T.n_out && k < T.width)) ws[(size_t)n * T.ld_out + k] = acc[i][j][reg];
       }
 
-  if (si == 0 && A.ws_db) {
+  if (T.db_off >= 0) {
+    float* red = lds;  // safe: the loop ended with a barrier
+    *reinterpret_cast<float4*>(&red[rg * LDT + col]) = dbacc;
     __syncthreads();
-    *reinterpret_cast<float4*>(&Gs[rg * LDT + col]) = dbacc;
-    __syncthreads();
-    if (tid < A.n_out) {
+    if (tid < T.n_out) {
       float s = 0.f;
 #pragma unroll
-      for (int r = 0; r < 8; ++r) s += Gs[r * LDT + tid];
-      A.ws_db[(size_t)chunk * A.n_out + tid] = s;
+      for (int r = 0; r < 8; ++r) s += red[r * LDT + tid];
+      A.ws[(size_t)slab * A.ws_stride + T.db_off + tid] = s;
     }
   }
 }
 
-}  // namespace
-
-extern "C" int gfv_dw_chunks(int32_t M) { return (M + RCH - 1) / RCH; }
-
-extern "C" size_t gfv_linear_dw_workspace_floats(int32_t M, int32_t n_out, int32_t K) {
-  const size_t ch = (size_t)((M + RCH - 1) / RCH);
-  return ch * (size_t)n_out * (size_t)K + ch * (size_t)n_out;
+__global__ __launch_bounds__(256, 2) void dw_multi_kernel(const DwLaunch A) {
+  __shared__ __attribute__((aligned(16))) float lds[4 * SUB * LDT];  // 2 buffers x (G, A)
+  const gfv_dw_tile_t& T = A.tile[blockIdx.y];
+  const bool full = (T.n_out == 128) && (T.width == 128) && ((T.ldg & 3) == 0) && ((T.ld & 3) == 0);
+  if (full) dw_body<true>(A, T, lds);
+  else dw_body<false>(A, T, lds);
 }
+
+}  // namespace
 
 extern "C" int gfv_reduce_partials(const float*, int32_t, int32_t, float*, int32_t, void*);
 
-extern "C" int gfv_linear_dw_ex(const float* G, int32_t ldg, int32_t n_out, const gfv_seg_t* segs, int32_t nseg,
-                                const float* in_add, int32_t a_op, const float* a_gamma, const float* a_beta, int32_t M,
-                                float* dW, int32_t ld_dw_unused, float* db, float* workspace, int32_t accumulate,
-                                void* stream) {
-  (void)ld_dw_unused;
-  if (nseg < 1 || nseg > 3 || n_out < 1 || n_out > 128 || M < 0) return GFV_ERR_ARG;
-  DwArgs a;
-  a.G = G; a.ldg = ldg; a.n_out = n_out; a.nseg = nseg; a.in_add = in_add; a.a_op = a_op;
-  a.a_gamma = a_gamma; a.a_beta = a_beta; a.M = M;
-  int K = 0;
-  for (int i = 0; i < nseg; ++i) {
-    if (segs[i].width < 1 || segs[i].width > 128) return GFV_ERR_ARG;
-    a.seg[i] = segs[i];
-    K += segs[i].width;
+extern "C" int gfv_dw_slabs(int32_t M, int32_t ntiles, int32_t* rows_per_slab) {
+  // aim at ~1024 workgroups per launch (2 per CU x 2 rounds), slabs of a multiple of 32 rows, at least 64 rows
+  if (ntiles < 1) ntiles = 1;
+  long target = 1024 / ntiles;
+  if (target < 1) target = 1;
+  long rows = (M + target - 1) / target;
+  rows = ((rows + 31) / 32) * 32;
+  if (rows < 64) rows = 64;
+  if (rows_per_slab) *rows_per_slab = (int)rows;
+  return (int)((M + rows - 1) / rows);
+}
+
+extern "C" int gfv_dw_multi(const gfv_dw_tile_t* tiles, int32_t ntiles, int32_t M, int64_t block_floats, float* workspace,
+                            float* grad_block, int32_t accumulate, void* stream) {
+  if (ntiles < 1 || ntiles > 6 || M < 0 || block_floats <= 0) return GFV_ERR_ARG;
+  if (M == 0) return GFV_OK;
+  DwLaunch a;
+  double fl = 0, by = 0;
+  for (int i = 0; i < ntiles; ++i) {
+    const gfv_dw_tile_t& t = tiles[i];
+    if (t.n_out < 1 || t.n_out > 128 || t.width < 1 || t.width > 128) return GFV_ERR_ARG;
+    if (t.a_op == 2 && t.width != 128) return GFV_ERR_ARG;
+    a.tile[i] = t;
+    fl += 2.0 * M * (double)t.n_out * t.width;
+    by += 4.0 * M * ((double)t.n_out + t.width);
   }
-  if (a_op == 2 && (nseg != 1 || segs[0].width != 128)) return GFV_ERR_ARG;
-  a.Ktot = K;
-  const int chunks = (M + RCH - 1) / RCH;
-  if (chunks == 0) return GFV_OK;
-  a.ws_dw = workspace;
-  a.ws_db = db ? workspace + (size_t)chunks * n_out * K : nullptr;
-  void* tok = gfv_prof_begin(GFV_K_DW, 2.0 * M * (double)n_out * K,
-                             4.0 * M * ((double)n_out + K) + 4.0 * (double)chunks * n_out * K, (hipStream_t)stream);
-  hipLaunchKernelGGL(linear_dw_kernel, dim3(chunks, nseg), dim3(256), 0, (hipStream_t)stream, a);
+  a.ntiles = ntiles;
+  a.M = M;
+  int rows = 0;
+  const int slabs = gfv_dw_slabs(M, ntiles, &rows);
+  a.rows_per_slab = rows;
+  a.ws_stride = block_floats;
+  a.ws = workspace;
+  // slots of the block that no tile writes (alignment padding) keep whatever the workspace held: callers hand in a
+  // zero-initialised workspace, so padding entries of the gradient block stay finite and are never read.
+  void* tok = gfv_prof_begin(GFV_K_DW, fl, by + 8.0 * (double)slabs * block_floats, (hipStream_t)stream);
+  hipLaunchKernelGGL(dw_multi_kernel, dim3(slabs, ntiles), dim3(256), 0, (hipStream_t)stream, a);
   gfv_prof_end(tok, (hipStream_t)stream);
   GFV_CHECK_LAUNCH();
-  int rc = gfv_reduce_partials(a.ws_dw, chunks, n_out * K, dW, accumulate, stream);
+  return gfv_reduce_partials(workspace, slabs, (int32_t)block_floats, grad_block, accumulate, stream);
+}
+
+extern "C" size_t gfv_dw_multi_workspace_floats(int32_t M, int32_t ntiles, int64_t block_floats) {
+  return (size_t)gfv_dw_slabs(M, ntiles, nullptr) * (size_t)block_floats;
+}
+
+// ---- single Linear layer (kept for callers that hold separate dW / db tensors) ------------------------------------
+extern "C" int gfv_dw_chunks(int32_t M) { return gfv_dw_slabs(M, 1, nullptr); }
+
+extern "C" size_t gfv_linear_dw_workspace_floats(int32_t M, int32_t n_out, int32_t K) {
+  return (size_t)(gfv_dw_slabs(M, 1, nullptr) + 2) * ((size_t)n_out * K + n_out + 4);
+}
+
+extern "C" int gfv_linear_dw_ex(const float* G, int32_t ldg, int32_t n_out, const gfv_seg_t* segs, int32_t nseg,
+                                const float* in_add, int32_t a_op, const float* a_gamma, const float* a_beta, int32_t M,
+                                float* dW, int32_t reserved, float* db, float* workspace, int32_t accumulate,
+                                void* stream) {
+  (void)reserved;
+  if (nseg < 1 || nseg > 3 || n_out < 1 || n_out > 128 || M < 0) return GFV_ERR_ARG;
+  int K = 0;
+  for (int i = 0; i < nseg; ++i) K += segs[i].width;
+  const long wfl = (long)n_out * K;
+  const long block = ((wfl + n_out + 3) / 4) * 4;
+  gfv_dw_tile_t t[3];
+  int koff = 0;
+  for (int i = 0; i < nseg; ++i) {
+    t[i].G = G; t[i].ldg = ldg; t[i].n_out = n_out;
+    t[i].A = segs[i].ptr; t[i].idx = segs[i].idx; t[i].width = segs[i].width; t[i].ld = segs[i].ld;
+    t[i].in_add = (i == 0) ? in_add : nullptr;
+    t[i].a_op = a_op; t[i].a_gamma = a_gamma; t[i].a_beta = a_beta;
+    t[i].out_off = koff; t[i].ld_out = K;
+    t[i].db_off = (i == 0 && db) ? wfl : -1;
+    koff += segs[i].width;
+  }
+  const int slabs = gfv_dw_slabs(M, nseg, nullptr);
+  float* tmp = workspace + (size_t)slabs * block;  // reduced block, then split into dW / db
+  int rc = gfv_dw_multi(t, nseg, M, block, workspace, tmp, 0, stream);
   if (rc) return rc;
-  if (db) rc = gfv_reduce_partials(a.ws_db, chunks, n_out, db, accumulate, stream);
+  rc = gfv_reduce_partials(tmp, 1, (int32_t)wfl, dW, accumulate, stream);
+  if (rc) return rc;
+  if (db) rc = gfv_reduce_partials(tmp + wfl, 1, n_out, db, accumulate, stream);
   return rc;
 }
 

@@ -124,6 +124,24 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
   }
 }
 
+// few outputs, many chunks (bias / LayerNorm partials): 32 columns x 8 chunk lanes per block, LDS tree at the end
+__global__ __launch_bounds__(256) void reduce_partials_small_kernel(const float* __restrict__ partial, int n_chunks, int n,
+                                                                    float* __restrict__ out, int accumulate) {
+  __shared__ float red[8][33];
+  const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+  const int j = blockIdx.x * 32 + cx;
+  float s = 0.f;
+  if (j < n)
+    for (int c = ry; c < n_chunks; c += 8) s += partial[(size_t)c * n + j];
+  red[ry][cx] = s;
+  __syncthreads();
+  if (ry == 0 && j < n) {
+    float t = ((red[0][cx] + red[1][cx]) + (red[2][cx] + red[3][cx])) + ((red[4][cx] + red[5][cx]) + (red[6][cx] + red[7][cx]));
+    if (accumulate) t += out[j];
+    out[j] = t;
+  }
+}
+
 __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, int ld_in, float* __restrict__ out,
                                                         int rows, int cols) {
   __shared__ float tile[32][33];
@@ -212,6 +230,12 @@ extern "C" int gfv_gather_pair(const float* a, const int32_t* s, const int32_t* 
 extern "C" int gfv_reduce_partials(const float* partial, int32_t n_chunks, int32_t n, float* out, int32_t accumulate,
                                    void* stream) {
   if (n <= 0) return GFV_OK;
+  if (n <= 4096 && n_chunks >= 32) {
+    hipLaunchKernelGGL(reduce_partials_small_kernel, dim3((n + 31) / 32), dim3(256), 0, (hipStream_t)stream, partial,
+                       n_chunks, n, out, accumulate);
+    GFV_CHECK_LAUNCH();
+    return GFV_OK;
+  }
   hipLaunchKernelGGL(reduce_partials_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, partial,
                      n_chunks, n, out, accumulate);
   GFV_CHECK_LAUNCH();

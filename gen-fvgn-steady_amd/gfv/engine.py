@@ -22,8 +22,43 @@ def _empty(dev, *shape):
     return torch.empty(shape, dtype=torch.float32, device=dev)
 
 
+class GradStore:
+    """Flat fp32 gradient storage with named views; every tensor starts on a 16-byte boundary, tensors keep the
+    order they were given in (state_dict order), so the gradients of one MLP / Linear form one contiguous block."""
+
+    def __init__(self, names, shapes, device, flat=None, skip=()):
+        self.off, self.shape = {}, {}
+        off = 0
+        for n, sh in zip(names, shapes):
+            k = 1
+            for d in sh:
+                k *= int(d)
+            self.off[n], self.shape[n] = off, tuple(sh)
+            off += (k + 3) // 4 * 4
+        self.total = off
+        self.flat = torch.zeros(off, dtype=torch.float32, device=device) if flat is None else flat
+        self.skip = set(skip)
+
+    def numel(self, n):
+        k = 1
+        for d in self.shape[n]:
+            k *= d
+        return k
+
+    def view(self, n):
+        if n in self.skip:
+            return None
+        return self.flat[self.off[n]:self.off[n] + self.numel(n)].view(self.shape[n])
+
+    def block(self, first, last):
+        """(offset, length) of the contiguous block first..last (inclusive, with padding)."""
+        end = self.off[last] + (self.numel(last) + 3) // 4 * 4
+        return self.off[first], end - self.off[first]
+
+
 class Engine:
     def __init__(self, message_passing_num=3, integrator="imex", ncn_smooth=True, net="TransFVGN_v2"):
+        self._dw_ws = None
         self.mp = message_passing_num
         self.mode = _MODE[integrator]
         self.smooth = 1 if ncn_smooth else 0
@@ -68,8 +103,8 @@ class Engine:
         nout = W3.shape[0]
         W3t, W2t = ops.transpose(W3), ops.transpose(W2)
         gz2, gz1 = _empty(dev, M, 128), _empty(dev, M, 128)
-        tiles = ops.rowtile_tiles(M)
-        part = _empty(dev, tiles, 2, 128) if ln else None
+        tiles_n = ops.rowtile_tiles(M)
+        part = _empty(dev, tiles_n, 2, 128) if ln else None
         g3 = _empty(dev, M, 128) if ln else G
         gseg = Seg(G, width=nout, ld=G.stride(0) if g_ld is None else g_ld)
         kw = dict(in_op=L.IN_LNBWD, in_gamma=P[names[6]], in_aux=sv["y3"], in_save=g3, ln_partial=part) if ln else {}
@@ -86,36 +121,70 @@ class Engine:
             ops.rowtile_chain(M, [gseg],
                               [LayerSpec(W3t, None, L.OP_MUL_DGELU, save=gz2, aux=sv["z2"]),
                                LayerSpec(W2t, None, L.OP_MUL_DGELU, aux=sv["z1"])], [gz1], **kw)
-        self._dw(grads, names[4], names[5], g3, nout, [Seg(sv["z2"])], M, a_op=1,
-                 ldg=(G.stride(0) if g_ld is None else g_ld) if not ln else None)
-        self._dw(grads, names[2], names[3], gz2, 128, [Seg(sv["z1"])], M, a_op=1)
-        self._dw(grads, names[0], names[1], gz1, 128, sv["segs"], M, in_add=sv["in_add"])
+        tiles = [self._tile(gz1, 128, sg, in_add=sv["in_add"] if i == 0 else None) for i, sg in enumerate(sv["segs"])]
+        tiles.append(self._tile(gz2, 128, Seg(sv["z1"]), a_op=1))
+        tiles.append(self._tile(g3, nout, Seg(sv["z2"]), a_op=1, ldg=(G.stride(0) if g_ld is None else g_ld) if not ln else None))
+        self._dw_block(grads, [(names[0], names[1], len(sv["segs"])), (names[2], names[3], 1), (names[4], names[5], 1)],
+                       tiles, M)
         if ln:
-            gb = ops.reduce_partials(part, tiles, 256)
-            self._put(grads, names[6], gb[:128])
-            self._put(grads, names[7], gb[128:])
+            ops.reduce_partials(part, tiles_n, 256, out=self._gview2(grads, names[6], names[7]))
+
+    @staticmethod
+    def _gview2(grads, n0, n1):
+        off, length = grads.block(n0, n1)
+        return grads.flat[off:off + length]
+
+    @staticmethod
+    def _tile(G, n_out, seg, *, a_op=0, a_gamma=None, a_beta=None, in_add=None, ldg=None, g_offset=0):
+        return dict(G=G, n_out=n_out, seg=seg, a_op=a_op, a_gamma=a_gamma, a_beta=a_beta, in_add=in_add,
+                    ldg=G.stride(0) if ldg is None else ldg, g_offset=g_offset)
+
+    def _workspace(self, n_floats, dev):
+        if self._dw_ws is None or self._dw_ws.numel() < n_floats or self._dw_ws.device != dev:
+            self._dw_ws = torch.zeros(int(n_floats * 1.25) + 1024, dtype=torch.float32, device=dev)
+        return self._dw_ws
+
+    def _dw_block(self, grads, layers, tiles, M, row0s=None):
+        """layers: [(weight name, bias name or None, n tiles of that weight)], in parameter order; tiles in the same
+        order.  One launch + one reduction into the contiguous gradient block of those parameters."""
+        lib = L.load()
+        first = layers[0][0]
+        last = layers[-1][1] if layers[-1][1] is not None else layers[-1][0]
+        off0, blen = grads.block(first, last)
+        ct = (L.DwTile * 6)()
+        ti = 0
+        for li, (wname, bname, nt) in enumerate(layers):
+            K = grads.shape[wname][1]
+            koff = 0
+            for j in range(nt):
+                t, c = tiles[ti], ct[ti]
+                sg = t["seg"]
+                row0 = 0 if row0s is None else row0s[ti]
+                c.G = t["G"].data_ptr() + 4 * t["g_offset"]
+                c.A = sg.t.data_ptr() + 4 * sg.offset
+                c.idx = None if sg.idx is None else sg.idx.data_ptr()
+                c.in_add = None if t["in_add"] is None else t["in_add"].data_ptr()
+                c.a_gamma = None if t["a_gamma"] is None else t["a_gamma"].data_ptr()
+                c.a_beta = None if t["a_beta"] is None else t["a_beta"].data_ptr()
+                c.ldg, c.n_out, c.width, c.ld = t["ldg"], t["n_out"], sg.width, sg.ld
+                c.a_op, c.ld_out = t["a_op"], K
+                if row0s is None:
+                    c.out_off = grads.off[wname] - off0 + koff
+                    c.db_off = (grads.off[bname] - off0) if (bname is not None and j == 0) else -1
+                    koff += sg.width
+                else:
+                    c.out_off = grads.off[wname] - off0 + row0 * K
+                    c.db_off = (grads.off[bname] - off0 + row0) if bname is not None else -1
+                ti += 1
+        need = lib.gfv_dw_multi_workspace_floats(M, ti, blen)
+        dev = grads.flat.device
+        ws = self._workspace(need, dev)
+        L.check(lib.gfv_dw_multi(ct, ti, M, blen, ws.data_ptr(), grads.flat.data_ptr() + 4 * off0, 0, L.stream_ptr()),
+                "gfv_dw_multi")
 
     @staticmethod
     def _put(grads, name, value):
-        dst = grads.get(name)
-        if dst is None:
-            grads[name] = value
-        else:
-            dst.copy_(value.reshape(dst.shape))
-
-    def _dw(self, grads, wname, bname, G, n_out, segs, M, *, a_op=0, a_gamma=None, a_beta=None, in_add=None, ldg=None,
-            g_offset=0, row0=0):
-        """dW rows [row0, row0+n_out) of parameter `wname` (and its bias) from G."""
-        K = sum(s.width for s in segs)
-        dst = grads.get(wname)
-        dev = G.device
-        if dst is None:
-            raise KeyError(wname)
-        dW = dst[row0:row0 + n_out]
-        db = grads[bname][row0:row0 + n_out] if bname is not None else None
-        assert dW.is_contiguous() and dW.shape[1] == K, (wname, dW.shape, K)
-        ops.linear_dw(G, n_out, segs, M, ldg=ldg, in_add=in_add, a_op=a_op, a_gamma=a_gamma, a_beta=a_beta, dW=dW, db=db,
-                      want_db=bname is not None, g_offset=g_offset)
+        grads.view(name).copy_(value.reshape(grads.shape[name]))
 
     # ------------------------------------------------------------------------------------------------------------
     # GnBlock (EPD.py:177-195, blocks.py)
@@ -209,7 +278,8 @@ class Engine:
         g_z = _empty(dev, N, 256)
         ops.rowtile_chain(N, [Seg(g_out)], [LayerSpec(ops.transpose(Wpost), None, L.OP_MUL_DGELU, aux=z)],
                           [(g_z, 256), (g_z.data_ptr() + 512, 256)])
-        self._dw(grads, f"{prefix}.mlp.linear_post.weight", f"{prefix}.mlp.linear_post.bias", g_out, 128, zsegs, N, a_op=1)
+        self._dw_block(grads, [(f"{prefix}.mlp.linear_post.weight", f"{prefix}.mlp.linear_post.bias", 2)],
+                       [self._tile(g_out, 128, zs, a_op=1) for zs in zsegs], N)
         # linear_pre behind LayerNorm ln_2
         tiles = ops.rowtile_tiles(N)
         part = _empty(dev, tiles, 2, 128)
@@ -218,16 +288,14 @@ class Engine:
         ops.rowtile_chain(N, [Seg(g_z, width=128, ld=256), Seg(g_z, width=128, ld=256, offset=128)],
                           [LayerSpec(ops.transpose(Wpre))], [g_fx1], fin_op=L.FIN_LNBWD, fin_gamma=gam2, fin_aux=fx1,
                           ln_partial=part, res=[g_out])
-        for h in range(2):
-            self._dw(grads, f"{prefix}.mlp.linear_pre.0.weight", f"{prefix}.mlp.linear_pre.0.bias", g_z, 128, [Seg(fx1)], N,
-                     a_op=2, a_gamma=gam2, a_beta=bet2, ldg=256, g_offset=128 * h, row0=128 * h)
-        gb = ops.reduce_partials(part, tiles, 256)
-        self._put(grads, f"{prefix}.ln_2.weight", gb[:128])
-        self._put(grads, f"{prefix}.ln_2.bias", gb[128:])
+        self._dw_block(grads, [(f"{prefix}.mlp.linear_pre.0.weight", f"{prefix}.mlp.linear_pre.0.bias", 2)],
+                       [self._tile(g_z, 128, Seg(fx1), a_op=2, a_gamma=gam2, a_beta=bet2, ldg=256, g_offset=128 * h)
+                        for h in range(2)], N, row0s=[0, 128])
+        ops.reduce_partials(part, tiles, 256, out=self._gview2(grads, f"{prefix}.ln_2.weight", f"{prefix}.ln_2.bias"))
         # to_out
         g_out_x = _empty(dev, N, 128)
         ops.rowtile_chain(N, [Seg(g_fx1)], [LayerSpec(ops.transpose(P[f"{a}.to_out.0.weight"]))], [g_out_x])
-        self._dw(grads, f"{a}.to_out.0.weight", f"{a}.to_out.0.bias", g_fx1, 128, [Seg(sv["out_x"])], N)
+        self._dw_block(grads, [(f"{a}.to_out.0.weight", f"{a}.to_out.0.bias", 1)], [self._tile(g_fx1, 128, Seg(sv["out_x"]))], N)
         # de-slice / attention / slice
         w, batch = sv["w"], pl.batch
         gw = _empty(dev, N, 256)
@@ -266,8 +334,9 @@ class Engine:
         t1, g_fx_in = _empty(dev, N, 128), _empty(dev, N, 128)
         ops.rowtile_chain(N, [Seg(g_fx_mid)], [LayerSpec(ops.transpose(P[f"{a}.in_project_fx.weight"]))], [t1], res=[g_fx1])
         ops.rowtile_chain(N, [Seg(g_x_mid)], [LayerSpec(ops.transpose(P[f"{a}.in_project_x.weight"]))], [g_fx_in], res=[t1])
-        self._dw(grads, f"{a}.in_project_fx.weight", f"{a}.in_project_fx.bias", g_fx_mid, 128, [Seg(fx_in)], N)
-        self._dw(grads, f"{a}.in_project_x.weight", f"{a}.in_project_x.bias", g_x_mid, 128, [Seg(fx_in)], N)
+        self._dw_block(grads, [(f"{a}.in_project_x.weight", f"{a}.in_project_x.bias", 1),
+                               (f"{a}.in_project_fx.weight", f"{a}.in_project_fx.bias", 1)],
+                       [self._tile(g_x_mid, 128, Seg(fx_in)), self._tile(g_fx_mid, 128, Seg(fx_in))], N)
         return g_fx_in
 
     # ------------------------------------------------------------------------------------------------------------

@@ -5,7 +5,7 @@ from __future__ import annotations
 
 import torch
 
-from .engine import Engine
+from .engine import Engine, GradStore
 from .plan import get_plan
 
 
@@ -15,7 +15,7 @@ def require_gpu(t):
 
 
 def _alloc_grads(names, tensors, skip=()):
-    return {n: torch.empty_like(t) for n, t in zip(names, tensors) if n not in skip}
+    return GradStore(names, [t.shape for t in tensors], tensors[0].device, skip=skip)
 
 
 def unused_param_names(names):
@@ -42,7 +42,7 @@ class GnBlockFn(torch.autograd.Function):
         if g_e is None:
             g_e = torch.zeros((ctx.plan.E, 128), device=dev)
         gx, ge = ctx.engine.gn_bwd(P, ctx.sv, g_x.contiguous(), g_e.contiguous(), grads, ctx.plan)
-        return (None, None, None, gx, ge) + tuple(grads[n] for n in ctx.names)
+        return (None, None, None, gx, ge) + tuple(grads.view(n) for n in ctx.names)
 
 
 class Mlp3Fn(torch.autograd.Function):
@@ -71,7 +71,7 @@ class Mlp3Fn(torch.autograd.Function):
             ctx.engine.mlp3_bwd(P, ctx.sv, g.contiguous(), grads, outs=[gx])
         else:
             ctx.engine.mlp3_bwd(P, ctx.sv, g.contiguous(), grads)
-        return (None, None, None, None, gx) + tuple(grads[n] for n in ctx.names)
+        return (None, None, None, None, gx) + tuple(grads.view(n) for n in ctx.names)
 
 
 class TransolverFn(torch.autograd.Function):
@@ -89,7 +89,7 @@ class TransolverFn(torch.autograd.Function):
         skip = unused_param_names(ctx.names)
         grads = _alloc_grads(ctx.names, [P[n] for n in ctx.names], skip)
         gfx = ctx.engine.trans_bwd(P, ctx.sv, g.contiguous(), grads, ctx.plan)
-        return (None, None, None, gfx) + tuple(grads.get(n) for n in ctx.names)
+        return (None, None, None, gfx) + tuple(grads.view(n) for n in ctx.names)
 
 
 class SimulatorFn(torch.autograd.Function):
@@ -107,7 +107,7 @@ class SimulatorFn(torch.autograd.Function):
         skip = unused_param_names(ctx.names)
         grads = _alloc_grads(ctx.names, [P[n] for n in ctx.names], skip)
         ctx.engine.simulator_bwd(P, ctx.sv, g.contiguous(), grads, ctx.plan)
-        return (None, None, None, None, None) + tuple(grads.get(n) for n in ctx.names)
+        return (None, None, None, None, None) + tuple(grads.view(n) for n in ctx.names)
 
 
 class IntegratorFn(torch.autograd.Function):
@@ -146,7 +146,7 @@ class ModelFn(torch.autograd.Function):
         skip = unused_param_names(ctx.names)
         grads = _alloc_grads(ctx.names, [P[n] for n in ctx.names], skip)
         ctx.engine.backward(P, ctx.sv, g_losses.contiguous(), grads, ctx.plan)
-        return (None, None, None, None, None, None) + tuple(grads.get(n) for n in ctx.names)
+        return (None, None, None, None, None, None) + tuple(grads.view(n) for n in ctx.names)
 
 
 __all__ = ["Engine", "get_plan", "GnBlockFn", "Mlp3Fn", "TransolverFn", "SimulatorFn", "IntegratorFn", "ModelFn",

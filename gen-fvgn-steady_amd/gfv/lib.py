@@ -42,6 +42,13 @@ class RowtileArgs(C.Structure):
     ]
 
 
+class DwTile(C.Structure):
+    _fields_ = [("G", C.c_void_p), ("A", C.c_void_p), ("idx", C.c_void_p), ("in_add", C.c_void_p),
+                ("a_gamma", C.c_void_p), ("a_beta", C.c_void_p), ("ldg", C.c_int32), ("n_out", C.c_int32),
+                ("width", C.c_int32), ("ld", C.c_int32), ("a_op", C.c_int32), ("ld_out", C.c_int32),
+                ("out_off", C.c_int64), ("db_off", C.c_int64)]
+
+
 _lib = None
 
 _SIGNATURES = {
@@ -64,6 +71,10 @@ _SIGNATURES = {
     "gfv_linear_dw_ex": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(Seg), C.c_int32, C.c_void_p, C.c_int32,
                                    C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
                                    C.c_int32, C.c_void_p]),
+    "gfv_dw_slabs": (C.c_int, [C.c_int32, C.c_int32, C.c_void_p]),
+    "gfv_dw_multi_workspace_floats": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int64]),
+    "gfv_dw_multi": (C.c_int, [C.POINTER(DwTile), C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32,
+                               C.c_void_p]),
     "gfv_reduce_partials": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
     "gfv_transpose": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "gfv_slice_softmax_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),

@@ -12,6 +12,7 @@ from __future__ import annotations
 import torch
 
 from . import lib as L
+from .engine import GradStore
 from .functions import unused_param_names
 from .plan import get_plan
 
@@ -35,25 +36,22 @@ class TrainStep:
 
         # flat parameter / gradient / moment buffers; the module's parameters become views of the flat buffer
         names, tensors = model.param_names_tensors()
-        total = sum((t.numel() + 3) // 4 * 4 for t in tensors)
+        skip = unused_param_names(names)
+        self.flat_g = None
+        self.G = GradStore(names, [t.shape for t in tensors], dev, skip=skip)
+        self.flat_g = self.G.flat
+        total = self.G.total
         self.flat_p = torch.zeros(total, dtype=torch.float32, device=dev)
-        self.flat_g = torch.zeros(total, dtype=torch.float32, device=dev)
         self.flat_m = torch.zeros(total, dtype=torch.float32, device=dev)
         self.flat_v = torch.zeros(total, dtype=torch.float32, device=dev)
         self.step_t = torch.zeros(1, dtype=torch.float32, device=dev)
-        self.P, self.G = {}, {}
-        skip = unused_param_names(names)
-        off = 0
+        self.P = {}
         for n, t in zip(names, tensors):
-            k = t.numel()
-            # keep every tensor 16-byte aligned inside the flat buffer (float4 loads in the kernels)
+            off, k = self.G.off[n], t.numel()
             view = self.flat_p[off:off + k].view(t.shape)
             view.copy_(t.data)
             t.data = view
             self.P[n] = view
-            if n not in skip:
-                self.G[n] = self.flat_g[off:off + k].view(t.shape)
-            off += (k + 3) // 4 * 4
         assert all(v.data_ptr() % 16 == 0 for v in self.P.values())
         self.n_params = total
         self.x = graphs[0].x

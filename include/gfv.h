@@ -121,6 +121,30 @@ int gfv_linear_dw_ex(const float* G, int32_t ldg, int32_t n_out, const gfv_seg_t
                      const float* in_add, int32_t a_op, const float* a_gamma, const float* a_beta, int32_t M,
                      float* dW, int32_t reserved, float* db, float* workspace, int32_t accumulate, void* stream);
 
+/* All weight gradients of one fused MLP (or any set of <= 6 output tiles) in ONE launch + ONE reduction.
+ * Tile t: dW_t[n,k] = sum_m G_t[m,n] * op(A_t[idx_t[m], k]) for n < n_out, k < width, written at
+ * block[out_off + n*ld_out + k]; if db_off >= 0 also block[db_off + n] = sum_m G_t[m,n].  `grad_block` is the
+ * contiguous gradient storage of the parameter block ([W1|b1|W2|b2|W3|b3] in state_dict order, each tensor padded
+ * to a multiple of 4 floats), block_floats its length.  workspace: gfv_dw_multi_workspace_floats(...) floats,
+ * zero-initialised once by the caller (padding slots are never written). */
+typedef struct {
+  const float* G;       /* [M, ldg] upstream gradient rows */
+  const float* A;       /* input rows [*, ld] */
+  const int32_t* idx;   /* optional gather index for A rows */
+  const float* in_add;  /* optional second addend for A (same idx / ld) */
+  const float* a_gamma; /* a_op == 2 */
+  const float* a_beta;
+  int32_t ldg, n_out, width, ld;
+  int32_t a_op;         /* 0 none, 1 GELU, 2 LayerNorm(a_gamma, a_beta) (width 128) */
+  int32_t ld_out;       /* row stride (K of the weight) inside the block */
+  int64_t out_off;      /* float offset of dW_t[0, 0] inside the block */
+  int64_t db_off;       /* float offset of the bias gradient, or -1 */
+} gfv_dw_tile_t;
+int gfv_dw_slabs(int32_t M, int32_t ntiles, int32_t* rows_per_slab);
+size_t gfv_dw_multi_workspace_floats(int32_t M, int32_t ntiles, int64_t block_floats);
+int gfv_dw_multi(const gfv_dw_tile_t* tiles, int32_t ntiles, int32_t M, int64_t block_floats, float* workspace,
+                 float* grad_block, int32_t accumulate, void* stream);
+
 /* out[j] (+)= sum_c partial[c, j]  (c < n_chunks, j < n) */
 int gfv_reduce_partials(const float* partial, int32_t n_chunks, int32_t n, float* out, int32_t accumulate,
                         void* stream);
