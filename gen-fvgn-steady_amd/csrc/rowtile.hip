@@ -81,35 +81,46 @@ __device__ __forceinline__ void wslice_store(float* Wb, const Ctx& c, const floa
   }
 }
 
-// one 32-wide k slice: acc[t] += X[wave rows][kx0..kx0+ksteps*16) * Wb^T
-__device__ __forceinline__ void mma_slice(floatx4 (&acc)[8], const float* Xs, const float* Wb, const Ctx& c, int kx0,
-                                         int ksteps, int ntiles) {
+// one 32-wide k slice: acc[t] += X[wave rows][kx0..kx0+KSTEPS*16) * Wb^T, statically unrolled (FAST kernel)
+template <int KSTEPS>
+__device__ __forceinline__ void mma_slice_full(floatx4 (&acc)[8], const float* Xs, const float* Wb, const Ctx& c, int kx0) {
+  const float* xrow = Xs + (c.wave * 16 + c.nl) * LDX + kx0 + 4 * c.q;
+  const float* wrow = Wb + c.nl * LDW + 4 * c.q;
+  float4 a[KSTEPS], b[KSTEPS][8];
+#pragma unroll
+  for (int ks = 0; ks < KSTEPS; ++ks) {
+    a[ks] = *reinterpret_cast<const float4*>(xrow + 16 * ks);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) b[ks][t] = *reinterpret_cast<const float4*>(wrow + t * 16 * LDW + 16 * ks);
+  }
+#pragma unroll
+  for (int ks = 0; ks < KSTEPS; ++ks) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks].x, b[ks][t].x, acc[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks].y, b[ks][t].y, acc[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks].z, b[ks][t].z, acc[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks].w, b[ks][t].w, acc[t], 0, 0, 0);
+  }
+}
+
+// generic slice (narrow outputs / 16-wide tails): only used by the non-FAST kernel
+__device__ __forceinline__ void mma_slice_generic(floatx4 (&acc)[8], const float* Xs, const float* Wb, const Ctx& c, int kx0,
+                                                  int ksteps, int ntiles) {
   const float* xrow = Xs + (c.wave * 16 + c.nl) * LDX + kx0 + 4 * c.q;
   const float* wrow = Wb + c.nl * LDW + 4 * c.q;
   for (int ks = 0; ks < ksteps; ++ks) {
     const float4 a = *reinterpret_cast<const float4*>(xrow + 16 * ks);
-    if (ntiles == 8) {
-      float4 b[8];
 #pragma unroll
-      for (int t = 0; t < 8; ++t) b[t] = *reinterpret_cast<const float4*>(wrow + t * 16 * LDW + 16 * ks);
-#pragma unroll
-      for (int t = 0; t < 8; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b[t].x, acc[t], 0, 0, 0);
-#pragma unroll
-      for (int t = 0; t < 8; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b[t].y, acc[t], 0, 0, 0);
-#pragma unroll
-      for (int t = 0; t < 8; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b[t].z, acc[t], 0, 0, 0);
-#pragma unroll
-      for (int t = 0; t < 8; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b[t].w, acc[t], 0, 0, 0);
-    } else {
-#pragma unroll
-      for (int t = 0; t < 8; ++t) {
-        if (t < ntiles) {
-          const float4 b = *reinterpret_cast<const float4*>(wrow + t * 16 * LDW + 16 * ks);
-          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc[t], 0, 0, 0);
-        }
+    for (int t = 0; t < 8; ++t) {
+      if (t < ntiles) {
+        const float4 b = *reinterpret_cast<const float4*>(wrow + t * 16 * LDW + 16 * ks);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc[t], 0, 0, 0);
       }
     }
   }
@@ -302,6 +313,9 @@ __device__ void final_epilogue(const gfv_rowtile_args_t& A, const gfv_layer_t& L
   }
 }
 
+// FAST: every layer width is a multiple of 128 and every input segment a multiple of 32 columns with 16-byte
+// aligned rows -> statically unrolled MFMA slices, accumulators never move between registers.
+template <bool FAST>
 __global__ __launch_bounds__(256, 2) void rowtile_chain_kernel(const gfv_rowtile_args_t A) {
   __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
   float* Xs = lds;
@@ -393,8 +407,12 @@ __global__ __launch_bounds__(256, 2) void rowtile_chain_kernel(const gfv_rowtile
             WSlice sn = make_slice(nl_, np_, nc_, nk_);
             wslice_load(sn, c, wreg);
           }
-          const int ksteps = (kpad - ks) >= WK ? 2 : 1;
-          mma_slice(acc, Xs, wbuf ? Wb1 : Wb0, c, ks, ksteps, ntiles);
+          if constexpr (FAST) {
+            mma_slice_full<2>(acc, Xs, wbuf ? Wb1 : Wb0, c, ks);
+          } else {
+            const int ksteps = (kpad - ks) >= WK ? 2 : 1;
+            mma_slice_generic(acc, Xs, wbuf ? Wb1 : Wb0, c, ks, ksteps, ntiles);
+          }
           if (have_next) wslice_store(wbuf ? Wb0 : Wb1, c, wreg);
           __syncthreads();
           wbuf ^= 1;
@@ -473,7 +491,16 @@ extern "C" int gfv_rowtile_chain(const gfv_rowtile_args_t* args, void* stream) {
     for (int c = 0; c < 3; ++c) if (args->res[c]) by += 4.0 * args->M * 128.0;
     tok = gfv_prof_begin(GFV_K_ROWTILE, fl, by, (hipStream_t)stream);
   }
-  hipLaunchKernelGGL(rowtile_chain_kernel, dim3(tiles), dim3(256), 0, (hipStream_t)stream, *args);
+  bool fast = true;
+  for (int i = 0; i < args->nseg; ++i)
+    fast = fast && (args->seg[i].width % 32 == 0) && (args->seg[i].ld % 4 == 0);
+  for (int l = 0; l < args->nlayers; ++l) fast = fast && (args->layer[l].N % 128 == 0) && (args->layer[l].K % 4 == 0);
+  for (int c = 0; c < 3; ++c)
+    if (args->out[c]) fast = fast && (args->out_ld[c] % 4 == 0);
+  if (fast)
+    hipLaunchKernelGGL(rowtile_chain_kernel<true>, dim3(tiles), dim3(256), 0, (hipStream_t)stream, *args);
+  else
+    hipLaunchKernelGGL(rowtile_chain_kernel<false>, dim3(tiles), dim3(256), 0, (hipStream_t)stream, *args);
   gfv_prof_end(tok, (hipStream_t)stream);
   GFV_CHECK_LAUNCH();
   return GFV_OK;

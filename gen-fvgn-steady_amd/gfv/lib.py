@@ -11,7 +11,7 @@ import os
 import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libgfv.so")
+LIB_PATH = os.environ.get("GFV_LIB", os.path.join(HERE, "libgfv.so"))
 
 c_float_p = C.c_void_p
 c_int_p = C.c_void_p
