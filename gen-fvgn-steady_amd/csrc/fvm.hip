@@ -132,7 +132,7 @@ __device__ __forceinline__ void load_An(const float* An, int i, LU5& m) {
 __global__ __launch_bounds__(256) void wlsq_fwd_kernel(const float* __restrict__ phi, const int* __restrict__ rowptr,
                                                        const int* __restrict__ outn, const float* __restrict__ Bp,
                                                        const float* __restrict__ An, const float* __restrict__ rn,
-                                                       float* __restrict__ grad, int N) {
+                                                       float* __restrict__ grad, float* __restrict__ full5, int N) {
   const int t = blockIdx.x * 256 + threadIdx.x;
   const int i = t >> 3, c = t & 7;
   if (i >= N) return;
@@ -154,6 +154,10 @@ __global__ __launch_bounds__(256) void wlsq_fwd_kernel(const float* __restrict__
     lu5_solve(m, rhs);
     grad[(size_t)i * 16 + 2 * c] = rhs[0];
     grad[(size_t)i * 16 + 2 * c + 1] = rhs[1];
+    if (full5) {
+#pragma unroll
+      for (int j = 0; j < 5; ++j) full5[((size_t)i * 8 + c) * 5 + j] = rhs[j];
+    }
   } else {
     grad[(size_t)i * 16 + 14] = 0.f;
     grad[(size_t)i * 16 + 15] = 0.f;
@@ -161,15 +165,21 @@ __global__ __launch_bounds__(256) void wlsq_fwd_kernel(const float* __restrict__
 }
 
 // WLSQ backward, stage 1: g_rhs[i,c,:] = (A_n^-T [g_grad[i,c,0:2],0,0,0]) / rn
-__global__ __launch_bounds__(256) void wlsq_bwd_solve_kernel(const float* __restrict__ ggrad, const float* __restrict__ An,
-                                                             const float* __restrict__ rn, float* __restrict__ grhs, int N) {
+__global__ __launch_bounds__(256) void wlsq_bwd_solve_kernel(const float* __restrict__ ggrad, const float* __restrict__ g5,
+                                                             const float* __restrict__ An, const float* __restrict__ rn,
+                                                             float* __restrict__ grhs, int N, int nch) {
   const int t = blockIdx.x * 256 + threadIdx.x;
   const int i = t >> 3, c = t & 7;
   if (i >= N) return;
   float b[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
-  if (c < 5) {  // channels 5,6 (uv_old) carry no gradient
-    b[0] = ggrad[(size_t)i * 16 + 2 * c];
-    b[1] = ggrad[(size_t)i * 16 + 2 * c + 1];
+  if (c < nch) {  // fused path: channels 5,6 (uv_old) carry no gradient
+    if (g5) {
+#pragma unroll
+      for (int j = 0; j < 5; ++j) b[j] = g5[((size_t)i * 8 + c) * 5 + j];
+    } else {
+      b[0] = ggrad[(size_t)i * 16 + 2 * c];
+      b[1] = ggrad[(size_t)i * 16 + 2 * c + 1];
+    }
     LU5 m;
     load_An(An, i, m);
     lu5_factor(m);
@@ -185,10 +195,10 @@ __global__ __launch_bounds__(256) void wlsq_bwd_solve_kernel(const float* __rest
 __global__ __launch_bounds__(256) void wlsq_bwd_gather_kernel(const float* __restrict__ grhs, const int* __restrict__ rowptr_o,
                                                               const int* __restrict__ inn, const float* __restrict__ Bo,
                                                               const float* __restrict__ sumB, float* __restrict__ gphi,
-                                                              int N) {
+                                                              int N, int nch) {
   const int t = blockIdx.x * 256 + threadIdx.x;
   const int j = t >> 3, c = t & 7;
-  if (j >= N || c >= 5) return;
+  if (j >= N || c >= nch) return;
   float s = 0.f;
   const int beg = rowptr_o[j], end = rowptr_o[j + 1];
   for (int k = beg; k < end; ++k) {
@@ -538,15 +548,29 @@ extern "C" int gfv_phi_bwd(const float* gphi, const float* dec, const int32_t* n
 
 extern "C" int gfv_wlsq_fwd(const float* phi, const int32_t* rowptr, const int32_t* outn, const float* Bp, const float* An,
                             const float* rn, float* grad, int32_t N, void* stream) {
-  LAUNCH1D(wlsq_fwd_kernel, (long)N * 8, stream, phi, rowptr, outn, Bp, An, rn, grad, N);
+  LAUNCH1D(wlsq_fwd_kernel, (long)N * 8, stream, phi, rowptr, outn, Bp, An, rn, grad, (float*)nullptr, N);
+  return GFV_OK;
+}
+
+extern "C" int gfv_wlsq_fwd_full(const float* phi, const int32_t* rowptr, const int32_t* outn, const float* Bp,
+                                 const float* An, const float* rn, float* grad, float* full5, int32_t N, void* stream) {
+  LAUNCH1D(wlsq_fwd_kernel, (long)N * 8, stream, phi, rowptr, outn, Bp, An, rn, grad, full5, N);
+  return GFV_OK;
+}
+
+extern "C" int gfv_wlsq_bwd_full(const float* g5, const float* An, const float* rn, const int32_t* rowptr_o,
+                                 const int32_t* inn, const float* Bo, const float* sumB, float* grhs_ws, float* gphi,
+                                 int32_t N, void* stream) {
+  LAUNCH1D(wlsq_bwd_solve_kernel, (long)N * 8, stream, (const float*)nullptr, g5, An, rn, grhs_ws, N, 7);
+  LAUNCH1D(wlsq_bwd_gather_kernel, (long)N * 8, stream, grhs_ws, rowptr_o, inn, Bo, sumB, gphi, N, 7);
   return GFV_OK;
 }
 
 extern "C" int gfv_wlsq_bwd(const float* ggrad, const float* An, const float* rn, const int32_t* rowptr_o,
                             const int32_t* inn, const float* Bo, const float* sumB, float* grhs_ws, float* gphi, int32_t N,
                             void* stream) {
-  LAUNCH1D(wlsq_bwd_solve_kernel, (long)N * 8, stream, ggrad, An, rn, grhs_ws, N);
-  LAUNCH1D(wlsq_bwd_gather_kernel, (long)N * 8, stream, grhs_ws, rowptr_o, inn, Bo, sumB, gphi, N);
+  LAUNCH1D(wlsq_bwd_solve_kernel, (long)N * 8, stream, ggrad, (const float*)nullptr, An, rn, grhs_ws, N, 5);
+  LAUNCH1D(wlsq_bwd_gather_kernel, (long)N * 8, stream, grhs_ws, rowptr_o, inn, Bo, sumB, gphi, N, 5);
   return GFV_OK;
 }
 

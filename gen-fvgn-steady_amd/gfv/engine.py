@@ -347,9 +347,20 @@ class Engine:
         st = L.stream_ptr()
         N, E, C, B = pl.N, pl.E, pl.C, pl.B
         dev = dec.device
-        phi, grad = _empty(dev, N, 8), _empty(dev, N, 16)
+        phi = _empty(dev, N, 8)
         L.check(lib.gfv_phi_fwd(dec.data_ptr(), pl.y.data_ptr(), pl.node_type.data_ptr(), uv_old.data_ptr(), phi.data_ptr(),
                                 N, self.mode, st), "phi_fwd")
+        losses, uvp_node, uvp_cell, sv = self.fvm_core_fwd(phi, pl, want_outputs)
+        sv["dec"] = dec
+        return losses, uvp_node, uvp_cell, sv
+
+    def fvm_core_fwd(self, phi, pl, want_outputs=True):
+        """phi [N,8] = (uvp_new, uv_hat, uv_old, 0) -> residual losses [B,4], smoothed node field, cell field."""
+        lib = L.load()
+        st = L.stream_ptr()
+        N, E, C, B = pl.N, pl.E, pl.C, pl.B
+        dev = phi.device
+        grad = _empty(dev, N, 16)
         L.check(lib.gfv_wlsq_fwd(phi.data_ptr(), pl.x_rowptr.data_ptr(), pl.x_out.data_ptr(), pl.x_B.data_ptr(),
                                  pl.An.data_ptr(), pl.rn.data_ptr(), grad.data_ptr(), N, st), "wlsq_fwd")
         Ff = _empty(dev, E, 16)
@@ -372,10 +383,19 @@ class Engine:
                                          pl.centroid.data_ptr(), pl.node_type.data_ptr(), pl.y.data_ptr(),
                                          pl.batch.data_ptr(), pl.uvp_dim.data_ptr(), pl.sigma.data_ptr(), phi.data_ptr(),
                                          self.smooth, uvp_node.data_ptr(), N, st), "cell_to_node")
-        sv = dict(dec=dec, Ff=Ff, cres=cres, sums=sums, phi=phi, grad=grad, phic=phic)
+        sv = dict(Ff=Ff, cres=cres, sums=sums, phi=phi, grad=grad, phic=phic)
         return losses, uvp_node, uvp_cell, sv
 
     def fvm_bwd(self, sv, gloss, pl):
+        lib = L.load()
+        gphi = self.fvm_core_bwd(sv, gloss, pl)
+        gdec = _empty(gloss.device, pl.N, 3)
+        L.check(lib.gfv_phi_bwd(gphi.data_ptr(), sv["dec"].data_ptr(), pl.node_type.data_ptr(), gdec.data_ptr(), pl.N,
+                                self.mode, L.stream_ptr()), "phi_bwd")
+        return gdec
+
+    def fvm_core_bwd(self, sv, gloss, pl):
+        """-> gphi [N,8] (channels 0..4 carry gradient; uv_old has none)."""
         lib = L.load()
         st = L.stream_ptr()
         N, E, C = pl.N, pl.E, pl.C
@@ -393,10 +413,7 @@ class Engine:
         L.check(lib.gfv_wlsq_bwd(ggrad.data_ptr(), pl.An.data_ptr(), pl.rn.data_ptr(), pl.xo_rowptr.data_ptr(),
                                  pl.xo_in.data_ptr(), pl.xo_B.data_ptr(), pl.sumB.data_ptr(), grhs.data_ptr(),
                                  gphi.data_ptr(), N, st), "wlsq_bwd")
-        gdec = _empty(dev, N, 3)
-        L.check(lib.gfv_phi_bwd(gphi.data_ptr(), sv["dec"].data_ptr(), pl.node_type.data_ptr(), gdec.data_ptr(), N,
-                                self.mode, st), "phi_bwd")
-        return gdec
+        return gphi
 
     # ------------------------------------------------------------------------------------------------------------
     # input preparation (importer.py:166-178)

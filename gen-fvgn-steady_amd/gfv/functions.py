@@ -20,7 +20,7 @@ def _alloc_grads(names, tensors, skip=()):
 
 def unused_param_names(names):
     """Parameters that exist in the reference state_dict but never receive a gradient."""
-    return {n for n in names if ".TransBlock.ln_1." in n or n.endswith(".Attn.temperature")}
+    return {n for n in names if ".ln_1." in ("." + n) or n.endswith("Attn.temperature")}
 
 
 class GnBlockFn(torch.autograd.Function):

@@ -1,0 +1,33 @@
+"""Data-parallel exchange of the hot path: ONE all-reduce(SUM) of the flat fp32 gradient per step, scaled by 1/world
+in the fused Adam.  Backend "nccl" (= RCCL over xGMI on the MI355X node), "gloo" in the CPU tests.
+Graphs are sharded by rank with equal counts, so the mean of the per-rank gradients of mean_b log(.) equals the gradient
+of the global-batch loss (pre_train_Adam.py:184)."""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n_items, rank, world):
+    """Contiguous, equal shards (rank r takes graphs r*k ... r*k+k-1)."""
+    if n_items % world:
+        raise ValueError("equal shards are required for the gradient mean to equal the global-batch gradient")
+    k = n_items // world
+    return range(rank * k, (rank + 1) * k)
+
+
+def allreduce_flat_grad(flat_grad, world, group=None):
+    if world > 1:
+        dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=group)
+    return 1.0 / world  # factor the optimiser applies
+
+
+def flat_pack(tensors, pad=4):
+    """Pack tensors (None -> zeros) into one flat buffer with every tensor aligned to `pad` floats."""
+    sizes = [((t.numel() + pad - 1) // pad) * pad for t in tensors]
+    flat = torch.zeros(sum(sizes), dtype=torch.float32, device=tensors[0].device)
+    off = 0
+    for t, s in zip(tensors, sizes):
+        flat[off:off + t.numel()] = t.reshape(-1)
+        off += s
+    return flat

@@ -113,6 +113,34 @@ def build_batch_plan(batch, plan=None):
     return plan
 
 
+def wlsq_part(p, face_node_x, support_edge, A, B1, Bx, N):
+    """Directed stencil [fx, fx.flip(0), support_edge] (FVgrad.py:264-271) in CSR order of the receiving node and of the
+    sending node, moment vectors permuted alongside (reverse direction: odd-order terms negated, FVgrad.py:299-312),
+    row-normalised A (FVgrad.py:335-337)."""
+    dev = face_node_x.device
+    i32 = lambda t: t.to(torch.int32).contiguous()
+    fx, sup = face_node_x, support_edge
+    out_idx = torch.cat((fx[0], fx[1], sup[0]))
+    in_idx = torch.cat((fx[1], fx[0], sup[1]))
+    B1 = B1.reshape(-1, 5)
+    Brev = B1.clone()
+    Brev[:, 0:2] *= -1
+    Bfull = torch.cat((B1, Brev, Bx.reshape(-1, 5)), 0).to(torch.float32)
+    p.x_rowptr, o_in = _csr(in_idx, N)
+    p.x_out = i32(out_idx[o_in])
+    p.x_B = Bfull[o_in].contiguous()
+    p.xo_rowptr, o_out = _csr(out_idx, N)
+    p.xo_in = i32(in_idx[o_out])
+    p.xo_B = Bfull[o_out].contiguous()
+    p.sumB = torch.zeros((N, 5), dtype=torch.float32, device=dev).index_add_(0, in_idx, Bfull).contiguous()
+    A = A.to(torch.float32)
+    row_norms = torch.norm(A, p=2, dim=2, keepdim=True)          # FVgrad.py:335
+    p.rn = (row_norms + 1e-8).reshape(N, 5).contiguous()
+    p.An = (A / (row_norms + 1e-8)).reshape(N, 25).contiguous()  # FVgrad.py:336
+    p.S = int(in_idx.shape[0])
+    return p
+
+
 def build_plan(graph_node, graph_node_x, graph_edge, graph_cell, graph_Index):
     p = MeshPlan()
     dev = graph_node.x.device
@@ -132,26 +160,8 @@ def build_plan(graph_node, graph_node_x, graph_edge, graph_cell, graph_Index):
     p.pos = f32(graph_node.pos)
 
     # ---- WLSQ stencil --------------------------------------------------------------------------------------------
-    fx = graph_node_x.face_node_x
-    sup = graph_node_x.support_edge
-    out_idx = torch.cat((fx[0], fx[1], sup[0]))
-    in_idx = torch.cat((fx[1], fx[0], sup[1]))
-    B1 = graph_node_x.single_B_node_to_node.reshape(-1, 5)
-    Brev = B1.clone()
-    Brev[:, 0:2] *= -1
-    Bfull = torch.cat((B1, Brev, graph_node_x.extra_B_node_to_node.reshape(-1, 5)), 0).to(torch.float32)
-    p.x_rowptr, o_in = _csr(in_idx, N)
-    p.x_out = i32(out_idx[o_in])
-    p.x_B = Bfull[o_in].contiguous()
-    p.xo_rowptr, o_out = _csr(out_idx, N)
-    p.xo_in = i32(in_idx[o_out])
-    p.xo_B = Bfull[o_out].contiguous()
-    p.sumB = torch.zeros((N, 5), dtype=torch.float32, device=dev).index_add_(0, in_idx, Bfull).contiguous()
-    A = graph_node_x.A_node_to_node.to(torch.float32)
-    row_norms = torch.norm(A, p=2, dim=2, keepdim=True)          # FVgrad.py:335
-    p.rn = (row_norms + 1e-8).reshape(N, 5).contiguous()
-    p.An = (A / (row_norms + 1e-8)).reshape(N, 25).contiguous()  # FVgrad.py:336
-    p.S = int(in_idx.shape[0])
+    wlsq_part(p, graph_node_x.face_node_x, graph_node_x.support_edge, graph_node_x.A_node_to_node,
+              graph_node_x.single_B_node_to_node, graph_node_x.extra_B_node_to_node, N)
 
     # ---- faces -------------------------------------------------------------------------------------------------
     p.ftype = i32(graph_edge.face_type.reshape(-1))

@@ -200,6 +200,11 @@ int gfv_wlsq_fwd(const float* phi, const int32_t* rowptr, const int32_t* outn, c
  * adds into gphi */
 int gfv_wlsq_bwd(const float* ggrad, const float* An, const float* rn, const int32_t* rowptr_o, const int32_t* inn,
                  const float* Bo, const float* sumB, float* grhs_ws, float* gphi, int32_t N, void* stream);
+/* stand-alone node_based_WLSQ: all five 2nd-order derivative entries, full5 / g5 laid out [N,8,5]; 7 channels */
+int gfv_wlsq_fwd_full(const float* phi, const int32_t* rowptr, const int32_t* outn, const float* Bp, const float* An,
+                      const float* rn, float* grad, float* full5, int32_t N, void* stream);
+int gfv_wlsq_bwd_full(const float* g5, const float* An, const float* rn, const int32_t* rowptr_o, const int32_t* inn,
+                      const float* Bo, const float* sumB, float* grhs_ws, float* gphi, int32_t N, void* stream);
 int gfv_face_fwd(const float* phi, const float* grad, const int32_t* es, const int32_t* er, const float* pos,
                  const float* fpos, const int32_t* ftype, const float* y, float* Ff, int32_t E, void* stream);
 int gfv_cell_fwd(const float* phi, const float* grad, const float* Ff, const float* pos, const int32_t* crow,

@@ -1,0 +1,179 @@
+"""GPU: the stand-alone operator API (same class names / signatures as the reference's FVMmodel sub-modules) and the
+fused TrainStep (flat buffers, fused Adam, hipGraph replay) against the oracle."""
+import pytest
+import torch
+
+import cases
+from oracle import fvgn_oracle as O
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def _load(module, P, prefix):
+    sd = module.state_dict()
+    for k in sd:
+        sd[k].copy_(P[f"{prefix}.{k}"])
+    module.load_state_dict(sd)
+    return module.cuda()
+
+
+@pytest.fixture(scope="module")
+def setup():
+    assert torch.cuda.is_available()
+    graphs = cases.make_graphs("cyl_cavity_b2")
+    P = O.init_parameters(cases.WEIGHT_SEED)
+    g = torch.Generator().manual_seed(5)
+    N, E = graphs[0].x.shape[0], graphs[0].edge_index.shape[1]
+    x = torch.randn(N, 128, generator=g)
+    e = torch.randn(E, 128, generator=g)
+    return graphs, P, x, e
+
+
+def test_gnblock_edgeblock_nodeblock(setup):
+    from FVMmodel.Models.FVGN.EPD import GnBlock
+    from gfv.graph import Data
+    graphs, P, x, e = setup
+    pre = "simulator.processpr_list.0.GN_block_list.1"
+    blk = _load(GnBlock(128), P, pre)
+    ei = graphs[0].edge_index
+    xg, eg = x.clone().requires_grad_(True), e.clone().requires_grad_(True)
+    Pg = {k: v.clone().requires_grad_(True) for k, v in P.items() if k.startswith(pre)}
+    ox, oe = O.gn_block(Pg, pre, xg, eg, ei)
+    wx, we = torch.randn_like(ox), torch.randn_like(oe)
+    ((ox * wx).sum() + (oe * we).sum()).backward()
+    xd, ed = x.cuda().requires_grad_(True), e.cuda().requires_grad_(True)
+    gd = Data(x=xd, edge_attr=ed, edge_index=ei.cuda(), face=None, num_graphs=2, batch=graphs[0].batch.cuda())
+    out = blk(gd)
+    assert rel(out.x, ox) < TOL and rel(out.edge_attr, oe) < TOL
+    ((out.x * wx.cuda()).sum() + (out.edge_attr * we.cuda()).sum()).backward()
+    assert rel(xd.grad, xg.grad) < 1e-4 and rel(ed.grad, eg.grad) < 1e-4
+    for k, p in blk.named_parameters():
+        assert rel(p.grad, Pg[f"{pre}.{k}"].grad) < 1e-4, k
+    # the two halves as stand-alone operators
+    oe2 = O.edge_block(P, pre + ".eb_module", x, e, ei)
+    out_e = blk.eb_module(Data(x=x.cuda(), edge_attr=e.cuda(), edge_index=ei.cuda(), face=None, num_graphs=2, batch=None))
+    assert rel(out_e.edge_attr, oe2) < TOL
+    ox2 = O.node_block(P, pre + ".nb_module", x, e, ei)
+    out_n = blk.nb_module(Data(x=x.cuda(), edge_attr=e.cuda(), edge_index=ei.cuda(), face=None, num_graphs=2, batch=None))
+    assert rel(out_n.x, ox2) < TOL
+
+
+def test_transolver_block(setup):
+    from FVMmodel.Models.GraphTransolver.GraphTransolver import Transolver_block
+    graphs, P, x, _ = setup
+    pre = "simulator.processpr_list.1.TransBlock"
+    blk = _load(Transolver_block(8, 128, 0, "gelu", 2, 32), P, pre)
+    batch = graphs[0].batch
+    xg = x.clone().requires_grad_(True)
+    Pg = {k: v.clone().requires_grad_(True) for k, v in P.items() if k.startswith(pre)}
+    o = O.transolver_block(Pg, pre, xg, batch, 2)
+    w = torch.randn_like(o)
+    (o * w).sum().backward()
+    xd = x.cuda().requires_grad_(True)
+    out = blk(xd, batch.cuda())
+    assert rel(out, o) < TOL
+    (out * w.cuda()).sum().backward()
+    assert rel(xd.grad, xg.grad) < 1e-4
+    gscale = max(float(v.grad.abs().max()) for v in Pg.values() if v.grad is not None)
+    for k, p in blk.named_parameters():
+        ref = Pg[f"{pre}.{k}"].grad
+        if ref is None:
+            assert p.grad is None, k
+            continue
+        err = float((p.grad.cpu().double() - ref.double()).abs().max())
+        assert err < 1e-4 * float(ref.abs().max()) + 1e-6 * gscale, (k, err)
+
+
+def test_simulator_encoder_decoder(setup):
+    from FVMmodel.Models.TransFVGN.TransFVGN_v2 import Simulator
+    from gfv.graph import Data
+    graphs, P, _, _ = setup
+    sim = _load(Simulator(3, 15, 12, 3), P, "simulator")
+    g0 = graphs[0]
+    xin = torch.randn(g0.x.shape[0], 12, generator=torch.Generator().manual_seed(1))
+    ea = O.relative_edge_attr(xin, g0.pos, g0.edge_index)
+    ref = O.simulator_v2(P, xin, ea, g0.edge_index, g0.batch, 2)
+    gd = Data(x=xin.cuda(), edge_attr=ea.cuda(), edge_index=g0.edge_index.cuda(), face=None, num_graphs=2,
+              batch=g0.batch.cuda())
+    out = sim(gd, None, None)
+    assert rel(out, ref) < TOL
+    latent, node_ = sim.encoder(gd)
+    assert rel(node_, O.mlp3(P, "simulator.encoder.nb_encoder", xin)) < TOL
+    assert rel(latent.edge_attr, O.mlp3(P, "simulator.encoder.eb_encoder", ea)) < TOL
+    assert rel(sim.decoder(latent), O.decoder(P, "simulator.decoder", O.mlp3(P, "simulator.encoder.nb_encoder", xin))) < TOL
+
+
+def test_integrator_and_wlsq_operators(setup):
+    from FVMmodel.FVdiscretization.FVscheme import Intergrator
+    from FVMmodel.FVdiscretization.FVgrad import node_based_WLSQ
+    from gfv.params import default_params
+    graphs, _, _, _ = setup
+    G = O.graph_tensors(*graphs)
+    gen = torch.Generator().manual_seed(3)
+    N = graphs[0].x.shape[0]
+    uvp = torch.randn(N, 3, generator=gen) * 0.3
+    uv_old = torch.randn(N, 2, generator=gen) * 0.3
+    uvp_g = uvp.clone().requires_grad_(True)
+    uv_hat = (uv_old + uvp_g[:, 0:2]) / 2
+    ref = O.integrator_conserved(uvp_g, uv_hat, uv_old, G, O.DEFAULT_HYPER)
+    w = torch.tensor([[6e4, 5e4, 5e4, 1.0]])
+    (torch.cat(ref[0:4], 1) * w).sum().backward()
+    cg = tuple(g.clone().to("cuda") for g in graphs)
+    ud = uvp.cuda().requires_grad_(True)
+    out = Intergrator()(uvp_new_node=ud, uv_hat_node=(uv_old.cuda() + ud[:, 0:2]) / 2, uv_old_node=uv_old.cuda(),
+                        graph_node=cg[0], graph_node_x=cg[1], graph_edge=cg[2], graph_cell=cg[3], graph_Index=cg[4],
+                        params=default_params())
+    for i in range(4):
+        assert rel(out[i], ref[i]) < TOL, i
+    assert rel(out[5], ref[5]) < TOL
+    (torch.cat(out[0:4], 1) * w.cuda()).sum().backward()
+    assert rel(ud.grad, uvp_g.grad) < 1e-4
+    # node_based_WLSQ stand-alone: all five 2nd-order entries and its adjoint
+    phi = torch.randn(N, 7, generator=gen)
+    pg = phi.clone().requires_grad_(True)
+    gref = O.node_based_WLSQ(pg, G["face_node_x"], G["support_edge"], G["A"], G["B1"], G["Bx"])
+    wg = torch.randn_like(gref)
+    (gref * wg).sum().backward()
+    pd = phi.cuda().requires_grad_(True)
+    gout = node_based_WLSQ(phi_node=pd, edge_index=cg[1].face_node_x, extra_edge_index=cg[1].support_edge,
+                           mesh_pos=cg[0].pos, order="2nd",
+                           precompute_Moments=[cg[1].A_node_to_node, cg[1].single_B_node_to_node, cg[1].extra_B_node_to_node])
+    assert rel(gout, gref) < 2e-5
+    (gout * wg.cuda()).sum().backward()
+    assert rel(pd.grad, pg.grad) < 1e-4
+    with pytest.raises(ValueError):
+        node_based_WLSQ(phi_node=pd, order="5th")
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_trainstep_tracks_oracle(use_graph):
+    """Flat-buffer TrainStep (fused loss / Adam, optional hipGraph replay) vs the oracle's train_step, 4 steps."""
+    from FVMmodel.importer import NNmodel
+    from gfv.params import default_params
+    from gfv.trainer import TrainStep
+    graphs = cases.make_graphs("cyl_b3")
+    P = O.init_parameters(cases.WEIGHT_SEED)
+    Po = {k: v.clone() for k, v in P.items()}
+    model = NNmodel(default_params(dataset_size=1))
+    sd = model.state_dict()
+    for k, v in P.items():
+        sd[k].copy_(v)
+    model.load_state_dict(sd)
+    model = model.cuda()
+    hg = tuple(g.clone().to("cuda") for g in graphs)
+    ts = TrainStep(model, hg, use_graph=use_graph)
+    buffers, state = O.new_normalizer_buffers(), {}
+    for step in range(4):
+        og = tuple(g.clone() for g in graphs)
+        oloss, oout, _ = O.train_step(Po, buffers, og, state, hyper={"dataset_size": 1})
+        loss = ts.step()
+        assert abs(float(loss) - float(oloss)) < 2e-5 * abs(float(oloss)), (step, float(loss), float(oloss))
+    assert rel(ts.uvp_node, oout[4]) < 1e-4
+    worst = max(rel(ts.P[k], Po[k]) for k in Po)
+    assert worst < 1e-4, worst
