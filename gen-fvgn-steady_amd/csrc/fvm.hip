@@ -329,19 +329,19 @@ __global__ __launch_bounds__(256) void cell_fwd_kernel(const CellArgs A) {
 }
 
 // per-graph sums of squares -> the four residual losses (FVscheme.py:158-164,184-188,243-250)
-__global__ __launch_bounds__(256) void graph_loss_kernel(const float* __restrict__ cres, const int* __restrict__ gcell_ptr,
+__global__ __launch_bounds__(1024) void graph_loss_kernel(const float* __restrict__ cres, const int* __restrict__ gcell_ptr,
                                                          const float* __restrict__ theta, const float* __restrict__ sigma,
                                                          float* __restrict__ sums, float* __restrict__ losses) {
-  __shared__ float red[4][256];
+  __shared__ float red[4][1024];
   const int b = blockIdx.x, tid = threadIdx.x;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  for (int c = gcell_ptr[b] + tid; c < gcell_ptr[b + 1]; c += 256) {
+  for (int c = gcell_ptr[b] + tid; c < gcell_ptr[b + 1]; c += 1024) {
     const float4 v = *reinterpret_cast<const float4*>(cres + (size_t)c * 4);
     s0 += v.x * v.x; s1 += v.y * v.y; s2 += v.z * v.z; s3 += v.w;
   }
   red[0][tid] = s0; red[1][tid] = s1; red[2][tid] = s2; red[3][tid] = s3;
   __syncthreads();
-  for (int o = 128; o >= 1; o >>= 1) {
+  for (int o = 512; o >= 1; o >>= 1) {
     if (tid < o) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) red[j][tid] += red[j][tid + o];
@@ -594,7 +594,7 @@ extern "C" int gfv_cell_fwd(const float* phi, const float* grad, const float* Ff
 extern "C" int gfv_graph_loss(const float* cres, const int32_t* gcell_ptr, const float* theta, const float* sigma,
                               float* sums, float* losses, int32_t B, void* stream) {
   if (B <= 0) return GFV_OK;
-  hipLaunchKernelGGL(graph_loss_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, cres, gcell_ptr, theta, sigma, sums,
+  hipLaunchKernelGGL(graph_loss_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, cres, gcell_ptr, theta, sigma, sums,
                      losses);
   GFV_CHECK_LAUNCH();
   return GFV_OK;

@@ -18,21 +18,21 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
 }
 
 // per graph: mean and population std of x[:,0:3] (importer.py:80-93), two passes like the reference
-__global__ __launch_bounds__(256) void graph_norm_stats_kernel(const float* __restrict__ x, int ldx,
+__global__ __launch_bounds__(1024) void graph_norm_stats_kernel(const float* __restrict__ x, int ldx,
                                                                const int* __restrict__ gnode_ptr, float* __restrict__ stats) {
-  __shared__ float red[4];
+  __shared__ float red[16];
   const int b = blockIdx.x, tid = threadIdx.x;
   const int beg = gnode_ptr[b], end = gnode_ptr[b + 1];
   const float cnt = fmaxf((float)(end - beg), 1.f);
   float mean[3];
   for (int c = 0; c < 3; ++c) {
     float s = 0.f;
-    for (int i = beg + tid; i < end; i += 256) s += x[(size_t)i * ldx + c];
+    for (int i = beg + tid; i < end; i += 1024) s += x[(size_t)i * ldx + c];
     mean[c] = block_sum(s, red) / cnt;
   }
   for (int c = 0; c < 3; ++c) {
     float s = 0.f;
-    for (int i = beg + tid; i < end; i += 256) {
+    for (int i = beg + tid; i < end; i += 1024) {
       const float d = x[(size_t)i * ldx + c] - mean[c];
       s += d * d;
     }
@@ -180,7 +180,7 @@ inline int cap_grid(long n) {
 extern "C" int gfv_graph_norm_stats(const float* x, int32_t ldx, const int32_t* gnode_ptr, int32_t B, float* stats,
                                     void* stream) {
   if (B <= 0) return GFV_OK;
-  hipLaunchKernelGGL(graph_norm_stats_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, x, ldx, gnode_ptr, stats);
+  hipLaunchKernelGGL(graph_norm_stats_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, x, ldx, gnode_ptr, stats);
   GFV_CHECK_LAUNCH();
   return GFV_OK;
 }

@@ -125,18 +125,26 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
 }
 
 // few outputs, many chunks (bias / LayerNorm partials): 32 columns x 8 chunk lanes per block, LDS tree at the end
-__global__ __launch_bounds__(256) void reduce_partials_small_kernel(const float* __restrict__ partial, int n_chunks, int n,
-                                                                    float* __restrict__ out, int accumulate) {
-  __shared__ float red[8][33];
+__global__ __launch_bounds__(1024) void reduce_partials_small_kernel(const float* __restrict__ partial, int n_chunks, int n,
+                                                                     float* __restrict__ out, int accumulate) {
+  __shared__ float red[32][33];
   const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
   const int j = blockIdx.x * 32 + cx;
-  float s = 0.f;
-  if (j < n)
-    for (int c = ry; c < n_chunks; c += 8) s += partial[(size_t)c * n + j];
-  red[ry][cx] = s;
+  float s0 = 0.f, s1 = 0.f;
+  if (j < n) {
+    int c = ry;
+    for (; c + 32 < n_chunks; c += 64) {
+      s0 += partial[(size_t)c * n + j];
+      s1 += partial[(size_t)(c + 32) * n + j];
+    }
+    if (c < n_chunks) s0 += partial[(size_t)c * n + j];
+  }
+  red[ry][cx] = s0 + s1;
   __syncthreads();
   if (ry == 0 && j < n) {
-    float t = ((red[0][cx] + red[1][cx]) + (red[2][cx] + red[3][cx])) + ((red[4][cx] + red[5][cx]) + (red[6][cx] + red[7][cx]));
+    float t = 0.f;
+#pragma unroll
+    for (int r = 0; r < 32; ++r) t += red[r][cx];
     if (accumulate) t += out[j];
     out[j] = t;
   }
@@ -231,7 +239,7 @@ extern "C" int gfv_reduce_partials(const float* partial, int32_t n_chunks, int32
                                    void* stream) {
   if (n <= 0) return GFV_OK;
   if (n <= 4096 && n_chunks >= 32) {
-    hipLaunchKernelGGL(reduce_partials_small_kernel, dim3((n + 31) / 32), dim3(256), 0, (hipStream_t)stream, partial,
+    hipLaunchKernelGGL(reduce_partials_small_kernel, dim3((n + 31) / 32), dim3(1024), 0, (hipStream_t)stream, partial,
                        n_chunks, n, out, accumulate);
     GFV_CHECK_LAUNCH();
     return GFV_OK;
@@ -246,6 +254,35 @@ extern "C" int gfv_transpose(const float* in, int32_t ld_in, float* out, int32_t
   if (rows <= 0 || cols <= 0) return GFV_ERR_ARG;
   hipLaunchKernelGGL(transpose_kernel, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(256), 0, (hipStream_t)stream, in,
                      ld_in, out, rows, cols);
+  GFV_CHECK_LAUNCH();
+  return GFV_OK;
+}
+
+namespace {
+__global__ __launch_bounds__(256) void transpose_batch_kernel(const gfv_transpose_desc_t* __restrict__ descs) {
+  __shared__ float tile[32][33];
+  const gfv_transpose_desc_t d = descs[blockIdx.z];
+  const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+  if (bx >= d.cols || by >= d.rows) return;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int j = ty; j < 32; j += 8) {
+    const int r = by + j, c = bx + tx;
+    tile[j][tx] = (r < d.rows && c < d.cols) ? d.in[(size_t)r * d.ld_in + c] : 0.f;
+  }
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8) {
+    const int c = bx + j, r = by + tx;
+    if (c < d.cols && r < d.rows) d.out[(size_t)c * d.rows + r] = tile[tx][j];
+  }
+}
+}  // namespace
+
+// All weight transposes of a step in one launch; descs lives in device memory.
+extern "C" int gfv_transpose_batch(const gfv_transpose_desc_t* descs, int32_t n, int32_t max_rows, int32_t max_cols,
+                                   void* stream) {
+  if (n <= 0) return GFV_OK;
+  hipLaunchKernelGGL(transpose_batch_kernel, dim3((max_cols + 31) / 32, (max_rows + 31) / 32, n), dim3(256), 0,
+                     (hipStream_t)stream, descs);
   GFV_CHECK_LAUNCH();
   return GFV_OK;
 }

@@ -204,8 +204,17 @@ __global__ __launch_bounds__(256) void slice_attention_fwd_kernel(const AttnFwdA
   const int c0 = A.gchunk_ptr[b], c1 = A.gchunk_ptr[b + 1];
   for (int idx = tid; idx < G * 17; idx += 256) {
     const int g = idx / 17, c = idx % 17;
-    float s = 0.f;
-    for (int ch = c0; ch < c1; ++ch) s += A.partial[((size_t)ch * 256 + h * G + g) * 17 + c];
+    const float* pp = A.partial + ((size_t)h * G + g) * 17 + c;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f, s5 = 0.f, s6 = 0.f, s7 = 0.f;
+    int ch = c0;
+    for (; ch + 8 <= c1; ch += 8) {  // 8 independent loads in flight, fixed summation order
+      s0 += pp[(size_t)(ch + 0) * 4352]; s1 += pp[(size_t)(ch + 1) * 4352];
+      s2 += pp[(size_t)(ch + 2) * 4352]; s3 += pp[(size_t)(ch + 3) * 4352];
+      s4 += pp[(size_t)(ch + 4) * 4352]; s5 += pp[(size_t)(ch + 5) * 4352];
+      s6 += pp[(size_t)(ch + 6) * 4352]; s7 += pp[(size_t)(ch + 7) * 4352];
+    }
+    for (; ch < c1; ++ch) s0 += pp[(size_t)ch * 4352];
+    const float s = ((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7));
     if (c < D) sTok[g][c] = s; else sNrm[g] = s;
   }
   __syncthreads();
@@ -281,9 +290,17 @@ __global__ __launch_bounds__(256) void slice_attention_bwd_kernel(const AttnBwdA
   const int c0 = A.gchunk_ptr[b], c1 = A.gchunk_ptr[b + 1];
   for (int idx = tid; idx < G * D; idx += 256) {
     const int g = idx / D, c = idx % D;
-    float s = 0.f;
-    for (int ch = c0; ch < c1; ++ch) s += A.gpartial[((size_t)ch * 256 + h * G + g) * 17 + c];
-    sGO[g][c] = s;  // grad wrt out_token
+    const float* pp = A.gpartial + ((size_t)h * G + g) * 17 + c;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f, s5 = 0.f, s6 = 0.f, s7 = 0.f;
+    int ch = c0;
+    for (; ch + 8 <= c1; ch += 8) {
+      s0 += pp[(size_t)(ch + 0) * 4352]; s1 += pp[(size_t)(ch + 1) * 4352];
+      s2 += pp[(size_t)(ch + 2) * 4352]; s3 += pp[(size_t)(ch + 3) * 4352];
+      s4 += pp[(size_t)(ch + 4) * 4352]; s5 += pp[(size_t)(ch + 5) * 4352];
+      s6 += pp[(size_t)(ch + 6) * 4352]; s7 += pp[(size_t)(ch + 7) * 4352];
+    }
+    for (; ch < c1; ++ch) s0 += pp[(size_t)ch * 4352];
+    sGO[g][c] = ((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7));  // grad wrt out_token
     sTok[g][c] = A.token[(size_t)bh * G * D + idx];
   }
   for (int idx = tid; idx < G * G; idx += 256) sA[idx / G][idx % G] = A.attn[(size_t)bh * G * G + idx];
@@ -362,32 +379,58 @@ __global__ __launch_bounds__(256) void slice_attention_bwd_kernel(const AttnBwdA
   }
 }
 
+// The slice tensor T[b] of a graph (8 heads x 32 x 16 floats = 16 KB) is staged in LDS when all 32 nodes of the block
+// belong to one graph (head stride 516 floats: the 8 heads of a wave hit disjoint bank quads); blocks that straddle a
+// graph boundary read T from L2.
+constexpr int TS = G * D + 4;
+
+__device__ __forceinline__ bool stage_T(const float* __restrict__ T, const int* __restrict__ batch, int N, float* sT) {
+  const int n_first = blockIdx.x * 32;
+  const int n_last = min(n_first + 31, N - 1);
+  const int b0 = batch[n_first];
+  const bool uniform = (batch[n_last] == b0);
+  if (uniform) {
+    const float4* src = reinterpret_cast<const float4*>(T + (size_t)b0 * H * G * D);
+    for (int i = threadIdx.x; i < H * G * D / 4; i += 256) {
+      const int h = i / (G * D / 4), r = i % (G * D / 4);
+      *reinterpret_cast<float4*>(&sT[h * TS + 4 * r]) = src[i];
+    }
+  }
+  __syncthreads();
+  return uniform;
+}
+
 // ---- de-slice:  out[n,h,c] = sum_g w[n,h,g] * T[b(n),h,g,c]    (thread per (n,h)) ------------------------------------
 __global__ __launch_bounds__(256) void deslice_kernel(const float* __restrict__ w, const float* __restrict__ T,
                                                       const int* __restrict__ batch, float* __restrict__ out, int N,
                                                       int accumulate) {
+  __shared__ __attribute__((aligned(16))) float sT[H * TS];
+  const bool uniform = stage_T(T, batch, N, sT);
   const long row = (long)blockIdx.x * 256 + threadIdx.x;
   if (row >= (long)N * H) return;
   const int n = (int)(row >> 3), h = (int)(row & 7);
-  const float* Tp = T + ((size_t)batch[n] * H + h) * G * D;
   float acc[D];
 #pragma unroll
   for (int c = 0; c < D; ++c) acc[c] = 0.f;
   const float4* wp = reinterpret_cast<const float4*>(w + row * G);
+  auto body = [&](const float* Tp) {
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const float4 wv = wp[i];
-    const float ww[4] = {wv.x, wv.y, wv.z, wv.w};
+    for (int i = 0; i < 8; ++i) {
+      const float4 wv = wp[i];
+      const float ww[4] = {wv.x, wv.y, wv.z, wv.w};
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const float4* tp = reinterpret_cast<const float4*>(Tp + (4 * i + k) * D);
+      for (int k = 0; k < 4; ++k) {
+        const float4* tp = reinterpret_cast<const float4*>(Tp + (4 * i + k) * D);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float4 t = tp[j];
-        acc[4 * j] += ww[k] * t.x; acc[4 * j + 1] += ww[k] * t.y; acc[4 * j + 2] += ww[k] * t.z; acc[4 * j + 3] += ww[k] * t.w;
+        for (int j = 0; j < 4; ++j) {
+          const float4 t = tp[j];
+          acc[4 * j] += ww[k] * t.x; acc[4 * j + 1] += ww[k] * t.y; acc[4 * j + 2] += ww[k] * t.z; acc[4 * j + 3] += ww[k] * t.w;
+        }
       }
     }
-  }
+  };
+  if (uniform) body(&sT[h * TS]);
+  else body(T + ((size_t)batch[n] * H + h) * G * D);
   float4* op = reinterpret_cast<float4*>(out + row * D);
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -401,11 +444,12 @@ __global__ __launch_bounds__(256) void deslice_kernel(const float* __restrict__ 
 __global__ __launch_bounds__(256) void slice_gw_kernel(const float* __restrict__ a, const float* __restrict__ T,
                                                        const float* __restrict__ add, const int* __restrict__ batch,
                                                        float* __restrict__ gw, int N, int accumulate) {
+  __shared__ __attribute__((aligned(16))) float sT[H * TS];
+  const bool uniform = stage_T(T, batch, N, sT);
   const long row = (long)blockIdx.x * 256 + threadIdx.x;
   if (row >= (long)N * H) return;
   const int n = (int)(row >> 3), h = (int)(row & 7);
   const size_t bh = (size_t)batch[n] * H + h;
-  const float* Tp = T + bh * G * D;
   float x[D];
   const float4* ap = reinterpret_cast<const float4*>(a + row * D);
 #pragma unroll
@@ -414,24 +458,28 @@ __global__ __launch_bounds__(256) void slice_gw_kernel(const float* __restrict__
     x[4 * i] = v.x; x[4 * i + 1] = v.y; x[4 * i + 2] = v.z; x[4 * i + 3] = v.w;
   }
   float4* op = reinterpret_cast<float4*>(gw + row * G);
+  auto body = [&](const float* Tp) {
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    float r[4];
+    for (int i = 0; i < 8; ++i) {
+      float r[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const float4* tp = reinterpret_cast<const float4*>(Tp + (4 * i + k) * D);
-      float s = add ? add[bh * G + 4 * i + k] : 0.f;
+      for (int k = 0; k < 4; ++k) {
+        const float4* tp = reinterpret_cast<const float4*>(Tp + (4 * i + k) * D);
+        float s = add ? add[bh * G + 4 * i + k] : 0.f;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float4 t = tp[j];
-        s += x[4 * j] * t.x + x[4 * j + 1] * t.y + x[4 * j + 2] * t.z + x[4 * j + 3] * t.w;
+        for (int j = 0; j < 4; ++j) {
+          const float4 t = tp[j];
+          s += x[4 * j] * t.x + x[4 * j + 1] * t.y + x[4 * j + 2] * t.z + x[4 * j + 3] * t.w;
+        }
+        r[k] = s;
       }
-      r[k] = s;
+      float4 v = make_float4(r[0], r[1], r[2], r[3]);
+      if (accumulate) { const float4 p = op[i]; v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w; }
+      op[i] = v;
     }
-    float4 v = make_float4(r[0], r[1], r[2], r[3]);
-    if (accumulate) { const float4 p = op[i]; v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w; }
-    op[i] = v;
-  }
+  };
+  if (uniform) body(&sT[h * TS]);
+  else body(T + bh * G * D);
 }
 
 }  // namespace

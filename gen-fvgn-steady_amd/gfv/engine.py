@@ -59,11 +59,63 @@ class GradStore:
 class Engine:
     def __init__(self, message_passing_num=3, integrator="imex", ncn_smooth=True, net="TransFVGN_v2"):
         self._dw_ws = None
+        self._wt, self._wt_key, self._wt_live = {}, None, False
         self.mp = message_passing_num
         self.mode = _MODE[integrator]
         self.smooth = 1 if ncn_smooth else 0
         self.n_proc = 2 if net in ("TransFVGN_v2", "TransFVGN") else 1
         self.net = net
+
+    # ------------------------------------------------------------------------------------------------------------
+    # transposed weights for the dX chains: one batched launch per step (prepare_transposes) or on demand
+    # ------------------------------------------------------------------------------------------------------------
+    def _T(self, W, perm=False):
+        """W^T ([in, out]); perm=True: NodeBlock first layer [128, 64+128] -> rows for x (128) first, then nbm (64)."""
+        hit = self._wt.get((W.data_ptr(), perm)) if self._wt_live else None
+        if hit is not None:
+            return hit
+        if not perm:
+            return ops.transpose(W)
+        out = _empty(W.device, 192, 128)
+        ops.transpose(W, out=out[0:128], col0=64, ncols=128)
+        ops.transpose(W, out=out[128:192], col0=0, ncols=64)
+        return out
+
+    def prepare_transposes(self, P):
+        """Transpose every weight the backward needs in ONE launch (descriptor table cached per parameter set)."""
+        lib = L.load()
+        key = tuple(t.data_ptr() for t in P.values())
+        if self._wt_key != key:
+            import ctypes as C
+            rows = []
+            self._wt = {}
+            dev = next(iter(P.values())).device
+            for n, W in P.items():
+                if not n.endswith(".weight") or W.dim() != 2:
+                    continue
+                if any(t in n for t in (".to_q.", ".to_k.", ".to_v.", ".in_project_slice.")):
+                    continue
+                if ".encoder." in n and n.endswith(".0.0.weight"):
+                    continue  # encoder inputs need no gradient
+                r, c = W.shape
+                if ".nb_module.net.0.0.weight" in n:
+                    out = _empty(dev, 192, 128)
+                    rows.append((W.data_ptr() + 4 * 64, out.data_ptr(), r, 128, c))
+                    rows.append((W.data_ptr(), out.data_ptr() + 4 * 128 * 128, r, 64, c))
+                    self._wt[(W.data_ptr(), True)] = out
+                else:
+                    out = _empty(dev, c, r)
+                    rows.append((W.data_ptr(), out.data_ptr(), r, c, c))
+                    self._wt[(W.data_ptr(), False)] = out
+            import struct
+            blob = b"".join(struct.pack("<QQiiii", a, b, r, c, ld, 0) for a, b, r, c, ld in rows)
+            self._wt_desc = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(dev)
+            self._wt_n = len(rows)
+            self._wt_max = (max(r[2] for r in rows), max(r[3] for r in rows))
+            self._wt_key = key
+        L.check(lib.gfv_transpose_batch(self._wt_desc.data_ptr(), self._wt_n, self._wt_max[0], self._wt_max[1],
+                                        L.stream_ptr()), "gfv_transpose_batch")
+        self._wt_live = True
 
     # ------------------------------------------------------------------------------------------------------------
     # fused 3-layer MLP (EPD.py:10-63)
@@ -101,7 +153,7 @@ class Engine:
         W1, W2, W3 = P[names[0]], P[names[2]], P[names[4]]
         dev = W1.device
         nout = W3.shape[0]
-        W3t, W2t = ops.transpose(W3), ops.transpose(W2)
+        W3t, W2t = self._T(W3), self._T(W2)
         gz2, gz1 = _empty(dev, M, 128), _empty(dev, M, 128)
         tiles_n = ops.rowtile_tiles(M)
         part = _empty(dev, tiles_n, 2, 128) if ln else None
@@ -112,7 +164,7 @@ class Engine:
             kw.update(gadd=gadd[0], gadd_s=gadd[1], gadd_r=gadd[2])
         if outs is not None:
             if W1t is None:
-                W1t = ops.transpose(W1)
+                W1t = self._T(W1)
             ops.rowtile_chain(M, [gseg],
                               [LayerSpec(W3t, None, L.OP_MUL_DGELU, save=gz2, aux=sv["z2"]),
                                LayerSpec(W2t, None, L.OP_MUL_DGELU, save=gz1, aux=sv["z1"]), LayerSpec(W1t)],
@@ -204,9 +256,7 @@ class Engine:
         dev = g_x_out.device
         prefix = sv["prefix"]
         W1n = P[f"{prefix}.nb_module.net.0.0.weight"]                      # [128, 64 + 128]
-        W1t = _empty(dev, 192, 128)
-        ops.transpose(W1n, out=W1t[0:128], col0=64, ncols=128)             # rows for x first, then nbm
-        ops.transpose(W1n, out=W1t[128:192], col0=0, ncols=64)
+        W1t = self._T(W1n, perm=True)                                       # rows for x first, then nbm
         g_x_in, g_nbm = _empty(dev, N, 128), _empty(dev, N, 64)
         self.mlp3_bwd(P, sv["sv_n"], g_x_out, grads, outs=[g_x_in, (g_nbm, 64)], res=[g_x_out, None], W1t=W1t)
         g_agg = ops.seg_gather_sum(g_nbm, pl.n_rowptr, pl.n_col_node, N, src_scale=pl.inv_deg)
@@ -276,7 +326,7 @@ class Engine:
         # linear_post
         Wpost, Wpre = P[f"{prefix}.mlp.linear_post.weight"], P[f"{prefix}.mlp.linear_pre.0.weight"]
         g_z = _empty(dev, N, 256)
-        ops.rowtile_chain(N, [Seg(g_out)], [LayerSpec(ops.transpose(Wpost), None, L.OP_MUL_DGELU, aux=z)],
+        ops.rowtile_chain(N, [Seg(g_out)], [LayerSpec(self._T(Wpost), None, L.OP_MUL_DGELU, aux=z)],
                           [(g_z, 256), (g_z.data_ptr() + 512, 256)])
         self._dw_block(grads, [(f"{prefix}.mlp.linear_post.weight", f"{prefix}.mlp.linear_post.bias", 2)],
                        [self._tile(g_out, 128, zs, a_op=1) for zs in zsegs], N)
@@ -286,7 +336,7 @@ class Engine:
         g_fx1 = _empty(dev, N, 128)
         gam2, bet2 = P[f"{prefix}.ln_2.weight"], P[f"{prefix}.ln_2.bias"]
         ops.rowtile_chain(N, [Seg(g_z, width=128, ld=256), Seg(g_z, width=128, ld=256, offset=128)],
-                          [LayerSpec(ops.transpose(Wpre))], [g_fx1], fin_op=L.FIN_LNBWD, fin_gamma=gam2, fin_aux=fx1,
+                          [LayerSpec(self._T(Wpre))], [g_fx1], fin_op=L.FIN_LNBWD, fin_gamma=gam2, fin_aux=fx1,
                           ln_partial=part, res=[g_out])
         self._dw_block(grads, [(f"{prefix}.mlp.linear_pre.0.weight", f"{prefix}.mlp.linear_pre.0.bias", 2)],
                        [self._tile(g_z, 128, Seg(fx1), a_op=2, a_gamma=gam2, a_beta=bet2, ldg=256, g_offset=128 * h)
@@ -294,7 +344,7 @@ class Engine:
         ops.reduce_partials(part, tiles, 256, out=self._gview2(grads, f"{prefix}.ln_2.weight", f"{prefix}.ln_2.bias"))
         # to_out
         g_out_x = _empty(dev, N, 128)
-        ops.rowtile_chain(N, [Seg(g_fx1)], [LayerSpec(ops.transpose(P[f"{a}.to_out.0.weight"]))], [g_out_x])
+        ops.rowtile_chain(N, [Seg(g_fx1)], [LayerSpec(self._T(P[f"{a}.to_out.0.weight"]))], [g_out_x])
         self._dw_block(grads, [(f"{a}.to_out.0.weight", f"{a}.to_out.0.bias", 1)], [self._tile(g_fx1, 128, Seg(sv["out_x"]))], N)
         # de-slice / attention / slice
         w, batch = sv["w"], pl.batch
@@ -332,8 +382,8 @@ class Engine:
         self._put(grads, f"{a}.graph_temperature", ds[544:552])
         # projections; fx_in also feeds the to_out residual
         t1, g_fx_in = _empty(dev, N, 128), _empty(dev, N, 128)
-        ops.rowtile_chain(N, [Seg(g_fx_mid)], [LayerSpec(ops.transpose(P[f"{a}.in_project_fx.weight"]))], [t1], res=[g_fx1])
-        ops.rowtile_chain(N, [Seg(g_x_mid)], [LayerSpec(ops.transpose(P[f"{a}.in_project_x.weight"]))], [g_fx_in], res=[t1])
+        ops.rowtile_chain(N, [Seg(g_fx_mid)], [LayerSpec(self._T(P[f"{a}.in_project_fx.weight"]))], [t1], res=[g_fx1])
+        ops.rowtile_chain(N, [Seg(g_x_mid)], [LayerSpec(self._T(P[f"{a}.in_project_x.weight"]))], [g_fx_in], res=[t1])
         self._dw_block(grads, [(f"{a}.in_project_x.weight", f"{a}.in_project_x.bias", 1),
                                (f"{a}.in_project_fx.weight", f"{a}.in_project_fx.bias", 1)],
                        [self._tile(g_x_mid, 128, Seg(fx_in)), self._tile(g_fx_mid, 128, Seg(fx_in))], N)
@@ -501,6 +551,10 @@ class Engine:
 
     def backward(self, P, ctx, gloss, grads, pl):
         """gloss [B,4] = dL/d(cont, mom_x, mom_y, press); fills `grads` (name -> preallocated tensor)."""
-        g_dec = self.fvm_bwd(ctx["fvm"], gloss, pl)
-        self.simulator_bwd(P, ctx["sim"], g_dec, grads, pl)
+        self.prepare_transposes(P)
+        try:
+            g_dec = self.fvm_bwd(ctx["fvm"], gloss, pl)
+            self.simulator_bwd(P, ctx["sim"], g_dec, grads, pl)
+        finally:
+            self._wt_live = False  # the cached transposes are only valid for this step's parameter values
         return grads

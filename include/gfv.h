@@ -149,6 +149,14 @@ int gfv_dw_multi(const gfv_dw_tile_t* tiles, int32_t ntiles, int32_t M, int64_t 
 int gfv_reduce_partials(const float* partial, int32_t n_chunks, int32_t n, float* out, int32_t accumulate,
                         void* stream);
 
+/* Batched form: one launch for all weight transposes of a step; `descs` [n] lives in DEVICE memory. */
+typedef struct {
+  const float* in; /* [rows, ld_in], columns [0, cols) are transposed */
+  float* out;      /* [cols, rows] */
+  int32_t rows, cols, ld_in, pad_;
+} gfv_transpose_desc_t;
+int gfv_transpose_batch(const gfv_transpose_desc_t* descs, int32_t n, int32_t max_rows, int32_t max_cols, void* stream);
+
 /* out [cols, rows] = in^T for a [rows, cols] fp32 matrix with row stride ld_in (weights for the dX chain). */
 int gfv_transpose(const float* in, int32_t ld_in, float* out, int32_t rows, int32_t cols, void* stream);
 
