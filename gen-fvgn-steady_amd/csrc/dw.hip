@@ -71,20 +71,28 @@ __device__ __forceinline__ void dw_body(const DwLaunch& A, const gfv_dw_tile_t& 
   const int m_end = min(m_beg + A.rows_per_slab, A.M);
   float4 greg[4], areg[4];
 
+  // loads only (rows clamped, no use of the data): the global latency overlaps the MFMAs of the current sub-tile;
+  // element ops (in_add, GELU / LayerNorm of the saved pre-activation, dead-row zeroing) happen at LDS-store time
+  float4 breg[4];
   auto load_sub = [&](int m0) {
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-      const int m = m0 + rg + 8 * p;
-      float4 g = make_float4(0.f, 0.f, 0.f, 0.f), a = g;
-      if (m < m_end) {
-        g = ld4(T.G, (size_t)m, T.ldg, col, FULL ? 128 : T.n_out, gvec);
-        const size_t srow = T.idx ? (size_t)T.idx[m] : (size_t)m;
-        a = ld4(T.A, srow, T.ld, col, FULL ? 128 : T.width, avec);
-        if (T.in_add) {
-          const float4 b = ld4(T.in_add, srow, T.ld, col, FULL ? 128 : T.width, avec);
-          a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
-        }
-      }
+      const int m = min(m0 + rg + 8 * p, m_end - 1);
+      greg[p] = ld4(T.G, (size_t)m, T.ldg, col, FULL ? 128 : T.n_out, gvec);
+      const size_t srow = T.idx ? (size_t)T.idx[m] : (size_t)m;
+      areg[p] = ld4(T.A, srow, T.ld, col, FULL ? 128 : T.width, avec);
+      if (T.in_add) breg[p] = ld4(T.in_add, srow, T.ld, col, FULL ? 128 : T.width, avec);
+    }
+  };
+  auto store_sub = [&](int buf, int m0) {
+    float* Gs = Gs0 + buf * 2 * SUB * LDT;
+    float* As = As0 + buf * 2 * SUB * LDT;
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const bool live = (m0 + rg + 8 * p) < m_end;
+      float4 g = greg[p], a = areg[p];
+      if (T.in_add) { a.x += breg[p].x; a.y += breg[p].y; a.z += breg[p].z; a.w += breg[p].w; }
       if (T.a_op == 1) {
         a = make_float4(gfv_gelu(a.x), gfv_gelu(a.y), gfv_gelu(a.z), gfv_gelu(a.w));
       } else if (T.a_op == 2) {
@@ -96,26 +104,17 @@ __device__ __forceinline__ void dw_body(const DwLaunch& A, const gfv_dw_tile_t& 
         a = make_float4(dx * rstd * gam.x + bet.x, dy * rstd * gam.y + bet.y, dz * rstd * gam.z + bet.z,
                         dw * rstd * gam.w + bet.w);
       }
-      if (m >= m_end) a = make_float4(0.f, 0.f, 0.f, 0.f);
-      greg[p] = g;
-      areg[p] = a;
-    }
-  };
-  auto store_sub = [&](int buf) {
-    float* Gs = Gs0 + buf * 2 * SUB * LDT;
-    float* As = As0 + buf * 2 * SUB * LDT;
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      *reinterpret_cast<float4*>(&Gs[(rg + 8 * p) * LDT + col]) = greg[p];
-      *reinterpret_cast<float4*>(&As[(rg + 8 * p) * LDT + col]) = areg[p];
-      dbacc.x += greg[p].x; dbacc.y += greg[p].y; dbacc.z += greg[p].z; dbacc.w += greg[p].w;
+      if (!live) { g = zero; a = zero; }
+      *reinterpret_cast<float4*>(&Gs[(rg + 8 * p) * LDT + col]) = g;
+      *reinterpret_cast<float4*>(&As[(rg + 8 * p) * LDT + col]) = a;
+      dbacc.x += g.x; dbacc.y += g.y; dbacc.z += g.z; dbacc.w += g.w;
     }
   };
 
   int buf = 0;
   if (m_beg < m_end) {
     load_sub(m_beg);
-    store_sub(0);
+    store_sub(0, m_beg);
   }
   __syncthreads();
   for (int m0 = m_beg; m0 < m_end; m0 += SUB) {
@@ -146,7 +145,7 @@ __device__ __forceinline__ void dw_body(const DwLaunch& A, const gfv_dw_tile_t& 
               acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(g[i], a[j], acc[i][j], 0, 0, 0);
       }
     }
-    if (more) store_sub(buf ^ 1);
+    if (more) store_sub(buf ^ 1, m0 + SUB);
     __syncthreads();
     buf ^= 1;
   }
