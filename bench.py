@@ -92,12 +92,18 @@ def main():
         raise SystemExit("launch with torch.distributed.run for --gpus > 1 (one process per GPU)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank % max(ndev, 1)  # one rank per GPU on the 8-GPU node; ranks share GPU 0 only in the 1-GPU self-test
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        backend = os.environ.get("GFV_DIST_BACKEND", "nccl")  # "nccl" IS RCCL on ROCm; "gloo" only for the self-test
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     from gfv import lib as L
     from gfv.params import default_params
@@ -134,16 +140,18 @@ def main():
     final_loss = float(ts.loss.item())
 
     # ---- roofline leg: same step, eager, HIP events around every launch of the main kernels -----------------
+    # every rank runs the instrumented steps (they contain the gradient all-reduce); rank 0 reports
     roof, roof_all = None, []
+    ts_use_graph = ts.use_graph
+    ts.use_graph = False
+    lib.gfv_profile_reset()
+    lib.gfv_profile_enable(1)
+    for _ in range(max(1, args.profile_steps)):
+        ts.step()
+    torch.cuda.synchronize()
+    lib.gfv_profile_enable(0)
+    ts.use_graph = ts_use_graph
     if rank == 0:
-        ts_use_graph = ts.use_graph
-        ts.use_graph = False
-        lib.gfv_profile_reset()
-        lib.gfv_profile_enable(1)
-        for _ in range(max(1, args.profile_steps)):
-            ts.step()
-        torch.cuda.synchronize()
-        lib.gfv_profile_enable(0)
         out = (ctypes.c_double * 4)()
         spec = {1: ("rowtile_chain_kernel", "mfma"), 2: ("linear_dw_kernel", "mfma"), 3: ("seg_gather_sum_vec", "hbm")}
         for kind, (kname, bound) in spec.items():
@@ -158,8 +166,6 @@ def main():
             roof_all.append({"kernel": kname, "bound": bound, "achieved": round(ach, 3), "peak": peak, "unit": unit,
                              "frac": round(ach / peak, 4), "traffic": None, "launches_per_step": n / args.profile_steps,
                              "avg_launch_us": round(1e3 * ms / n, 2), "ms_per_step": round(ms / args.profile_steps, 4)})
-        lib.gfv_profile_reset()
-        ts.use_graph = ts_use_graph
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
             traffic = json.load(open(pmc))
@@ -168,6 +174,7 @@ def main():
         if roof_all:
             roof = max(roof_all, key=lambda r: r["ms_per_step"])
 
+    lib.gfv_profile_reset()
     if world > 1:
         dist.barrier()
 
