@@ -56,3 +56,16 @@ def projection(n):
 def fingerprint(a):
     a = np.asarray(a, dtype=np.float64).reshape(-1)
     return np.array([a.sum(), np.sqrt((a * a).sum()), (a * projection(a.size)).sum()])
+
+
+def real_cylinder(golden_dir=None):
+    """The reference's own example mesh mesh_example/cylinder_flow_full_tri (raw reader arrays committed as data in
+    real_cylinder.npz by make_real_mesh_golden.py) -> (graphs, fixture)."""
+    import json
+    golden_dir = golden_dir or os.path.dirname(os.path.abspath(__file__))
+    fx = np.load(os.path.join(golden_dir, "real_cylinder.npz"))
+    raw = {k[4:]: (fx[k].astype(np.int64) if fx[k].dtype.kind == "i" else fx[k]) for k in fx.files
+           if k.startswith("raw.") and k != "raw.bc"}
+    raw["bc"] = json.loads(str(fx["raw.bc"]))
+    mesh = meshgen.finish_mesh(raw)
+    return build_batch([mesh], [fx["field"]]), fx

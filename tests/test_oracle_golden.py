@@ -79,3 +79,14 @@ def test_wlsq_known_answer(golden_dir):
     g = O.node_based_WLSQ(phi, t("face_node_x"), t("support_edge"), t("A_node_to_node"),
                           t("single_B_node_to_node"), t("extra_B_node_to_node"))
     assert _rel(g.numpy(), fx["grad"]) < TOL
+
+
+def test_oracle_on_reference_example_mesh(golden_dir):
+    """mesh_example/cylinder_flow_full_tri (7 798 nodes / 15 074 cells, COMSOL): raw arrays -> gfv.meshgen -> oracle,
+    against the outputs the reference produced on its own mesh pipeline (tests/golden/make_real_mesh_golden.py)."""
+    graphs, fx = cases.real_cylinder(golden_dir)
+    assert graphs[0].x.shape[0] == 7798 and graphs[3].pos.shape[0] == 15074 and graphs[0].edge_index.shape[1] == 22872
+    out = O.model_forward(O.init_parameters(cases.WEIGHT_SEED), O.new_normalizer_buffers(), graphs)
+    for i, key in enumerate(("loss_cont", "loss_mom_x", "loss_mom_y", "loss_press", "uvp_node", "uvp_cell")):
+        assert _rel(out[i].detach().numpy(), fx[key]) < TOL, key
+    assert abs(float(O.training_loss(out)) - float(fx["loss"])) < TOL * abs(float(fx["loss"]))
