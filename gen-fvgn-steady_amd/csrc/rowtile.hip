@@ -10,6 +10,7 @@
 // Operand trick: the k index inside a 16-wide k step is permuted consistently for A and B (lane group q takes
 // k = 4q..4q+3), so every lane fetches its four A (and four B) values of four consecutive MFMAs with ONE
 // ds_read_b128 from row-major [row][k] / [n][k] images - nn.Linear's [out,in] weight layout is read as stored.
+#include <stdlib.h>
 #include "gfv_common.h"
 #include "gfv_prof.h"
 #include "../../include/gfv.h"
@@ -451,6 +452,19 @@ __global__ __launch_bounds__(256, 2) void rowtile_chain_kernel(const gfv_rowtile
 
 }  // namespace
 
+int gfv_internal_tchain_launch(const gfv_rowtile_args_t* args, int rows_per_wg, hipStream_t stream);  // tchain.hip
+
+static int tchain_mode() {
+  // GFV_TCHAIN: 0 = LDS row-tile kernel for everything, 64 / 128 = register-resident chain with that many rows per
+  // workgroup (default 64)
+  static int mode = -1;
+  if (mode < 0) {
+    const char* e = getenv("GFV_TCHAIN");
+    mode = e ? atoi(e) : 64;
+  }
+  return mode;
+}
+
 extern "C" int gfv_rowtile_tiles(int32_t M) { return (M + BM - 1) / BM; }
 
 extern "C" int gfv_rowtile_chain(const gfv_rowtile_args_t* args, void* stream) {
@@ -497,7 +511,11 @@ extern "C" int gfv_rowtile_chain(const gfv_rowtile_args_t* args, void* stream) {
   for (int l = 0; l < args->nlayers; ++l) fast = fast && (args->layer[l].N % 128 == 0) && (args->layer[l].K % 4 == 0);
   for (int c = 0; c < 3; ++c)
     if (args->out[c]) fast = fast && (args->out_ld[c] % 4 == 0);
-  if (fast)
+  for (int c = 0; c < 3; ++c)
+    if (args->res[c]) fast = fast && (args->res_ld[c] % 4 == 0);
+  if (fast && tchain_mode() != 0)
+    gfv_internal_tchain_launch(args, tchain_mode(), (hipStream_t)stream);
+  else if (fast)
     hipLaunchKernelGGL(rowtile_chain_kernel<true>, dim3(tiles), dim3(256), 0, (hipStream_t)stream, *args);
   else
     hipLaunchKernelGGL(rowtile_chain_kernel<false>, dim3(tiles), dim3(256), 0, (hipStream_t)stream, *args);

@@ -1,0 +1,499 @@
+// Register-resident fused GEMM chain on fp32 MFMA (gfx950): the fast path behind gfv_rowtile_chain
+// (contract: include/gfv.h).  Used when every segment width is a multiple of 32 and every layer width a
+// multiple of 128; rowtile.hip keeps the generic shapes.
+//
+// Idea: compute the TRANSPOSED product.  For v_mfma_f32_16x16x4_f32 the A operand is the weight tile
+// (A[i][k] = W[16nt+i][k]) and the B operand the activations (B[k][j] = X[row j][k]), so the accumulator of lane
+// (j = lane&15, g = lane>>4) holds out[row j][16nt + 4g + r], r = 0..3.  With the contraction index of MFMA step
+// (t, s) chosen as k = 16t + 4g + s, the B operand of the NEXT layer for lane (j, g) at step (t, s) is exactly
+// accumulator register (nt = t, r = s) of this layer: activations never leave the registers between the layers of the
+// chain - no LDS round trip, no transposes, element ops (bias, GELU, GELU', LayerNorm, LayerNorm backward,
+// residuals) act on the accumulators in place, and inputs / saved tensors / outputs move as float4 per lane straight
+// between global memory and registers (one row per lane, the 4 g-lanes of a row cover 64 contiguous bytes).
+//
+// LDS holds only the weight stream: 32-wide k slices [128 n][32 k] (16 KB), double buffered, one barrier per slice.
+// The image is written linearly (thread tid -> bytes 16*tid + 4096*p) with the 16-B chunk index XOR-swizzled on the
+// SOURCE side (chunk c of row n sits in slot c ^ ((n>>1)&7)), which makes every ds_read_b128 lane group hit 16
+// distinct slots: the A fragments of four consecutive MFMAs come from one conflict-free ds_read_b128.
+#include "gfv_common.h"
+#include "gfv_prof.h"
+#include "../../include/gfv.h"
+
+#ifdef GFV_TIMING
+// phase timing build (scratch experiments only): per wave 10 int64 counters written through ln_partial
+#define TS_DECL long long ts_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; long long t_prev_ = clock64(); const long long t_start_ = t_prev_;
+#define TS(k) do { const long long now_ = clock64(); ts_[k] += now_ - t_prev_; t_prev_ = now_; } while (0)
+#define TS_WAIT() __builtin_amdgcn_s_waitcnt(0)
+#else
+#define TS_DECL
+#define TS(k)
+#define TS_WAIT()
+#endif
+
+namespace {
+
+constexpr int WK = 32;
+constexpr int WS_FLOATS = 128 * WK;  // one weight slice
+
+struct WBlk {
+  const float* w;  // &W[128*pass][koff]
+  int ldw;
+  int nsl;  // 32-wide slices in the block
+};
+
+__device__ __forceinline__ WBlk w_block(const gfv_rowtile_args_t& A, int layer, int pass, int chunk) {
+  const gfv_layer_t& L = A.layer[layer];
+  int koff = 0, width = 128;
+  if (layer == 0) {
+    for (int i = 0; i < chunk; ++i) koff += A.seg[i].width;
+    width = A.seg[chunk].width;
+  }
+  WBlk b;
+  b.w = L.W + (size_t)(128 * pass) * L.K + koff;
+  b.ldw = L.K;
+  b.nsl = width / WK;
+  return b;
+}
+
+// Weight prefetch registers are four NAMED native vectors and the load is unconditional (pointer picked with a
+// ternary): an array of HIP float4 filled under a branch is parked in scratch by the compiler with a vmcnt wait right
+// behind the load, which serialises the whole weight stream on the L2 latency.
+struct WRegs {
+  floatx4 a, b, c, d;
+};
+__device__ __forceinline__ WRegs w_load(const float* w, int ldw, int wrow, int wc) {
+  WRegs r;
+  const float* p0 = w + (size_t)wrow * ldw + wc;
+  const size_t step = (size_t)32 * ldw;
+  r.a = *reinterpret_cast<const floatx4*>(p0);
+  r.b = *reinterpret_cast<const floatx4*>(p0 + step);
+  r.c = *reinterpret_cast<const floatx4*>(p0 + 2 * step);
+  r.d = *reinterpret_cast<const floatx4*>(p0 + 3 * step);
+  return r;
+}
+__device__ __forceinline__ void w_store(float* Wb, int tid, const WRegs& r) {
+  *reinterpret_cast<floatx4*>(Wb + 4 * tid) = r.a;
+  *reinterpret_cast<floatx4*>(Wb + 4 * tid + 1024) = r.b;
+  *reinterpret_cast<floatx4*>(Wb + 4 * tid + 2048) = r.c;
+  *reinterpret_cast<floatx4*>(Wb + 4 * tid + 3072) = r.d;
+}
+
+// sum over the 4 lanes (g = 0..3) that share a row
+__device__ __forceinline__ float row_sum(float v) {
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
+  return v;
+}
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, const float (&v)[4]) {
+  *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+}
+
+// LayerNorm statistics of one row spread over 4 lanes x 8 x 4 registers
+__device__ __forceinline__ void ln_stats(const float (&v)[8][4], float& mean, float& rstd) {
+  float s = 0.f;
+#pragma unroll
+  for (int t = 0; t < 8; ++t) s += (v[t][0] + v[t][1]) + (v[t][2] + v[t][3]);
+  mean = row_sum(s) * (1.0f / 128.0f);
+  float q = 0.f;
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    const float d0 = v[t][0] - mean, d1 = v[t][1] - mean, d2 = v[t][2] - mean, d3 = v[t][3] - mean;
+    q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+  }
+  rstd = rsqrtf(row_sum(q) * (1.0f / 128.0f) + 1e-5f);  // nn.LayerNorm eps (EPD.py:32)
+}
+
+// v <- LayerNorm(v) * gamma + beta (gamma / beta at columns 16t + 4g + r)
+__device__ __forceinline__ void ln_apply(float (&v)[8][4], const float* gamma, const float* beta, int g) {
+  float mean, rstd;
+  ln_stats(v, mean, rstd);
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    const float4 ga = ld4(gamma + 16 * t + 4 * g), be = ld4(beta + 16 * t + 4 * g);
+    v[t][0] = (v[t][0] - mean) * rstd * ga.x + be.x;
+    v[t][1] = (v[t][1] - mean) * rstd * ga.y + be.y;
+    v[t][2] = (v[t][2] - mean) * rstd * ga.z + be.z;
+    v[t][3] = (v[t][3] - mean) * rstd * ga.w + be.w;
+  }
+}
+
+// LayerNorm backward of one row: y = LN input (pre-normalisation), go = grad wrt LN output (in v, replaced by the
+// grad wrt the LN input); accumulates this lane's 32 columns of dgamma / dbeta.
+__device__ __forceinline__ void ln_bwd(float (&v)[8][4], const float (&y)[8][4], const float* gamma, int g,
+                                       float (&dgam)[8][4], float (&dbet)[8][4]) {
+  float mean, rstd;
+  ln_stats(y, mean, rstd);
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    const float4 ga = ld4(gamma + 16 * t + 4 * g);
+    const float gv[4] = {ga.x, ga.y, ga.z, ga.w};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float xh = (y[t][r] - mean) * rstd;
+      dgam[t][r] += v[t][r] * xh;
+      dbet[t][r] += v[t][r];
+      v[t][r] *= gv[r];  // gg
+      s1 += v[t][r];
+      s2 += v[t][r] * xh;
+    }
+  }
+  const float m1 = row_sum(s1) * (1.0f / 128.0f), m2 = row_sum(s2) * (1.0f / 128.0f);
+#pragma unroll
+  for (int t = 0; t < 8; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[t][r] = rstd * (v[t][r] - m1 - ((y[t][r] - mean) * rstd) * m2);
+}
+
+// fold the lane-private (dgamma, dbeta) sums over the 16 rows of the wave and park them in LDS: red[wave][2][128]
+__device__ __forceinline__ void ln_park(float (&dgam)[8][4], float (&dbet)[8][4], float* red, int wave, int li, int g) {
+#pragma unroll
+  for (int t = 0; t < 8; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float a = dgam[t][r], b = dbet[t][r];
+#pragma unroll
+      for (int o = 8; o >= 1; o >>= 1) {
+        a += __shfl_xor(a, o, 64);
+        b += __shfl_xor(b, o, 64);
+      }
+      dgam[t][r] = a;
+      dbet[t][r] = b;
+    }
+  if (li == 0) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      st4(red + (wave * 2 + 0) * 128 + 16 * t + 4 * g, dgam[t]);
+      st4(red + (wave * 2 + 1) * 128 + 16 * t + 4 * g, dbet[t]);
+    }
+  }
+}
+
+// one 32-wide k slice: acc[tt][nt] += W[16nt + i][k] * act[tt][k], k = 16t + 4g + s for t in {2sl, 2sl+1}
+template <int T>
+__device__ __forceinline__ void mma_slice(floatx4 (&acc)[T][8], const float (&act)[T][8][4], int t0, const float* Wb, int off0) {
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    float4 w[8];
+    const float* wp = Wb + (h ? (off0 ^ 16) : off0);
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt) w[nt] = *reinterpret_cast<const float4*>(wp + 512 * nt);
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt)
+#pragma unroll
+      for (int tt = 0; tt < T; ++tt) acc[tt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[nt].x, act[tt][t0 + h][0], acc[tt][nt], 0, 0, 0);
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt)
+#pragma unroll
+      for (int tt = 0; tt < T; ++tt) acc[tt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[nt].y, act[tt][t0 + h][1], acc[tt][nt], 0, 0, 0);
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt)
+#pragma unroll
+      for (int tt = 0; tt < T; ++tt) acc[tt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[nt].z, act[tt][t0 + h][2], acc[tt][nt], 0, 0, 0);
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt)
+#pragma unroll
+      for (int tt = 0; tt < T; ++tt) acc[tt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[nt].w, act[tt][t0 + h][3], acc[tt][nt], 0, 0, 0);
+  }
+}
+
+// ---- input segment -> activation registers (gather / concat piece / prologue element ops) -------------------------
+template <int T, int LNM>
+__device__ __forceinline__ void load_segment(const gfv_rowtile_args_t& A, int si, int rowbase, int g, float (&act)[T][8][4],
+                                             float (&dgam)[8][4], float (&dbet)[8][4]) {
+  const gfv_seg_t& s = A.seg[si];
+  const int nt_valid = s.width >> 4;
+  const bool first = (si == 0);
+#pragma unroll
+  for (int tt = 0; tt < T; ++tt) {
+    const int m = rowbase + 16 * tt;
+    const bool live = m < A.M;
+    const int mc = live ? m : A.M - 1;
+    const size_t srow = s.idx ? (size_t)s.idx[mc] : (size_t)mc;
+    const float* rp = s.ptr + srow * (size_t)s.ld + 4 * g;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (t < nt_valid) v = ld4(rp + 16 * t);
+      act[tt][t][0] = v.x; act[tt][t][1] = v.y; act[tt][t][2] = v.z; act[tt][t][3] = v.w;
+    }
+    if (first && A.in_add) {
+      const float* ap = A.in_add + srow * (size_t)s.ld + 4 * g;
+#pragma unroll
+      for (int t = 0; t < 8; ++t)
+        if (t < nt_valid) {
+          const float4 v = ld4(ap + 16 * t);
+          act[tt][t][0] += v.x; act[tt][t][1] += v.y; act[tt][t][2] += v.z; act[tt][t][3] += v.w;
+        }
+    }
+    if (first && A.gadd) {
+      const float* gs = A.gadd + (size_t)A.gadd_s[mc] * 64 + 4 * g;
+      const float* gr = A.gadd + (size_t)A.gadd_r[mc] * 64 + 4 * g;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const float4 v = ld4((t < 4 ? gs : gr) + 16 * (t & 3));
+        act[tt][t][0] += v.x; act[tt][t][1] += v.y; act[tt][t][2] += v.z; act[tt][t][3] += v.w;
+      }
+    }
+    if (A.in_op == GFV_IN_GELU) {
+#pragma unroll
+      for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) act[tt][t][r] = gfv_gelu(act[tt][t][r]);
+    } else if (A.in_op == GFV_IN_LN) {
+      ln_apply(act[tt], A.in_gamma, A.in_beta, g);
+    } else if (LNM == 1 && A.in_op == GFV_IN_LNBWD) {
+      float y[8][4];
+      const float* yp = A.in_aux + (size_t)mc * 128 + 4 * g;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const float4 v = ld4(yp + 16 * t);
+        y[t][0] = v.x; y[t][1] = v.y; y[t][2] = v.z; y[t][3] = v.w;
+      }
+      if (!live) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) act[tt][t][r] = 0.f;
+      }
+      ln_bwd(act[tt], y, A.in_gamma, g, dgam, dbet);
+    }
+    if (!live) {
+#pragma unroll
+      for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) act[tt][t][r] = 0.f;
+    }
+    if (first && A.in_save && live) {
+      float* sp = A.in_save + (size_t)m * 128 + 4 * g;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) st4(sp + 16 * t, act[tt][t]);
+    }
+  }
+}
+
+// LNM: 0 = no LayerNorm backward, 1 = GFV_IN_LNBWD prologue, 2 = GFV_FIN_LNBWD epilogue (the (dgamma, dbeta)
+// accumulators exist only in those instantiations)
+template <int T, int LNM>
+__global__ __launch_bounds__(256, 2) void tchain_kernel(const gfv_rowtile_args_t A) {
+  __shared__ __attribute__((aligned(16))) float lds[2 * WS_FLOATS + 1024];
+  float* red = lds + 2 * WS_FLOATS;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, g = lane >> 4;
+  const int rowbase = blockIdx.x * (64 * T) + wave * (16 * T) + li;
+  // weight staging: thread -> row (tid>>3) + 32p, LDS slot tid&7, source chunk slot ^ ((row>>1)&7)
+  const int wrow = tid >> 3;
+  const int wc = 4 * ((tid & 7) ^ ((tid >> 4) & 7));
+  // fragment reads: row 16nt + li, chunk (4h + g) ^ ((li>>1)&7)
+  const int off0 = li * 32 + 4 * (g ^ ((li >> 1) & 7));
+
+  float act[T][8][4];
+  floatx4 acc[T][8];
+  constexpr bool lnb_in = (LNM == 1), lnb_fin = (LNM == 2);
+
+  int wbuf = 0;
+  TS_DECL
+  WBlk cur = w_block(A, 0, 0, 0);
+  WRegs wreg = w_load(cur.w, cur.ldw, wrow, wc);
+  w_store(lds, tid, wreg);
+  __syncthreads();
+  TS(0);
+
+  for (int layer = 0; layer < A.nlayers; ++layer) {
+    const gfv_layer_t& L = A.layer[layer];
+    const bool last = (layer == A.nlayers - 1);
+    const int npass = last ? L.N / 128 : 1;
+    const int nchunk = (layer == 0) ? A.nseg : 1;
+    for (int pass = 0; pass < npass; ++pass) {
+#pragma unroll
+      for (int tt = 0; tt < T; ++tt)
+#pragma unroll
+        for (int nt = 0; nt < 8; ++nt) acc[tt][nt] = floatx4{0.f, 0.f, 0.f, 0.f};
+      for (int chunk = 0; chunk < nchunk; ++chunk) {
+        // next block in the flat (layer, pass, chunk) order
+        int nl_ = layer, np_ = pass, nc_ = chunk + 1;
+        bool have_next = true;
+        if (nc_ >= nchunk) {
+          nc_ = 0;
+          np_ = pass + 1;
+          if (np_ >= npass) {
+            np_ = 0;
+            nl_ = layer + 1;
+            if (nl_ >= A.nlayers) have_next = false;
+          }
+        }
+        WBlk nxt = cur;
+        if (have_next) nxt = w_block(A, nl_, np_, nc_);
+        if (layer == 0 && (nchunk > 1 || pass == 0)) {
+          // (dgamma, dbeta) accumulators live only here: parked in LDS before the MFMA loop needs the registers
+          float dgam[8][4], dbet[8][4];
+          if (lnb_in) {
+#pragma unroll
+            for (int t = 0; t < 8; ++t)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) dgam[t][r] = dbet[t][r] = 0.f;
+          }
+          load_segment<T, LNM>(A, chunk, rowbase, g, act, dgam, dbet);
+          if (lnb_in) ln_park(dgam, dbet, red, wave, li, g);
+          TS_WAIT();
+          TS(1);
+        }
+#pragma unroll
+        for (int sl = 0; sl < 4; ++sl) {
+          if (sl < cur.nsl) {
+            // prefetch the next slice (after the very last one: a harmless reload of nxt == cur slice 0)
+            const bool more = (sl + 1 < cur.nsl);
+            wreg = w_load(more ? cur.w + WK * (sl + 1) : nxt.w, more ? cur.ldw : nxt.ldw, wrow, wc);
+            TS(2);
+            mma_slice<T>(acc, act, 2 * sl, lds + wbuf * WS_FLOATS, off0);
+            TS(3);
+            w_store(lds + (wbuf ^ 1) * WS_FLOATS, tid, wreg);
+            TS(4);
+            __syncthreads();
+            TS(5);
+            wbuf ^= 1;
+          }
+        }
+        cur = nxt;
+      }
+
+      if (!last) {
+        // ---- intermediate epilogue: accumulators -> next layer's activations, in registers ----
+#pragma unroll
+        for (int tt = 0; tt < T; ++tt) {
+          const int m = rowbase + 16 * tt;
+          const bool live = m < A.M;
+          const size_t mrow = (size_t)(live ? m : A.M - 1) * 128 + 4 * g;
+#pragma unroll
+          for (int nt = 0; nt < 8; ++nt) {
+            float v[4] = {acc[tt][nt][0], acc[tt][nt][1], acc[tt][nt][2], acc[tt][nt][3]};
+            if (L.op == GFV_OP_MUL_DGELU) {
+              const float4 z = ld4(L.aux + mrow + 16 * nt);
+              v[0] *= gfv_dgelu(z.x); v[1] *= gfv_dgelu(z.y); v[2] *= gfv_dgelu(z.z); v[3] *= gfv_dgelu(z.w);
+              if (L.save && live) st4(L.save + mrow + 16 * nt, v);
+            } else {
+              if (L.bias) {
+                const float4 b = ld4(L.bias + 16 * nt + 4 * g);
+                v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+              }
+              if (L.op == GFV_OP_BIAS_GELU) {
+                if (L.save && live) st4(L.save + mrow + 16 * nt, v);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = gfv_gelu(v[r]);
+              }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) act[tt][nt][r] = v[r];
+          }
+        }
+        TS_WAIT();
+        TS(6);
+      } else {
+        // ---- final epilogue for output chunk `pass` ----
+        float* out = pass == 0 ? A.out[0] : (pass == 1 ? A.out[1] : A.out[2]);
+        const float* res = pass == 0 ? A.res[0] : (pass == 1 ? A.res[1] : A.res[2]);
+        const int old = pass == 0 ? A.out_ld[0] : (pass == 1 ? A.out_ld[1] : A.out_ld[2]);
+        const int rld = pass == 0 ? A.res_ld[0] : (pass == 1 ? A.res_ld[1] : A.res_ld[2]);
+        float dgam[8][4], dbet[8][4];
+        if (lnb_fin) {
+#pragma unroll
+          for (int t = 0; t < 8; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dgam[t][r] = dbet[t][r] = 0.f;
+        }
+#pragma unroll
+        for (int tt = 0; tt < T; ++tt) {
+          const int m = rowbase + 16 * tt;
+          const bool live = m < A.M;
+          const size_t mc = (size_t)(live ? m : A.M - 1);
+          float v[8][4];
+#pragma unroll
+          for (int nt = 0; nt < 8; ++nt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[nt][r] = acc[tt][nt][r];
+            if (L.bias) {
+              const float4 b = ld4(L.bias + 128 * pass + 16 * nt + 4 * g);
+              v[nt][0] += b.x; v[nt][1] += b.y; v[nt][2] += b.z; v[nt][3] += b.w;
+            }
+            if (L.op == GFV_OP_MUL_DGELU) {
+              const float4 z = ld4(L.aux + mc * (size_t)L.N + 128 * pass + 16 * nt + 4 * g);
+              v[nt][0] *= gfv_dgelu(z.x); v[nt][1] *= gfv_dgelu(z.y); v[nt][2] *= gfv_dgelu(z.z); v[nt][3] *= gfv_dgelu(z.w);
+            }
+          }
+          if (A.fin_op == GFV_FIN_LN) {
+            if (A.fin_presave && live) {
+#pragma unroll
+              for (int nt = 0; nt < 8; ++nt) st4(A.fin_presave + mc * 128 + 16 * nt + 4 * g, v[nt]);
+            }
+            ln_apply(v, A.fin_gamma, A.fin_beta, g);
+          } else if (lnb_fin) {
+            float y[8][4];
+#pragma unroll
+            for (int nt = 0; nt < 8; ++nt) {
+              const float4 yy = ld4(A.fin_aux + mc * 128 + 16 * nt + 4 * g);
+              y[nt][0] = yy.x; y[nt][1] = yy.y; y[nt][2] = yy.z; y[nt][3] = yy.w;
+              if (!live) v[nt][0] = v[nt][1] = v[nt][2] = v[nt][3] = 0.f;
+            }
+            ln_bwd(v, y, A.fin_gamma, g, dgam, dbet);
+          }
+          if (live) {
+            if (pass == 0 && A.out_nores) {
+#pragma unroll
+              for (int nt = 0; nt < 8; ++nt) st4(A.out_nores + mc * 128 + 16 * nt + 4 * g, v[nt]);
+            }
+#pragma unroll
+            for (int nt = 0; nt < 8; ++nt) {
+              if (res) {
+                const float4 rv = ld4(res + mc * (size_t)rld + 16 * nt + 4 * g);
+                v[nt][0] += rv.x; v[nt][1] += rv.y; v[nt][2] += rv.z; v[nt][3] += rv.w;
+              }
+              st4(out + mc * (size_t)old + 16 * nt + 4 * g, v[nt]);
+            }
+          }
+        }
+        if (lnb_fin) ln_park(dgam, dbet, red, wave, li, g);
+        TS_WAIT();
+        TS(7);
+      }
+    }
+  }
+
+#ifdef GFV_TIMING
+  if (A.ln_partial && LNM == 0) {
+    ts_[8] = clock64() - t_start_;
+    ts_[9] = t_start_;
+    if (lane == 0)
+      for (int k = 0; k < 10; ++k) reinterpret_cast<long long*>(A.ln_partial)[((size_t)blockIdx.x * 4 + wave) * 10 + k] = ts_[k];
+    return;
+  }
+#endif
+  if (A.ln_partial) {
+    __syncthreads();
+    const float s = red[tid] + red[256 + tid] + red[512 + tid] + red[768 + tid];
+    // ln_partial rows are indexed by 64-row tile: a T-tile workgroup owns T consecutive rows
+    A.ln_partial[(size_t)blockIdx.x * T * 256 + tid] = s;
+#pragma unroll
+    for (int x = 1; x < T; ++x)
+      if (blockIdx.x * T + x < (A.M + 63) / 64) A.ln_partial[((size_t)blockIdx.x * T + x) * 256 + tid] = 0.f;
+  }
+}
+
+}  // namespace
+
+// fast-path launcher used by gfv_rowtile_chain (rowtile.hip); rows_per_wg: 64 or 128
+int gfv_internal_tchain_launch(const gfv_rowtile_args_t* args, int rows_per_wg, hipStream_t stream) {
+  const int lnm = args->in_op == GFV_IN_LNBWD ? 1 : (args->fin_op == GFV_FIN_LNBWD ? 2 : 0);
+  if (rows_per_wg == 128) {
+    const dim3 wgs((args->M + 127) / 128);
+    if (lnm == 0) hipLaunchKernelGGL((tchain_kernel<2, 0>), wgs, dim3(256), 0, stream, *args);
+    else if (lnm == 1) hipLaunchKernelGGL((tchain_kernel<2, 1>), wgs, dim3(256), 0, stream, *args);
+    else hipLaunchKernelGGL((tchain_kernel<2, 2>), wgs, dim3(256), 0, stream, *args);
+  } else {
+    const dim3 wgs((args->M + 63) / 64);
+    if (lnm == 0) hipLaunchKernelGGL((tchain_kernel<1, 0>), wgs, dim3(256), 0, stream, *args);
+    else if (lnm == 1) hipLaunchKernelGGL((tchain_kernel<1, 1>), wgs, dim3(256), 0, stream, *args);
+    else hipLaunchKernelGGL((tchain_kernel<1, 2>), wgs, dim3(256), 0, stream, *args);
+  }
+  return 0;
+}
