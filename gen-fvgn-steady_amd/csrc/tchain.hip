@@ -32,6 +32,9 @@
 
 namespace {
 
+#ifndef W_DIST
+#define W_DIST 1  // weight prefetch distance in slices (2 was measured: no gain, +33 VGPRs)
+#endif
 constexpr int WK = 32;
 constexpr int WS_FLOATS = 128 * WK;  // one weight slice
 
@@ -216,7 +219,11 @@ __device__ __forceinline__ void load_segment(const gfv_rowtile_args_t& A, int si
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+#ifndef ABL_NOSEG
       if (t < nt_valid) v = ld4(rp + 16 * t);
+#else
+      v = make_float4(0.001f * t, 0.002f, 0.003f * g, 0.004f);
+#endif
       act[tt][t][0] = v.x; act[tt][t][1] = v.y; act[tt][t][2] = v.z; act[tt][t][3] = v.w;
     }
     if (first && A.in_add) {
@@ -295,8 +302,16 @@ __global__ __launch_bounds__(256, 2) void tchain_kernel(const gfv_rowtile_args_t
   int wbuf = 0;
   TS_DECL
   WBlk cur = w_block(A, 0, 0, 0);
-  WRegs wreg = w_load(cur.w, cur.ldw, wrow, wc);
-  w_store(lds, tid, wreg);
+  // weight pipeline, prefetch distance 2: at the start of slice j (parity p) LDS buffer p holds slice j and register
+  // set 1-p holds slice j+1; slice j issues the loads of slice j+2 into set p, runs its MFMAs, then parks set 1-p in
+  // buffer 1-p.  Every block has an even number of slices, so the parity is the unrolled slice index.
+  WRegs wr0 = w_load(cur.w, cur.ldw, wrow, wc);
+  w_store(lds, tid, wr0);
+#if W_DIST == 2
+  WRegs wr1 = w_load(cur.w + WK, cur.ldw, wrow, wc);
+#else
+  WRegs wr1 = wr0;  // unused
+#endif
   __syncthreads();
   TS(0);
 
@@ -342,15 +357,33 @@ __global__ __launch_bounds__(256, 2) void tchain_kernel(const gfv_rowtile_args_t
 #pragma unroll
         for (int sl = 0; sl < 4; ++sl) {
           if (sl < cur.nsl) {
-            // prefetch the next slice (after the very last one: a harmless reload of nxt == cur slice 0)
+#if W_DIST == 2
+            // prefetch slice j+2 (past the end of the chain: a harmless reload, nxt == cur there)
+            const bool more = (sl + 2 < cur.nsl);
+            const float* wsrc = more ? cur.w + WK * (sl + 2) : nxt.w + WK * (sl + 2 - cur.nsl);
+#else
             const bool more = (sl + 1 < cur.nsl);
-            wreg = w_load(more ? cur.w + WK * (sl + 1) : nxt.w, more ? cur.ldw : nxt.ldw, wrow, wc);
+            const float* wsrc = more ? cur.w + WK * (sl + 1) : nxt.w;
+#endif
+            const int wld = more ? cur.ldw : nxt.ldw;
+#ifndef ABL_NOW
+            if (W_DIST == 1 || !(sl & 1)) wr0 = w_load(wsrc, wld, wrow, wc);
+            else wr1 = w_load(wsrc, wld, wrow, wc);
+#endif
+#ifndef NO_SCHEDB
+            __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ABOVE the MFMAs (the scheduler sinks it otherwise)
+#endif
             TS(2);
             mma_slice<T>(acc, act, 2 * sl, lds + wbuf * WS_FLOATS, off0);
             TS(3);
-            w_store(lds + (wbuf ^ 1) * WS_FLOATS, tid, wreg);
+#ifndef NO_SCHEDB
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+#ifndef ABL_NOW
+            w_store(lds + (wbuf ^ 1) * WS_FLOATS, tid, (W_DIST == 1 || (sl & 1)) ? wr0 : wr1);
             TS(4);
             __syncthreads();
+#endif
             TS(5);
             wbuf ^= 1;
           }
@@ -378,9 +411,13 @@ __global__ __launch_bounds__(256, 2) void tchain_kernel(const gfv_rowtile_args_t
                 v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
               }
               if (L.op == GFV_OP_BIAS_GELU) {
+#ifndef ABL_NOSTORE
                 if (L.save && live) st4(L.save + mrow + 16 * nt, v);
+#endif
+#ifndef ABL_NOGELU
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = gfv_gelu(v[r]);
+#endif
               }
             }
 #pragma unroll
@@ -422,10 +459,12 @@ __global__ __launch_bounds__(256, 2) void tchain_kernel(const gfv_rowtile_args_t
             }
           }
           if (A.fin_op == GFV_FIN_LN) {
+#ifndef ABL_NOSTORE
             if (A.fin_presave && live) {
 #pragma unroll
               for (int nt = 0; nt < 8; ++nt) st4(A.fin_presave + mc * 128 + 16 * nt + 4 * g, v[nt]);
             }
+#endif
             ln_apply(v, A.fin_gamma, A.fin_beta, g);
           } else if (lnb_fin) {
             float y[8][4];
@@ -438,10 +477,12 @@ __global__ __launch_bounds__(256, 2) void tchain_kernel(const gfv_rowtile_args_t
             ln_bwd(v, y, A.fin_gamma, g, dgam, dbet);
           }
           if (live) {
+#ifndef ABL_NOSTORE
             if (pass == 0 && A.out_nores) {
 #pragma unroll
               for (int nt = 0; nt < 8; ++nt) st4(A.out_nores + mc * 128 + 16 * nt + 4 * g, v[nt]);
             }
+#endif
 #pragma unroll
             for (int nt = 0; nt < 8; ++nt) {
               if (res) {
