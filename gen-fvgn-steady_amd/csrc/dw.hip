@@ -74,15 +74,30 @@ __device__ __forceinline__ void dw_body(const DwLaunch& A, const gfv_dw_tile_t& 
   // loads only (rows clamped, no use of the data): the global latency overlaps the MFMAs of the current sub-tile;
   // element ops (in_add, GELU / LayerNorm of the saved pre-activation, dead-row zeroing) happen at LDS-store time
   float4 breg[4];
+  // gather indices run one sub-tile ahead of the row loads, so the row loads never wait for an index round trip
+  int nidx[4];
+  auto load_idx = [&](int m0) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int m = min(m0 + rg + 8 * p, m_end - 1);
+      nidx[p] = T.idx ? T.idx[m] : m;
+    }
+  };
   auto load_sub = [&](int m0) {
+    size_t srow[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) srow[p] = (size_t)nidx[p];
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
       const int m = min(m0 + rg + 8 * p, m_end - 1);
       greg[p] = ld4(T.G, (size_t)m, T.ldg, col, FULL ? 128 : T.n_out, gvec);
-      const size_t srow = T.idx ? (size_t)T.idx[m] : (size_t)m;
-      areg[p] = ld4(T.A, srow, T.ld, col, FULL ? 128 : T.width, avec);
-      if (T.in_add) breg[p] = ld4(T.in_add, srow, T.ld, col, FULL ? 128 : T.width, avec);
     }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      areg[p] = ld4(T.A, srow[p], T.ld, col, FULL ? 128 : T.width, avec);
+      if (T.in_add) breg[p] = ld4(T.in_add, srow[p], T.ld, col, FULL ? 128 : T.width, avec);
+    }
+    load_idx(m0 + SUB);
   };
   auto store_sub = [&](int buf, int m0) {
     float* Gs = Gs0 + buf * 2 * SUB * LDT;
@@ -113,6 +128,7 @@ __device__ __forceinline__ void dw_body(const DwLaunch& A, const gfv_dw_tile_t& 
 
   int buf = 0;
   if (m_beg < m_end) {
+    load_idx(m_beg);
     load_sub(m_beg);
     store_sub(0, m_beg);
   }

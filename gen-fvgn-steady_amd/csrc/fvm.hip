@@ -69,9 +69,16 @@ __device__ __forceinline__ void lu5_factor(LU5& m) {
       if (v > mx) { mx = v; p = r; }
     }
     m.piv[k] = p;
-    if (p != k) {
+    // row swap with static register indices (a[p][c] with a run-time p would put the matrix in scratch memory)
 #pragma unroll
-      for (int c = 0; c < 5; ++c) { const float t = m.a[k][c]; m.a[k][c] = m.a[p][c]; m.a[p][c] = t; }
+    for (int r = k + 1; r < 5; ++r) {
+      const bool sw = (p == r);
+#pragma unroll
+      for (int c = 0; c < 5; ++c) {
+        const float tk = m.a[k][c], tr = m.a[r][c];
+        m.a[k][c] = sw ? tr : tk;
+        m.a[r][c] = sw ? tk : tr;
+      }
     }
     const float inv = 1.0f / m.a[k][k];
 #pragma unroll
@@ -87,7 +94,13 @@ __device__ __forceinline__ void lu5_solve(const LU5& m, float (&b)[5]) {
 #pragma unroll
   for (int k = 0; k < 5; ++k) {
     const int p = m.piv[k];
-    if (p != k) { const float t = b[k]; b[k] = b[p]; b[p] = t; }
+#pragma unroll
+    for (int r = k + 1; r < 5; ++r) {
+      const bool sw = (p == r);
+      const float tk = b[k], tr = b[r];
+      b[k] = sw ? tr : tk;
+      b[r] = sw ? tk : tr;
+    }
   }
 #pragma unroll
   for (int k = 0; k < 5; ++k)
@@ -116,7 +129,13 @@ __device__ __forceinline__ void lu5_solve_t(const LU5& m, float (&b)[5]) {
 #pragma unroll
   for (int k = 4; k >= 0; --k) {  // x = P^T mu
     const int p = m.piv[k];
-    if (p != k) { const float t = b[k]; b[k] = b[p]; b[p] = t; }
+#pragma unroll
+    for (int r = k + 1; r < 5; ++r) {
+      const bool sw = (p == r);
+      const float tk = b[k], tr = b[r];
+      b[k] = sw ? tr : tk;
+      b[r] = sw ? tk : tr;
+    }
   }
 }
 

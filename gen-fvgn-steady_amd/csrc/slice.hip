@@ -401,6 +401,24 @@ __device__ __forceinline__ bool stage_T(const float* __restrict__ T, const int* 
 }
 
 // ---- de-slice:  out[n,h,c] = sum_g w[n,h,g] * T[b(n),h,g,c]    (thread per (n,h)) ------------------------------------
+// (a plain function, not a lambda capturing acc by reference: the closure kept acc[] in scratch memory)
+__device__ __forceinline__ void deslice_row(const float4* __restrict__ wp, const float* __restrict__ Tp, float (&acc)[D]) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const float4 wv = wp[i];
+    const float ww[4] = {wv.x, wv.y, wv.z, wv.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float4* tp = reinterpret_cast<const float4*>(Tp + (4 * i + k) * D);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float4 t = tp[j];
+        acc[4 * j] += ww[k] * t.x; acc[4 * j + 1] += ww[k] * t.y; acc[4 * j + 2] += ww[k] * t.z; acc[4 * j + 3] += ww[k] * t.w;
+      }
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void deslice_kernel(const float* __restrict__ w, const float* __restrict__ T,
                                                       const int* __restrict__ batch, float* __restrict__ out, int N,
                                                       int accumulate) {
@@ -413,24 +431,8 @@ __global__ __launch_bounds__(256) void deslice_kernel(const float* __restrict__ 
 #pragma unroll
   for (int c = 0; c < D; ++c) acc[c] = 0.f;
   const float4* wp = reinterpret_cast<const float4*>(w + row * G);
-  auto body = [&](const float* Tp) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const float4 wv = wp[i];
-      const float ww[4] = {wv.x, wv.y, wv.z, wv.w};
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const float4* tp = reinterpret_cast<const float4*>(Tp + (4 * i + k) * D);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float4 t = tp[j];
-          acc[4 * j] += ww[k] * t.x; acc[4 * j + 1] += ww[k] * t.y; acc[4 * j + 2] += ww[k] * t.z; acc[4 * j + 3] += ww[k] * t.w;
-        }
-      }
-    }
-  };
-  if (uniform) body(&sT[h * TS]);
-  else body(T + ((size_t)batch[n] * H + h) * G * D);
+  if (uniform) deslice_row(wp, &sT[h * TS], acc);
+  else deslice_row(wp, T + ((size_t)batch[n] * H + h) * G * D, acc);
   float4* op = reinterpret_cast<float4*>(out + row * D);
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
