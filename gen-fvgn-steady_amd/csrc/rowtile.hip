@@ -10,6 +10,7 @@
 // Operand trick: the k index inside a 16-wide k step is permuted consistently for A and B (lane group q takes
 // k = 4q..4q+3), so every lane fetches its four A (and four B) values of four consecutive MFMAs with ONE
 // ds_read_b128 from row-major [row][k] / [n][k] images - nn.Linear's [out,in] weight layout is read as stored.
+#include <stdio.h>
 #include <stdlib.h>
 #include "gfv_common.h"
 #include "gfv_prof.h"
@@ -509,11 +510,26 @@ extern "C" int gfv_rowtile_chain(const gfv_rowtile_args_t* args, void* stream) {
   for (int i = 0; i < args->nseg; ++i)
     fast = fast && (args->seg[i].width % 32 == 0) && (args->seg[i].ld % 4 == 0);
   for (int l = 0; l < args->nlayers; ++l) fast = fast && (args->layer[l].N % 128 == 0) && (args->layer[l].K % 4 == 0);
-  for (int c = 0; c < 3; ++c)
-    if (args->out[c]) fast = fast && (args->out_ld[c] % 4 == 0);
-  for (int c = 0; c < 3; ++c)
-    if (args->res[c]) fast = fast && (args->res_ld[c] % 4 == 0);
-  if (fast && tchain_mode() != 0)
+  // the register-resident chain also takes a last layer whose final 128-chunk is 64 wide (NodeBlock dX: 128 + 64)
+  bool fast_t = true;
+  for (int i = 0; i < args->nseg; ++i) fast_t = fast_t && (args->seg[i].width % 32 == 0) && (args->seg[i].ld % 4 == 0);
+  for (int l = 0; l < args->nlayers; ++l) {
+    const bool lastl = (l == args->nlayers - 1);
+    fast_t = fast_t && (args->layer[l].K % 4 == 0) && (args->layer[l].N % (lastl ? 64 : 128) == 0);
+  }
+  if (args->fin_op != GFV_FIN_PLAIN) fast_t = fast_t && last.N == 128;
+  for (int c = 0; c < 3; ++c) {
+    if (args->out[c]) { fast = fast && (args->out_ld[c] % 4 == 0); fast_t = fast_t && (args->out_ld[c] % 4 == 0); }
+    if (args->res[c]) { fast = fast && (args->res_ld[c] % 4 == 0); fast_t = fast_t && (args->res_ld[c] % 4 == 0); }
+  }
+  static const bool dbg = getenv("GFV_ROWTILE_DEBUG") != nullptr;
+  if (dbg && !fast_t) {
+    fprintf(stderr, "[gfv] generic rowtile: M=%d nseg=%d widths=%d,%d,%d ld0=%d nlayers=%d K0=%d Nlast=%d out_ld=%d in_op=%d fin_op=%d\n",
+            args->M, args->nseg, args->seg[0].width, args->nseg > 1 ? args->seg[1].width : 0,
+            args->nseg > 2 ? args->seg[2].width : 0, args->seg[0].ld, args->nlayers, args->layer[0].K, last.N,
+            args->out_ld[0], args->in_op, args->fin_op);
+  }
+  if (fast_t && tchain_mode() != 0)
     gfv_internal_tchain_launch(args, tchain_mode(), (hipStream_t)stream);
   else if (fast)
     hipLaunchKernelGGL(rowtile_chain_kernel<true>, dim3(tiles), dim3(256), 0, (hipStream_t)stream, *args);

@@ -41,7 +41,8 @@ constexpr int WS_FLOATS = 128 * WK;  // one weight slice
 struct WBlk {
   const float* w;  // &W[128*pass][koff]
   int ldw;
-  int nsl;  // 32-wide slices in the block
+  int nsl;    // 32-wide slices in the block
+  int nrows;  // valid output rows of the block (128, or the 64-wide tail of a 192-wide last layer)
 };
 
 __device__ __forceinline__ WBlk w_block(const gfv_rowtile_args_t& A, int layer, int pass, int chunk) {
@@ -55,6 +56,7 @@ __device__ __forceinline__ WBlk w_block(const gfv_rowtile_args_t& A, int layer, 
   b.w = L.W + (size_t)(128 * pass) * L.K + koff;
   b.ldw = L.K;
   b.nsl = width / WK;
+  b.nrows = min(128, L.N - 128 * pass);
   return b;
 }
 
@@ -64,14 +66,14 @@ __device__ __forceinline__ WBlk w_block(const gfv_rowtile_args_t& A, int layer, 
 struct WRegs {
   floatx4 a, b, c, d;
 };
-__device__ __forceinline__ WRegs w_load(const float* w, int ldw, int wrow, int wc) {
-  WRegs r;
-  const float* p0 = w + (size_t)wrow * ldw + wc;
-  const size_t step = (size_t)32 * ldw;
-  r.a = *reinterpret_cast<const floatx4*>(p0);
-  r.b = *reinterpret_cast<const floatx4*>(p0 + step);
-  r.c = *reinterpret_cast<const floatx4*>(p0 + 2 * step);
-  r.d = *reinterpret_cast<const floatx4*>(p0 + 3 * step);
+__device__ __forceinline__ WRegs w_load(const float* w, int ldw, int nrows, int wrow, int wc) {
+  WRegs r;  // rows past the block's last valid row re-read that row (their products are never stored)
+  const float* p0 = w + wc;
+  const int last = nrows - 1;
+  r.a = *reinterpret_cast<const floatx4*>(p0 + (size_t)min(wrow, last) * ldw);
+  r.b = *reinterpret_cast<const floatx4*>(p0 + (size_t)min(wrow + 32, last) * ldw);
+  r.c = *reinterpret_cast<const floatx4*>(p0 + (size_t)min(wrow + 64, last) * ldw);
+  r.d = *reinterpret_cast<const floatx4*>(p0 + (size_t)min(wrow + 96, last) * ldw);
   return r;
 }
 __device__ __forceinline__ void w_store(float* Wb, int tid, const WRegs& r) {
@@ -305,10 +307,10 @@ __global__ __launch_bounds__(256, 2) void tchain_kernel(const gfv_rowtile_args_t
   // weight pipeline, prefetch distance 2: at the start of slice j (parity p) LDS buffer p holds slice j and register
   // set 1-p holds slice j+1; slice j issues the loads of slice j+2 into set p, runs its MFMAs, then parks set 1-p in
   // buffer 1-p.  Every block has an even number of slices, so the parity is the unrolled slice index.
-  WRegs wr0 = w_load(cur.w, cur.ldw, wrow, wc);
+  WRegs wr0 = w_load(cur.w, cur.ldw, cur.nrows, wrow, wc);
   w_store(lds, tid, wr0);
 #if W_DIST == 2
-  WRegs wr1 = w_load(cur.w + WK, cur.ldw, wrow, wc);
+  WRegs wr1 = w_load(cur.w + WK, cur.ldw, cur.nrows, wrow, wc);
 #else
   WRegs wr1 = wr0;  // unused
 #endif
@@ -318,7 +320,7 @@ __global__ __launch_bounds__(256, 2) void tchain_kernel(const gfv_rowtile_args_t
   for (int layer = 0; layer < A.nlayers; ++layer) {
     const gfv_layer_t& L = A.layer[layer];
     const bool last = (layer == A.nlayers - 1);
-    const int npass = last ? L.N / 128 : 1;
+    const int npass = last ? (L.N + 127) / 128 : 1;
     const int nchunk = (layer == 0) ? A.nseg : 1;
     for (int pass = 0; pass < npass; ++pass) {
 #pragma unroll
@@ -366,9 +368,10 @@ __global__ __launch_bounds__(256, 2) void tchain_kernel(const gfv_rowtile_args_t
             const float* wsrc = more ? cur.w + WK * (sl + 1) : nxt.w;
 #endif
             const int wld = more ? cur.ldw : nxt.ldw;
+            const int wnr = more ? cur.nrows : nxt.nrows;
 #ifndef ABL_NOW
-            if (W_DIST == 1 || !(sl & 1)) wr0 = w_load(wsrc, wld, wrow, wc);
-            else wr1 = w_load(wsrc, wld, wrow, wc);
+            if (W_DIST == 1 || !(sl & 1)) wr0 = w_load(wsrc, wld, wnr, wrow, wc);
+            else wr1 = w_load(wsrc, wld, wnr, wrow, wc);
 #endif
 #ifndef NO_SCHEDB
             __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ABOVE the MFMAs (the scheduler sinks it otherwise)
@@ -432,6 +435,7 @@ __global__ __launch_bounds__(256, 2) void tchain_kernel(const gfv_rowtile_args_t
         const float* res = pass == 0 ? A.res[0] : (pass == 1 ? A.res[1] : A.res[2]);
         const int old = pass == 0 ? A.out_ld[0] : (pass == 1 ? A.out_ld[1] : A.out_ld[2]);
         const int rld = pass == 0 ? A.res_ld[0] : (pass == 1 ? A.res_ld[1] : A.res_ld[2]);
+        const int ntv = min(128, L.N - 128 * pass) >> 4;  // valid 16-column groups of this chunk (8, or 4 for N = 192)
         float dgam[8][4], dbet[8][4];
         if (lnb_fin) {
 #pragma unroll
@@ -449,11 +453,11 @@ __global__ __launch_bounds__(256, 2) void tchain_kernel(const gfv_rowtile_args_t
           for (int nt = 0; nt < 8; ++nt) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[nt][r] = acc[tt][nt][r];
-            if (L.bias) {
+            if (L.bias && nt < ntv) {
               const float4 b = ld4(L.bias + 128 * pass + 16 * nt + 4 * g);
               v[nt][0] += b.x; v[nt][1] += b.y; v[nt][2] += b.z; v[nt][3] += b.w;
             }
-            if (L.op == GFV_OP_MUL_DGELU) {
+            if (L.op == GFV_OP_MUL_DGELU && nt < ntv) {
               const float4 z = ld4(L.aux + mc * (size_t)L.N + 128 * pass + 16 * nt + 4 * g);
               v[nt][0] *= gfv_dgelu(z.x); v[nt][1] *= gfv_dgelu(z.y); v[nt][2] *= gfv_dgelu(z.z); v[nt][3] *= gfv_dgelu(z.w);
             }
@@ -485,11 +489,13 @@ __global__ __launch_bounds__(256, 2) void tchain_kernel(const gfv_rowtile_args_t
 #endif
 #pragma unroll
             for (int nt = 0; nt < 8; ++nt) {
-              if (res) {
-                const float4 rv = ld4(res + mc * (size_t)rld + 16 * nt + 4 * g);
-                v[nt][0] += rv.x; v[nt][1] += rv.y; v[nt][2] += rv.z; v[nt][3] += rv.w;
+              if (nt < ntv) {
+                if (res) {
+                  const float4 rv = ld4(res + mc * (size_t)rld + 16 * nt + 4 * g);
+                  v[nt][0] += rv.x; v[nt][1] += rv.y; v[nt][2] += rv.z; v[nt][3] += rv.w;
+                }
+                st4(out + mc * (size_t)old + 16 * nt + 4 * g, v[nt]);
               }
-              st4(out + mc * (size_t)old + 16 * nt + 4 * g, v[nt]);
             }
           }
         }

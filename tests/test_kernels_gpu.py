@@ -196,6 +196,40 @@ def test_rowtile_node_mlp_and_small_widths(dev):
     assert rel(dW1, Pg["W1"].grad) < TOL and rel(db1, Pg["b1"].grad) < TOL
 
 
+def test_rowtile_node_mlp_backward_192_wide(dev):
+    """NodeBlock dX chain: LN backward, two 128x128 transposed layers, last layer 192 wide written as
+    [x part 128 (+ residual) | nbm part 64] (blocks.py:101-111 adjoint); rows not a multiple of the tile."""
+    from gfv import lib as L, ops
+    g = torch.Generator().manual_seed(11)
+    M = 333
+    d = lambda t: t.to(dev).contiguous()
+    nbm, x = torch.randn(M, 64, generator=g), torch.randn(M, 128, generator=g)
+    P = _mlp_params(g, 192)
+    Pg = {k: v.double().requires_grad_(True) for k, v in P.items()}
+    X = torch.cat((nbm, x), 1).double().requires_grad_(True)
+    z1, z2, y3, ln = _mlp_ref(Pg, X)
+    go = torch.randn(M, 128, generator=g)
+    (ln * go.double()).sum().backward()
+    Pd = {k: d(v) for k, v in P.items()}
+    z1d, z2d, y3d = d(z1.detach().float()), d(z2.detach().float()), d(y3.detach().float())
+    W1t = torch.empty(192, 128, device=dev)          # rows for x first, then nbm (engine._T(perm=True))
+    ops.transpose(Pd["W1"], out=W1t[0:128], col0=64, ncols=128)
+    ops.transpose(Pd["W1"], out=W1t[128:192], col0=0, ncols=64)
+    gx, gnbm = torch.empty(M, 128, device=dev), torch.empty(M, 64, device=dev)
+    g3, gz2, gz1 = (torch.empty(M, 128, device=dev) for _ in range(3))
+    tiles = ops.rowtile_tiles(M)
+    part = torch.empty(tiles, 2, 128, device=dev)
+    god = d(go)
+    ops.rowtile_chain(M, [ops.Seg(god)],
+                      [ops.LayerSpec(ops.transpose(Pd["W3"]), None, L.OP_MUL_DGELU, save=gz2, aux=z2d),
+                       ops.LayerSpec(ops.transpose(Pd["W2"]), None, L.OP_MUL_DGELU, save=gz1, aux=z1d),
+                       ops.LayerSpec(W1t)], [gx, (gnbm, 64)], res=[god, None], in_op=L.IN_LNBWD, in_gamma=Pd["gamma"],
+                      in_aux=y3d, in_save=g3, ln_partial=part)
+    assert rel(gx, X.grad[:, 64:] + go.double()) < TOL and rel(gnbm, X.grad[:, :64]) < TOL
+    dgb = ops.reduce_partials(part, tiles, 256)
+    assert rel(dgb[:128], Pg["gamma"].grad) < TOL and rel(dgb[128:], Pg["beta"].grad) < TOL
+
+
 def test_rowtile_transolver_linears(dev):
     """Single-layer uses: X=a+b, LayerNorm prologue with N=256, GELU prologue with K=256, LN-backward epilogue."""
     from gfv import lib as L, ops
