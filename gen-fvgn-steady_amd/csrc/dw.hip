@@ -9,6 +9,7 @@
 // lane.  The 4 waves own the 64x64 quadrants of the tile (16 accumulator tiles each).  Slab partials are written
 // to a workspace laid out like the parameter block ([slab][W1|b1|W2|b2|W3|b3]) and summed in a fixed order by
 // gfv_reduce_partials: no float atomics, deterministic.
+#include <stdlib.h>
 #include "gfv_common.h"
 #include "gfv_prof.h"
 #include "../../include/gfv.h"
@@ -204,9 +205,16 @@ __global__ __launch_bounds__(256, 2) void dw_multi_kernel(const DwLaunch A) {
 extern "C" int gfv_reduce_partials(const float*, int32_t, int32_t, float*, int32_t, void*);
 
 extern "C" int gfv_dw_slabs(int32_t M, int32_t ntiles, int32_t* rows_per_slab) {
-  // aim at ~1024 workgroups per launch (2 per CU x 2 rounds), slabs of a multiple of 32 rows, at least 64 rows
+  // aim at ~512 workgroups per launch (one full round at 2 per CU; measured best of 384/512/768/1024: fewer slabs =
+  // less partial-sum traffic), slabs of a multiple of 32 rows, at least 64 rows
   if (ntiles < 1) ntiles = 1;
-  long target = 1024 / ntiles;
+  static int wgs = 0;
+  if (wgs == 0) {
+    const char* e = getenv("GFV_DW_WGS");
+    wgs = e ? atoi(e) : 512;
+    if (wgs < 1) wgs = 512;
+  }
+  long target = wgs / ntiles;
   if (target < 1) target = 1;
   long rows = (M + target - 1) / target;
   rows = ((rows + 31) / 32) * 32;
