@@ -146,7 +146,8 @@ def main():
     ts.use_graph = False
     lib.gfv_profile_reset()
     lib.gfv_profile_enable(1)
-    for _ in range(max(1, args.profile_steps)):
+    args.profile_steps = max(1, args.profile_steps)
+    for _ in range(args.profile_steps):
         ts.step()
     torch.cuda.synchronize()
     lib.gfv_profile_enable(0)

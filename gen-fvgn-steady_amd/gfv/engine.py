@@ -9,6 +9,8 @@ Parameters are addressed by the reference's state_dict names.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import lib as L
@@ -65,6 +67,46 @@ class Engine:
         self.smooth = 1 if ncn_smooth else 0
         self.n_proc = 2 if net in ("TransFVGN_v2", "TransFVGN") else 1
         self.net = net
+        # weight-gradient kernels run on a side stream, concurrently with the dX chain of the next layer block: both
+        # kernel types leave the MFMA pipe half idle on their own and fit on a CU together (registers + LDS)
+        self.overlap = os.environ.get("GFV_OVERLAP", "1") != "0"
+        self._side = None
+        self._keep = []
+
+    # ------------------------------------------------------------------------------------------------------------
+    # side stream for work nothing downstream of the backward chain waits for (dW, LayerNorm dgamma/dbeta)
+    # ------------------------------------------------------------------------------------------------------------
+    class _Fork:
+        def __init__(self, eng, keep):
+            self.eng, self.keep = eng, keep
+
+        def __enter__(self):
+            e = self.eng
+            if not e.overlap:
+                return self
+            if e._side is None:
+                e._side = torch.cuda.Stream()
+            e._side.wait_stream(torch.cuda.current_stream())
+            # tensors the side stream reads must outlive this call: the caching allocator would hand their blocks to
+            # the next allocation on the main stream while the side stream is still reading them
+            e._keep.extend(t for t in self.keep if t is not None)
+            self._ctx = torch.cuda.stream(e._side)
+            self._ctx.__enter__()
+            return self
+
+        def __exit__(self, *exc):
+            if self.eng.overlap:
+                self._ctx.__exit__(*exc)
+            return False
+
+    def fork(self, *keep):
+        return Engine._Fork(self, keep)
+
+    def join(self):
+        """Main stream waits for the side stream (call before anything reads the gradients)."""
+        if self.overlap and self._side is not None:
+            torch.cuda.current_stream().wait_stream(self._side)
+        self._keep.clear()
 
     # ------------------------------------------------------------------------------------------------------------
     # transposed weights for the dX chains: one batched launch per step (prepare_transposes) or on demand
@@ -176,10 +218,12 @@ class Engine:
         tiles = [self._tile(gz1, 128, sg, in_add=sv["in_add"] if i == 0 else None) for i, sg in enumerate(sv["segs"])]
         tiles.append(self._tile(gz2, 128, Seg(sv["z1"]), a_op=1))
         tiles.append(self._tile(g3, nout, Seg(sv["z2"]), a_op=1, ldg=(G.stride(0) if g_ld is None else g_ld) if not ln else None))
-        self._dw_block(grads, [(names[0], names[1], len(sv["segs"])), (names[2], names[3], 1), (names[4], names[5], 1)],
-                       tiles, M)
-        if ln:
-            ops.reduce_partials(part, tiles_n, 256, out=self._gview2(grads, names[6], names[7]))
+        with self.fork(gz1, gz2, g3, G, part, sv["z1"], sv["z2"], sv["in_add"], *[sg.t for sg in sv["segs"]],
+                       *[sg.idx for sg in sv["segs"]]):
+            self._dw_block(grads, [(names[0], names[1], len(sv["segs"])), (names[2], names[3], 1), (names[4], names[5], 1)],
+                           tiles, M)
+            if ln:
+                ops.reduce_partials(part, tiles_n, 256, out=self._gview2(grads, names[6], names[7]))
 
     @staticmethod
     def _gview2(grads, n0, n1):
@@ -328,8 +372,9 @@ class Engine:
         g_z = _empty(dev, N, 256)
         ops.rowtile_chain(N, [Seg(g_out)], [LayerSpec(self._T(Wpost), None, L.OP_MUL_DGELU, aux=z)],
                           [(g_z, 256), (g_z.data_ptr() + 512, 256)])
-        self._dw_block(grads, [(f"{prefix}.mlp.linear_post.weight", f"{prefix}.mlp.linear_post.bias", 2)],
-                       [self._tile(g_out, 128, zs, a_op=1) for zs in zsegs], N)
+        with self.fork(g_out, z):
+            self._dw_block(grads, [(f"{prefix}.mlp.linear_post.weight", f"{prefix}.mlp.linear_post.bias", 2)],
+                           [self._tile(g_out, 128, zs, a_op=1) for zs in zsegs], N)
         # linear_pre behind LayerNorm ln_2
         tiles = ops.rowtile_tiles(N)
         part = _empty(dev, tiles, 2, 128)
@@ -338,14 +383,16 @@ class Engine:
         ops.rowtile_chain(N, [Seg(g_z, width=128, ld=256), Seg(g_z, width=128, ld=256, offset=128)],
                           [LayerSpec(self._T(Wpre))], [g_fx1], fin_op=L.FIN_LNBWD, fin_gamma=gam2, fin_aux=fx1,
                           ln_partial=part, res=[g_out])
-        self._dw_block(grads, [(f"{prefix}.mlp.linear_pre.0.weight", f"{prefix}.mlp.linear_pre.0.bias", 2)],
-                       [self._tile(g_z, 128, Seg(fx1), a_op=2, a_gamma=gam2, a_beta=bet2, ldg=256, g_offset=128 * h)
-                        for h in range(2)], N, row0s=[0, 128])
-        ops.reduce_partials(part, tiles, 256, out=self._gview2(grads, f"{prefix}.ln_2.weight", f"{prefix}.ln_2.bias"))
+        with self.fork(g_z, fx1, part):
+            self._dw_block(grads, [(f"{prefix}.mlp.linear_pre.0.weight", f"{prefix}.mlp.linear_pre.0.bias", 2)],
+                           [self._tile(g_z, 128, Seg(fx1), a_op=2, a_gamma=gam2, a_beta=bet2, ldg=256, g_offset=128 * h)
+                            for h in range(2)], N, row0s=[0, 128])
+            ops.reduce_partials(part, tiles, 256, out=self._gview2(grads, f"{prefix}.ln_2.weight", f"{prefix}.ln_2.bias"))
         # to_out
         g_out_x = _empty(dev, N, 128)
         ops.rowtile_chain(N, [Seg(g_fx1)], [LayerSpec(self._T(P[f"{a}.to_out.0.weight"]))], [g_out_x])
-        self._dw_block(grads, [(f"{a}.to_out.0.weight", f"{a}.to_out.0.bias", 1)], [self._tile(g_fx1, 128, Seg(sv["out_x"]))], N)
+        with self.fork(g_fx1, sv["out_x"]):
+            self._dw_block(grads, [(f"{a}.to_out.0.weight", f"{a}.to_out.0.bias", 1)], [self._tile(g_fx1, 128, Seg(sv["out_x"]))], N)
         # de-slice / attention / slice
         w, batch = sv["w"], pl.batch
         gw = _empty(dev, N, 256)
@@ -384,9 +431,10 @@ class Engine:
         t1, g_fx_in = _empty(dev, N, 128), _empty(dev, N, 128)
         ops.rowtile_chain(N, [Seg(g_fx_mid)], [LayerSpec(self._T(P[f"{a}.in_project_fx.weight"]))], [t1], res=[g_fx1])
         ops.rowtile_chain(N, [Seg(g_x_mid)], [LayerSpec(self._T(P[f"{a}.in_project_x.weight"]))], [g_fx_in], res=[t1])
-        self._dw_block(grads, [(f"{a}.in_project_x.weight", f"{a}.in_project_x.bias", 1),
-                               (f"{a}.in_project_fx.weight", f"{a}.in_project_fx.bias", 1)],
-                       [self._tile(g_x_mid, 128, Seg(fx_in)), self._tile(g_fx_mid, 128, Seg(fx_in))], N)
+        with self.fork(g_x_mid, g_fx_mid, fx_in):
+            self._dw_block(grads, [(f"{a}.in_project_x.weight", f"{a}.in_project_x.bias", 1),
+                                   (f"{a}.in_project_fx.weight", f"{a}.in_project_fx.bias", 1)],
+                           [self._tile(g_x_mid, 128, Seg(fx_in)), self._tile(g_fx_mid, 128, Seg(fx_in))], N)
         return g_fx_in
 
     # ------------------------------------------------------------------------------------------------------------
@@ -555,6 +603,7 @@ class Engine:
         try:
             g_dec = self.fvm_bwd(ctx["fvm"], gloss, pl)
             self.simulator_bwd(P, ctx["sim"], g_dec, grads, pl)
+            self.join()
         finally:
             self._wt_live = False  # the cached transposes are only valid for this step's parameter values
         return grads

@@ -42,6 +42,7 @@ class GnBlockFn(torch.autograd.Function):
         if g_e is None:
             g_e = torch.zeros((ctx.plan.E, 128), device=dev)
         gx, ge = ctx.engine.gn_bwd(P, ctx.sv, g_x.contiguous(), g_e.contiguous(), grads, ctx.plan)
+        ctx.engine.join()
         return (None, None, None, gx, ge) + tuple(grads.view(n) for n in ctx.names)
 
 
@@ -69,8 +70,10 @@ class Mlp3Fn(torch.autograd.Function):
             gx = torch.empty((ctx.sv["M"], ctx.in_width), dtype=torch.float32, device=g.device)
             assert ctx.in_width == 128, "input gradients are only needed for 128-wide latent inputs"
             ctx.engine.mlp3_bwd(P, ctx.sv, g.contiguous(), grads, outs=[gx])
+            ctx.engine.join()
         else:
             ctx.engine.mlp3_bwd(P, ctx.sv, g.contiguous(), grads)
+            ctx.engine.join()
         return (None, None, None, None, gx) + tuple(grads.view(n) for n in ctx.names)
 
 
@@ -89,6 +92,7 @@ class TransolverFn(torch.autograd.Function):
         skip = unused_param_names(ctx.names)
         grads = _alloc_grads(ctx.names, [P[n] for n in ctx.names], skip)
         gfx = ctx.engine.trans_bwd(P, ctx.sv, g.contiguous(), grads, ctx.plan)
+        ctx.engine.join()
         return (None, None, None, gfx) + tuple(grads.view(n) for n in ctx.names)
 
 
@@ -107,6 +111,7 @@ class SimulatorFn(torch.autograd.Function):
         skip = unused_param_names(ctx.names)
         grads = _alloc_grads(ctx.names, [P[n] for n in ctx.names], skip)
         ctx.engine.simulator_bwd(P, ctx.sv, g.contiguous(), grads, ctx.plan)
+        ctx.engine.join()
         return (None, None, None, None, None) + tuple(grads.view(n) for n in ctx.names)
 
 
