@@ -237,7 +237,7 @@ __device__ __forceinline__ void acc_to_xs(const floatx4 (&acc)[8], float* Xs, co
 }
 
 // intermediate epilogue: element op in the coalesced layout, result stays in Xs as the next layer's input
-__device__ void mid_epilogue(const gfv_layer_t& L, float* Xs, const Ctx& c) {
+__device__ void mid_epilogue(const gfv_rowtile_args_t& A, int layer, const gfv_layer_t& L, float* Xs, const Ctx& c) {
   const int col = 4 * c.c4;
   float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
   if (L.bias && L.op != GFV_OP_MUL_DGELU) bias = *reinterpret_cast<const float4*>(L.bias + col);
@@ -246,6 +246,10 @@ __device__ void mid_epilogue(const gfv_layer_t& L, float* Xs, const Ctx& c) {
     const int r = c.wave * 16 + c.rr + 2 * p;
     const int m = c.row0 + r;
     float4 v = f4_add(*reinterpret_cast<const float4*>(&Xs[r * LDX + col]), bias);
+    if (layer == 0 && A.padd && m < c.M) {
+      v = f4_add(v, *reinterpret_cast<const float4*>(A.padd + (size_t)A.padd_s[m] * A.padd_ld + col));
+      v = f4_add(v, *reinterpret_cast<const float4*>(A.padd + (size_t)A.padd_r[m] * A.padd_ld + 128 + col));
+    }
     if (L.op == GFV_OP_BIAS_GELU) {
       if (L.save && m < c.M) *reinterpret_cast<float4*>(L.save + (size_t)m * 128 + col) = v;
       v = make_float4(gfv_gelu(v.x), gfv_gelu(v.y), gfv_gelu(v.z), gfv_gelu(v.w));
@@ -345,7 +349,7 @@ __global__ __launch_bounds__(256, 2) void rowtile_chain_kernel(const gfv_rowtile
     WSlice s;
     const gfv_layer_t& L = A.layer[layer];
     s.W = L.W;
-    s.ldw = L.K;
+    s.ldw = L.ldw ? L.ldw : L.K;
     s.n0 = 128 * pass;
     s.N = L.N;
     int koff = 0, width = 128;
@@ -355,7 +359,7 @@ __global__ __launch_bounds__(256, 2) void rowtile_chain_kernel(const gfv_rowtile
     }
     s.kcol = koff + ks;
     s.kvalid = width - ks;
-    s.vec = ((L.K & 3) == 0) && ((koff & 3) == 0) && ((width & 3) == 0);
+    s.vec = ((s.ldw & 3) == 0) && ((koff & 3) == 0) && ((width & 3) == 0) && ((reinterpret_cast<size_t>(L.W) & 15) == 0);
     return s;
   };
 
@@ -424,7 +428,7 @@ __global__ __launch_bounds__(256, 2) void rowtile_chain_kernel(const gfv_rowtile
         wave_lds_sync();
         acc_to_xs(acc, Xs, c);
         wave_lds_sync();
-        mid_epilogue(L, Xs, c);
+        mid_epilogue(A, layer, L, Xs, c);
         wave_lds_sync();
       } else {
         final_epilogue(A, L, pass, acc, Os, c, dgam, dbet);
@@ -480,6 +484,9 @@ extern "C" int gfv_rowtile_chain(const gfv_rowtile_args_t* args, void* stream) {
   if (k0 != args->layer[0].K) return GFV_ERR_ARG;
   const gfv_layer_t& last = args->layer[args->nlayers - 1];
   if (last.N > 384 || last.N < 1) return GFV_ERR_ARG;
+  if (args->padd && (args->nlayers < 2 || args->padd_ld < 256 || (args->padd_ld & 3) || !args->padd_s || !args->padd_r)) return GFV_ERR_ARG;
+  for (int l = 0; l < args->nlayers; ++l)
+    if (args->layer[l].ldw != 0 && args->layer[l].ldw < args->layer[l].K) return GFV_ERR_ARG;
   if (last.N > 128 && (last.N & 15)) return GFV_ERR_ARG;
   if ((args->fin_op != GFV_FIN_PLAIN || args->in_op == GFV_IN_LN || args->in_op == GFV_IN_LNBWD) &&
       (args->fin_op != GFV_FIN_PLAIN ? last.N != 128 : false))
@@ -509,13 +516,13 @@ extern "C" int gfv_rowtile_chain(const gfv_rowtile_args_t* args, void* stream) {
   bool fast = true;
   for (int i = 0; i < args->nseg; ++i)
     fast = fast && (args->seg[i].width % 32 == 0) && (args->seg[i].ld % 4 == 0);
-  for (int l = 0; l < args->nlayers; ++l) fast = fast && (args->layer[l].N % 128 == 0) && (args->layer[l].K % 4 == 0);
+  for (int l = 0; l < args->nlayers; ++l) fast = fast && (args->layer[l].N % 128 == 0) && (args->layer[l].K % 4 == 0) && (args->layer[l].ldw % 4 == 0);
   // the register-resident chain also takes a last layer whose final 128-chunk is 64 wide (NodeBlock dX: 128 + 64)
   bool fast_t = true;
   for (int i = 0; i < args->nseg; ++i) fast_t = fast_t && (args->seg[i].width % 32 == 0) && (args->seg[i].ld % 4 == 0);
   for (int l = 0; l < args->nlayers; ++l) {
     const bool lastl = (l == args->nlayers - 1);
-    fast_t = fast_t && (args->layer[l].K % 4 == 0) && (args->layer[l].N % (lastl ? 64 : 128) == 0);
+    fast_t = fast_t && (args->layer[l].K % 4 == 0) && (args->layer[l].ldw % 4 == 0) && (args->layer[l].N % (lastl ? 64 : 128) == 0);
   }
   if (args->fin_op != GFV_FIN_PLAIN) fast_t = fast_t && last.N == 128;
   for (int c = 0; c < 3; ++c) {

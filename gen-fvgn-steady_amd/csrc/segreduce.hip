@@ -272,7 +272,7 @@ __global__ __launch_bounds__(256) void transpose_batch_kernel(const gfv_transpos
   __syncthreads();
   for (int j = ty; j < 32; j += 8) {
     const int c = bx + j, r = by + tx;
-    if (c < d.cols && r < d.rows) d.out[(size_t)c * d.rows + r] = tile[tx][j];
+    if (c < d.cols && r < d.rows) d.out[(size_t)c * (d.ld_out ? d.ld_out : d.rows) + r] = tile[tx][j];
   }
 }
 }  // namespace

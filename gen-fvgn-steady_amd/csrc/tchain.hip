@@ -53,8 +53,8 @@ __device__ __forceinline__ WBlk w_block(const gfv_rowtile_args_t& A, int layer, 
     width = A.seg[chunk].width;
   }
   WBlk b;
-  b.w = L.W + (size_t)(128 * pass) * L.K + koff;
-  b.ldw = L.K;
+  b.ldw = L.ldw ? L.ldw : L.K;
+  b.w = L.W + (size_t)(128 * pass) * b.ldw + koff;
   b.nsl = width / WK;
   b.nrows = min(128, L.N - 128 * pass);
   return b;
@@ -396,6 +396,16 @@ __global__ __launch_bounds__(256, 2) void tchain_kernel(const gfv_rowtile_args_t
 
       if (!last) {
         // ---- intermediate epilogue: accumulators -> next layer's activations, in registers ----
+        const float* pad_s[T];
+        const float* pad_r[T];
+        if (layer == 0 && A.padd) {
+#pragma unroll
+          for (int tt = 0; tt < T; ++tt) {
+            const int mc = min(rowbase + 16 * tt, A.M - 1);
+            pad_s[tt] = A.padd + (size_t)A.padd_s[mc] * A.padd_ld + 4 * g;
+            pad_r[tt] = A.padd + (size_t)A.padd_r[mc] * A.padd_ld + 128 + 4 * g;
+          }
+        }
 #pragma unroll
         for (int tt = 0; tt < T; ++tt) {
           const int m = rowbase + 16 * tt;
@@ -412,6 +422,11 @@ __global__ __launch_bounds__(256, 2) void tchain_kernel(const gfv_rowtile_args_t
               if (L.bias) {
                 const float4 b = ld4(L.bias + 16 * nt + 4 * g);
                 v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+              }
+              if (layer == 0 && A.padd) {
+                // first layer factored through the nodes: + (W1a x)[s] + (W1b x)[r]
+                const float4 pa = ld4(pad_s[tt] + 16 * nt), pb = ld4(pad_r[tt] + 16 * nt);
+                v[0] += pa.x + pb.x; v[1] += pa.y + pb.y; v[2] += pa.z + pb.z; v[3] += pa.w + pb.w;
               }
               if (L.op == GFV_OP_BIAS_GELU) {
 #ifndef ABL_NOSTORE

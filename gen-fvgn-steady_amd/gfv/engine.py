@@ -70,6 +70,10 @@ class Engine:
         # weight-gradient kernels run on a side stream, concurrently with the dX chain of the next layer block: both
         # kernel types leave the MFMA pipe half idle on their own and fit on a CU together (registers + LDS)
         self.overlap = os.environ.get("GFV_OVERLAP", "1") != "0"
+        # EdgeBlock first layer factored through the nodes: W1 [x_s | x_r | e] = (W1a x)[s] + (W1b x)[r] + W1c e, the two
+        # node-level products (and their adjoints / weight gradients) run over N rows instead of E = 3N
+        self.factor = os.environ.get("GFV_EDGE_FACTOR", "1") != "0"
+        self._etmp = None
         self._side = None
         self._keep = []
 
@@ -118,6 +122,10 @@ class Engine:
             return hit
         if not perm:
             return ops.transpose(W)
+        if perm == "c":      # (W1[:, 256:384])^T
+            return ops.transpose(W, col0=256, ncols=128)
+        if perm == "ab":     # [ (W1[:, 0:128])^T | (W1[:, 128:256])^T ]  ([128, 256])
+            return torch.cat((ops.transpose(W, col0=0, ncols=128), ops.transpose(W, col0=128, ncols=128)), 1).contiguous()
         out = _empty(W.device, 192, 128)
         ops.transpose(W, out=out[0:128], col0=64, ncols=128)
         ops.transpose(W, out=out[128:192], col0=0, ncols=64)
@@ -142,15 +150,22 @@ class Engine:
                 r, c = W.shape
                 if ".nb_module.net.0.0.weight" in n:
                     out = _empty(dev, 192, 128)
-                    rows.append((W.data_ptr() + 4 * 64, out.data_ptr(), r, 128, c))
-                    rows.append((W.data_ptr(), out.data_ptr() + 4 * 128 * 128, r, 64, c))
+                    rows.append((W.data_ptr() + 4 * 64, out.data_ptr(), r, 128, c, 0))
+                    rows.append((W.data_ptr(), out.data_ptr() + 4 * 128 * 128, r, 64, c, 0))
                     self._wt[(W.data_ptr(), True)] = out
+                elif self.factor and ".eb_module.net.0.0.weight" in n:
+                    oc, oab = _empty(dev, 128, 128), _empty(dev, 128, 256)
+                    rows.append((W.data_ptr() + 4 * 256, oc.data_ptr(), r, 128, c, 0))
+                    rows.append((W.data_ptr(), oab.data_ptr(), r, 128, c, 256))
+                    rows.append((W.data_ptr() + 4 * 128, oab.data_ptr() + 4 * 128, r, 128, c, 256))
+                    self._wt[(W.data_ptr(), "c")] = oc
+                    self._wt[(W.data_ptr(), "ab")] = oab
                 else:
                     out = _empty(dev, c, r)
-                    rows.append((W.data_ptr(), out.data_ptr(), r, c, c))
+                    rows.append((W.data_ptr(), out.data_ptr(), r, c, c, 0))
                     self._wt[(W.data_ptr(), False)] = out
             import struct
-            blob = b"".join(struct.pack("<QQiiii", a, b, r, c, ld, 0) for a, b, r, c, ld in rows)
+            blob = b"".join(struct.pack("<QQiiii", a, b, r, c, ld, ldo) for a, b, r, c, ld, ldo in rows)
             self._wt_desc = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(dev)
             self._wt_n = len(rows)
             self._wt_max = (max(r[2] for r in rows), max(r[3] for r in rows))
@@ -168,9 +183,14 @@ class Engine:
         return [f"{lin}.0.weight", f"{lin}.0.bias", f"{lin}.2.weight", f"{lin}.2.bias", f"{lin}.4.weight",
                 f"{lin}.4.bias"] + ([f"{prefix}.1.weight", f"{prefix}.1.bias"] if ln else [])
 
-    def mlp3_fwd(self, P, prefix, M, segs, *, ln=True, res=None, in_add=None, want_nores=False, keep=True):
+    def mlp3_fwd(self, P, prefix, M, segs, *, ln=True, res=None, in_add=None, want_nores=False, keep=True, w1=None,
+                 padd=None):
+        """w1: column block of the first weight that multiplies `segs` (default: all of it); padd = (t [*,256], s, r):
+        gathered addend t[s[m], :128] + t[r[m], 128:] to the first pre-activation (factored EdgeBlock)."""
         names = self._mlp_names(prefix, ln)
         W1, b1, W2, b2, W3, b3 = (P[n] for n in names[:6])
+        if w1 is not None:
+            W1 = w1
         dev = W1.device
         nout = W3.shape[0]
         z1 = _empty(dev, M, 128) if keep else None
@@ -183,7 +203,8 @@ class Engine:
             [LayerSpec(W1, b1, L.OP_BIAS_GELU, save=z1), LayerSpec(W2, b2, L.OP_BIAS_GELU, save=z2), LayerSpec(W3, b3)],
             [out], in_add=in_add, fin_op=L.FIN_LN if ln else L.FIN_PLAIN,
             fin_gamma=P[names[6]] if ln else None, fin_beta=P[names[7]] if ln else None, fin_presave=y3,
-            res=[res] if res is not None else None, out_nores=nores)
+            res=[res] if res is not None else None, out_nores=nores,
+            **(dict(padd=padd[0], padd_s=padd[1], padd_r=padd[2]) if padd is not None else {}))
         saved = dict(z1=z1, z2=z2, y3=y3, segs=segs, in_add=in_add, M=M, ln=ln, prefix=prefix)
         return out, nores, saved
 
@@ -288,12 +309,66 @@ class Engine:
     def gn_fwd(self, P, prefix, x, e, pl):
         N, E = pl.N, pl.E
         nb = ops.seg_gather_sum(x, pl.n_rowptr, pl.n_col_node, N)
-        e_out, e_new, sv_e = self.mlp3_fwd(P, f"{prefix}.eb_module.net", E, [Seg(nb, pl.es), Seg(nb, pl.er), Seg(e)],
-                                           res=e, want_nores=True)
+        if self.factor:
+            W1 = P[f"{prefix}.eb_module.net.0.0.weight"]                   # [128, 384] = [W1a | W1b | W1c]
+            pab = _empty(x.device, N, 256)                                  # [W1a nb | W1b nb] per node
+            ops.rowtile_chain(N, [Seg(nb)], [LayerSpec(W1[:, 0:128])], [(pab, 256)])
+            ops.rowtile_chain(N, [Seg(nb)], [LayerSpec(W1[:, 128:256])], [(pab.data_ptr() + 512, 256)])
+            e_out, e_new, sv_e = self.mlp3_fwd(P, f"{prefix}.eb_module.net", E, [Seg(e)], res=e, want_nores=True,
+                                               w1=W1[:, 256:384], padd=(pab, pl.es, pl.er))
+            sv_e["nb"] = nb
+        else:
+            e_out, e_new, sv_e = self.mlp3_fwd(P, f"{prefix}.eb_module.net", E, [Seg(nb, pl.es), Seg(nb, pl.er), Seg(e)],
+                                               res=e, want_nores=True)
         agg = ops.seg_gather_sum(e_new.view(2 * E, 64), pl.n_rowptr, pl.n_col_edge2, N)
         nbm = ops.seg_gather_sum(agg, pl.n_rowptr, pl.n_col_node, N, scale=pl.inv_deg)
         x_out, _, sv_n = self.mlp3_fwd(P, f"{prefix}.nb_module.net", N, [Seg(nbm), Seg(x)], res=x)
         return x_out, e_out, dict(sv_e=sv_e, sv_n=sv_n, prefix=prefix)
+
+    def _edge_tmp(self, dev):
+        if self._etmp is None or self._etmp[0].flat.device != dev:
+            e = GradStore(["W1c", "b1", "W2", "b2", "W3", "b3"], [(128, 128), (128,), (128, 128), (128,), (128, 128), (128,)], dev)
+            n = GradStore(["W1ab"], [(128, 256)], dev)
+            self._etmp = (e, n)
+        return self._etmp
+
+    def edge_bwd_factored(self, P, sv, G, grads, pl, gadd):
+        """Adjoint of the factored EdgeBlock MLP.  Returns (grad wrt nb [N,128], grad wrt e [E,128] incl. residual)."""
+        prefix, M, N = sv["prefix"], sv["M"], pl.N
+        names = self._mlp_names(prefix, True)
+        W1, W2, W3 = P[names[0]], P[names[2]], P[names[4]]
+        dev = W1.device
+        W3t, W2t, W1ct, Wabt = self._T(W3), self._T(W2), self._T(W1, perm="c"), self._T(W1, perm="ab")
+        gz2, gz1, g3, g_e_in = (_empty(dev, M, 128) for _ in range(4))
+        tiles_n = ops.rowtile_tiles(M)
+        part = _empty(dev, tiles_n, 2, 128)
+        e = sv["segs"][0].t
+        ops.rowtile_chain(M, [Seg(G)],
+                          [LayerSpec(W3t, None, L.OP_MUL_DGELU, save=gz2, aux=sv["z2"]),
+                           LayerSpec(W2t, None, L.OP_MUL_DGELU, save=gz1, aux=sv["z1"]), LayerSpec(W1ct)],
+                          [g_e_in], res=[G], in_op=L.IN_LNBWD, in_gamma=P[names[6]], in_aux=sv["y3"], in_save=g3,
+                          ln_partial=part, gadd=gadd[0], gadd_s=gadd[1], gadd_r=gadd[2])
+        # adjoint of the gathers (W1a nb)[s], (W1b nb)[r]: per-side scatter of dz1 to the nodes, then ONE node-level GEMM
+        G_s = ops.seg_gather_sum(gz1, pl.s_rowptr, pl.s_col, N)
+        G_r = ops.seg_gather_sum(gz1, pl.r_rowptr, pl.r_col, N)
+        g_nb = _empty(dev, N, 128)
+        ops.rowtile_chain(N, [Seg(G_s), Seg(G_r)], [LayerSpec(Wabt)], [g_nb])
+        nb = sv["nb"]
+        with self.fork(gz1, gz2, g3, G_s, G_r, nb, e, part, sv["z1"], sv["z2"]):
+            tmpE, tmpN = self._edge_tmp(dev)
+            self._dw_block(tmpE, [("W1c", "b1", 1), ("W2", "b2", 1), ("W3", "b3", 1)],
+                           [self._tile(gz1, 128, Seg(e)), self._tile(gz2, 128, Seg(sv["z1"]), a_op=1),
+                            self._tile(g3, 128, Seg(sv["z2"]), a_op=1)], M)
+            self._dw_block(tmpN, [("W1ab", None, 2)], [self._tile(G_s, 128, Seg(nb)), self._tile(G_r, 128, Seg(nb))], N)
+            gW1 = grads.view(names[0])
+            gW1[:, 0:256].copy_(tmpN.view("W1ab"))
+            gW1[:, 256:384].copy_(tmpE.view("W1c"))
+            off, length = grads.block(names[1], names[5])
+            o2, l2 = tmpE.block("b1", "b3")
+            assert l2 == length
+            grads.flat[off:off + length].copy_(tmpE.flat[o2:o2 + l2])
+            ops.reduce_partials(part, tiles_n, 256, out=self._gview2(grads, names[6], names[7]))
+        return g_nb, g_e_in
 
     def gn_bwd(self, P, sv, g_x_out, g_e_out, grads, pl):
         N, E = pl.N, pl.E
@@ -304,10 +379,13 @@ class Engine:
         g_x_in, g_nbm = _empty(dev, N, 128), _empty(dev, N, 64)
         self.mlp3_bwd(P, sv["sv_n"], g_x_out, grads, outs=[g_x_in, (g_nbm, 64)], res=[g_x_out, None], W1t=W1t)
         g_agg = ops.seg_gather_sum(g_nbm, pl.n_rowptr, pl.n_col_node, N, src_scale=pl.inv_deg)
-        gnb2, g_e_in = _empty(dev, E, 256), _empty(dev, E, 128)
-        self.mlp3_bwd(P, sv["sv_e"], g_e_out, grads, outs=[(gnb2, 256), (gnb2.data_ptr() + 512, 256), g_e_in],
-                      res=[None, None, g_e_out], gadd=(g_agg, pl.es, pl.er))
-        g_nb = ops.seg_gather_sum(gnb2.view(2 * E, 128), pl.n_rowptr, pl.n_col_edge2, N)
+        if "nb" in sv["sv_e"]:
+            g_nb, g_e_in = self.edge_bwd_factored(P, sv["sv_e"], g_e_out, grads, pl, (g_agg, pl.es, pl.er))
+        else:
+            gnb2, g_e_in = _empty(dev, E, 256), _empty(dev, E, 128)
+            self.mlp3_bwd(P, sv["sv_e"], g_e_out, grads, outs=[(gnb2, 256), (gnb2.data_ptr() + 512, 256), g_e_in],
+                          res=[None, None, g_e_out], gadd=(g_agg, pl.es, pl.er))
+            g_nb = ops.seg_gather_sum(gnb2.view(2 * E, 128), pl.n_rowptr, pl.n_col_edge2, N)
         ops.seg_gather_sum(g_nb, pl.n_rowptr, pl.n_col_node, N, out=g_x_in, accumulate=True)
         return g_x_in, g_e_in
 

@@ -27,7 +27,7 @@ class Seg(C.Structure):
 
 class Layer(C.Structure):
     _fields_ = [("W", C.c_void_p), ("bias", C.c_void_p), ("K", C.c_int32), ("N", C.c_int32), ("op", C.c_int32),
-                ("pad_", C.c_int32), ("save", C.c_void_p), ("aux", C.c_void_p)]
+                ("ldw", C.c_int32), ("save", C.c_void_p), ("aux", C.c_void_p)]
 
 
 class RowtileArgs(C.Structure):
@@ -38,7 +38,8 @@ class RowtileArgs(C.Structure):
         ("ln_partial", C.c_void_p), ("layer", Layer * 3), ("fin_op", C.c_int32), ("pad_", C.c_int32),
         ("fin_gamma", C.c_void_p), ("fin_beta", C.c_void_p), ("fin_aux", C.c_void_p), ("fin_presave", C.c_void_p),
         ("res", C.c_void_p * 3), ("res_ld", C.c_int32 * 3), ("out_ld", C.c_int32 * 3), ("out", C.c_void_p * 3),
-        ("out_nores", C.c_void_p),
+        ("out_nores", C.c_void_p), ("padd", C.c_void_p), ("padd_s", C.c_void_p), ("padd_r", C.c_void_p),
+        ("padd_ld", C.c_int32), ("pad2_", C.c_int32),
     ]
 
 

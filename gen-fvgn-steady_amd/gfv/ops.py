@@ -88,7 +88,8 @@ class LayerSpec:
 
 def rowtile_chain(M, segs, layers, outs, *, in_add=None, in_op=L.IN_NONE, in_gamma=None, in_beta=None, in_aux=None,
                   gadd=None, gadd_s=None, gadd_r=None, in_save=None, ln_partial=None, fin_op=L.FIN_PLAIN,
-                  fin_gamma=None, fin_beta=None, fin_aux=None, fin_presave=None, res=None, out_nores=None):
+                  fin_gamma=None, fin_beta=None, fin_aux=None, fin_presave=None, res=None, out_nores=None,
+                  padd=None, padd_s=None, padd_r=None):
     """Launch the fused row-tile GEMM chain.  outs / res: list (per 128-wide chunk of the last layer) of
     (tensor, ld) or tensors; see include/gfv.h for the semantics of every field."""
     lib = L.load()
@@ -107,6 +108,8 @@ def rowtile_chain(M, segs, layers, outs, *, in_add=None, in_op=L.IN_NONE, in_gam
         cl = a.layer[i]
         cl.W, cl.bias = _p(ly.W), _p(ly.bias)
         cl.N, cl.K = ly.W.shape[0], ly.W.shape[1]
+        assert ly.W.stride(1) == 1
+        cl.ldw = ly.W.stride(0)  # a column block of a wider weight keeps the parent's row stride
         cl.op = ly.op
         cl.save, cl.aux = _p(ly.save), _p(ly.aux)
     a.fin_op = fin_op
@@ -123,6 +126,8 @@ def rowtile_chain(M, segs, layers, outs, *, in_add=None, in_op=L.IN_NONE, in_gam
             a.res[i] = t.data_ptr() if torch.is_tensor(t) else t
             a.res_ld[i] = ld
     a.out_nores = _p(out_nores)
+    if padd is not None:
+        a.padd, a.padd_s, a.padd_r, a.padd_ld = _p(padd), _p(padd_s), _p(padd_r), padd.stride(0)
     rc = lib.gfv_rowtile_chain(C.byref(a), L.stream_ptr())
     L.check(rc, "gfv_rowtile_chain")
 

@@ -53,6 +53,11 @@ def _gnn_part(p, edge_index, N):
     p.n_col_edge2 = i32(eid2[order])
     deg = torch.bincount(indeg, minlength=N).to(torch.float32)
     p.inv_deg = (1.0 / deg.clamp(min=1.0)).contiguous()
+    # edges by sender / by receiver (adjoint of the per-side gathers x[s], x[r] of the factored EdgeBlock first layer)
+    p.s_rowptr, so = _csr(s, N)
+    p.s_col = i32(so)
+    p.r_rowptr, ro = _csr(r, N)
+    p.r_col = i32(ro)
     return p
 
 

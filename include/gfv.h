@@ -70,7 +70,7 @@ typedef struct {
   const float* bias;  /* [N] or NULL */
   int32_t K, N;       /* K = input width, N = output width (128 for inner layers; last layer: <= 384) */
   int32_t op;
-  int32_t pad_;
+  int32_t ldw;        /* row stride of W in floats; 0 = K (a column block of a wider weight: W1[:, 256:384]) */
   float* save;        /* optional [M, N] */
   const float* aux;   /* [M, N] for GFV_OP_MUL_DGELU */
 } gfv_layer_t;
@@ -102,6 +102,15 @@ typedef struct {
   int32_t out_ld[3];
   float* out[3];          /* output pointer per 128-wide chunk of the last layer */
   float* out_nores;       /* optional [M,128]: chunk 0 result BEFORE the residual addend (EdgeBlock output e') */
+  /* optional gathered addend to the FIRST layer's pre-activation (needs nlayers >= 2):
+   *   z1[m, c] += padd[padd_s[m], c] + padd[padd_r[m], 128 + c],  c < 128,  padd = [*, padd_ld >= 256].
+   * EdgeBlock first layer factored through the nodes: W1 [x_s | x_r | e] = (W1a x)[s] + (W1b x)[r] + W1c e
+   * (blocks.py:54 concat + EPD.py:21 Linear), the two node-level products are computed once per node. */
+  const float* padd;
+  const int32_t* padd_s;
+  const int32_t* padd_r;
+  int32_t padd_ld;
+  int32_t pad2_;
 } gfv_rowtile_args_t;
 
 int gfv_rowtile_tiles(int32_t M); /* number of 64-row tiles = rows of ln_partial */
@@ -152,8 +161,8 @@ int gfv_reduce_partials(const float* partial, int32_t n_chunks, int32_t n, float
 /* Batched form: one launch for all weight transposes of a step; `descs` [n] lives in DEVICE memory. */
 typedef struct {
   const float* in; /* [rows, ld_in], columns [0, cols) are transposed */
-  float* out;      /* [cols, rows] */
-  int32_t rows, cols, ld_in, pad_;
+  float* out;      /* [cols, ld_out] */
+  int32_t rows, cols, ld_in, ld_out; /* ld_out: row stride of out, 0 = rows */
 } gfv_transpose_desc_t;
 int gfv_transpose_batch(const gfv_transpose_desc_t* descs, int32_t n, int32_t max_rows, int32_t max_cols, void* stream);
 
