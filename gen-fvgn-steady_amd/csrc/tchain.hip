@@ -37,6 +37,7 @@ namespace {
 #endif
 constexpr int WK = 32;
 constexpr int WS_FLOATS = 128 * WK;  // one weight slice
+constexpr int PAR_GAMMA = 640, PAR_BETA = 768, PAR_FLOATS = 896;
 
 struct WBlk {
   const float* w;  // &W[128*pass][koff]
@@ -206,8 +207,9 @@ __device__ __forceinline__ void mma_slice(floatx4 (&acc)[T][8], const float (&ac
 
 // ---- input segment -> activation registers (gather / concat piece / prologue element ops) -------------------------
 template <int T, int LNM>
-__device__ __forceinline__ void load_segment(const gfv_rowtile_args_t& A, int si, int rowbase, int g, float (&act)[T][8][4],
-                                             float (&dgam)[8][4], float (&dbet)[8][4]) {
+__device__ __forceinline__ void load_segment(const gfv_rowtile_args_t& A, int si, int rowbase, int g, const float* gam,
+                                             const float* bet, float (&act)[T][8][4], float (&dgam)[8][4],
+                                             float (&dbet)[8][4]) {
   const gfv_seg_t& s = A.seg[si];
   const int nt_valid = s.width >> 4;
   const bool first = (si == 0);
@@ -252,7 +254,7 @@ __device__ __forceinline__ void load_segment(const gfv_rowtile_args_t& A, int si
 #pragma unroll
         for (int r = 0; r < 4; ++r) act[tt][t][r] = gfv_gelu(act[tt][t][r]);
     } else if (A.in_op == GFV_IN_LN) {
-      ln_apply(act[tt], A.in_gamma, A.in_beta, g);
+      ln_apply(act[tt], gam, bet, g);
     } else if (LNM == 1 && A.in_op == GFV_IN_LNBWD) {
       float y[8][4];
       const float* yp = A.in_aux + (size_t)mc * 128 + 4 * g;
@@ -267,7 +269,7 @@ __device__ __forceinline__ void load_segment(const gfv_rowtile_args_t& A, int si
 #pragma unroll
           for (int r = 0; r < 4; ++r) act[tt][t][r] = 0.f;
       }
-      ln_bwd(act[tt], y, A.in_gamma, g, dgam, dbet);
+      ln_bwd(act[tt], y, gam, g, dgam, dbet);
     }
     if (!live) {
 #pragma unroll
@@ -287,8 +289,9 @@ __device__ __forceinline__ void load_segment(const gfv_rowtile_args_t& A, int si
 // accumulators exist only in those instantiations)
 template <int T, int LNM>
 __global__ __launch_bounds__(256, 2) void tchain_kernel(const gfv_rowtile_args_t A) {
-  __shared__ __attribute__((aligned(16))) float lds[2 * WS_FLOATS + 1024];
+  __shared__ __attribute__((aligned(16))) float lds[2 * WS_FLOATS + 1024 + PAR_FLOATS];
   float* red = lds + 2 * WS_FLOATS;
+  float* par = red + 1024;  // bias of layer l at 128 l (N_l floats), LayerNorm gamma / beta: read from LDS in the epilogues
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, g = lane >> 4;
   const int rowbase = blockIdx.x * (64 * T) + wave * (16 * T) + li;
   // weight staging: thread -> row (tid>>3) + 32p, LDS slot tid&7, source chunk slot ^ ((row>>1)&7)
@@ -301,6 +304,36 @@ __global__ __launch_bounds__(256, 2) void tchain_kernel(const gfv_rowtile_args_t
   floatx4 acc[T][8];
   constexpr bool lnb_in = (LNM == 1), lnb_fin = (LNM == 2);
 
+  // gather rows of the factored first-layer addend: index round trip issued first thing, used in the first epilogue
+  const float* pad_s[T];
+  const float* pad_r[T];
+  if (A.padd) {
+#pragma unroll
+    for (int tt = 0; tt < T; ++tt) {
+      const int mc = min(rowbase + 16 * tt, A.M - 1);
+      pad_s[tt] = A.padd + (size_t)A.padd_s[mc] * A.padd_ld + 4 * g;
+      pad_r[tt] = A.padd + (size_t)A.padd_r[mc] * A.padd_ld + 128 + 4 * g;
+    }
+  }
+  // small parameter vectors -> LDS: one round trip at kernel start (overlapping the first weight slice) instead of a
+  // synchronous global load in every epilogue; visible after the first barrier
+#pragma unroll
+  for (int l = 0; l < 3; ++l) {
+    if (l < A.nlayers) {
+      const float* bp = A.layer[l].bias;
+      const int nl = A.layer[l].N;
+      for (int c = tid; c < nl; c += 256) par[128 * l + c] = bp ? bp[c] : 0.f;
+    }
+  }
+  {
+    const bool in_ln = (A.in_op == GFV_IN_LN || A.in_op == GFV_IN_LNBWD);
+    const float* gp = in_ln ? A.in_gamma : A.fin_gamma;
+    const float* bp = (A.in_op == GFV_IN_LN) ? A.in_beta : A.fin_beta;
+    if (in_ln || A.fin_op != GFV_FIN_PLAIN) {
+      if (tid < 128) par[PAR_GAMMA + tid] = gp[tid];
+      else if (A.in_op == GFV_IN_LN || A.fin_op == GFV_FIN_LN) par[PAR_BETA + tid - 128] = bp[tid - 128];
+    }
+  }
   int wbuf = 0;
   TS_DECL
   WBlk cur = w_block(A, 0, 0, 0);
@@ -351,7 +384,7 @@ __global__ __launch_bounds__(256, 2) void tchain_kernel(const gfv_rowtile_args_t
 #pragma unroll
               for (int r = 0; r < 4; ++r) dgam[t][r] = dbet[t][r] = 0.f;
           }
-          load_segment<T, LNM>(A, chunk, rowbase, g, act, dgam, dbet);
+          load_segment<T, LNM>(A, chunk, rowbase, g, par + PAR_GAMMA, par + PAR_BETA, act, dgam, dbet);
           if (lnb_in) ln_park(dgam, dbet, red, wave, li, g);
           TS_WAIT();
           TS(1);
@@ -396,16 +429,6 @@ __global__ __launch_bounds__(256, 2) void tchain_kernel(const gfv_rowtile_args_t
 
       if (!last) {
         // ---- intermediate epilogue: accumulators -> next layer's activations, in registers ----
-        const float* pad_s[T];
-        const float* pad_r[T];
-        if (layer == 0 && A.padd) {
-#pragma unroll
-          for (int tt = 0; tt < T; ++tt) {
-            const int mc = min(rowbase + 16 * tt, A.M - 1);
-            pad_s[tt] = A.padd + (size_t)A.padd_s[mc] * A.padd_ld + 4 * g;
-            pad_r[tt] = A.padd + (size_t)A.padd_r[mc] * A.padd_ld + 128 + 4 * g;
-          }
-        }
 #pragma unroll
         for (int tt = 0; tt < T; ++tt) {
           const int m = rowbase + 16 * tt;
@@ -419,8 +442,8 @@ __global__ __launch_bounds__(256, 2) void tchain_kernel(const gfv_rowtile_args_t
               v[0] *= gfv_dgelu(z.x); v[1] *= gfv_dgelu(z.y); v[2] *= gfv_dgelu(z.z); v[3] *= gfv_dgelu(z.w);
               if (L.save && live) st4(L.save + mrow + 16 * nt, v);
             } else {
-              if (L.bias) {
-                const float4 b = ld4(L.bias + 16 * nt + 4 * g);
+              {
+                const float4 b = ld4(par + 128 * layer + 16 * nt + 4 * g);
                 v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
               }
               if (layer == 0 && A.padd) {
@@ -468,8 +491,8 @@ __global__ __launch_bounds__(256, 2) void tchain_kernel(const gfv_rowtile_args_t
           for (int nt = 0; nt < 8; ++nt) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[nt][r] = acc[tt][nt][r];
-            if (L.bias && nt < ntv) {
-              const float4 b = ld4(L.bias + 128 * pass + 16 * nt + 4 * g);
+            if (nt < ntv) {
+              const float4 b = ld4(par + 128 * layer + 128 * pass + 16 * nt + 4 * g);
               v[nt][0] += b.x; v[nt][1] += b.y; v[nt][2] += b.z; v[nt][3] += b.w;
             }
             if (L.op == GFV_OP_MUL_DGELU && nt < ntv) {
@@ -484,7 +507,7 @@ __global__ __launch_bounds__(256, 2) void tchain_kernel(const gfv_rowtile_args_t
               for (int nt = 0; nt < 8; ++nt) st4(A.fin_presave + mc * 128 + 16 * nt + 4 * g, v[nt]);
             }
 #endif
-            ln_apply(v, A.fin_gamma, A.fin_beta, g);
+            ln_apply(v, par + PAR_GAMMA, par + PAR_BETA, g);
           } else if (lnb_fin) {
             float y[8][4];
 #pragma unroll
@@ -493,7 +516,7 @@ __global__ __launch_bounds__(256, 2) void tchain_kernel(const gfv_rowtile_args_t
               y[nt][0] = yy.x; y[nt][1] = yy.y; y[nt][2] = yy.z; y[nt][3] = yy.w;
               if (!live) v[nt][0] = v[nt][1] = v[nt][2] = v[nt][3] = 0.f;
             }
-            ln_bwd(v, y, A.fin_gamma, g, dgam, dbet);
+            ln_bwd(v, y, par + PAR_GAMMA, g, dgam, dbet);
           }
           if (live) {
 #ifndef ABL_NOSTORE
