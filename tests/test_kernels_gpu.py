@@ -230,6 +230,38 @@ def test_rowtile_node_mlp_backward_192_wide(dev):
     assert rel(dgb[:128], Pg["gamma"].grad) < TOL and rel(dgb[128:], Pg["beta"].grad) < TOL
 
 
+@pytest.mark.parametrize("M", [500, 64])
+def test_rowtile_factored_first_layer(dev, M):
+    """EdgeBlock first layer factored through the nodes: z1 = e W1c^T + (nb W1a^T)[s] + (nb W1b^T)[r] + b1 with W1c a
+    column block of W1 (row stride 384) and the node products gathered in the first epilogue (gfv.h: padd, ldw);
+    must equal the concat form (blocks.py:54 + EPD.py:21)."""
+    from gfv import lib as L, ops
+    g = torch.Generator().manual_seed(100 + M)
+    n_nodes = 200
+    nb = torch.randn(n_nodes, 128, generator=g)
+    e = torch.randn(M, 128, generator=g)
+    s = torch.randint(0, n_nodes, (M,), generator=g)
+    r = torch.randint(0, n_nodes, (M,), generator=g)
+    P = _mlp_params(g, 384)
+    X = torch.cat((nb[s], nb[r], e), 1).double()
+    z1, z2, y3, ln = _mlp_ref(P, X)
+    d = lambda t: t.to(dev).contiguous()
+    Pd = {k: d(v) for k, v in P.items()}
+    nbd, ed, sd, rd = d(nb), d(e), d(s.int()), d(r.int())
+    W1 = Pd["W1"]
+    pab = torch.empty(n_nodes, 256, device=dev)
+    ops.rowtile_chain(n_nodes, [ops.Seg(nbd)], [ops.LayerSpec(W1[:, 0:128])], [(pab, 256)])
+    ops.rowtile_chain(n_nodes, [ops.Seg(nbd)], [ops.LayerSpec(W1[:, 128:256])], [(pab.data_ptr() + 512, 256)])
+    assert rel(pab[:, :128], nb.double() @ P["W1"][:, :128].double().t()) < TOL
+    z1d, z2d, y3d, outd = (torch.empty(M, 128, device=dev) for _ in range(4))
+    ops.rowtile_chain(M, [ops.Seg(ed)],
+                      [ops.LayerSpec(W1[:, 256:384], Pd["b1"], L.OP_BIAS_GELU, save=z1d),
+                       ops.LayerSpec(Pd["W2"], Pd["b2"], L.OP_BIAS_GELU, save=z2d), ops.LayerSpec(Pd["W3"], Pd["b3"])],
+                      [outd], fin_op=L.FIN_LN, fin_gamma=Pd["gamma"], fin_beta=Pd["beta"], fin_presave=y3d, res=[ed],
+                      padd=pab, padd_s=sd, padd_r=rd)
+    assert rel(z1d, z1) < TOL and rel(z2d, z2) < TOL and rel(y3d, y3) < TOL and rel(outd, ln + e.double()) < TOL
+
+
 def test_rowtile_transolver_linears(dev):
     """Single-layer uses: X=a+b, LayerNorm prologue with N=256, GELU prologue with K=256, LN-backward epilogue."""
     from gfv import lib as L, ops

@@ -150,3 +150,31 @@ def test_reference_example_mesh_matches_reference_outputs(golden_dir):
             continue
         mine = cases.fingerprint(p.grad.cpu().numpy())
         assert abs(mine[1] - gfp[i, 1]) < 1e-4 * gfp[i, 1] + 1e-6 * gscale, k
+
+
+def test_factored_edge_block_and_side_stream_match_plain_path():
+    """The two engine-level restructurings (EdgeBlock first layer factored through the nodes; weight gradients on a
+    side stream) against the plain single-stream concat form, same kernels otherwise: losses and every gradient."""
+    graphs = cases.make_graphs("cyl_cavity_b2")
+    P = O.init_parameters(cases.WEIGHT_SEED)
+    results = []
+    for factor, overlap in ((True, True), (False, False)):
+        model = _hip_model(P)
+        eng = model.engine()
+        eng.factor, eng.overlap = factor, overlap
+        hg = tuple(g.clone().to("cuda") for g in graphs)
+        hg[0].norm_uvp, hg[0].norm_global = True, True
+        out = model(*hg)
+        hp = O.DEFAULT_HYPER
+        loss = torch.mean(torch.log(hp["loss_press"] * out[3] + hp["loss_cont"] * out[0] + hp["loss_mom"] * out[1]
+                                    + hp["loss_mom"] * out[2]))
+        loss.backward()
+        torch.cuda.synchronize()
+        results.append((float(loss), {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}))
+    (l0, g0), (l1, g1) = results
+    assert abs(l0 - l1) < TOL * abs(l1)
+    gscale = max(float(g.abs().max()) for g in g1.values())
+    assert g0.keys() == g1.keys()
+    for k in g1:
+        err = float((g0[k] - g1[k]).abs().max())
+        assert err < 1e-4 * float(g1[k].abs().max()) + 1e-6 * gscale, (k, err)
