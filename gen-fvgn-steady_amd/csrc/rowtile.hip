@@ -494,25 +494,6 @@ extern "C" int gfv_rowtile_chain(const gfv_rowtile_args_t* args, void* stream) {
   if ((args->in_op == GFV_IN_LN || args->in_op == GFV_IN_LNBWD) && (args->nseg != 1 || args->seg[0].width != 128))
     return GFV_ERR_ARG;
   const int tiles = (args->M + BM - 1) / BM;
-  void* tok = nullptr;
-  if (gfv_prof_enabled()) {
-    // algorithmic work: 2*M*K*N flops per layer; bytes: every input row read once, every output/saved row written once
-    double fl = 0, by = 0;
-    for (int l = 0; l < args->nlayers; ++l) {
-      fl += 2.0 * args->M * (double)args->layer[l].K * args->layer[l].N;
-      by += 4.0 * ((double)args->layer[l].K * args->layer[l].N + args->layer[l].N);
-      if (args->layer[l].save) by += 4.0 * args->M * args->layer[l].N;
-      if (args->layer[l].aux) by += 4.0 * args->M * args->layer[l].N;
-    }
-    by += 4.0 * args->M * (double)args->layer[0].K + 4.0 * args->M * (double)last.N;
-    for (int i = 0; i < args->nseg; ++i) if (args->seg[i].idx) by += 4.0 * args->M;
-    if (args->in_aux || args->fin_aux) by += 4.0 * args->M * 128.0;
-    if (args->in_save) by += 4.0 * args->M * 128.0;
-    if (args->fin_presave) by += 4.0 * args->M * 128.0;
-    if (args->out_nores) by += 4.0 * args->M * 128.0;
-    for (int c = 0; c < 3; ++c) if (args->res[c]) by += 4.0 * args->M * 128.0;
-    tok = gfv_prof_begin(GFV_K_ROWTILE, fl, by, (hipStream_t)stream);
-  }
   bool fast = true;
   for (int i = 0; i < args->nseg; ++i)
     fast = fast && (args->seg[i].width % 32 == 0) && (args->seg[i].ld % 4 == 0);
@@ -535,6 +516,28 @@ extern "C" int gfv_rowtile_chain(const gfv_rowtile_args_t* args, void* stream) {
             args->M, args->nseg, args->seg[0].width, args->nseg > 1 ? args->seg[1].width : 0,
             args->nseg > 2 ? args->seg[2].width : 0, args->seg[0].ld, args->nlayers, args->layer[0].K, last.N,
             args->out_ld[0], args->in_op, args->fin_op);
+  }
+  void* tok = nullptr;
+  if (gfv_prof_enabled()) {
+    // algorithmic work: 2*M*K*N flops per layer; bytes: every input row read once, every output/saved row written once
+    double fl = 0, by = 0;
+    for (int l = 0; l < args->nlayers; ++l) {
+      fl += 2.0 * args->M * (double)args->layer[l].K * args->layer[l].N;
+      by += 4.0 * ((double)args->layer[l].K * args->layer[l].N + args->layer[l].N);
+      if (args->layer[l].save) by += 4.0 * args->M * args->layer[l].N;
+      if (args->layer[l].aux) by += 4.0 * args->M * args->layer[l].N;
+    }
+    by += 4.0 * args->M * (double)args->layer[0].K + 4.0 * args->M * (double)last.N;
+    for (int i = 0; i < args->nseg; ++i) if (args->seg[i].idx) by += 4.0 * args->M;
+    if (args->in_aux || args->fin_aux) by += 4.0 * args->M * 128.0;
+    if (args->in_save) by += 4.0 * args->M * 128.0;
+    if (args->fin_presave) by += 4.0 * args->M * 128.0;
+    if (args->out_nores) by += 4.0 * args->M * 128.0;
+    if (args->padd) by += 4.0 * args->M * 258.0;
+    for (int c = 0; c < 3; ++c) if (args->res[c]) by += 4.0 * args->M * 128.0;
+    const int lnm = args->in_op == GFV_IN_LNBWD ? 1 : (args->fin_op == GFV_FIN_LNBWD ? 2 : 0);
+    const int kind = (fast_t && tchain_mode() != 0) ? GFV_K_TCHAIN0 + lnm : GFV_K_ROWTILE;
+    tok = gfv_prof_begin(kind, fl, by, (hipStream_t)stream);
   }
   if (fast_t && tchain_mode() != 0)
     gfv_internal_tchain_launch(args, tchain_mode(), (hipStream_t)stream);
