@@ -124,6 +124,45 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
   }
 }
 
+// many outputs, many chunks (weight-gradient slabs): a block = 64 column quads (float4) x 4 chunk groups; chunk group
+// cg sums chunks cg, cg+4, ... with four 16-B loads in flight, the four groups are combined through LDS in a fixed
+// order (deterministic).  n and the buffers are 16-B aligned (GradStore layout).
+__global__ __launch_bounds__(256) void reduce_partials_vec_kernel(const float* __restrict__ partial, int n_chunks, int n4,
+                                                                  float* __restrict__ out, int accumulate) {
+  __shared__ float4 red[4][64];
+  const int q = threadIdx.x & 63, cg = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + q;  // column quad
+  float4 s[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) s[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (j < n4) {
+    const float4* p = reinterpret_cast<const float4*>(partial) + j;
+    int c = cg;
+    for (; c + 12 < n_chunks; c += 16) {
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = p[(size_t)(c + 4 * u) * n4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { s[u].x += v[u].x; s[u].y += v[u].y; s[u].z += v[u].z; s[u].w += v[u].w; }
+    }
+    for (; c < n_chunks; c += 4) {
+      const float4 v = p[(size_t)c * n4];
+      s[0].x += v.x; s[0].y += v.y; s[0].z += v.z; s[0].w += v.w;
+    }
+  }
+  red[cg][q] = make_float4((s[0].x + s[1].x) + (s[2].x + s[3].x), (s[0].y + s[1].y) + (s[2].y + s[3].y),
+                           (s[0].z + s[1].z) + (s[2].z + s[3].z), (s[0].w + s[1].w) + (s[2].w + s[3].w));
+  __syncthreads();
+  if (cg == 0 && j < n4) {
+    const float4 a = red[0][q], b = red[1][q], c = red[2][q], d = red[3][q];
+    float4 t = make_float4((a.x + b.x) + (c.x + d.x), (a.y + b.y) + (c.y + d.y), (a.z + b.z) + (c.z + d.z),
+                           (a.w + b.w) + (c.w + d.w));
+    float4* o = reinterpret_cast<float4*>(out) + j;
+    if (accumulate) { const float4 pv = *o; t.x += pv.x; t.y += pv.y; t.z += pv.z; t.w += pv.w; }
+    *o = t;
+  }
+}
+
 // few outputs, many chunks (bias / LayerNorm partials): 32 columns x 8 chunk lanes per block, LDS tree at the end
 __global__ __launch_bounds__(1024) void reduce_partials_small_kernel(const float* __restrict__ partial, int n_chunks, int n,
                                                                      float* __restrict__ out, int accumulate) {
@@ -241,6 +280,12 @@ extern "C" int gfv_reduce_partials(const float* partial, int32_t n_chunks, int32
   if (n <= 4096 && n_chunks >= 32) {
     hipLaunchKernelGGL(reduce_partials_small_kernel, dim3((n + 31) / 32), dim3(1024), 0, (hipStream_t)stream, partial,
                        n_chunks, n, out, accumulate);
+    GFV_CHECK_LAUNCH();
+    return GFV_OK;
+  }
+  if ((n & 3) == 0 && n_chunks >= 16 && ((reinterpret_cast<size_t>(partial) | reinterpret_cast<size_t>(out)) & 15) == 0) {
+    hipLaunchKernelGGL(reduce_partials_vec_kernel, dim3((n / 4 + 63) / 64), dim3(256), 0, (hipStream_t)stream, partial,
+                       n_chunks, n / 4, out, accumulate);
     GFV_CHECK_LAUNCH();
     return GFV_OK;
   }
