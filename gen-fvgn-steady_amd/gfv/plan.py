@@ -14,7 +14,7 @@ from __future__ import annotations
 
 import torch
 
-SLICE_CHUNK = 64  # nodes per partial-token chunk (~400 workgroups on the 25k-node mesh)
+SLICE_CHUNK = int(__import__("os").environ.get("GFV_SLICE_CHUNK", "64"))  # nodes per partial-token chunk
 
 
 def _csr(index, n_rows):
