@@ -177,3 +177,36 @@ def test_trainstep_tracks_oracle(use_graph):
     assert rel(ts.uvp_node, oout[4]) < 1e-4
     worst = max(rel(ts.P[k], Po[k]) for k in Po)
     assert worst < 1e-4, worst
+
+
+def test_side_stream_is_bit_identical_and_repeatable():
+    """The side stream only reorders independent launches: parameters after 6 hipGraph-replayed steps on a 3 000-cell
+    mesh must be bit-identical with and without it, and from run to run (a buffer-lifetime race between the two
+    streams would show up here as a mismatch)."""
+    from FVMmodel.importer import NNmodel
+    from gfv import meshgen
+    from gfv.graph import build_batch
+    from gfv.params import default_params
+    from gfv.trainer import TrainStep
+    nx, ny = meshgen.cylinder_grid_for_cells(3000)
+    mesh = meshgen.finish_mesh(meshgen.raw_tri_channel_cylinder(nx=nx, ny=ny, seed=5), U=0.3)
+    graphs = build_batch([mesh], [meshgen.random_fields(mesh, seed=9)])
+    P = O.init_parameters(cases.WEIGHT_SEED)
+    finals = []
+    for overlap in (True, False, True):
+        model = NNmodel(default_params(dataset_size=1))
+        sd = model.state_dict()
+        for k, v in P.items():
+            sd[k].copy_(v)
+        model.load_state_dict(sd)
+        model = model.cuda()
+        model.engine().overlap = overlap
+        ts = TrainStep(model, tuple(g.clone().to("cuda") for g in graphs), use_graph=True)
+        for _ in range(6):
+            ts.step()
+        torch.cuda.synchronize()
+        finals.append(({k: v.clone() for k, v in ts.P.items()}, float(ts.loss)))  # (alignment padding of the flat buffer excluded)
+    for other in finals[1:]:
+        assert other[1] == finals[0][1]
+        bad = [k for k in finals[0][0] if not torch.equal(other[0][k], finals[0][0][k])]
+        assert not bad, bad
