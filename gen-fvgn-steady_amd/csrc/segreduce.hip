@@ -163,6 +163,44 @@ __global__ __launch_bounds__(256) void reduce_partials_vec_kernel(const float* _
   }
 }
 
+// segmented form: out[b, :] = sum of the chunk rows seg_ptr[b] .. seg_ptr[b+1]-1 (blockIdx.y = b); same thread layout
+// and summation order as reduce_partials_vec_kernel.  Used to pre-reduce the per-chunk slice tokens of every graph, so
+// that the (graph, head) attention blocks - only 8 per graph - do not walk hundreds of chunk partials serially.
+__global__ __launch_bounds__(256) void reduce_partials_seg_kernel(const float* __restrict__ partial,
+                                                                  const int* __restrict__ seg_ptr, int n4,
+                                                                  float* __restrict__ out) {
+  __shared__ float4 red[4][64];
+  const int q = threadIdx.x & 63, cg = threadIdx.x >> 6, b = blockIdx.y;
+  const int j = blockIdx.x * 64 + q;
+  const int c0 = seg_ptr[b], c1 = seg_ptr[b + 1];
+  float4 s[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) s[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (j < n4) {
+    const float4* p = reinterpret_cast<const float4*>(partial) + j;
+    int c = c0 + cg;
+    for (; c + 12 < c1; c += 16) {
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = p[(size_t)(c + 4 * u) * n4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { s[u].x += v[u].x; s[u].y += v[u].y; s[u].z += v[u].z; s[u].w += v[u].w; }
+    }
+    for (; c < c1; c += 4) {
+      const float4 v = p[(size_t)c * n4];
+      s[0].x += v.x; s[0].y += v.y; s[0].z += v.z; s[0].w += v.w;
+    }
+  }
+  red[cg][q] = make_float4((s[0].x + s[1].x) + (s[2].x + s[3].x), (s[0].y + s[1].y) + (s[2].y + s[3].y),
+                           (s[0].z + s[1].z) + (s[2].z + s[3].z), (s[0].w + s[1].w) + (s[2].w + s[3].w));
+  __syncthreads();
+  if (cg == 0 && j < n4) {
+    const float4 a = red[0][q], bb = red[1][q], c = red[2][q], d = red[3][q];
+    reinterpret_cast<float4*>(out)[(size_t)b * n4 + j] =
+        make_float4((a.x + bb.x) + (c.x + d.x), (a.y + bb.y) + (c.y + d.y), (a.z + bb.z) + (c.z + d.z), (a.w + bb.w) + (c.w + d.w));
+  }
+}
+
 // few outputs, many chunks (bias / LayerNorm partials): 32 columns x 8 chunk lanes per block, LDS tree at the end
 __global__ __launch_bounds__(1024) void reduce_partials_small_kernel(const float* __restrict__ partial, int n_chunks, int n,
                                                                      float* __restrict__ out, int accumulate) {
@@ -291,6 +329,16 @@ extern "C" int gfv_reduce_partials(const float* partial, int32_t n_chunks, int32
   }
   hipLaunchKernelGGL(reduce_partials_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, partial,
                      n_chunks, n, out, accumulate);
+  GFV_CHECK_LAUNCH();
+  return GFV_OK;
+}
+
+extern "C" int gfv_reduce_partials_seg(const float* partial, const int32_t* seg_ptr, int32_t n_seg, int32_t n, float* out,
+                                       void* stream) {
+  if (n_seg <= 0 || n <= 0) return GFV_OK;
+  if ((n & 3) || ((reinterpret_cast<size_t>(partial) | reinterpret_cast<size_t>(out)) & 15)) return GFV_ERR_ARG;
+  hipLaunchKernelGGL(reduce_partials_seg_kernel, dim3((n / 4 + 63) / 64, n_seg), dim3(256), 0, (hipStream_t)stream,
+                     partial, seg_ptr, n / 4, out);
   GFV_CHECK_LAUNCH();
   return GFV_OK;
 }

@@ -411,9 +411,10 @@ class Engine:
         partial = _empty(dev, pl.n_chunks, 256, 17)
         L.check(lib.gfv_slice_token_partial(w.data_ptr(), fx_mid.data_ptr(), pl.chunk_beg.data_ptr(),
                                             pl.chunk_end.data_ptr(), pl.n_chunks, partial.data_ptr(), st), "token_partial")
+        partial = self._graph_partials(partial, pl)
         token, norm = _empty(dev, B, 8, 32, 16), _empty(dev, B, 8, 32)
         attn, out_token = _empty(dev, B, 8, 32, 32), _empty(dev, B, 8, 32, 16)
-        L.check(lib.gfv_slice_attention_fwd(partial.data_ptr(), pl.gchunk_ptr.data_ptr(), B, P[f"{a}.to_q.weight"].data_ptr(),
+        L.check(lib.gfv_slice_attention_fwd(partial.data_ptr(), pl.gunit_ptr.data_ptr(), B, P[f"{a}.to_q.weight"].data_ptr(),
                                             P[f"{a}.to_k.weight"].data_ptr(), P[f"{a}.to_v.weight"].data_ptr(),
                                             token.data_ptr(), norm.data_ptr(), attn.data_ptr(), out_token.data_ptr(), st),
                 "slice_attention_fwd")
@@ -435,6 +436,15 @@ class Engine:
         sv = dict(prefix=prefix, fx_in=fx_in, fx_mid=fx_mid, x_mid=x_mid, w=w, token=token, norm=norm, attn=attn,
                   out_token=out_token, out_x=out_x, fx1=fx1, z=z)
         return out, sv
+
+    @staticmethod
+    def _graph_partials(partial, pl):
+        """[n_chunks, 256, 17] per-chunk slice tokens -> [B, 256, 17] per-graph sums (one wide launch; the attention
+        blocks - 8 per graph - then read one row instead of walking every chunk of their graph)."""
+        out = _empty(partial.device, pl.B, 256, 17)
+        L.check(L.load().gfv_reduce_partials_seg(partial.data_ptr(), pl.gchunk_ptr.data_ptr(), pl.B, 256 * 17,
+                                                 out.data_ptr(), L.stream_ptr()), "reduce_partials_seg")
+        return out
 
     def trans_bwd(self, P, sv, g_out, grads, pl):
         lib = L.load()
@@ -481,7 +491,8 @@ class Engine:
                                             pl.chunk_end.data_ptr(), pl.n_chunks, gpartial.data_ptr(), st), "token_partial")
         g_raw, g_norm = _empty(dev, B, 8, 32, 16), _empty(dev, B, 8, 32)
         dwp = _empty(dev, B * 8, 3, 16, 16)
-        L.check(lib.gfv_slice_attention_bwd(gpartial.data_ptr(), pl.gchunk_ptr.data_ptr(), B,
+        gpartial = self._graph_partials(gpartial, pl)
+        L.check(lib.gfv_slice_attention_bwd(gpartial.data_ptr(), pl.gunit_ptr.data_ptr(), B,
                                             P[f"{a}.to_q.weight"].data_ptr(), P[f"{a}.to_k.weight"].data_ptr(),
                                             P[f"{a}.to_v.weight"].data_ptr(), sv["token"].data_ptr(), sv["norm"].data_ptr(),
                                             sv["attn"].data_ptr(), g_raw.data_ptr(), g_norm.data_ptr(), dwp.data_ptr(), st),

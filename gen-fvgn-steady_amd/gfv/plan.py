@@ -82,6 +82,7 @@ def _batch_part(p, nb, B=None):
     p.chunk_end = torch.tensor(ce, dtype=torch.int32, device=dev)
     p.gchunk_ptr = torch.tensor(gcp, dtype=torch.int32, device=dev)
     p.n_chunks = len(cb)
+    p.gunit_ptr = torch.arange(B + 1, dtype=torch.int32, device=dev)  # one pre-reduced partial row per graph
     return p
 
 

@@ -158,6 +158,11 @@ int gfv_dw_multi(const gfv_dw_tile_t* tiles, int32_t ntiles, int32_t M, int64_t 
 int gfv_reduce_partials(const float* partial, int32_t n_chunks, int32_t n, float* out, int32_t accumulate,
                         void* stream);
 
+/* Segmented form: out[b, 0:n] = sum of the chunk rows seg_ptr[b] .. seg_ptr[b+1]-1 of partial [n_chunks, n] (n % 4 == 0,
+ * 16-byte aligned).  Pre-reduces the per-chunk slice tokens of each graph (GraphTransolver.py:64-73 global_add_pool). */
+int gfv_reduce_partials_seg(const float* partial, const int32_t* seg_ptr, int32_t n_seg, int32_t n, float* out,
+                            void* stream);
+
 /* Batched form: one launch for all weight transposes of a step; `descs` [n] lives in DEVICE memory. */
 typedef struct {
   const float* in; /* [rows, ld_in], columns [0, cols) are transposed */
