@@ -158,8 +158,9 @@ def main():
     if rank == 0:
         out = (ctypes.c_double * 4)()
         # names as rocprofv3 prints them (profiles/*_kernel_stats.csv)
-        spec = {7: ("tchain_kernel<1, 0>", "mfma"), 8: ("tchain_kernel<1, 1>", "mfma"), 9: ("tchain_kernel<1, 2>", "mfma"),
-                1: ("rowtile_chain_kernel<false>", "mfma"), 2: ("dw_multi_kernel", "mfma"), 3: ("seg_gather_sum_vec", "hbm")}
+        spec = {7: ("tchain_kernel<1, 0, false>", "mfma"), 8: ("tchain_kernel<1, 1, false>", "mfma"),
+                9: ("tchain_kernel<1, 2, false>", "mfma"), 10: ("tchain_kernel<1, 0, true>", "mfma"),
+                1: ("rowtile_chain_kernel", "mfma"), 2: ("dw_multi_kernel", "mfma"), 3: ("seg_gather_sum_vec", "hbm")}
         for kind, (kname, bound) in spec.items():
             lib.gfv_profile_collect(kind, out)
             n, ms, fl, by = out[0], out[1], out[2], out[3]

@@ -510,8 +510,18 @@ extern "C" int gfv_rowtile_chain(const gfv_rowtile_args_t* args, void* stream) {
     if (args->out[c]) { fast = fast && (args->out_ld[c] % 4 == 0); fast_t = fast_t && (args->out_ld[c] % 4 == 0); }
     if (args->res[c]) { fast = fast && (args->res_ld[c] % 4 == 0); fast_t = fast_t && (args->res_ld[c] % 4 == 0); }
   }
+  // ragged shapes the register-resident chain also takes (its RAG instantiation): any segment width / row stride, any
+  // first-layer K, a last layer of any width <= 128 (decoder N = 3); no LayerNorm backward, no DGELU on a ragged last
+  // layer, inner layers 128 wide
+  bool rag_t = !fast_t && args->in_op != GFV_IN_LNBWD && args->fin_op != GFV_FIN_LNBWD;
+  for (int l = 0; l + 1 < args->nlayers; ++l) rag_t = rag_t && args->layer[l].N == 128;
+  if (last.N > 128) rag_t = rag_t && (last.N % 64 == 0);
+  if (last.N % 16) rag_t = rag_t && last.op != GFV_OP_MUL_DGELU && args->fin_op == GFV_FIN_PLAIN && !args->out_nores;
+  if (args->in_op == GFV_IN_LN) rag_t = rag_t && args->seg[0].width == 128 && (args->seg[0].ld % 4 == 0);
+  if (args->gadd) rag_t = rag_t && args->seg[0].width == 128 && (args->seg[0].ld % 4 == 0);
+  for (int l = 1; l < args->nlayers; ++l) rag_t = rag_t && (args->layer[l].K == 128);
   static const bool dbg = getenv("GFV_ROWTILE_DEBUG") != nullptr;
-  if (dbg && !fast_t) {
+  if (dbg && !fast_t && !rag_t) {
     fprintf(stderr, "[gfv] generic rowtile: M=%d nseg=%d widths=%d,%d,%d ld0=%d nlayers=%d K0=%d Nlast=%d out_ld=%d in_op=%d fin_op=%d\n",
             args->M, args->nseg, args->seg[0].width, args->nseg > 1 ? args->seg[1].width : 0,
             args->nseg > 2 ? args->seg[2].width : 0, args->seg[0].ld, args->nlayers, args->layer[0].K, last.N,
@@ -536,11 +546,13 @@ extern "C" int gfv_rowtile_chain(const gfv_rowtile_args_t* args, void* stream) {
     if (args->padd) by += 4.0 * args->M * 258.0;
     for (int c = 0; c < 3; ++c) if (args->res[c]) by += 4.0 * args->M * 128.0;
     const int lnm = args->in_op == GFV_IN_LNBWD ? 1 : (args->fin_op == GFV_FIN_LNBWD ? 2 : 0);
-    const int kind = (fast_t && tchain_mode() != 0) ? GFV_K_TCHAIN0 + lnm : GFV_K_ROWTILE;
+    const int kind = (fast_t && tchain_mode() != 0) ? GFV_K_TCHAIN0 + lnm : ((rag_t && tchain_mode() != 0) ? GFV_K_TCHAIN_RAG : GFV_K_ROWTILE);
     tok = gfv_prof_begin(kind, fl, by, (hipStream_t)stream);
   }
   if (fast_t && tchain_mode() != 0)
     gfv_internal_tchain_launch(args, tchain_mode(), (hipStream_t)stream);
+  else if (rag_t && tchain_mode() != 0)
+    gfv_internal_tchain_launch(args, -1, (hipStream_t)stream);
   else if (fast)
     hipLaunchKernelGGL(rowtile_chain_kernel<true>, dim3(tiles), dim3(256), 0, (hipStream_t)stream, *args);
   else

@@ -44,6 +44,8 @@ struct WBlk {
   int ldw;
   int nsl;    // 32-wide slices in the block
   int nrows;  // valid output rows of the block (128, or the 64-wide tail of a 192-wide last layer)
+  int kvalid; // valid k columns of the block (RAG instantiation: first-layer K of 12 / 15 / 3)
+  int rag;    // block needs element-wise weight loads (k not a multiple of 32, or rows not 16-B aligned)
 };
 
 __device__ __forceinline__ WBlk w_block(const gfv_rowtile_args_t& A, int layer, int pass, int chunk) {
@@ -56,8 +58,10 @@ __device__ __forceinline__ WBlk w_block(const gfv_rowtile_args_t& A, int layer, 
   WBlk b;
   b.ldw = L.ldw ? L.ldw : L.K;
   b.w = L.W + (size_t)(128 * pass) * b.ldw + koff;
-  b.nsl = width / WK;
+  b.nsl = (width + WK - 1) / WK;
   b.nrows = min(128, L.N - 128 * pass);
+  b.kvalid = width;
+  b.rag = ((width % WK != 0) || (b.ldw & 3) || ((reinterpret_cast<size_t>(b.w) & 15) != 0)) ? 1 : 0;
   return b;
 }
 
@@ -75,6 +79,23 @@ __device__ __forceinline__ WRegs w_load(const float* w, int ldw, int nrows, int 
   r.b = *reinterpret_cast<const floatx4*>(p0 + (size_t)min(wrow + 32, last) * ldw);
   r.c = *reinterpret_cast<const floatx4*>(p0 + (size_t)min(wrow + 64, last) * ldw);
   r.d = *reinterpret_cast<const floatx4*>(p0 + (size_t)min(wrow + 96, last) * ldw);
+  return r;
+}
+// element-wise form for ragged blocks: k >= kvalid reads as zero, no alignment assumed
+__device__ __forceinline__ WRegs w_load_ragged(const float* w, int ldw, int nrows, int k0, int kvalid, int wrow, int wc) {
+  WRegs r;
+  const int last = nrows - 1;
+  floatx4 v[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const float* rp = w + (size_t)min(wrow + 32 * p, last) * ldw;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int k = k0 + wc + e;
+      v[p][e] = k < kvalid ? rp[k] : 0.f;
+    }
+  }
+  r.a = v[0]; r.b = v[1]; r.c = v[2]; r.d = v[3];
   return r;
 }
 __device__ __forceinline__ void w_store(float* Wb, int tid, const WRegs& r) {
@@ -206,7 +227,7 @@ __device__ __forceinline__ void mma_slice(floatx4 (&acc)[T][8], const float (&ac
 }
 
 // ---- input segment -> activation registers (gather / concat piece / prologue element ops) -------------------------
-template <int T, int LNM>
+template <int T, int LNM, bool RAG>
 __device__ __forceinline__ void load_segment(const gfv_rowtile_args_t& A, int si, int rowbase, int g, const float* gam,
                                              const float* bet, float (&act)[T][8][4], float (&dgam)[8][4],
                                              float (&dbet)[8][4]) {
@@ -220,6 +241,21 @@ __device__ __forceinline__ void load_segment(const gfv_rowtile_args_t& A, int si
     const int mc = live ? m : A.M - 1;
     const size_t srow = s.idx ? (size_t)s.idx[mc] : (size_t)mc;
     const float* rp = s.ptr + srow * (size_t)s.ld + 4 * g;
+    if (RAG && ((s.width & 31) || (s.ld & 3))) {
+      // ragged segment (encoder inputs of 12 / 15 columns, the decoder's 3-wide gradient): element-wise, zero padded
+#pragma unroll
+      for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int col = 16 * t + 4 * g + r;
+          float v = 0.f;
+          if (col < s.width) {
+            v = rp[16 * t + r];
+            if (first && A.in_add) v += A.in_add[srow * (size_t)s.ld + col];
+          }
+          act[tt][t][r] = v;
+        }
+    } else {
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -230,7 +266,8 @@ __device__ __forceinline__ void load_segment(const gfv_rowtile_args_t& A, int si
 #endif
       act[tt][t][0] = v.x; act[tt][t][1] = v.y; act[tt][t][2] = v.z; act[tt][t][3] = v.w;
     }
-    if (first && A.in_add) {
+    }
+    if (first && A.in_add && !(RAG && ((s.width & 31) || (s.ld & 3)))) {
       const float* ap = A.in_add + srow * (size_t)s.ld + 4 * g;
 #pragma unroll
       for (int t = 0; t < 8; ++t)
@@ -287,7 +324,9 @@ __device__ __forceinline__ void load_segment(const gfv_rowtile_args_t& A, int si
 
 // LNM: 0 = no LayerNorm backward, 1 = GFV_IN_LNBWD prologue, 2 = GFV_FIN_LNBWD epilogue (the (dgamma, dbeta)
 // accumulators exist only in those instantiations)
-template <int T, int LNM>
+// RAG: also takes ragged shapes (first-layer K / segment widths that are not multiples of 32, unaligned rows, a last
+// layer narrower than 64): element-wise loads / stores on those pieces only
+template <int T, int LNM, bool RAG>
 __global__ __launch_bounds__(256, 2) void tchain_kernel(const gfv_rowtile_args_t A) {
   __shared__ __attribute__((aligned(16))) float lds[2 * WS_FLOATS + 1024 + PAR_FLOATS];
   float* red = lds + 2 * WS_FLOATS;
@@ -340,7 +379,8 @@ __global__ __launch_bounds__(256, 2) void tchain_kernel(const gfv_rowtile_args_t
   // weight pipeline, prefetch distance 2: at the start of slice j (parity p) LDS buffer p holds slice j and register
   // set 1-p holds slice j+1; slice j issues the loads of slice j+2 into set p, runs its MFMAs, then parks set 1-p in
   // buffer 1-p.  Every block has an even number of slices, so the parity is the unrolled slice index.
-  WRegs wr0 = w_load(cur.w, cur.ldw, cur.nrows, wrow, wc);
+  WRegs wr0 = (RAG && cur.rag) ? w_load_ragged(cur.w, cur.ldw, cur.nrows, 0, cur.kvalid, wrow, wc)
+                               : w_load(cur.w, cur.ldw, cur.nrows, wrow, wc);
   w_store(lds, tid, wr0);
 #if W_DIST == 2
   WRegs wr1 = w_load(cur.w + WK, cur.ldw, cur.nrows, wrow, wc);
@@ -384,7 +424,7 @@ __global__ __launch_bounds__(256, 2) void tchain_kernel(const gfv_rowtile_args_t
 #pragma unroll
               for (int r = 0; r < 4; ++r) dgam[t][r] = dbet[t][r] = 0.f;
           }
-          load_segment<T, LNM>(A, chunk, rowbase, g, par + PAR_GAMMA, par + PAR_BETA, act, dgam, dbet);
+          load_segment<T, LNM, RAG>(A, chunk, rowbase, g, par + PAR_GAMMA, par + PAR_BETA, act, dgam, dbet);
           if (lnb_in) ln_park(dgam, dbet, red, wave, li, g);
           TS_WAIT();
           TS(1);
@@ -403,8 +443,13 @@ __global__ __launch_bounds__(256, 2) void tchain_kernel(const gfv_rowtile_args_t
             const int wld = more ? cur.ldw : nxt.ldw;
             const int wnr = more ? cur.nrows : nxt.nrows;
 #ifndef ABL_NOW
-            if (W_DIST == 1 || !(sl & 1)) wr0 = w_load(wsrc, wld, wnr, wrow, wc);
-            else wr1 = w_load(wsrc, wld, wnr, wrow, wc);
+            if (RAG && (more ? cur.rag : nxt.rag)) {
+              wr0 = w_load_ragged(more ? cur.w : nxt.w, wld, wnr, more ? WK * (sl + 1) : 0, more ? cur.kvalid : nxt.kvalid,
+                                  wrow, wc);
+            } else {
+              if (W_DIST == 1 || !(sl & 1)) wr0 = w_load(wsrc, wld, wnr, wrow, wc);
+              else wr1 = w_load(wsrc, wld, wnr, wrow, wc);
+            }
 #endif
 #ifndef NO_SCHEDB
             __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ABOVE the MFMAs (the scheduler sinks it otherwise)
@@ -473,7 +518,9 @@ __global__ __launch_bounds__(256, 2) void tchain_kernel(const gfv_rowtile_args_t
         const float* res = pass == 0 ? A.res[0] : (pass == 1 ? A.res[1] : A.res[2]);
         const int old = pass == 0 ? A.out_ld[0] : (pass == 1 ? A.out_ld[1] : A.out_ld[2]);
         const int rld = pass == 0 ? A.res_ld[0] : (pass == 1 ? A.res_ld[1] : A.res_ld[2]);
-        const int ntv = min(128, L.N - 128 * pass) >> 4;  // valid 16-column groups of this chunk (8, or 4 for N = 192)
+        const int ncols = min(128, L.N - 128 * pass);
+        const int ntv = (ncols + 15) >> 4;  // 16-column groups of this chunk with valid columns (8; 4 for N = 192; 1 for N = 3)
+        const bool rag_out = RAG && ((ncols & 15) || (old & 3));
         float dgam[8][4], dbet[8][4];
         if (lnb_fin) {
 #pragma unroll
@@ -528,11 +575,19 @@ __global__ __launch_bounds__(256, 2) void tchain_kernel(const gfv_rowtile_args_t
 #pragma unroll
             for (int nt = 0; nt < 8; ++nt) {
               if (nt < ntv) {
-                if (res) {
-                  const float4 rv = ld4(res + mc * (size_t)rld + 16 * nt + 4 * g);
-                  v[nt][0] += rv.x; v[nt][1] += rv.y; v[nt][2] += rv.z; v[nt][3] += rv.w;
+                if (rag_out) {
+#pragma unroll
+                  for (int r = 0; r < 4; ++r) {
+                    const int col = 16 * nt + 4 * g + r;
+                    if (col < ncols) out[mc * (size_t)old + col] = v[nt][r] + (res ? res[mc * (size_t)rld + col] : 0.f);
+                  }
+                } else {
+                  if (res) {
+                    const float4 rv = ld4(res + mc * (size_t)rld + 16 * nt + 4 * g);
+                    v[nt][0] += rv.x; v[nt][1] += rv.y; v[nt][2] += rv.z; v[nt][3] += rv.w;
+                  }
+                  st4(out + mc * (size_t)old + 16 * nt + 4 * g, v[nt]);
                 }
-                st4(out + mc * (size_t)old + 16 * nt + 4 * g, v[nt]);
               }
             }
           }
@@ -566,19 +621,24 @@ __global__ __launch_bounds__(256, 2) void tchain_kernel(const gfv_rowtile_args_t
 
 }  // namespace
 
-// fast-path launcher used by gfv_rowtile_chain (rowtile.hip); rows_per_wg: 64 or 128
+// fast-path launcher used by gfv_rowtile_chain (rowtile.hip); rows_per_wg: 64 or 128, < 0 = ragged-shape instantiation
 int gfv_internal_tchain_launch(const gfv_rowtile_args_t* args, int rows_per_wg, hipStream_t stream) {
   const int lnm = args->in_op == GFV_IN_LNBWD ? 1 : (args->fin_op == GFV_FIN_LNBWD ? 2 : 0);
+  if (rows_per_wg < 0) {  // ragged shapes (only without LayerNorm backward)
+    const dim3 wgs((args->M + 63) / 64);
+    hipLaunchKernelGGL((tchain_kernel<1, 0, true>), wgs, dim3(256), 0, stream, *args);
+    return 0;
+  }
   if (rows_per_wg == 128) {
     const dim3 wgs((args->M + 127) / 128);
-    if (lnm == 0) hipLaunchKernelGGL((tchain_kernel<2, 0>), wgs, dim3(256), 0, stream, *args);
-    else if (lnm == 1) hipLaunchKernelGGL((tchain_kernel<2, 1>), wgs, dim3(256), 0, stream, *args);
-    else hipLaunchKernelGGL((tchain_kernel<2, 2>), wgs, dim3(256), 0, stream, *args);
+    if (lnm == 0) hipLaunchKernelGGL((tchain_kernel<2, 0, false>), wgs, dim3(256), 0, stream, *args);
+    else if (lnm == 1) hipLaunchKernelGGL((tchain_kernel<2, 1, false>), wgs, dim3(256), 0, stream, *args);
+    else hipLaunchKernelGGL((tchain_kernel<2, 2, false>), wgs, dim3(256), 0, stream, *args);
   } else {
     const dim3 wgs((args->M + 63) / 64);
-    if (lnm == 0) hipLaunchKernelGGL((tchain_kernel<1, 0>), wgs, dim3(256), 0, stream, *args);
-    else if (lnm == 1) hipLaunchKernelGGL((tchain_kernel<1, 1>), wgs, dim3(256), 0, stream, *args);
-    else hipLaunchKernelGGL((tchain_kernel<1, 2>), wgs, dim3(256), 0, stream, *args);
+    if (lnm == 0) hipLaunchKernelGGL((tchain_kernel<1, 0, false>), wgs, dim3(256), 0, stream, *args);
+    else if (lnm == 1) hipLaunchKernelGGL((tchain_kernel<1, 1, false>), wgs, dim3(256), 0, stream, *args);
+    else hipLaunchKernelGGL((tchain_kernel<1, 2, false>), wgs, dim3(256), 0, stream, *args);
   }
   return 0;
 }

@@ -12,9 +12,8 @@ import os
 import sys
 
 out_dir = sys.argv[1]
-KEYS = {"tchain_kernel<1, 0>": "tchain_kernel<1, 0>", "tchain_kernel<1, 1>": "tchain_kernel<1, 1>",
-        "tchain_kernel<1, 2>": "tchain_kernel<1, 2>", "rowtile_chain_kernel<false>": "rowtile_chain_kernel<false>",
-        "dw_multi_kernel": "dw_multi_kernel", "seg_gather_sum_vec": "seg_gather_sum_vec"}
+KEYS = {k: k for k in ("tchain_kernel<1, 0, false>", "tchain_kernel<1, 1, false>", "tchain_kernel<1, 2, false>",
+                       "tchain_kernel<1, 0, true>", "rowtile_chain_kernel", "dw_multi_kernel", "seg_gather_sum_vec")}
 acc = {c: collections.defaultdict(lambda: [0.0, 0]) for c in ("FETCH_SIZE", "WRITE_SIZE")}
 for c in acc:
     for f in glob.glob(os.path.join(out_dir, f"pmc_{c}", "**", "*counter_collection.csv"), recursive=True):
