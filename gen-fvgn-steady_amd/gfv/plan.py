@@ -140,10 +140,10 @@ def wlsq_part(p, face_node_x, support_edge, A, B1, Bx, N):
     p.xo_B = Bfull[o_out].contiguous()
     # per-receiver sum of the moment vectors: segmented sum over the CSR order by a float64 prefix sum (index_add_ on the
     # device uses float atomics: the plan, and with it every gradient, would differ in the last bit from run to run)
-    cs = torch.zeros((p.x_B.shape[0] + 1, 5), dtype=torch.float64, device=dev)
-    cs[1:] = torch.cumsum(p.x_B.to(torch.float64), 0)
+    cs = torch.zeros((5, p.x_B.shape[0] + 1), dtype=torch.float64, device=dev)
+    cs[:, 1:] = torch.cumsum(p.x_B.to(torch.float64).t().contiguous(), 1)   # scan along the contiguous dimension
     rp = p.x_rowptr.to(torch.int64)
-    p.sumB = (cs[rp[1:]] - cs[rp[:-1]]).to(torch.float32).contiguous()
+    p.sumB = (cs[:, rp[1:]] - cs[:, rp[:-1]]).t().to(torch.float32).contiguous()
     A = A.to(torch.float32)
     row_norms = torch.norm(A, p=2, dim=2, keepdim=True)          # FVgrad.py:335
     p.rn = (row_norms + 1e-8).reshape(N, 5).contiguous()
