@@ -237,3 +237,33 @@ extern "C" int gfv_train_loss(const float* losses, int32_t B, float w_cont, floa
   GFV_CHECK_LAUNCH();
   return GFV_OK;
 }
+
+// ---- batch assembly for the device-resident state pool ---------------------------------------
+// One launch copies every per-mesh piece of every plan / field tensor of a batch to its place in the batched tensor,
+// adding the index offset of the mesh (node / face / cell / incidence offsets of the block-diagonal batch,
+// Graph_loader.py:405-480 __inc__ rules); kind 2 fills a constant (graph id).  32-bit words throughout.
+namespace {
+__global__ __launch_bounds__(256) void concat_offsets_kernel(const gfv_concat_desc_t* __restrict__ descs) {
+  const gfv_concat_desc_t d = descs[blockIdx.y];
+  const long n = d.n_words;
+  const int* __restrict__ src = reinterpret_cast<const int*>(d.src);
+  int* __restrict__ dst = reinterpret_cast<int*>(d.dst);
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    int v;
+    if (d.kind == 2) v = d.add;
+    else {
+      v = src[i];
+      if (d.kind == 1) v += d.add;
+    }
+    dst[i] = v;
+  }
+}
+}  // namespace
+
+extern "C" int gfv_concat_offsets(const gfv_concat_desc_t* descs, int32_t n_desc, int32_t blocks_per_desc, void* stream) {
+  if (n_desc <= 0) return GFV_OK;
+  if (blocks_per_desc < 1) blocks_per_desc = 1;
+  hipLaunchKernelGGL(concat_offsets_kernel, dim3(blocks_per_desc, n_desc), dim3(256), 0, (hipStream_t)stream, descs);
+  GFV_CHECK_LAUNCH();
+  return GFV_OK;
+}

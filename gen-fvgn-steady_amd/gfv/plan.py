@@ -138,12 +138,15 @@ def wlsq_part(p, face_node_x, support_edge, A, B1, Bx, N):
     p.xo_rowptr, o_out = _csr(out_idx, N)
     p.xo_in = i32(in_idx[o_out])
     p.xo_B = Bfull[o_out].contiguous()
-    # per-receiver sum of the moment vectors: segmented sum over the CSR order by a float64 prefix sum (index_add_ on the
-    # device uses float atomics: the plan, and with it every gradient, would differ in the last bit from run to run)
-    cs = torch.zeros((5, p.x_B.shape[0] + 1), dtype=torch.float64, device=dev)
-    cs[:, 1:] = torch.cumsum(p.x_B.to(torch.float64).t().contiguous(), 1)   # scan along the contiguous dimension
+    # per-receiver sum of the moment vectors: exact fixed-point (2^-40) prefix sum in int64 and a difference per CSR row.
+    # Integer arithmetic is associative and wraps modulo 2^64, so the row sums are exact whatever precedes them:
+    # deterministic (index_add_ on the device uses float atomics - every gradient would differ in the last bit from run
+    # to run) and independent of where the mesh sits in a batch (gfv.pool assembles plans mesh by mesh).
+    fx = torch.round(p.x_B.to(torch.float64) * float(2 ** 40)).to(torch.int64).t().contiguous()      # [5, S]
+    cs = torch.zeros((5, fx.shape[1] + 1), dtype=torch.int64, device=dev)
+    cs[:, 1:] = torch.cumsum(fx, 1)
     rp = p.x_rowptr.to(torch.int64)
-    p.sumB = (cs[:, rp[1:]] - cs[:, rp[:-1]]).t().to(torch.float32).contiguous()
+    p.sumB = ((cs[:, rp[1:]] - cs[:, rp[:-1]]).to(torch.float64) * float(2.0 ** -40)).t().to(torch.float32).contiguous()
     A = A.to(torch.float32)
     row_norms = torch.norm(A, p=2, dim=2, keepdim=True)          # FVgrad.py:335
     p.rn = (row_norms + 1e-8).reshape(N, 5).contiguous()
@@ -208,6 +211,9 @@ def build_plan(graph_node, graph_node_x, graph_edge, graph_cell, graph_Index):
 def get_plan(graphs):
     """Plan cached on graph_node (keyed by the identity of its index tensors)."""
     graph_node = graphs[0]
+    pooled = getattr(graph_node, "_gfv_pool_plan", None)   # batch assembled by gfv.pool.DevicePool: plan comes with it
+    if pooled is not None:
+        return pooled
     key = (graph_node.edge_index.data_ptr(), graph_node.face.data_ptr(), graphs[1].face_node_x.data_ptr(),
            graph_node.x.shape[0], str(graph_node.x.device))
     cached = getattr(graph_node, "_gfv_plan", None)

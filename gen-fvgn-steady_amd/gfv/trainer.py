@@ -63,6 +63,18 @@ class TrainStep:
         self.uvp_node = None
         self._graphs = {}
 
+    def set_batch(self, graphs):
+        """Switch to another batch (dataset training: a new batch every step, pre_train_Adam.py:146-156).  Captured
+        hipGraphs belong to the tensors of one batch and are dropped; with a gfv.pool.DevicePool the switch costs one
+        small launch."""
+        self.graphs = graphs
+        self.plan = get_plan(graphs)
+        self.x = graphs[0].x
+        self.x_backup = self.x.clone()
+        if self.gloss.shape[0] != self.plan.B:
+            self.gloss = torch.zeros((self.plan.B, 4), dtype=torch.float32, device=self.dev)
+        self._graphs = {}
+
     # one un-captured step body ------------------------------------------------------------------------------
     def _body(self, accumulate, with_adam=True):
         lib = L.load()

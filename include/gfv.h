@@ -171,6 +171,19 @@ typedef struct {
 } gfv_transpose_desc_t;
 int gfv_transpose_batch(const gfv_transpose_desc_t* descs, int32_t n, int32_t max_rows, int32_t max_cols, void* stream);
 
+/* Batch assembly of the device-resident state pool (replaces the per-step host batching + H2D copy of
+ * Load_mesh/Graph_loader.py:405-480,830-1006): descriptor i copies n_words 32-bit words src -> dst, kind 0 verbatim
+ * (floats, ids), kind 1 adding `add` to every (int32) word (index offsets of the block-diagonal batch), kind 2 filling
+ * `add` (graph id).  `descs` [n_desc] lives in DEVICE memory; one launch for the whole batch. */
+typedef struct {
+  const void* src;
+  void* dst;
+  int64_t n_words;
+  int32_t kind;
+  int32_t add;
+} gfv_concat_desc_t;
+int gfv_concat_offsets(const gfv_concat_desc_t* descs, int32_t n_desc, int32_t blocks_per_desc, void* stream);
+
 /* out [cols, rows] = in^T for a [rows, cols] fp32 matrix with row stride ld_in (weights for the dX chain). */
 int gfv_transpose(const float* in, int32_t ld_in, float* out, int32_t rows, int32_t cols, void* stream);
 

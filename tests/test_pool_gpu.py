@@ -1,0 +1,95 @@
+"""the device-resident state pool.  A batch assembled on the device by one concat-with-offsets launch
+must be tensor-for-tensor the plan that `build_plan(build_batch(...))` builds from scratch, give the same model outputs
+and gradients, and `payback` must update the pooled fields (Graph_loader.py:370-396,405-480)."""
+import pytest
+import torch
+
+import cases
+from oracle import fvgn_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _meshes():
+    from gfv import meshgen
+    ms, fs = [], []
+    for fac, kw, U, seed in (("raw_tri_channel_cylinder", dict(nx=30, ny=6, quad_fraction=0.0, seed=21), 0.15, 5),
+                             ("raw_quad_cavity", dict(n=7, jitter=0.1, tri_fraction=0.3, seed=13), 1.0, 3),
+                             ("raw_tri_channel_cylinder", dict(nx=36, ny=7, quad_fraction=0.3, seed=22), 0.25, 6),
+                             ("raw_poisson_cavity", dict(n=6, seed=14), None, 4)):
+        m = meshgen.finish_mesh(getattr(meshgen, fac)(**kw), U=U)
+        ms.append(m)
+        fs.append(meshgen.random_fields(m, seed=seed))
+    return ms, fs
+
+
+@pytest.mark.parametrize("indices", [[2, 0], [1], [3, 1, 0, 2], [0, 0]])
+def test_pooled_batch_equals_rebuilt_batch(indices):
+    from gfv.graph import build_batch
+    from gfv.plan import build_plan
+    from gfv.pool import DevicePool
+    ms, fs = _meshes()
+    pool = DevicePool(ms, fs)
+    graphs, plan = pool.batch(indices)
+    ref_graphs = build_batch([ms[i] for i in indices], [fs[i] for i in indices], device="cuda")
+    ref = build_plan(*ref_graphs)
+    torch.cuda.synchronize()
+    assert torch.equal(graphs[0].x, ref_graphs[0].x)
+    checked = 0
+    for k, v in vars(ref).items():
+        if torch.is_tensor(v):
+            mine = getattr(plan, k)
+            assert mine.shape == v.shape and mine.dtype == v.dtype, (k, mine.shape, v.shape)
+            assert torch.equal(mine, v), k
+            checked += 1
+        elif isinstance(v, int):
+            assert getattr(plan, k) == v, k
+    assert checked >= 45
+
+
+def test_pooled_batch_through_the_model_and_payback():
+    from FVMmodel.importer import NNmodel
+    from gfv.graph import build_batch
+    from gfv.params import default_params
+    from gfv.pool import DevicePool
+    ms, fs = _meshes()
+    pool = DevicePool(ms, fs)
+    P = O.init_parameters(cases.WEIGHT_SEED)
+
+    def model():
+        m = NNmodel(default_params(dataset_size=1))
+        sd = m.state_dict()
+        for k, v in P.items():
+            sd[k].copy_(v)
+        m.load_state_dict(sd)
+        return m.cuda()
+
+    idx = [2, 0, 3]
+    hp = O.DEFAULT_HYPER
+    outs = []
+    for pooled in (True, False):
+        if pooled:
+            graphs, _ = pool.batch(idx)
+        else:
+            graphs = build_batch([ms[i] for i in idx], [fs[i] for i in idx], device="cuda")
+            graphs[0].norm_uvp, graphs[0].norm_global = True, True
+        m = model()
+        out = m(*graphs)
+        loss = torch.mean(torch.log(hp["loss_press"] * out[3] + hp["loss_cont"] * out[0] + hp["loss_mom"] * out[1]
+                                    + hp["loss_mom"] * out[2]))
+        loss.backward()
+        outs.append(([o.detach().clone() for o in out], {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}))
+    for a, b in zip(*[o[0] for o in outs]):
+        assert torch.equal(a, b)
+    for k in outs[0][1]:
+        assert torch.equal(outs[0][1][k], outs[1][1][k]), k
+    # payback: the prediction replaces (u, v, p) of every mesh of the batch, theta columns untouched
+    uvp = outs[0][0][4]
+    before = [pool.x[i].clone() for i in range(4)]
+    pool.payback(idx, uvp)
+    o = 0
+    for i in idx:
+        n = pool.x[i].shape[0]
+        assert torch.equal(pool.x[i][:, 0:3], uvp[o:o + n]) and torch.equal(pool.x[i][:, 3:], before[i][:, 3:])
+        o += n
+    assert torch.equal(pool.x[1], before[1])
