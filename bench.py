@@ -81,6 +81,9 @@ def main():
     ap.add_argument("--cells", type=int, default=50000)
     ap.add_argument("--meshes-per-gpu", type=int, default=1)
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
+    ap.add_argument("--graph", choices=("auto", "on", "off"), default="auto",
+                    help="hipGraph replay of the step; auto = time a few warm-up steps both ways and keep the faster "
+                         "(eager launches overlap the side stream better, graph replay needs no host time)")
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU work for the cpu_baseline leg (0 = skip)")
     ap.add_argument("--profile-steps", type=int, default=3)
     args = ap.parse_args()
@@ -117,7 +120,8 @@ def main():
     # dataset_size=1: the solve-script regime (solve_with_grad_GPU.py), where the online Normalizer never accumulates
     # and is the identity (utils/normalization.py:39); a single mesh has constant conditioning columns.
     model = NNmodel(default_params(dataset_size=1)).to(device)
-    ts = TrainStep(model, graphs, world_size=world, use_graph=not args.no_graph)
+    graph_mode = "off" if args.no_graph else args.graph
+    ts = TrainStep(model, graphs, world_size=world, use_graph=(graph_mode != "off"))
 
     def barrier():
         torch.cuda.synchronize()
@@ -127,6 +131,24 @@ def main():
 
     for _ in range(args.warmup):
         ts.step()
+    if graph_mode == "auto":
+        # both ways are the same launches in the same order; which one is faster depends on the host (eager needs ~270
+        # launches per step from Python) - decide on this box, all ranks alike (rank 0's measurement is broadcast)
+        cal = {}
+        for mode in (True, False):
+            ts.use_graph = mode
+            for _ in range(3):
+                ts.step()
+            barrier()
+            tc = time.perf_counter()
+            for _ in range(10):
+                ts.step()
+            barrier()
+            cal[mode] = time.perf_counter() - tc
+        pick = torch.tensor([1 if cal[True] <= cal[False] else 0], device=device)
+        if world > 1:
+            dist.broadcast(pick, src=0)
+        ts.use_graph = bool(pick.item())
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -207,7 +229,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "cylinder_flow tri mesh, TransFVGN_v2 (hidden 128, mp 3), 2nd-order WLSQ, conserved form",
                        "cells": sz["C"], "nodes": sz["N"], "faces": sz["E"], "meshes_per_gpu": args.meshes_per_gpu,
-                       "global_batch": total_meshes, "parallelism": f"dp{world}", "hip_graph": not args.no_graph,
+                       "global_batch": total_meshes, "parallelism": f"dp{world}", "hip_graph": bool(ts.use_graph),
                        "final_loss": round(final_loss, 6)},
             "roofline": ({k: roof[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")} | {"kernel": roof["kernel"]})
             if roof else None,
