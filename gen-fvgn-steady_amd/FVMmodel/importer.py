@@ -24,6 +24,8 @@ class NNmodel(nn.Module):
         self.params = params
         if params.net in ("TransFVGN_v2", "TransFVGN"):
             from FVMmodel.Models.TransFVGN.TransFVGN_v2 import Simulator
+        elif params.net == "TransFVGN_v1":
+            from FVMmodel.Models.TransFVGN.TransFVGN_v1 import Simulator
         elif params.net == "FVGN":
             raise ImportError("net='FVGN' does not import in the reference either (GenFVGN.py:6); SURVEY.md row #6")
         else:
@@ -63,7 +65,8 @@ class NNmodel(nn.Module):
             if getattr(p, "order", "2nd") != "2nd":
                 raise NotImplementedError("WLSQ order != 2nd: SURVEY.md row f4 (next)")
             self._engine = GF.Engine(message_passing_num=p.message_passing_num, integrator=p.integrator,
-                                     ncn_smooth=p.ncn_smooth, net="TransFVGN_v2")
+                                     ncn_smooth=p.ncn_smooth,
+                                     net="TransFVGN_v1" if p.net == "TransFVGN_v1" else "TransFVGN_v2")
         return self._engine
 
     def param_names_tensors(self):

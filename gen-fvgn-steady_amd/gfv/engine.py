@@ -497,10 +497,11 @@ class Engine:
                                             P[f"{a}.to_v.weight"].data_ptr(), sv["token"].data_ptr(), sv["norm"].data_ptr(),
                                             sv["attn"].data_ptr(), g_raw.data_ptr(), g_norm.data_ptr(), dwp.data_ptr(), st),
                 "slice_attention_bwd")
-        dqkv = ops.reduce_partials(dwp, B * 8, 768)
-        self._put(grads, f"{a}.to_q.weight", dqkv[0:256])
-        self._put(grads, f"{a}.to_k.weight", dqkv[256:512])
-        self._put(grads, f"{a}.to_v.weight", dqkv[512:768])
+        with self.fork(dwp):   # parameter gradients only: off the critical path
+            dqkv = ops.reduce_partials(dwp, B * 8, 768)
+            self._put(grads, f"{a}.to_q.weight", dqkv[0:256])
+            self._put(grads, f"{a}.to_k.weight", dqkv[256:512])
+            self._put(grads, f"{a}.to_v.weight", dqkv[512:768])
         g_fx_mid = _empty(dev, N, 128)
         L.check(lib.gfv_deslice(w.data_ptr(), g_raw.data_ptr(), batch.data_ptr(), g_fx_mid.data_ptr(), N, 0, st), "deslice")
         L.check(lib.gfv_slice_gw(sv["fx_mid"].data_ptr(), g_raw.data_ptr(), g_norm.data_ptr(), batch.data_ptr(),
@@ -512,10 +513,11 @@ class Engine:
         L.check(lib.gfv_slice_softmax_bwd(sv["x_mid"].data_ptr(), P[f"{a}.in_project_slice.weight"].data_ptr(),
                                           P[f"{a}.in_project_slice.bias"].data_ptr(), temp.data_ptr(), w.data_ptr(),
                                           gw.data_ptr(), g_x_mid.data_ptr(), sp.data_ptr(), N, st), "slice_softmax_bwd")
-        ds = ops.reduce_partials(sp, nblk, 552)
-        self._put(grads, f"{a}.in_project_slice.weight", ds[0:512])
-        self._put(grads, f"{a}.in_project_slice.bias", ds[512:544])
-        self._put(grads, f"{a}.graph_temperature", ds[544:552])
+        with self.fork(sp):
+            ds = ops.reduce_partials(sp, nblk, 552)
+            self._put(grads, f"{a}.in_project_slice.weight", ds[0:512])
+            self._put(grads, f"{a}.in_project_slice.bias", ds[512:544])
+            self._put(grads, f"{a}.graph_temperature", ds[544:552])
         # projections; fx_in also feeds the to_out residual
         t1, g_fx_in = _empty(dev, N, 128), _empty(dev, N, 128)
         ops.rowtile_chain(N, [Seg(g_fx_mid)], [LayerSpec(self._T(P[f"{a}.in_project_fx.weight"]))], [t1], res=[g_fx1])
@@ -646,13 +648,16 @@ class Engine:
                 blocks.append(sv)
             procs.append(dict(blocks=blocks, trans=None))
         else:
-            for ip in range(self.n_proc):
+            # TransFVGN_v2: two AttnProcessors (TransFVGN_v2.py:69-76); TransFVGN_v1: one processor whose modules hang
+            # directly off the simulator (TransFVGN_v1.py:30-46,53-74)
+            pps = [prefix] if self.net == "TransFVGN_v1" else [f"{prefix}.processpr_list.{ip}" for ip in range(self.n_proc)]
+            for pp in pps:
                 emb = xn
                 blocks = []
                 for ig in range(self.mp):
-                    xn, en, sv = self.gn_fwd(P, f"{prefix}.processpr_list.{ip}.GN_block_list.{ig}", xn, en, pl)
+                    xn, en, sv = self.gn_fwd(P, f"{pp}.GN_block_list.{ig}", xn, en, pl)
                     blocks.append(sv)
-                xn, svt = self.trans_fwd(P, f"{prefix}.processpr_list.{ip}.TransBlock", xn, emb, pl)
+                xn, svt = self.trans_fwd(P, f"{pp}.TransBlock", xn, emb, pl)
                 procs.append(dict(blocks=blocks, trans=svt))
         dec, _, sv_dec = self.mlp3_fwd(P, f"{prefix}.decoder.node_decode_module", N, [Seg(xn)], ln=False)
         return dec, dict(sv_nenc=sv_nenc, sv_eenc=sv_eenc, procs=procs, sv_dec=sv_dec)

@@ -163,19 +163,30 @@ def decoder(P, prefix, x):
     return mlp3(P, prefix + ".node_decode_module", x, layer_norm=False)
 
 
+def processor_prefixes(net, prefix="simulator"):
+    """Parameter prefixes of the (GnBlocks + Transolver block) processors: TransFVGN_v2 has two AttnProcessors
+    (TransFVGN_v2.py:69-76), TransFVGN_v1 one, whose modules hang directly off the simulator (TransFVGN_v1.py:30-46)."""
+    if net in ("TransFVGN_v2", "TransFVGN"):
+        return [f"{prefix}.processpr_list.0", f"{prefix}.processpr_list.1"]
+    if net == "TransFVGN_v1":
+        return [prefix]
+    raise NotImplementedError(net)
+
+
 def simulator_v2(P, x, edge_attr, edge_index, batch, num_graphs, mp=3, heads=8, prefix="simulator",
-                 return_intermediates=False):
-    """TransFVGN_v2.py:54-105 - Encoder, 2 x AttnProcessor(mp GnBlocks + Transolver block), Decoder."""
+                 return_intermediates=False, net="TransFVGN_v2"):
+    """TransFVGN_v2.py:54-105 - Encoder, 2 x AttnProcessor(mp GnBlocks + Transolver block), Decoder;
+    net="TransFVGN_v1" (TransFVGN_v1.py:53-74): the same with ONE processor."""
     inter = {}
     xn = mlp3(P, f"{prefix}.encoder.nb_encoder", x)            # EPD.py:118
     en = mlp3(P, f"{prefix}.encoder.eb_encoder", edge_attr)    # EPD.py:119
     inter["enc_x"], inter["enc_e"] = xn, en
-    for ip in range(2):
+    for ip, pp in enumerate(processor_prefixes(net, prefix)):
         emb = xn
         for ig in range(mp):
-            xn, en = gn_block(P, f"{prefix}.processpr_list.{ip}.GN_block_list.{ig}", xn, en, edge_index)
+            xn, en = gn_block(P, f"{pp}.GN_block_list.{ig}", xn, en, edge_index)
             inter[f"p{ip}.gn{ig}.x"], inter[f"p{ip}.gn{ig}.e"] = xn, en
-        xn = transolver_block(P, f"{prefix}.processpr_list.{ip}.TransBlock", xn + emb, batch, num_graphs, heads)
+        xn = transolver_block(P, f"{pp}.TransBlock", xn + emb, batch, num_graphs, heads)
         inter[f"p{ip}.trans.x"] = xn
     out = decoder(P, f"{prefix}.decoder", xn)
     return (out, inter) if return_intermediates else out
@@ -366,7 +377,7 @@ def model_forward(P, buffers, graphs, hyper=None, norm_uvp=True, norm_global=Tru
     edge_attr = relative_edge_attr(xin, G["pos"], G["edge_index"])                        # :178
     graph_node.edge_attr = edge_attr
     sim = simulator_v2(P, xin, edge_attr, G["edge_index"], nb, B, hyper["message_passing_num"], hyper["heads"],
-                       return_intermediates=return_intermediates)
+                       return_intermediates=return_intermediates, net=hyper["net"])
     dec, inter = sim if return_intermediates else (sim, {})
     uvp_new = torch.tanh(dec / 10) * 10                                                   # :187
     uvp_new = enforce_boundary_condition(uvp_new, G["node_type"], G["y"])                 # :189
@@ -425,12 +436,12 @@ def parameter_shapes(hyper=None):
 
     mlp("simulator.encoder.eb_encoder", nin + 3)
     mlp("simulator.encoder.nb_encoder", nin)
-    for ip in range(2):
+    for pp in processor_prefixes(hyper["net"]):
         for ig in range(mp):
-            g = f"simulator.processpr_list.{ip}.GN_block_list.{ig}"
+            g = f"{pp}.GN_block_list.{ig}"
             mlp(f"{g}.nb_module.net", H + H // 2)
             mlp(f"{g}.eb_module.net", 3 * H)
-        t = f"simulator.processpr_list.{ip}.TransBlock"
+        t = f"{pp}.TransBlock"
         shapes[f"{t}.ln_1.weight"], shapes[f"{t}.ln_1.bias"] = (H,), (H,)
         shapes[f"{t}.Attn.temperature"] = (1, heads, 1, 1)
         shapes[f"{t}.Attn.graph_temperature"] = (1, heads, 1)

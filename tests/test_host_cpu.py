@@ -145,3 +145,14 @@ def test_edge_cases_empty_outflow_and_ragged_cells():
     assert set(counts.tolist()) == {3, 4}
     out = O.model_forward(O.init_parameters(0), O.new_normalizer_buffers(), graphs)
     assert float(out[3][0]) > 0 and float(out[3][1]) == 0.0
+
+
+def test_state_dict_layout_transfvgn_v1():
+    from FVMmodel.importer import NNmodel
+    from gfv.params import default_params
+    m = NNmodel(default_params(net="TransFVGN_v1"))
+    sd = {k: v for k, v in m.state_dict().items() if not k.startswith("node_norm.")}
+    shapes = O.parameter_shapes({"net": "TransFVGN_v1"})   # = the reference's keys / order (tests/golden/make_golden_v1.py)
+    assert list(sd) == list(shapes)
+    for k, v in sd.items():
+        assert tuple(v.shape) == tuple(shapes[k]), k

@@ -178,3 +178,35 @@ def test_factored_edge_block_and_side_stream_match_plain_path():
     for k in g1:
         err = float((g0[k] - g1[k]).abs().max())
         assert err < 1e-4 * float(g1[k].abs().max()) + 1e-6 * gscale, (k, err)
+
+
+def test_transfvgn_v1_matches_oracle_and_reference(golden_dir):
+    """net='TransFVGN_v1' on the HIP path vs the oracle (forward, loss, every gradient) and vs the
+    reference's own outputs (tests/golden/v1_cyl_cavity_b2.npz)."""
+    hyper = {"net": "TransFVGN_v1"}
+    graphs = cases.make_graphs("cyl_cavity_b2")
+    P = O.init_parameters(cases.WEIGHT_SEED, hyper=hyper)
+    Pg = {k: v.detach().requires_grad_(True) for k, v in P.items()}
+    oout = O.model_forward(Pg, O.new_normalizer_buffers(), tuple(g.clone() for g in graphs), hyper=hyper)
+    oloss = O.training_loss(oout)
+    names = list(Pg)
+    ograds = dict(zip(names, torch.autograd.grad(oloss, [Pg[k] for k in names], allow_unused=True)))
+    model = _hip_model(P, net="TransFVGN_v1")
+    hg = tuple(g.clone().to("cuda") for g in graphs)
+    hg[0].norm_uvp, hg[0].norm_global = True, True
+    out = model(*hg)
+    fx = np.load(os.path.join(golden_dir, "v1_cyl_cavity_b2.npz"))
+    for i, key in enumerate(("loss_cont", "loss_mom_x", "loss_mom_y", "loss_press", "uvp_node", "uvp_cell")):
+        assert rel(out[i], oout[i]) < TOL and rel(out[i], torch.from_numpy(fx[key])) < TOL, key
+    hp = O.DEFAULT_HYPER
+    loss = torch.mean(torch.log(hp["loss_press"] * out[3] + hp["loss_cont"] * out[0] + hp["loss_mom"] * out[1]
+                                + hp["loss_mom"] * out[2]))
+    assert abs(float(loss) - float(fx["loss"])) < TOL * abs(float(fx["loss"]))
+    loss.backward()
+    gscale = max(float(g.abs().max()) for g in ograds.values() if g is not None)
+    for k, p in model.named_parameters():
+        if ograds[k] is None:
+            assert p.grad is None, k
+            continue
+        err = float((p.grad.cpu() - ograds[k]).abs().max())
+        assert err < 1e-4 * float(ograds[k].abs().max()) + 1e-6 * gscale, (k, err)

@@ -90,3 +90,18 @@ def test_oracle_on_reference_example_mesh(golden_dir):
     for i, key in enumerate(("loss_cont", "loss_mom_x", "loss_mom_y", "loss_press", "uvp_node", "uvp_cell")):
         assert _rel(out[i].detach().numpy(), fx[key]) < TOL, key
     assert abs(float(O.training_loss(out)) - float(fx["loss"])) < TOL * abs(float(fx["loss"]))
+
+
+def test_oracle_transfvgn_v1_matches_reference(golden_dir):
+    """net='TransFVGN_v1' (one processor).  Fixture = the reference itself run with that net
+    (tests/golden/make_golden_v1.py); the oracle's forward agrees bit for bit there (make_golden_v1.log)."""
+    fx = np.load(os.path.join(golden_dir, "v1_cyl_cavity_b2.npz"))
+    hyper = {"net": "TransFVGN_v1"}
+    shapes = O.parameter_shapes(hyper)
+    assert list(shapes) == [str(k) for k in fx["param_names"]] and len(shapes) == 91
+    assert sum(int(np.prod(v)) for v in shapes.values()) == 642611
+    graphs = cases.make_graphs("cyl_cavity_b2")
+    out = O.model_forward(O.init_parameters(cases.WEIGHT_SEED, hyper=hyper), O.new_normalizer_buffers(), graphs, hyper=hyper)
+    for i, key in enumerate(("loss_cont", "loss_mom_x", "loss_mom_y", "loss_press", "uvp_node", "uvp_cell")):
+        assert _rel(out[i].detach().numpy(), fx[key]) < TOL, key
+    assert abs(float(O.training_loss(out)) - float(fx["loss"])) < TOL * abs(float(fx["loss"]))
