@@ -1,5 +1,6 @@
 """GPU: the stand-alone operator API (same class names / signatures as the reference's FVMmodel sub-modules) and the
 fused TrainStep (flat buffers, fused Adam, hipGraph replay) against the oracle."""
+import numpy as np
 import pytest
 import torch
 
@@ -210,3 +211,36 @@ def test_side_stream_is_bit_identical_and_repeatable():
         assert other[1] == finals[0][1]
         bad = [k for k in finals[0][0] if not torch.equal(other[0][k], finals[0][0][k])]
         assert not bad, bad
+
+
+def test_lbfgs_closure_driver_runs_on_the_drop_in_model():
+    """SURVEY.md row f4 (LBFGS driver): the reference's closure loop (solve_with_grad_GPU_LBFGS.py:67-160: restore x,
+    re-arm the norm flags, forward, clamp + log loss, backward inside torch.optim.LBFGS with strong-Wolfe line search)
+    runs unchanged on the drop-in nn.Module and lowers the PDE loss."""
+    from FVMmodel.importer import NNmodel
+    from gfv.params import default_params
+    graphs = tuple(g.to("cuda") for g in cases.make_graphs("cavity_mixed_b1"))
+    torch.manual_seed(0)
+    params = default_params(dataset_size=1)
+    model = NNmodel(params).cuda()
+    gn = graphs[0]
+    backup_x = gn.x[:, 3:].clone()
+    uvp_node = gn.x[:, 0:3].clone()
+    opt = torch.optim.LBFGS(model.parameters(), max_iter=6, history_size=10, tolerance_grad=1e-6, tolerance_change=1e-8,
+                            line_search_fn="strong_wolfe")
+    history = []
+
+    def closure():
+        opt.zero_grad()
+        gn.x = torch.cat((uvp_node.detach(), backup_x), dim=-1)
+        gn.norm_uvp, gn.norm_global = params.norm_uvp, params.norm_global
+        lc, lmx, lmy, lp, _, _ = model(*graphs)
+        lb = params.loss_press * lp + params.loss_cont * lc + params.loss_mom * lmx + params.loss_mom * lmy
+        loss = torch.mean(torch.log(torch.clamp(lb, min=1e-10, max=1e10)))
+        loss.backward()
+        history.append(float(loss))
+        return loss
+
+    opt.step(closure)
+    assert len(history) >= 3 and all(np.isfinite(history))
+    assert min(history) < history[0] - 1e-3, history
