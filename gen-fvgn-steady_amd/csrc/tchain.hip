@@ -32,9 +32,6 @@
 
 namespace {
 
-#ifndef W_DIST
-#define W_DIST 1  // weight prefetch distance in slices (2 was measured: no gain, +33 VGPRs)
-#endif
 constexpr int WK = 32;
 constexpr int WS_FLOATS = 128 * WK;  // one weight slice
 constexpr int PAR_GAMMA = 640, PAR_BETA = 768, PAR_FLOATS = 896;
@@ -376,17 +373,11 @@ __global__ __launch_bounds__(256, 2) void tchain_kernel(const gfv_rowtile_args_t
   int wbuf = 0;
   TS_DECL
   WBlk cur = w_block(A, 0, 0, 0);
-  // weight pipeline, prefetch distance 2: at the start of slice j (parity p) LDS buffer p holds slice j and register
-  // set 1-p holds slice j+1; slice j issues the loads of slice j+2 into set p, runs its MFMAs, then parks set 1-p in
-  // buffer 1-p.  Every block has an even number of slices, so the parity is the unrolled slice index.
+  // weight pipeline: slice j+1 is loaded to registers while slice j feeds the MFMAs, then parked in the other LDS
+  // buffer (prefetch distance 2 with a second register set was measured: no gain, +33 VGPRs)
   WRegs wr0 = (RAG && cur.rag) ? w_load_ragged(cur.w, cur.ldw, cur.nrows, 0, cur.kvalid, wrow, wc)
                                : w_load(cur.w, cur.ldw, cur.nrows, wrow, wc);
   w_store(lds, tid, wr0);
-#if W_DIST == 2
-  WRegs wr1 = w_load(cur.w + WK, cur.ldw, cur.nrows, wrow, wc);
-#else
-  WRegs wr1 = wr0;  // unused
-#endif
   __syncthreads();
   TS(0);
 
@@ -432,14 +423,9 @@ __global__ __launch_bounds__(256, 2) void tchain_kernel(const gfv_rowtile_args_t
 #pragma unroll
         for (int sl = 0; sl < 4; ++sl) {
           if (sl < cur.nsl) {
-#if W_DIST == 2
-            // prefetch slice j+2 (past the end of the chain: a harmless reload, nxt == cur there)
-            const bool more = (sl + 2 < cur.nsl);
-            const float* wsrc = more ? cur.w + WK * (sl + 2) : nxt.w + WK * (sl + 2 - cur.nsl);
-#else
+            // prefetch the next slice (after the very last one: a harmless reload, nxt == cur there)
             const bool more = (sl + 1 < cur.nsl);
             const float* wsrc = more ? cur.w + WK * (sl + 1) : nxt.w;
-#endif
             const int wld = more ? cur.ldw : nxt.ldw;
             const int wnr = more ? cur.nrows : nxt.nrows;
 #ifndef ABL_NOW
@@ -447,8 +433,7 @@ __global__ __launch_bounds__(256, 2) void tchain_kernel(const gfv_rowtile_args_t
               wr0 = w_load_ragged(more ? cur.w : nxt.w, wld, wnr, more ? WK * (sl + 1) : 0, more ? cur.kvalid : nxt.kvalid,
                                   wrow, wc);
             } else {
-              if (W_DIST == 1 || !(sl & 1)) wr0 = w_load(wsrc, wld, wnr, wrow, wc);
-              else wr1 = w_load(wsrc, wld, wnr, wrow, wc);
+              wr0 = w_load(wsrc, wld, wnr, wrow, wc);
             }
 #endif
 #ifndef NO_SCHEDB
@@ -461,7 +446,7 @@ __global__ __launch_bounds__(256, 2) void tchain_kernel(const gfv_rowtile_args_t
             __builtin_amdgcn_sched_barrier(0);
 #endif
 #ifndef ABL_NOW
-            w_store(lds + (wbuf ^ 1) * WS_FLOATS, tid, (W_DIST == 1 || (sl & 1)) ? wr0 : wr1);
+            w_store(lds + (wbuf ^ 1) * WS_FLOATS, tid, wr0);
             TS(4);
             __syncthreads();
 #endif

@@ -321,3 +321,18 @@ def test_rowtile_transolver_linears(dev):
         ops.linear_dw(gz, 128, [ops.Seg(fxd)], M, a_op=2, a_gamma=gd, a_beta=btd, dW=dWp[128 * h:128 * h + 128],
                       db=dbp[128 * h:128 * h + 128], ldg=256, g_offset=128 * h)
     assert rel(dWp, Wp6.grad) < TOL and rel(dbp, bp6.grad) < TOL
+
+
+def test_lds_rowtile_fallback_kernel_still_passes():
+    """`GFV_TCHAIN=0` routes every fused-MLP launch to the first implementation (rowtile.hip, 64-row tile in LDS), which
+    stays in the library as the fallback.  The switch is read once per process, so the row-tile tests of this file are
+    re-run in a child process with it set (a child, never an exec of this GPU process)."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, GFV_TCHAIN="0")
+    here = os.path.abspath(__file__)
+    r = subprocess.run([sys.executable, "-m", "pytest", here, "-q", "-x", "-m", "gpu", "-k", "rowtile and not fallback"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
