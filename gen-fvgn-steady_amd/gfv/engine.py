@@ -76,6 +76,9 @@ class Engine:
         self._etmp = None
         self._side = None
         self._keep = []
+        # data parallel: (world, process group) set by TrainStep; the Normalizer statistics are exchanged inside the
+        # forward, between accumulation and use
+        self.dist_world, self.dist_group = 1, None
 
     # ------------------------------------------------------------------------------------------------------------
     # side stream for work nothing downstream of the backward chain waits for (dW, LayerNorm dgamma/dbeta)
@@ -620,10 +623,21 @@ class Engine:
         if norm_global:
             nb = lib.gfv_normalizer_blocks(N)
             pws = _empty(dev, nb, 18)
-            L.check(lib.gfv_normalizer_update(x.data_ptr(), 12, N, 1 if accumulate else 0, buffers["acc_count"].data_ptr(),
-                                              buffers["num_accumulations"].data_ptr(), buffers["acc_sum"].data_ptr(),
-                                              buffers["acc_sum_squared"].data_ptr(), pws.data_ptr(), mean_std.data_ptr(),
-                                              st), "normalizer_update")
+            sync = accumulate and self.dist_world > 1
+            if sync:
+                from . import parallel
+                before = parallel.snapshot_normalizer(buffers)
+
+            def update(acc):
+                L.check(lib.gfv_normalizer_update(x.data_ptr(), 12, N, 1 if acc else 0, buffers["acc_count"].data_ptr(),
+                                                  buffers["num_accumulations"].data_ptr(), buffers["acc_sum"].data_ptr(),
+                                                  buffers["acc_sum_squared"].data_ptr(), pws.data_ptr(),
+                                                  mean_std.data_ptr(), L.stream_ptr()), "normalizer_update")
+            update(accumulate)
+            if sync:
+                # statistics of the GLOBAL batch on every rank, then mean / std recomputed from them (finalize only)
+                parallel.allreduce_normalizer(buffers, before, self.dist_world, self.dist_group)
+                update(False)
         uv_old = _empty(dev, N, 2)
         L.check(lib.gfv_node_prep(x.data_ptr(), 12, pl.batch.data_ptr(), stats.data_ptr(), pl.uvp_dim.data_ptr(),
                                   mean_std.data_ptr(), 1 if norm_global else 0, uv_old.data_ptr(), N, st), "node_prep")

@@ -31,3 +31,26 @@ def flat_pack(tensors, pad=4):
         flat[off:off + t.numel()] = t.reshape(-1)
         off += s
     return flat
+
+
+def snapshot_normalizer(buffers):
+    """19 floats: (acc_sum[9], acc_sum_squared[9], acc_count) before this rank's batch is accumulated."""
+    return torch.cat((buffers["acc_sum"].reshape(-1), buffers["acc_sum_squared"].reshape(-1),
+                      buffers["acc_count"].reshape(-1))).clone()
+
+
+def allreduce_normalizer(buffers, before, world, group=None):
+    """the online Normalizer (utils/normalization.py:32-85) accumulates sum x, sum x^2 and the row count of
+    every batch it sees; with the graphs sharded by rank each replica would keep different statistics and the replicas
+    would drift.  `buffers` already hold this rank's batch, `before` is `snapshot_normalizer` taken before it: the
+    buffers become  before + all-reduce(sum)(this rank's delta)  - the statistics of the GLOBAL batch, and identical
+    bit for bit on every rank (the same two operands are added everywhere)."""
+    if world <= 1:
+        return
+    delta = snapshot_normalizer(buffers) - before
+    dist.all_reduce(delta, op=dist.ReduceOp.SUM, group=group)
+    new = before + delta
+    n = buffers["acc_sum"].numel()
+    buffers["acc_sum"].copy_(new[0:n].view_as(buffers["acc_sum"]))
+    buffers["acc_sum_squared"].copy_(new[n:2 * n].view_as(buffers["acc_sum_squared"]))
+    buffers["acc_count"].copy_(new[2 * n:2 * n + 1].view_as(buffers["acc_count"]))

@@ -29,6 +29,7 @@ class TrainStep:
         self.betas, self.eps = betas, eps
         self.w_cont, self.w_mom, self.w_press = loss_weights or (p.loss_cont, p.loss_mom, p.loss_press)
         self.world_size, self.pg = world_size, process_group
+        self.engine.dist_world, self.engine.dist_group = world_size, process_group
         self.use_graph = use_graph
         self.want_outputs = want_outputs
         dev = graphs[0].x.device
@@ -104,7 +105,8 @@ class TrainStep:
         """One training iteration.  Returns the (device) scalar loss tensor of this rank's batch."""
         acc = self.model.node_norm.should_accumulate()
         dist_on = self.world_size > 1
-        if not self.use_graph:
+        if not self.use_graph or (acc and dist_on):
+            # (an accumulating data-parallel step exchanges the Normalizer statistics inside the forward: not captured)
             self._body(acc, with_adam=not dist_on)
             if dist_on:
                 self._allreduce()

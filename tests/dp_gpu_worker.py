@@ -1,0 +1,68 @@
+"""Worker of tests/test_operators_gpu.py::test_data_parallel_trainstep_two_ranks (launched with torch.distributed.run,
+2 ranks sharing GPU 0, gloo): sharded TrainStep with an ACCUMULATING Normalizer (dataset_size 5) for 3 steps; prints
+whether the ranks hold identical parameters / Normalizer buffers and the deviation from a single-process run over the
+global batch."""
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "gen-fvgn-steady_amd"), os.path.join(ROOT, "tests", "golden")):
+    sys.path.insert(0, p)
+
+
+def main():
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    torch.cuda.set_device(0)
+    import cases
+    from oracle import fvgn_oracle as O
+    from FVMmodel.importer import NNmodel
+    from gfv import meshgen
+    from gfv.graph import build_batch
+    from gfv.params import default_params
+    from gfv.trainer import TrainStep
+    specs = cases.CASES["cyl_b3"][:2]
+    meshes = [meshgen.finish_mesh(getattr(meshgen, fac)(**kw), U=U) for fac, kw, U, _ in specs]
+    fields = [meshgen.random_fields(m, seed=s[3]) for m, s in zip(meshes, specs)]
+    P = O.init_parameters(cases.WEIGHT_SEED)
+
+    def make(ids, ws):
+        model = NNmodel(default_params(dataset_size=5))
+        sd = model.state_dict()
+        for k, v in P.items():
+            sd[k].copy_(v)
+        model.load_state_dict(sd)
+        model = model.cuda()
+        g = build_batch([meshes[i] for i in ids], [fields[i] for i in ids], device="cuda")
+        return model, TrainStep(model, g, world_size=ws, use_graph=False)
+
+    model, ts = make([rank], world)
+    for _ in range(3):
+        ts.step()
+    torch.cuda.synchronize()
+    mine = torch.cat([ts.P[k].reshape(-1) for k in ts.P] + [model.node_norm.acc_sum.reshape(-1),
+                                                          model.node_norm.acc_sum_squared.reshape(-1),
+                                                          model.node_norm.acc_count.reshape(-1)]).cpu()
+    gathered = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(gathered, mine)
+    same = all(torch.equal(gathered[0], t) for t in gathered)
+    if rank == 0:
+        ref_model, ref_ts = make([0, 1], 1)
+        for _ in range(3):
+            ref_ts.step()
+        torch.cuda.synchronize()
+        ref = torch.cat([ref_ts.P[k].reshape(-1) for k in ref_ts.P] + [ref_model.node_norm.acc_sum.reshape(-1),
+                                                                     ref_model.node_norm.acc_sum_squared.reshape(-1),
+                                                                     ref_model.node_norm.acc_count.reshape(-1)]).cpu()
+        n = sum(v.numel() for v in ts.P.values())
+        perr = float((mine[:n] - ref[:n]).abs().max() / ref[:n].abs().max())
+        nerr = float((mine[n:] - ref[n:]).abs().max() / ref[n:].abs().max())
+        print(f"DPRESULT same={int(same)} param_err={perr:.3e} norm_err={nerr:.3e}")
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -244,3 +244,22 @@ def test_lbfgs_closure_driver_runs_on_the_drop_in_model():
     opt.step(closure)
     assert len(history) >= 3 and all(np.isfinite(history))
     assert min(history) < history[0] - 1e-3, history
+
+
+def test_data_parallel_trainstep_two_ranks():
+    """SURVEY.md 8e on the device path: two ranks (one mesh each, sharing this GPU, gloo) run the sharded TrainStep with an
+    accumulating Normalizer; both ranks must end bit-identical, and equal (to rounding) to a single process stepping on
+    the two-mesh batch.  Child processes via torch.distributed.run (tests/dp_gpu_worker.py)."""
+    import os
+    import re
+    import subprocess
+    import sys
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "dp_gpu_worker.py")
+    port = 29600 + (os.getpid() % 300)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), worker],
+                       capture_output=True, text=True, timeout=600, env=dict(os.environ, MASTER_ADDR="127.0.0.1"))
+    m = re.search(r"DPRESULT same=(\d) param_err=(\S+) norm_err=(\S+)", r.stdout)
+    assert r.returncode == 0 and m, r.stdout[-1500:] + r.stderr[-1500:]
+    assert m.group(1) == "1", "ranks diverged"
+    assert float(m.group(2)) < 2e-5 and float(m.group(3)) < 1e-6, m.group(0)

@@ -55,8 +55,26 @@ def _worker(rank, world, port, ret):
     gathered = [torch.zeros_like(flat_p) for _ in range(world)]
     dist.all_gather(gathered, flat_p)
     same = all(torch.equal(gathered[0], t) for t in gathered)
+    # Normalizer statistics: each rank accumulates its own shard, the exchange must leave every rank with
+    # the statistics of the global batch, bit-identical across ranks
+    from gfv.parallel import allreduce_normalizer, snapshot_normalizer
+    feats = lambda ids: build_batch([meshes[i] for i in ids], [fields[i] for i in ids])[0].x[:, 3:]
+    nbuf = O.new_normalizer_buffers()
+    nbuf["acc_sum"] += 0.5                      # pretend earlier steps have been accumulated already
+    nbuf["acc_count"] += 100.0
+    full_buf = {k: v.clone() for k, v in nbuf.items()}
+    before = snapshot_normalizer(nbuf)
+    O.normalizer_forward(nbuf, feats(mine), max_accumulations=10)
+    allreduce_normalizer(nbuf, before, world)
+    O.normalizer_forward(full_buf, feats(list(range(len(meshes)))), max_accumulations=10)
+    nerr = max(float((nbuf[k] - full_buf[k]).abs().max() / (full_buf[k].abs().max() + 1e-30))
+               for k in ("acc_sum", "acc_sum_squared", "acc_count", "num_accumulations"))
+    packed = snapshot_normalizer(nbuf)
+    gathered_n = [torch.zeros_like(packed) for _ in range(world)]
+    dist.all_gather(gathered_n, packed)
+    nsame = all(torch.equal(gathered_n[0], t) for t in gathered_n)
     if rank == 0:
-        ret["err"], ret["same"] = err, same
+        ret["err"], ret["same"], ret["nerr"], ret["nsame"] = err, same, nerr, nsame
     dist.destroy_process_group()
 
 
@@ -68,3 +86,5 @@ def test_sharded_gradient_allreduce_equals_global_batch_gradient():
     mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
     assert ret["same"], "ranks diverged after the optimiser step"
     assert ret["err"] < 1e-5, ret["err"]
+    assert ret["nsame"], "Normalizer buffers differ across ranks after the exchange"
+    assert ret["nerr"] < 1e-6, ret["nerr"]
