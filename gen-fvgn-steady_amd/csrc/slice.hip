@@ -133,15 +133,24 @@ __global__ __launch_bounds__(256) void slice_softmax_bwd_kernel(const float* __r
   }
   sT[tid] = dT;
   __syncthreads();
-  // dWs[g][c] = sum_rows GL[row][g] * X[row][c]: 512 outputs, 2 per thread
+  // dWs[g][c] = sum_rows GL[row][g] * X[row][c]: a [32 x 256] x [256 x 16] product per block -> two 16x16 MFMA tiles
+  // (v_mfma_f32_16x16x4_f32, exact fp32), one per wave 0 / 1, 64 k-steps each (was: 512 scalar LDS iterations / thread)
   float* out = partial + (size_t)blockIdx.x * 552;
+  {
+    const int wave = tid >> 6, lane = tid & 63, li = lane & 15, kq = lane >> 4;
+    if (wave < 2) {
+      floatx4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+      for (int ks = 0; ks < 64; ++ks) {
+        const int r = 4 * ks + kq;
+        const float a = sGL[r * (G + 1) + 16 * wave + li];   // A[i = g][k = row]
+        const float b = sX[r * (D + 1) + li];                // B[k = row][j = c]
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+      }
+      // D[i][j]: lane (j = li, group kq) holds rows i = 4 kq + reg
 #pragma unroll
-  for (int o = 0; o < 2; ++o) {
-    const int idx = tid + 256 * o;
-    const int g = idx / D, c = idx % D;
-    float s = 0.f;
-    for (int r = 0; r < 256; ++r) s += sGL[r * (G + 1) + g] * sX[r * (D + 1) + c];
-    out[idx] = s;
+      for (int reg = 0; reg < 4; ++reg) out[(16 * wave + 4 * kq + reg) * D + li] = acc[reg];
+    }
   }
   if (tid < G) {
     float s = 0.f;
