@@ -250,6 +250,7 @@ extern "C" int gfv_dw_multi(const gfv_dw_tile_t* tiles, int32_t ntiles, int32_t 
   hipLaunchKernelGGL(dw_multi_kernel, dim3(slabs, ntiles), dim3(256), 0, (hipStream_t)stream, a);
   gfv_prof_end(tok, (hipStream_t)stream);
   GFV_CHECK_LAUNCH();
+  if (!grad_block) return GFV_OK;  // the caller reduces the slab workspace itself (gfv_reduce_partials_2d)
   return gfv_reduce_partials(workspace, slabs, (int32_t)block_floats, grad_block, accumulate, stream);
 }
 

@@ -163,6 +163,44 @@ __global__ __launch_bounds__(256) void reduce_partials_vec_kernel(const float* _
   }
 }
 
+// 2-D form: out[r * ld_out + c] = sum_chunks partial[chunk * chunk_stride + r * cols + c]  (r < rows, c < cols): reduces a
+// [rows, cols] sub-block of the slab workspace straight into a column block of a wider gradient matrix (W1[:, 256:384]
+// of the factored EdgeBlock) - same thread layout and summation order as reduce_partials_vec_kernel.
+__global__ __launch_bounds__(256) void reduce_partials_2d_kernel(const float* __restrict__ partial, int n_chunks,
+                                                                 long chunk_stride4, int n4, int cols4, int ld_out4,
+                                                                 float* __restrict__ out) {
+  __shared__ float4 red[4][64];
+  const int q = threadIdx.x & 63, cg = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + q;
+  float4 s[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) s[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (j < n4) {
+    const float4* p = reinterpret_cast<const float4*>(partial) + j;
+    int c = cg;
+    for (; c + 12 < n_chunks; c += 16) {
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = p[(size_t)(c + 4 * u) * chunk_stride4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { s[u].x += v[u].x; s[u].y += v[u].y; s[u].z += v[u].z; s[u].w += v[u].w; }
+    }
+    for (; c < n_chunks; c += 4) {
+      const float4 v = p[(size_t)c * chunk_stride4];
+      s[0].x += v.x; s[0].y += v.y; s[0].z += v.z; s[0].w += v.w;
+    }
+  }
+  red[cg][q] = make_float4((s[0].x + s[1].x) + (s[2].x + s[3].x), (s[0].y + s[1].y) + (s[2].y + s[3].y),
+                           (s[0].z + s[1].z) + (s[2].z + s[3].z), (s[0].w + s[1].w) + (s[2].w + s[3].w));
+  __syncthreads();
+  if (cg == 0 && j < n4) {
+    const float4 a = red[0][q], b = red[1][q], c = red[2][q], d = red[3][q];
+    const int r = j / cols4, cc = j - r * cols4;
+    reinterpret_cast<float4*>(out)[(size_t)r * ld_out4 + cc] =
+        make_float4((a.x + b.x) + (c.x + d.x), (a.y + b.y) + (c.y + d.y), (a.z + b.z) + (c.z + d.z), (a.w + b.w) + (c.w + d.w));
+  }
+}
+
 // segmented form: out[b, :] = sum of the chunk rows seg_ptr[b] .. seg_ptr[b+1]-1 (blockIdx.y = b); same thread layout
 // and summation order as reduce_partials_vec_kernel.  Used to pre-reduce the per-chunk slice tokens of every graph, so
 // that the (graph, head) attention blocks - only 8 per graph - do not walk hundreds of chunk partials serially.
@@ -329,6 +367,19 @@ extern "C" int gfv_reduce_partials(const float* partial, int32_t n_chunks, int32
   }
   hipLaunchKernelGGL(reduce_partials_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, partial,
                      n_chunks, n, out, accumulate);
+  GFV_CHECK_LAUNCH();
+  return GFV_OK;
+}
+
+extern "C" int gfv_reduce_partials_2d(const float* partial, int32_t n_chunks, int64_t chunk_stride, int32_t rows,
+                                      int32_t cols, int32_t ld_out, float* out, void* stream) {
+  if (n_chunks <= 0 || rows <= 0 || cols <= 0) return GFV_OK;
+  if ((cols & 3) || (ld_out & 3) || (chunk_stride & 3) || ld_out < cols ||
+      ((reinterpret_cast<size_t>(partial) | reinterpret_cast<size_t>(out)) & 15))
+    return GFV_ERR_ARG;
+  const int n4 = rows * (cols / 4);
+  hipLaunchKernelGGL(reduce_partials_2d_kernel, dim3((n4 + 63) / 64), dim3(256), 0, (hipStream_t)stream, partial, n_chunks,
+                     (long)(chunk_stride / 4), n4, cols / 4, ld_out / 4, out);
   GFV_CHECK_LAUNCH();
   return GFV_OK;
 }

@@ -264,7 +264,7 @@ class Engine:
             self._dw_ws = torch.zeros(int(n_floats * 1.25) + 1024, dtype=torch.float32, device=dev)
         return self._dw_ws
 
-    def _dw_block(self, grads, layers, tiles, M, row0s=None):
+    def _dw_block(self, grads, layers, tiles, M, row0s=None, reduce=True):
         """layers: [(weight name, bias name or None, n tiles of that weight)], in parameter order; tiles in the same
         order.  One launch + one reduction into the contiguous gradient block of those parameters."""
         lib = L.load()
@@ -299,8 +299,10 @@ class Engine:
         need = lib.gfv_dw_multi_workspace_floats(M, ti, blen)
         dev = grads.flat.device
         ws = self._workspace(need, dev)
-        L.check(lib.gfv_dw_multi(ct, ti, M, blen, ws.data_ptr(), grads.flat.data_ptr() + 4 * off0, 0, L.stream_ptr()),
-                "gfv_dw_multi")
+        L.check(lib.gfv_dw_multi(ct, ti, M, blen, ws.data_ptr(), (grads.flat.data_ptr() + 4 * off0) if reduce else None, 0,
+                                 L.stream_ptr()), "gfv_dw_multi")
+        if not reduce:   # (workspace, slabs, floats per slab): the caller reduces pieces of it itself
+            return ws, lib.gfv_dw_slabs(M, ti, None), blen
 
     @staticmethod
     def _put(grads, name, value):
@@ -358,18 +360,23 @@ class Engine:
         ops.rowtile_chain(N, [Seg(G_s), Seg(G_r)], [LayerSpec(Wabt)], [g_nb])
         nb = sv["nb"]
         with self.fork(gz1, gz2, g3, G_s, G_r, nb, e, part, sv["z1"], sv["z2"]):
+            # slab partials are laid out like small stand-in blocks ([W1c | b1 | W2 | b2 | W3 | b3] and [W1a | W1b]) and
+            # reduced straight into their places of the real gradient block: W1c / W1ab are column blocks of W1 [128, 384]
             tmpE, tmpN = self._edge_tmp(dev)
-            self._dw_block(tmpE, [("W1c", "b1", 1), ("W2", "b2", 1), ("W3", "b3", 1)],
-                           [self._tile(gz1, 128, Seg(e)), self._tile(gz2, 128, Seg(sv["z1"]), a_op=1),
-                            self._tile(g3, 128, Seg(sv["z2"]), a_op=1)], M)
-            self._dw_block(tmpN, [("W1ab", None, 2)], [self._tile(G_s, 128, Seg(nb)), self._tile(G_r, 128, Seg(nb))], N)
             gW1 = grads.view(names[0])
-            gW1[:, 0:256].copy_(tmpN.view("W1ab"))
-            gW1[:, 256:384].copy_(tmpE.view("W1c"))
+            ws, slabs, blen = self._dw_block(tmpE, [("W1c", "b1", 1), ("W2", "b2", 1), ("W3", "b3", 1)],
+                                             [self._tile(gz1, 128, Seg(e)), self._tile(gz2, 128, Seg(sv["z1"]), a_op=1),
+                                              self._tile(g3, 128, Seg(sv["z2"]), a_op=1)], M, reduce=False)
+            red2d = L.load().gfv_reduce_partials_2d
+            L.check(red2d(ws.data_ptr(), slabs, blen, 128, 128, 384, gW1.data_ptr() + 4 * 256, L.stream_ptr()), "reduce_2d")
             off, length = grads.block(names[1], names[5])
             o2, l2 = tmpE.block("b1", "b3")
             assert l2 == length
-            grads.flat[off:off + length].copy_(tmpE.flat[o2:o2 + l2])
+            L.check(red2d(ws.data_ptr() + 4 * o2, slabs, blen, 1, l2, l2, grads.flat.data_ptr() + 4 * off, L.stream_ptr()),
+                    "reduce_2d")
+            ws, slabs, blen = self._dw_block(tmpN, [("W1ab", None, 2)],
+                                             [self._tile(G_s, 128, Seg(nb)), self._tile(G_r, 128, Seg(nb))], N, reduce=False)
+            L.check(red2d(ws.data_ptr(), slabs, blen, 128, 256, 384, gW1.data_ptr(), L.stream_ptr()), "reduce_2d")
             ops.reduce_partials(part, tiles_n, 256, out=self._gview2(grads, names[6], names[7]))
         return g_nb, g_e_in
 

@@ -79,6 +79,7 @@ _SIGNATURES = {
                                C.c_void_p]),
     "gfv_reduce_partials": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
     "gfv_concat_offsets": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    "gfv_reduce_partials_2d": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "gfv_reduce_partials_seg": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "gfv_transpose": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "gfv_slice_softmax_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),

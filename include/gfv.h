@@ -158,6 +158,12 @@ int gfv_dw_multi(const gfv_dw_tile_t* tiles, int32_t ntiles, int32_t M, int64_t 
 int gfv_reduce_partials(const float* partial, int32_t n_chunks, int32_t n, float* out, int32_t accumulate,
                         void* stream);
 
+/* 2-D form: out[r * ld_out + c] = sum_chunk partial[chunk * chunk_stride + r * cols + c] (r < rows, c < cols; cols, ld_out,
+ * chunk_stride multiples of 4, 16-byte aligned): a [rows, cols] piece of the slab workspace of gfv_dw_multi reduced straight
+ * into a column block of a wider gradient matrix.  gfv_dw_multi with grad_block == NULL leaves the reduction to the caller. */
+int gfv_reduce_partials_2d(const float* partial, int32_t n_chunks, int64_t chunk_stride, int32_t rows, int32_t cols,
+                           int32_t ld_out, float* out, void* stream);
+
 /* Segmented form: out[b, 0:n] = sum of the chunk rows seg_ptr[b] .. seg_ptr[b+1]-1 of partial [n_chunks, n] (n % 4 == 0,
  * 16-byte aligned).  Pre-reduces the per-chunk slice tokens of each graph (GraphTransolver.py:64-73 global_add_pool). */
 int gfv_reduce_partials_seg(const float* partial, const int32_t* seg_ptr, int32_t n_seg, int32_t n, float* out,
