@@ -290,6 +290,8 @@ struct CellArgs {
   float* cres;           // [C,4] = (div, Rx, Ry, lp2)
   float* uvp_cell;       // [C,3] dimensional cell output
   int C;
+  int mode;              // 0 conserved form (FVscheme.py:50-274), 1 non-conserved form (:276-511, hessian None)
+  float* gradc;          // mode 1: [C,16] cell means of the node gradients of channels 0..4 (saved for the adjoint)
 };
 
 __global__ __launch_bounds__(256) void cell_fwd_kernel(const CellArgs A) {
@@ -302,6 +304,8 @@ __global__ __launch_bounds__(256) void cell_fwd_kernel(const CellArgs A) {
   const float area = A.area[c];
   float pc[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   float div = 0.f, Jx = 0.f, Jy = 0.f, lp2 = 0.f;
+  float gcs[10] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // mode 1: sum of node gradients, channels 0..4
+  float vx = 0.f, vy = 0.f;                                            // mode 1: sum_faces grad(uv_hat)_f . S
   const int beg = A.crow[c], end = A.crow[c + 1];
   for (int k = beg; k < end; ++k) {
     const int n = A.knode[k], f = A.kface[k];
@@ -314,13 +318,20 @@ __global__ __launch_bounds__(256) void cell_fwd_kernel(const CellArgs A) {
     const float4 f0 = fp[0], f1 = fp[1], f2 = fp[2], f3 = fp[3];
     // f0 = (u, v, p, uh)  f1 = (vh, gu_x, gu_y, gv_x)  f2 = (gv_y, gp_x, gp_y, guh_x)  f3 = (guh_y, gvh_x, gvh_y, pad)
     const float u = f0.x, v = f0.y, p = f0.z, uh = f0.w, vh = f1.x;
-    div += u * Sx + v * Sy;
-    const float m00 = (uh * uh) * th2 + p * th3 - f2.w * th4;
-    const float m01 = (uh * vh) * th2 + 0.f * th3 - f3.x * th4;
-    const float m10 = (vh * uh) * th2 + 0.f * th3 - f3.y * th4;
-    const float m11 = (vh * vh) * th2 + p * th3 - f3.z * th4;
-    Jx += m00 * Sx + m01 * Sy;
-    Jy += m10 * Sx + m11 * Sy;
+    if (A.mode == 0) {
+      div += u * Sx + v * Sy;
+      const float m00 = (uh * uh) * th2 + p * th3 - f2.w * th4;
+      const float m01 = (uh * vh) * th2 + 0.f * th3 - f3.x * th4;
+      const float m10 = (vh * uh) * th2 + 0.f * th3 - f3.y * th4;
+      const float m11 = (vh * vh) * th2 + p * th3 - f3.z * th4;
+      Jx += m00 * Sx + m01 * Sy;
+      Jy += m10 * Sx + m11 * Sy;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 10; ++j) gcs[j] += A.grad[(size_t)n * 16 + j];
+      vx += f2.w * Sx + f3.x * Sy;   // divergence-form diffusion (FVscheme.py:458-469)
+      vy += f3.y * Sx + f3.z * Sy;
+    }
     if (A.ftype[f] == NT_OUTFLOW) {
       const float l0 = th4 * (f1.y * Sx + f1.z * Sy) - p * Sx;
       const float l1 = th4 * (f1.w * Sx + f2.x * Sy) - p * Sy;
@@ -333,7 +344,25 @@ __global__ __launch_bounds__(256) void cell_fwd_kernel(const CellArgs A) {
   const float dtb = A.dt[b];
   const float ux = ((pc[0] - pc[5]) / dtb) * area, uy = ((pc[1] - pc[6]) / dtb) * area;
   const float src = th5 * area;
-  const float Rx = th0 * ux + (Jx - src), Ry = th0 * uy + (Jy - src);
+  float Rx, Ry;
+  if (A.mode == 0) {
+    Rx = th0 * ux + (Jx - src);
+    Ry = th0 * uy + (Jy - src);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 10; ++j) gcs[j] = gcs[j] / cnt;
+    div = (gcs[0] + gcs[3]) * area;                                      // (du/dx + dv/dy) area, FVscheme.py:405-408
+    const float cvx = (gcs[6] * pc[3] + gcs[7] * pc[4]) * area;          // (u_hat . grad) u_hat, :447-450
+    const float cvy = (gcs[8] * pc[3] + gcs[9] * pc[4]) * area;
+    const float gpx = gcs[4] * area, gpy = gcs[5] * area;                // grad p, :454
+    Rx = th0 * ux + th2 * cvx + th3 * gpx - th4 * vx - src;              // :472-478
+    Ry = th0 * uy + th2 * cvy + th3 * gpy - th4 * vy - src;
+    float4* og = reinterpret_cast<float4*>(A.gradc + (size_t)c * 16);
+    og[0] = make_float4(gcs[0], gcs[1], gcs[2], gcs[3]);
+    og[1] = make_float4(gcs[4], gcs[5], gcs[6], gcs[7]);
+    og[2] = make_float4(gcs[8], gcs[9], 0.f, 0.f);
+    og[3] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
   float4* o = reinterpret_cast<float4*>(A.phic + (size_t)c * 8);
   o[0] = make_float4(pc[0], pc[1], pc[2], pc[3]);
   o[1] = make_float4(pc[4], pc[5], pc[6], 0.f);
@@ -434,7 +463,8 @@ __global__ __launch_bounds__(256) void face_bwd_kernel(const float* __restrict__
                                                        const int* __restrict__ frow, const int* __restrict__ fk,
                                                        const int* __restrict__ kcell, const float* __restrict__ kS,
                                                        const int* __restrict__ ftype, const int* __restrict__ cbatch,
-                                                       const float* __restrict__ theta, float* __restrict__ gFf, int E) {
+                                                       const float* __restrict__ theta, float* __restrict__ gFf, int E,
+                                                       int mode) {
   const int f = blockIdx.x * 256 + threadIdx.x;
   if (f >= E) return;
   const float4* fp = reinterpret_cast<const float4*>(Ff + (size_t)f * 16);
@@ -452,12 +482,14 @@ __global__ __launch_bounds__(256) void face_bwd_kernel(const float* __restrict__
     const float Sx = kS[2 * k], Sy = kS[2 * k + 1];
     const float4 gcv = *reinterpret_cast<const float4*>(gc + (size_t)c * 4);
     const float gd = gcv.x, gx = gcv.y, gy = gcv.z;
-    g[0] += gd * Sx;
-    g[1] += gd * Sy;
-    const float uS = uh * Sx + vh * Sy, gU = gx * uh + gy * vh, gS = gx * Sx + gy * Sy;
-    g[3] += th2 * (gx * uS + gU * Sx);
-    g[4] += th2 * (gy * uS + gU * Sy);
-    g[2] += th3 * gS;
+    if (mode == 0) {  // face fluxes of the conserved form; the non-conserved form takes these terms from cell gradients
+      g[0] += gd * Sx;
+      g[1] += gd * Sy;
+      const float uS = uh * Sx + vh * Sy, gU = gx * uh + gy * vh, gS = gx * Sx + gy * Sy;
+      g[3] += th2 * (gx * uS + gU * Sx);
+      g[4] += th2 * (gy * uS + gU * Sy);
+      g[2] += th3 * gS;
+    }
     g[5 + 6] -= th4 * gx * Sx;  // d/d grad(u_hat)_x
     g[5 + 7] -= th4 * gx * Sy;
     g[5 + 8] -= th4 * gy * Sx;
@@ -498,6 +530,9 @@ struct NodeBwdArgs {
   float* gphi;           // [N,8]
   float* ggrad;          // [N,16]
   int N;
+  int mode;              // 1: non-conserved form
+  const float* gradc;    // mode 1: [C,16] saved cell gradients
+  const float* phic;     // mode 1: [C,8] saved cell values
 };
 
 __global__ __launch_bounds__(256) void node_bwd_kernel(const NodeBwdArgs A) {
@@ -532,6 +567,26 @@ __global__ __launch_bounds__(256) void node_bwd_kernel(const NodeBwdArgs A) {
     gp[0] += gx; gp[1] += gy;
     gg[0] += gx * rx; gg[1] += gx * ry;
     gg[2] += gy * rx; gg[3] += gy * ry;
+    if (A.mode == 1) {
+      // adjoint of the gradient-based terms of the non-conserved form: every node of the cell carries 1/cnt of the cell
+      // mean of the node gradients, and of the cell value uv_hat that multiplies them in the convection term
+      const float* th = A.theta + (size_t)b * 9;
+      const float w = A.area[c] / cnt;
+      const float gd = A.gc[(size_t)c * 4] * w, gRx = A.gc[(size_t)c * 4 + 1] * w, gRy = A.gc[(size_t)c * 4 + 2] * w;
+      const float* gcv = A.gradc + (size_t)c * 16;
+      const float uhc = A.phic[(size_t)c * 8 + 3], vhc = A.phic[(size_t)c * 8 + 4];
+      const float th2 = th[2], th3 = th[3];
+      gg[0] += gd;                          // d div / d (du/dx)
+      gg[3] += gd;                          // d div / d (dv/dy)
+      gg[4] += th3 * gRx; gg[5] += th3 * gRy;
+      gg[6] += th2 * gRx * uhc; gg[7] += th2 * gRx * vhc;
+      gg[8] += th2 * gRy * uhc; gg[9] += th2 * gRy * vhc;
+      const float a3 = th2 * (gRx * gcv[6] + gRy * gcv[8]);   // d / d u_hat(cell), per node share
+      const float a4 = th2 * (gRx * gcv[7] + gRy * gcv[9]);   // d / d v_hat(cell)
+      gp[3] += a3; gp[4] += a4;
+      gg[6] += a3 * rx; gg[7] += a3 * ry;
+      gg[8] += a4 * rx; gg[9] += a4 * ry;
+    }
   }
   float4* o = reinterpret_cast<float4*>(A.gphi + (size_t)i * 8);
   o[0] = make_float4(gp[0], gp[1], gp[2], gp[3]);
@@ -599,15 +654,25 @@ extern "C" int gfv_face_fwd(const float* phi, const float* grad, const int32_t* 
   return GFV_OK;
 }
 
+extern "C" int gfv_cell_fwd_ex(const float* phi, const float* grad, const float* Ff, const float* pos, const int32_t* crow,
+                               const int32_t* kface, const int32_t* knode, const float* kS, const int32_t* ftype,
+                               const float* centroid, const float* area, const int32_t* cbatch, const float* theta,
+                               const float* dt, const float* uvp_dim, const float* sigma, float* phic, float* cres,
+                               float* uvp_cell, int32_t C, int32_t non_conserved, float* gradc, void* stream) {
+  if (non_conserved && !gradc) return GFV_ERR_ARG;
+  CellArgs a{phi, grad, Ff, pos, crow, kface, knode, kS, ftype, centroid, area, cbatch, theta, dt, uvp_dim, sigma,
+             phic, cres, uvp_cell, C, non_conserved ? 1 : 0, gradc};
+  LAUNCH1D(cell_fwd_kernel, C, stream, a);
+  return GFV_OK;
+}
+
 extern "C" int gfv_cell_fwd(const float* phi, const float* grad, const float* Ff, const float* pos, const int32_t* crow,
                             const int32_t* kface, const int32_t* knode, const float* kS, const int32_t* ftype,
                             const float* centroid, const float* area, const int32_t* cbatch, const float* theta,
                             const float* dt, const float* uvp_dim, const float* sigma, float* phic, float* cres,
                             float* uvp_cell, int32_t C, void* stream) {
-  CellArgs a{phi, grad, Ff, pos, crow, kface, knode, kS, ftype, centroid, area, cbatch, theta, dt, uvp_dim, sigma,
-             phic, cres, uvp_cell, C};
-  LAUNCH1D(cell_fwd_kernel, C, stream, a);
-  return GFV_OK;
+  return gfv_cell_fwd_ex(phi, grad, Ff, pos, crow, kface, knode, kS, ftype, centroid, area, cbatch, theta, dt, uvp_dim, sigma,
+                         phic, cres, uvp_cell, C, 0, nullptr, stream);
 }
 
 extern "C" int gfv_graph_loss(const float* cres, const int32_t* gcell_ptr, const float* theta, const float* sigma,
@@ -628,15 +693,30 @@ extern "C" int gfv_cell_to_node(const float* phic, const int32_t* nrow, const in
   return GFV_OK;
 }
 
+extern "C" int gfv_fvm_bwd_ex(const float* cres, const float* sums, const float* gloss, const float* Ff,
+                              const int32_t* cbatch, const float* theta, const float* sigma, const float* dt,
+                              const int32_t* frow, const int32_t* fk, const int32_t* kcell, const float* kS,
+                              const int32_t* ftype, const int32_t* nfrow, const int32_t* nfcol2, const int32_t* nrow,
+                              const int32_t* ncell, const int32_t* crow, const float* pos, const float* fpos,
+                              const float* centroid, const float* area, float* gc_ws, float* gFf_ws, float* gphi,
+                              float* ggrad, int32_t N, int32_t E, int32_t C, int32_t non_conserved, const float* gradc,
+                              const float* phic, void* stream) {
+  if (non_conserved && (!gradc || !phic)) return GFV_ERR_ARG;
+  const int mode = non_conserved ? 1 : 0;
+  LAUNCH1D(cell_bwd_kernel, C, stream, cres, sums, gloss, cbatch, theta, sigma, gc_ws, C);
+  LAUNCH1D(face_bwd_kernel, E, stream, Ff, gc_ws, frow, fk, kcell, kS, ftype, cbatch, theta, gFf_ws, E, mode);
+  NodeBwdArgs a{gFf_ws, gc_ws, nfrow, nfcol2, nrow, ncell, pos, fpos, centroid, crow, area, cbatch, theta, dt, gphi, ggrad, N,
+                mode, gradc, phic};
+  LAUNCH1D(node_bwd_kernel, N, stream, a);
+  return GFV_OK;
+}
+
 extern "C" int gfv_fvm_bwd(const float* cres, const float* sums, const float* gloss, const float* Ff, const int32_t* cbatch,
                            const float* theta, const float* sigma, const float* dt, const int32_t* frow, const int32_t* fk,
                            const int32_t* kcell, const float* kS, const int32_t* ftype, const int32_t* nfrow,
                            const int32_t* nfcol2, const int32_t* nrow, const int32_t* ncell, const int32_t* crow,
                            const float* pos, const float* fpos, const float* centroid, const float* area, float* gc_ws,
                            float* gFf_ws, float* gphi, float* ggrad, int32_t N, int32_t E, int32_t C, void* stream) {
-  LAUNCH1D(cell_bwd_kernel, C, stream, cres, sums, gloss, cbatch, theta, sigma, gc_ws, C);
-  LAUNCH1D(face_bwd_kernel, E, stream, Ff, gc_ws, frow, fk, kcell, kS, ftype, cbatch, theta, gFf_ws, E);
-  NodeBwdArgs a{gFf_ws, gc_ws, nfrow, nfcol2, nrow, ncell, pos, fpos, centroid, crow, area, cbatch, theta, dt, gphi, ggrad, N};
-  LAUNCH1D(node_bwd_kernel, N, stream, a);
-  return GFV_OK;
+  return gfv_fvm_bwd_ex(cres, sums, gloss, Ff, cbatch, theta, sigma, dt, frow, fk, kcell, kS, ftype, nfrow, nfcol2, nrow, ncell,
+                        crow, pos, fpos, centroid, area, gc_ws, gFf_ws, gphi, ggrad, N, E, C, 0, nullptr, nullptr, stream);
 }

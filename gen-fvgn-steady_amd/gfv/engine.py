@@ -59,12 +59,13 @@ class GradStore:
 
 
 class Engine:
-    def __init__(self, message_passing_num=3, integrator="imex", ncn_smooth=True, net="TransFVGN_v2"):
+    def __init__(self, message_passing_num=3, integrator="imex", ncn_smooth=True, net="TransFVGN_v2", conserved_form=True):
         self._dw_ws = None
         self._wt, self._wt_key, self._wt_live = {}, None, False
         self.mp = message_passing_num
         self.mode = _MODE[integrator]
         self.smooth = 1 if ncn_smooth else 0
+        self.nc = 0 if conserved_form else 1   # residuals of the non-conserved form (FVscheme.py:276-511), row f4
         self.n_proc = 2 if net in ("TransFVGN_v2", "TransFVGN") else 1
         self.net = net
         # weight-gradient kernels run on a side stream, concurrently with the dX chain of the next layer block: both
@@ -567,11 +568,13 @@ class Engine:
                                  pl.fpos.data_ptr(), pl.ftype.data_ptr(), pl.y.data_ptr(), Ff.data_ptr(), E, st), "face_fwd")
         phic, cres = _empty(dev, C, 8), _empty(dev, C, 4)
         uvp_cell = _empty(dev, C, 3) if want_outputs else None
-        L.check(lib.gfv_cell_fwd(phi.data_ptr(), grad.data_ptr(), Ff.data_ptr(), pl.pos.data_ptr(), pl.crow.data_ptr(),
-                                 pl.kface.data_ptr(), pl.knode.data_ptr(), pl.kS.data_ptr(), pl.ftype.data_ptr(),
-                                 pl.centroid.data_ptr(), pl.area.data_ptr(), pl.cbatch.data_ptr(), pl.theta.data_ptr(),
-                                 pl.dt.data_ptr(), pl.uvp_dim.data_ptr(), pl.sigma.data_ptr(), phic.data_ptr(),
-                                 cres.data_ptr(), None if uvp_cell is None else uvp_cell.data_ptr(), C, st), "cell_fwd")
+        gradc = _empty(dev, C, 16) if self.nc else None
+        L.check(lib.gfv_cell_fwd_ex(phi.data_ptr(), grad.data_ptr(), Ff.data_ptr(), pl.pos.data_ptr(), pl.crow.data_ptr(),
+                                    pl.kface.data_ptr(), pl.knode.data_ptr(), pl.kS.data_ptr(), pl.ftype.data_ptr(),
+                                    pl.centroid.data_ptr(), pl.area.data_ptr(), pl.cbatch.data_ptr(), pl.theta.data_ptr(),
+                                    pl.dt.data_ptr(), pl.uvp_dim.data_ptr(), pl.sigma.data_ptr(), phic.data_ptr(),
+                                    cres.data_ptr(), None if uvp_cell is None else uvp_cell.data_ptr(), C, self.nc,
+                                    None if gradc is None else gradc.data_ptr(), st), "cell_fwd")
         sums, losses = _empty(dev, B, 4), _empty(dev, B, 4)
         L.check(lib.gfv_graph_loss(cres.data_ptr(), pl.gcell_ptr.data_ptr(), pl.theta.data_ptr(), pl.sigma.data_ptr(),
                                    sums.data_ptr(), losses.data_ptr(), B, st), "graph_loss")
@@ -582,7 +585,7 @@ class Engine:
                                          pl.centroid.data_ptr(), pl.node_type.data_ptr(), pl.y.data_ptr(),
                                          pl.batch.data_ptr(), pl.uvp_dim.data_ptr(), pl.sigma.data_ptr(), phi.data_ptr(),
                                          self.smooth, uvp_node.data_ptr(), N, st), "cell_to_node")
-        sv = dict(Ff=Ff, cres=cres, sums=sums, phi=phi, grad=grad, phic=phic)
+        sv = dict(Ff=Ff, cres=cres, sums=sums, phi=phi, grad=grad, phic=phic, gradc=gradc)
         return losses, uvp_node, uvp_cell, sv
 
     def fvm_bwd(self, sv, gloss, pl):
@@ -601,13 +604,14 @@ class Engine:
         dev = gloss.device
         gc, gFf = _empty(dev, C, 4), _empty(dev, E, 16)
         gphi, ggrad = _empty(dev, N, 8), _empty(dev, N, 16)
-        L.check(lib.gfv_fvm_bwd(sv["cres"].data_ptr(), sv["sums"].data_ptr(), gloss.data_ptr(), sv["Ff"].data_ptr(),
+        L.check(lib.gfv_fvm_bwd_ex(sv["cres"].data_ptr(), sv["sums"].data_ptr(), gloss.data_ptr(), sv["Ff"].data_ptr(),
                                 pl.cbatch.data_ptr(), pl.theta.data_ptr(), pl.sigma.data_ptr(), pl.dt.data_ptr(),
                                 pl.frow.data_ptr(), pl.fk.data_ptr(), pl.kcell.data_ptr(), pl.kS.data_ptr(),
                                 pl.ftype.data_ptr(), pl.n_rowptr.data_ptr(), pl.n_col_edge2.data_ptr(), pl.nrow.data_ptr(),
                                 pl.ncell.data_ptr(), pl.crow.data_ptr(), pl.pos.data_ptr(), pl.fpos.data_ptr(),
                                 pl.centroid.data_ptr(), pl.area.data_ptr(), gc.data_ptr(), gFf.data_ptr(), gphi.data_ptr(),
-                                ggrad.data_ptr(), N, E, C, st), "fvm_bwd")
+                                ggrad.data_ptr(), N, E, C, self.nc, None if not self.nc else sv["gradc"].data_ptr(),
+                                None if not self.nc else sv["phic"].data_ptr(), st), "fvm_bwd")
         grhs = _empty(dev, N, 8, 5)
         L.check(lib.gfv_wlsq_bwd(ggrad.data_ptr(), pl.An.data_ptr(), pl.rn.data_ptr(), pl.xo_rowptr.data_ptr(),
                                  pl.xo_in.data_ptr(), pl.xo_B.data_ptr(), pl.sumB.data_ptr(), grhs.data_ptr(),

@@ -252,6 +252,13 @@ int gfv_cell_fwd(const float* phi, const float* grad, const float* Ff, const flo
                  const int32_t* kface, const int32_t* knode, const float* kS, const int32_t* ftype, const float* centroid,
                  const float* area, const int32_t* cbatch, const float* theta, const float* dt, const float* uvp_dim,
                  const float* sigma, float* phic, float* cres, float* uvp_cell, int32_t C, void* stream);
+/* Same with the residuals of the NON-conserved form (FVscheme.py:276-511 as the reference calls it, hessian None):
+ * continuity, convection and pressure terms from the cell means of the node gradients (saved to gradc [C,16]). */
+int gfv_cell_fwd_ex(const float* phi, const float* grad, const float* Ff, const float* pos, const int32_t* crow,
+                    const int32_t* kface, const int32_t* knode, const float* kS, const int32_t* ftype,
+                    const float* centroid, const float* area, const int32_t* cbatch, const float* theta, const float* dt,
+                    const float* uvp_dim, const float* sigma, float* phic, float* cres, float* uvp_cell, int32_t C,
+                    int32_t non_conserved, float* gradc, void* stream);
 int gfv_graph_loss(const float* cres, const int32_t* gcell_ptr, const float* theta, const float* sigma, float* sums,
                    float* losses, int32_t B, void* stream);
 int gfv_cell_to_node(const float* phic, const int32_t* nrow, const int32_t* ncell, const float* pos, const float* centroid,
@@ -264,6 +271,13 @@ int gfv_fvm_bwd(const float* cres, const float* sums, const float* gloss, const 
                 const int32_t* nrow, const int32_t* ncell, const int32_t* crow, const float* pos, const float* fpos,
                 const float* centroid, const float* area, float* gc_ws, float* gFf_ws, float* gphi, float* ggrad,
                 int32_t N, int32_t E, int32_t C, void* stream);
+int gfv_fvm_bwd_ex(const float* cres, const float* sums, const float* gloss, const float* Ff, const int32_t* cbatch,
+                   const float* theta, const float* sigma, const float* dt, const int32_t* frow, const int32_t* fk,
+                   const int32_t* kcell, const float* kS, const int32_t* ftype, const int32_t* nfrow, const int32_t* nfcol2,
+                   const int32_t* nrow, const int32_t* ncell, const int32_t* crow, const float* pos, const float* fpos,
+                   const float* centroid, const float* area, float* gc_ws, float* gFf_ws, float* gphi, float* ggrad,
+                   int32_t N, int32_t E, int32_t C, int32_t non_conserved, const float* gradc, const float* phic,
+                   void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Input normalisation / edge features / optimiser.  Replace FVMmodel/importer.py:54-93,114-130,166-178,

@@ -335,6 +335,63 @@ def integrator_conserved(uvp_new, uv_hat, uv_old, G, hyper, return_intermediates
     return res
 
 
+def integrator_non_conserved(uvp_new, uv_hat, uv_old, G, hyper, return_intermediates=False):
+    """FVscheme.py:618-724 (forward) -> non_conserved_form (:276-511) with hessian_phi = None, as the reference passes
+    it (:660-669): gradient-based continuity, convection and pressure terms from the CELL-averaged node gradients,
+    divergence-form diffusion and the pressure-outlet condition from the face values as in the conserved form."""
+    phi = torch.cat((uvp_new[:, 0:3], uv_hat[:, 0:2], uv_old[:, 0:2]), dim=-1)
+    grad_l = node_based_WLSQ(phi, G["face_node_x"], G["support_edge"], G["A"], G["B1"], G["Bx"], hyper["order"])
+    grad = grad_l[:, :, 0:2]
+    cells_node, cells_face, cells_index = G["cells_node"], G["cells_face"], G["cells_index"]
+    edge_index, face_type = G["edge_index"], G["face_type"]
+    B = G["num_graphs"]
+    C = G["centroid"].shape[0]
+    theta_c = G["theta_PDE"][G["cell_batch"]]
+    cells_area = G["cells_area"].view(-1, 1)
+    Svec = G["cells_face_unv"].view(-1, 2) * G["face_area"].view(-1, 1)[cells_face]
+    unsteady, conv_c, gradp_c, diff_c = theta_c[:, 0:1], theta_c[:, 2:3], theta_c[:, 3:4], theta_c[:, 4:5]
+    source = theta_c[:, 5:6] * cells_area
+    dt_cell = G["dt_graph"][G["cell_batch"], :]
+
+    phi_cell = node_to_cell_2nd_order(phi, grad, cells_node, cells_index, G["pos"], G["centroid"])       # :326-332
+    uvp_cell_new, uv_cell_hat, uv_cell_old = phi_cell[:, 0:3], phi_cell[:, 3:5], phi_cell[:, 5:7]
+    phi_face = node_to_face_2nd_order(phi[:, 0:5], grad[:, 0:5], edge_index, G["pos"], G["face_pos"])     # :338-344
+    p_face_new = phi_face[:, 2:3]
+    grad_face = node_to_face_2nd_order(grad[:, 0:5], None, edge_index, G["pos"], G["face_pos"])           # :349-354
+    grad_cell = scatter_mean(grad[:, 0:5][cells_node], cells_index, C)                                   # :356-361
+    nabla_uvp_face, nabla_uvp_cell = grad_face[:, 0:3], grad_cell[:, 0:3]
+    nabla_uv_face_hat, nabla_uv_cell_hat = grad_face[:, 3:5], grad_cell[:, 3:5]
+
+    out_mask = face_type[cells_face] == OUTFLOW                                                         # :375-398
+    if bool(out_mask.any()):
+        visc = diff_c[cells_index] * torch.matmul(nabla_uvp_face[cells_face, 0:2], Svec.unsqueeze(2)).squeeze(2)
+        surface_p = p_face_new[cells_face, :] * Svec
+        lp = (visc - surface_p)[out_mask]
+        loss_press = torch.sqrt(global_add_pool(lp ** 2, G["edge_batch"][cells_face[out_mask]], B)
+                                .sum(dim=-1, keepdim=True))
+    else:
+        loss_press = torch.zeros((B, 1), dtype=phi.dtype, device=phi.device)
+
+    unsteady_cell = ((uvp_cell_new[:, 0:2] - uv_cell_old) / dt_cell) * cells_area                        # :401
+    div = (nabla_uvp_cell[:, 0:1, 0] + nabla_uvp_cell[:, 1:2, 1]) * cells_area                           # :405-408
+    loss_cont = torch.sqrt(global_add_pool(div ** 2, G["cell_batch"], B)) * G["theta_PDE"][:, 1:2]
+    conv = torch.matmul(nabla_uv_cell_hat, uv_cell_hat.unsqueeze(2)).squeeze(2) * cells_area             # :447-450
+    gradp = nabla_uvp_cell[:, 2] * cells_area                                                            # :454
+    visc_face = torch.matmul(nabla_uv_face_hat[cells_face, 0:2], Svec.unsqueeze(2)).squeeze(2)           # :458-461
+    visc_force = scatter_add(visc_face, cells_index, C)                                                  # :463-469
+    mom = unsteady * unsteady_cell + conv_c * conv + gradp_c * gradp - diff_c * visc_force - source       # :472-478
+    loss_mom = torch.sqrt(global_add_pool(mom ** 2, G["cell_batch"], B)) * G["sigma"][:, 0:2]
+
+    if hyper["ncn_smooth"]:
+        rt = cell_to_node_2nd_order(uvp_cell_new[:, 0:3], cells_node, cells_index, G["centroid"], G["pos"])
+    else:
+        rt = uvp_new
+    res = (loss_cont, loss_mom[:, 0:1], loss_mom[:, 1:2], loss_press, rt, uvp_cell_new)
+    if return_intermediates:
+        return res, dict(grad=grad, phi_cell=phi_cell, grad_cell=grad_cell, div=div, mom=mom)
+    return res
+
+
 # --------------------------------------------------------------------------------------------------------------
 # a-1: model forward, a-15: loss / Adam
 # --------------------------------------------------------------------------------------------------------------
@@ -387,9 +444,8 @@ def model_forward(P, buffers, graphs, hyper=None, norm_uvp=True, norm_global=Tru
         uv_hat = uvp_new[:, 0:2]
     else:
         uv_hat = (uv_old + uvp_new[:, 0:2]) / 2.0                                         # :198-201
-    if not hyper["conserved_form"]:
-        raise NotImplementedError("non_conserved_form is SURVEY.md row f4 (next)")
-    res = integrator_conserved(uvp_new, uv_hat, uv_old, G, hyper, return_intermediates)
+    integ = integrator_conserved if hyper["conserved_form"] else integrator_non_conserved
+    res = integ(uvp_new, uv_hat, uv_old, G, hyper, return_intermediates)
     (lc, lmx, lmy, lp, smoothed, uvp_cell), finter = res if return_intermediates else (res, {})
     smoothed = enforce_boundary_condition(smoothed, G["node_type"], G["y"])               # :223
     uvp_node_dim = smoothed * G["uvp_dim"][nb] * G["sigma"][nb]                           # :228-231

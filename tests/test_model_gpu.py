@@ -210,3 +210,40 @@ def test_transfvgn_v1_matches_oracle_and_reference(golden_dir):
             continue
         err = float((p.grad.cpu() - ograds[k]).abs().max())
         assert err < 1e-4 * float(ograds[k].abs().max()) + 1e-6 * gscale, (k, err)
+
+
+@pytest.mark.parametrize("name", ["cyl_cavity_b2", "cavity_mixed_b1"])
+def test_non_conserved_form_matches_oracle_and_reference(name, golden_dir):
+    """conserved_form=False on the HIP path (cell-gradient continuity / convection / pressure terms
+    and their hand-written adjoint) vs the oracle - forward, loss, every gradient - and, for the case with a fixture,
+    vs the reference's own outputs (tests/golden/nc_cyl_cavity_b2.npz)."""
+    hyper = {"conserved_form": False}
+    graphs = cases.make_graphs(name)
+    P = O.init_parameters(cases.WEIGHT_SEED)
+    Pg = {k: v.detach().requires_grad_(True) for k, v in P.items()}
+    oout = O.model_forward(Pg, O.new_normalizer_buffers(), tuple(g.clone() for g in graphs), hyper=hyper)
+    oloss = O.training_loss(oout)
+    names = list(Pg)
+    ograds = dict(zip(names, torch.autograd.grad(oloss, [Pg[k] for k in names], allow_unused=True)))
+    model = _hip_model(P, conserved_form=False)
+    hg = tuple(g.clone().to("cuda") for g in graphs)
+    hg[0].norm_uvp, hg[0].norm_global = True, True
+    out = model(*hg)
+    for i, key in enumerate(("loss_cont", "loss_mom_x", "loss_mom_y", "loss_press", "uvp_node", "uvp_cell")):
+        assert rel(out[i], oout[i]) < TOL, (key, rel(out[i], oout[i]))
+    if name == "cyl_cavity_b2":
+        fx = np.load(os.path.join(golden_dir, "nc_cyl_cavity_b2.npz"))
+        for i, key in enumerate(("loss_cont", "loss_mom_x", "loss_mom_y", "loss_press", "uvp_node", "uvp_cell")):
+            assert rel(out[i], torch.from_numpy(fx[key])) < TOL, key
+    hp = O.DEFAULT_HYPER
+    loss = torch.mean(torch.log(hp["loss_press"] * out[3] + hp["loss_cont"] * out[0] + hp["loss_mom"] * out[1]
+                                + hp["loss_mom"] * out[2]))
+    assert abs(float(loss) - float(oloss)) < TOL * abs(float(oloss))
+    loss.backward()
+    gscale = max(float(g.abs().max()) for g in ograds.values() if g is not None)
+    for k, p in model.named_parameters():
+        if ograds[k] is None:
+            assert p.grad is None, k
+            continue
+        err = float((p.grad.cpu() - ograds[k]).abs().max())
+        assert err < 1e-4 * float(ograds[k].abs().max()) + 1e-6 * gscale, (k, err)

@@ -105,3 +105,15 @@ def test_oracle_transfvgn_v1_matches_reference(golden_dir):
     for i, key in enumerate(("loss_cont", "loss_mom_x", "loss_mom_y", "loss_press", "uvp_node", "uvp_cell")):
         assert _rel(out[i].detach().numpy(), fx[key]) < TOL, key
     assert abs(float(O.training_loss(out)) - float(fx["loss"])) < TOL * abs(float(fx["loss"]))
+
+
+def test_oracle_non_conserved_form_matches_reference(golden_dir):
+    """conserved_form=False (FVscheme.py:276-511).  Fixture = the reference itself run with that
+    switch (tests/golden/make_golden_nc.py); the oracle's forward agrees bit for bit there."""
+    fx = np.load(os.path.join(golden_dir, "nc_cyl_cavity_b2.npz"))
+    hyper = {"conserved_form": False}
+    graphs = cases.make_graphs("cyl_cavity_b2")
+    out = O.model_forward(O.init_parameters(cases.WEIGHT_SEED), O.new_normalizer_buffers(), graphs, hyper=hyper)
+    for i, key in enumerate(("loss_cont", "loss_mom_x", "loss_mom_y", "loss_press", "uvp_node", "uvp_cell")):
+        assert _rel(out[i].detach().numpy(), fx[key]) < TOL, key
+    assert abs(float(O.training_loss(out)) - float(fx["loss"])) < TOL * abs(float(fx["loss"]))
