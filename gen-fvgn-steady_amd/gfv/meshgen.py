@@ -392,18 +392,29 @@ def velocity_profile(pos, mean_u, kind):
     return uv
 
 
-def finish_mesh(raw, U=None):
-    """raw mesh -> full mesh dict with stencil, moments, PDE coefficients and Dirichlet targets (float64/int64)."""
+def finish_mesh(raw, U=None, device=None):
+    """raw mesh -> full mesh dict with stencil, moments, PDE coefficients and Dirichlet targets (float64/int64).
+
+    device: run the two heavy steps (k-hop stencil, WLSQ moments) with torch ops on that device (gfv.device_prep,
+    SURVEY.md row f2) instead of the host numpy code; same stencil, moments equal to ~1e-12 in float64."""
     mesh = derive_geometry(raw)
     bc = dict(raw["bc"])
     if U is not None:
         bc["U"] = float(U)
     pos = mesh["node|pos"]
     n_nodes = pos.shape[0]
-    extra = k_hop_pairs(mesh["face|face_node"], n_nodes, int(bc["stencil|khops"]))
-    face_node_x = np.concatenate((mesh["face_node_x_base"], extra), axis=1)  # duplicates kept (Load_mesh.py:485)
     support_edge = np.array([[0, 1], [1, 0]], dtype=np.int64)
-    A, B1, Bx = wlsq_moments(pos, face_node_x, support_edge)
+    if device is None:
+        extra = k_hop_pairs(mesh["face|face_node"], n_nodes, int(bc["stencil|khops"]))
+        face_node_x = np.concatenate((mesh["face_node_x_base"], extra), axis=1)  # duplicates kept (Load_mesh.py:485)
+        A, B1, Bx = wlsq_moments(pos, face_node_x, support_edge)
+    else:
+        import torch
+        from . import device_prep
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+        extra = device_prep.k_hop_pairs(t(mesh["face|face_node"]), n_nodes, int(bc["stencil|khops"])).cpu().numpy()
+        face_node_x = np.concatenate((mesh["face_node_x_base"], extra), axis=1)
+        A, B1, Bx = (x.cpu().numpy() for x in device_prep.wlsq_moments(t(pos), t(face_node_x), t(support_edge)))
     th = bc["theta_PDE"]
     Uin, rho, mu = float(bc["U"]), float(bc["rho"]), float(bc["mu"])
     aoa = float(bc["aoa"])

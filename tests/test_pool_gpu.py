@@ -93,3 +93,27 @@ def test_pooled_batch_through_the_model_and_payback():
         assert torch.equal(pool.x[i][:, 0:3], uvp[o:o + n]) and torch.equal(pool.x[i][:, 3:], before[i][:, 3:])
         o += n
     assert torch.equal(pool.x[1], before[1])
+
+
+def test_device_preprocessing_matches_host():
+    """k-hop stencil and WLSQ moments computed with torch ops on the GPU vs the host (numpy) code of
+    gfv.meshgen, which is validated against the reference's pipeline: stencil pairs identical, float64 moments to 1e-10
+    (prefix-sum differences; the consumers use them in fp32)."""
+    import numpy as np
+    from gfv import device_prep, meshgen
+    nx, ny = meshgen.cylinder_grid_for_cells(12000)
+    m = meshgen.derive_geometry(meshgen.raw_tri_channel_cylinder(nx=nx, ny=ny, quad_fraction=0.2, seed=8))
+    pos, fn = m["node|pos"], m["face|face_node"]
+    n = pos.shape[0]
+    host_pairs = meshgen.k_hop_pairs(fn, n, 2)
+    dev_pairs = device_prep.k_hop_pairs(torch.from_numpy(fn).cuda(), n, 2)
+    assert np.array_equal(dev_pairs.cpu().numpy(), host_pairs)
+    fx = np.concatenate((m["face_node_x_base"], host_pairs), axis=1)
+    sup = np.array([[0, 1], [1, 0]], dtype=np.int64)
+    A, B1, Bx = meshgen.wlsq_moments(pos, fx, sup)
+    dA, dB1, dBx = device_prep.wlsq_moments(torch.from_numpy(pos).cuda(), torch.from_numpy(fx).cuda(), torch.from_numpy(sup).cuda())
+    for mine, ref in ((dA, A), (dB1, B1), (dBx, Bx)):
+        ref = torch.from_numpy(np.asarray(ref))
+        assert mine.shape == ref.shape
+        err = float((mine.cpu() - ref).abs().max() / ref.abs().max())
+        assert err < 1e-10, err
