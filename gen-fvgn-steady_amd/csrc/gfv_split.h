@@ -1,0 +1,36 @@
+// fp32 -> two fp16 parts (x = hi + lo after an exact power-of-two scaling), shared by the weight-image kernel and the
+// chain kernel's in-register activation split.
+#pragma once
+#include <hip/hip_runtime.h>
+
+typedef _Float16 gfv_f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 gfv_f16x2 __attribute__((ext_vector_type(2)));
+typedef float gfv_float2 __attribute__((ext_vector_type(2)));
+typedef unsigned gfv_uint4 __attribute__((ext_vector_type(4)));
+
+// exact power of two s with s * m in [2^13, 2^14) (fp16 overflows at 2^16); m = 0 / subnormal / tiny: capped at 2^60
+__device__ __forceinline__ float gfv_pow2_scale(float m) {
+  const int e = (int)((__float_as_uint(m) >> 23) & 255u);  // biased exponent of m >= 0
+  const int se = min(max(267 - e, 1), 187);                // biased exponent of 2^(13 - (e - 127))
+  return __uint_as_float((unsigned)se << 23);
+}
+
+__device__ __forceinline__ unsigned gfv_pk_f16(float a, float b) {
+  const gfv_f16x2 v = __builtin_convertvector(gfv_float2{a, b}, gfv_f16x2);
+  return __builtin_bit_cast(unsigned, v);
+}
+// (a, b) -> packed hi halves, packed lo halves (lo = fp16(x - hi), exact residual before the rounding)
+__device__ __forceinline__ void gfv_split_pair(float a, float b, unsigned& hi, unsigned& lo) {
+  hi = gfv_pk_f16(a, b);
+  const gfv_f16x2 h = __builtin_bit_cast(gfv_f16x2, hi);
+  lo = gfv_pk_f16(a - (float)h[0], b - (float)h[1]);
+}
+__device__ __forceinline__ void gfv_split8(const float (&v)[8], gfv_uint4& hi, gfv_uint4& lo) {
+  unsigned h0, h1, h2, h3, l0, l1, l2, l3;
+  gfv_split_pair(v[0], v[1], h0, l0);
+  gfv_split_pair(v[2], v[3], h1, l1);
+  gfv_split_pair(v[4], v[5], h2, l2);
+  gfv_split_pair(v[6], v[7], h3, l3);
+  hi = gfv_uint4{h0, h1, h2, h3};
+  lo = gfv_uint4{l0, l1, l2, l3};
+}

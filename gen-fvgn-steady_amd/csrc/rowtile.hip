@@ -457,11 +457,10 @@ __global__ __launch_bounds__(256, 2) void rowtile_chain_kernel(const gfv_rowtile
 
 }  // namespace
 
-int gfv_internal_tchain_launch(const gfv_rowtile_args_t* args, int rows_per_wg, hipStream_t stream);  // tchain.hip
+int gfv_internal_tchain_launch(const gfv_rowtile_args_t* args, int ragged, int f16, hipStream_t stream);  // tchain.hip
 
 static int tchain_mode() {
-  // GFV_TCHAIN: 0 = LDS row-tile kernel for everything, 64 / 128 = register-resident chain with that many rows per
-  // workgroup (default 64)
+  // GFV_TCHAIN: 0 = LDS row-tile kernel for everything, otherwise the register-resident chain (default)
   static int mode = -1;
   if (mode < 0) {
     const char* e = getenv("GFV_TCHAIN");
@@ -469,6 +468,19 @@ static int tchain_mode() {
   }
   return mode;
 }
+
+static int f16_mode() {
+  // GFV_F16SPLIT: 0 = fp32 MFMA even when the launch carries split-fp16 weight images
+  static int mode = -1;
+  if (mode < 0) {
+    const char* e = getenv("GFV_F16SPLIT");
+    mode = e ? atoi(e) : 1;
+  }
+  return mode;
+}
+
+static thread_local int g_last_path = -1;
+extern "C" int gfv_rowtile_last_path(void) { return g_last_path; }
 
 extern "C" int gfv_rowtile_tiles(int32_t M) { return (M + BM - 1) / BM; }
 
@@ -520,6 +532,10 @@ extern "C" int gfv_rowtile_chain(const gfv_rowtile_args_t* args, void* stream) {
   if (args->in_op == GFV_IN_LN) rag_t = rag_t && args->seg[0].width == 128 && (args->seg[0].ld % 4 == 0);
   if (args->gadd) rag_t = rag_t && args->seg[0].width == 128 && (args->seg[0].ld % 4 == 0);
   for (int l = 1; l < args->nlayers; ++l) rag_t = rag_t && (args->layer[l].K == 128);
+  // split-fp16 form: every layer carries a weight image; first-layer segments start at 32-k slice boundaries
+  bool f16 = (fast_t || rag_t) && tchain_mode() != 0 && f16_mode() != 0 && args->wmax != nullptr;
+  for (int l = 0; l < args->nlayers; ++l) f16 = f16 && args->layer[l].Wh != nullptr;
+  for (int i = 0; i + 1 < args->nseg; ++i) f16 = f16 && (args->seg[i].width % 32 == 0);
   static const bool dbg = getenv("GFV_ROWTILE_DEBUG") != nullptr;
   if (dbg && !fast_t && !rag_t) {
     fprintf(stderr, "[gfv] generic rowtile: M=%d nseg=%d widths=%d,%d,%d ld0=%d nlayers=%d K0=%d Nlast=%d out_ld=%d in_op=%d fin_op=%d\n",
@@ -549,10 +565,11 @@ extern "C" int gfv_rowtile_chain(const gfv_rowtile_args_t* args, void* stream) {
     const int kind = (fast_t && tchain_mode() != 0) ? GFV_K_TCHAIN0 + lnm : ((rag_t && tchain_mode() != 0) ? GFV_K_TCHAIN_RAG : GFV_K_ROWTILE);
     tok = gfv_prof_begin(kind, fl, by, (hipStream_t)stream);
   }
+  g_last_path = (tchain_mode() != 0 && (fast_t || rag_t)) ? ((fast_t ? 1 : 2) + (f16 ? 4 : 0)) : 0;
   if (fast_t && tchain_mode() != 0)
-    gfv_internal_tchain_launch(args, tchain_mode(), (hipStream_t)stream);
+    gfv_internal_tchain_launch(args, 0, f16 ? 1 : 0, (hipStream_t)stream);
   else if (rag_t && tchain_mode() != 0)
-    gfv_internal_tchain_launch(args, -1, (hipStream_t)stream);
+    gfv_internal_tchain_launch(args, 1, f16 ? 1 : 0, (hipStream_t)stream);
   else if (fast)
     hipLaunchKernelGGL(rowtile_chain_kernel<true>, dim3(tiles), dim3(256), 0, (hipStream_t)stream, *args);
   else

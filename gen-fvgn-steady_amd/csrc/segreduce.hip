@@ -432,3 +432,12 @@ extern "C" int gfv_transpose_batch(const gfv_transpose_desc_t* descs, int32_t n,
 }
 
 extern "C" int gfv_abi_version(void) { return GFV_ABI_VERSION; }
+extern "C" int gfv_struct_size(int32_t which) {
+  switch (which) {
+    case 0: return (int)sizeof(gfv_seg_t);
+    case 1: return (int)sizeof(gfv_layer_t);
+    case 2: return (int)sizeof(gfv_rowtile_args_t);
+    case 3: return (int)sizeof(gfv_wimg_desc_t);
+    default: return -1;
+  }
+}

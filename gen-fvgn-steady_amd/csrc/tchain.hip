@@ -15,8 +15,18 @@
 // The image is written linearly (thread tid -> bytes 16*tid + 4096*p) with the 16-B chunk index XOR-swizzled on the
 // SOURCE side (chunk c of row n sits in slot c ^ ((n>>1)&7)), which makes every ds_read_b128 lane group hit 16
 // distinct slots: the A fragments of four consecutive MFMAs come from one conflict-free ds_read_b128.
+//
+// H instantiations (gfv_layer_t.Wh given): the same chain with every fp32 product split into fp16 parts on the f16 MFMA
+// pipe - v_mfma_f32_16x16x32_f16 has the SAME accumulator layout, and its operand lane (j, g) holds 8 k-slots whose
+// assignment to actual k is free as long as A and B agree: slot e of lane group g in 32-group T is k = 32T + 16(e>>2) +
+// 4g + (e&3), i.e. exactly the accumulator registers (nt = 2T, 2T+1; r = 0..3) this lane already owns, so the
+// register-resident chaining carries over.  x = hi + lo per operand (activations: split in registers after an exact
+// per-row power-of-two scaling; weights: pre-split image, one global scale), acc += w_lo x_hi + w_hi x_lo + w_hi x_hi:
+// 3 MFMAs of 16 cycles per (n-tile, 32 k) instead of 8 of 32, with the error of the f32 MFMA.  The LDS slice is the
+// image's (pass, T) block copied linearly: [nt][part][lane] x 16 B, conflict-free ds_read_b128 without a swizzle.
 #include "gfv_common.h"
 #include "gfv_prof.h"
+#include "gfv_split.h"
 #include "../../include/gfv.h"
 
 #ifdef GFV_TIMING
@@ -45,6 +55,7 @@ struct WBlk {
   int rag;    // block needs element-wise weight loads (k not a multiple of 32, or rows not 16-B aligned)
 };
 
+template <bool H>
 __device__ __forceinline__ WBlk w_block(const gfv_rowtile_args_t& A, int layer, int pass, int chunk) {
   const gfv_layer_t& L = A.layer[layer];
   int koff = 0, width = 128;
@@ -53,6 +64,16 @@ __device__ __forceinline__ WBlk w_block(const gfv_rowtile_args_t& A, int layer, 
     width = A.seg[chunk].width;
   }
   WBlk b;
+  if (H) {  // image slices of 4096 floats (16 KB), [pass][T]; the block starts at T = koff / 32
+    const int nT = (L.K + 31) >> 5;
+    b.w = reinterpret_cast<const float*>(L.Wh) + ((size_t)pass * nT + (koff >> 5)) * 4096;
+    b.ldw = 0;
+    b.nsl = (width + WK - 1) / WK;
+    b.nrows = min(128, L.N - 128 * pass);
+    b.kvalid = width;
+    b.rag = 0;
+    return b;
+  }
   b.ldw = L.ldw ? L.ldw : L.K;
   b.w = L.W + (size_t)(128 * pass) * b.ldw + koff;
   b.nsl = (width + WK - 1) / WK;
@@ -223,6 +244,62 @@ __device__ __forceinline__ void mma_slice(floatx4 (&acc)[T][8], const float (&ac
   }
 }
 
+// H: a slice is 16 KB contiguous in the image, copied linearly
+__device__ __forceinline__ WRegs w_load_h(const float* slice, int tid) {
+  WRegs r;
+  r.a = *reinterpret_cast<const floatx4*>(slice + 4 * tid);
+  r.b = *reinterpret_cast<const floatx4*>(slice + 4 * tid + 1024);
+  r.c = *reinterpret_cast<const floatx4*>(slice + 4 * tid + 2048);
+  r.d = *reinterpret_cast<const floatx4*>(slice + 4 * tid + 3072);
+  return r;
+}
+
+// H: one 32-wide k group on the f16 pipe; LDS slice image [nt 8][part 2][lane 64] x 16 B; n-tiles >= 4 are skipped for
+// the 64-wide tail chunk of a 192-wide last layer (nth = number of 4-tile halves with valid rows)
+__device__ __forceinline__ void mma_slice_h(floatx4 (&acc)[8], const gfv_f16x8& xh, const gfv_f16x8& xl, const float* Wb,
+                                            int lane, int nth) {
+  const gfv_f16x8* wp = reinterpret_cast<const gfv_f16x8*>(Wb) + lane;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    if (h < nth) {
+      gfv_f16x8 w0[4], w1[4];
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        w0[n] = wp[((4 * h + n) * 2 + 0) * 64];
+        w1[n] = wp[((4 * h + n) * 2 + 1) * 64];
+      }
+#pragma unroll
+      for (int n = 0; n < 4; ++n) acc[4 * h + n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[n], xh, acc[4 * h + n], 0, 0, 0);
+#pragma unroll
+      for (int n = 0; n < 4; ++n) acc[4 * h + n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0[n], xl, acc[4 * h + n], 0, 0, 0);
+#pragma unroll
+      for (int n = 0; n < 4; ++n) acc[4 * h + n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0[n], xh, acc[4 * h + n], 0, 0, 0);
+    }
+  }
+}
+
+// H: power-of-two scale of one row (max over the lane's 32 values and the 4 lanes of the row)
+__device__ __forceinline__ float row_scale(const float (&v)[8][4]) {
+  float m = 0.f;
+#pragma unroll
+  for (int t = 0; t < 8; ++t) m = fmaxf(fmaxf(m, fmaxf(fabsf(v[t][0]), fabsf(v[t][1]))), fmaxf(fabsf(v[t][2]), fabsf(v[t][3])));
+  m = fmaxf(m, __shfl_xor(m, 16, 64));
+  m = fmaxf(m, __shfl_xor(m, 32, 64));
+  return gfv_pow2_scale(m);
+}
+// H: fp32 activations -> B-operand fragments of the four 32-groups: slots e = 0..3 <- act[2T][.], 4..7 <- act[2T+1][.]
+__device__ __forceinline__ void to_halves(const float (&v)[8][4], float sc, gfv_f16x8 (&xh)[4], gfv_f16x8 (&xl)[4]) {
+#pragma unroll
+  for (int T32 = 0; T32 < 4; ++T32) {
+    const float e[8] = {v[2 * T32][0] * sc,     v[2 * T32][1] * sc,     v[2 * T32][2] * sc,     v[2 * T32][3] * sc,
+                        v[2 * T32 + 1][0] * sc, v[2 * T32 + 1][1] * sc, v[2 * T32 + 1][2] * sc, v[2 * T32 + 1][3] * sc};
+    gfv_uint4 hi, lo;
+    gfv_split8(e, hi, lo);
+    xh[T32] = __builtin_bit_cast(gfv_f16x8, hi);
+    xl[T32] = __builtin_bit_cast(gfv_f16x8, lo);
+  }
+}
+
 // ---- input segment -> activation registers (gather / concat piece / prologue element ops) -------------------------
 template <int T, int LNM, bool RAG>
 __device__ __forceinline__ void load_segment(const gfv_rowtile_args_t& A, int si, int rowbase, int g, const float* gam,
@@ -323,8 +400,10 @@ __device__ __forceinline__ void load_segment(const gfv_rowtile_args_t& A, int si
 // accumulators exist only in those instantiations)
 // RAG: also takes ragged shapes (first-layer K / segment widths that are not multiples of 32, unaligned rows, a last
 // layer narrower than 64): element-wise loads / stores on those pieces only
-template <int T, int LNM, bool RAG>
+// H: products on the f16 MFMA pipe from the layers' split-fp16 weight images (T = 1 only)
+template <int T, int LNM, bool RAG, bool H>
 __global__ __launch_bounds__(256, 2) void tchain_kernel(const gfv_rowtile_args_t A) {
+  static_assert(!H || T == 1, "the f16 form is instantiated for 16 rows per wave");
   __shared__ __attribute__((aligned(16))) float lds[2 * WS_FLOATS + 1024 + PAR_FLOATS];
   float* red = lds + 2 * WS_FLOATS;
   float* par = red + 1024;  // bias of layer l at 128 l (N_l floats), LayerNorm gamma / beta: read from LDS in the epilogues
@@ -339,6 +418,9 @@ __global__ __launch_bounds__(256, 2) void tchain_kernel(const gfv_rowtile_args_t
   float act[T][8][4];
   floatx4 acc[T][8];
   constexpr bool lnb_in = (LNM == 1), lnb_fin = (LNM == 2);
+  gfv_f16x8 xh[4], xl[4];                                    // H: the activations as (hi, lo) B fragments
+  float sx = 1.f;                                            // H: this row's current power-of-two scale
+  const float ws = H ? gfv_pow2_scale(*A.wmax) : 1.f;        // H: the images' weight scale
 
   // gather rows of the factored first-layer addend: index round trip issued first thing, used in the first epilogue
   const float* pad_s[T];
@@ -372,11 +454,12 @@ __global__ __launch_bounds__(256, 2) void tchain_kernel(const gfv_rowtile_args_t
   }
   int wbuf = 0;
   TS_DECL
-  WBlk cur = w_block(A, 0, 0, 0);
+  WBlk cur = w_block<H>(A, 0, 0, 0);
   // weight pipeline: slice j+1 is loaded to registers while slice j feeds the MFMAs, then parked in the other LDS
   // buffer (prefetch distance 2 with a second register set was measured: no gain, +33 VGPRs)
-  WRegs wr0 = (RAG && cur.rag) ? w_load_ragged(cur.w, cur.ldw, cur.nrows, 0, cur.kvalid, wrow, wc)
-                               : w_load(cur.w, cur.ldw, cur.nrows, wrow, wc);
+  WRegs wr0 = H ? w_load_h(cur.w, tid)
+                 : ((RAG && cur.rag) ? w_load_ragged(cur.w, cur.ldw, cur.nrows, 0, cur.kvalid, wrow, wc)
+                                     : w_load(cur.w, cur.ldw, cur.nrows, wrow, wc));
   w_store(lds, tid, wr0);
   __syncthreads();
   TS(0);
@@ -405,7 +488,7 @@ __global__ __launch_bounds__(256, 2) void tchain_kernel(const gfv_rowtile_args_t
           }
         }
         WBlk nxt = cur;
-        if (have_next) nxt = w_block(A, nl_, np_, nc_);
+        if (have_next) nxt = w_block<H>(A, nl_, np_, nc_);
         if (layer == 0 && (nchunk > 1 || pass == 0)) {
           // (dgamma, dbeta) accumulators live only here: parked in LDS before the MFMA loop needs the registers
           float dgam[8][4], dbet[8][4];
@@ -417,6 +500,17 @@ __global__ __launch_bounds__(256, 2) void tchain_kernel(const gfv_rowtile_args_t
           }
           load_segment<T, LNM, RAG>(A, chunk, rowbase, g, par + PAR_GAMMA, par + PAR_BETA, act, dgam, dbet);
           if (lnb_in) ln_park(dgam, dbet, red, wave, li, g);
+          if (H) {
+            // every segment gets its own row scale; the accumulator follows (exact: powers of two)
+            const float sn = row_scale(act[0]);
+            if (chunk > 0) {
+              const float ratio = sn / sx;
+#pragma unroll
+              for (int nt = 0; nt < 8; ++nt) acc[0][nt] *= ratio;
+            }
+            sx = sn;
+            to_halves(act[0], sx, xh, xl);
+          }
           TS_WAIT();
           TS(1);
         }
@@ -429,7 +523,9 @@ __global__ __launch_bounds__(256, 2) void tchain_kernel(const gfv_rowtile_args_t
             const int wld = more ? cur.ldw : nxt.ldw;
             const int wnr = more ? cur.nrows : nxt.nrows;
 #ifndef ABL_NOW
-            if (RAG && (more ? cur.rag : nxt.rag)) {
+            if (H) {
+              wr0 = w_load_h(more ? cur.w + 4096 * (sl + 1) : nxt.w, tid);
+            } else if (RAG && (more ? cur.rag : nxt.rag)) {
               wr0 = w_load_ragged(more ? cur.w : nxt.w, wld, wnr, more ? WK * (sl + 1) : 0, more ? cur.kvalid : nxt.kvalid,
                                   wrow, wc);
             } else {
@@ -440,7 +536,8 @@ __global__ __launch_bounds__(256, 2) void tchain_kernel(const gfv_rowtile_args_t
             __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ABOVE the MFMAs (the scheduler sinks it otherwise)
 #endif
             TS(2);
-            mma_slice<T>(acc, act, 2 * sl, lds + wbuf * WS_FLOATS, off0);
+            if (H) mma_slice_h(acc[0], xh[sl], xl[sl], lds + wbuf * WS_FLOATS, lane, (cur.nrows + 63) >> 6);
+            else mma_slice<T>(acc, act, 2 * sl, lds + wbuf * WS_FLOATS, off0);
             TS(3);
 #ifndef NO_SCHEDB
             __builtin_amdgcn_sched_barrier(0);
@@ -457,6 +554,7 @@ __global__ __launch_bounds__(256, 2) void tchain_kernel(const gfv_rowtile_args_t
         cur = nxt;
       }
 
+      const float inv = H ? 1.0f / (sx * ws) : 1.0f;   // H: undo the operand scales (exact)
       if (!last) {
         // ---- intermediate epilogue: accumulators -> next layer's activations, in registers ----
 #pragma unroll
@@ -467,6 +565,10 @@ __global__ __launch_bounds__(256, 2) void tchain_kernel(const gfv_rowtile_args_t
 #pragma unroll
           for (int nt = 0; nt < 8; ++nt) {
             float v[4] = {acc[tt][nt][0], acc[tt][nt][1], acc[tt][nt][2], acc[tt][nt][3]};
+            if (H) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] *= inv;
+            }
             if (L.op == GFV_OP_MUL_DGELU) {
               const float4 z = ld4(L.aux + mrow + 16 * nt);
               v[0] *= gfv_dgelu(z.x); v[1] *= gfv_dgelu(z.y); v[2] *= gfv_dgelu(z.z); v[3] *= gfv_dgelu(z.w);
@@ -495,6 +597,10 @@ __global__ __launch_bounds__(256, 2) void tchain_kernel(const gfv_rowtile_args_t
             for (int r = 0; r < 4; ++r) act[tt][nt][r] = v[r];
           }
         }
+        if (H) {
+          sx = row_scale(act[0]);
+          to_halves(act[0], sx, xh, xl);
+        }
         TS_WAIT();
         TS(6);
       } else {
@@ -522,7 +628,7 @@ __global__ __launch_bounds__(256, 2) void tchain_kernel(const gfv_rowtile_args_t
 #pragma unroll
           for (int nt = 0; nt < 8; ++nt) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[nt][r] = acc[tt][nt][r];
+            for (int r = 0; r < 4; ++r) v[nt][r] = H ? acc[tt][nt][r] * inv : acc[tt][nt][r];
             if (nt < ntv) {
               const float4 b = ld4(par + 128 * layer + 128 * pass + 16 * nt + 4 * g);
               v[nt][0] += b.x; v[nt][1] += b.y; v[nt][2] += b.z; v[nt][3] += b.w;
@@ -606,24 +712,21 @@ __global__ __launch_bounds__(256, 2) void tchain_kernel(const gfv_rowtile_args_t
 
 }  // namespace
 
-// fast-path launcher used by gfv_rowtile_chain (rowtile.hip); rows_per_wg: 64 or 128, < 0 = ragged-shape instantiation
-int gfv_internal_tchain_launch(const gfv_rowtile_args_t* args, int rows_per_wg, hipStream_t stream) {
+// fast-path launcher used by gfv_rowtile_chain (rowtile.hip); ragged: the instantiation that also takes ragged shapes
+// (only without LayerNorm backward); f16: the split-fp16 form (every layer has a weight image)
+int gfv_internal_tchain_launch(const gfv_rowtile_args_t* args, int ragged, int f16, hipStream_t stream) {
   const int lnm = args->in_op == GFV_IN_LNBWD ? 1 : (args->fin_op == GFV_FIN_LNBWD ? 2 : 0);
-  if (rows_per_wg < 0) {  // ragged shapes (only without LayerNorm backward)
-    const dim3 wgs((args->M + 63) / 64);
-    hipLaunchKernelGGL((tchain_kernel<1, 0, true>), wgs, dim3(256), 0, stream, *args);
+  const dim3 wgs((args->M + 63) / 64), blk(256);
+  if (f16) {
+    if (ragged) hipLaunchKernelGGL((tchain_kernel<1, 0, true, true>), wgs, blk, 0, stream, *args);
+    else if (lnm == 0) hipLaunchKernelGGL((tchain_kernel<1, 0, false, true>), wgs, blk, 0, stream, *args);
+    else if (lnm == 1) hipLaunchKernelGGL((tchain_kernel<1, 1, false, true>), wgs, blk, 0, stream, *args);
+    else hipLaunchKernelGGL((tchain_kernel<1, 2, false, true>), wgs, blk, 0, stream, *args);
     return 0;
   }
-  if (rows_per_wg == 128) {
-    const dim3 wgs((args->M + 127) / 128);
-    if (lnm == 0) hipLaunchKernelGGL((tchain_kernel<2, 0, false>), wgs, dim3(256), 0, stream, *args);
-    else if (lnm == 1) hipLaunchKernelGGL((tchain_kernel<2, 1, false>), wgs, dim3(256), 0, stream, *args);
-    else hipLaunchKernelGGL((tchain_kernel<2, 2, false>), wgs, dim3(256), 0, stream, *args);
-  } else {
-    const dim3 wgs((args->M + 63) / 64);
-    if (lnm == 0) hipLaunchKernelGGL((tchain_kernel<1, 0, false>), wgs, dim3(256), 0, stream, *args);
-    else if (lnm == 1) hipLaunchKernelGGL((tchain_kernel<1, 1, false>), wgs, dim3(256), 0, stream, *args);
-    else hipLaunchKernelGGL((tchain_kernel<1, 2, false>), wgs, dim3(256), 0, stream, *args);
-  }
+  if (ragged) hipLaunchKernelGGL((tchain_kernel<1, 0, true, false>), wgs, blk, 0, stream, *args);
+  else if (lnm == 0) hipLaunchKernelGGL((tchain_kernel<1, 0, false, false>), wgs, blk, 0, stream, *args);
+  else if (lnm == 1) hipLaunchKernelGGL((tchain_kernel<1, 1, false, false>), wgs, blk, 0, stream, *args);
+  else hipLaunchKernelGGL((tchain_kernel<1, 2, false, false>), wgs, blk, 0, stream, *args);
   return 0;
 }

@@ -1,0 +1,69 @@
+// Split-fp16 weight images for the f16-MFMA form of the fused GEMM chain (contract: include/gfv.h, gfv_weight_images).
+#include "gfv_common.h"
+#include "gfv_split.h"
+#include "../../include/gfv.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void wabsmax_kernel(const gfv_wimg_desc_t* __restrict__ descs, float* __restrict__ wmax) {
+  const gfv_wimg_desc_t d = descs[blockIdx.y];
+  const int total = d.N * d.K;
+  float m = 0.f;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    const int n = i / d.K, k = i - n * d.K;
+    m = fmaxf(m, fabsf(d.W[(size_t)n * d.ldw + k]));
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  // non-negative floats order like their bit patterns
+  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(reinterpret_cast<unsigned*>(wmax), __float_as_uint(m));
+}
+
+// one thread = one (pass, T, nt, lane) fragment, both parts
+__global__ __launch_bounds__(256) void wimg_kernel(const gfv_wimg_desc_t* __restrict__ descs, const float* __restrict__ wmax) {
+  const gfv_wimg_desc_t d = descs[blockIdx.y];
+  const int nT = (d.K + 31) >> 5, npass = (d.N + 127) >> 7;
+  const long f = (long)blockIdx.x * 256 + threadIdx.x;
+  if (f >= (long)npass * nT * 512) return;
+  const float ws = gfv_pow2_scale(*wmax);
+  const int lane = (int)(f & 63), nt = (int)((f >> 6) & 7);
+  const int rest = (int)(f >> 9);
+  const int T = rest % nT, pass = rest / nT;
+  const int n = 128 * pass + 16 * nt + (lane & 15), g = lane >> 4;
+  float v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int k = 32 * T + 16 * (e >> 2) + 4 * g + (e & 3);
+    v[e] = (n < d.N && k < d.K) ? d.W[(size_t)n * d.ldw + k] * ws : 0.f;
+  }
+  gfv_uint4 hi, lo;
+  gfv_split8(v, hi, lo);
+  gfv_uint4* img = reinterpret_cast<gfv_uint4*>(d.img) + ((size_t)(pass * nT + T) * 8 + nt) * 128 + lane;
+  img[0] = hi;
+  img[64] = lo;
+}
+
+}  // namespace
+
+extern "C" size_t gfv_weight_image_bytes(int32_t N, int32_t K) {
+  return (size_t)((N + 127) / 128) * ((K + 31) / 32) * 16384;
+}
+
+extern "C" int gfv_weight_absmax(const gfv_wimg_desc_t* descs_dev, int32_t n_desc, float* wmax, void* stream) {
+  if (!descs_dev || !wmax || n_desc < 0) return GFV_ERR_ARG;
+  if (hipMemsetAsync(wmax, 0, sizeof(float), (hipStream_t)stream) != hipSuccess) return GFV_ERR_LAUNCH;
+  if (n_desc == 0) return GFV_OK;
+  hipLaunchKernelGGL(wabsmax_kernel, dim3(16, n_desc), dim3(256), 0, (hipStream_t)stream, descs_dev, wmax);
+  GFV_CHECK_LAUNCH();
+  return GFV_OK;
+}
+
+extern "C" int gfv_weight_images(const gfv_wimg_desc_t* descs_dev, int32_t n_desc, int64_t max_frags, const float* wmax,
+                                 void* stream) {
+  if (!descs_dev || !wmax || n_desc < 0 || max_frags < 0) return GFV_ERR_ARG;
+  if (n_desc == 0 || max_frags == 0) return GFV_OK;
+  hipLaunchKernelGGL(wimg_kernel, dim3((unsigned)((max_frags + 255) / 256), n_desc), dim3(256), 0, (hipStream_t)stream,
+                     descs_dev, wmax);
+  GFV_CHECK_LAUNCH();
+  return GFV_OK;
+}

@@ -74,6 +74,9 @@ class Engine:
         # EdgeBlock first layer factored through the nodes: W1 [x_s | x_r | e] = (W1a x)[s] + (W1b x)[r] + W1c e, the two
         # node-level products (and their adjoints / weight gradients) run over N rows instead of E = 3N
         self.factor = os.environ.get("GFV_EDGE_FACTOR", "1") != "0"
+        # fp32 products of the chain kernels as split-fp16 on the f16 MFMA pipe (include/gfv.h, gfv_weight_images)
+        self.f16split = os.environ.get("GFV_F16SPLIT", "1") != "0"
+        self._wi, self._wi_key, self._wmax, self._wi_abs = None, None, None, None
         self._etmp = None
         self._side = None
         self._keep = []
@@ -115,6 +118,39 @@ class Engine:
         if self.overlap and self._side is not None:
             torch.cuda.current_stream().wait_stream(self._side)
         self._keep.clear()
+
+    # ------------------------------------------------------------------------------------------------------------
+    # split-fp16 weight images: one set for the forward launches (built from the parameters when the forward starts),
+    # one for the backward (built from the transposed copies right after prepare_transposes)
+    # ------------------------------------------------------------------------------------------------------------
+    def _wi_enter(self, phase, P):
+        if not self.f16split:
+            return None
+        key = tuple(t.data_ptr() for t in P.values())
+        if self._wi_key != key:
+            dev = next(iter(P.values())).device
+            self._wmax = torch.zeros((1,), dtype=torch.float32, device=dev)
+            self._wi = {ph: ops.WeightImages(dev, self._wmax) for ph in ("fwd", "bwd")}
+            self._wi["fwd"].add_static(P.values())
+            mats = [t for t in P.values() if t.dim() == 2 and t.stride(1) == 1]
+            self._wi_abs = (ops.WeightImages._upload([((t.data_ptr(), t.stride(0), t.shape[0], t.shape[1]), t) for t in mats],
+                                                     dev), len(mats))
+            self._wi_key = key
+        wi = self._wi[phase]
+        if phase == "fwd":
+            # one power-of-two scale for all weight images of this step, from max|W| over every weight matrix
+            L.check(L.load().gfv_weight_absmax(self._wi_abs[0].data_ptr(), self._wi_abs[1], self._wmax.data_ptr(),
+                                               L.stream_ptr()), "gfv_weight_absmax")
+        elif not wi.static and self._wt:
+            wi.add_static(self._wt.values())
+        wi.build()
+        return ops.set_weight_images(wi)
+
+    def _wi_exit(self, phase, prev):
+        if not self.f16split:
+            return
+        self._wi[phase].invalidate()    # the images are only valid for this step's parameter values
+        ops.set_weight_images(prev)
 
     # ------------------------------------------------------------------------------------------------------------
     # transposed weights for the dX chains: one batched launch per step (prepare_transposes) or on demand
@@ -712,17 +748,23 @@ class Engine:
     # ------------------------------------------------------------------------------------------------------------
     def forward(self, P, buffers, x, pl, *, norm_global=True, accumulate=True, want_outputs=True, want_edge_attr15=True):
         uv_old, ea16, ea15 = self.prep_fwd(x, buffers, pl, norm_global, accumulate, want_edge_attr15)
-        dec, sv_sim = self.simulator_fwd(P, x, ea16, pl)
+        prev = self._wi_enter("fwd", P)
+        try:
+            dec, sv_sim = self.simulator_fwd(P, x, ea16, pl)
+        finally:
+            self._wi_exit("fwd", prev)
         losses, uvp_node, uvp_cell, sv_fvm = self.fvm_fwd(dec, uv_old, pl, want_outputs)
         return losses, uvp_node, uvp_cell, ea15, dict(sim=sv_sim, fvm=sv_fvm)
 
     def backward(self, P, ctx, gloss, grads, pl):
         """gloss [B,4] = dL/d(cont, mom_x, mom_y, press); fills `grads` (name -> preallocated tensor)."""
         self.prepare_transposes(P)
+        prev = self._wi_enter("bwd", P)
         try:
             g_dec = self.fvm_bwd(ctx["fvm"], gloss, pl)
             self.simulator_bwd(P, ctx["sim"], g_dec, grads, pl)
             self.join()
         finally:
             self._wt_live = False  # the cached transposes are only valid for this step's parameter values
+            self._wi_exit("bwd", prev)
         return grads

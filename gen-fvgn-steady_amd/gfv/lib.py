@@ -27,7 +27,7 @@ class Seg(C.Structure):
 
 class Layer(C.Structure):
     _fields_ = [("W", C.c_void_p), ("bias", C.c_void_p), ("K", C.c_int32), ("N", C.c_int32), ("op", C.c_int32),
-                ("ldw", C.c_int32), ("save", C.c_void_p), ("aux", C.c_void_p)]
+                ("ldw", C.c_int32), ("save", C.c_void_p), ("aux", C.c_void_p), ("Wh", C.c_void_p)]
 
 
 class RowtileArgs(C.Structure):
@@ -39,8 +39,13 @@ class RowtileArgs(C.Structure):
         ("fin_gamma", C.c_void_p), ("fin_beta", C.c_void_p), ("fin_aux", C.c_void_p), ("fin_presave", C.c_void_p),
         ("res", C.c_void_p * 3), ("res_ld", C.c_int32 * 3), ("out_ld", C.c_int32 * 3), ("out", C.c_void_p * 3),
         ("out_nores", C.c_void_p), ("padd", C.c_void_p), ("padd_s", C.c_void_p), ("padd_r", C.c_void_p),
-        ("padd_ld", C.c_int32), ("pad2_", C.c_int32),
+        ("padd_ld", C.c_int32), ("pad2_", C.c_int32), ("wmax", C.c_void_p),
     ]
+
+
+class WimgDesc(C.Structure):
+    _fields_ = [("W", C.c_void_p), ("img", C.c_void_p), ("ldw", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
+                ("reserved", C.c_int32)]
 
 
 class DwTile(C.Structure):
@@ -54,6 +59,7 @@ _lib = None
 
 _SIGNATURES = {
     "gfv_abi_version": (C.c_int, []),
+    "gfv_struct_size": (C.c_int, [C.c_int32]),
     "gfv_seg_gather_sum": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                      C.c_int32, C.c_int32, C.c_void_p]),
     "gfv_seg_gather_sum_nnz": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
@@ -66,6 +72,7 @@ _SIGNATURES = {
                                   C.c_void_p]),
     "gfv_rowtile_tiles": (C.c_int, [C.c_int32]),
     "gfv_rowtile_chain": (C.c_int, [C.POINTER(RowtileArgs), C.c_void_p]),
+    "gfv_rowtile_last_path": (C.c_int, []),
     "gfv_dw_chunks": (C.c_int, [C.c_int32]),
     "gfv_linear_dw_workspace_floats": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     "gfv_linear_dw": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(Seg), C.c_int32, C.c_void_p, C.c_int32,
@@ -79,6 +86,9 @@ _SIGNATURES = {
                                C.c_void_p]),
     "gfv_reduce_partials": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
     "gfv_concat_offsets": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    "gfv_weight_image_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
+    "gfv_weight_absmax": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    "gfv_weight_images": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p]),
     "gfv_reduce_partials_2d": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "gfv_reduce_partials_seg": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "gfv_transpose": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),

@@ -86,10 +86,88 @@ class LayerSpec:
         self.W, self.bias, self.op, self.save, self.aux = W, bias, op, save, aux
 
 
+class WeightImages:
+    """Split-fp16 images (include/gfv.h, gfv_weight_images) of the weight blocks a set of chain launches uses.
+
+    The set builds itself: the first launch that brings a weight block (pointer, row stride, shape) gets its image made
+    on the spot; from then on `build()` refreshes every known image in one launch per step (the weights change with
+    every optimizer step).  Only blocks inside `static` address ranges (parameters, the engine's persistent transposed
+    copies) qualify - a temporary would be gone by the next step; anything else runs on the fp32 MFMA.  `wmax` is the
+    device scalar max|W| all images of an engine are scaled with (the caller keeps it current)."""
+
+    def __init__(self, device, wmax):
+        self.device, self.wmax = device, wmax
+        self.images = {}                            # key -> uint8 tensor
+        self.valid = set()                          # keys whose image holds this step's values
+        self.static = []                            # sorted [(start, end)]
+        self._desc, self._desc_keys, self._max_frags = None, (), 0
+
+    def add_static(self, tensors):
+        for t in tensors:
+            st = t.untyped_storage()
+            self.static.append((st.data_ptr(), st.data_ptr() + st.nbytes()))
+        self.static.sort()
+
+    def _is_static(self, ptr):
+        import bisect
+        i = bisect.bisect_right(self.static, (ptr, 1 << 62)) - 1
+        return i >= 0 and self.static[i][0] <= ptr < self.static[i][1]
+
+    @staticmethod
+    def _upload(items, device):
+        descs = (L.WimgDesc * len(items))()
+        for d, (key, img) in zip(descs, items):
+            d.W, d.img, d.ldw, d.N, d.K = key[0], img.data_ptr(), key[1], key[2], key[3]
+        return torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(device)
+
+    def lookup(self, W):
+        """-> image pointer (0: none; the launch then takes the fp32 path)."""
+        key = (W.data_ptr(), W.stride(0), W.shape[0], W.shape[1])
+        img = self.images.get(key)
+        if img is not None:
+            return img.data_ptr() if key in self.valid else 0
+        if not self._is_static(key[0]) or torch.cuda.is_current_stream_capturing():
+            return 0   # (allocations and uploads stay out of a hipGraph capture)
+        lib = L.load()
+        img = torch.empty((lib.gfv_weight_image_bytes(key[2], key[3]),), dtype=torch.uint8, device=self.device)
+        desc = self._upload([(key, img)], self.device)
+        L.check(lib.gfv_weight_images(desc.data_ptr(), 1, img.numel() // 32, self.wmax.data_ptr(), L.stream_ptr()),
+                "gfv_weight_images")
+        self.images[key] = img
+        self.valid.add(key)
+        return img.data_ptr()
+
+    def build(self):
+        """Refresh every known image from the current weight values: one launch."""
+        if not self.images:
+            return
+        if len(self._desc_keys) != len(self.images) and not torch.cuda.is_current_stream_capturing():
+            self._desc_keys = tuple(self.images)
+            self._desc = self._upload(list(self.images.items()), self.device)
+            self._max_frags = max(img.numel() for img in self.images.values()) // 32
+        if self._desc is None:
+            return
+        L.check(L.load().gfv_weight_images(self._desc.data_ptr(), len(self._desc_keys), self._max_frags,
+                                           self.wmax.data_ptr(), L.stream_ptr()), "gfv_weight_images")
+        self.valid = set(self._desc_keys)
+
+    def invalidate(self):
+        self.valid = set()
+
+
+_WI = None   # the WeightImages the chain launches currently consult (set by the engine around forward / backward)
+
+
+def set_weight_images(wi):
+    global _WI
+    prev, _WI = _WI, wi
+    return prev
+
+
 def rowtile_chain(M, segs, layers, outs, *, in_add=None, in_op=L.IN_NONE, in_gamma=None, in_beta=None, in_aux=None,
                   gadd=None, gadd_s=None, gadd_r=None, in_save=None, ln_partial=None, fin_op=L.FIN_PLAIN,
                   fin_gamma=None, fin_beta=None, fin_aux=None, fin_presave=None, res=None, out_nores=None,
-                  padd=None, padd_s=None, padd_r=None):
+                  padd=None, padd_s=None, padd_r=None, wimg=None):
     """Launch the fused row-tile GEMM chain.  outs / res: list (per 128-wide chunk of the last layer) of
     (tensor, ld) or tensors; see include/gfv.h for the semantics of every field."""
     lib = L.load()
@@ -112,6 +190,13 @@ def rowtile_chain(M, segs, layers, outs, *, in_add=None, in_op=L.IN_NONE, in_gam
         cl.ldw = ly.W.stride(0)  # a column block of a wider weight keeps the parent's row stride
         cl.op = ly.op
         cl.save, cl.aux = _p(ly.save), _p(ly.aux)
+    wi = wimg if wimg is not None else _WI
+    if wi is not None:
+        hs = [wi.lookup(ly.W) for ly in layers]
+        if all(hs):
+            for i, h in enumerate(hs):
+                a.layer[i].Wh = h
+            a.wmax = wi.wmax.data_ptr()
     a.fin_op = fin_op
     a.fin_gamma, a.fin_beta, a.fin_aux, a.fin_presave = _p(fin_gamma), _p(fin_beta), _p(fin_aux), _p(fin_presave)
     for i, o in enumerate(outs):

@@ -120,8 +120,11 @@ class TrainStep:
                 s.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(s):
                     self._snapshot()
-                    self._body(acc, with_adam=not dist_on)
-                    self._restore()
+                    # twice: the first pass notes the weight blocks of the chain launches, the second allocates and
+                    # builds their split-fp16 images - the capture then records the launch sequence of a steady step
+                    for _ in range(2 if self.engine.f16split else 1):
+                        self._body(acc, with_adam=not dist_on)
+                        self._restore()
                 torch.cuda.current_stream().wait_stream(s)
                 torch.cuda.synchronize()
                 g = torch.cuda.CUDAGraph()

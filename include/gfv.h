@@ -20,6 +20,9 @@ extern "C" {
 
 #define GFV_ABI_VERSION 1
 int gfv_abi_version(void);
+/* sizeof of the argument structs as the library was compiled (which: 0 gfv_seg_t, 1 gfv_layer_t, 2 gfv_rowtile_args_t,
+ * 3 gfv_wimg_desc_t): lets a binding check its own layout */
+int gfv_struct_size(int32_t which);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Segmented (CSR) gather-reduce:  out[r,:] = scale[r] * sum_{k in [rowptr[r],rowptr[r+1])} src[col[k],:]
@@ -73,6 +76,8 @@ typedef struct {
   int32_t ldw;        /* row stride of W in floats; 0 = K (a column block of a wider weight: W1[:, 256:384]) */
   float* save;        /* optional [M, N] */
   const float* aux;   /* [M, N] for GFV_OP_MUL_DGELU */
+  const void* Wh;     /* optional: split-fp16 image of W (gfv_weight_images); when every layer of a launch has one
+                       * (and args.wmax is set) the products run on the f16 MFMA pipe, see below */
 } gfv_layer_t;
 
 typedef struct {
@@ -111,10 +116,34 @@ typedef struct {
   const int32_t* padd_r;
   int32_t padd_ld;
   int32_t pad2_;
+  const float* wmax;      /* device scalar max|W| the layers' Wh images were built with (gfv_weight_images) */
 } gfv_rowtile_args_t;
 
 int gfv_rowtile_tiles(int32_t M); /* number of 64-row tiles = rows of ln_partial */
 int gfv_rowtile_chain(const gfv_rowtile_args_t* args, void* stream);
+/* which kernel the calling thread's last gfv_rowtile_chain launch took: 0 generic LDS row-tile, 1 register-resident
+ * chain, 2 its ragged-shape instantiation; + 4 when the products ran as split-fp16 (tests assert the path they mean) */
+int gfv_rowtile_last_path(void);
+
+/* fp32 products on the f16 MFMA pipe (v_mfma_f32_16x16x32_f16, 16x the f32 MFMA rate): every fp32 operand is split
+ * into two fp16 parts, x = hi + lo (22 mantissa bits after an exact power-of-two scaling: per input row for the
+ * activations, one global scale 2^s from max|W| for the weights), and hi*hi + hi*lo + lo*hi is accumulated in fp32 -
+ * 3 MFMAs instead of 8, error <= that of the f32 MFMA (products are exact, the dropped lo*lo term is 2^-22 relative).
+ * The weights are split once per step into an image in MFMA-fragment order:
+ *   image[pass = n/128][T = k/32][nt = (n%128)/16][part][lane = 16 g + i][e]  (fp16),
+ *   element = part(2^s W[128 pass + 16 nt + i][32 T + 16 (e>>2) + 4 g + (e&3)]),  zero outside [N, K]
+ * (16 KB per (pass, T): exactly the LDS slice the chain kernel streams).  The activations are split in registers. */
+typedef struct {
+  const float* W; /* [N, K], row stride ldw */
+  void* img;      /* gfv_weight_image_bytes(N, K) bytes */
+  int32_t ldw, N, K, reserved;
+} gfv_wimg_desc_t;
+size_t gfv_weight_image_bytes(int32_t N, int32_t K);
+/* wmax[0] = max |W| over all described blocks (device scalar, overwritten) */
+int gfv_weight_absmax(const gfv_wimg_desc_t* descs_dev, int32_t n_desc, float* wmax, void* stream);
+/* build every image; max_frags = max over descs of gfv_weight_image_bytes / 32 */
+int gfv_weight_images(const gfv_wimg_desc_t* descs_dev, int32_t n_desc, int64_t max_frags, const float* wmax,
+                      void* stream);
 
 /* Weight gradient of a Linear layer: dW[n,k] = sum_m G[m,n] * A[m,k], db[n] = sum_m G[m,n] (two-stage,
  * deterministic).  A is assembled like the forward input (segments, gather, optional GELU of a saved

@@ -1,4 +1,6 @@
 """GPU: every C-ABI kernel against a float64 torch restatement of the same op (tolerance 1e-5 relative, fp32)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -20,6 +22,35 @@ def dev():
     from gfv import lib
     lib.load()
     return torch.device("cuda:0")
+
+
+@pytest.fixture(params=["f32", "f16split"], autouse=True)
+def chain_mode(request, dev, monkeypatch):
+    """Every test of this file runs twice: with the chain launches on the fp32 MFMA, and with the products as split-fp16
+    on the f16 MFMA pipe (weight images made on the spot, then once more after the batched refresh - the second result is
+    what the test sees; the library must report that the split form really ran)."""
+    if request.param == "f32":
+        yield "f32"
+        return
+    if os.environ.get("GFV_TCHAIN") == "0" or "fallback" in request.node.name:
+        pytest.skip("the split-fp16 form lives in the register-resident chain kernel")
+    from gfv import lib as L, ops
+    orig = ops.rowtile_chain
+    wmax = torch.zeros(1, device=dev)
+
+    def split(M, segs, layers, *a, **k):
+        # max |W| of this launch's weights, then the launch with images made on the spot
+        wmax.copy_(torch.stack([ly.W.abs().max() for ly in layers]).max().reshape(1))
+        wi = ops.WeightImages(dev, wmax)
+        wi.static = [(0, 1 << 62)]
+        orig(M, segs, layers, *a, wimg=wi, **k)
+        assert L.load().gfv_rowtile_last_path() >= 5, "split-fp16 chain did not run"
+        wi.build()    # the batched refresh writes the same images
+        orig(M, segs, layers, *a, wimg=wi, **k)
+        assert L.load().gfv_rowtile_last_path() >= 5
+
+    monkeypatch.setattr(ops, "rowtile_chain", split)
+    yield "f16split"
 
 
 def _csr(index, n_rows):

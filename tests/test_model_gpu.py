@@ -63,6 +63,9 @@ def test_forward_backward_matches_oracle(name, golden_dir):
                                 + hp["loss_mom"] * out[2]))
     assert abs(float(loss) - float(oloss)) < TOL * abs(float(oloss))
     loss.backward()
+    from gfv import lib as L
+    split = os.environ.get("GFV_F16SPLIT", "1") != "0"
+    assert (L.load().gfv_rowtile_last_path() >= 5) == split   # the chain launches ran in the form this process asked for
     gscale = max(float(g.abs().max()) for g in ograds.values() if g is not None)
     worst = 0.0
     for k, p in model.named_parameters():
@@ -247,3 +250,17 @@ def test_non_conserved_form_matches_oracle_and_reference(name, golden_dir):
             continue
         err = float((p.grad.cpu() - ograds[k]).abs().max())
         assert err < 1e-4 * float(ograds[k].abs().max()) + 1e-6 * gscale, (k, err)
+
+
+def test_fp32_mfma_form_still_matches_oracle():
+    """`GFV_F16SPLIT=0` keeps every chain product on the fp32 MFMA (the first form of the kernels, and what a launch
+    without weight images takes).  The switch is read once per process: the oracle-parity tests of this file are re-run
+    in a child process with it set (a child, never an exec of this GPU process)."""
+    import subprocess
+    import sys
+    env = dict(os.environ, GFV_F16SPLIT="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k",
+                        "test_forward_backward_matches_oracle or test_adam_training_steps"], env=env, capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
