@@ -12,6 +12,7 @@
 #include <stdlib.h>
 #include "gfv_common.h"
 #include "gfv_prof.h"
+#include "gfv_split.h"
 #include "../../include/gfv.h"
 
 namespace {
@@ -192,12 +193,207 @@ __device__ __forceinline__ void dw_body(const DwLaunch& A, const gfv_dw_tile_t& 
   }
 }
 
+
+// ---- split-fp16 form (GFV_F16SPLIT, default) -------------------------------------------------------------------------
+// Same tiling, products on the f16 MFMA pipe (v_mfma_f32_16x16x32_f16: one MFMA contracts a whole 32-row sub-tile):
+// G and A are split into (hi, lo) fp16 parts while they are staged, dW += G_lo^T A_hi + G_hi^T A_lo + G_hi^T A_hi with
+// fp32 accumulation - 3 MFMAs of 16 cycles per 16x16 output tile and sub-tile instead of 8 of 32.  The contraction
+// index is the row m, so a scale must be constant over the rows of a sub-tile: the gradient rows are scaled by ONE exact
+// power of two per slab, from max|G| over the slab (a first pass over the slab's G rows - they are re-read from L2 right
+// after); the activations (inputs, GELU / LayerNorm outputs: O(1)) are split unscaled, clamped to the fp16 range.
+// LDS image per operand and sub-tile: [column tile 8][part 2] blocks of 64 lanes x 16 B in MFMA-fragment order (lane
+// (i, g) holds rows m = 8g..8g+7 of column 16 ct + i); column i of tile ct sits in lane slot i ^ (ct & 3), which spreads
+// the staging writes (a thread owns 4 consecutive rows of 4 columns: one 8-B piece per column and part) over the banks.
+constexpr int HBLK = 1024;                 // bytes per (column tile, part) block
+constexpr int HOP = 16 * HBLK;             // bytes per operand and sub-tile
+constexpr int HBUF = 2 * HOP;              // bytes per buffer (G, A)
+
+template <bool FULL>
+__device__ __forceinline__ void dw_body_h(const DwLaunch& A, const gfv_dw_tile_t& T, unsigned char* lds) {
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, nl = lane & 15, q = lane >> 4;
+  const int wn = wave >> 1, wk = wave & 1;
+  const int slab = blockIdx.x;
+  const int kpad = FULL ? 128 : ((T.width + 15) & ~15);
+  const int npad = FULL ? 128 : ((T.n_out + 15) & ~15);
+  const bool gvec = FULL || (((T.ldg & 3) == 0) && ((T.n_out & 3) == 0));
+  const bool avec = FULL || (((T.ld & 3) == 0) && ((T.width & 3) == 0));
+  const int c4 = tid & 31, r4 = tid >> 5;  // staging: float4 column, group of 4 consecutive rows (0..7)
+  const int col = 4 * c4;
+  float4 gam = make_float4(1.f, 1.f, 1.f, 1.f), bet = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (T.a_op == 2) {
+    gam = *reinterpret_cast<const float4*>(T.a_gamma + col);
+    bet = *reinterpret_cast<const float4*>(T.a_beta + col);
+  }
+  const int m_beg = slab * A.rows_per_slab;
+  const int m_end = min(m_beg + A.rows_per_slab, A.M);
+
+  // ---- slab scale of the gradient rows ----
+  float gm = 0.f;
+  for (int m = m_beg + r4; m < m_end; m += 8) {
+    const float4 v = ld4(T.G, (size_t)m, T.ldg, col, FULL ? 128 : T.n_out, gvec);
+    gm = fmaxf(fmaxf(gm, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) gm = fmaxf(gm, __shfl_xor(gm, o, 64));
+  float* wred = reinterpret_cast<float*>(lds);
+  if (lane == 0) wred[wave] = gm;
+  __syncthreads();
+  const float sg = gfv_pow2_scale(fmaxf(fmaxf(wred[0], wred[1]), fmaxf(wred[2], wred[3])));
+  __syncthreads();
+
+  floatx4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+  float4 dbacc = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 greg[4], areg[4], breg[4];
+  int nidx[4];
+  auto load_idx = [&](int m0) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int m = min(m0 + 4 * r4 + p, m_end - 1);
+      nidx[p] = T.idx ? T.idx[m] : m;
+    }
+  };
+  auto load_sub = [&](int m0) {
+    size_t srow[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) srow[p] = (size_t)nidx[p];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int m = min(m0 + 4 * r4 + p, m_end - 1);
+      greg[p] = ld4(T.G, (size_t)m, T.ldg, col, FULL ? 128 : T.n_out, gvec);
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      areg[p] = ld4(T.A, srow[p], T.ld, col, FULL ? 128 : T.width, avec);
+      if (T.in_add) breg[p] = ld4(T.in_add, srow[p], T.ld, col, FULL ? 128 : T.width, avec);
+    }
+    load_idx(m0 + SUB);
+  };
+  // this thread's 8-B slot inside a (column tile, part) block: lane (i = column & 15, g = r4 >> 1), rows e = 4 (r4 & 1)..+3
+  const int slot = ((r4 >> 1) * 16) * 16 + 8 * (r4 & 1);
+  auto put4 = [&](unsigned char* op, int c, float v0, float v1, float v2, float v3) {
+    unsigned h0, h1, l0, l1;
+    gfv_split_pair(v0, v1, h0, l0);
+    gfv_split_pair(v2, v3, h1, l1);
+    unsigned char* b = op + ((c >> 4) * 2) * HBLK + ((c & 15) ^ ((c >> 4) & 3)) * 16 + slot;
+    *reinterpret_cast<uint2*>(b) = make_uint2(h0, h1);
+    *reinterpret_cast<uint2*>(b + HBLK) = make_uint2(l0, l1);
+  };
+  auto store_sub = [&](int buf, int m0) {
+    unsigned char* Gs = lds + buf * HBUF;
+    unsigned char* As = Gs + HOP;
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 g[4], a[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const bool live = (m0 + 4 * r4 + p) < m_end;
+      g[p] = greg[p];
+      a[p] = areg[p];
+      if (T.in_add) { a[p].x += breg[p].x; a[p].y += breg[p].y; a[p].z += breg[p].z; a[p].w += breg[p].w; }
+      if (T.a_op == 1) {
+        a[p] = make_float4(gfv_gelu(a[p].x), gfv_gelu(a[p].y), gfv_gelu(a[p].z), gfv_gelu(a[p].w));
+      } else if (T.a_op == 2) {
+        const float mean = gfv_half_sum((a[p].x + a[p].y) + (a[p].z + a[p].w)) * (1.0f / 128.0f);
+        const float dx = a[p].x - mean, dy = a[p].y - mean, dz = a[p].z - mean, dw = a[p].w - mean;
+        const float var = gfv_half_sum((dx * dx + dy * dy) + (dz * dz + dw * dw)) * (1.0f / 128.0f);
+        const float rstd = rsqrtf(var + 1e-5f);
+        a[p] = make_float4(dx * rstd * gam.x + bet.x, dy * rstd * gam.y + bet.y, dz * rstd * gam.z + bet.z,
+                           dw * rstd * gam.w + bet.w);
+      }
+      if (!live) { g[p] = zero; a[p] = zero; }
+      dbacc.x += g[p].x; dbacc.y += g[p].y; dbacc.z += g[p].z; dbacc.w += g[p].w;
+      // fp16 range of the unscaled activations
+      a[p].x = fminf(fmaxf(a[p].x, -65000.f), 65000.f); a[p].y = fminf(fmaxf(a[p].y, -65000.f), 65000.f);
+      a[p].z = fminf(fmaxf(a[p].z, -65000.f), 65000.f); a[p].w = fminf(fmaxf(a[p].w, -65000.f), 65000.f);
+    }
+    put4(Gs, col + 0, g[0].x * sg, g[1].x * sg, g[2].x * sg, g[3].x * sg);
+    put4(Gs, col + 1, g[0].y * sg, g[1].y * sg, g[2].y * sg, g[3].y * sg);
+    put4(Gs, col + 2, g[0].z * sg, g[1].z * sg, g[2].z * sg, g[3].z * sg);
+    put4(Gs, col + 3, g[0].w * sg, g[1].w * sg, g[2].w * sg, g[3].w * sg);
+    put4(As, col + 0, a[0].x, a[1].x, a[2].x, a[3].x);
+    put4(As, col + 1, a[0].y, a[1].y, a[2].y, a[3].y);
+    put4(As, col + 2, a[0].z, a[1].z, a[2].z, a[3].z);
+    put4(As, col + 3, a[0].w, a[1].w, a[2].w, a[3].w);
+  };
+
+  int buf = 0;
+  if (m_beg < m_end) {
+    load_idx(m_beg);
+    load_sub(m_beg);
+    store_sub(0, m_beg);
+  }
+  __syncthreads();
+  for (int m0 = m_beg; m0 < m_end; m0 += SUB) {
+    const bool more = m0 + SUB < m_end;
+    if (more) load_sub(m0 + SUB);
+    const unsigned char* Gs = lds + buf * HBUF;
+    const unsigned char* As = Gs + HOP;
+    gfv_f16x8 gh[4], gl[4], ah[4], al[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {   // tile ct = 4 wn + i (4 wk + i): ct & 3 = i
+      gh[i] = *reinterpret_cast<const gfv_f16x8*>(Gs + ((4 * wn + i) * 2 + 0) * HBLK + (lane ^ i) * 16);
+      gl[i] = *reinterpret_cast<const gfv_f16x8*>(Gs + ((4 * wn + i) * 2 + 1) * HBLK + (lane ^ i) * 16);
+      ah[i] = *reinterpret_cast<const gfv_f16x8*>(As + ((4 * wk + i) * 2 + 0) * HBLK + (lane ^ i) * 16);
+      al[i] = *reinterpret_cast<const gfv_f16x8*>(As + ((4 * wk + i) * 2 + 1) * HBLK + (lane ^ i) * 16);
+    }
+#pragma unroll
+    for (int term = 0; term < 3; ++term)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (FULL || (64 * wn + 16 * i < npad && 64 * wk + 16 * j < kpad))
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(term == 0 ? gl[i] : gh[i], term == 1 ? al[j] : ah[j],
+                                                               acc[i][j], 0, 0, 0);
+    if (more) store_sub(buf ^ 1, m0 + SUB);
+    __syncthreads();
+    buf ^= 1;
+  }
+
+  const float inv = 1.0f / sg;
+  float* ws = A.ws + (size_t)slab * A.ws_stride + T.out_off;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int n = 64 * wn + 16 * i + 4 * q + reg;
+        const int k = 64 * wk + 16 * j + nl;
+        if (FULL || (n < T.n_out && k < T.width)) ws[(size_t)n * T.ld_out + k] = acc[i][j][reg] * inv;
+      }
+
+  if (T.db_off >= 0) {
+    float* red = reinterpret_cast<float*>(lds);  // safe: the loop ended with a barrier
+    *reinterpret_cast<float4*>(&red[r4 * LDT + col]) = dbacc;
+    __syncthreads();
+    if (tid < T.n_out) {
+      float s = 0.f;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) s += red[r * LDT + tid];
+      A.ws[(size_t)slab * A.ws_stride + T.db_off + tid] = s;
+    }
+  }
+}
+
 __global__ __launch_bounds__(256, 2) void dw_multi_kernel(const DwLaunch A) {
   __shared__ __attribute__((aligned(16))) float lds[4 * SUB * LDT];  // 2 buffers x (G, A)
   const gfv_dw_tile_t& T = A.tile[blockIdx.y];
   const bool full = (T.n_out == 128) && (T.width == 128) && ((T.ldg & 3) == 0) && ((T.ld & 3) == 0);
   if (full) dw_body<true>(A, T, lds);
   else dw_body<false>(A, T, lds);
+}
+
+__global__ __launch_bounds__(256, 2) void dw_multi_h_kernel(const DwLaunch A) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * HBUF];
+  static_assert(2 * HBUF >= 8 * LDT * 4, "the bias-gradient fold reuses the staging buffers");
+  const gfv_dw_tile_t& T = A.tile[blockIdx.y];
+  const bool full = (T.n_out == 128) && (T.width == 128) && ((T.ldg & 3) == 0) && ((T.ld & 3) == 0);
+  if (full) dw_body_h<true>(A, T, lds);
+  else dw_body_h<false>(A, T, lds);
 }
 
 }  // namespace
@@ -247,7 +443,9 @@ extern "C" int gfv_dw_multi(const gfv_dw_tile_t* tiles, int32_t ntiles, int32_t 
   // slots of the block that no tile writes (alignment padding) keep whatever the workspace held: callers hand in a
   // zero-initialised workspace, so padding entries of the gradient block stay finite and are never read.
   void* tok = gfv_prof_begin(GFV_K_DW, fl, by + 8.0 * (double)slabs * block_floats, (hipStream_t)stream);
-  hipLaunchKernelGGL(dw_multi_kernel, dim3(slabs, ntiles), dim3(256), 0, (hipStream_t)stream, a);
+  static const bool f16 = [] { const char* e = getenv("GFV_F16SPLIT"); return e ? atoi(e) != 0 : true; }();
+  if (f16) hipLaunchKernelGGL(dw_multi_h_kernel, dim3(slabs, ntiles), dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(dw_multi_kernel, dim3(slabs, ntiles), dim3(256), 0, (hipStream_t)stream, a);
   gfv_prof_end(tok, (hipStream_t)stream);
   GFV_CHECK_LAUNCH();
   if (!grad_block) return GFV_OK;  // the caller reduces the slab workspace itself (gfv_reduce_partials_2d)

@@ -7,11 +7,18 @@ namespace {
 
 __global__ __launch_bounds__(256) void wabsmax_kernel(const gfv_wimg_desc_t* __restrict__ descs, float* __restrict__ wmax) {
   const gfv_wimg_desc_t d = descs[blockIdx.y];
-  const int total = d.N * d.K;
   float m = 0.f;
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
-    const int n = i / d.K, k = i - n * d.K;
-    m = fmaxf(m, fabsf(d.W[(size_t)n * d.ldw + k]));
+  if (d.ldw == d.K && ((d.N * d.K) & 3) == 0 && (reinterpret_cast<size_t>(d.W) & 15) == 0) {
+    // a whole parameter matrix: contiguous, float4
+    const int total4 = (d.N * d.K) >> 2;
+    const float4* w4 = reinterpret_cast<const float4*>(d.W);
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total4; i += gridDim.x * 256) {
+      const float4 v = w4[i];
+      m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+  } else {
+    for (int n = blockIdx.x * 4 + (threadIdx.x >> 6); n < d.N; n += gridDim.x * 4)
+      for (int k = threadIdx.x & 63; k < d.K; k += 64) m = fmaxf(m, fabsf(d.W[(size_t)n * d.ldw + k]));
   }
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
@@ -53,7 +60,7 @@ extern "C" int gfv_weight_absmax(const gfv_wimg_desc_t* descs_dev, int32_t n_des
   if (!descs_dev || !wmax || n_desc < 0) return GFV_ERR_ARG;
   if (hipMemsetAsync(wmax, 0, sizeof(float), (hipStream_t)stream) != hipSuccess) return GFV_ERR_LAUNCH;
   if (n_desc == 0) return GFV_OK;
-  hipLaunchKernelGGL(wabsmax_kernel, dim3(16, n_desc), dim3(256), 0, (hipStream_t)stream, descs_dev, wmax);
+  hipLaunchKernelGGL(wabsmax_kernel, dim3(4, n_desc), dim3(256), 0, (hipStream_t)stream, descs_dev, wmax);
   GFV_CHECK_LAUNCH();
   return GFV_OK;
 }

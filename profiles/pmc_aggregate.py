@@ -12,8 +12,9 @@ import os
 import sys
 
 out_dir = sys.argv[1]
-KEYS = {k: k for k in ("tchain_kernel<1, 0, false>", "tchain_kernel<1, 1, false>", "tchain_kernel<1, 2, false>",
-                       "tchain_kernel<1, 0, true>", "rowtile_chain_kernel", "dw_multi_kernel", "seg_gather_sum_vec")}
+_CH = [f"tchain_kernel<1, {lnm}, {rag}, {h}>" for lnm, rag in ((0, "false"), (1, "false"), (2, "false"), (0, "true"))
+       for h in ("true", "false")]   # last template argument: split-fp16 products (true) / fp32 MFMA (false)
+KEYS = {k: k for k in (*_CH, "rowtile_chain_kernel", "dw_multi_h_kernel", "dw_multi_kernel", "seg_gather_sum_vec")}
 acc = {c: collections.defaultdict(lambda: [0.0, 0]) for c in ("FETCH_SIZE", "WRITE_SIZE")}
 for c in acc:
     for f in glob.glob(os.path.join(out_dir, f"pmc_{c}", "**", "*counter_collection.csv"), recursive=True):
