@@ -8,10 +8,11 @@ typedef _Float16 gfv_f16x2 __attribute__((ext_vector_type(2)));
 typedef float gfv_float2 __attribute__((ext_vector_type(2)));
 typedef unsigned gfv_uint4 __attribute__((ext_vector_type(4)));
 
-// exact power of two s with s * m in [2^13, 2^14) (fp16 overflows at 2^16); m = 0 / subnormal / tiny: capped at 2^60
+// exact power of two s with s * m in [2^13, 2^14) (fp16 overflows at 2^16); m = 0 / subnormal: capped at 2^126.
+// Undo it with a multiplication by 1 / s on its own (the product of two such scales may leave the fp32 range).
 __device__ __forceinline__ float gfv_pow2_scale(float m) {
   const int e = (int)((__float_as_uint(m) >> 23) & 255u);  // biased exponent of m >= 0
-  const int se = min(max(267 - e, 1), 187);                // biased exponent of 2^(13 - (e - 127))
+  const int se = min(max(267 - e, 1), 253);                // biased exponent of 2^(13 - (e - 127))
   return __uint_as_float((unsigned)se << 23);
 }
 

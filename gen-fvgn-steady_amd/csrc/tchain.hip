@@ -502,8 +502,11 @@ __global__ __launch_bounds__(256, 2) void tchain_kernel(const gfv_rowtile_args_t
           if (lnb_in) ln_park(dgam, dbet, red, wave, li, g);
           if (H) {
             // every segment gets its own row scale; the accumulator follows (exact: powers of two)
-            const float sn = row_scale(act[0]);
+            float sn = row_scale(act[0]);
             if (chunk > 0) {
+              // a segment 2^40 below what the accumulator already holds cannot be resolved next to it anyway: its
+              // scale is capped so that the ratio stays finite
+              sn = fminf(sn, sx * 1.099511627776e12f);
               const float ratio = sn / sx;
 #pragma unroll
               for (int nt = 0; nt < 8; ++nt) acc[0][nt] *= ratio;
@@ -554,7 +557,7 @@ __global__ __launch_bounds__(256, 2) void tchain_kernel(const gfv_rowtile_args_t
         cur = nxt;
       }
 
-      const float inv = H ? 1.0f / (sx * ws) : 1.0f;   // H: undo the operand scales (exact)
+      const float invx = H ? 1.0f / sx : 1.0f, invw = H ? 1.0f / ws : 1.0f;   // H: undo the operand scales (exact)
       if (!last) {
         // ---- intermediate epilogue: accumulators -> next layer's activations, in registers ----
 #pragma unroll
@@ -567,7 +570,7 @@ __global__ __launch_bounds__(256, 2) void tchain_kernel(const gfv_rowtile_args_t
             float v[4] = {acc[tt][nt][0], acc[tt][nt][1], acc[tt][nt][2], acc[tt][nt][3]};
             if (H) {
 #pragma unroll
-              for (int r = 0; r < 4; ++r) v[r] *= inv;
+              for (int r = 0; r < 4; ++r) v[r] = (v[r] * invx) * invw;
             }
             if (L.op == GFV_OP_MUL_DGELU) {
               const float4 z = ld4(L.aux + mrow + 16 * nt);
@@ -628,7 +631,7 @@ __global__ __launch_bounds__(256, 2) void tchain_kernel(const gfv_rowtile_args_t
 #pragma unroll
           for (int nt = 0; nt < 8; ++nt) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[nt][r] = H ? acc[tt][nt][r] * inv : acc[tt][nt][r];
+            for (int r = 0; r < 4; ++r) v[nt][r] = H ? (acc[tt][nt][r] * invx) * invw : acc[tt][nt][r];
             if (nt < ntv) {
               const float4 b = ld4(par + 128 * layer + 128 * pass + 16 * nt + 4 * g);
               v[nt][0] += b.x; v[nt][1] += b.y; v[nt][2] += b.z; v[nt][3] += b.w;

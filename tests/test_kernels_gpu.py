@@ -354,6 +354,39 @@ def test_rowtile_transolver_linears(dev):
     assert rel(dWp, Wp6.grad) < TOL and rel(dbp, bp6.grad) < TOL
 
 
+def test_rowtile_and_dw_extreme_dynamic_range(dev, chain_mode):
+    """Rows spanning 40 orders of magnitude, all-zero rows, and segments of very different scale in one concat: the
+    per-row (chain) and per-slab (dW) power-of-two scalings of the split-fp16 form must neither overflow nor lose the
+    small rows; each row is judged against its own scale, with the error budget of an fp32 dot product."""
+    from gfv import lib as L, ops
+    g = torch.Generator().manual_seed(99)
+    M = 1100
+    d = lambda t: t.to(dev).contiguous()
+    rs = 10.0 ** torch.randint(-20, 21, (M, 1), generator=g).float()
+    rs[::7] = 0.0
+    xa = torch.randn(M, 128, generator=g) * rs
+    xb = torch.randn(M, 128, generator=g) * rs * 10.0 ** torch.randint(-6, 7, (M, 1), generator=g).float()
+    W = torch.randn(128, 256, generator=g) * 0.1
+    b = torch.zeros(128)
+    out = torch.empty(M, 128, device=dev)
+    ops.rowtile_chain(M, [ops.Seg(d(xa)), ops.Seg(d(xb))], [ops.LayerSpec(d(W), d(b))], [out])
+    X = torch.cat((xa, xb), 1).double()
+    ref = X @ W.double().T
+    mag = X.abs() @ W.double().abs().T          # sum |x w| per output
+    err = (out.double().cpu() - ref).abs()
+    assert torch.isfinite(out).all()
+    assert float((err / (mag + 1e-300)).max()) < 2e-6, float((err / (mag + 1e-300)).max())
+    # weight gradient: slabs whose gradient rows are tiny next to slabs with large ones
+    G = torch.randn(M, 128, generator=g) * 10.0 ** (torch.arange(M).float()[:, None] // 200 * 4 - 12)
+    A = torch.randn(M, 128, generator=g)
+    dW, db = ops.linear_dw(d(G), 128, [ops.Seg(d(A))], M)
+    refW = G.double().T @ A.double()
+    magW = G.double().abs().T @ A.double().abs()
+    assert torch.isfinite(dW).all()
+    assert float(((dW.double().cpu() - refW).abs() / magW).max()) < 2e-6
+    assert rel(db, G.double().sum(0)) < TOL
+
+
 def test_lds_rowtile_fallback_kernel_still_passes():
     """`GFV_TCHAIN=0` routes every fused-MLP launch to the first implementation (rowtile.hip, 64-row tile in LDS), which
     stays in the library as the fallback.  The switch is read once per process, so the row-tile tests of this file are
