@@ -24,22 +24,29 @@ __global__ __launch_bounds__(1024) void graph_norm_stats_kernel(const float* __r
   const int b = blockIdx.x, tid = threadIdx.x;
   const int beg = gnode_ptr[b], end = gnode_ptr[b + 1];
   const float cnt = fmaxf((float)(end - beg), 1.f);
+  // one sweep per statistic for the three columns together (per column the same summation order as a sweep of its own)
   float mean[3];
-  for (int c = 0; c < 3; ++c) {
-    float s = 0.f;
-    for (int i = beg + tid; i < end; i += 1024) s += x[(size_t)i * ldx + c];
-    mean[c] = block_sum(s, red) / cnt;
-  }
-  for (int c = 0; c < 3; ++c) {
-    float s = 0.f;
+  {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
     for (int i = beg + tid; i < end; i += 1024) {
-      const float d = x[(size_t)i * ldx + c] - mean[c];
-      s += d * d;
+      const float* r = x + (size_t)i * ldx;
+      s0 += r[0]; s1 += r[1]; s2 += r[2];
     }
-    const float var = block_sum(s, red) / cnt;
-    if (tid == 0) {
+    mean[0] = block_sum(s0, red) / cnt;
+    mean[1] = block_sum(s1, red) / cnt;
+    mean[2] = block_sum(s2, red) / cnt;
+  }
+  float q0 = 0.f, q1 = 0.f, q2 = 0.f;
+  for (int i = beg + tid; i < end; i += 1024) {
+    const float* r = x + (size_t)i * ldx;
+    const float d0 = r[0] - mean[0], d1 = r[1] - mean[1], d2 = r[2] - mean[2];
+    q0 += d0 * d0; q1 += d1 * d1; q2 += d2 * d2;
+  }
+  const float var[3] = {block_sum(q0, red) / cnt, block_sum(q1, red) / cnt, block_sum(q2, red) / cnt};
+  if (tid == 0) {
+    for (int c = 0; c < 3; ++c) {
       stats[6 * b + c] = mean[c];
-      stats[6 * b + 3 + c] = sqrtf(var);
+      stats[6 * b + 3 + c] = sqrtf(var[c]);
     }
   }
 }
