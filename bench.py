@@ -222,6 +222,30 @@ def main():
     if world > 1:
         dist.barrier()
 
+    # ---- the same step with every GEMM product on the fp32 MFMA (the form without the fp16 split), for the record ----
+    fp32_form = None
+    if ts.engine.f16split:
+        ts_use_graph = ts.use_graph
+        ts.use_graph, ts.engine.f16split = False, False
+        lib.gfv_set_f16split(0)
+        for _ in range(3):
+            ts.step()
+        barrier()
+        t0 = time.perf_counter()
+        nf = max(5, min(20, args.steps))
+        for _ in range(nf):
+            ts.step()
+        barrier()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        lib.gfv_set_f16split(1)
+        ts.use_graph, ts.engine.f16split = ts_use_graph, True
+        fp32_form = {"value": round(world * args.meshes_per_gpu * nf / el, 3), "ms_per_step": round(1e3 * el / nf, 4),
+                     "steps": nf, "note": "eager launches, all products on v_mfma_f32_16x16x4_f32 (GFV_F16SPLIT=0)"}
+
     cpu = None
     if rank == 0 and world == 1 and args.cpu_budget > 0:
         # 16 threads is the fastest setting for this launch-bound eager workload on the GPU box's host
@@ -251,6 +275,7 @@ def main():
             "roofline": ({k: roof[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")} | {"kernel": roof["kernel"]})
             if roof else None,
             "roofline_kernels": roof_all,
+            "fp32_mfma_form": fp32_form,
             # reference algorithm vs what the launches execute (EdgeBlock first layer factored through
             # the nodes, gfv/engine.py): the fraction of the fp32 MFMA peak is quoted on the EXECUTED flops
             "algorithmic_step_tflops": round(algorithmic_step_flops(sz) / 1e12, 4),

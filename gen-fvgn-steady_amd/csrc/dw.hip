@@ -443,8 +443,7 @@ extern "C" int gfv_dw_multi(const gfv_dw_tile_t* tiles, int32_t ntiles, int32_t 
   // slots of the block that no tile writes (alignment padding) keep whatever the workspace held: callers hand in a
   // zero-initialised workspace, so padding entries of the gradient block stay finite and are never read.
   void* tok = gfv_prof_begin(GFV_K_DW, fl, by + 8.0 * (double)slabs * block_floats, (hipStream_t)stream);
-  static const bool f16 = [] { const char* e = getenv("GFV_F16SPLIT"); return e ? atoi(e) != 0 : true; }();
-  if (f16) hipLaunchKernelGGL(dw_multi_h_kernel, dim3(slabs, ntiles), dim3(256), 0, (hipStream_t)stream, a);
+  if (gfv_f16split_enabled()) hipLaunchKernelGGL(dw_multi_h_kernel, dim3(slabs, ntiles), dim3(256), 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL(dw_multi_kernel, dim3(slabs, ntiles), dim3(256), 0, (hipStream_t)stream, a);
   gfv_prof_end(tok, (hipStream_t)stream);
   GFV_CHECK_LAUNCH();

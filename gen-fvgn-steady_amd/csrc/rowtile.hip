@@ -469,15 +469,21 @@ static int tchain_mode() {
   return mode;
 }
 
-static int f16_mode() {
-  // GFV_F16SPLIT: 0 = fp32 MFMA even when the launch carries split-fp16 weight images
-  static int mode = -1;
-  if (mode < 0) {
+// GFV_F16SPLIT (or gfv_set_f16split): 0 = every GEMM product on the fp32 MFMA, even when a launch carries split-fp16
+// weight images; shared with dw.hip
+static int g_f16split = -1;
+extern "C" int gfv_f16split_enabled(void) {
+  if (g_f16split < 0) {
     const char* e = getenv("GFV_F16SPLIT");
-    mode = e ? atoi(e) : 1;
+    g_f16split = e ? (atoi(e) != 0) : 1;
   }
-  return mode;
+  return g_f16split;
 }
+extern "C" int gfv_set_f16split(int32_t on) {
+  g_f16split = on ? 1 : 0;
+  return GFV_OK;
+}
+static int f16_mode() { return gfv_f16split_enabled(); }
 
 static thread_local int g_last_path = -1;
 extern "C" int gfv_rowtile_last_path(void) { return g_last_path; }

@@ -77,6 +77,7 @@ class Engine:
         # fp32 products of the chain kernels as split-fp16 on the f16 MFMA pipe (include/gfv.h, gfv_weight_images)
         self.f16split = os.environ.get("GFV_F16SPLIT", "1") != "0"
         self._wi, self._wi_key, self._wmax, self._wi_abs = None, None, None, None
+        self._pkey_cache = None
         self._etmp = None
         self._side = None
         self._keep = []
@@ -123,10 +124,18 @@ class Engine:
     # split-fp16 weight images: one set for the forward launches (built from the parameters when the forward starts),
     # one for the backward (built from the transposed copies right after prepare_transposes)
     # ------------------------------------------------------------------------------------------------------------
+    def _pkey(self, P, fresh=False):
+        """Identity of a parameter set (the data pointers of its tensors); computed when a forward starts and reused
+        by the backward of the same step (same dict object)."""
+        hit = self._pkey_cache
+        if fresh or hit is None or hit[0] is not P:
+            self._pkey_cache = hit = (P, tuple(t.data_ptr() for t in P.values()))
+        return hit[1]
+
     def _wi_enter(self, phase, P):
         if not self.f16split:
             return None
-        key = tuple(t.data_ptr() for t in P.values())
+        key = self._pkey(P, fresh=(phase == "fwd"))
         if self._wi_key != key:
             dev = next(iter(P.values())).device
             self._wmax = torch.zeros((1,), dtype=torch.float32, device=dev)
@@ -174,7 +183,7 @@ class Engine:
     def prepare_transposes(self, P):
         """Transpose every weight the backward needs in ONE launch (descriptor table cached per parameter set)."""
         lib = L.load()
-        key = tuple(t.data_ptr() for t in P.values())
+        key = self._pkey(P)
         if self._wt_key != key:
             import ctypes as C
             rows = []

@@ -140,6 +140,10 @@ typedef struct {
 } gfv_wimg_desc_t;
 size_t gfv_weight_image_bytes(int32_t N, int32_t K);
 /* wmax[0] = max |W| over all described blocks (device scalar, overwritten) */
+/* the process-wide switch between the two product forms (initial value: environment GFV_F16SPLIT, default 1);
+ * 0 = fp32 MFMA everywhere (chain launches ignore their images, weight gradients take the fp32 kernel) */
+int gfv_f16split_enabled(void);
+int gfv_set_f16split(int32_t on);
 int gfv_weight_absmax(const gfv_wimg_desc_t* descs_dev, int32_t n_desc, float* wmax, void* stream);
 /* build every image; max_frags = max over descs of gfv_weight_image_bytes / 32 */
 int gfv_weight_images(const gfv_wimg_desc_t* descs_dev, int32_t n_desc, int64_t max_frags, const float* wmax,
