@@ -1,6 +1,7 @@
 """`node_based_WLSQ` with the reference's signature (FVMmodel/FVdiscretization/FVgrad.py:235-244), precomputed-moments
-branch, 2nd order: HIP kernels `gfv_wlsq_fwd` / `gfv_wlsq_bwd` (CSR-ordered stencil gather, per-node 5x5 LU with
-partial pivoting on the row-normalised moment matrix, transpose solve for the adjoint)."""
+branch, orders 1st .. 4th (M = 2 / 5 / 9 / 14 Taylor terms, FVorder.py:23-72): HIP kernels `gfv_wlsq_fwd_ex` /
+`gfv_wlsq_bwd_ex` (CSR-ordered stencil gather, per-node M x M LU with partial pivoting on the row-normalised moment matrix,
+transpose solve for the adjoint)."""
 import torch
 
 from gfv import functions as GF
@@ -17,10 +18,10 @@ class _WlsqFn(torch.autograd.Function):
         phi8 = torch.zeros((N, 8), dtype=torch.float32, device=phi.device)
         phi8[:, :C] = phi.detach()
         grad = torch.empty((N, 16), dtype=torch.float32, device=phi.device)
-        full = torch.empty((N, 8, 5), dtype=torch.float32, device=phi.device)
-        L.check(lib.gfv_wlsq_fwd_full(phi8.data_ptr(), plan.x_rowptr.data_ptr(), plan.x_out.data_ptr(), plan.x_B.data_ptr(),
-                                      plan.An.data_ptr(), plan.rn.data_ptr(), grad.data_ptr(), full.data_ptr(), N,
-                                      L.stream_ptr()), "wlsq_fwd_full")
+        full = torch.empty((N, 8, plan.M), dtype=torch.float32, device=phi.device)
+        L.check(lib.gfv_wlsq_fwd_ex(phi8.data_ptr(), plan.x_rowptr.data_ptr(), plan.x_out.data_ptr(), plan.x_B.data_ptr(),
+                                    plan.An.data_ptr(), plan.rn.data_ptr(), grad.data_ptr(), full.data_ptr(), N, plan.M,
+                                    L.stream_ptr()), "wlsq_fwd_ex")
         ctx.plan, ctx.C = plan, C
         return full[:, :C, :].clone()
 
@@ -29,13 +30,13 @@ class _WlsqFn(torch.autograd.Function):
         lib = L.load()
         plan, C = ctx.plan, ctx.C
         N = g.shape[0]
-        g8 = torch.zeros((N, 8, 5), dtype=torch.float32, device=g.device)
+        g8 = torch.zeros((N, 8, plan.M), dtype=torch.float32, device=g.device)
         g8[:, :C, :] = g
         gphi = torch.zeros((N, 8), dtype=torch.float32, device=g.device)
-        ws = torch.empty((N, 8, 5), dtype=torch.float32, device=g.device)
-        L.check(lib.gfv_wlsq_bwd_full(g8.data_ptr(), plan.An.data_ptr(), plan.rn.data_ptr(), plan.xo_rowptr.data_ptr(),
-                                      plan.xo_in.data_ptr(), plan.xo_B.data_ptr(), plan.sumB.data_ptr(), ws.data_ptr(),
-                                      gphi.data_ptr(), N, L.stream_ptr()), "wlsq_bwd_full")
+        ws = torch.empty((N, 8, plan.M), dtype=torch.float32, device=g.device)
+        L.check(lib.gfv_wlsq_bwd_ex(None, g8.data_ptr(), plan.An.data_ptr(), plan.rn.data_ptr(), plan.xo_rowptr.data_ptr(),
+                                    plan.xo_in.data_ptr(), plan.xo_B.data_ptr(), plan.sumB.data_ptr(), ws.data_ptr(),
+                                    gphi.data_ptr(), N, plan.M, L.stream_ptr()), "wlsq_bwd_ex")
         return None, gphi[:, :C]
 
 
@@ -43,9 +44,12 @@ def node_based_WLSQ(phi_node=None, edge_index=None, extra_edge_index=None, mesh_
                     precompute_Moments: list = None, periodic_idx=None, rt_cond=False):
     if (order is None) or (order not in ["1st", "2nd", "3rd", "4th"]):
         raise ValueError("order must be specified in [\"1st\", \"2nd\", \"3rd\", \"4th\"]")   # FVgrad.py:261-262
-    if order != "2nd" or precompute_Moments is None or rt_cond:
-        raise NotImplementedError("only the precomputed-moments 2nd-order branch used by Intergrator.forward "
-                                  "(FVscheme.py:648-655) is built; other orders are SURVEY.md row f4")
+    if precompute_Moments is None or rt_cond:
+        raise NotImplementedError("only the precomputed-moments branch used by Intergrator.forward (FVscheme.py:648-655) "
+                                  "is built")
+    terms = {"1st": 2, "2nd": 5, "3rd": 9, "4th": 14}[order]
+    if precompute_Moments[0].shape[-1] != terms:
+        raise ValueError(f"moment matrices are {precompute_Moments[0].shape[-1]} wide, order {order} needs {terms}")
     if phi_node.shape[1] > 7:
         raise NotImplementedError("at most 7 channels (FVscheme.py:643-646)")
     A, B1, Bx = precompute_Moments

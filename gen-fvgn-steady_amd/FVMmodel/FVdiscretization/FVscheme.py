@@ -31,14 +31,13 @@ class Intergrator(nn.Module):
 
     def forward(self, uvp_new_node=None, uv_hat_node=None, uv_old_node=None, graph_node=None, graph_node_x=None,
                 graph_edge=None, graph_cell=None, graph_Index=None, params=None):
-        if getattr(params, "order", "2nd") != "2nd":
-            raise NotImplementedError("WLSQ order != 2nd: SURVEY.md row f4 (next)")
         plan = get_plan((graph_node, graph_node_x, graph_edge, graph_cell, graph_Index))
         n = uvp_new_node.shape[0]
         phi8 = torch.cat((uvp_new_node[:, 0:3], uv_hat_node[:, 0:2], uv_old_node[:, 0:2],
                           torch.zeros((n, 1), dtype=uvp_new_node.dtype, device=uvp_new_node.device)), dim=-1)
         eng = GF.Engine(ncn_smooth=getattr(params, "ncn_smooth", True),
-                        conserved_form=bool(getattr(params, "conserved_form", True)))   # FVscheme.py:671-715
+                        conserved_form=bool(getattr(params, "conserved_form", True)),   # FVscheme.py:671-715
+                        order=getattr(params, "order", "2nd"))                          # FVscheme.py:653
         losses, uvp_node, uvp_cell = _IntegratorPhiFn.apply(eng, plan, phi8)
         # the reference returns the smoothed node field BEFORE the Dirichlet overwrite / re-dimensionalisation of
         # importer.py:223-231; the fused kernel applies both, so undo the scaling here for the stand-alone operator

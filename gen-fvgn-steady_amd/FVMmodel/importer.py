@@ -60,12 +60,11 @@ class NNmodel(nn.Module):
     def engine(self):
         if self._engine is None:
             p = self.params
-            if getattr(p, "order", "2nd") != "2nd":
-                raise NotImplementedError("WLSQ order != 2nd: SURVEY.md row f4 (next)")
             self._engine = GF.Engine(message_passing_num=p.message_passing_num, integrator=p.integrator,
                                      ncn_smooth=p.ncn_smooth,
                                      net="TransFVGN_v1" if p.net == "TransFVGN_v1" else "TransFVGN_v2",
-                                     conserved_form=bool(getattr(p, "conserved_form", True)))
+                                     conserved_form=bool(getattr(p, "conserved_form", True)),
+                                     order=getattr(p, "order", "2nd"))
         return self._engine
 
     def param_names_tensors(self):

@@ -52,29 +52,32 @@ __global__ __launch_bounds__(256) void phi_bwd_kernel(const float* __restrict__ 
   gdec[3 * i + 2] = gp * (1.f - t2 * t2);
 }
 
-// ---- 5x5 LU with partial pivoting (LAPACK getf2 order), solve and transpose-solve ---------------------------------
-struct LU5 {
-  float a[5][5];
-  int piv[5];
+// ---- M x M LU with partial pivoting (LAPACK getf2 order), solve and transpose-solve; M = Taylor terms of the WLSQ
+// reconstruction order: 2 (1st), 5 (2nd, the default), 9 (3rd), 14 (4th) (FVorder.py:23-72) ------------------------------
+template <int M>
+struct LU {
+  float a[M][M];
+  int piv[M];
 };
 
-__device__ __forceinline__ void lu5_factor(LU5& m) {
+template <int M>
+__device__ __forceinline__ void lu_factor(LU<M>& m) {
 #pragma unroll
-  for (int k = 0; k < 5; ++k) {
+  for (int k = 0; k < M; ++k) {
     int p = k;
     float mx = fabsf(m.a[k][k]);
 #pragma unroll
-    for (int r = k + 1; r < 5; ++r) {
+    for (int r = k + 1; r < M; ++r) {
       const float v = fabsf(m.a[r][k]);
       if (v > mx) { mx = v; p = r; }
     }
     m.piv[k] = p;
     // row swap with static register indices (a[p][c] with a run-time p would put the matrix in scratch memory)
 #pragma unroll
-    for (int r = k + 1; r < 5; ++r) {
+    for (int r = k + 1; r < M; ++r) {
       const bool sw = (p == r);
 #pragma unroll
-      for (int c = 0; c < 5; ++c) {
+      for (int c = 0; c < M; ++c) {
         const float tk = m.a[k][c], tr = m.a[r][c];
         m.a[k][c] = sw ? tr : tk;
         m.a[r][c] = sw ? tk : tr;
@@ -82,20 +85,21 @@ __device__ __forceinline__ void lu5_factor(LU5& m) {
     }
     const float inv = 1.0f / m.a[k][k];
 #pragma unroll
-    for (int r = k + 1; r < 5; ++r) {
+    for (int r = k + 1; r < M; ++r) {
       m.a[r][k] *= inv;
 #pragma unroll
-      for (int c = k + 1; c < 5; ++c) m.a[r][c] -= m.a[r][k] * m.a[k][c];
+      for (int c = k + 1; c < M; ++c) m.a[r][c] -= m.a[r][k] * m.a[k][c];
     }
   }
 }
 
-__device__ __forceinline__ void lu5_solve(const LU5& m, float (&b)[5]) {
+template <int M>
+__device__ __forceinline__ void lu_solve(const LU<M>& m, float (&b)[M]) {
 #pragma unroll
-  for (int k = 0; k < 5; ++k) {
+  for (int k = 0; k < M; ++k) {
     const int p = m.piv[k];
 #pragma unroll
-    for (int r = k + 1; r < 5; ++r) {
+    for (int r = k + 1; r < M; ++r) {
       const bool sw = (p == r);
       const float tk = b[k], tr = b[r];
       b[k] = sw ? tr : tk;
@@ -103,11 +107,11 @@ __device__ __forceinline__ void lu5_solve(const LU5& m, float (&b)[5]) {
     }
   }
 #pragma unroll
-  for (int k = 0; k < 5; ++k)
+  for (int k = 0; k < M; ++k)
 #pragma unroll
-    for (int r = k + 1; r < 5; ++r) b[r] -= m.a[r][k] * b[k];
+    for (int r = k + 1; r < M; ++r) b[r] -= m.a[r][k] * b[k];
 #pragma unroll
-  for (int k = 4; k >= 0; --k) {
+  for (int k = M - 1; k >= 0; --k) {
     b[k] /= m.a[k][k];
 #pragma unroll
     for (int r = 0; r < k; ++r) b[r] -= m.a[r][k] * b[k];
@@ -115,22 +119,23 @@ __device__ __forceinline__ void lu5_solve(const LU5& m, float (&b)[5]) {
 }
 
 // solve A^T x = b with A = P^T L U
-__device__ __forceinline__ void lu5_solve_t(const LU5& m, float (&b)[5]) {
+template <int M>
+__device__ __forceinline__ void lu_solve_t(const LU<M>& m, float (&b)[M]) {
 #pragma unroll
-  for (int k = 0; k < 5; ++k) {  // U^T w = b
+  for (int k = 0; k < M; ++k) {  // U^T w = b
 #pragma unroll
     for (int r = 0; r < k; ++r) b[k] -= m.a[r][k] * b[r];
     b[k] /= m.a[k][k];
   }
 #pragma unroll
-  for (int k = 4; k >= 0; --k)  // L^T mu = w (unit diagonal)
+  for (int k = M - 1; k >= 0; --k)  // L^T mu = w (unit diagonal)
 #pragma unroll
-    for (int r = k + 1; r < 5; ++r) b[k] -= m.a[r][k] * b[r];
+    for (int r = k + 1; r < M; ++r) b[k] -= m.a[r][k] * b[r];
 #pragma unroll
-  for (int k = 4; k >= 0; --k) {  // x = P^T mu
+  for (int k = M - 1; k >= 0; --k) {  // x = P^T mu
     const int p = m.piv[k];
 #pragma unroll
-    for (int r = k + 1; r < 5; ++r) {
+    for (int r = k + 1; r < M; ++r) {
       const bool sw = (p == r);
       const float tk = b[k], tr = b[r];
       b[k] = sw ? tr : tk;
@@ -139,43 +144,47 @@ __device__ __forceinline__ void lu5_solve_t(const LU5& m, float (&b)[5]) {
   }
 }
 
-__device__ __forceinline__ void load_An(const float* An, int i, LU5& m) {
-  const float* p = An + (size_t)i * 25;
+template <int M>
+__device__ __forceinline__ void load_An(const float* An, int i, LU<M>& m) {
+  const float* p = An + (size_t)i * (M * M);
 #pragma unroll
-  for (int r = 0; r < 5; ++r)
+  for (int r = 0; r < M; ++r)
 #pragma unroll
-    for (int c = 0; c < 5; ++c) m.a[r][c] = p[5 * r + c];
+    for (int c = 0; c < M; ++c) m.a[r][c] = p[M * r + c];
 }
 
 // WLSQ forward (FVgrad.py:295-359): lane (node i, channel c), 8 lanes per node
+template <int M>
 __global__ __launch_bounds__(256) void wlsq_fwd_kernel(const float* __restrict__ phi, const int* __restrict__ rowptr,
                                                        const int* __restrict__ outn, const float* __restrict__ Bp,
                                                        const float* __restrict__ An, const float* __restrict__ rn,
-                                                       float* __restrict__ grad, float* __restrict__ full5, int N) {
+                                                       float* __restrict__ grad, float* __restrict__ full, int N) {
   const int t = blockIdx.x * 256 + threadIdx.x;
   const int i = t >> 3, c = t & 7;
   if (i >= N) return;
-  float rhs[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+  float rhs[M];
+#pragma unroll
+  for (int j = 0; j < M; ++j) rhs[j] = 0.f;
   if (c < 7) {
     const float pi = phi[(size_t)i * 8 + c];
     const int beg = rowptr[i], end = rowptr[i + 1];
     for (int k = beg; k < end; ++k) {
       const float d = phi[(size_t)outn[k] * 8 + c] - pi;
-      const float* b = Bp + (size_t)k * 5;
+      const float* b = Bp + (size_t)k * M;
 #pragma unroll
-      for (int j = 0; j < 5; ++j) rhs[j] += b[j] * d;
+      for (int j = 0; j < M; ++j) rhs[j] += b[j] * d;
     }
-    LU5 m;
+    LU<M> m;
     load_An(An, i, m);
 #pragma unroll
-    for (int j = 0; j < 5; ++j) rhs[j] = rhs[j] / rn[(size_t)i * 5 + j];
-    lu5_factor(m);
-    lu5_solve(m, rhs);
+    for (int j = 0; j < M; ++j) rhs[j] = rhs[j] / rn[(size_t)i * M + j];
+    lu_factor(m);
+    lu_solve(m, rhs);
     grad[(size_t)i * 16 + 2 * c] = rhs[0];
     grad[(size_t)i * 16 + 2 * c + 1] = rhs[1];
-    if (full5) {
+    if (full) {
 #pragma unroll
-      for (int j = 0; j < 5; ++j) full5[((size_t)i * 8 + c) * 5 + j] = rhs[j];
+      for (int j = 0; j < M; ++j) full[((size_t)i * 8 + c) * M + j] = rhs[j];
     }
   } else {
     grad[(size_t)i * 16 + 14] = 0.f;
@@ -183,34 +192,51 @@ __global__ __launch_bounds__(256) void wlsq_fwd_kernel(const float* __restrict__
   }
 }
 
-// WLSQ backward, stage 1: g_rhs[i,c,:] = (A_n^-T [g_grad[i,c,0:2],0,0,0]) / rn
-__global__ __launch_bounds__(256) void wlsq_bwd_solve_kernel(const float* __restrict__ ggrad, const float* __restrict__ g5,
+// WLSQ backward, stage 1: g_rhs[i,c,:] = (A_n^-T [g_grad[i,c,0:2],0,...]) / rn
+template <int M>
+__global__ __launch_bounds__(256) void wlsq_bwd_solve_kernel(const float* __restrict__ ggrad, const float* __restrict__ gfull,
                                                              const float* __restrict__ An, const float* __restrict__ rn,
                                                              float* __restrict__ grhs, int N, int nch) {
   const int t = blockIdx.x * 256 + threadIdx.x;
   const int i = t >> 3, c = t & 7;
   if (i >= N) return;
-  float b[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
-  if (c < nch) {  // fused path: channels 5,6 (uv_old) carry no gradient
-    if (g5) {
+  float b[M];
 #pragma unroll
-      for (int j = 0; j < 5; ++j) b[j] = g5[((size_t)i * 8 + c) * 5 + j];
+  for (int j = 0; j < M; ++j) b[j] = 0.f;
+  if (c < nch) {  // fused path: channels 5,6 (uv_old) carry no gradient
+    if (gfull) {
+#pragma unroll
+      for (int j = 0; j < M; ++j) b[j] = gfull[((size_t)i * 8 + c) * M + j];
     } else {
       b[0] = ggrad[(size_t)i * 16 + 2 * c];
       b[1] = ggrad[(size_t)i * 16 + 2 * c + 1];
     }
-    LU5 m;
+    LU<M> m;
     load_An(An, i, m);
-    lu5_factor(m);
-    lu5_solve_t(m, b);
+    lu_factor(m);
+    lu_solve_t(m, b);
 #pragma unroll
-    for (int j = 0; j < 5; ++j) b[j] = b[j] / rn[(size_t)i * 5 + j];
+    for (int j = 0; j < M; ++j) b[j] = b[j] / rn[(size_t)i * M + j];
   }
 #pragma unroll
-  for (int j = 0; j < 5; ++j) grhs[((size_t)i * 8 + c) * 5 + j] = b[j];
+  for (int j = 0; j < M; ++j) grhs[((size_t)i * 8 + c) * M + j] = b[j];
+}
+
+// dot product of two M-vectors, paired like the 5-term form this kernel started with
+template <int M>
+__device__ __forceinline__ float dotM(const float* b, const float* g) {
+  float s = 0.f;
+  if (M == 5) {
+    s = (b[0] * g[0] + b[1] * g[1]) + (b[2] * g[2] + b[3] * g[3]) + b[4] * g[4];
+  } else {
+#pragma unroll
+    for (int j = 0; j < M; ++j) s += b[j] * g[j];
+  }
+  return s;
 }
 
 // stage 2: g_phi[j,c] += sum_{d: out_d = j} B_d . g_rhs[in_d,c,:]  -  sumB[j] . g_rhs[j,c,:]
+template <int M>
 __global__ __launch_bounds__(256) void wlsq_bwd_gather_kernel(const float* __restrict__ grhs, const int* __restrict__ rowptr_o,
                                                               const int* __restrict__ inn, const float* __restrict__ Bo,
                                                               const float* __restrict__ sumB, float* __restrict__ gphi,
@@ -220,14 +246,8 @@ __global__ __launch_bounds__(256) void wlsq_bwd_gather_kernel(const float* __res
   if (j >= N || c >= nch) return;
   float s = 0.f;
   const int beg = rowptr_o[j], end = rowptr_o[j + 1];
-  for (int k = beg; k < end; ++k) {
-    const float* g = grhs + ((size_t)inn[k] * 8 + c) * 5;
-    const float* b = Bo + (size_t)k * 5;
-    s += (b[0] * g[0] + b[1] * g[1]) + (b[2] * g[2] + b[3] * g[3]) + b[4] * g[4];
-  }
-  const float* g = grhs + ((size_t)j * 8 + c) * 5;
-  const float* sb = sumB + (size_t)j * 5;
-  s -= (sb[0] * g[0] + sb[1] * g[1]) + (sb[2] * g[2] + sb[3] * g[3]) + sb[4] * g[4];
+  for (int k = beg; k < end; ++k) s += dotM<M>(Bo + (size_t)k * M, grhs + ((size_t)inn[k] * 8 + c) * M);
+  s -= dotM<M>(sumB + (size_t)j * M, grhs + ((size_t)j * 8 + c) * M);
   gphi[(size_t)j * 8 + c] += s;
 }
 
@@ -620,32 +640,53 @@ extern "C" int gfv_phi_bwd(const float* gphi, const float* dec, const int32_t* n
   return GFV_OK;
 }
 
+// terms = Taylor terms of the reconstruction order (2 / 5 / 9 / 14)
+#define WLSQ_DISPATCH(terms, CALL)        \
+  switch (terms) {                        \
+    case 2: { constexpr int MM = 2; CALL; break; }   \
+    case 5: { constexpr int MM = 5; CALL; break; }   \
+    case 9: { constexpr int MM = 9; CALL; break; }   \
+    case 14: { constexpr int MM = 14; CALL; break; } \
+    default: return GFV_ERR_ARG;          \
+  }
+
+extern "C" int gfv_wlsq_fwd_ex(const float* phi, const int32_t* rowptr, const int32_t* outn, const float* Bp,
+                               const float* An, const float* rn, float* grad, float* full, int32_t N, int32_t terms,
+                               void* stream) {
+  WLSQ_DISPATCH(terms, LAUNCH1D(wlsq_fwd_kernel<MM>, (long)N * 8, stream, phi, rowptr, outn, Bp, An, rn, grad, full, N));
+  return GFV_OK;
+}
+
+extern "C" int gfv_wlsq_bwd_ex(const float* ggrad, const float* gfull, const float* An, const float* rn,
+                               const int32_t* rowptr_o, const int32_t* inn, const float* Bo, const float* sumB,
+                               float* grhs_ws, float* gphi, int32_t N, int32_t terms, void* stream) {
+  if ((ggrad == nullptr) == (gfull == nullptr)) return GFV_ERR_ARG;
+  const int nch = gfull ? 7 : 5;
+  WLSQ_DISPATCH(terms, LAUNCH1D(wlsq_bwd_solve_kernel<MM>, (long)N * 8, stream, ggrad, gfull, An, rn, grhs_ws, N, nch));
+  WLSQ_DISPATCH(terms, LAUNCH1D(wlsq_bwd_gather_kernel<MM>, (long)N * 8, stream, grhs_ws, rowptr_o, inn, Bo, sumB, gphi, N, nch));
+  return GFV_OK;
+}
+
 extern "C" int gfv_wlsq_fwd(const float* phi, const int32_t* rowptr, const int32_t* outn, const float* Bp, const float* An,
                             const float* rn, float* grad, int32_t N, void* stream) {
-  LAUNCH1D(wlsq_fwd_kernel, (long)N * 8, stream, phi, rowptr, outn, Bp, An, rn, grad, (float*)nullptr, N);
-  return GFV_OK;
+  return gfv_wlsq_fwd_ex(phi, rowptr, outn, Bp, An, rn, grad, nullptr, N, 5, stream);
 }
 
 extern "C" int gfv_wlsq_fwd_full(const float* phi, const int32_t* rowptr, const int32_t* outn, const float* Bp,
                                  const float* An, const float* rn, float* grad, float* full5, int32_t N, void* stream) {
-  LAUNCH1D(wlsq_fwd_kernel, (long)N * 8, stream, phi, rowptr, outn, Bp, An, rn, grad, full5, N);
-  return GFV_OK;
+  return gfv_wlsq_fwd_ex(phi, rowptr, outn, Bp, An, rn, grad, full5, N, 5, stream);
 }
 
 extern "C" int gfv_wlsq_bwd_full(const float* g5, const float* An, const float* rn, const int32_t* rowptr_o,
                                  const int32_t* inn, const float* Bo, const float* sumB, float* grhs_ws, float* gphi,
                                  int32_t N, void* stream) {
-  LAUNCH1D(wlsq_bwd_solve_kernel, (long)N * 8, stream, (const float*)nullptr, g5, An, rn, grhs_ws, N, 7);
-  LAUNCH1D(wlsq_bwd_gather_kernel, (long)N * 8, stream, grhs_ws, rowptr_o, inn, Bo, sumB, gphi, N, 7);
-  return GFV_OK;
+  return gfv_wlsq_bwd_ex(nullptr, g5, An, rn, rowptr_o, inn, Bo, sumB, grhs_ws, gphi, N, 5, stream);
 }
 
 extern "C" int gfv_wlsq_bwd(const float* ggrad, const float* An, const float* rn, const int32_t* rowptr_o,
                             const int32_t* inn, const float* Bo, const float* sumB, float* grhs_ws, float* gphi, int32_t N,
                             void* stream) {
-  LAUNCH1D(wlsq_bwd_solve_kernel, (long)N * 8, stream, ggrad, (const float*)nullptr, An, rn, grhs_ws, N, 5);
-  LAUNCH1D(wlsq_bwd_gather_kernel, (long)N * 8, stream, grhs_ws, rowptr_o, inn, Bo, sumB, gphi, N, 5);
-  return GFV_OK;
+  return gfv_wlsq_bwd_ex(ggrad, nullptr, An, rn, rowptr_o, inn, Bo, sumB, grhs_ws, gphi, N, 5, stream);
 }
 
 extern "C" int gfv_face_fwd(const float* phi, const float* grad, const int32_t* es, const int32_t* er, const float* pos,

@@ -59,13 +59,17 @@ class GradStore:
 
 
 class Engine:
-    def __init__(self, message_passing_num=3, integrator="imex", ncn_smooth=True, net="TransFVGN_v2", conserved_form=True):
+    def __init__(self, message_passing_num=3, integrator="imex", ncn_smooth=True, net="TransFVGN_v2", conserved_form=True,
+                 order="2nd"):
         self._dw_ws = None
         self._wt, self._wt_key, self._wt_live = {}, None, False
         self.mp = message_passing_num
         self.mode = _MODE[integrator]
         self.smooth = 1 if ncn_smooth else 0
         self.nc = 0 if conserved_form else 1   # residuals of the non-conserved form (FVscheme.py:276-511), row f4
+        if order not in ("1st", "2nd", "3rd", "4th"):   # FVgrad.py:261-262
+            raise ValueError("order must be specified in [\"1st\", \"2nd\", \"3rd\", \"4th\"]")
+        self.order_terms = {"1st": 2, "2nd": 5, "3rd": 9, "4th": 14}[order]   # WLSQ Taylor terms (FVorder.py:23-72), row f4
         self.n_proc = 2 if net in ("TransFVGN_v2", "TransFVGN") else 1
         self.net = net
         # weight-gradient kernels run on a side stream, concurrently with the dX chain of the next layer block: both
@@ -606,8 +610,12 @@ class Engine:
         N, E, C, B = pl.N, pl.E, pl.C, pl.B
         dev = phi.device
         grad = _empty(dev, N, 16)
-        L.check(lib.gfv_wlsq_fwd(phi.data_ptr(), pl.x_rowptr.data_ptr(), pl.x_out.data_ptr(), pl.x_B.data_ptr(),
-                                 pl.An.data_ptr(), pl.rn.data_ptr(), grad.data_ptr(), N, st), "wlsq_fwd")
+        # pl.M: Taylor terms of the reconstruction order the mesh's moment matrices were built for (2 / 5 / 9 / 14)
+        if pl.M != self.order_terms:
+            raise ValueError(f"params.order needs {self.order_terms}-term WLSQ moments, the batch carries {pl.M}-term ones "
+                             "(Load_mesh.py:543-546 builds them for params.order)")
+        L.check(lib.gfv_wlsq_fwd_ex(phi.data_ptr(), pl.x_rowptr.data_ptr(), pl.x_out.data_ptr(), pl.x_B.data_ptr(),
+                                    pl.An.data_ptr(), pl.rn.data_ptr(), grad.data_ptr(), None, N, pl.M, st), "wlsq_fwd")
         Ff = _empty(dev, E, 16)
         L.check(lib.gfv_face_fwd(phi.data_ptr(), grad.data_ptr(), pl.es.data_ptr(), pl.er.data_ptr(), pl.pos.data_ptr(),
                                  pl.fpos.data_ptr(), pl.ftype.data_ptr(), pl.y.data_ptr(), Ff.data_ptr(), E, st), "face_fwd")
@@ -657,10 +665,10 @@ class Engine:
                                 pl.centroid.data_ptr(), pl.area.data_ptr(), gc.data_ptr(), gFf.data_ptr(), gphi.data_ptr(),
                                 ggrad.data_ptr(), N, E, C, self.nc, None if not self.nc else sv["gradc"].data_ptr(),
                                 None if not self.nc else sv["phic"].data_ptr(), st), "fvm_bwd")
-        grhs = _empty(dev, N, 8, 5)
-        L.check(lib.gfv_wlsq_bwd(ggrad.data_ptr(), pl.An.data_ptr(), pl.rn.data_ptr(), pl.xo_rowptr.data_ptr(),
-                                 pl.xo_in.data_ptr(), pl.xo_B.data_ptr(), pl.sumB.data_ptr(), grhs.data_ptr(),
-                                 gphi.data_ptr(), N, st), "wlsq_bwd")
+        grhs = _empty(dev, N, 8, pl.M)
+        L.check(lib.gfv_wlsq_bwd_ex(ggrad.data_ptr(), None, pl.An.data_ptr(), pl.rn.data_ptr(), pl.xo_rowptr.data_ptr(),
+                                    pl.xo_in.data_ptr(), pl.xo_B.data_ptr(), pl.sumB.data_ptr(), grhs.data_ptr(),
+                                    gphi.data_ptr(), N, pl.M, st), "wlsq_bwd")
         return gphi
 
     # ------------------------------------------------------------------------------------------------------------

@@ -359,16 +359,37 @@ def k_hop_pairs(face_node, n_nodes, k_hop):
     return _unique_cols(np.sort(e, axis=0))
 
 
+ORDER_TERMS = {"1st": 2, "2nd": 5, "3rd": 9, "4th": 14}   # Taylor terms of the reconstruction (FVorder.py:23-72)
+
+
+def taylor_displacement(d, order="2nd"):
+    """[S, ORDER_TERMS[order]]: the Taylor monomials of the position difference, in the reference's column order
+    (FVorder.py:23-72): (dx, dy | dx^2/2, dy^2/2, dx dy | dx^3/6, dy^3/6, dx^2 dy/2, dy^2 dx/2 | dx^4/24, dx^3 dy/6,
+    dx^2 dy^2/4, dx dy^3/6, dy^4/24)."""
+    if order not in ORDER_TERMS:
+        raise NotImplementedError(f"{order} Order not implemented")
+    x, y = d[:, 0:1], d[:, 1:2]
+    cols = [d]
+    if order in ("2nd", "3rd", "4th"):
+        cols += [0.5 * d ** 2, x * y]
+    if order in ("3rd", "4th"):
+        cols += [(1 / 6) * d ** 3, 0.5 * x ** 2 * y, 0.5 * y ** 2 * x]
+    if order == "4th":
+        cols += [(1 / 24) * x ** 4, (1 / 6) * x ** 3 * y, (1 / 4) * x ** 2 * y ** 2, (1 / 6) * x * y ** 3, (1 / 24) * y ** 4]
+    return np.concatenate(cols, axis=1)
+
+
 def second_order_displacement(d):
-    return np.concatenate((d, 0.5 * d ** 2, d[:, 0:1] * d[:, 1:2]), axis=1)  # [S,5]
+    return taylor_displacement(d, "2nd")  # [S,5]
 
 
-def wlsq_moments(pos, face_node_x, support_edge):
-    """A [N,5,5], one-way B [Ex,5,1], extra B [2,5,1] in float64 (cast to f32 by the caller, Load_mesh.py:264-269)."""
+def wlsq_moments(pos, face_node_x, support_edge, order="2nd"):
+    """A [N,M,M], one-way B [Ex,M,1], extra B [2,M,1] in float64, M = ORDER_TERMS[order] (cast to f32 by the caller,
+    Load_mesh.py:264-269)."""
     comp = np.concatenate((face_node_x, face_node_x[::-1], support_edge), axis=1)
     out_idx, in_idx = comp[0], comp[1]
     d = pos[out_idx] - pos[in_idx]
-    disp = second_order_displacement(d)
+    disp = taylor_displacement(d, order)
     w = 1.0 / np.linalg.norm(d, axis=1, keepdims=True)
     left = (disp * w)[:, :, None] * disp[:, None, :]
     A = _seg_sum(left, in_idx, int(in_idx.max()) + 1)
@@ -392,8 +413,9 @@ def velocity_profile(pos, mean_u, kind):
     return uv
 
 
-def finish_mesh(raw, U=None, device=None):
+def finish_mesh(raw, U=None, device=None, order="2nd"):
     """raw mesh -> full mesh dict with stencil, moments, PDE coefficients and Dirichlet targets (float64/int64).
+    order: WLSQ reconstruction order the moment matrices are built for (Load_mesh.py:543-546, params.order).
 
     device: run the two heavy steps (k-hop stencil, WLSQ moments) with torch ops on that device (gfv.device_prep,
     SURVEY.md row f2) instead of the host numpy code; same stencil, moments equal to ~1e-12 in float64."""
@@ -407,13 +429,15 @@ def finish_mesh(raw, U=None, device=None):
     if device is None:
         extra = k_hop_pairs(mesh["face|face_node"], n_nodes, int(bc["stencil|khops"]))
         face_node_x = np.concatenate((mesh["face_node_x_base"], extra), axis=1)  # duplicates kept (Load_mesh.py:485)
-        A, B1, Bx = wlsq_moments(pos, face_node_x, support_edge)
+        A, B1, Bx = wlsq_moments(pos, face_node_x, support_edge, order)
     else:
         import torch
         from . import device_prep
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
         extra = device_prep.k_hop_pairs(t(mesh["face|face_node"]), n_nodes, int(bc["stencil|khops"])).cpu().numpy()
         face_node_x = np.concatenate((mesh["face_node_x_base"], extra), axis=1)
+        if order != "2nd":
+            raise NotImplementedError("device-side moments are built for the 2nd-order reconstruction")
         A, B1, Bx = (x.cpu().numpy() for x in device_prep.wlsq_moments(t(pos), t(face_node_x), t(support_edge)))
     th = bc["theta_PDE"]
     Uin, rho, mu = float(bc["U"]), float(bc["rho"]), float(bc["mu"])

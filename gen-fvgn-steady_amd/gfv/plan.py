@@ -128,10 +128,13 @@ def wlsq_part(p, face_node_x, support_edge, A, B1, Bx, N):
     fx, sup = face_node_x, support_edge
     out_idx = torch.cat((fx[0], fx[1], sup[0]))
     in_idx = torch.cat((fx[1], fx[0], sup[1]))
-    B1 = B1.reshape(-1, 5)
+    M = int(A.shape[-1])          # Taylor terms of the reconstruction order: 2 / 5 / 9 / 14 (FVorder.py:23-72)
+    B1 = B1.reshape(-1, M)
     Brev = B1.clone()
     Brev[:, 0:2] *= -1
-    Bfull = torch.cat((B1, Brev, Bx.reshape(-1, 5)), 0).to(torch.float32)
+    if M >= 9:                    # 3rd-order terms are odd too (FVgrad.py:309-310)
+        Brev[:, 5:9] *= -1
+    Bfull = torch.cat((B1, Brev, Bx.reshape(-1, M)), 0).to(torch.float32)
     p.x_rowptr, o_in = _csr(in_idx, N)
     p.x_out = i32(out_idx[o_in])
     p.x_B = Bfull[o_in].contiguous()
@@ -142,16 +145,16 @@ def wlsq_part(p, face_node_x, support_edge, A, B1, Bx, N):
     # Integer arithmetic is associative and wraps modulo 2^64, so the row sums are exact whatever precedes them:
     # deterministic (index_add_ on the device uses float atomics - every gradient would differ in the last bit from run
     # to run) and independent of where the mesh sits in a batch (gfv.pool assembles plans mesh by mesh).
-    fx = torch.round(p.x_B.to(torch.float64) * float(2 ** 40)).to(torch.int64).t().contiguous()      # [5, S]
-    cs = torch.zeros((5, fx.shape[1] + 1), dtype=torch.int64, device=dev)
+    fx = torch.round(p.x_B.to(torch.float64) * float(2 ** 40)).to(torch.int64).t().contiguous()      # [M, S]
+    cs = torch.zeros((M, fx.shape[1] + 1), dtype=torch.int64, device=dev)
     cs[:, 1:] = torch.cumsum(fx, 1)
     rp = p.x_rowptr.to(torch.int64)
     p.sumB = ((cs[:, rp[1:]] - cs[:, rp[:-1]]).to(torch.float64) * float(2.0 ** -40)).t().to(torch.float32).contiguous()
     A = A.to(torch.float32)
     row_norms = torch.norm(A, p=2, dim=2, keepdim=True)          # FVgrad.py:335
-    p.rn = (row_norms + 1e-8).reshape(N, 5).contiguous()
-    p.An = (A / (row_norms + 1e-8)).reshape(N, 25).contiguous()  # FVgrad.py:336
-    p.S = int(in_idx.shape[0])
+    p.rn = (row_norms + 1e-8).reshape(N, M).contiguous()
+    p.An = (A / (row_norms + 1e-8)).reshape(N, M * M).contiguous()  # FVgrad.py:336
+    p.S, p.M = int(in_idx.shape[0]), M
     return p
 
 

@@ -121,6 +121,7 @@ class DevicePool:
             pos += len(v)
         p.N, p.E, p.C, p.B = int(off["n"][B]), int(off["e"][B]), int(off["c"][B]), B
         p.S, p.Sg, p.n_chunks, p.device = int(off["s"][B]), int(off["k"][B]), gcp[-1], dev
+        p.M = self.plans[idx[0]].M                         # WLSQ Taylor terms (all meshes of a pool share the order)
         p._keep = dblob                                    # the small arrays are views of the upload buffer
         graph_node = Data(x=out["x"], batch=p.batch, pos=p.pos, num_graphs=B, norm_uvp=True, norm_global=True)
         graph_node._gfv_pool_plan = p

@@ -279,6 +279,14 @@ int gfv_wlsq_fwd_full(const float* phi, const int32_t* rowptr, const int32_t* ou
                       const float* rn, float* grad, float* full5, int32_t N, void* stream);
 int gfv_wlsq_bwd_full(const float* g5, const float* An, const float* rn, const int32_t* rowptr_o, const int32_t* inn,
                       const float* Bo, const float* sumB, float* grhs_ws, float* gphi, int32_t N, void* stream);
+/* any reconstruction order (FVorder.py:23-72; row f4): terms = Taylor terms M = 2 (1st) / 5 (2nd) / 9 (3rd) / 14 (4th);
+ * Bp / Bo [S,M], An [N,M*M], rn / sumB [N,M], grhs_ws [N,8,M].  full / gfull (optional) [N,8,M]: all M derivative entries
+ * (7 channels) out of the forward / into the adjoint; the adjoint takes exactly one of ggrad [N,16] and gfull. */
+int gfv_wlsq_fwd_ex(const float* phi, const int32_t* rowptr, const int32_t* outn, const float* Bp, const float* An,
+                    const float* rn, float* grad, float* full, int32_t N, int32_t terms, void* stream);
+int gfv_wlsq_bwd_ex(const float* ggrad, const float* gfull, const float* An, const float* rn, const int32_t* rowptr_o,
+                    const int32_t* inn, const float* Bo, const float* sumB, float* grhs_ws, float* gphi, int32_t N,
+                    int32_t terms, void* stream);
 int gfv_face_fwd(const float* phi, const float* grad, const int32_t* es, const int32_t* er, const float* pos,
                  const float* fpos, const int32_t* ftype, const float* y, float* Ff, int32_t E, void* stream);
 int gfv_cell_fwd(const float* phi, const float* grad, const float* Ff, const float* pos, const int32_t* crow,

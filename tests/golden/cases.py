@@ -33,17 +33,17 @@ CASES = {
 WEIGHT_SEED = 0
 
 
-def make_meshes(name):
+def make_meshes(name, order="2nd"):
     meshes, fields = [], []
     for fac, kw, U, fseed in CASES[name]:
-        m = meshgen.finish_mesh(getattr(meshgen, fac)(**kw), U=U)
+        m = meshgen.finish_mesh(getattr(meshgen, fac)(**kw), U=U, order=order)
         meshes.append(m)
         fields.append(meshgen.random_fields(m, seed=fseed))
     return meshes, fields
 
 
-def make_graphs(name, device="cpu"):
-    meshes, fields = make_meshes(name)
+def make_graphs(name, device="cpu", order="2nd"):
+    meshes, fields = make_meshes(name, order)
     return build_batch(meshes, fields, device=device)
 
 

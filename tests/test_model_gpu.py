@@ -252,6 +252,107 @@ def test_non_conserved_form_matches_oracle_and_reference(name, golden_dir):
         assert err < 1e-4 * float(ograds[k].abs().max()) + 1e-6 * gscale, (k, err)
 
 
+def test_wlsq_first_order_matches_oracle_and_reference(golden_dir):
+    """1st-order WLSQ reconstruction (2 Taylor terms, 2x2 systems) on the HIP path vs the oracle -
+    forward, loss, every gradient - and vs the reference's own outputs (tests/golden/order_1st_cyl_cavity_b2.npz)."""
+    order = "1st"
+    graphs = cases.make_graphs("cyl_cavity_b2", order=order)
+    P = O.init_parameters(cases.WEIGHT_SEED)
+    Pg = {k: v.detach().requires_grad_(True) for k, v in P.items()}
+    oout = O.model_forward(Pg, O.new_normalizer_buffers(), tuple(g.clone() for g in graphs), hyper={"order": order})
+    oloss = O.training_loss(oout)
+    names = list(Pg)
+    ograds = dict(zip(names, torch.autograd.grad(oloss, [Pg[k] for k in names], allow_unused=True)))
+    model = _hip_model(P, order=order)
+    hg = tuple(g.clone().to("cuda") for g in graphs)
+    hg[0].norm_uvp, hg[0].norm_global = True, True
+    out = model(*hg)
+    fx = np.load(os.path.join(golden_dir, f"order_{order}_cyl_cavity_b2.npz"))
+    for i, key in enumerate(("loss_cont", "loss_mom_x", "loss_mom_y", "loss_press", "uvp_node", "uvp_cell")):
+        assert rel(out[i], oout[i]) < TOL, (key, rel(out[i], oout[i]))
+        assert rel(out[i], torch.from_numpy(fx[key])) < TOL, key
+    hp = O.DEFAULT_HYPER
+    loss = torch.mean(torch.log(hp["loss_press"] * out[3] + hp["loss_cont"] * out[0] + hp["loss_mom"] * out[1]
+                                + hp["loss_mom"] * out[2]))
+    assert abs(float(loss) - float(oloss)) < TOL * abs(float(oloss))
+    loss.backward()
+    gscale = max(float(g.abs().max()) for g in ograds.values() if g is not None)
+    for k, p in model.named_parameters():
+        if ograds[k] is None:
+            assert p.grad is None, k
+            continue
+        err = float((p.grad.cpu() - ograds[k]).abs().max())
+        assert err < 1e-4 * float(ograds[k].abs().max()) + 1e-6 * gscale, (k, err)
+    # a batch whose moments were built for another order is refused
+    model2 = _hip_model(P, order="2nd")
+    hg2 = tuple(g.clone().to("cuda") for g in graphs)
+    hg2[0].norm_uvp, hg2[0].norm_global = True, True
+    with pytest.raises(ValueError):
+        model2(*hg2)
+
+
+@pytest.mark.parametrize("order", ["3rd", "4th"])
+def test_wlsq_high_orders_operator(order):
+    """3rd / 4th-order WLSQ (9 / 14 Taylor terms).  On the reference's meshes these systems are
+    numerically singular in fp32 (row-normalised condition numbers: median 2e4 / 3e8, maximum > 1e12 on the small cases -
+    corner nodes have fewer neighbours than unknowns, and there is no column scaling), so the reference's own numbers at
+    these orders are not reproducible by any other LU: the oracle (the same torch.linalg.solve) is pinned bit for bit by
+    tests/test_oracle_golden.py, and the HIP kernels (per-node M x M LU, transpose solve) are tested where the problem
+    is well posed: coordinates in units of the mesh size, a 3-hop stencil, nodes with condition number < 1e4 - against a
+    float64 solve of the same fp32 moments, against the exact derivatives of a polynomial of that degree, and the
+    adjoint against autograd of the oracle, with error bars proportional to the condition number."""
+    from FVMmodel.FVdiscretization.FVgrad import node_based_WLSQ
+    from gfv import meshgen
+    deg, M = {"3rd": (3, 9), "4th": (4, 14)}[order]
+    m = cases.make_meshes("cyl_b3")[0][0]
+    fn = m["face|face_node"]
+    h = np.median(np.linalg.norm(m["node|pos"][fn[0]] - m["node|pos"][fn[1]], axis=1))
+    pos = m["node|pos"] / h
+    n = pos.shape[0]
+    fxx = meshgen.k_hop_pairs(fn, n, 3)
+    sup = m["support_edge"]
+    A, B1, Bx = meshgen.wlsq_moments(pos, fxx, sup, order)
+    A32, B132, Bx32 = (torch.from_numpy(x.astype(np.float32)) for x in (A, B1, Bx))
+    An = A32.double() / (torch.norm(A32, p=2, dim=2, keepdim=True).double() + 1e-8)
+    cond = torch.linalg.cond(An)
+    good = cond < 1e4
+    assert int(good.sum()) > n // 2
+    x, y = torch.from_numpy(pos[:, 0]), torch.from_numpy(pos[:, 1])
+    x, y = x - x.mean(), y - y.mean()
+    sx, sy = x / x.abs().max(), y / y.abs().max()       # polynomial in O(1) variables, derivatives by the chain rule
+    ax, ay = 1.0 / float(x.abs().max()), 1.0 / float(y.abs().max())
+    coef = [0.3, -1.2, 0.7, 0.9, -0.4, 1.1, 0.5, -0.8, 0.6, -0.3, 0.2, 0.45, -0.55, 0.35, 0.25]
+    terms = [(i, j) for d in range(deg + 1) for i in range(d, -1, -1) for j in [d - i]]
+    phi = sum(c * sx ** i * sy ** j for c, (i, j) in zip(coef, terms))
+    gx = sum(c * i * sx ** max(i - 1, 0) * sy ** j * ax for c, (i, j) in zip(coef, terms) if i > 0)
+    gy = sum(c * j * sx ** i * sy ** max(j - 1, 0) * ay for c, (i, j) in zip(coef, terms) if j > 0)
+    phi2 = torch.stack((phi, 0.5 * phi - 2.0 * sx), 1).float()            # two channels
+    d = lambda t: t.to("cuda")
+    fxt, supt = torch.from_numpy(fxx), torch.from_numpy(sup)
+    pd = d(phi2).requires_grad_(True)
+    out = node_based_WLSQ(phi_node=pd, edge_index=d(fxt), extra_edge_index=d(supt), mesh_pos=d(torch.from_numpy(pos).float()),
+                          order=order, precompute_Moments=[d(A32), d(B132), d(Bx32)])
+    assert out.shape == (n, 2, M)
+    # float64 solve of the same fp32 inputs
+    pref = phi2.double().requires_grad_(True)
+    ref = O.node_based_WLSQ(pref, fxt, supt, A32.double(), B132.double(), Bx32.double(), order)
+    scale = float(ref[good].abs().max())
+    err = (out.detach().cpu().double() - ref.detach()).abs().amax(dim=(1, 2))
+    bound = 2e-6 * cond * scale                                           # ~ 30 eps * cond
+    assert bool((err[good] < bound[good]).all()), float((err[good] / bound[good]).max())
+    # polynomial exactness of the gradient (first two entries), same error model
+    e_gx = (out[:, 0, 0].detach().cpu().double() - gx).abs()
+    e_gy = (out[:, 0, 1].detach().cpu().double() - gy).abs()
+    gs = float(torch.maximum(gx.abs(), gy.abs()).max())
+    assert bool(((e_gx + e_gy)[good] < (4e-6 * cond * gs)[good]).all())
+    # adjoint: d/dphi of a weighted sum of all M entries at the well-conditioned nodes
+    w = torch.randn(n, 2, M, generator=torch.Generator().manual_seed(3)).double() * good[:, None, None]
+    (out * d(w.float())).sum().backward()
+    (ref * w).sum().backward()
+    ga, gr = pd.grad.cpu().double(), pref.grad
+    assert float((ga - gr).abs().max()) < 2e-6 * float(cond[good].max()) * float(gr.abs().max())
+
+
 def test_fp32_mfma_form_still_matches_oracle():
     """`GFV_F16SPLIT=0` keeps every chain product on the fp32 MFMA (the first form of the kernels, and what a launch
     without weight images takes).  The switch is read once per process: the oracle-parity tests of this file are re-run

@@ -117,3 +117,17 @@ def test_oracle_non_conserved_form_matches_reference(golden_dir):
     for i, key in enumerate(("loss_cont", "loss_mom_x", "loss_mom_y", "loss_press", "uvp_node", "uvp_cell")):
         assert _rel(out[i].detach().numpy(), fx[key]) < TOL, key
     assert abs(float(O.training_loss(out)) - float(fx["loss"])) < TOL * abs(float(fx["loss"]))
+
+
+@pytest.mark.parametrize("order", ["1st", "3rd", "4th"])
+def test_oracle_wlsq_orders_match_reference(order, golden_dir):
+    """WLSQ reconstruction orders 1st / 3rd / 4th (2 / 9 / 14 Taylor terms, FVorder.py:23-72,
+    FVgrad.py:299-312).  Fixture = the reference itself run with params.order on meshes whose moment matrices are built
+    for that order (tests/golden/make_golden_orders.py); the oracle's forward agrees bit for bit there."""
+    fx = np.load(os.path.join(golden_dir, f"order_{order}_cyl_cavity_b2.npz"))
+    graphs = cases.make_graphs("cyl_cavity_b2", order=order)
+    assert graphs[1].A_node_to_node.shape[-1] == {"1st": 2, "3rd": 9, "4th": 14}[order]
+    out = O.model_forward(O.init_parameters(cases.WEIGHT_SEED), O.new_normalizer_buffers(), graphs, hyper={"order": order})
+    for i, key in enumerate(("loss_cont", "loss_mom_x", "loss_mom_y", "loss_press", "uvp_node", "uvp_cell")):
+        assert _rel(out[i].detach().numpy(), fx[key]) < TOL, key
+    assert abs(float(O.training_loss(out)) - float(fx["loss"])) < TOL * abs(float(fx["loss"]))
