@@ -39,22 +39,38 @@ def k_hop_pairs(face_node, n_nodes, k_hop):
     return torch.unique(e, dim=1)
 
 
-def wlsq_moments(pos, face_node_x, support_edge):
-    """A [N,5,5], one-way B [Ex,5,1], extra B [2,5,1] in float64 (= gfv.meshgen.wlsq_moments)."""
+def taylor_displacement(d, order="2nd"):
+    """= gfv.meshgen.taylor_displacement (FVorder.py:23-72) with torch ops."""
+    x, y = d[:, 0:1], d[:, 1:2]
+    cols = [d]
+    if order in ("2nd", "3rd", "4th"):
+        cols += [0.5 * d ** 2, x * y]
+    if order in ("3rd", "4th"):
+        cols += [(1 / 6) * d ** 3, 0.5 * x ** 2 * y, 0.5 * y ** 2 * x]
+    if order == "4th":
+        cols += [(1 / 24) * x ** 4, (1 / 6) * x ** 3 * y, (1 / 4) * x ** 2 * y ** 2, (1 / 6) * x * y ** 3, (1 / 24) * y ** 4]
+    if order not in ("1st", "2nd", "3rd", "4th"):
+        raise NotImplementedError(f"{order} Order not implemented")
+    return torch.cat(cols, dim=1)
+
+
+def wlsq_moments(pos, face_node_x, support_edge, order="2nd"):
+    """A [N,M,M], one-way B [Ex,M,1], extra B [2,M,1] in float64 (= gfv.meshgen.wlsq_moments)."""
     comp = torch.cat((face_node_x, face_node_x.flip(0), support_edge), dim=1)
     out_idx, in_idx = comp[0], comp[1]
     d = pos[out_idx] - pos[in_idx]
-    disp = torch.cat((d, 0.5 * d ** 2, d[:, 0:1] * d[:, 1:2]), dim=1)             # [S,5]
+    disp = taylor_displacement(d, order)                                          # [S,M]
+    M = disp.shape[1]
     w = 1.0 / torch.linalg.norm(d, dim=1, keepdim=True)
-    left = ((disp * w).unsqueeze(2) * disp.unsqueeze(1)).reshape(-1, 25)
+    left = ((disp * w).unsqueeze(2) * disp.unsqueeze(1)).reshape(-1, M * M)
     n = int(pos.shape[0])
-    order = torch.argsort(in_idx, stable=True)
+    perm = torch.argsort(in_idx, stable=True)
     counts = torch.bincount(in_idx, minlength=n)
     rp = torch.zeros(n + 1, dtype=torch.int64, device=pos.device)
     rp[1:] = torch.cumsum(counts, 0)
-    cs = torch.zeros((25, left.shape[0] + 1), dtype=torch.float64, device=pos.device)
-    cs[:, 1:] = torch.cumsum(left[order].t().contiguous(), 1)
-    A = (cs[:, rp[1:]] - cs[:, rp[:-1]]).t().reshape(n, 5, 5)
+    cs = torch.zeros((M * M, left.shape[0] + 1), dtype=torch.float64, device=pos.device)
+    cs[:, 1:] = torch.cumsum(left[perm].t().contiguous(), 1)
+    A = (cs[:, rp[1:]] - cs[:, rp[:-1]]).t().reshape(n, M, M)
     B = (w * disp).unsqueeze(2)
     ex = face_node_x.shape[1]
     return A, B[:ex], B[2 * ex:]

@@ -436,9 +436,7 @@ def finish_mesh(raw, U=None, device=None, order="2nd"):
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
         extra = device_prep.k_hop_pairs(t(mesh["face|face_node"]), n_nodes, int(bc["stencil|khops"])).cpu().numpy()
         face_node_x = np.concatenate((mesh["face_node_x_base"], extra), axis=1)
-        if order != "2nd":
-            raise NotImplementedError("device-side moments are built for the 2nd-order reconstruction")
-        A, B1, Bx = (x.cpu().numpy() for x in device_prep.wlsq_moments(t(pos), t(face_node_x), t(support_edge)))
+        A, B1, Bx = (x.cpu().numpy() for x in device_prep.wlsq_moments(t(pos), t(face_node_x), t(support_edge), order))
     th = bc["theta_PDE"]
     Uin, rho, mu = float(bc["U"]), float(bc["rho"]), float(bc["mu"])
     aoa = float(bc["aoa"])
