@@ -413,6 +413,21 @@ def velocity_profile(pos, mean_u, kind):
     return uv
 
 
+def pde_coefficients(bc):
+    """bc (sampled U, rho, mu, source, aoa, dt, L + theta_PDE switches) -> theta_PDE [1,9], dt_graph [1,1], uvp_dim [1,3]
+    (Load_mesh.py:134-211: set_theta_PDE / makedimless)."""
+    th = bc["theta_PDE"]
+    Uin, rho, mu = float(bc["U"]), float(bc["rho"]), float(bc["mu"])
+    aoa = float(bc["aoa"])
+    Re = rho * Uin * float(bc["L"]) / mu if mu != 0 else 0.0
+    diffusion = (mu / Uin) if th["convection"] == 0 else (mu / (rho * Uin))
+    theta = np.array([[th["unsteady"], th["continuity"], th["convection"], th["grad_p"] / rho, diffusion,
+                       float(bc["source"]) / Uin, Uin * math.cos(math.radians(aoa)),
+                       Uin * math.sin(math.radians(aoa)), Re]], dtype=np.float32)
+    return (theta, np.array([[float(bc["dt"]) * Uin]], dtype=np.float32),
+            np.array([[Uin, Uin, Uin * Uin]], dtype=np.float32))
+
+
 def finish_mesh(raw, U=None, device=None, order="2nd"):
     """raw mesh -> full mesh dict with stencil, moments, PDE coefficients and Dirichlet targets (float64/int64).
     order: WLSQ reconstruction order the moment matrices are built for (Load_mesh.py:543-546, params.order).
@@ -437,14 +452,8 @@ def finish_mesh(raw, U=None, device=None, order="2nd"):
         extra = device_prep.k_hop_pairs(t(mesh["face|face_node"]), n_nodes, int(bc["stencil|khops"])).cpu().numpy()
         face_node_x = np.concatenate((mesh["face_node_x_base"], extra), axis=1)
         A, B1, Bx = (x.cpu().numpy() for x in device_prep.wlsq_moments(t(pos), t(face_node_x), t(support_edge), order))
-    th = bc["theta_PDE"]
-    Uin, rho, mu = float(bc["U"]), float(bc["rho"]), float(bc["mu"])
-    aoa = float(bc["aoa"])
-    Re = rho * Uin * float(bc["L"]) / mu if mu != 0 else 0.0
-    diffusion = (mu / Uin) if th["convection"] == 0 else (mu / (rho * Uin))
-    theta = np.array([[th["unsteady"], th["continuity"], th["convection"], th["grad_p"] / rho, diffusion,
-                       float(bc["source"]) / Uin, Uin * math.cos(math.radians(aoa)),
-                       Uin * math.sin(math.radians(aoa)), Re]], dtype=np.float32)
+    theta, dt_graph, uvp_dim = pde_coefficients(bc)
+    Uin = float(bc["U"])
     nt = mesh["node|node_type"]
     inlet = (nt == INFLOW) | (nt == IN_WALL) | (nt == PRESS_POINT)
     uv = velocity_profile(pos, Uin, bc["inlet_type"]).astype(np.float32)
@@ -455,9 +464,8 @@ def finish_mesh(raw, U=None, device=None, order="2nd"):
         "face_node_x": face_node_x, "support_edge": support_edge,
         "A_node_to_node": A.astype(np.float32), "single_B_node_to_node": B1.astype(np.float32),
         "extra_B_node_to_node": Bx.astype(np.float32),
-        "theta_PDE": theta, "dt_graph": np.array([[float(bc["dt"]) * Uin]], dtype=np.float32),
-        "uvp_dim": np.array([[Uin, Uin, Uin * Uin]], dtype=np.float32),
-        "sigma": np.array([bc["sigma"]], dtype=np.float32),
+        "theta_PDE": theta, "dt_graph": dt_graph, "uvp_dim": uvp_dim,
+        "sigma": np.array([bc["sigma"]], dtype=np.float32), "bc": bc,
         "target|uvp": (uv / np.float32(Uin)).astype(np.float32),
         "init_uvp": np.concatenate((uv, np.zeros((n_nodes, 1), np.float32)), axis=1),
     })

@@ -38,6 +38,8 @@ class DevicePool:
         self.device = torch.device(device)
         self.n = len(meshes)
         self.plans, self.x, self.sizes = [], [], []
+        self.bc = [dict(m["bc"]) if "bc" in m else None for m in meshes]       # sampled PDE parameters per mesh
+        self.pos64 = [torch.from_numpy(np.ascontiguousarray(m["node|pos"])).to(self.device) for m in meshes]
         for i, m in enumerate(meshes):
             g = build_batch([m], None if fields is None else [fields[i]], device=self.device)
             p = build_plan(*g)
@@ -129,6 +131,55 @@ class DevicePool:
                   Data(theta_PDE=p.theta, sigma=p.sigma, uvp_dim=p.uvp_dim, dt_graph=p.dt.view(-1, 1), num_graphs=B))
         self._last = (idx, off["n"])
         return graphs, p
+
+    # ------------------------------------------------------------------------------------------------------------
+    def reset_env(self, i, **sampled):
+        """Re-select the boundary condition of mesh `i` and restart its field, in place on the device
+        (Data_Pool.reset_env -> CFDdatasetBase.transform_mesh, Graph_loader.py:154-229, Load_mesh.py:82-130,134-246,
+        524-565).  `sampled`: any of U, rho, mu, source, aoa, dt, L - the values the reference draws from the ranges of
+        BC.json (select_PDE_coef; the draw itself stays with the caller).  Geometry, stencil and moment matrices do not
+        depend on them and stay as they are (the reference rebuilds identical copies); what changes is theta_PDE, dt, the
+        dimensional scales, the Dirichlet targets and the initial field: 31 scalars from the host, the per-node part
+        (inlet velocity profile -> target, initial state) with torch ops on the device."""
+        from . import meshgen
+        if self.bc[i] is None:
+            raise ValueError("the mesh was given without its 'bc' record (gfv.meshgen.finish_mesh keeps it)")
+        bc = self.bc[i]
+        bc.update({k: float(v) for k, v in sampled.items()})
+        theta, dt_graph, uvp_dim = meshgen.pde_coefficients(bc)
+        p, dev = self.plans[i], self.device
+        small = torch.from_numpy(np.concatenate((theta.reshape(-1), dt_graph.reshape(-1), uvp_dim.reshape(-1)))).to(dev)
+        p.theta.copy_(small[0:9].view(1, 9))
+        p.dt.copy_(small[9:10])
+        p.uvp_dim.copy_(small[10:13].view(1, 3))
+        U = float(bc["U"])
+        pos, nt = self.pos64[i], p.node_type
+        inlet = (nt == meshgen.INFLOW) | (nt == meshgen.IN_WALL) | (nt == meshgen.PRESS_POINT)
+
+        def profile(pp):   # gfv.meshgen.velocity_profile in float64
+            u = torch.zeros(pp.shape[0], dtype=torch.float64, device=dev)
+            if pp.shape[0] == 0:
+                return u
+            if bc["inlet_type"] == "parabolic":
+                yy = pp[:, 1] - pp[:, 1].min()
+                ymax, ymin = yy.max(), yy.min()
+                u = 6 * U * yy * (((ymax - ymin) - yy) / (ymax - ymin) ** 2)
+            elif bc["inlet_type"] == "uniform":
+                u = u + U
+            else:
+                raise ValueError(bc["inlet_type"])
+            return u
+
+        u = profile(pos).to(torch.float32)
+        u[inlet] = profile(pos[inlet]).to(torch.float32)
+        u = torch.where(nt == meshgen.WALL, torch.zeros_like(u), u)
+        u = torch.where(nt == meshgen.IN_WALL, u / 2.0, u)
+        x = self.x[i]
+        x[:, 0] = u
+        x[:, 1:3] = 0.0
+        x[:, 3:12] = p.theta
+        p.y[:, 0] = u / np.float32(U)
+        p.y[:, 1] = 0.0
 
     # ------------------------------------------------------------------------------------------------------------
     def payback(self, indices, uvp_node):

@@ -121,3 +121,41 @@ def test_device_preprocessing_matches_host():
             scale = ref.abs().amax(dim=0, keepdim=True) + 1e-300
             err = float(((mine.cpu() - ref).abs() / scale).max())
             assert err < 1e-9, (order, err)
+
+
+def test_reset_env_on_the_device_equals_host_transform_mesh():
+    """SURVEY.md rows f1 / f2 (`Data_Pool.reset_env` -> `transform_mesh`, Graph_loader.py:154-229, Load_mesh.py:524-565):
+    re-selecting a mesh's boundary condition in the pool (new inlet velocity, viscosity, source, angle of attack, time
+    step) must leave the batch exactly as if the mesh had been re-finished on the host with those values - PDE
+    coefficients, scales and the plan bit for bit, targets and the restarted field to fp32 round-off of the float64
+    velocity profile."""
+    import numpy as np
+    from gfv import meshgen
+    from gfv.graph import build_batch
+    from gfv.plan import build_plan
+    from gfv.pool import DevicePool
+    specs = (("raw_tri_channel_cylinder", dict(nx=30, ny=6, quad_fraction=0.0, seed=21), 0.15),
+             ("raw_quad_cavity", dict(n=7, jitter=0.1, tri_fraction=0.3, seed=13), 1.0))
+    raws = [getattr(meshgen, fac)(**kw) for fac, kw, _ in specs]
+    ms = [meshgen.finish_mesh(r, U=U) for r, (_, _, U) in zip(raws, specs)]
+    pool = DevicePool(ms)                                   # fields: each mesh's own initial state
+    new = dict(U=0.31, mu=2.0e-3, source=0.05, aoa=3.0, dt=0.02)
+    pool.reset_env(0, **new)
+    graphs, plan = pool.batch([0, 1])
+    raw0 = dict(raws[0])
+    raw0["bc"] = dict(raws[0]["bc"], **new)
+    ref_ms = [meshgen.finish_mesh(raw0), ms[1]]
+    ref_graphs = build_batch(ref_ms, device="cuda")
+    ref = build_plan(*ref_graphs)
+    torch.cuda.synchronize()
+    assert float(ref.theta[0, 6]) != float(build_plan(*build_batch(ms, device="cuda")).theta[0, 6])   # it did change
+    for k in ("theta", "dt", "uvp_dim", "sigma"):
+        assert torch.equal(getattr(plan, k), getattr(ref, k)), k
+    for k, v in vars(ref).items():                          # everything geometric is untouched
+        if torch.is_tensor(v) and k not in ("theta", "dt", "uvp_dim", "y"):
+            assert torch.equal(getattr(plan, k), v), k
+    assert torch.equal(graphs[0].x[:, 3:12], ref_graphs[0].x[:, 3:12])
+    for mine, want in ((graphs[0].x[:, 0:3], ref_graphs[0].x[:, 0:3]), (plan.y, ref.y)):
+        assert float((mine - want).abs().max()) <= 2e-7 * float(want.abs().max())
+    n0 = ms[0]["node|pos"].shape[0]
+    assert float(graphs[0].x[:n0, 0].abs().max()) > 0 and float(plan.y[:n0, 0].max()) > 1.0   # a parabolic inlet profile
