@@ -4,6 +4,11 @@ import torch
 from gfv import lib as L, ops
 from gfv.ops import Seg, LayerSpec
 dev='cuda'
+import os
+if os.environ.get('SPLIT', '1') != '0':   # chain products as split-fp16 (weight images made on first use; static weights)
+    _wi = ops.WeightImages(torch.device(dev), torch.full((1,), 0.25, device=dev))
+    _wi.static = [(0, 1 << 62)]
+    ops.set_weight_images(_wi)
 def timeit(fn, n=30):
     for _ in range(5): fn()
     torch.cuda.synchronize()
