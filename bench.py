@@ -211,7 +211,8 @@ def main():
                              "fp32_equiv_tflops": round(tf, 3), "algorithmic_gbs": round(gbs, 1),
                              "frac_mfma": round(f_mfma, 4), "frac_hbm": round(f_hbm, 4)})
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):
+        # the committed PMC figures were collected on the default workload (one 50 k-cell mesh per GPU)
+        if os.path.exists(pmc) and args.meshes_per_gpu == 1 and args.cells == 50000:
             traffic = json.load(open(pmc))
             for r in roof_all:
                 r["traffic"] = traffic.get(r["kernel"])
