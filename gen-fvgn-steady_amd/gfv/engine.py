@@ -88,6 +88,9 @@ class Engine:
         # data parallel: (world, process group) set by TrainStep; the Normalizer statistics are exchanged inside the
         # forward, between accumulation and use
         self.dist_world, self.dist_group = 1, None
+        # called once in the backward, when every gradient of the LAST processor and of the decoder has been launched
+        # (TrainStep starts the all-reduce of that half of the flat gradient there, overlapped with the rest)
+        self.bucket_hook = None
 
     # ------------------------------------------------------------------------------------------------------------
     # side stream for work nothing downstream of the backward chain waits for (dW, LayerNorm dgamma/dbeta)
@@ -757,6 +760,8 @@ class Engine:
                 g_x, g_e = self.gn_bwd(P, blk, g_x, g_e, grads, pl)
             if g_emb is not None:
                 g_x = g_x + g_emb  # the processor input also entered the Transolver residual (TransFVGN_v2.py:46-49)
+            if self.bucket_hook is not None and proc is sv["procs"][-1] and len(sv["procs"]) > 1:
+                self.bucket_hook()
         self.mlp3_bwd(P, sv["sv_nenc"], g_x, grads)
         self.mlp3_bwd(P, sv["sv_eenc"], g_e, grads)
 

@@ -31,6 +31,7 @@ class TrainStep:
         self.world_size, self.pg = world_size, process_group
         self.engine.dist_world, self.engine.dist_group = world_size, process_group
         self.use_graph = use_graph
+        self._split, self._comm, self._work = None, None, None
         self.want_outputs = want_outputs
         dev = graphs[0].x.device
         self.dev = dev
@@ -97,9 +98,39 @@ class TrainStep:
                                   self.flat_v.data_ptr(), self.n_params, self.step_t.data_ptr(), self.lr, self.betas[0],
                                   self.betas[1], self.eps, 1.0 / self.world_size, L.stream_ptr()), "adam_step")
 
+    # data-parallel exchange: the flat gradient is reduced in two buckets.  The upper one (last processor + decoder:
+    # their backward runs first) goes out on a communication stream as soon as its last gradient kernel is launched and
+    # overlaps the backward of the first processor and the encoders; the lower one follows the backward.
+    def _bucket_split(self):
+        if self._split is None:
+            names = [n for n in self.G.off if ".processpr_list." in n]
+            last = max((int(n.split(".processpr_list.")[1].split(".")[0]) for n in names), default=-1)
+            offs = [self.G.off[n] for n in names if f".processpr_list.{last}." in n]
+            self._split = min(offs) if (last > 0 and offs) else 0
+        return self._split
+
+    def _bucket_ready(self):
+        import torch.distributed as dist
+        split = self._bucket_split()
+        if split <= 0 or torch.cuda.is_current_stream_capturing():
+            return
+        if self._comm is None:
+            self._comm = torch.cuda.Stream()
+        self._comm.wait_stream(torch.cuda.current_stream())
+        if self.engine._side is not None:
+            self._comm.wait_stream(self.engine._side)      # the weight-gradient kernels run there
+        with torch.cuda.stream(self._comm):
+            self._work = dist.all_reduce(self.flat_g[split:], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+
     def _allreduce(self):
         import torch.distributed as dist
-        dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM, group=self.pg)
+        if self._work is not None:
+            dist.all_reduce(self.flat_g[:self._split], op=dist.ReduceOp.SUM, group=self.pg)
+            self._work.wait()                              # the current stream waits for the early bucket
+            torch.cuda.current_stream().wait_stream(self._comm)
+            self._work = None
+        else:
+            dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM, group=self.pg)
 
     def step(self):
         """One training iteration.  Returns the (device) scalar loss tensor of this rank's batch."""
@@ -107,7 +138,11 @@ class TrainStep:
         dist_on = self.world_size > 1
         if not self.use_graph or (acc and dist_on):
             # (an accumulating data-parallel step exchanges the Normalizer statistics inside the forward: not captured)
-            self._body(acc, with_adam=not dist_on)
+            self.engine.bucket_hook = self._bucket_ready if dist_on else None
+            try:
+                self._body(acc, with_adam=not dist_on)
+            finally:
+                self.engine.bucket_hook = None
             if dist_on:
                 self._allreduce()
                 self._adam()

@@ -43,6 +43,9 @@ def main():
     for _ in range(3):
         ts.step()
     torch.cuda.synchronize()
+    # the gradient exchange ran in two buckets: the upper one (last processor + decoder) was started from inside the backward
+    split = ts._bucket_split()
+    assert 0 < split < ts.flat_g.numel() and ts._comm is not None and ts._work is None, (split, ts._comm, ts._work)
     mine = torch.cat([ts.P[k].reshape(-1) for k in ts.P] + [model.node_norm.acc_sum.reshape(-1),
                                                           model.node_norm.acc_sum_squared.reshape(-1),
                                                           model.node_norm.acc_count.reshape(-1)]).cpu()
