@@ -149,8 +149,7 @@ class Engine:
             self._wi = {ph: ops.WeightImages(dev, self._wmax) for ph in ("fwd", "bwd")}
             self._wi["fwd"].add_static(P.values())
             mats = [t for t in P.values() if t.dim() == 2 and t.stride(1) == 1]
-            self._wi_abs = (ops.WeightImages._upload([((t.data_ptr(), t.stride(0), t.shape[0], t.shape[1]), t) for t in mats],
-                                                     dev), len(mats))
+            self._wi_abs = ops.WeightImages._upload([((t.data_ptr(), t.stride(0), t.shape[0], t.shape[1]), t) for t in mats], dev)
             self._wi_key = key
         wi = self._wi[phase]
         if phase == "fwd":
@@ -370,8 +369,8 @@ class Engine:
         if self.factor:
             W1 = P[f"{prefix}.eb_module.net.0.0.weight"]                   # [128, 384] = [W1a | W1b | W1c]
             pab = _empty(x.device, N, 256)                                  # [W1a nb | W1b nb] per node
-            ops.rowtile_chain(N, [Seg(nb)], [LayerSpec(W1[:, 0:128])], [(pab, 256)])
-            ops.rowtile_chain(N, [Seg(nb)], [LayerSpec(W1[:, 128:256])], [(pab.data_ptr() + 512, 256)])
+            ops.rowtile_chain(N, [Seg(nb)], [LayerSpec(W1[:, 0:128], stack=W1[:, 128:256])],
+                              [(pab, 256), (pab.data_ptr() + 512, 256)])
             e_out, e_new, sv_e = self.mlp3_fwd(P, f"{prefix}.eb_module.net", E, [Seg(e)], res=e, want_nores=True,
                                                w1=W1[:, 256:384], padd=(pab, pl.es, pl.er))
             sv_e["nb"] = nb

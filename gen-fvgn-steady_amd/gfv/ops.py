@@ -82,8 +82,11 @@ class Seg:
 
 
 class LayerSpec:
-    def __init__(self, W, bias=None, op=L.OP_NONE, save=None, aux=None):
-        self.W, self.bias, self.op, self.save, self.aux = W, bias, op, save, aux
+    def __init__(self, W, bias=None, op=L.OP_NONE, save=None, aux=None, stack=None):
+        """stack: a second [128, K] weight block whose rows follow W's 128 rows in a virtual [256, K] last layer (two
+        products of the same input in one launch).  Exists only as a split-fp16 image: `rowtile_chain` launches the
+        layer once when the image is there and once per block otherwise."""
+        self.W, self.bias, self.op, self.save, self.aux, self.stack = W, bias, op, save, aux, stack
 
 
 class WeightImages:
@@ -114,24 +117,39 @@ class WeightImages:
         return i >= 0 and self.static[i][0] <= ptr < self.static[i][1]
 
     @staticmethod
-    def _upload(items, device):
-        descs = (L.WimgDesc * len(items))()
-        for d, (key, img) in zip(descs, items):
-            d.W, d.img, d.ldw, d.N, d.K = key[0], img.data_ptr(), key[1], key[2], key[3]
-        return torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(device)
+    def _parts(key, img):
+        """(block key, destination pointer) per described weight block: a stacked image is its blocks' images back to
+        back (the image layout is [128-row pass][k group], include/gfv.h)."""
+        if key[0] != "stack":
+            return [(key, img.data_ptr())]
+        per = img.numel() // (len(key) - 1)
+        return [(k, img.data_ptr() + i * per) for i, k in enumerate(key[1:])]
 
-    def lookup(self, W):
+    @staticmethod
+    def _upload(items, device):
+        parts = [pt for key, img in items for pt in WeightImages._parts(key, img)]
+        descs = (L.WimgDesc * len(parts))()
+        for d, (key, dst) in zip(descs, parts):
+            d.W, d.img, d.ldw, d.N, d.K = key[0], dst, key[1], key[2], key[3]
+        return torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(device), len(parts)
+
+    def lookup(self, W, stack=None):
         """-> image pointer (0: none; the launch then takes the fp32 path)."""
         key = (W.data_ptr(), W.stride(0), W.shape[0], W.shape[1])
+        if stack is not None:
+            assert W.shape == stack.shape and W.shape[0] == 128
+            key = ("stack", key, (stack.data_ptr(), stack.stride(0), stack.shape[0], stack.shape[1]))
         img = self.images.get(key)
         if img is not None:
             return img.data_ptr() if key in self.valid else 0
-        if not self._is_static(key[0]) or torch.cuda.is_current_stream_capturing():
+        blocks = key[1:] if key[0] == "stack" else (key,)
+        if not all(self._is_static(k[0]) for k in blocks) or torch.cuda.is_current_stream_capturing():
             return 0   # (allocations and uploads stay out of a hipGraph capture)
         lib = L.load()
-        img = torch.empty((lib.gfv_weight_image_bytes(key[2], key[3]),), dtype=torch.uint8, device=self.device)
-        desc = self._upload([(key, img)], self.device)
-        L.check(lib.gfv_weight_images(desc.data_ptr(), 1, img.numel() // 32, self.wmax.data_ptr(), L.stream_ptr()),
+        nbytes = sum(lib.gfv_weight_image_bytes(k[2], k[3]) for k in blocks)
+        img = torch.empty((nbytes,), dtype=torch.uint8, device=self.device)
+        desc, nd = self._upload([(key, img)], self.device)
+        L.check(lib.gfv_weight_images(desc.data_ptr(), nd, img.numel() // 32, self.wmax.data_ptr(), L.stream_ptr()),
                 "gfv_weight_images")
         self.images[key] = img
         self.valid.add(key)
@@ -143,11 +161,11 @@ class WeightImages:
             return
         if len(self._desc_keys) != len(self.images) and not torch.cuda.is_current_stream_capturing():
             self._desc_keys = tuple(self.images)
-            self._desc = self._upload(list(self.images.items()), self.device)
+            self._desc, self._ndesc = self._upload(list(self.images.items()), self.device)
             self._max_frags = max(img.numel() for img in self.images.values()) // 32
         if self._desc is None:
             return
-        L.check(L.load().gfv_weight_images(self._desc.data_ptr(), len(self._desc_keys), self._max_frags,
+        L.check(L.load().gfv_weight_images(self._desc.data_ptr(), self._ndesc, self._max_frags,
                                            self.wmax.data_ptr(), L.stream_ptr()), "gfv_weight_images")
         self.valid = set(self._desc_keys)
 
@@ -171,6 +189,19 @@ def rowtile_chain(M, segs, layers, outs, *, in_add=None, in_op=L.IN_NONE, in_gam
     """Launch the fused row-tile GEMM chain.  outs / res: list (per 128-wide chunk of the last layer) of
     (tensor, ld) or tensors; see include/gfv.h for the semantics of every field."""
     lib = L.load()
+    wi = wimg if wimg is not None else _WI
+    if layers[-1].stack is not None:
+        # two [128, K] blocks applied to the same input: one launch over a virtual 256-row layer when its stacked image
+        # exists, otherwise one launch per block (outs[0], outs[1])
+        ly = layers[-1]
+        h = wi.lookup(ly.W, ly.stack) if (wi is not None and len(layers) == 1 and ly.bias is None
+                                          and lib.gfv_f16split_enabled()) else 0
+        if not h:
+            assert len(layers) == 1 and len(outs) == 2 and res is None and out_nores is None
+            kw = dict(in_add=in_add, in_op=in_op, in_gamma=in_gamma, in_beta=in_beta, wimg=wimg)
+            rowtile_chain(M, segs, [LayerSpec(ly.W, ly.bias, ly.op)], [outs[0]], **kw)
+            rowtile_chain(M, segs, [LayerSpec(ly.stack, ly.bias, ly.op)], [outs[1]], **kw)
+            return
     a = L.RowtileArgs()
     a.M = M
     a.nseg = len(segs)
@@ -184,15 +215,14 @@ def rowtile_chain(M, segs, layers, outs, *, in_add=None, in_op=L.IN_NONE, in_gam
     a.in_save, a.ln_partial = _p(in_save), _p(ln_partial)
     for i, ly in enumerate(layers):
         cl = a.layer[i]
-        cl.W, cl.bias = _p(ly.W), _p(ly.bias)
-        cl.N, cl.K = ly.W.shape[0], ly.W.shape[1]
+        cl.W, cl.bias = (None if ly.stack is not None else _p(ly.W)), _p(ly.bias)   # a stacked layer exists as an image only
+        cl.N, cl.K = ly.W.shape[0] * (2 if ly.stack is not None else 1), ly.W.shape[1]
         assert ly.W.stride(1) == 1
         cl.ldw = ly.W.stride(0)  # a column block of a wider weight keeps the parent's row stride
         cl.op = ly.op
         cl.save, cl.aux = _p(ly.save), _p(ly.aux)
-    wi = wimg if wimg is not None else _WI
     if wi is not None:
-        hs = [wi.lookup(ly.W) for ly in layers]
+        hs = [wi.lookup(ly.W, ly.stack) for ly in layers]
         if all(hs):
             for i, h in enumerate(hs):
                 a.layer[i].Wh = h

@@ -69,7 +69,8 @@ enum { GFV_IN_NONE = 0, GFV_IN_GELU = 1, GFV_IN_LN = 2, GFV_IN_LNBWD = 3 };
 enum { GFV_FIN_PLAIN = 0, GFV_FIN_LN = 1, GFV_FIN_LNBWD = 2 };
 
 typedef struct {
-  const float* W;     /* [N, K] row-major: nn.Linear weight (forward) or its transpose (dX chain) */
+  const float* W;     /* [N, K] row-major: nn.Linear weight (forward) or its transpose (dX chain); NULL only with Wh: a
+                       * virtual layer whose 128-row passes come from different weight blocks, image = their images back to back */
   const float* bias;  /* [N] or NULL */
   int32_t K, N;       /* K = input width, N = output width (128 for inner layers; last layer: <= 384) */
   int32_t op;

@@ -354,6 +354,25 @@ def test_rowtile_transolver_linears(dev):
     assert rel(dWp, Wp6.grad) < TOL and rel(dbp, bp6.grad) < TOL
 
 
+def test_rowtile_stacked_last_layer(dev, chain_mode):
+    """Two [128, K] column blocks of one wider weight applied to the same rows (the node-level products of the factored
+    EdgeBlock, W1a x and W1b x): `LayerSpec(stack=...)` = one launch over a virtual 256-row layer in the split-fp16 form
+    (its image is the two blocks' images back to back), one launch per block otherwise; same numbers either way."""
+    from gfv import lib as L, ops
+    g = torch.Generator().manual_seed(5)
+    M = 900
+    d = lambda t: t.to(dev).contiguous()
+    x = torch.randn(M, 128, generator=g)
+    W1 = d(torch.randn(128, 384, generator=g) * 0.1)
+    out = torch.empty(M, 256, device=dev)
+    ops.rowtile_chain(M, [ops.Seg(d(x))], [ops.LayerSpec(W1[:, 0:128], stack=W1[:, 128:256])],
+                      [(out, 256), (out.data_ptr() + 512, 256)])
+    ref = torch.cat((x.double() @ W1[:, 0:128].double().cpu().T, x.double() @ W1[:, 128:256].double().cpu().T), 1)
+    assert rel(out, ref) < TOL
+    if chain_mode == "f16split":
+        assert L.load().gfv_rowtile_last_path() == 5    # one launch of the plain instantiation, split form
+
+
 def test_rowtile_and_dw_extreme_dynamic_range(dev, chain_mode):
     """Rows spanning 40 orders of magnitude, all-zero rows, and segments of very different scale in one concat: the
     per-row (chain) and per-slab (dW) power-of-two scalings of the split-fp16 form must neither overflow nor lose the
