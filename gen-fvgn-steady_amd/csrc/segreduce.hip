@@ -245,16 +245,17 @@ __global__ __launch_bounds__(1024) void reduce_partials_small_kernel(const float
   __shared__ float red[32][33];
   const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
   const int j = blockIdx.x * 32 + cx;
-  float s0 = 0.f, s1 = 0.f;
+  // 8 loads in flight per thread (the loop was one memory round trip per pair of chunks); fixed summation order
+  float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (j < n) {
     int c = ry;
-    for (; c + 32 < n_chunks; c += 64) {
-      s0 += partial[(size_t)c * n + j];
-      s1 += partial[(size_t)(c + 32) * n + j];
+    for (; c + 7 * 32 < n_chunks; c += 8 * 32) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s[u] += partial[(size_t)(c + 32 * u) * n + j];
     }
-    if (c < n_chunks) s0 += partial[(size_t)c * n + j];
+    for (int u = 0; c < n_chunks; c += 32, ++u) s[u] += partial[(size_t)c * n + j];
   }
-  red[ry][cx] = s0 + s1;
+  red[ry][cx] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
   __syncthreads();
   if (ry == 0 && j < n) {
     float t = 0.f;
