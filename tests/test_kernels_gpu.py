@@ -373,6 +373,39 @@ def test_rowtile_stacked_last_layer(dev, chain_mode):
         assert L.load().gfv_rowtile_last_path() == 5    # one launch of the plain instantiation, split form
 
 
+def test_runtime_switch_between_product_forms(dev, chain_mode):
+    """`gfv_set_f16split(0)` moves the whole process to the fp32 MFMA at run time (bench.py times both forms in one run):
+    a launch that carries weight images then ignores them, the weight-gradient launch takes the fp32 kernel; both forms
+    agree with each other far inside the parity tolerance."""
+    if chain_mode != "f32":
+        pytest.skip("one pass is enough")
+    from gfv import lib as L, ops
+    lib = L.load()
+    g = torch.Generator().manual_seed(17)
+    M = 1500
+    d = lambda t: t.to(dev).contiguous()
+    x, W, b = d(torch.randn(M, 128, generator=g)), d(torch.randn(128, 128, generator=g) * 0.1), d(torch.randn(128, generator=g))
+    G = d(torch.randn(M, 128, generator=g) * 1e-3)
+    wi = ops.WeightImages(dev, W.abs().max().reshape(1).clone())
+    wi.static = [(0, 1 << 62)]
+    outs, dws = {}, {}
+    assert lib.gfv_f16split_enabled() == 1
+    try:
+        for form in (1, 0, 1):
+            lib.gfv_set_f16split(form)
+            o = torch.empty(M, 128, device=dev)
+            ops.rowtile_chain(M, [ops.Seg(x)], [ops.LayerSpec(W, b)], [o], wimg=wi)
+            assert (lib.gfv_rowtile_last_path() >= 4) == bool(form)
+            outs[form] = o
+            dws[form] = ops.linear_dw(G, 128, [ops.Seg(x)], M)[0]
+    finally:
+        lib.gfv_set_f16split(1)
+    ref = x.double().cpu() @ W.double().cpu().T + b.double().cpu()
+    assert rel(outs[1], ref) < TOL and rel(outs[0], ref) < TOL and rel(outs[1], outs[0]) < 2e-6
+    refW = G.double().cpu().T @ x.double().cpu()
+    assert rel(dws[1], refW) < TOL and rel(dws[0], refW) < TOL and not torch.equal(dws[1], dws[0])
+
+
 def test_rowtile_and_dw_extreme_dynamic_range(dev, chain_mode):
     """Rows spanning 40 orders of magnitude, all-zero rows, and segments of very different scale in one concat: the
     per-row (chain) and per-slab (dW) power-of-two scalings of the split-fp16 form must neither overflow nor lose the
