@@ -544,7 +544,7 @@ extern "C" int gfv_rowtile_chain(const gfv_rowtile_args_t* args, void* stream) {
   for (int i = 0; i + 1 < args->nseg; ++i) f16 = f16 && (args->seg[i].width % 32 == 0);
   // a layer may come without fp32 weights (a row-stacked virtual layer that exists as an image only): split form or nothing
   for (int l = 0; l < args->nlayers; ++l)
-    if (!args->layer[l].W && !f16) return GFV_ERR_ARG;
+    if ((!args->layer[l].W || args->layer[l].bias2) && !f16) return GFV_ERR_ARG;
   static const bool dbg = getenv("GFV_ROWTILE_DEBUG") != nullptr;
   if (dbg && !fast_t && !rag_t) {
     fprintf(stderr, "[gfv] generic rowtile: M=%d nseg=%d widths=%d,%d,%d ld0=%d nlayers=%d K0=%d Nlast=%d out_ld=%d in_op=%d fin_op=%d\n",

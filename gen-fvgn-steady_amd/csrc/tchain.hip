@@ -439,8 +439,9 @@ __global__ __launch_bounds__(256, 2) void tchain_kernel(const gfv_rowtile_args_t
   for (int l = 0; l < 3; ++l) {
     if (l < A.nlayers) {
       const float* bp = A.layer[l].bias;
+      const float* b2 = A.layer[l].bias2;   // columns >= 128 of a row-stacked last layer
       const int nl = A.layer[l].N;
-      for (int c = tid; c < nl; c += 256) par[128 * l + c] = bp ? bp[c] : 0.f;
+      for (int c = tid; c < nl; c += 256) par[128 * l + c] = (b2 && c >= 128) ? b2[c - 128] : (bp ? bp[c] : 0.f);
     }
   }
   {

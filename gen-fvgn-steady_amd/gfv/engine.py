@@ -461,10 +461,11 @@ class Engine:
         dev = xg.device
         a = f"{prefix}.Attn"
         fx_in, fx_mid, x_mid = _empty(dev, N, 128), _empty(dev, N, 128), _empty(dev, N, 128)
-        ops.rowtile_chain(N, [Seg(xg)], [LayerSpec(P[f"{a}.in_project_fx.weight"], P[f"{a}.in_project_fx.bias"])],
-                          [fx_mid], in_add=emb, in_save=fx_in)
-        ops.rowtile_chain(N, [Seg(fx_in)], [LayerSpec(P[f"{a}.in_project_x.weight"], P[f"{a}.in_project_x.bias"])],
-                          [x_mid])
+        # fx_mid = in_project_fx(xg + emb), x_mid = in_project_x(xg + emb): one launch over the row-stacked pair
+        ops.rowtile_chain(N, [Seg(xg)],
+                          [LayerSpec(P[f"{a}.in_project_fx.weight"], P[f"{a}.in_project_fx.bias"],
+                                     stack=P[f"{a}.in_project_x.weight"], bias2=P[f"{a}.in_project_x.bias"])],
+                          [fx_mid, x_mid], in_add=emb, in_save=fx_in)
         w = _empty(dev, N, 256)
         temp = P[f"{a}.graph_temperature"]
         L.check(lib.gfv_slice_softmax_fwd(x_mid.data_ptr(), P[f"{a}.in_project_slice.weight"].data_ptr(),
@@ -582,8 +583,12 @@ class Engine:
             self._put(grads, f"{a}.graph_temperature", ds[544:552])
         # projections; fx_in also feeds the to_out residual
         t1, g_fx_in = _empty(dev, N, 128), _empty(dev, N, 128)
-        ops.rowtile_chain(N, [Seg(g_fx_mid)], [LayerSpec(self._T(P[f"{a}.in_project_fx.weight"]))], [t1], res=[g_fx1])
-        ops.rowtile_chain(N, [Seg(g_x_mid)], [LayerSpec(self._T(P[f"{a}.in_project_x.weight"]))], [g_fx_in], res=[t1])
+        Wfxt, Wxt = self._T(P[f"{a}.in_project_fx.weight"]), self._T(P[f"{a}.in_project_x.weight"])
+        if ops.stack_ready(Wfxt, Wxt):   # g_fx_in = g_fx_mid Wfx + g_x_mid Wx + g_fx1: one launch, column-stacked pair
+            ops.rowtile_chain(N, [Seg(g_fx_mid), Seg(g_x_mid)], [LayerSpec(Wfxt, stack_cols=Wxt)], [g_fx_in], res=[g_fx1])
+        else:
+            ops.rowtile_chain(N, [Seg(g_fx_mid)], [LayerSpec(Wfxt)], [t1], res=[g_fx1])
+            ops.rowtile_chain(N, [Seg(g_x_mid)], [LayerSpec(Wxt)], [g_fx_in], res=[t1])
         with self.fork(g_x_mid, g_fx_mid, fx_in):
             self._dw_block(grads, [(f"{a}.in_project_x.weight", f"{a}.in_project_x.bias", 1),
                                    (f"{a}.in_project_fx.weight", f"{a}.in_project_fx.bias", 1)],

@@ -27,7 +27,8 @@ class Seg(C.Structure):
 
 class Layer(C.Structure):
     _fields_ = [("W", C.c_void_p), ("bias", C.c_void_p), ("K", C.c_int32), ("N", C.c_int32), ("op", C.c_int32),
-                ("ldw", C.c_int32), ("save", C.c_void_p), ("aux", C.c_void_p), ("Wh", C.c_void_p)]
+                ("ldw", C.c_int32), ("save", C.c_void_p), ("aux", C.c_void_p), ("Wh", C.c_void_p),
+                ("bias2", C.c_void_p)]
 
 
 class RowtileArgs(C.Structure):

@@ -82,11 +82,14 @@ class Seg:
 
 
 class LayerSpec:
-    def __init__(self, W, bias=None, op=L.OP_NONE, save=None, aux=None, stack=None):
-        """stack: a second [128, K] weight block whose rows follow W's 128 rows in a virtual [256, K] last layer (two
-        products of the same input in one launch).  Exists only as a split-fp16 image: `rowtile_chain` launches the
-        layer once when the image is there and once per block otherwise."""
-        self.W, self.bias, self.op, self.save, self.aux, self.stack = W, bias, op, save, aux, stack
+    def __init__(self, W, bias=None, op=L.OP_NONE, save=None, aux=None, stack=None, bias2=None, stack_cols=None):
+        """stack (+ bias2): a second [128, K] weight block whose rows follow W's 128 rows in a virtual [256, K] last layer
+        (two Linear layers applied to the same input in one launch, outputs = the two 128-wide chunks).
+        stack_cols: a second [128, 128] block whose columns follow W's in a virtual [128, 256] layer (the sum of two
+        Linear layers applied to two 128-wide input segments).  Either exists only as a split-fp16 image - the blocks'
+        images back to back; `stack_ready` tells whether it can be used, a row stack falls back to one launch per block."""
+        self.W, self.bias, self.op, self.save, self.aux = W, bias, op, save, aux
+        self.stack, self.bias2, self.stack_cols = stack, bias2, stack_cols
 
 
 class WeightImages:
@@ -176,6 +179,12 @@ class WeightImages:
 _WI = None   # the WeightImages the chain launches currently consult (set by the engine around forward / backward)
 
 
+def stack_ready(Wa, Wb):
+    """True when a launch may use the virtual layer stacked from the blocks Wa, Wb (split-fp16 form on, images available)."""
+    return (_WI is not None and L.load().gfv_f16split_enabled() and Wa.shape == Wb.shape and Wa.shape[0] == 128
+            and _WI.lookup(Wa, Wb) != 0)
+
+
 def set_weight_images(wi):
     global _WI
     prev, _WI = _WI, wi
@@ -194,13 +203,12 @@ def rowtile_chain(M, segs, layers, outs, *, in_add=None, in_op=L.IN_NONE, in_gam
         # two [128, K] blocks applied to the same input: one launch over a virtual 256-row layer when its stacked image
         # exists, otherwise one launch per block (outs[0], outs[1])
         ly = layers[-1]
-        h = wi.lookup(ly.W, ly.stack) if (wi is not None and len(layers) == 1 and ly.bias is None
-                                          and lib.gfv_f16split_enabled()) else 0
+        h = wi.lookup(ly.W, ly.stack) if (wi is not None and len(layers) == 1 and lib.gfv_f16split_enabled()) else 0
         if not h:
             assert len(layers) == 1 and len(outs) == 2 and res is None and out_nores is None
             kw = dict(in_add=in_add, in_op=in_op, in_gamma=in_gamma, in_beta=in_beta, wimg=wimg)
-            rowtile_chain(M, segs, [LayerSpec(ly.W, ly.bias, ly.op)], [outs[0]], **kw)
-            rowtile_chain(M, segs, [LayerSpec(ly.stack, ly.bias, ly.op)], [outs[1]], **kw)
+            rowtile_chain(M, segs, [LayerSpec(ly.W, ly.bias, ly.op)], [outs[0]], in_save=in_save, **kw)
+            rowtile_chain(M, segs, [LayerSpec(ly.stack, ly.bias2, ly.op)], [outs[1]], **kw)
             return
     a = L.RowtileArgs()
     a.M = M
@@ -215,14 +223,16 @@ def rowtile_chain(M, segs, layers, outs, *, in_add=None, in_op=L.IN_NONE, in_gam
     a.in_save, a.ln_partial = _p(in_save), _p(ln_partial)
     for i, ly in enumerate(layers):
         cl = a.layer[i]
-        cl.W, cl.bias = (None if ly.stack is not None else _p(ly.W)), _p(ly.bias)   # a stacked layer exists as an image only
-        cl.N, cl.K = ly.W.shape[0] * (2 if ly.stack is not None else 1), ly.W.shape[1]
+        stacked = ly.stack is not None or ly.stack_cols is not None
+        cl.W, cl.bias, cl.bias2 = (None if stacked else _p(ly.W)), _p(ly.bias), _p(ly.bias2)   # stacked: image only
+        cl.N = ly.W.shape[0] * (2 if ly.stack is not None else 1)
+        cl.K = ly.W.shape[1] * (2 if ly.stack_cols is not None else 1)
         assert ly.W.stride(1) == 1
-        cl.ldw = ly.W.stride(0)  # a column block of a wider weight keeps the parent's row stride
+        cl.ldw = 0 if (ly.stack is not None or ly.stack_cols is not None) else ly.W.stride(0)  # column block: parent's stride
         cl.op = ly.op
         cl.save, cl.aux = _p(ly.save), _p(ly.aux)
     if wi is not None:
-        hs = [wi.lookup(ly.W, ly.stack) for ly in layers]
+        hs = [wi.lookup(ly.W, ly.stack if ly.stack is not None else ly.stack_cols) for ly in layers]
         if all(hs):
             for i, h in enumerate(hs):
                 a.layer[i].Wh = h

@@ -79,6 +79,8 @@ typedef struct {
   const float* aux;   /* [M, N] for GFV_OP_MUL_DGELU */
   const void* Wh;     /* optional: split-fp16 image of W (gfv_weight_images); when every layer of a launch has one
                        * (and args.wmax is set) the products run on the f16 MFMA pipe, see below */
+  const float* bias2; /* optional: bias of output columns >= 128 (a last layer whose two 128-row passes come from
+                       * different Linear layers); NULL = bias[128..] */
 } gfv_layer_t;
 
 typedef struct {

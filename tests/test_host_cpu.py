@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
 def test_ctypes_structs_match_header_layout():
     import ctypes as C
     from gfv import lib
-    assert C.sizeof(lib.Seg) == 24 and C.sizeof(lib.Layer) == 56
+    assert C.sizeof(lib.Seg) == 24 and C.sizeof(lib.Layer) == 64
     assert C.sizeof(lib.DwTile) == 6 * 8 + 6 * 4 + 2 * 8
     assert C.sizeof(lib.RowtileArgs) % 8 == 0
     handle = lib.load()   # the library reports the sizes it was compiled with

@@ -354,23 +354,40 @@ def test_rowtile_transolver_linears(dev):
     assert rel(dWp, Wp6.grad) < TOL and rel(dbp, bp6.grad) < TOL
 
 
-def test_rowtile_stacked_last_layer(dev, chain_mode):
-    """Two [128, K] column blocks of one wider weight applied to the same rows (the node-level products of the factored
-    EdgeBlock, W1a x and W1b x): `LayerSpec(stack=...)` = one launch over a virtual 256-row layer in the split-fp16 form
-    (its image is the two blocks' images back to back), one launch per block otherwise; same numbers either way."""
+def test_rowtile_stacked_layers(dev, chain_mode):
+    """Virtual layers stacked from two weight blocks, which exist as split-fp16 images only (the blocks' images back to
+    back).  Rows: two Linear layers applied to the same input in one launch (`LayerSpec(stack=, bias2=)`: the node-level
+    products W1a x, W1b x of the factored EdgeBlock; in_project_fx / in_project_x of the Transolver block) - one launch per
+    block when the image is missing.  Columns: the sum of two Linear layers applied to two input segments
+    (`stack_cols`: the adjoint of the in_project pair)."""
     from gfv import lib as L, ops
     g = torch.Generator().manual_seed(5)
     M = 900
     d = lambda t: t.to(dev).contiguous()
-    x = torch.randn(M, 128, generator=g)
+    x, emb = torch.randn(M, 128, generator=g), torch.randn(M, 128, generator=g)
     W1 = d(torch.randn(128, 384, generator=g) * 0.1)
+    b1, b2 = d(torch.randn(128, generator=g)), d(torch.randn(128, generator=g))
     out = torch.empty(M, 256, device=dev)
-    ops.rowtile_chain(M, [ops.Seg(d(x))], [ops.LayerSpec(W1[:, 0:128], stack=W1[:, 128:256])],
-                      [(out, 256), (out.data_ptr() + 512, 256)])
-    ref = torch.cat((x.double() @ W1[:, 0:128].double().cpu().T, x.double() @ W1[:, 128:256].double().cpu().T), 1)
-    assert rel(out, ref) < TOL
+    xin = torch.empty(M, 128, device=dev)
+    ops.rowtile_chain(M, [ops.Seg(d(x))], [ops.LayerSpec(W1[:, 0:128], b1, stack=W1[:, 128:256], bias2=b2)],
+                      [(out, 256), (out.data_ptr() + 512, 256)], in_add=d(emb), in_save=xin)
+    xs = (x + emb).double()
+    ref = torch.cat((xs @ W1[:, 0:128].double().cpu().T + b1.double().cpu(),
+                     xs @ W1[:, 128:256].double().cpu().T + b2.double().cpu()), 1)
+    assert rel(out, ref) < TOL and rel(xin, xs) < TOL
     if chain_mode == "f16split":
         assert L.load().gfv_rowtile_last_path() == 5    # one launch of the plain instantiation, split form
+        Wa, Wb = d(torch.randn(128, 128, generator=g) * 0.1), d(torch.randn(128, 128, generator=g) * 0.1)
+        r = torch.randn(M, 128, generator=g)
+        o2 = torch.empty(M, 128, device=dev)
+        ops.rowtile_chain(M, [ops.Seg(d(x)), ops.Seg(d(emb))], [ops.LayerSpec(Wa, stack_cols=Wb)], [o2], res=[d(r)])
+        ref2 = x.double() @ Wa.double().cpu().T + emb.double() @ Wb.double().cpu().T + r.double()
+        assert rel(o2, ref2) < TOL
+    else:
+        # without an image a column-stacked layer has no weights to run on: the C entry refuses it
+        with pytest.raises(RuntimeError):
+            ops.rowtile_chain(M, [ops.Seg(d(x)), ops.Seg(d(emb))], [ops.LayerSpec(W1[:, 0:128], stack_cols=W1[:, 128:256])],
+                              [torch.empty(M, 128, device=dev)])
 
 
 def test_runtime_switch_between_product_forms(dev, chain_mode):
