@@ -82,6 +82,7 @@ class Engine:
         self.f16split = os.environ.get("GFV_F16SPLIT", "1") != "0"
         self._wi, self._wi_key, self._wmax, self._wi_abs = None, None, None, None
         self._pkey_cache = None
+        self._zero_e = None
         self._etmp = None
         self._side = None
         self._keep = []
@@ -760,7 +761,11 @@ class Engine:
                 g_emb = g_x
             for blk in reversed(proc["blocks"]):
                 if g_e is None:
-                    g_e = torch.zeros((E, 128), dtype=torch.float32, device=dev)  # last block's edges feed nothing
+                    # last block's edges feed nothing: a zero gradient, kept across steps (read-only: gn_bwd returns a
+                    # fresh tensor for the block before)
+                    if self._zero_e is None or self._zero_e.shape[0] != E or self._zero_e.device != dev:
+                        self._zero_e = torch.zeros((E, 128), dtype=torch.float32, device=dev)
+                    g_e = self._zero_e
                 g_x, g_e = self.gn_bwd(P, blk, g_x, g_e, grads, pl)
             if g_emb is not None:
                 g_x = g_x + g_emb  # the processor input also entered the Transolver residual (TransFVGN_v2.py:46-49)
