@@ -229,9 +229,17 @@ __device__ __forceinline__ void dw_body_h(const DwLaunch& A, const gfv_dw_tile_t
 
   // ---- slab scale of the gradient rows ----
   float gm = 0.f;
-  for (int m = m_beg + r4; m < m_end; m += 8) {
-    const float4 v = ld4(T.G, (size_t)m, T.ldg, col, FULL ? 128 : T.n_out, gvec);
-    gm = fmaxf(fmaxf(gm, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+  {
+    // 8 independent row loads in flight per thread (rows clamped to the slab: a repeated row does not change a maximum)
+    int m = m_beg + r4;
+    for (; m < m_end; m += 64) {
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = ld4(T.G, (size_t)min(m + 8 * u, m_end - 1), T.ldg, col, FULL ? 128 : T.n_out, gvec);
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        gm = fmaxf(fmaxf(gm, fmaxf(fabsf(v[u].x), fabsf(v[u].y))), fmaxf(fabsf(v[u].z), fabsf(v[u].w)));
+    }
   }
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) gm = fmaxf(gm, __shfl_xor(gm, o, 64));
