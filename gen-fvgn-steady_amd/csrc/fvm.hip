@@ -168,7 +168,21 @@ __global__ __launch_bounds__(256) void wlsq_fwd_kernel(const float* __restrict__
   if (c < 7) {
     const float pi = phi[(size_t)i * 8 + c];
     const int beg = rowptr[i], end = rowptr[i + 1];
-    for (int k = beg; k < end; ++k) {
+    // 4 stencil entries per trip: index, neighbour value and moment vector of all four are requested before the first
+    // dependent multiply (the loop was one memory round trip per entry); the accumulation order stays entry by entry
+    int k = beg;
+    for (; k + 4 <= end; k += 4) {
+      float dv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) dv[u] = phi[(size_t)outn[k + u] * 8 + c] - pi;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float* b = Bp + (size_t)(k + u) * M;
+#pragma unroll
+        for (int j = 0; j < M; ++j) rhs[j] += b[j] * dv[u];
+      }
+    }
+    for (; k < end; ++k) {
       const float d = phi[(size_t)outn[k] * 8 + c] - pi;
       const float* b = Bp + (size_t)k * M;
 #pragma unroll
@@ -246,7 +260,14 @@ __global__ __launch_bounds__(256) void wlsq_bwd_gather_kernel(const float* __res
   if (j >= N || c >= nch) return;
   float s = 0.f;
   const int beg = rowptr_o[j], end = rowptr_o[j + 1];
-  for (int k = beg; k < end; ++k) s += dotM<M>(Bo + (size_t)k * M, grhs + ((size_t)inn[k] * 8 + c) * M);
+  int k = beg;
+  for (; k + 4 <= end; k += 4) {   // 4 entries per trip (loads of all four in flight), summed entry by entry
+    float t[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) t[u] = dotM<M>(Bo + (size_t)(k + u) * M, grhs + ((size_t)inn[k + u] * 8 + c) * M);
+    s += t[0]; s += t[1]; s += t[2]; s += t[3];
+  }
+  for (; k < end; ++k) s += dotM<M>(Bo + (size_t)k * M, grhs + ((size_t)inn[k] * 8 + c) * M);
   s -= dotM<M>(sumB + (size_t)j * M, grhs + ((size_t)j * 8 + c) * M);
   gphi[(size_t)j * 8 + c] += s;
 }
