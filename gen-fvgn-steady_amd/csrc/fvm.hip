@@ -424,7 +424,17 @@ __global__ __launch_bounds__(1024) void graph_loss_kernel(const float* __restric
   __shared__ float red[4][1024];
   const int b = blockIdx.x, tid = threadIdx.x;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  for (int c = gcell_ptr[b] + tid; c < gcell_ptr[b + 1]; c += 1024) {
+  // one workgroup per graph: 8 loads in flight per thread (the loop was one memory round trip per cell), summed in order
+  const int c_end = gcell_ptr[b + 1];
+  int c = gcell_ptr[b] + tid;
+  for (; c + 7 * 1024 < c_end; c += 8 * 1024) {
+    float4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(cres + (size_t)(c + 1024 * u) * 4);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { s0 += v[u].x * v[u].x; s1 += v[u].y * v[u].y; s2 += v[u].z * v[u].z; s3 += v[u].w; }
+  }
+  for (; c < c_end; c += 1024) {
     const float4 v = *reinterpret_cast<const float4*>(cres + (size_t)c * 4);
     s0 += v.x * v.x; s1 += v.y * v.y; s2 += v.z * v.z; s3 += v.w;
   }
