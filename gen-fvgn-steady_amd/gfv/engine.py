@@ -264,7 +264,7 @@ class Engine:
         saved = dict(z1=z1, z2=z2, y3=y3, segs=segs, in_add=in_add, M=M, ln=ln, prefix=prefix)
         return out, nores, saved
 
-    def mlp3_bwd(self, P, sv, G, grads, *, outs=None, res=None, gadd=None, W1t=None, g_ld=None):
+    def mlp3_bwd(self, P, sv, G, grads, *, outs=None, res=None, gadd=None, W1t=None, g_ld=None, g_add=None):
         """G: grad wrt the MLP output (after LayerNorm, before the residual) [M, nout].  outs: per 128-chunk of the
         (possibly permuted) input, or None when the input needs no gradient (encoders)."""
         prefix, M, ln = sv["prefix"], sv["M"], sv["ln"]
@@ -281,6 +281,9 @@ class Engine:
         kw = dict(in_op=L.IN_LNBWD, in_gamma=P[names[6]], in_aux=sv["y3"], in_save=g3, ln_partial=part) if ln else {}
         if gadd is not None:
             kw.update(gadd=gadd[0], gadd_s=gadd[1], gadd_r=gadd[2])
+        if g_add is not None:   # G + g_add is the gradient (added in the prologue, before the LayerNorm backward)
+            assert ln, "the addend is folded into the LayerNorm-backward prologue"
+            kw.update(in_add=g_add)
         if outs is not None:
             if W1t is None:
                 W1t = self._T(W1)
@@ -510,7 +513,9 @@ class Engine:
                                                  out.data_ptr(), L.stream_ptr()), "reduce_partials_seg")
         return out
 
-    def trans_bwd(self, P, sv, g_out, grads, pl):
+    def trans_bwd(self, P, sv, g_out, grads, pl, g_add=None):
+        """g_add: optional addend of the incoming gradient (g_out + g_add is the gradient); the sum is formed in the
+        prologue of the first launch and kept (no separate elementwise pass)."""
         lib = L.load()
         st = L.stream_ptr()
         N, B = pl.N, pl.B
@@ -522,8 +527,11 @@ class Engine:
         # linear_post
         Wpost, Wpre = P[f"{prefix}.mlp.linear_post.weight"], P[f"{prefix}.mlp.linear_pre.0.weight"]
         g_z = _empty(dev, N, 256)
+        g_sum = _empty(dev, N, 128) if g_add is not None else None
         ops.rowtile_chain(N, [Seg(g_out)], [LayerSpec(self._T(Wpost), None, L.OP_MUL_DGELU, aux=z)],
-                          [(g_z, 256), (g_z.data_ptr() + 512, 256)])
+                          [(g_z, 256), (g_z.data_ptr() + 512, 256)], in_add=g_add, in_save=g_sum)
+        if g_add is not None:
+            g_out = g_sum
         with self.fork(g_out, z):
             self._dw_block(grads, [(f"{prefix}.mlp.linear_post.weight", f"{prefix}.mlp.linear_post.bias", 2)],
                            [self._tile(g_out, 128, zs, a_op=1) for zs in zsegs], N)
@@ -754,11 +762,15 @@ class Engine:
         g_x = _empty(dev, N, 128)
         self.mlp3_bwd(P, sv["sv_dec"], g_dec, grads, outs=[g_x])
         g_e = None
+        pending = None   # an addend of g_x that the next consumer folds into its first launch
         for proc in reversed(sv["procs"]):
             g_emb = None
             if proc["trans"] is not None:
-                g_x = self.trans_bwd(P, proc["trans"], g_x, grads, pl)   # grad wrt (x_GN + emb)
+                g_x = self.trans_bwd(P, proc["trans"], g_x, grads, pl, g_add=pending)   # grad wrt (x_GN + emb)
+                pending = None
                 g_emb = g_x
+            elif pending is not None:
+                g_x, pending = g_x + pending, None
             for blk in reversed(proc["blocks"]):
                 if g_e is None:
                     # last block's edges feed nothing: a zero gradient, kept across steps (read-only: gn_bwd returns a
@@ -768,10 +780,10 @@ class Engine:
                     g_e = self._zero_e
                 g_x, g_e = self.gn_bwd(P, blk, g_x, g_e, grads, pl)
             if g_emb is not None:
-                g_x = g_x + g_emb  # the processor input also entered the Transolver residual (TransFVGN_v2.py:46-49)
+                pending = g_emb  # the processor input also entered the Transolver residual (TransFVGN_v2.py:46-49)
             if self.bucket_hook is not None and proc is sv["procs"][-1] and len(sv["procs"]) > 1:
                 self.bucket_hook()
-        self.mlp3_bwd(P, sv["sv_nenc"], g_x, grads)
+        self.mlp3_bwd(P, sv["sv_nenc"], g_x, grads, g_add=pending)
         self.mlp3_bwd(P, sv["sv_eenc"], g_e, grads)
 
     # ------------------------------------------------------------------------------------------------------------
