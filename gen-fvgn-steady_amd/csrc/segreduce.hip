@@ -24,33 +24,50 @@ __global__ __launch_bounds__(256) void seg_gather_sum_vec(const float* __restric
   for (int r = blockIdx.x * ROWS_PER_BLOCK + sub; r < n_rows; r += gridDim.x * ROWS_PER_BLOCK) {
     const int beg = rowptr[r], end = rowptr[r + 1];
     float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
+    // the column indices of up to 8 entries come back in ONE round trip (clamped reads past the row end are cheap 4-B
+    // loads that are never used); the gathers then go out in groups of four (tail: up to three at once).  Accumulation
+    // pattern unchanged: full groups of four -> a0..a3, a tail of < 4 entries -> a0.
+    auto gat = [&](int cc) {
+      float4 v = *reinterpret_cast<const float4*>(src + (size_t)cc * F + 4 * l);
+      if (src_scale) {
+        const float sc = src_scale[cc];
+        v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
+      }
+      return v;
+    };
     int k = beg;
-    for (; k + 4 <= end; k += 4) {
-      const int c0 = col[k], c1 = col[k + 1], c2 = col[k + 2], c3 = col[k + 3];
-      float4 v0 = *reinterpret_cast<const float4*>(src + (size_t)c0 * F + 4 * l);
-      float4 v1 = *reinterpret_cast<const float4*>(src + (size_t)c1 * F + 4 * l);
-      float4 v2 = *reinterpret_cast<const float4*>(src + (size_t)c2 * F + 4 * l);
-      float4 v3 = *reinterpret_cast<const float4*>(src + (size_t)c3 * F + 4 * l);
-      if (src_scale) {
-        const float s0 = src_scale[c0], s1 = src_scale[c1], s2 = src_scale[c2], s3 = src_scale[c3];
-        v0.x *= s0; v0.y *= s0; v0.z *= s0; v0.w *= s0;
-        v1.x *= s1; v1.y *= s1; v1.z *= s1; v1.w *= s1;
-        v2.x *= s2; v2.y *= s2; v2.z *= s2; v2.w *= s2;
-        v3.x *= s3; v3.y *= s3; v3.z *= s3; v3.w *= s3;
+    while (k < end) {
+      const int last = end - 1;
+      const int c0 = col[min(k, last)], c1 = col[min(k + 1, last)], c2 = col[min(k + 2, last)], c3 = col[min(k + 3, last)];
+      const int c4 = col[min(k + 4, last)], c5 = col[min(k + 5, last)], c6 = col[min(k + 6, last)], c7 = col[min(k + 7, last)];
+      int t0 = c0, t1 = c1, t2 = c2;   // tail candidates
+      if (k + 4 <= end) {
+        const float4 v0 = gat(c0), v1 = gat(c1), v2 = gat(c2), v3 = gat(c3);
+        a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+        a1.x += v1.x; a1.y += v1.y; a1.z += v1.z; a1.w += v1.w;
+        a2.x += v2.x; a2.y += v2.y; a2.z += v2.z; a2.w += v2.w;
+        a3.x += v3.x; a3.y += v3.y; a3.z += v3.z; a3.w += v3.w;
+        k += 4;
+        if (k + 4 <= end) {
+          const float4 w0 = gat(c4), w1 = gat(c5), w2 = gat(c6), w3 = gat(c7);
+          a0.x += w0.x; a0.y += w0.y; a0.z += w0.z; a0.w += w0.w;
+          a1.x += w1.x; a1.y += w1.y; a1.z += w1.z; a1.w += w1.w;
+          a2.x += w2.x; a2.y += w2.y; a2.z += w2.z; a2.w += w2.w;
+          a3.x += w3.x; a3.y += w3.y; a3.z += w3.z; a3.w += w3.w;
+          k += 4;
+          continue;
+        }
+        t0 = c4; t1 = c5; t2 = c6;
       }
-      a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
-      a1.x += v1.x; a1.y += v1.y; a1.z += v1.z; a1.w += v1.w;
-      a2.x += v2.x; a2.y += v2.y; a2.z += v2.z; a2.w += v2.w;
-      a3.x += v3.x; a3.y += v3.y; a3.z += v3.z; a3.w += v3.w;
-    }
-    for (; k < end; ++k) {
-      const int c0 = col[k];
-      float4 v0 = *reinterpret_cast<const float4*>(src + (size_t)c0 * F + 4 * l);
-      if (src_scale) {
-        const float s0 = src_scale[c0];
-        v0.x *= s0; v0.y *= s0; v0.z *= s0; v0.w *= s0;
+      const int r3 = end - k;   // 0..3 tail entries
+      if (r3 > 0) {
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 v0 = gat(t0), v1 = (r3 > 1) ? gat(t1) : z, v2 = (r3 > 2) ? gat(t2) : z;
+        a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+        if (r3 > 1) { a0.x += v1.x; a0.y += v1.y; a0.z += v1.z; a0.w += v1.w; }
+        if (r3 > 2) { a0.x += v2.x; a0.y += v2.y; a0.z += v2.z; a0.w += v2.w; }
       }
-      a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+      k = end;
     }
     float4 s = make_float4((a0.x + a1.x) + (a2.x + a3.x), (a0.y + a1.y) + (a2.y + a3.y),
                            (a0.z + a1.z) + (a2.z + a3.z), (a0.w + a1.w) + (a2.w + a3.w));
