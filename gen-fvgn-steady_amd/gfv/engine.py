@@ -790,9 +790,12 @@ class Engine:
     # whole model (importer.py:156-240)
     # ------------------------------------------------------------------------------------------------------------
     def forward(self, P, buffers, x, pl, *, norm_global=True, accumulate=True, want_outputs=True, want_edge_attr15=True):
-        uv_old, ea16, ea15 = self.prep_fwd(x, buffers, pl, norm_global, accumulate, want_edge_attr15)
-        prev = self._wi_enter("fwd", P)
+        # the per-step weight images are built on the side stream while the input preparation runs on the main one
+        with self.fork():
+            prev = self._wi_enter("fwd", P)
         try:
+            uv_old, ea16, ea15 = self.prep_fwd(x, buffers, pl, norm_global, accumulate, want_edge_attr15)
+            self.join()
             dec, sv_sim = self.simulator_fwd(P, x, ea16, pl)
         finally:
             self._wi_exit("fwd", prev)
@@ -801,10 +804,12 @@ class Engine:
 
     def backward(self, P, ctx, gloss, grads, pl):
         """gloss [B,4] = dL/d(cont, mom_x, mom_y, press); fills `grads` (name -> preallocated tensor)."""
-        self.prepare_transposes(P)
-        prev = self._wi_enter("bwd", P)
+        with self.fork():   # transposed copies + their images: beside the finite-volume adjoint
+            self.prepare_transposes(P)
+            prev = self._wi_enter("bwd", P)
         try:
             g_dec = self.fvm_bwd(ctx["fvm"], gloss, pl)
+            self.join()
             self.simulator_bwd(P, ctx["sim"], g_dec, grads, pl)
             self.join()
         finally:
