@@ -79,6 +79,10 @@ def test_full_size_forward_backward_matches_oracle(bench_mesh):
     loss = _loss(out)
     assert abs(float(loss) - float(oloss)) < 3 * TOL * abs(float(oloss))   # carries the oracle's pooling error
     loss.backward()
+    import os
+    from gfv import lib as L
+    # the bench configuration in the form bench.py times by default: chain products as split-fp16 on the f16 MFMA pipe
+    assert (L.load().gfv_rowtile_last_path() >= 5) == (os.environ.get("GFV_F16SPLIT", "1") != "0")
     # gradients are sums over 25 k nodes / 75 k edges of mixed-sign terms: the fp32 oracle itself carries ~1e-4 of
     # summation noise in the small tensors at this size, so the comparison is norm-wise per tensor (3e-3, with a floor
     # of 1e-4 of the global gradient norm) - the element-wise 1e-4 bar is applied at the sizes of test_model_gpu.py
