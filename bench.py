@@ -7,9 +7,17 @@ batch resident on the device) on the synthetic ~50k-cell cylinder mesh (BASELINE
 
 One process per GPU; every rank owns `--meshes-per-gpu` meshes (weak scaling, graphs sharded by rank) and
 the flat fp32 gradient (4.7 MB) is all-reduced with RCCL before the fused Adam step.  Rank 0 prints ONE JSON line.
-`roofline` is measured live with HIP events around every launch of the dominant kernel (an instrumented pass of
-the same step); `cpu_baseline` times the oracle (oracle/fvgn_oracle.py, the CPU restatement pinned to the reference)
-on the host cores for a bounded number of steps of the same workload.
+
+What the line carries (DESIGN.md 5 explains every figure):
+  value / ms_per_step   K-step timed loops bracketed by barrier + synchronize, repeated until `--min-time` seconds have
+                        been timed (so the device is visibly busy); value = all timed steps / all timed seconds, no picking
+  step_modes            the same step timed as eager launches AND as hipGraph replay (the faster one runs the timed loops)
+  roofline              the dominant kernel, measured live with HIP events around every launch (single stream, eager)
+  roofline_kernels      every kernel class of the step (chains, weight gradients, segmented reduce, slice attention,
+                        finite-volume, reductions, weight images, input preparation / Adam) with algorithmic flops / bytes
+  roofline_step         SURVEY.md 8(d) COMPULSORY bytes of the whole step over the step time and 8 TB/s (frac_compulsory),
+                        per class and for the step, and the share of the single-stream step the priced launches cover
+  cpu_baseline          the oracle (oracle/fvgn_oracle.py, the CPU restatement pinned to the reference) on the host cores
 """
 from __future__ import annotations
 
@@ -30,15 +38,21 @@ import torch
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, exact fp32
 PEAK_F16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense f16 / bf16 MFMA peak (no sparsity)
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec
+N_PARAMS = 1181539             # TransFVGN_v2, hidden 128, mp 3
 
 
-def build_workload(cells, meshes, rank, device):
+def build_workload(workload, cells, meshes, rank, device):
     from gfv import meshgen
     from gfv.graph import build_batch
-    nx, ny = meshgen.cylinder_grid_for_cells(cells)
     ms, fs = [], []
     for i in range(meshes):
-        raw = meshgen.raw_tri_channel_cylinder(nx=nx, ny=ny, jitter=0.2, seed=1234 + rank * meshes + i)
+        seed = 1234 + rank * meshes + i
+        if workload == "cavity":      # BASELINE.json configs[1]: lid-driven cavity, n x n quads (71 x 71 = 5 041 cells)
+            n = max(2, int(round(cells ** 0.5)))
+            raw = meshgen.raw_quad_cavity(n=n, jitter=0.0, seed=seed)
+        else:                         # configs[2]: triangulated channel with a cylinder, ~cells cells
+            nx, ny = meshgen.cylinder_grid_for_cells(cells)
+            raw = meshgen.raw_tri_channel_cylinder(nx=nx, ny=ny, jitter=0.2, seed=seed)
         m = meshgen.finish_mesh(raw)
         ms.append(m)
         fs.append(meshgen.random_fields(m, seed=1 + rank * meshes + i))
@@ -51,6 +65,23 @@ def build_workload(cells, meshes, rank, device):
 def algorithmic_step_flops(sz, mp=3):
     # forward FLOPs per node / per edge (H=128, TransFVGN_v2), step = 3x forward
     return 3.0 * (1330944.0 * sz["N"] + 1052416.0 * sz["E"])
+
+
+def compulsory_step_bytes(sz):
+    """SURVEY.md 8(d) convention: every distinct input element read once, every output element written once, int32
+    indices; a step = forward + ~2x backward.  Per class (bytes per STEP):
+      gnn   6 GnBlocks x (1584 E + 3584 N) forward (8d), + encoders (read x 48 N, edge_attr 60 E; write 512 N + 512 E),
+            decoder (512 N in, 12 N out), 2 Transolver blocks as Linear layers only (in/out 512 N each per Linear pair:
+            3 passes of 1024 N) - all x3 for the step
+      slice 2 blocks x (x_mid 512 N in + slice weights 1024 N out/in + out 512 N) x3
+      fvm   WLSQ 28 Ex + 408 N, interpolation / flux 100 Sigma (8d: ~15 MB at 50 k cells), x3
+      misc  Adam 28 B / parameter (8d), input preparation 108 N + 72 E once"""
+    N, E, Ex, Sg = sz["N"], sz["E"], sz["Ex"], sz["Sigma"]
+    gnn = 3.0 * (6 * (1584.0 * E + 3584.0 * N) + (48.0 + 512.0) * N + (60.0 + 512.0) * E + 524.0 * N + 2 * 3 * 1024.0 * N)
+    slc = 3.0 * 2 * 2048.0 * N
+    fvm = 3.0 * (28.0 * Ex + 408.0 * N + 100.0 * Sg)
+    misc = 28.0 * N_PARAMS + 108.0 * N + 72.0 * E
+    return {"gnn": gnn, "slice": slc, "fvm": fvm, "misc": misc}
 
 
 def cpu_baseline(graphs_cpu, budget_s, max_steps=3):
@@ -79,14 +110,19 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", choices=("cylinder", "cavity"), default="cylinder",
+                    help="cylinder: BASELINE configs[2] (~50k-cell tri mesh, the headline); cavity: configs[1] (use --cells 5041)")
     ap.add_argument("--cells", type=int, default=50000)
     ap.add_argument("--meshes-per-gpu", type=int, default=1)
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
     ap.add_argument("--graph", choices=("auto", "on", "off"), default="auto",
-                    help="hipGraph replay of the step; auto = time a few warm-up steps both ways and keep the faster "
-                         "(eager launches overlap the side stream better, graph replay needs no host time)")
+                    help="hipGraph replay of the step; auto = time both ways (reported as step_modes) and keep the faster")
+    ap.add_argument("--min-time", type=float, default=2.0,
+                    help="repeat the timed K-step loop until this many seconds have been timed (0: exactly one loop)")
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU work for the cpu_baseline leg (0 = skip)")
     ap.add_argument("--profile-steps", type=int, default=3)
+    ap.add_argument("--allow-shared-gpu", action="store_true",
+                    help="self-test only: let several ranks share one GPU (the JSON then says so in distinct_gpus)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -94,13 +130,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world == 1:
         raise SystemExit("launch with torch.distributed.run for --gpus > 1 (one process per GPU)")
-    if not torch.cuda.is_available():
+    ndev = torch.cuda.device_count()   # (counting devices does not initialise the GPU)
+    if ndev < 1:
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
-    ndev = torch.cuda.device_count()
-    dev_index = local_rank % max(ndev, 1)  # one rank per GPU on the 8-GPU node; ranks share GPU 0 only in the 1-GPU self-test
+    if world > ndev and not args.allow_shared_gpu:
+        raise SystemExit(f"WORLD_SIZE={world} > {ndev} visible GPUs: one rank per GPU is the contract "
+                         "(--allow-shared-gpu for the single-GPU self-test)")
+    dev_index = local_rank % ndev
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
-    if world > 1:
+    backend = None
+    if world > 1 or os.environ.get("GFV_DIST_FORCE") == "1":
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("GFV_DIST_BACKEND", "nccl")  # "nccl" IS RCCL on ROCm; "gloo" only for the self-test
@@ -108,6 +148,7 @@ def main():
             dist.init_process_group("nccl", device_id=device)
         else:
             dist.init_process_group(backend)
+    dist_on = backend is not None
 
     from gfv import lib as L
     from gfv.params import default_params
@@ -115,61 +156,77 @@ def main():
     from FVMmodel.importer import NNmodel
     lib = L.load()
 
-    graphs_cpu, sz = build_workload(args.cells, args.meshes_per_gpu, rank, device)
+    graphs_cpu, sz = build_workload(args.workload, args.cells, args.meshes_per_gpu, rank, device)
     graphs = tuple(g.clone().to(device) for g in graphs_cpu)
     torch.manual_seed(0)  # identical initial weights on every rank (data parallel replicas)
     # dataset_size=1: the solve-script regime (solve_with_grad_GPU.py), where the online Normalizer never accumulates
     # and is the identity (utils/normalization.py:39); a single mesh has constant conditioning columns.
     model = NNmodel(default_params(dataset_size=1)).to(device)
     graph_mode = "off" if args.no_graph else args.graph
-    ts = TrainStep(model, graphs, world_size=world, use_graph=(graph_mode != "off"))
+    ts = TrainStep(model, graphs, world_size=world, use_graph=False, distributed=dist_on)
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_on:
             dist.barrier()
             torch.cuda.synchronize()
 
+    def timed(n):
+        barrier()
+        tc = time.perf_counter()
+        for _ in range(n):
+            ts.step()
+        barrier()
+        el = time.perf_counter() - tc
+        if dist_on:
+            t = torch.tensor([el], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el
+
     for _ in range(args.warmup):
         ts.step()
-    if graph_mode == "auto":
-        # both ways are the same launches in the same order; which one is faster depends on the host (eager needs ~270
-        # launches per step from Python) - decide on this box, all ranks alike (rank 0's measurement is broadcast)
-        cal = {}
-        for mode in (True, False):
-            ts.use_graph = mode
-            for _ in range(3):
-                ts.step()
-            barrier()
-            tc = time.perf_counter()
-            for _ in range(10):
-                ts.step()
-            barrier()
-            cal[mode] = time.perf_counter() - tc
-        pick = torch.tensor([1 if cal[True] <= cal[False] else 0], device=device)
-        if world > 1:
-            dist.broadcast(pick, src=0)
-        ts.use_graph = bool(pick.item())
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
+    # the same launches in the same order, as eager launches and as one hipGraph replay: both are measured and reported;
+    # the timed loops use the faster (all ranks alike: rank 0's decision is broadcast)
+    modes = {}
+    cal_steps = max(5, min(20, args.steps))
+    for name, flag in (("eager", False), ("hip_graph", True)):
+        if (graph_mode == "off" and flag) or (graph_mode == "on" and not flag):
+            continue
+        ts.use_graph = flag
+        for _ in range(3):
+            ts.step()
+        modes[name] = timed(cal_steps) / cal_steps
+    pick = torch.tensor([1 if modes.get("hip_graph", 1e9) <= modes.get("eager", 1e9) else 0], device=device)
+    if dist_on:
+        dist.broadcast(pick, src=0)
+    ts.use_graph = bool(pick.item())
+    for _ in range(2):
         ts.step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+
+    reps, elapsed = [], 0.0
+    while True:
+        el = timed(args.steps)           # EXACTLY K steps between barrier + synchronize on both sides
+        reps.append(el)
+        elapsed += el
+        if elapsed >= args.min_time or len(reps) >= 200:
+            break
+    timed_steps = args.steps * len(reps)
+    ms_per_step = 1e3 * elapsed / timed_steps
     final_loss = float(ts.loss.item())
 
-    # ---- roofline leg: same step, eager, HIP events around every launch of the main kernels -----------------
+    # ---- roofline leg: same step, eager, HIP events around every launch --------------------------------------------
     # every rank runs the instrumented steps (they contain the gradient all-reduce); rank 0 reports.  The timed region
     # above runs the weight-gradient kernels on a side stream, concurrently with the dX chains; here every kernel is
     # launched on ONE stream so that its duration is its own (concurrent kernels share the CUs and stretch each other).
     roof, roof_all = None, []
     ts_use_graph, eng_overlap = ts.use_graph, ts.engine.overlap
     ts.use_graph, ts.engine.overlap = False, False
+    for _ in range(2):
+        ts.step()
+    single_stream_ms = 1e3 * timed(5) / 5          # the un-instrumented single-stream eager step the classes must add up to
     lib.gfv_profile_reset()
+    lib.gfv_profile_set_sizes(float(2 * sz["Ex"] + 2 * sz["B"]), float(sz["Sigma"]))
     lib.gfv_profile_enable(1)
     args.profile_steps = max(1, args.profile_steps)
     for _ in range(args.profile_steps):
@@ -178,20 +235,27 @@ def main():
     lib.gfv_profile_enable(0)
     ts.use_graph, ts.engine.overlap = ts_use_graph, eng_overlap
     executed_flops = 0.0
+    step_roof = None
     if rank == 0:
         out = (ctypes.c_double * 4)()
-        # names as rocprofv3 prints them (profiles/*_kernel_stats.csv)
-        # the chain kernels run their fp32 products as 3 f16 MFMAs per product group (include/gfv.h): their matrix
-        # roofline is the f16 MFMA peak / 3 in fp32-equivalent flops; every kernel is priced against BOTH rooflines
-        # (algorithmic flops and algorithmic bytes over the measured duration) and reported on the one it sits closer to
+        # names as rocprofv3 prints them (profiles/*_kernel_stats.csv).  The chain kernels run their fp32 products as 3 f16
+        # MFMAs per product group (include/gfv.h): their matrix roofline is the f16 MFMA peak / 3 in fp32-equivalent
+        # flops; every kernel is priced against BOTH rooflines (algorithmic flops and algorithmic bytes over the measured
+        # duration) and reported on the one it sits closer to
         h = ", true>" if ts.engine.f16split else ", false>"
         chain_peak = PEAK_F16_MFMA_TFLOPS / 3.0 if ts.engine.f16split else PEAK_F32_MFMA_TFLOPS
-        spec = {7: ("tchain_kernel<1, 0, false" + h, chain_peak), 8: ("tchain_kernel<1, 1, false" + h, chain_peak),
-                9: ("tchain_kernel<1, 2, false" + h, chain_peak), 10: ("tchain_kernel<1, 0, true" + h, chain_peak),
-                1: ("rowtile_chain_kernel", PEAK_F32_MFMA_TFLOPS),
-                2: ("dw_multi_h_kernel" if ts.engine.f16split else "dw_multi_kernel", chain_peak),
-                3: ("seg_gather_sum_vec", None)}
-        for kind, (kname, mfma_peak) in spec.items():
+        spec = {7: ("tchain_kernel<1, 0, false" + h, chain_peak, "gnn"), 8: ("tchain_kernel<1, 1, false" + h, chain_peak, "gnn"),
+                9: ("tchain_kernel<1, 2, false" + h, chain_peak, "gnn"), 10: ("tchain_kernel<1, 0, true" + h, chain_peak, "gnn"),
+                1: ("rowtile_chain_kernel", PEAK_F32_MFMA_TFLOPS, "gnn"),
+                2: ("dw_multi_h_kernel" if ts.engine.f16split else "dw_multi_kernel", chain_peak, "gnn"),
+                3: ("seg_gather_sum_vec", None, "gnn"),
+                11: ("reduce_partials_*", None, "gnn"),
+                4: ("slice_* / deslice (Transolver slice attention)", None, "slice"),
+                5: ("wlsq_* / face_* / cell_* / node_bwd / graph_loss (finite volume)", None, "fvm"),
+                12: ("wimg / wabsmax / transpose_batch (per-step weight images)", None, "misc"),
+                6: ("input preparation, train_loss, adam", None, "misc")}
+        class_ms = {}
+        for kind, (kname, mfma_peak, cls) in spec.items():
             lib.gfv_profile_collect(kind, out)
             n, ms, fl, by = out[0], out[1], out[2], out[3]
             if n == 0:
@@ -205,22 +269,40 @@ def main():
                 bound, ach, peak, unit = "mfma", tf, mfma_peak, "TFLOP/s"
             else:
                 bound, ach, peak, unit = "hbm", gbs, PEAK_HBM_GBS, "GB/s"
-            roof_all.append({"kernel": kname, "bound": bound, "achieved": round(ach, 3), "peak": round(peak, 1), "unit": unit,
-                             "frac": round(ach / peak, 4), "traffic": None, "launches_per_step": n / args.profile_steps,
+            class_ms[cls] = class_ms.get(cls, 0.0) + ms / args.profile_steps
+            roof_all.append({"kernel": kname, "class": cls, "bound": bound, "achieved": round(ach, 3), "peak": round(peak, 1),
+                             "unit": unit, "frac": round(ach / peak, 4), "traffic": None,
+                             "launches_per_step": n / args.profile_steps,
                              "avg_launch_us": round(1e3 * ms / n, 2), "ms_per_step": round(ms / args.profile_steps, 4),
                              "fp32_equiv_tflops": round(tf, 3), "algorithmic_gbs": round(gbs, 1),
                              "frac_mfma": round(f_mfma, 4), "frac_hbm": round(f_hbm, 4)})
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        traffic_source = None
         # the committed PMC figures were collected on the default workload (one 50 k-cell mesh per GPU)
-        if os.path.exists(pmc) and args.meshes_per_gpu == 1 and args.cells == 50000:
+        if os.path.exists(pmc) and args.meshes_per_gpu == 1 and args.cells == 50000 and args.workload == "cylinder":
             traffic = json.load(open(pmc))
+            traffic_source = ("profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of this "
+                              "command (profiles/collect.sh), bytes per launch; NOT measured in this run")
             for r in roof_all:
                 r["traffic"] = traffic.get(r["kernel"])
         if roof_all:
             roof = max(roof_all, key=lambda r: r["ms_per_step"])
+        comp = compulsory_step_bytes(sz)
+        priced_ms = sum(class_ms.values())
+        step_roof = {
+            "compulsory_bytes_per_step": {k: round(v) for k, v in comp.items()} | {"total": round(sum(comp.values()))},
+            "frac_compulsory": round(sum(comp.values()) / (ms_per_step * 1e-3) / (PEAK_HBM_GBS * 1e9), 4),
+            "frac_compulsory_by_class": {k: round(comp[k] / (class_ms[k] * 1e-3) / (PEAK_HBM_GBS * 1e9), 4)
+                                         for k in comp if class_ms.get(k)},
+            "class_ms_per_step_single_stream": {k: round(v, 4) for k, v in class_ms.items()},
+            "priced_ms_per_step": round(priced_ms, 4), "single_stream_eager_ms_per_step": round(single_stream_ms, 4),
+            "priced_share_of_single_stream_step": round(priced_ms / single_stream_ms, 4),
+            "priced_launch_records_per_step": sum(r["launches_per_step"] for r in roof_all),
+            "convention": "SURVEY.md 8(d): distinct inputs read once, outputs written once, int32 indices; step = 3 x forward",
+        }
 
     lib.gfv_profile_reset()
-    if world > 1:
+    if dist_on:
         dist.barrier()
 
     # ---- the same step with every GEMM product on the fp32 MFMA (the form without the fp16 split), for the record ----
@@ -231,17 +313,8 @@ def main():
         lib.gfv_set_f16split(0)
         for _ in range(3):
             ts.step()
-        barrier()
-        t0 = time.perf_counter()
         nf = max(5, min(20, args.steps))
-        for _ in range(nf):
-            ts.step()
-        barrier()
-        el = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([el], dtype=torch.float64, device=device)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            el = float(t.item())
+        el = timed(nf)
         lib.gfv_set_f16split(1)
         ts.use_graph, ts.engine.f16split = ts_use_graph, True
         fp32_form = {"value": round(world * args.meshes_per_gpu * nf / el, 3), "ms_per_step": round(1e3 * el / nf, 4),
@@ -260,35 +333,45 @@ def main():
 
     if rank == 0:
         total_meshes = world * args.meshes_per_gpu
-        value = total_meshes * args.steps / elapsed
+        value = total_meshes * timed_steps / elapsed
+        wl = ("cylinder_flow tri mesh" if args.workload == "cylinder" else "lid_driven_cavity quad mesh") + \
+            ", TransFVGN_v2 (hidden 128, mp 3), 2nd-order WLSQ, conserved form"
         line = {
-            "metric": "training iters/sec, 50k-cell cylinder mesh (fwd + loss + bwd + Adam, batch resident in HBM)",
+            "metric": f"training iters/sec, {sz['C'] // 1000}k-cell {args.workload} mesh (fwd + loss + bwd + Adam, batch resident in HBM)",
             "value": round(value, 3), "unit": "mesh-train-iters/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "timed": {"loops": len(reps), "steps_per_loop": args.steps, "timed_steps": timed_steps,
+                      "timed_seconds": round(elapsed, 4), "min_time": args.min_time,
+                      "loop_ms_per_step_min_max": [round(1e3 * min(reps) / args.steps, 4), round(1e3 * max(reps) / args.steps, 4)]},
+            "step_modes": {k + "_ms_per_step": round(1e3 * v, 4) for k, v in modes.items()} | {"used": "hip_graph" if ts.use_graph else "eager"},
             "dtype_note": ("fp32 values end to end; the products of the fused GEMM chains run as 3 f16 MFMAs on exact (hi, lo) "
                            "fp16 splits of the fp32 operands with fp32 accumulation (error <= the f32 MFMA's, parity tests at 1e-5)"
                            if ts.engine.f16split else "fp32 MFMA"),
-            "config": {"workload": "cylinder_flow tri mesh, TransFVGN_v2 (hidden 128, mp 3), 2nd-order WLSQ, conserved form",
-                       "cells": sz["C"], "nodes": sz["N"], "faces": sz["E"], "meshes_per_gpu": args.meshes_per_gpu,
-                       "global_batch": total_meshes, "parallelism": f"dp{world}", "hip_graph": bool(ts.use_graph),
-                       "final_loss": round(final_loss, 6)},
-            "roofline": ({k: roof[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")} | {"kernel": roof["kernel"]})
-            if roof else None,
+            "config": {"workload": wl, "cells": sz["C"], "nodes": sz["N"], "faces": sz["E"],
+                       "meshes_per_gpu": args.meshes_per_gpu, "global_batch": total_meshes, "parallelism": f"dp{world}",
+                       "hip_graph": bool(ts.use_graph), "final_loss": round(final_loss, 6)},
+            "rccl_ranks": (dist.get_world_size() if dist_on else 0), "dist_backend": (dist.get_backend() if dist_on else None),
+            "distinct_gpus": min(world, ndev),
+            "roofline": ({k: roof[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")}
+                         | {"kernel": roof["kernel"], "traffic_source": traffic_source}) if roof else None,
+            "roofline_step": step_roof,
             "roofline_kernels": roof_all,
             "fp32_mfma_form": fp32_form,
             # reference algorithm vs what the launches execute (EdgeBlock first layer factored through
             # the nodes, gfv/engine.py): the fraction of the fp32 MFMA peak is quoted on the EXECUTED flops
             "algorithmic_step_tflops": round(algorithmic_step_flops(sz) / 1e12, 4),
             "executed_step_tflops": round(executed_flops / 1e12, 4),
-            "step_mfma_frac": round(executed_flops / (elapsed / args.steps) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
-            "roofline_note": "per-kernel durations: HIP events, one stream, eager; value: hipGraph replay with dW on a side stream",
+            "step_mfma_frac": round(executed_flops / (ms_per_step * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+            "roofline_note": ("per-kernel durations: HIP events around every launch, ONE stream, eager (profile leg); value: "
+                              + ("hipGraph replay" if ts.use_graph else "eager launches")
+                              + (" with the weight gradients on a side stream" if ts.engine.overlap else "")),
             "cpu_baseline": cpu,
         }
         if cpu:
             line["gpu_over_cpu"] = round(value / cpu["value"], 1)
         print(json.dumps(line))
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 

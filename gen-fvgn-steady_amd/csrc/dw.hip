@@ -15,6 +15,19 @@
 #include "gfv_split.h"
 #include "../../include/gfv.h"
 
+__device__ int g_gfv_status_flags = 0;
+
+extern "C" int gfv_status_flags(int32_t* flags_out) {
+  int v = 0;
+  if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_gfv_status_flags), sizeof(int)) != hipSuccess) return GFV_ERR_LAUNCH;
+  if (v) {
+    const int zero = 0;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_gfv_status_flags), &zero, sizeof(int)) != hipSuccess) return GFV_ERR_LAUNCH;
+  }
+  if (flags_out) *flags_out = v;
+  return GFV_OK;
+}
+
 namespace {
 
 constexpr int SUB = 32;   // rows per staged sub-tile
@@ -199,8 +212,12 @@ __device__ __forceinline__ void dw_body(const DwLaunch& A, const gfv_dw_tile_t& 
 // G and A are split into (hi, lo) fp16 parts while they are staged, dW += G_lo^T A_hi + G_hi^T A_lo + G_hi^T A_hi with
 // fp32 accumulation - 3 MFMAs of 16 cycles per 16x16 output tile and sub-tile instead of 8 of 32.  The contraction
 // index is the row m, so a scale must be constant over the rows of a sub-tile: the gradient rows are scaled by ONE exact
-// power of two per slab, from max|G| over the slab (a first pass over the slab's G rows - they are re-read from L2 right
-// after); the activations (inputs, GELU / LayerNorm outputs: O(1)) are split unscaled, clamped to the fp16 range.
+// power of two per slab: the minimum of the per-16-row scales the chain launch that produced G left behind (tile.gscale;
+// no extra pass), or, for gradient rows that come from elsewhere, from max|G| over a first pass over the slab's rows.
+// On the activation side the free index is the COLUMN, so raw inputs (a_op == 0: encoder features with geometric columns
+// at mesh-spacing scale next to O(1) ones, latent rows) get one exact power of two per column and slab from a pass over
+// the slab's A rows (they are re-read from L2 right after); GELU / LayerNorm outputs (a_op 1 / 2, O(1) by construction)
+// are split unscaled, and a value beyond the fp16 range raises GFV_FLAG_DW_RANGE instead of being clamped.
 // LDS image per operand and sub-tile: [column tile 8][part 2] blocks of 64 lanes x 16 B in MFMA-fragment order (lane
 // (i, g) holds rows m = 8g..8g+7 of column 16 ct + i); column i of tile ct sits in lane slot i ^ (ct & 3), which spreads
 // the staging writes (a thread owns 4 consecutive rows of 4 columns: one 8-B piece per column and part) over the banks.
@@ -228,11 +245,22 @@ __device__ __forceinline__ void dw_body_h(const DwLaunch& A, const gfv_dw_tile_t
   const int m_end = min(m_beg + A.rows_per_slab, A.M);
 
   // ---- slab scale of the gradient rows ----
-  float gm = 0.f;
-  {
+  float* wred = reinterpret_cast<float*>(lds);
+  float sg;
+  if (T.gscale) {
+    // the producer left one power of two per group of 16 rows: the slab takes the smallest (slabs start at multiples of 32)
+    float smin = 8.5070592e37f;
+    for (int q = (m_beg >> 4) + tid; q < ((m_end + 15) >> 4); q += 256) smin = fminf(smin, T.gscale[q]);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) smin = fminf(smin, __shfl_xor(smin, o, 64));
+    if (lane == 0) wred[wave] = smin;
+    __syncthreads();
+    sg = fminf(fminf(wred[0], wred[1]), fminf(wred[2], wred[3]));
+    __syncthreads();
+  } else {
+    float gm = 0.f;
     // 8 independent row loads in flight per thread (rows clamped to the slab: a repeated row does not change a maximum)
-    int m = m_beg + r4;
-    for (; m < m_end; m += 64) {
+    for (int m = m_beg + r4; m < m_end; m += 64) {
       float4 v[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) v[u] = ld4(T.G, (size_t)min(m + 8 * u, m_end - 1), T.ldg, col, FULL ? 128 : T.n_out, gvec);
@@ -240,14 +268,47 @@ __device__ __forceinline__ void dw_body_h(const DwLaunch& A, const gfv_dw_tile_t
       for (int u = 0; u < 8; ++u)
         gm = fmaxf(fmaxf(gm, fmaxf(fabsf(v[u].x), fabsf(v[u].y))), fmaxf(fabsf(v[u].z), fabsf(v[u].w)));
     }
-  }
 #pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) gm = fmaxf(gm, __shfl_xor(gm, o, 64));
-  float* wred = reinterpret_cast<float*>(lds);
-  if (lane == 0) wred[wave] = gm;
-  __syncthreads();
-  const float sg = gfv_pow2_scale(fmaxf(fmaxf(wred[0], wred[1]), fmaxf(wred[2], wred[3])));
-  __syncthreads();
+    for (int o = 32; o >= 1; o >>= 1) gm = fmaxf(gm, __shfl_xor(gm, o, 64));
+    if (lane == 0) wred[wave] = gm;
+    __syncthreads();
+    sg = gfv_pow2_scale(fmaxf(fmaxf(wred[0], wred[1]), fmaxf(wred[2], wred[3])));
+    __syncthreads();
+  }
+
+  // ---- column scales of raw-input activations ----
+  float4 sa = make_float4(1.f, 1.f, 1.f, 1.f);   // this thread's 4 staging columns
+  if (T.a_op == 0 && m_beg < m_end) {
+    float4 cm = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int m = m_beg + r4; m < m_end; m += 64) {
+      float4 v[8], b[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int mm = min(m + 8 * u, m_end - 1);
+        const size_t row = T.idx ? (size_t)T.idx[mm] : (size_t)mm;
+        v[u] = ld4(T.A, row, T.ld, col, FULL ? 128 : T.width, avec);
+        b[u] = T.in_add ? ld4(T.in_add, row, T.ld, col, FULL ? 128 : T.width, avec) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        cm.x = fmaxf(cm.x, fabsf(v[u].x + b[u].x)); cm.y = fmaxf(cm.y, fabsf(v[u].y + b[u].y));
+        cm.z = fmaxf(cm.z, fabsf(v[u].z + b[u].z)); cm.w = fmaxf(cm.w, fabsf(v[u].w + b[u].w));
+      }
+    }
+    *reinterpret_cast<float4*>(&wred[r4 * 128 + col]) = cm;
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const float4 o = *reinterpret_cast<const float4*>(&wred[r * 128 + col]);
+      cm.x = fmaxf(cm.x, o.x); cm.y = fmaxf(cm.y, o.y); cm.z = fmaxf(cm.z, o.z); cm.w = fmaxf(cm.w, o.w);
+    }
+    sa = make_float4(gfv_pow2_scale(cm.x), gfv_pow2_scale(cm.y), gfv_pow2_scale(cm.z), gfv_pow2_scale(cm.w));
+    __syncthreads();
+  }
+  // the inverse column scales wait in LDS (behind the staging buffers) for the output stage
+  float* inv_sa = reinterpret_cast<float*>(lds + 2 * HBUF);
+  if (r4 == 0) *reinterpret_cast<float4*>(&inv_sa[col]) = make_float4(1.0f / sa.x, 1.0f / sa.y, 1.0f / sa.z, 1.0f / sa.w);
+  float amax = 0.f;   // a_op 1 / 2: range check of the unscaled split
 
   floatx4 acc[4][4];
 #pragma unroll
@@ -313,9 +374,8 @@ __device__ __forceinline__ void dw_body_h(const DwLaunch& A, const gfv_dw_tile_t
       }
       if (!live) { g[p] = zero; a[p] = zero; }
       dbacc.x += g[p].x; dbacc.y += g[p].y; dbacc.z += g[p].z; dbacc.w += g[p].w;
-      // fp16 range of the unscaled activations
-      a[p].x = fminf(fmaxf(a[p].x, -65000.f), 65000.f); a[p].y = fminf(fmaxf(a[p].y, -65000.f), 65000.f);
-      a[p].z = fminf(fmaxf(a[p].z, -65000.f), 65000.f); a[p].w = fminf(fmaxf(a[p].w, -65000.f), 65000.f);
+      a[p].x *= sa.x; a[p].y *= sa.y; a[p].z *= sa.z; a[p].w *= sa.w;   // (1 for a_op 1 / 2)
+      amax = fmaxf(fmaxf(amax, fmaxf(fabsf(a[p].x), fabsf(a[p].y))), fmaxf(fabsf(a[p].z), fabsf(a[p].w)));
     }
     put4(Gs, col + 0, g[0].x * sg, g[1].x * sg, g[2].x * sg, g[3].x * sg);
     put4(Gs, col + 1, g[0].y * sg, g[1].y * sg, g[2].y * sg, g[3].y * sg);
@@ -361,18 +421,21 @@ __device__ __forceinline__ void dw_body_h(const DwLaunch& A, const gfv_dw_tile_t
     buf ^= 1;
   }
 
+  if (!(amax <= 65504.f)) atomicOr(&g_gfv_status_flags, GFV_FLAG_DW_RANGE);   // (integer atomic; also catches NaN)
   const float inv = 1.0f / sg;
   float* ws = A.ws + (size_t)slab * A.ws_stride + T.out_off;
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int j = 0; j < 4; ++j) {
+    const int k = 64 * wk + 16 * j + nl;
+    const float inva = inv_sa[k];       // both scales are powers of two: undone one after the other, exactly
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) {
         const int n = 64 * wn + 16 * i + 4 * q + reg;
-        const int k = 64 * wk + 16 * j + nl;
-        if (FULL || (n < T.n_out && k < T.width)) ws[(size_t)n * T.ld_out + k] = acc[i][j][reg] * inv;
+        if (FULL || (n < T.n_out && k < T.width)) ws[(size_t)n * T.ld_out + k] = (acc[i][j][reg] * inv) * inva;
       }
+  }
 
   if (T.db_off >= 0) {
     float* red = reinterpret_cast<float*>(lds);  // safe: the loop ended with a barrier
@@ -396,7 +459,7 @@ __global__ __launch_bounds__(256, 2) void dw_multi_kernel(const DwLaunch A) {
 }
 
 __global__ __launch_bounds__(256, 2) void dw_multi_h_kernel(const DwLaunch A) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * HBUF];
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * HBUF + 512];   // + the inverse column scales
   static_assert(2 * HBUF >= 8 * LDT * 4, "the bias-gradient fold reuses the staging buffers");
   const gfv_dw_tile_t& T = A.tile[blockIdx.y];
   const bool full = (T.n_out == 128) && (T.width == 128) && ((T.ldg & 3) == 0) && ((T.ld & 3) == 0);
@@ -470,11 +533,10 @@ extern "C" size_t gfv_linear_dw_workspace_floats(int32_t M, int32_t n_out, int32
   return (size_t)(gfv_dw_slabs(M, 1, nullptr) + 2) * ((size_t)n_out * K + n_out + 4);
 }
 
-extern "C" int gfv_linear_dw_ex(const float* G, int32_t ldg, int32_t n_out, const gfv_seg_t* segs, int32_t nseg,
+extern "C" int gfv_linear_dw_gs(const float* G, int32_t ldg, int32_t n_out, const gfv_seg_t* segs, int32_t nseg,
                                 const float* in_add, int32_t a_op, const float* a_gamma, const float* a_beta, int32_t M,
-                                float* dW, int32_t reserved, float* db, float* workspace, int32_t accumulate,
+                                float* dW, const float* gscale, float* db, float* workspace, int32_t accumulate,
                                 void* stream) {
-  (void)reserved;
   if (nseg < 1 || nseg > 3 || n_out < 1 || n_out > 128 || M < 0) return GFV_ERR_ARG;
   int K = 0;
   for (int i = 0; i < nseg; ++i) K += segs[i].width;
@@ -489,6 +551,7 @@ extern "C" int gfv_linear_dw_ex(const float* G, int32_t ldg, int32_t n_out, cons
     t[i].a_op = a_op; t[i].a_gamma = a_gamma; t[i].a_beta = a_beta;
     t[i].out_off = koff; t[i].ld_out = K;
     t[i].db_off = (i == 0 && db) ? wfl : -1;
+    t[i].gscale = gscale;
     koff += segs[i].width;
   }
   const int slabs = gfv_dw_slabs(M, nseg, nullptr);
@@ -499,6 +562,15 @@ extern "C" int gfv_linear_dw_ex(const float* G, int32_t ldg, int32_t n_out, cons
   if (rc) return rc;
   if (db) rc = gfv_reduce_partials(tmp + wfl, 1, n_out, db, accumulate, stream);
   return rc;
+}
+
+extern "C" int gfv_linear_dw_ex(const float* G, int32_t ldg, int32_t n_out, const gfv_seg_t* segs, int32_t nseg,
+                                const float* in_add, int32_t a_op, const float* a_gamma, const float* a_beta, int32_t M,
+                                float* dW, int32_t reserved, float* db, float* workspace, int32_t accumulate,
+                                void* stream) {
+  (void)reserved;
+  return gfv_linear_dw_gs(G, ldg, n_out, segs, nseg, in_add, a_op, a_gamma, a_beta, M, dW, nullptr, db, workspace, accumulate,
+                          stream);
 }
 
 extern "C" int gfv_linear_dw(const float* G, int32_t ldg, int32_t n_out, const gfv_seg_t* segs, int32_t nseg,

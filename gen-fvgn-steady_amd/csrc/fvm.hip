@@ -7,6 +7,7 @@
 // cell-parallel) with no atomics, so results are deterministic; plans (CSR tables, permuted moment vectors,
 // normalised 5x5 matrices) are built once per mesh batch.
 #include "gfv_common.h"
+#include "gfv_prof.h"
 #include "../../include/gfv.h"
 
 namespace {
@@ -661,12 +662,14 @@ __global__ __launch_bounds__(256) void node_bwd_kernel(const NodeBwdArgs A) {
 
 extern "C" int gfv_phi_fwd(const float* dec, const float* y, const int32_t* node_type, const float* uv_old, float* phi,
                            int32_t N, int32_t mode, void* stream) {
+  GfvProfScope ps_(GFV_K_FVM, 0, 56.0 * N, stream);
   LAUNCH1D(phi_fwd_kernel, N, stream, dec, y, node_type, uv_old, phi, N, mode);
   return GFV_OK;
 }
 
 extern "C" int gfv_phi_bwd(const float* gphi, const float* dec, const int32_t* node_type, float* gdec, int32_t N,
                            int32_t mode, void* stream) {
+  GfvProfScope ps_(GFV_K_FVM, 0, 60.0 * N, stream);
   LAUNCH1D(phi_bwd_kernel, N, stream, gphi, dec, node_type, gdec, N, mode);
   return GFV_OK;
 }
@@ -684,6 +687,8 @@ extern "C" int gfv_phi_bwd(const float* gphi, const float* dec, const int32_t* n
 extern "C" int gfv_wlsq_fwd_ex(const float* phi, const int32_t* rowptr, const int32_t* outn, const float* Bp,
                                const float* An, const float* rn, float* grad, float* full, int32_t N, int32_t terms,
                                void* stream) {
+  // stencil entry = index + moment vector, per node phi + A + rn + grad
+  GfvProfScope ps_(GFV_K_FVM, 0, (4.0 + 4.0 * terms) * gfv_prof_size_S() + (32.0 + 4.0 * terms * terms + 4.0 * terms + 64.0) * N, stream);
   WLSQ_DISPATCH(terms, LAUNCH1D(wlsq_fwd_kernel<MM>, (long)N * 8, stream, phi, rowptr, outn, Bp, An, rn, grad, full, N));
   return GFV_OK;
 }
@@ -691,6 +696,7 @@ extern "C" int gfv_wlsq_fwd_ex(const float* phi, const int32_t* rowptr, const in
 extern "C" int gfv_wlsq_bwd_ex(const float* ggrad, const float* gfull, const float* An, const float* rn,
                                const int32_t* rowptr_o, const int32_t* inn, const float* Bo, const float* sumB,
                                float* grhs_ws, float* gphi, int32_t N, int32_t terms, void* stream) {
+  GfvProfScope ps_(GFV_K_FVM, 0, (4.0 + 4.0 * terms) * gfv_prof_size_S() + (64.0 + 4.0 * terms * terms + 4.0 * terms + 2 * 32.0 * terms + 32.0) * N, stream);
   if ((ggrad == nullptr) == (gfull == nullptr)) return GFV_ERR_ARG;
   const int nch = gfull ? 7 : 5;
   WLSQ_DISPATCH(terms, LAUNCH1D(wlsq_bwd_solve_kernel<MM>, (long)N * 8, stream, ggrad, gfull, An, rn, grhs_ws, N, nch));
@@ -722,6 +728,7 @@ extern "C" int gfv_wlsq_bwd(const float* ggrad, const float* An, const float* rn
 
 extern "C" int gfv_face_fwd(const float* phi, const float* grad, const int32_t* es, const int32_t* er, const float* pos,
                             const float* fpos, const int32_t* ftype, const float* y, float* Ff, int32_t E, void* stream) {
+  GfvProfScope ps_(GFV_K_FVM, 0, (8.0 + 8.0 + 4.0 + 64.0) * E, stream);   // indices, face centre, type, Ff out (node rows are cache hits)
   LAUNCH1D(face_fwd_kernel, E, stream, phi, grad, es, er, pos, fpos, ftype, y, Ff, E);
   return GFV_OK;
 }
@@ -731,6 +738,7 @@ extern "C" int gfv_cell_fwd_ex(const float* phi, const float* grad, const float*
                                const float* centroid, const float* area, const int32_t* cbatch, const float* theta,
                                const float* dt, const float* uvp_dim, const float* sigma, float* phic, float* cres,
                                float* uvp_cell, int32_t C, int32_t non_conserved, float* gradc, void* stream) {
+  GfvProfScope ps_(GFV_K_FVM, 0, 16.0 * gfv_prof_size_Sigma() + (4.0 + 8.0 + 4.0 + 4.0 + 32.0 + 16.0 + 12.0) * C, stream);
   if (non_conserved && !gradc) return GFV_ERR_ARG;
   CellArgs a{phi, grad, Ff, pos, crow, kface, knode, kS, ftype, centroid, area, cbatch, theta, dt, uvp_dim, sigma,
              phic, cres, uvp_cell, C, non_conserved ? 1 : 0, gradc};
@@ -749,6 +757,7 @@ extern "C" int gfv_cell_fwd(const float* phi, const float* grad, const float* Ff
 
 extern "C" int gfv_graph_loss(const float* cres, const int32_t* gcell_ptr, const float* theta, const float* sigma,
                               float* sums, float* losses, int32_t B, void* stream) {
+  GfvProfScope ps_(GFV_K_FVM, 0, 16.0 * gfv_prof_size_Sigma() / 3.0, stream);
   if (B <= 0) return GFV_OK;
   hipLaunchKernelGGL(graph_loss_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, cres, gcell_ptr, theta, sigma, sums,
                      losses);
@@ -760,6 +769,7 @@ extern "C" int gfv_cell_to_node(const float* phic, const int32_t* nrow, const in
                                 const float* centroid, const int32_t* node_type, const float* y, const int32_t* nbatch,
                                 const float* uvp_dim, const float* sigma, const float* phi, int32_t smooth, float* out,
                                 int32_t N, void* stream) {
+  GfvProfScope ps_(GFV_K_FVM, 0, 4.0 * gfv_prof_size_Sigma() + (4.0 + 8.0 + 4.0 + 8.0 + 32.0 + 12.0) * N, stream);
   LAUNCH1D(cell_to_node_kernel, N, stream, phic, nrow, ncell, pos, centroid, node_type, y, nbatch, uvp_dim, sigma, phi,
            smooth, out, N);
   return GFV_OK;
@@ -773,6 +783,7 @@ extern "C" int gfv_fvm_bwd_ex(const float* cres, const float* sums, const float*
                               const float* centroid, const float* area, float* gc_ws, float* gFf_ws, float* gphi,
                               float* ggrad, int32_t N, int32_t E, int32_t C, int32_t non_conserved, const float* gradc,
                               const float* phic, void* stream) {
+  GfvProfScope ps_(GFV_K_FVM, 0, 40.0 * gfv_prof_size_Sigma() + 32.0 * C + 140.0 * E + 120.0 * N, stream);
   if (non_conserved && (!gradc || !phic)) return GFV_ERR_ARG;
   const int mode = non_conserved ? 1 : 0;
   LAUNCH1D(cell_bwd_kernel, C, stream, cres, sums, gloss, cbatch, theta, sigma, gc_ws, C);

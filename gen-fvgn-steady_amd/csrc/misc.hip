@@ -2,6 +2,7 @@
 // Reference: FVMmodel/importer.py:54-93,114-130,166-178; utils/normalization.py:32-85; torch.optim.Adam defaults
 // (pre_train_Adam.py:79,191).  All HBM-bound elementwise / small-reduction work.
 #include "gfv_common.h"
+#include "gfv_prof.h"
 #include "../../include/gfv.h"
 
 namespace {
@@ -136,14 +137,24 @@ __global__ __launch_bounds__(256) void edge_attr_kernel(const float* __restrict_
   }
 }
 
-__global__ void adam_tick_kernel(float* step) { *step = *step + 1.0f; }
+// Adam (torch.optim.Adam defaults, pre_train_Adam.py:115): the step counter and the hyper-parameters live in device
+// memory, so a captured hipGraph follows lr changes (lr_scheduler.step() every epoch in both reference drivers).
+// state = {t, lr / (1 - b1^t), sqrt(1 - b2^t), reserved}: the bias corrections are formed in double like torch's host
+// code (fp32 powf at t = 1 is 1.3e-5 away), once per step by the tick kernel.
+// hyper = {lr, beta1, beta2, eps, grad_scale, 0, 0, 0}
+__global__ void adam_tick_kernel(float* state, const float* __restrict__ hyper) {
+  const float t = state[0] + 1.0f;
+  const double bc1 = 1.0 - pow((double)hyper[1], (double)t), bc2 = 1.0 - pow((double)hyper[2], (double)t);
+  state[0] = t;
+  state[1] = (float)((double)hyper[0] / bc1);
+  state[2] = (float)sqrt(bc2);
+}
 
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                                                   float* __restrict__ v, long n, const float* __restrict__ step, float lr,
-                                                   float b1, float b2, float eps, float grad_scale) {
-  const float t = *step;
-  const float bc1 = 1.0f - powf(b1, t), bc2 = 1.0f - powf(b2, t);
-  const float step_size = lr / bc1, bc2_sqrt = sqrtf(bc2);
+                                                   float* __restrict__ v, long n, const float* __restrict__ state,
+                                                   const float* __restrict__ hyper) {
+  const float step_size = state[1], bc2_sqrt = state[2];
+  const float b1 = hyper[1], b2 = hyper[2], eps = hyper[3], grad_scale = hyper[4];
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
     const float gi = g[i] * grad_scale;
     const float mi = m[i] * b1 + (1.0f - b1) * gi;
@@ -157,8 +168,9 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 // loss = mean_b log(w_p*L_p + w_c*L_c + w_m*L_mx + w_m*L_my) (pre_train_Adam.py:177-184) and its gradient wrt the
 // four per-graph residuals; losses layout [B,4] = (cont, momx, momy, press)
 __global__ void train_loss_kernel(const float* __restrict__ losses, int B, float wc, float wm, float wp,
-                                  float* __restrict__ loss, float* __restrict__ gloss) {
+                                  const float* __restrict__ hyper, float* __restrict__ loss, float* __restrict__ gloss) {
   __shared__ float red[64];
+  if (hyper) { wc = hyper[5]; wm = hyper[6]; wp = hyper[7]; }   // device-resident weights (captured steps follow them)
   const int tid = threadIdx.x;
   float s = 0.f;
   for (int b = tid; b < B; b += 64) {
@@ -186,6 +198,7 @@ inline int cap_grid(long n) {
 
 extern "C" int gfv_graph_norm_stats(const float* x, int32_t ldx, const int32_t* gnode_ptr, int32_t B, float* stats,
                                     void* stream) {
+  GfvProfScope ps_(GFV_K_MISC, 0, 12.0 * 0.0, stream);
   if (B <= 0) return GFV_OK;
   hipLaunchKernelGGL(graph_norm_stats_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, x, ldx, gnode_ptr, stats);
   GFV_CHECK_LAUNCH();
@@ -197,6 +210,7 @@ extern "C" int gfv_normalizer_blocks(int32_t N) { int g = (N + 255) / 256; retur
 extern "C" int gfv_normalizer_update(const float* x, int32_t ldx, int32_t N, int32_t accumulate, float* acc_count,
                                      float* num_acc, float* acc_sum, float* acc_sq, float* partial_ws, float* mean_std,
                                      void* stream) {
+  GfvProfScope ps_(GFV_K_MISC, 0, accumulate ? 36.0 * N : 0.0, stream);
   const int nb = gfv_normalizer_blocks(N);
   if (accumulate && N > 0) {
     hipLaunchKernelGGL(normalizer_partial_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, x, ldx, N, partial_ws);
@@ -210,6 +224,7 @@ extern "C" int gfv_normalizer_update(const float* x, int32_t ldx, int32_t N, int
 
 extern "C" int gfv_node_prep(float* x, int32_t ldx, const int32_t* batch, const float* stats, const float* uvp_dim,
                              const float* mean_std, int32_t norm_global, float* uv_old, int32_t N, void* stream) {
+  GfvProfScope ps_(GFV_K_MISC, 0, (96.0 + 4.0 + 8.0) * N, stream);
   if (N <= 0) return GFV_OK;
   hipLaunchKernelGGL(node_prep_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, ldx, batch, stats,
                      uvp_dim, mean_std, norm_global, uv_old, N);
@@ -219,6 +234,7 @@ extern "C" int gfv_node_prep(float* x, int32_t ldx, const int32_t* batch, const 
 
 extern "C" int gfv_edge_attr(const float* x, int32_t ldx, const float* pos, const int32_t* es, const int32_t* er,
                              float* out16, float* out15, int32_t E, void* stream) {
+  GfvProfScope ps_(GFV_K_MISC, 0, (8.0 + 64.0 + (out15 ? 60.0 : 0.0)) * E, stream);
   if (E <= 0) return GFV_OK;
   hipLaunchKernelGGL(edge_attr_kernel, dim3((E + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, ldx, pos, es, er,
                      out16, out15, E);
@@ -226,12 +242,13 @@ extern "C" int gfv_edge_attr(const float* x, int32_t ldx, const float* pos, cons
   return GFV_OK;
 }
 
-extern "C" int gfv_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float* step, float lr, float beta1,
-                             float beta2, float eps, float grad_scale, void* stream) {
+extern "C" int gfv_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, float* state, const float* hyper,
+                                 void* stream) {
+  GfvProfScope ps_(GFV_K_MISC, 0, 28.0 * (double)n, stream);   // p, g, m, v in; p, m, v out
   if (n <= 0) return GFV_OK;
-  hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step);
-  hipLaunchKernelGGL(adam_kernel, dim3(cap_grid(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long)n, step, lr,
-                     beta1, beta2, eps, grad_scale);
+  if (!state || !hyper) return GFV_ERR_ARG;
+  hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, state, hyper);
+  hipLaunchKernelGGL(adam_kernel, dim3(cap_grid(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long)n, state, hyper);
   GFV_CHECK_LAUNCH();
   return GFV_OK;
 }
@@ -239,8 +256,16 @@ extern "C" int gfv_adam_step(float* p, const float* g, float* m, float* v, int64
 extern "C" int gfv_train_loss(const float* losses, int32_t B, float w_cont, float w_mom, float w_press, float* loss,
                               float* gloss, void* stream) {
   if (B <= 0) return GFV_ERR_ARG;
-  hipLaunchKernelGGL(train_loss_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, losses, B, w_cont, w_mom, w_press, loss,
-                     gloss);
+  hipLaunchKernelGGL(train_loss_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, losses, B, w_cont, w_mom, w_press,
+                     (const float*)nullptr, loss, gloss);
+  GFV_CHECK_LAUNCH();
+  return GFV_OK;
+}
+
+extern "C" int gfv_train_loss_dev(const float* losses, int32_t B, const float* hyper, float* loss, float* gloss, void* stream) {
+  GfvProfScope ps_(GFV_K_MISC, 0, 32.0 * B, stream);
+  if (B <= 0 || !hyper) return GFV_ERR_ARG;
+  hipLaunchKernelGGL(train_loss_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, losses, B, 0.f, 0.f, 0.f, hyper, loss, gloss);
   GFV_CHECK_LAUNCH();
   return GFV_OK;
 }

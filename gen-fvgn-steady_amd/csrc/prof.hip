@@ -7,10 +7,19 @@
 namespace {
 struct Rec { int kind; double flops, bytes; hipEvent_t a, b; };
 bool g_on = false;
+double g_S = 0, g_Sigma = 0;
 std::vector<Rec> g_recs;
 }  // namespace
 
 bool gfv_prof_enabled() { return g_on; }
+double gfv_prof_size_S() { return g_S; }
+double gfv_prof_size_Sigma() { return g_Sigma; }
+
+extern "C" int gfv_profile_set_sizes(double stencil_entries, double incidences) {
+  g_S = stencil_entries;
+  g_Sigma = incidences;
+  return 0;
+}
 
 void* gfv_prof_begin(int kind, double flops, double bytes, hipStream_t st) {
   if (!g_on) return nullptr;

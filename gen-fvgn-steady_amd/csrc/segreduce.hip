@@ -370,6 +370,7 @@ extern "C" int gfv_gather_pair(const float* a, const int32_t* s, const int32_t* 
 
 extern "C" int gfv_reduce_partials(const float* partial, int32_t n_chunks, int32_t n, float* out, int32_t accumulate,
                                    void* stream) {
+  GfvProfScope ps_(GFV_K_REDUCE, 0, 4.0 * ((double)n_chunks + 1.0) * n, stream);
   if (n <= 0) return GFV_OK;
   if (n <= 4096 && n_chunks >= 32) {
     hipLaunchKernelGGL(reduce_partials_small_kernel, dim3((n + 31) / 32), dim3(1024), 0, (hipStream_t)stream, partial,
@@ -391,6 +392,7 @@ extern "C" int gfv_reduce_partials(const float* partial, int32_t n_chunks, int32
 
 extern "C" int gfv_reduce_partials_2d(const float* partial, int32_t n_chunks, int64_t chunk_stride, int32_t rows,
                                       int32_t cols, int32_t ld_out, float* out, void* stream) {
+  GfvProfScope ps_(GFV_K_REDUCE, 0, 4.0 * ((double)n_chunks + 1.0) * rows * cols, stream);
   if (n_chunks <= 0 || rows <= 0 || cols <= 0) return GFV_OK;
   if ((cols & 3) || (ld_out & 3) || (chunk_stride & 3) || ld_out < cols ||
       ((reinterpret_cast<size_t>(partial) | reinterpret_cast<size_t>(out)) & 15))
@@ -404,6 +406,7 @@ extern "C" int gfv_reduce_partials_2d(const float* partial, int32_t n_chunks, in
 
 extern "C" int gfv_reduce_partials_seg(const float* partial, const int32_t* seg_ptr, int32_t n_seg, int32_t n, float* out,
                                        void* stream) {
+  GfvProfScope ps_(GFV_K_REDUCE, 0, 4.0 * 64.0 * n_seg * n, stream);
   if (n_seg <= 0 || n <= 0) return GFV_OK;
   if ((n & 3) || ((reinterpret_cast<size_t>(partial) | reinterpret_cast<size_t>(out)) & 15)) return GFV_ERR_ARG;
   hipLaunchKernelGGL(reduce_partials_seg_kernel, dim3((n / 4 + 63) / 64, n_seg), dim3(256), 0, (hipStream_t)stream,
@@ -442,6 +445,7 @@ __global__ __launch_bounds__(256) void transpose_batch_kernel(const gfv_transpos
 // All weight transposes of a step in one launch; descs lives in device memory.
 extern "C" int gfv_transpose_batch(const gfv_transpose_desc_t* descs, int32_t n, int32_t max_rows, int32_t max_cols,
                                    void* stream) {
+  GfvProfScope ps_(GFV_K_WIMG, 0, 8.0 * (double)n * max_rows * max_cols, stream);
   if (n <= 0) return GFV_OK;
   hipLaunchKernelGGL(transpose_batch_kernel, dim3((max_cols + 31) / 32, (max_rows + 31) / 32, n), dim3(256), 0,
                      (hipStream_t)stream, descs);
@@ -456,6 +460,7 @@ extern "C" int gfv_struct_size(int32_t which) {
     case 1: return (int)sizeof(gfv_layer_t);
     case 2: return (int)sizeof(gfv_rowtile_args_t);
     case 3: return (int)sizeof(gfv_wimg_desc_t);
+    case 4: return (int)sizeof(gfv_dw_tile_t);
     default: return -1;
   }
 }

@@ -5,6 +5,7 @@
 // The reference materialises [N,8,32,16] products twice per forward (28 % of its CPU time); here the per-node
 // work stays in registers and only w [N,8,32] and the per-graph tokens [B,8,32,16] touch memory.
 #include "gfv_common.h"
+#include "gfv_prof.h"
 #include "../../include/gfv.h"
 
 namespace {
@@ -520,6 +521,7 @@ __global__ __launch_bounds__(256) void slice_gw_kernel(const float* __restrict__
 
 extern "C" int gfv_slice_softmax_fwd(const float* xmid, const float* Ws, const float* bs, const float* temp, float* w,
                                      int32_t N, void* stream) {
+  GfvProfScope ps_(GFV_K_SLICE, 0, 1536.0 * N, stream);   // x_mid [N,128] in, w [N,8,32] out
   if (N <= 0) return N == 0 ? GFV_OK : GFV_ERR_ARG;
   hipLaunchKernelGGL(slice_softmax_fwd_kernel, dim3(gfv_div_up((long)N * H, 256)), dim3(256), 0, (hipStream_t)stream,
                      xmid, Ws, bs, temp, w, N);
@@ -532,6 +534,7 @@ extern "C" int gfv_slice_softmax_bwd_blocks(int32_t N) { return gfv_div_up((long
 extern "C" int gfv_slice_softmax_bwd(const float* xmid, const float* Ws, const float* bs, const float* temp,
                                      const float* w, const float* gw, float* gxmid, float* partial, int32_t N,
                                      void* stream) {
+  GfvProfScope ps_(GFV_K_SLICE, 0, 3072.0 * N, stream);   // x_mid, w, gw in, g_x_mid out
   if (N <= 0) return N == 0 ? GFV_OK : GFV_ERR_ARG;
   hipLaunchKernelGGL(slice_softmax_bwd_kernel, dim3(gfv_div_up((long)N * H, 256)), dim3(256), 0, (hipStream_t)stream,
                      xmid, Ws, bs, temp, w, gw, gxmid, partial, N);
@@ -541,6 +544,7 @@ extern "C" int gfv_slice_softmax_bwd(const float* xmid, const float* Ws, const f
 
 extern "C" int gfv_slice_token_partial(const float* w, const float* a, const int32_t* chunk_beg, const int32_t* chunk_end,
                                        int32_t n_chunks, float* partial, void* stream) {
+  GfvProfScope ps_(GFV_K_SLICE, 0, 64.0 * 1536.0 * n_chunks, stream);   // 64-node chunks: w + a rows in
   if (n_chunks <= 0) return n_chunks == 0 ? GFV_OK : GFV_ERR_ARG;
   hipLaunchKernelGGL(slice_token_partial_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, w, a, chunk_beg,
                      chunk_end, partial);
@@ -551,6 +555,7 @@ extern "C" int gfv_slice_token_partial(const float* w, const float* a, const int
 extern "C" int gfv_slice_attention_fwd(const float* partial, const int32_t* gchunk_ptr, int32_t B, const float* Wq,
                                        const float* Wk, const float* Wv, float* token, float* norm, float* attn,
                                        float* out_token, void* stream) {
+  GfvProfScope ps_(GFV_K_SLICE, 0, 60000.0 * B, stream);
   if (B <= 0) return B == 0 ? GFV_OK : GFV_ERR_ARG;
   AttnFwdArgs a{partial, gchunk_ptr, Wq, Wk, Wv, token, norm, attn, out_token};
   hipLaunchKernelGGL(slice_attention_fwd_kernel, dim3(B, H), dim3(256), 0, (hipStream_t)stream, a);
@@ -561,6 +566,7 @@ extern "C" int gfv_slice_attention_fwd(const float* partial, const int32_t* gchu
 extern "C" int gfv_slice_attention_bwd(const float* gpartial, const int32_t* gchunk_ptr, int32_t B, const float* Wq,
                                        const float* Wk, const float* Wv, const float* token, const float* norm,
                                        const float* attn, float* g_raw, float* g_norm, float* dW_partial, void* stream) {
+  GfvProfScope ps_(GFV_K_SLICE, 0, 100000.0 * B, stream);
   if (B <= 0) return B == 0 ? GFV_OK : GFV_ERR_ARG;
   AttnBwdArgs a{gpartial, gchunk_ptr, Wq, Wk, Wv, token, norm, attn, g_raw, g_norm, dW_partial};
   hipLaunchKernelGGL(slice_attention_bwd_kernel, dim3(B, H), dim3(256), 0, (hipStream_t)stream, a);
@@ -570,6 +576,7 @@ extern "C" int gfv_slice_attention_bwd(const float* gpartial, const int32_t* gch
 
 extern "C" int gfv_deslice(const float* w, const float* T, const int32_t* batch, float* out, int32_t N, int32_t accumulate,
                            void* stream) {
+  GfvProfScope ps_(GFV_K_SLICE, 0, 1536.0 * N, stream);   // w in, out [N,128]
   if (N <= 0) return N == 0 ? GFV_OK : GFV_ERR_ARG;
   hipLaunchKernelGGL(deslice_kernel, dim3(gfv_div_up((long)N * H, 256)), dim3(256), 0, (hipStream_t)stream, w, T, batch,
                      out, N, accumulate);
@@ -579,6 +586,7 @@ extern "C" int gfv_deslice(const float* w, const float* T, const int32_t* batch,
 
 extern "C" int gfv_slice_gw(const float* a, const float* T, const float* add, const int32_t* batch, float* gw, int32_t N,
                             int32_t accumulate, void* stream) {
+  GfvProfScope ps_(GFV_K_SLICE, 0, (accumulate ? 3072.0 : 1536.0) * N, stream);   // a in, gw out (+ gw in, fx_mid)
   if (N <= 0) return N == 0 ? GFV_OK : GFV_ERR_ARG;
   hipLaunchKernelGGL(slice_gw_kernel, dim3(gfv_div_up((long)N * H, 256)), dim3(256), 0, (hipStream_t)stream, a, T, add,
                      batch, gw, N, accumulate);

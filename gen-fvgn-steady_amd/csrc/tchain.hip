@@ -24,6 +24,7 @@
 // per-row power-of-two scaling; weights: pre-split image, one global scale), acc += w_lo x_hi + w_hi x_lo + w_hi x_hi:
 // 3 MFMAs of 16 cycles per (n-tile, 32 k) instead of 8 of 32, with the error of the f32 MFMA.  The LDS slice is the
 // image's (pass, T) block copied linearly: [nt][part][lane] x 16 B, conflict-free ds_read_b128 without a swizzle.
+#include <stdlib.h>
 #include "gfv_common.h"
 #include "gfv_prof.h"
 #include "gfv_split.h"
@@ -244,14 +245,27 @@ __device__ __forceinline__ void mma_slice(floatx4 (&acc)[T][8], const float (&ac
   }
 }
 
-// H: a slice is 16 KB contiguous in the image, copied linearly
+// H: a slice is 16 KB contiguous in the image, copied linearly by the NW waves of the workgroup (16 / NW chunks of 16 B
+// per thread: 4 for the 4-wave workgroup, 2 / 1 for the 8- / 16-wave ones that share one weight stream over more rows)
+template <int NW>
 __device__ __forceinline__ WRegs w_load_h(const float* slice, int tid) {
   WRegs r;
   r.a = *reinterpret_cast<const floatx4*>(slice + 4 * tid);
-  r.b = *reinterpret_cast<const floatx4*>(slice + 4 * tid + 1024);
-  r.c = *reinterpret_cast<const floatx4*>(slice + 4 * tid + 2048);
-  r.d = *reinterpret_cast<const floatx4*>(slice + 4 * tid + 3072);
+  if (NW <= 8) r.b = *reinterpret_cast<const floatx4*>(slice + 4 * tid + 256 * NW);
+  if (NW <= 4) {
+    r.c = *reinterpret_cast<const floatx4*>(slice + 4 * tid + 2048);
+    r.d = *reinterpret_cast<const floatx4*>(slice + 4 * tid + 3072);
+  }
   return r;
+}
+template <int NW>
+__device__ __forceinline__ void w_store_n(float* Wb, int tid, const WRegs& r) {
+  *reinterpret_cast<floatx4*>(Wb + 4 * tid) = r.a;
+  if (NW <= 8) *reinterpret_cast<floatx4*>(Wb + 4 * tid + 256 * NW) = r.b;
+  if (NW <= 4) {
+    *reinterpret_cast<floatx4*>(Wb + 4 * tid + 2048) = r.c;
+    *reinterpret_cast<floatx4*>(Wb + 4 * tid + 3072) = r.d;
+  }
 }
 
 // H: one 32-wide k group on the f16 pipe; LDS slice image [nt 8][part 2][lane 64] x 16 B; n-tiles >= 4 are skipped for
@@ -286,6 +300,15 @@ __device__ __forceinline__ float row_scale(const float (&v)[8][4]) {
   m = fmaxf(m, __shfl_xor(m, 16, 64));
   m = fmaxf(m, __shfl_xor(m, 32, 64));
   return gfv_pow2_scale(m);
+}
+// H: the scale of a group of 16 rows (= this wave's rows) is the smallest of its rows' scales; lane 0 leaves it for the
+// weight-gradient kernel (gfv_rowtile_args_t.gscale)
+__device__ __forceinline__ void group_scale_out(float* dst, float s, int lane) {
+  s = fminf(s, __shfl_xor(s, 1, 64));
+  s = fminf(s, __shfl_xor(s, 2, 64));
+  s = fminf(s, __shfl_xor(s, 4, 64));
+  s = fminf(s, __shfl_xor(s, 8, 64));
+  if (lane == 0) *dst = s;
 }
 // H: fp32 activations -> B-operand fragments of the four 32-groups: slots e = 0..3 <- act[2T][.], 4..7 <- act[2T+1][.]
 __device__ __forceinline__ void to_halves(const float (&v)[8][4], float sc, gfv_f16x8 (&xh)[4], gfv_f16x8 (&xl)[4]) {
@@ -401,14 +424,22 @@ __device__ __forceinline__ void load_segment(const gfv_rowtile_args_t& A, int si
 // RAG: also takes ragged shapes (first-layer K / segment widths that are not multiples of 32, unaligned rows, a last
 // layer narrower than 64): element-wise loads / stores on those pieces only
 // H: products on the f16 MFMA pipe from the layers' split-fp16 weight images (T = 1 only)
-template <int T, int LNM, bool RAG, bool H>
-__global__ __launch_bounds__(256, 2) void tchain_kernel(const gfv_rowtile_args_t A) {
+// NW: waves per workgroup (4; 8 exists in the H form for experiments): a workgroup owns 16 NW rows and ONE weight stream.
+// Per 64-row tile the three layers' images are 192 KB from L2 next to 256 KB of activations; an 8-wave workgroup (one per
+// CU at 2 waves / SIMD, the occupancy of two 4-wave ones) moves half the weight bytes and runs half the barrier rounds
+// per row - and was slower (see the launcher): 8 waves marching in lockstep through the slice barriers hide less latency
+// than two independent groups of 4.  The LayerNorm partials stay per 64-row tile (same sums, same order) either way.
+template <int T, int LNM, bool RAG, bool H, int NW = 4>
+__global__ __launch_bounds__(64 * NW, NW == 16 ? 4 : 2) void tchain_kernel(const gfv_rowtile_args_t A) {
   static_assert(!H || T == 1, "the f16 form is instantiated for 16 rows per wave");
-  __shared__ __attribute__((aligned(16))) float lds[2 * WS_FLOATS + 1024 + PAR_FLOATS];
+  static_assert(NW == 4 || (H && T == 1 && NW == 8), "the wide workgroup exists in the f16 form only");
+  constexpr int NT = 64 * NW;
+  __shared__ __attribute__((aligned(16))) float lds[2 * WS_FLOATS + 256 * NW + PAR_FLOATS];
   float* red = lds + 2 * WS_FLOATS;
-  float* par = red + 1024;  // bias of layer l at 128 l (N_l floats), LayerNorm gamma / beta: read from LDS in the epilogues
+  float* par = red + 256 * NW;  // bias of layer l at 128 l (N_l floats), LayerNorm gamma / beta: read from LDS in the epilogues
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, g = lane >> 4;
-  const int rowbase = blockIdx.x * (64 * T) + wave * (16 * T) + li;
+  const int rowbase = blockIdx.x * (16 * NW * T) + wave * (16 * T) + li;
+  const int rowgroup = blockIdx.x * NW + wave;   // H (T = 1): index of this wave's 16 rows
   // weight staging: thread -> row (tid>>3) + 32p, LDS slot tid&7, source chunk slot ^ ((row>>1)&7)
   const int wrow = tid >> 3;
   const int wc = 4 * ((tid & 7) ^ ((tid >> 4) & 7));
@@ -441,7 +472,7 @@ __global__ __launch_bounds__(256, 2) void tchain_kernel(const gfv_rowtile_args_t
       const float* bp = A.layer[l].bias;
       const float* b2 = A.layer[l].bias2;   // columns >= 128 of a row-stacked last layer
       const int nl = A.layer[l].N;
-      for (int c = tid; c < nl; c += 256) par[128 * l + c] = (b2 && c >= 128) ? b2[c - 128] : (bp ? bp[c] : 0.f);
+      for (int c = tid; c < nl; c += NT) par[128 * l + c] = (b2 && c >= 128) ? b2[c - 128] : (bp ? bp[c] : 0.f);
     }
   }
   {
@@ -450,7 +481,7 @@ __global__ __launch_bounds__(256, 2) void tchain_kernel(const gfv_rowtile_args_t
     const float* bp = (A.in_op == GFV_IN_LN) ? A.in_beta : A.fin_beta;
     if (in_ln || A.fin_op != GFV_FIN_PLAIN) {
       if (tid < 128) par[PAR_GAMMA + tid] = gp[tid];
-      else if (A.in_op == GFV_IN_LN || A.fin_op == GFV_FIN_LN) par[PAR_BETA + tid - 128] = bp[tid - 128];
+      else if (tid < 256 && (A.in_op == GFV_IN_LN || A.fin_op == GFV_FIN_LN)) par[PAR_BETA + tid - 128] = bp[tid - 128];
     }
   }
   int wbuf = 0;
@@ -458,10 +489,10 @@ __global__ __launch_bounds__(256, 2) void tchain_kernel(const gfv_rowtile_args_t
   WBlk cur = w_block<H>(A, 0, 0, 0);
   // weight pipeline: slice j+1 is loaded to registers while slice j feeds the MFMAs, then parked in the other LDS
   // buffer (prefetch distance 2 with a second register set was measured: no gain, +33 VGPRs)
-  WRegs wr0 = H ? w_load_h(cur.w, tid)
+  WRegs wr0 = H ? w_load_h<NW>(cur.w, tid)
                  : ((RAG && cur.rag) ? w_load_ragged(cur.w, cur.ldw, cur.nrows, 0, cur.kvalid, wrow, wc)
                                      : w_load(cur.w, cur.ldw, cur.nrows, wrow, wc));
-  w_store(lds, tid, wr0);
+  w_store_n<NW>(lds, tid, wr0);
   __syncthreads();
   TS(0);
 
@@ -504,6 +535,7 @@ __global__ __launch_bounds__(256, 2) void tchain_kernel(const gfv_rowtile_args_t
           if (H) {
             // every segment gets its own row scale; the accumulator follows (exact: powers of two)
             float sn = row_scale(act[0]);
+            if (A.gscale && chunk == 0 && pass == 0) group_scale_out(A.gscale + rowgroup, sn, lane);
             if (chunk > 0) {
               // a segment 2^40 below what the accumulator already holds cannot be resolved next to it anyway: its
               // scale is capped so that the ratio stays finite
@@ -528,7 +560,7 @@ __global__ __launch_bounds__(256, 2) void tchain_kernel(const gfv_rowtile_args_t
             const int wnr = more ? cur.nrows : nxt.nrows;
 #ifndef ABL_NOW
             if (H) {
-              wr0 = w_load_h(more ? cur.w + 4096 * (sl + 1) : nxt.w, tid);
+              wr0 = w_load_h<NW>(more ? cur.w + 4096 * (sl + 1) : nxt.w, tid);
             } else if (RAG && (more ? cur.rag : nxt.rag)) {
               wr0 = w_load_ragged(more ? cur.w : nxt.w, wld, wnr, more ? WK * (sl + 1) : 0, more ? cur.kvalid : nxt.kvalid,
                                   wrow, wc);
@@ -547,7 +579,7 @@ __global__ __launch_bounds__(256, 2) void tchain_kernel(const gfv_rowtile_args_t
             __builtin_amdgcn_sched_barrier(0);
 #endif
 #ifndef ABL_NOW
-            w_store(lds + (wbuf ^ 1) * WS_FLOATS, tid, wr0);
+            w_store_n<NW>(lds + (wbuf ^ 1) * WS_FLOATS, tid, wr0);
             TS(4);
             __syncthreads();
 #endif
@@ -603,6 +635,7 @@ __global__ __launch_bounds__(256, 2) void tchain_kernel(const gfv_rowtile_args_t
         }
         if (H) {
           sx = row_scale(act[0]);
+          if (A.gscale && L.op == GFV_OP_MUL_DGELU) group_scale_out(A.gscale + (size_t)(layer + 1) * A.gscale_ld + rowgroup, sx, lane);
           to_halves(act[0], sx, xh, xl);
         }
         TS_WAIT();
@@ -660,6 +693,11 @@ __global__ __launch_bounds__(256, 2) void tchain_kernel(const gfv_rowtile_args_t
             }
             ln_bwd(v, y, par + PAR_GAMMA, g, dgam, dbet);
           }
+          if (H && A.gscale && npass == 1 && A.nlayers <= 2 && L.op == GFV_OP_MUL_DGELU && !res) {
+            float rs = row_scale(v);             // (all lanes take part in the row / group reductions)
+            if (!live) rs = 8.5070592e37f;       // 2^126: a dead row never lowers the group's scale
+            group_scale_out(A.gscale + (size_t)A.nlayers * A.gscale_ld + rowgroup, rs, lane);
+          }
           if (live) {
 #ifndef ABL_NOSTORE
             if (pass == 0 && A.out_nores) {
@@ -705,16 +743,29 @@ __global__ __launch_bounds__(256, 2) void tchain_kernel(const gfv_rowtile_args_t
 #endif
   if (A.ln_partial) {
     __syncthreads();
-    const float s = red[tid] + red[256 + tid] + red[512 + tid] + red[768 + tid];
-    // ln_partial rows are indexed by 64-row tile: a T-tile workgroup owns T consecutive rows
-    A.ln_partial[(size_t)blockIdx.x * T * 256 + tid] = s;
+    // ln_partial rows are indexed by 64-row tile: every group of 4 waves folds its own (same sums, same order, whatever
+    // the workgroup width); a T-tile workgroup owns T consecutive rows
+    const int q = tid >> 8, t = tid & 255;
+    const float* rq = red + q * 1024;
+    const float s = rq[t] + rq[256 + t] + rq[512 + t] + rq[768 + t];
+    const size_t tile = (size_t)blockIdx.x * (NW / 4) * T + q * T;
+    if (tile < (size_t)((A.M + 63) / 64)) A.ln_partial[tile * 256 + t] = s;
 #pragma unroll
     for (int x = 1; x < T; ++x)
-      if (blockIdx.x * T + x < (A.M + 63) / 64) A.ln_partial[((size_t)blockIdx.x * T + x) * 256 + tid] = 0.f;
+      if (tile + x < (size_t)((A.M + 63) / 64)) A.ln_partial[(tile + x) * 256 + t] = 0.f;
   }
 }
 
 }  // namespace
+
+template <int NW>
+static void launch_h(const gfv_rowtile_args_t* args, int ragged, int lnm, hipStream_t stream) {
+  const dim3 wgs((args->M + 16 * NW - 1) / (16 * NW)), blk(64 * NW);
+  if (ragged) hipLaunchKernelGGL((tchain_kernel<1, 0, true, true, NW>), wgs, blk, 0, stream, *args);
+  else if (lnm == 0) hipLaunchKernelGGL((tchain_kernel<1, 0, false, true, NW>), wgs, blk, 0, stream, *args);
+  else if (lnm == 1) hipLaunchKernelGGL((tchain_kernel<1, 1, false, true, NW>), wgs, blk, 0, stream, *args);
+  else hipLaunchKernelGGL((tchain_kernel<1, 2, false, true, NW>), wgs, blk, 0, stream, *args);
+}
 
 // fast-path launcher used by gfv_rowtile_chain (rowtile.hip); ragged: the instantiation that also takes ragged shapes
 // (only without LayerNorm backward); f16: the split-fp16 form (every layer has a weight image)
@@ -722,10 +773,9 @@ int gfv_internal_tchain_launch(const gfv_rowtile_args_t* args, int ragged, int f
   const int lnm = args->in_op == GFV_IN_LNBWD ? 1 : (args->fin_op == GFV_FIN_LNBWD ? 2 : 0);
   const dim3 wgs((args->M + 63) / 64), blk(256);
   if (f16) {
-    if (ragged) hipLaunchKernelGGL((tchain_kernel<1, 0, true, true>), wgs, blk, 0, stream, *args);
-    else if (lnm == 0) hipLaunchKernelGGL((tchain_kernel<1, 0, false, true>), wgs, blk, 0, stream, *args);
-    else if (lnm == 1) hipLaunchKernelGGL((tchain_kernel<1, 1, false, true>), wgs, blk, 0, stream, *args);
-    else hipLaunchKernelGGL((tchain_kernel<1, 2, false, true>), wgs, blk, 0, stream, *args);
+    // (an 8-wave workgroup sharing one weight stream over 128 rows - launch_h<8> - was measured in round 2: 5.28 ms / step
+    // against 4.96 with it on the 75 k-row launches, 5.29 with it everywhere; the 4-wave form stays)
+    launch_h<4>(args, ragged, lnm, stream);
     return 0;
   }
   if (ragged) hipLaunchKernelGGL((tchain_kernel<1, 0, true, false>), wgs, blk, 0, stream, *args);

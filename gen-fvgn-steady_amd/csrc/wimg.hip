@@ -1,5 +1,6 @@
 // Split-fp16 weight images for the f16-MFMA form of the fused GEMM chain (contract: include/gfv.h, gfv_weight_images).
 #include "gfv_common.h"
+#include "gfv_prof.h"
 #include "gfv_split.h"
 #include "../../include/gfv.h"
 
@@ -57,6 +58,7 @@ extern "C" size_t gfv_weight_image_bytes(int32_t N, int32_t K) {
 }
 
 extern "C" int gfv_weight_absmax(const gfv_wimg_desc_t* descs_dev, int32_t n_desc, float* wmax, void* stream) {
+  GfvProfScope ps_(GFV_K_WIMG, 0, 4.0 * 1181539.0, stream);
   if (!descs_dev || !wmax || n_desc < 0) return GFV_ERR_ARG;
   if (hipMemsetAsync(wmax, 0, sizeof(float), (hipStream_t)stream) != hipSuccess) return GFV_ERR_LAUNCH;
   if (n_desc == 0) return GFV_OK;
@@ -67,6 +69,7 @@ extern "C" int gfv_weight_absmax(const gfv_wimg_desc_t* descs_dev, int32_t n_des
 
 extern "C" int gfv_weight_images(const gfv_wimg_desc_t* descs_dev, int32_t n_desc, int64_t max_frags, const float* wmax,
                                  void* stream) {
+  GfvProfScope ps_(GFV_K_WIMG, 0, 32.0 * (double)max_frags * n_desc, stream);
   if (!descs_dev || !wmax || n_desc < 0 || max_frags < 0) return GFV_ERR_ARG;
   if (n_desc == 0 || max_frags == 0) return GFV_OK;
   hipLaunchKernelGGL(wimg_kernel, dim3((unsigned)((max_frags + 255) / 256), n_desc), dim3(256), 0, (hipStream_t)stream,

@@ -13,6 +13,7 @@ import os
 
 import torch
 
+from . import cmdlist
 from . import lib as L
 from . import ops
 from .ops import LayerSpec, Seg
@@ -61,7 +62,8 @@ class GradStore:
 class Engine:
     def __init__(self, message_passing_num=3, integrator="imex", ncn_smooth=True, net="TransFVGN_v2", conserved_form=True,
                  order="2nd"):
-        self._dw_ws = None
+        self._dw_ws, self._dw_ws_main = None, None
+        self._pending = []
         self._wt, self._wt_key, self._wt_live = {}, None, False
         self.mp = message_passing_num
         self.mode = _MODE[integrator]
@@ -88,7 +90,8 @@ class Engine:
         self._keep = []
         # data parallel: (world, process group) set by TrainStep; the Normalizer statistics are exchanged inside the
         # forward, between accumulation and use
-        self.dist_world, self.dist_group = 1, None
+        self.dist_world, self.dist_group, self.dist_force = 1, None, False
+        self._retired = []   # superseded image sets / descriptor tables: kept alive while captured graphs may point at them
         # called once in the backward, when every gradient of the LAST processor and of the decoder has been launched
         # (TrainStep starts the all-reduce of that half of the flat gradient there, overlapped with the rest)
         self.bucket_hook = None
@@ -105,8 +108,10 @@ class Engine:
             if not e.overlap:
                 return self
             if e._side is None:
-                e._side = torch.cuda.Stream()
-            e._side.wait_stream(torch.cuda.current_stream())
+                # the dX chains on the main stream are the critical path; the weight-gradient work beside them is not:
+                # a low-priority queue lets the dispatcher prefer main-stream workgroups when both are pending
+                e._side = torch.cuda.Stream(priority=int(os.environ.get("GFV_SIDE_PRIO", "0")))
+            cmdlist.call(e._side.wait_stream, torch.cuda.current_stream())
             # tensors the side stream reads must outlive this call: the caching allocator would hand their blocks to
             # the next allocation on the main stream while the side stream is still reading them
             e._keep.extend(t for t in self.keep if t is not None)
@@ -122,10 +127,39 @@ class Engine:
     def fork(self, *keep):
         return Engine._Fork(self, keep)
 
+    def defer(self, fn, *keep):
+        """Queue parameter-gradient work (nothing downstream of the backward chain reads it) for the side stream.  The
+        queue is flushed ONCE per block (`flush`): every fork is an event on the main queue, ~6.5 us of bubble each
+        (rocprofv3 --kernel-trace), and a block used to fork three to five times.  Without the side stream the work runs
+        right here - results do not depend on where it runs (disjoint gradient blocks, fixed summation orders)."""
+        if not self.overlap:
+            fn()
+        else:
+            self._pending.append((fn, keep))
+
+    def flush(self, on_main=False):
+        """Launch the queued work on the side stream (one fork), or - `on_main` - on the main stream: the last pieces of
+        the backward have nothing left to hide behind, both queues then drain together."""
+        if not self._pending:
+            return
+        pend, self._pending = self._pending, []
+        if on_main:
+            ws, self._dw_ws = self._dw_ws, self._dw_ws_main   # the side stream may still be using its workspace
+            try:
+                for fn, _ in pend:
+                    fn()
+            finally:
+                self._dw_ws_main, self._dw_ws = self._dw_ws, ws
+            return
+        with self.fork(*[t for _, keep in pend for t in keep]):
+            for fn, _ in pend:
+                fn()
+
     def join(self):
         """Main stream waits for the side stream (call before anything reads the gradients)."""
+        self.flush()
         if self.overlap and self._side is not None:
-            torch.cuda.current_stream().wait_stream(self._side)
+            cmdlist.call(torch.cuda.current_stream().wait_stream, self._side)
         self._keep.clear()
 
     # ------------------------------------------------------------------------------------------------------------
@@ -146,6 +180,7 @@ class Engine:
         key = self._pkey(P, fresh=(phase == "fwd"))
         if self._wi_key != key:
             dev = next(iter(P.values())).device
+            self._retired.append((self._wi, self._wmax, self._wi_abs))
             self._wmax = torch.zeros((1,), dtype=torch.float32, device=dev)
             self._wi = {ph: ops.WeightImages(dev, self._wmax) for ph in ("fwd", "bwd")}
             self._wi["fwd"].add_static(P.values())
@@ -161,6 +196,13 @@ class Engine:
             wi.add_static(self._wt.values())
         wi.build()
         return ops.set_weight_images(wi)
+
+    def capture_signature(self):
+        """Identity of everything a captured step points at inside the engine (weight images, descriptor tables,
+        transposed copies); TrainStep drops its hipGraphs when it changes."""
+        wi = self._wi or {}
+        return (self._wi_key, self._wt_key, tuple((ph, len(w.images), None if w._desc is None else w._desc.data_ptr())
+                                                  for ph, w in sorted(wi.items())))
 
     def _wi_exit(self, phase, prev):
         if not self.f16split:
@@ -194,6 +236,7 @@ class Engine:
         if self._wt_key != key:
             import ctypes as C
             rows = []
+            self._retired.append((self._wt, getattr(self, "_wt_desc", None)))
             self._wt = {}
             dev = next(iter(P.values())).device
             for n, W in P.items():
@@ -284,26 +327,32 @@ class Engine:
         if g_add is not None:   # G + g_add is the gradient (added in the prologue, before the LayerNorm backward)
             assert ln, "the addend is folded into the LayerNorm-backward prologue"
             kw.update(in_add=g_add)
+        gs = _empty(dev, 3, ops.gscale_ld(M))   # per-16-row scales of (g3 | G, gz2, gz1) for the weight-gradient launch
         if outs is not None:
             if W1t is None:
                 W1t = self._T(W1)
-            ops.rowtile_chain(M, [gseg],
-                              [LayerSpec(W3t, None, L.OP_MUL_DGELU, save=gz2, aux=sv["z2"]),
-                               LayerSpec(W2t, None, L.OP_MUL_DGELU, save=gz1, aux=sv["z1"]), LayerSpec(W1t)],
-                              outs, res=res, **kw)
+            have = ops.rowtile_chain(M, [gseg],
+                                     [LayerSpec(W3t, None, L.OP_MUL_DGELU, save=gz2, aux=sv["z2"]),
+                                      LayerSpec(W2t, None, L.OP_MUL_DGELU, save=gz1, aux=sv["z1"]), LayerSpec(W1t)],
+                                     outs, res=res, gscale=gs, **kw)
         else:
-            ops.rowtile_chain(M, [gseg],
-                              [LayerSpec(W3t, None, L.OP_MUL_DGELU, save=gz2, aux=sv["z2"]),
-                               LayerSpec(W2t, None, L.OP_MUL_DGELU, aux=sv["z1"])], [gz1], **kw)
-        tiles = [self._tile(gz1, 128, sg, in_add=sv["in_add"] if i == 0 else None) for i, sg in enumerate(sv["segs"])]
-        tiles.append(self._tile(gz2, 128, Seg(sv["z1"]), a_op=1))
-        tiles.append(self._tile(g3, nout, Seg(sv["z2"]), a_op=1, ldg=(G.stride(0) if g_ld is None else g_ld) if not ln else None))
-        with self.fork(gz1, gz2, g3, G, part, sv["z1"], sv["z2"], sv["in_add"], *[sg.t for sg in sv["segs"]],
-                       *[sg.idx for sg in sv["segs"]]):
+            have = ops.rowtile_chain(M, [gseg],
+                                     [LayerSpec(W3t, None, L.OP_MUL_DGELU, save=gz2, aux=sv["z2"]),
+                                      LayerSpec(W2t, None, L.OP_MUL_DGELU, aux=sv["z1"])], [gz1], gscale=gs, **kw)
+        s0, s1, s2 = (gs[0], gs[1], gs[2]) if have else (None, None, None)
+        if not ln and (gadd is not None or g_add is not None):
+            s0 = None   # slot 0 describes the prologue RESULT (= g3 with LayerNorm); without it the weight gradient reads G
+        tiles = [self._tile(gz1, 128, sg, in_add=sv["in_add"] if i == 0 else None, gscale=s2) for i, sg in enumerate(sv["segs"])]
+        tiles.append(self._tile(gz2, 128, Seg(sv["z1"]), a_op=1, gscale=s1))
+        tiles.append(self._tile(g3, nout, Seg(sv["z2"]), a_op=1, ldg=(G.stride(0) if g_ld is None else g_ld) if not ln else None,
+                                gscale=s0))
+        def side():
             self._dw_block(grads, [(names[0], names[1], len(sv["segs"])), (names[2], names[3], 1), (names[4], names[5], 1)],
                            tiles, M)
             if ln:
                 ops.reduce_partials(part, tiles_n, 256, out=self._gview2(grads, names[6], names[7]))
+        self.defer(side, gz1, gz2, g3, G, part, gs, sv["z1"], sv["z2"], sv["in_add"], *[sg.t for sg in sv["segs"]],
+                   *[sg.idx for sg in sv["segs"]])
 
     @staticmethod
     def _gview2(grads, n0, n1):
@@ -311,9 +360,10 @@ class Engine:
         return grads.flat[off:off + length]
 
     @staticmethod
-    def _tile(G, n_out, seg, *, a_op=0, a_gamma=None, a_beta=None, in_add=None, ldg=None, g_offset=0):
+    def _tile(G, n_out, seg, *, a_op=0, a_gamma=None, a_beta=None, in_add=None, ldg=None, g_offset=0, gscale=None):
+        """gscale: a slot (row) of the buffer the chain launch that produced G filled, or None."""
         return dict(G=G, n_out=n_out, seg=seg, a_op=a_op, a_gamma=a_gamma, a_beta=a_beta, in_add=in_add,
-                    ldg=G.stride(0) if ldg is None else ldg, g_offset=g_offset)
+                    ldg=G.stride(0) if ldg is None else ldg, g_offset=g_offset, gscale=gscale)
 
     def _workspace(self, n_floats, dev):
         if self._dw_ws is None or self._dw_ws.numel() < n_floats or self._dw_ws.device != dev:
@@ -342,6 +392,7 @@ class Engine:
                 c.in_add = None if t["in_add"] is None else t["in_add"].data_ptr()
                 c.a_gamma = None if t["a_gamma"] is None else t["a_gamma"].data_ptr()
                 c.a_beta = None if t["a_beta"] is None else t["a_beta"].data_ptr()
+                c.gscale = None if t.get("gscale") is None else t["gscale"].data_ptr()
                 c.ldg, c.n_out, c.width, c.ld = t["ldg"], t["n_out"], sg.width, sg.ld
                 c.a_op, c.ld_out = t["a_op"], K
                 if row0s is None:
@@ -362,7 +413,7 @@ class Engine:
 
     @staticmethod
     def _put(grads, name, value):
-        grads.view(name).copy_(value.reshape(grads.shape[name]))
+        cmdlist.call(grads.view(name).copy_, value.reshape(grads.shape[name]))
 
     # ------------------------------------------------------------------------------------------------------------
     # GnBlock (EPD.py:177-195, blocks.py)
@@ -404,25 +455,28 @@ class Engine:
         tiles_n = ops.rowtile_tiles(M)
         part = _empty(dev, tiles_n, 2, 128)
         e = sv["segs"][0].t
-        ops.rowtile_chain(M, [Seg(G)],
-                          [LayerSpec(W3t, None, L.OP_MUL_DGELU, save=gz2, aux=sv["z2"]),
-                           LayerSpec(W2t, None, L.OP_MUL_DGELU, save=gz1, aux=sv["z1"]), LayerSpec(W1ct)],
-                          [g_e_in], res=[G], in_op=L.IN_LNBWD, in_gamma=P[names[6]], in_aux=sv["y3"], in_save=g3,
-                          ln_partial=part, gadd=gadd[0], gadd_s=gadd[1], gadd_r=gadd[2])
+        gs = _empty(dev, 3, ops.gscale_ld(M))
+        have = ops.rowtile_chain(M, [Seg(G)],
+                                 [LayerSpec(W3t, None, L.OP_MUL_DGELU, save=gz2, aux=sv["z2"]),
+                                  LayerSpec(W2t, None, L.OP_MUL_DGELU, save=gz1, aux=sv["z1"]), LayerSpec(W1ct)],
+                                 [g_e_in], res=[G], in_op=L.IN_LNBWD, in_gamma=P[names[6]], in_aux=sv["y3"], in_save=g3,
+                                 ln_partial=part, gadd=gadd[0], gadd_s=gadd[1], gadd_r=gadd[2], gscale=gs)
+        s0, s1, s2 = (gs[0], gs[1], gs[2]) if have else (None, None, None)
         # adjoint of the gathers (W1a nb)[s], (W1b nb)[r]: per-side scatter of dz1 to the nodes, then ONE node-level GEMM
         G_s = ops.seg_gather_sum(gz1, pl.s_rowptr, pl.s_col, N)
         G_r = ops.seg_gather_sum(gz1, pl.r_rowptr, pl.r_col, N)
         g_nb = _empty(dev, N, 128)
         ops.rowtile_chain(N, [Seg(G_s), Seg(G_r)], [LayerSpec(Wabt)], [g_nb])
         nb = sv["nb"]
-        with self.fork(gz1, gz2, g3, G_s, G_r, nb, e, part, sv["z1"], sv["z2"]):
+        def side():
             # slab partials are laid out like small stand-in blocks ([W1c | b1 | W2 | b2 | W3 | b3] and [W1a | W1b]) and
             # reduced straight into their places of the real gradient block: W1c / W1ab are column blocks of W1 [128, 384]
             tmpE, tmpN = self._edge_tmp(dev)
             gW1 = grads.view(names[0])
             ws, slabs, blen = self._dw_block(tmpE, [("W1c", "b1", 1), ("W2", "b2", 1), ("W3", "b3", 1)],
-                                             [self._tile(gz1, 128, Seg(e)), self._tile(gz2, 128, Seg(sv["z1"]), a_op=1),
-                                              self._tile(g3, 128, Seg(sv["z2"]), a_op=1)], M, reduce=False)
+                                             [self._tile(gz1, 128, Seg(e), gscale=s2),
+                                              self._tile(gz2, 128, Seg(sv["z1"]), a_op=1, gscale=s1),
+                                              self._tile(g3, 128, Seg(sv["z2"]), a_op=1, gscale=s0)], M, reduce=False)
             red2d = L.load().gfv_reduce_partials_2d
             L.check(red2d(ws.data_ptr(), slabs, blen, 128, 128, 384, gW1.data_ptr() + 4 * 256, L.stream_ptr()), "reduce_2d")
             off, length = grads.block(names[1], names[5])
@@ -434,6 +488,7 @@ class Engine:
                                              [self._tile(G_s, 128, Seg(nb)), self._tile(G_r, 128, Seg(nb))], N, reduce=False)
             L.check(red2d(ws.data_ptr(), slabs, blen, 128, 256, 384, gW1.data_ptr(), L.stream_ptr()), "reduce_2d")
             ops.reduce_partials(part, tiles_n, 256, out=self._gview2(grads, names[6], names[7]))
+        self.defer(side, gz1, gz2, g3, G_s, G_r, nb, e, part, gs, sv["z1"], sv["z2"])
         return g_nb, g_e_in
 
     def gn_bwd(self, P, sv, g_x_out, g_e_out, grads, pl):
@@ -453,6 +508,7 @@ class Engine:
                           res=[None, None, g_e_out], gadd=(g_agg, pl.es, pl.er))
             g_nb = ops.seg_gather_sum(gnb2.view(2 * E, 128), pl.n_rowptr, pl.n_col_edge2, N)
         ops.seg_gather_sum(g_nb, pl.n_rowptr, pl.n_col_node, N, out=g_x_in, accumulate=True)
+        self.flush()   # the block's weight gradients: one fork
         return g_x_in, g_e_in
 
     # ------------------------------------------------------------------------------------------------------------
@@ -528,13 +584,15 @@ class Engine:
         Wpost, Wpre = P[f"{prefix}.mlp.linear_post.weight"], P[f"{prefix}.mlp.linear_pre.0.weight"]
         g_z = _empty(dev, N, 256)
         g_sum = _empty(dev, N, 128) if g_add is not None else None
-        ops.rowtile_chain(N, [Seg(g_out)], [LayerSpec(self._T(Wpost), None, L.OP_MUL_DGELU, aux=z)],
-                          [(g_z, 256), (g_z.data_ptr() + 512, 256)], in_add=g_add, in_save=g_sum)
+        gs = _empty(dev, 3, ops.gscale_ld(N))
+        have = ops.rowtile_chain(N, [Seg(g_out)], [LayerSpec(self._T(Wpost), None, L.OP_MUL_DGELU, aux=z)],
+                                 [(g_z, 256), (g_z.data_ptr() + 512, 256)], in_add=g_add, in_save=g_sum, gscale=gs)
+        s_post = gs[0] if have else None   # scale of the prologue result g_out (+ g_add) = the rows linear_post's dW reads
         if g_add is not None:
             g_out = g_sum
-        with self.fork(g_out, z):
-            self._dw_block(grads, [(f"{prefix}.mlp.linear_post.weight", f"{prefix}.mlp.linear_post.bias", 2)],
-                           [self._tile(g_out, 128, zs, a_op=1) for zs in zsegs], N)
+        g_post = g_out
+        self.defer(lambda: self._dw_block(grads, [(f"{prefix}.mlp.linear_post.weight", f"{prefix}.mlp.linear_post.bias", 2)],
+                                          [self._tile(g_post, 128, zs, a_op=1, gscale=s_post) for zs in zsegs], N), g_post, z, gs)
         # linear_pre behind LayerNorm ln_2
         tiles = ops.rowtile_tiles(N)
         part = _empty(dev, tiles, 2, 128)
@@ -543,16 +601,17 @@ class Engine:
         ops.rowtile_chain(N, [Seg(g_z, width=128, ld=256), Seg(g_z, width=128, ld=256, offset=128)],
                           [LayerSpec(self._T(Wpre))], [g_fx1], fin_op=L.FIN_LNBWD, fin_gamma=gam2, fin_aux=fx1,
                           ln_partial=part, res=[g_out])
-        with self.fork(g_z, fx1, part):
+        def side_pre():
             self._dw_block(grads, [(f"{prefix}.mlp.linear_pre.0.weight", f"{prefix}.mlp.linear_pre.0.bias", 2)],
                            [self._tile(g_z, 128, Seg(fx1), a_op=2, a_gamma=gam2, a_beta=bet2, ldg=256, g_offset=128 * h)
                             for h in range(2)], N, row0s=[0, 128])
             ops.reduce_partials(part, tiles, 256, out=self._gview2(grads, f"{prefix}.ln_2.weight", f"{prefix}.ln_2.bias"))
+        self.defer(side_pre, g_z, fx1, part)
         # to_out
         g_out_x = _empty(dev, N, 128)
         ops.rowtile_chain(N, [Seg(g_fx1)], [LayerSpec(self._T(P[f"{a}.to_out.0.weight"]))], [g_out_x])
-        with self.fork(g_fx1, sv["out_x"]):
-            self._dw_block(grads, [(f"{a}.to_out.0.weight", f"{a}.to_out.0.bias", 1)], [self._tile(g_fx1, 128, Seg(sv["out_x"]))], N)
+        self.defer(lambda: self._dw_block(grads, [(f"{a}.to_out.0.weight", f"{a}.to_out.0.bias", 1)],
+                                          [self._tile(g_fx1, 128, Seg(sv["out_x"]))], N), g_fx1, sv["out_x"])
         # de-slice / attention / slice
         w, batch = sv["w"], pl.batch
         gw = _empty(dev, N, 256)
@@ -569,11 +628,12 @@ class Engine:
                                             P[f"{a}.to_v.weight"].data_ptr(), sv["token"].data_ptr(), sv["norm"].data_ptr(),
                                             sv["attn"].data_ptr(), g_raw.data_ptr(), g_norm.data_ptr(), dwp.data_ptr(), st),
                 "slice_attention_bwd")
-        with self.fork(dwp):   # parameter gradients only: off the critical path
+        def side_qkv():   # parameter gradients only: off the critical path
             dqkv = ops.reduce_partials(dwp, B * 8, 768)
             self._put(grads, f"{a}.to_q.weight", dqkv[0:256])
             self._put(grads, f"{a}.to_k.weight", dqkv[256:512])
             self._put(grads, f"{a}.to_v.weight", dqkv[512:768])
+        self.defer(side_qkv, dwp)
         g_fx_mid = _empty(dev, N, 128)
         L.check(lib.gfv_deslice(w.data_ptr(), g_raw.data_ptr(), batch.data_ptr(), g_fx_mid.data_ptr(), N, 0, st), "deslice")
         L.check(lib.gfv_slice_gw(sv["fx_mid"].data_ptr(), g_raw.data_ptr(), g_norm.data_ptr(), batch.data_ptr(),
@@ -585,11 +645,12 @@ class Engine:
         L.check(lib.gfv_slice_softmax_bwd(sv["x_mid"].data_ptr(), P[f"{a}.in_project_slice.weight"].data_ptr(),
                                           P[f"{a}.in_project_slice.bias"].data_ptr(), temp.data_ptr(), w.data_ptr(),
                                           gw.data_ptr(), g_x_mid.data_ptr(), sp.data_ptr(), N, st), "slice_softmax_bwd")
-        with self.fork(sp):
+        def side_slice():
             ds = ops.reduce_partials(sp, nblk, 552)
             self._put(grads, f"{a}.in_project_slice.weight", ds[0:512])
             self._put(grads, f"{a}.in_project_slice.bias", ds[512:544])
             self._put(grads, f"{a}.graph_temperature", ds[544:552])
+        self.defer(side_slice, sp)
         # projections; fx_in also feeds the to_out residual
         t1, g_fx_in = _empty(dev, N, 128), _empty(dev, N, 128)
         Wfxt, Wxt = self._T(P[f"{a}.in_project_fx.weight"]), self._T(P[f"{a}.in_project_x.weight"])
@@ -598,10 +659,11 @@ class Engine:
         else:
             ops.rowtile_chain(N, [Seg(g_fx_mid)], [LayerSpec(Wfxt)], [t1], res=[g_fx1])
             ops.rowtile_chain(N, [Seg(g_x_mid)], [LayerSpec(Wxt)], [g_fx_in], res=[t1])
-        with self.fork(g_x_mid, g_fx_mid, fx_in):
-            self._dw_block(grads, [(f"{a}.in_project_x.weight", f"{a}.in_project_x.bias", 1),
-                                   (f"{a}.in_project_fx.weight", f"{a}.in_project_fx.bias", 1)],
-                           [self._tile(g_x_mid, 128, Seg(fx_in)), self._tile(g_fx_mid, 128, Seg(fx_in))], N)
+        self.defer(lambda: self._dw_block(grads, [(f"{a}.in_project_x.weight", f"{a}.in_project_x.bias", 1),
+                                                  (f"{a}.in_project_fx.weight", f"{a}.in_project_fx.bias", 1)],
+                                          [self._tile(g_x_mid, 128, Seg(fx_in)), self._tile(g_fx_mid, 128, Seg(fx_in))], N),
+                   g_x_mid, g_fx_mid, fx_in)
+        self.flush()   # the block's parameter gradients: one fork
         return g_fx_in
 
     # ------------------------------------------------------------------------------------------------------------
@@ -703,7 +765,7 @@ class Engine:
         if norm_global:
             nb = lib.gfv_normalizer_blocks(N)
             pws = _empty(dev, nb, 18)
-            sync = accumulate and self.dist_world > 1
+            sync = accumulate and (self.dist_world > 1 or self.dist_force)
             if sync:
                 from . import parallel
                 before = parallel.snapshot_normalizer(buffers)
@@ -716,7 +778,7 @@ class Engine:
             update(accumulate)
             if sync:
                 # statistics of the GLOBAL batch on every rank, then mean / std recomputed from them (finalize only)
-                parallel.allreduce_normalizer(buffers, before, self.dist_world, self.dist_group)
+                parallel.allreduce_normalizer(buffers, before, self.dist_world, self.dist_group, force=self.dist_force)
                 update(False)
         uv_old = _empty(dev, N, 2)
         L.check(lib.gfv_node_prep(x.data_ptr(), 12, pl.batch.data_ptr(), stats.data_ptr(), pl.uvp_dim.data_ptr(),
@@ -761,6 +823,7 @@ class Engine:
         dev = g_dec.device
         g_x = _empty(dev, N, 128)
         self.mlp3_bwd(P, sv["sv_dec"], g_dec, grads, outs=[g_x])
+        self.flush()
         g_e = None
         pending = None   # an addend of g_x that the next consumer folds into its first launch
         for proc in reversed(sv["procs"]):
@@ -782,9 +845,13 @@ class Engine:
             if g_emb is not None:
                 pending = g_emb  # the processor input also entered the Transolver residual (TransFVGN_v2.py:46-49)
             if self.bucket_hook is not None and proc is sv["procs"][-1] and len(sv["procs"]) > 1:
+                self.flush()
                 self.bucket_hook()
         self.mlp3_bwd(P, sv["sv_nenc"], g_x, grads, g_add=pending)
+        self.flush()
+        # the last weight gradients have no dX chain left to run beside: on the main stream, while the side stream drains
         self.mlp3_bwd(P, sv["sv_eenc"], g_e, grads)
+        self.flush(on_main=True)
 
     # ------------------------------------------------------------------------------------------------------------
     # whole model (importer.py:156-240)

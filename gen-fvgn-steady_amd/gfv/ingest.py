@@ -217,3 +217,212 @@ def load_comsol_mesh(mphtxt_path, bc_json_path, **physics):
     with open(bc_json_path, "r") as f:
         bc_json = json.load(f)
     return comsol_to_raw(read_mphtxt(mphtxt_path), bc_json, **physics)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# Tecplot FEPolygon meshes (Extract_mesh/parse_tecplot.py:50-699): polygon cells of any size (config 5 of BASELINE.json)
+# ------------------------------------------------------------------------------------------------------------
+def read_tecplot(path):
+    """Parse a Tecplot ASCII ``.dat`` mesh as the reference's `TecplotMesh` does (parse_tecplot.py:74-351): ONE interior
+    zone (ZONETYPE FEPolygon / FETriangle / FEQuadrilateral, BLOCK packing: all X, then all Y; sections ``# face nodes``,
+    ``# left elements``, ``# right elements``, 1-based, 0 = outside) followed by boundary line zones whose node
+    coordinates mark the obstacle surface.  Returns a dict: ``pos`` [N,2] float64, ``face_node`` [E,2] int64 (0-based, file
+    order and orientation), ``left`` / ``right`` [E] int64 (0-based, -1 = outside), ``boundary_pos`` [Nb,2] float64
+    (coordinates of every boundary-zone node, zones concatenated in file order), ``variables``, ``zones``."""
+    with open(path, "r") as f:
+        lines = f.read().split("\n")
+    i, n = 0, len(lines)
+    variables, zones = [], []
+    out = {"boundary_pos": []}
+    while i < n:
+        line = lines[i].strip()
+        if line.startswith("VARIABLES"):
+            variables = [line.split("=", 1)[1].strip().strip('"')]
+            i += 1
+            while i < n and not lines[i].strip().startswith("ZONE"):
+                s = lines[i].strip()
+                if s and not s.startswith("DATASETAUXDATA"):
+                    variables.append(s.strip('"'))
+                i += 1
+            continue
+        if line.startswith("ZONE"):
+            info = {"ZONE": line.split("=", 1)[1].strip().strip('"')}
+            i += 1
+            while i < n and not lines[i].strip().startswith("DT"):
+                for kv in lines[i].strip().split(","):
+                    if "=" in kv:
+                        k, v = kv.split("=", 1)
+                        info[k.strip()] = v.strip()
+                i += 1
+            i += 1                                                        # the DT=(...) line
+            n_nodes = int(info.get("Nodes", 0))
+            need = n_nodes * len(variables)
+            vals = []
+            while len(vals) < need:
+                vals.extend(lines[i].split())
+                i += 1
+            data = np.asarray(vals[:need], dtype=np.float64).reshape(len(variables), n_nodes)
+            xy = np.stack((data[variables.index("X")], data[variables.index("Y")]), axis=1)
+            sections, key = {}, None
+            while i < n and not lines[i].startswith("ZONE"):
+                s = lines[i].strip()
+                i += 1
+                if not s:
+                    continue
+                if s.startswith("#"):
+                    key = "_".join(s.split("#", 1)[1].split())
+                    sections[key] = []
+                    continue
+                sections.setdefault(key, []).append(s)
+            ints = {k: np.asarray(" ".join(v).split(), dtype=np.int64) for k, v in sections.items()}
+            zones.append(info)
+            if info.get("ZONETYPE", "").lower() in ("fepolygon", "fetriangle", "fequadrilateral"):
+                out["pos"] = xy
+                out["face_node"] = ints["face_nodes"].reshape(-1, 2) - 1
+                out["left"] = ints["left_elements"] - 1
+                out["right"] = ints["right_elements"] - 1
+            else:
+                out["boundary_pos"].append(xy)
+            continue
+        i += 1
+    out["boundary_pos"] = np.concatenate(out["boundary_pos"], axis=0) if out["boundary_pos"] else np.zeros((0, 2))
+    out["variables"], out["zones"] = variables, zones
+    return out
+
+
+def _ensure_ccw(items, cells_index, coords):
+    """parse_base.py:142-191 (`is_convex`, `reorder_polygon`, `ensure_counterclockwise`) for every cell at once: a cell whose
+    list, as given, turns the same way at every corner ((a - b) x (c - b) >= 0) is kept; any other is sorted by angle
+    about the mean of its points (stable, like Python's `sorted`)."""
+    out = items.copy()
+    counts = np.bincount(cells_index)
+    start = np.concatenate(([0], np.cumsum(counts)))[:-1]
+    for ct in np.unique(counts[counts > 0]):
+        cells = np.nonzero(counts == ct)[0]
+        idx = start[cells][:, None] + np.arange(ct)[None, :]
+        ids = items[idx]                                                   # [nc, ct]
+        p = coords[ids]
+        a, b, c = p, np.roll(p, -1, axis=1), np.roll(p, -2, axis=1)
+        ba, bc = a - b, c - b
+        cross = ba[:, :, 0] * bc[:, :, 1] - ba[:, :, 1] * bc[:, :, 0]
+        bad = (cross < 0).any(axis=1)
+        if bad.any():
+            pb = p[bad]
+            cen = pb.mean(axis=1, keepdims=True)
+            order = np.argsort(np.arctan2(pb[:, :, 1] - cen[:, :, 1], pb[:, :, 0] - cen[:, :, 0]), axis=1, kind="stable")
+            ids[bad] = np.take_along_axis(ids[bad], order, axis=1)
+            out[idx] = ids
+    return out
+
+
+def tecplot_cells(face_node, left, right, pos=None):
+    """Flat (cell, face) / (cell, node) incidence lists in the reader order of parse_tecplot.py:176-207: the faces of a cell
+    are its occurrences in [left elements | right elements] in that order (ascending face id inside each half), its nodes
+    the ascending unique node ids of those faces; with `pos`, each list then goes through the reference's
+    `ensure_counterclockwise` (faces by their centres, nodes by their coordinates).  The final CCW ordering is applied
+    afterwards by extract_mesh_state = meshgen.derive_geometry, whatever this order is.
+    Cells are numbered as in the file; cells of different size interleave (derive_geometry regroups them by size)."""
+    E = face_node.shape[0]
+    two_way = np.concatenate((left, right))
+    face_index = np.tile(np.arange(E, dtype=np.int64), 2)
+    keep = two_way >= 0
+    order = np.argsort(two_way[keep], kind="stable")
+    cells_index = two_way[keep][order]
+    cells_face = face_index[keep][order]
+    pairs = np.stack((np.repeat(cells_index, 2), face_node[cells_face].reshape(-1)), axis=1)
+    pairs = np.unique(pairs, axis=0)                                     # sorted by (cell, node)
+    n_cells = int(cells_index.max()) + 1
+    if not np.array_equal(np.bincount(pairs[:, 0], minlength=n_cells), np.bincount(cells_index, minlength=n_cells)):
+        raise ValueError("a cell does not have as many nodes as faces: not a polygon mesh")
+    cells_node = pairs[:, 1].copy()
+    if pos is not None:
+        fc = (pos[face_node[:, 0]] + pos[face_node[:, 1]]) / 2.0
+        cells_face = _ensure_ccw(cells_face, cells_index, fc)
+        cells_node = _ensure_ccw(cells_node, cells_index, pos)
+    return cells_node, cells_face, cells_index
+
+
+def pipe_flow_node_types(pos, boundary_pos):
+    """Node typing of the reference's Tecplot path (parse_tecplot.py:563-643, `extract_pipe_flow_boundary`): float32
+    coordinates shifted by |min|; left edge INFLOW, top / bottom WALL, right edge OUTFLOW (corners belong to the walls),
+    interior nodes whose coordinates coincide exactly with a boundary-zone node are the obstacle (WALL + surf mask)."""
+    shift = np.abs(pos.astype(np.float32).min(axis=0))
+    p = pos.astype(np.float32) + shift
+    bp = boundary_pos.astype(np.float32) + shift
+    top, bottom = p[:, 1].max(), p[:, 1].min()
+    outlet, inlet = p[:, 0].max(), p[:, 0].min()
+    x, y = p[:, 0].astype(np.float64), p[:, 1].astype(np.float64)
+
+    def is_equal(v, pivot):                                               # parse_base.py:193-211
+        return (np.abs(v) >= abs(float(pivot)) - 1e-8) & (np.abs(v) <= abs(float(pivot)) + 1e-8)
+
+    inside_y = (y > float(bottom) + 1e-12) & (y < float(top) - 1e-12)
+    is_in = is_equal(x, inlet) & inside_y
+    is_wall = ~is_in & ((p[:, 1] >= top) | (p[:, 1] <= bottom))
+    is_out = ~is_in & ~is_wall & is_equal(x, outlet) & inside_y
+    key = lambda a: np.ascontiguousarray(a).view(np.dtype((np.void, 8))).reshape(-1)
+    on_zone = np.isin(key(p), key(bp))
+    is_obst = ~is_in & ~is_wall & ~is_out & on_zone & (x > 0) & (x < float(outlet) - 1e-12) & (y > 0) & (y < float(top) - 1e-12)
+    nt = np.full((pos.shape[0],), NORMAL, dtype=np.int64)
+    nt[is_in] = INFLOW
+    nt[is_wall] = WALL
+    nt[is_out] = OUTFLOW
+    nt[is_obst] = WALL
+    return nt, is_obst
+
+
+def tecplot_to_raw(tec, bc_json, **physics):
+    """-> raw mesh dict for ``gfv.meshgen.finish_mesh`` (same contract as `comsol_to_raw`); face|face_node keeps the file's
+    order and orientation (parse_tecplot.py:656)."""
+    nt, surf = pipe_flow_node_types(tec["pos"], tec["boundary_pos"])
+    cells_node, cells_face, cells_index = tecplot_cells(tec["face_node"], tec["left"], tec["right"], tec["pos"])
+    th = bc_json["theta_PDE"]
+    first = lambda v: float(v[0] if isinstance(v, list) else v)
+    pb = {"stencil|khops": int(bc_json.get("stencil|khops", 2)),
+          "theta_PDE": {k: th[k] for k in ("unsteady", "continuity", "convection", "grad_p")},
+          "U": first(th["inlet"]), "rho": first(th["rho"]), "mu": first(th["mu"]), "source": first(th["source"]),
+          "aoa": first(th["aoa"]), "dt": float(th["dt"]), "L": float(th["L"]), "sigma": list(bc_json["sigma"]),
+          "inlet_type": bc_json["inlet_type"]}
+    pb.update(physics)
+    return {"node|pos": tec["pos"].astype(np.float64), "node|node_type": nt, "node|surf_mask": surf,
+            "face|face_node": np.ascontiguousarray(tec["face_node"].T).astype(np.int64), "cells_node": cells_node,
+            "cells_index": cells_index, "cells_face": cells_face, "bc": pb}
+
+
+def load_tecplot_mesh(dat_path, bc_json_path, **physics):
+    with open(bc_json_path, "r") as f:
+        bc_json = json.load(f)
+    return tecplot_to_raw(read_tecplot(dat_path), bc_json, **physics)
+
+
+def write_tecplot(path, pos, face_node, left, right, n_cells, boundary_zones=()):
+    """Write a polygon mesh in the Tecplot ASCII layout `read_tecplot` (and the reference's reader) takes: 1-based
+    `face_node` [E,2], `left` / `right` [E] (0 = outside); boundary_zones: [(name, coordinates [n,2])]."""
+    pos = np.asarray(pos, dtype=np.float64)
+
+    def block(f, values, per_line, fmt):
+        values = list(values)
+        for i in range(0, len(values), per_line):
+            f.write(" " + " ".join(fmt % v for v in values[i:i + per_line]) + "\n")
+
+    with open(path, "w") as f:
+        f.write('TITLE     = "gfv polygon mesh"\nVARIABLES = "X"\n"Y"\n')
+        f.write('ZONE T="Surf: tank"\n STRANDID=1, SOLUTIONTIME=0\n')
+        f.write(f" Nodes={pos.shape[0]}, Faces={len(left)}, Elements={n_cells}, ZONETYPE=FEPolygon\n DATAPACKING=BLOCK\n")
+        f.write(" NumConnectedBoundaryFaces=0, TotalNumBoundaryConnections=0\n DT=(SINGLE SINGLE )\n")
+        block(f, pos[:, 0], 5, "%.9E")
+        block(f, pos[:, 1], 5, "%.9E")
+        f.write("# face nodes\n")
+        block(f, np.asarray(face_node).reshape(-1), 10, "%d")
+        f.write("# left elements\n")
+        block(f, left, 10, "%d")
+        f.write("# right elements\n")
+        block(f, right, 10, "%d")
+        for name, xy in boundary_zones:
+            xy = np.asarray(xy, dtype=np.float64).reshape(-1, 2)
+            f.write(f'ZONE T="{name}"\n STRANDID=2, SOLUTIONTIME=0\n')
+            f.write(f" Nodes={xy.shape[0]}, Elements={max(xy.shape[0] - 1, 1)}, ZONETYPE=FELineSeg\n DATAPACKING=BLOCK\n")
+            f.write(" DT=(SINGLE SINGLE )\n")
+            block(f, xy[:, 0], 5, "%.9E")
+            block(f, xy[:, 1], 5, "%.9E")
+            block(f, [v for i in range(max(xy.shape[0] - 1, 1)) for v in (i + 1, min(i + 2, xy.shape[0]))], 10, "%d")

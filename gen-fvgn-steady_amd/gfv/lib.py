@@ -41,6 +41,7 @@ class RowtileArgs(C.Structure):
         ("res", C.c_void_p * 3), ("res_ld", C.c_int32 * 3), ("out_ld", C.c_int32 * 3), ("out", C.c_void_p * 3),
         ("out_nores", C.c_void_p), ("padd", C.c_void_p), ("padd_s", C.c_void_p), ("padd_r", C.c_void_p),
         ("padd_ld", C.c_int32), ("pad2_", C.c_int32), ("wmax", C.c_void_p),
+        ("gscale", C.c_void_p), ("gscale_ld", C.c_int32), ("pad3_", C.c_int32),
     ]
 
 
@@ -53,7 +54,7 @@ class DwTile(C.Structure):
     _fields_ = [("G", C.c_void_p), ("A", C.c_void_p), ("idx", C.c_void_p), ("in_add", C.c_void_p),
                 ("a_gamma", C.c_void_p), ("a_beta", C.c_void_p), ("ldg", C.c_int32), ("n_out", C.c_int32),
                 ("width", C.c_int32), ("ld", C.c_int32), ("a_op", C.c_int32), ("ld_out", C.c_int32),
-                ("out_off", C.c_int64), ("db_off", C.c_int64)]
+                ("out_off", C.c_int64), ("db_off", C.c_int64), ("gscale", C.c_void_p)]
 
 
 _lib = None
@@ -66,9 +67,11 @@ _SIGNATURES = {
     "gfv_seg_gather_sum_nnz": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                          C.c_int32, C.c_int32, C.c_int64, C.c_void_p]),
     "gfv_transpose_batch": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "gfv_status_flags": (C.c_int, [C.POINTER(C.c_int32)]),
     "gfv_profile_enable": (C.c_int, [C.c_int]),
     "gfv_profile_collect": (C.c_int, [C.c_int, C.POINTER(C.c_double)]),
     "gfv_profile_reset": (C.c_int, []),
+    "gfv_profile_set_sizes": (C.c_int, [C.c_double, C.c_double]),
     "gfv_gather_pair": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
                                   C.c_void_p]),
     "gfv_rowtile_tiles": (C.c_int, [C.c_int32]),
@@ -80,6 +83,9 @@ _SIGNATURES = {
                                 C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "gfv_linear_dw_ex": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(Seg), C.c_int32, C.c_void_p, C.c_int32,
                                    C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
+                                   C.c_int32, C.c_void_p]),
+    "gfv_linear_dw_gs": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(Seg), C.c_int32, C.c_void_p, C.c_int32,
+                                   C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_int32, C.c_void_p]),
     "gfv_dw_slabs": (C.c_int, [C.c_int32, C.c_int32, C.c_void_p]),
     "gfv_dw_multi_workspace_floats": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int64]),
@@ -123,7 +129,8 @@ _SIGNATURES = {
     "gfv_normalizer_update": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gfv_node_prep": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
     "gfv_edge_attr": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
-    "gfv_adam_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
+    "gfv_adam_step_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gfv_train_loss_dev": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gfv_train_loss": (C.c_int, [C.c_void_p, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
 }
 
@@ -139,11 +146,14 @@ def register(name, restype, argtypes):
         fn.restype, fn.argtypes = restype, argtypes
 
 
-def load():
+_recording = None   # gfv.cmdlist: while a step is being recorded, launches go through a noting proxy
+
+
+def load(raw=False):
     """Load libgfv.so or raise.  No CPU / PyTorch fallback exists for the product path."""
     global _lib
     if _lib is not None:
-        return _lib
+        return _lib if (_recording is None or raw) else _recording
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
             f"libgfv.so not found at {LIB_PATH}: build it with `python gen-fvgn-steady_amd/gfv/build.py` "
@@ -153,7 +163,7 @@ def load():
         fn = getattr(lib, name)  # raises AttributeError if the symbol is missing
         fn.restype, fn.argtypes = restype, argtypes
     _lib = lib
-    return lib
+    return lib if (_recording is None or raw) else _recording
 
 
 def stream_ptr():

@@ -65,6 +65,11 @@ def rowtile_tiles(M):
     return (M + 63) // 64
 
 
+def gscale_ld(M):
+    """Row length of a `gscale` buffer for M rows: one float per group of 16 rows, whole 128-row workgroups."""
+    return (M + 127) // 128 * 8
+
+
 class Seg:
     """Input segment: rows of `t` (optionally gathered by int32 `idx`), `width` valid columns, row stride `ld`."""
 
@@ -107,6 +112,7 @@ class WeightImages:
         self.valid = set()                          # keys whose image holds this step's values
         self.static = []                            # sorted [(start, end)]
         self._desc, self._desc_keys, self._max_frags = None, (), 0
+        self._retired = []
 
     def add_static(self, tensors):
         for t in tensors:
@@ -164,6 +170,7 @@ class WeightImages:
             return
         if len(self._desc_keys) != len(self.images) and not torch.cuda.is_current_stream_capturing():
             self._desc_keys = tuple(self.images)
+            self._retired.append(self._desc)   # a captured graph may still read the old table
             self._desc, self._ndesc = self._upload(list(self.images.items()), self.device)
             self._max_frags = max(img.numel() for img in self.images.values()) // 32
         if self._desc is None:
@@ -194,9 +201,11 @@ def set_weight_images(wi):
 def rowtile_chain(M, segs, layers, outs, *, in_add=None, in_op=L.IN_NONE, in_gamma=None, in_beta=None, in_aux=None,
                   gadd=None, gadd_s=None, gadd_r=None, in_save=None, ln_partial=None, fin_op=L.FIN_PLAIN,
                   fin_gamma=None, fin_beta=None, fin_aux=None, fin_presave=None, res=None, out_nores=None,
-                  padd=None, padd_s=None, padd_r=None, wimg=None):
+                  padd=None, padd_s=None, padd_r=None, wimg=None, gscale=None):
     """Launch the fused row-tile GEMM chain.  outs / res: list (per 128-wide chunk of the last layer) of
-    (tensor, ld) or tensors; see include/gfv.h for the semantics of every field."""
+    (tensor, ld) or tensors; see include/gfv.h for the semantics of every field.  gscale: [3, ld] buffer for the
+    per-16-row scales of the gradient rows the launch leaves behind; returns True when the launch wrote it (split-fp16
+    form), so the weight-gradient launch may take its slots instead of a pass over the rows."""
     lib = L.load()
     wi = wimg if wimg is not None else _WI
     if layers[-1].stack is not None:
@@ -253,12 +262,16 @@ def rowtile_chain(M, segs, layers, outs, *, in_add=None, in_op=L.IN_NONE, in_gam
     a.out_nores = _p(out_nores)
     if padd is not None:
         a.padd, a.padd_s, a.padd_r, a.padd_ld = _p(padd), _p(padd_s), _p(padd_r), padd.stride(0)
+    if gscale is not None:
+        assert gscale.dim() == 2 and gscale.shape[0] >= 3 and gscale.shape[1] >= gscale_ld(M)
+        a.gscale, a.gscale_ld = gscale.data_ptr(), gscale.stride(0)
     rc = lib.gfv_rowtile_chain(C.byref(a), L.stream_ptr())
     L.check(rc, "gfv_rowtile_chain")
+    return gscale is not None and lib.gfv_rowtile_last_path() >= 5
 
 
 def linear_dw(G, n_out, segs, M, *, ldg=None, in_add=None, a_op=0, a_gamma=None, a_beta=None, dW=None, db=None,
-              want_db=True, accumulate=False, workspace=None, g_offset=0):
+              want_db=True, accumulate=False, workspace=None, g_offset=0, gscale=None):
     """dW[n,k] = sum_m G[m,n] A[m,k]; db[n] = sum_m G[m,n].  Returns (dW [n_out,K], db [n_out] or None)."""
     lib = L.load()
     K = sum(s.width for s in segs)
@@ -274,7 +287,8 @@ def linear_dw(G, n_out, segs, M, *, ldg=None, in_add=None, a_op=0, a_gamma=None,
     for i, s in enumerate(segs):
         s.fill(cs[i])
     ldg = G.stride(0) if ldg is None else ldg
-    rc = lib.gfv_linear_dw_ex(G.data_ptr() + 4 * g_offset, ldg, n_out, cs, len(segs), _p(in_add), a_op, _p(a_gamma),
-                              _p(a_beta), M, _p(dW), 0, _p(db), _p(workspace), 1 if accumulate else 0, L.stream_ptr())
-    L.check(rc, "gfv_linear_dw_ex")
+    rc = lib.gfv_linear_dw_gs(G.data_ptr() + 4 * g_offset, ldg, n_out, cs, len(segs), _p(in_add), a_op, _p(a_gamma),
+                              _p(a_beta), M, _p(dW), _p(gscale), _p(db), _p(workspace), 1 if accumulate else 0,
+                              L.stream_ptr())
+    L.check(rc, "gfv_linear_dw_gs")
     return dW, db

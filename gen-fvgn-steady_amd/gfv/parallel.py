@@ -39,17 +39,26 @@ def snapshot_normalizer(buffers):
                       buffers["acc_count"].reshape(-1))).clone()
 
 
-def allreduce_normalizer(buffers, before, world, group=None):
+def allreduce_normalizer(buffers, before, world, group=None, force=False):
     """the online Normalizer (utils/normalization.py:32-85) accumulates sum x, sum x^2 and the row count of
     every batch it sees; with the graphs sharded by rank each replica would keep different statistics and the replicas
     would drift.  `buffers` already hold this rank's batch, `before` is `snapshot_normalizer` taken before it: the
     buffers become  before + all-reduce(sum)(this rank's delta)  - the statistics of the GLOBAL batch, and identical
     bit for bit on every rank (the same two operands are added everywhere)."""
     if world <= 1:
+        if force:
+            # a one-rank group (the single-GPU RCCL self-test): the collective is the identity; the statistics go through
+            # it unchanged, so the result stays bit-identical to the non-distributed step
+            cur = snapshot_normalizer(buffers)
+            dist.all_reduce(cur, op=dist.ReduceOp.SUM, group=group)
+            _write_normalizer(buffers, cur)
         return
     delta = snapshot_normalizer(buffers) - before
     dist.all_reduce(delta, op=dist.ReduceOp.SUM, group=group)
-    new = before + delta
+    _write_normalizer(buffers, before + delta)
+
+
+def _write_normalizer(buffers, new):
     n = buffers["acc_sum"].numel()
     buffers["acc_sum"].copy_(new[0:n].view_as(buffers["acc_sum"]))
     buffers["acc_sum_squared"].copy_(new[n:2 * n].view_as(buffers["acc_sum_squared"]))

@@ -211,8 +211,31 @@ def build_plan(graph_node, graph_node_x, graph_edge, graph_cell, graph_Index):
     return p
 
 
+def _live_tensors(graphs):
+    """Caller-owned data the plan holds copies (or aliases) of: boundary targets, node / face types, per-graph PDE
+    coefficients.  The reference re-reads them on every forward, so an in-place edit must reach the plan."""
+    gn, ge, gi = graphs[0], graphs[2], graphs[4]
+    return (gn.y, gn.node_type, ge.face_type, gi.theta_PDE, gi.sigma, gi.uvp_dim, gi.dt_graph)
+
+
+def _live_key(graphs):
+    return tuple((t.data_ptr(), t._version) for t in _live_tensors(graphs))
+
+
+def _refresh_live(p, graphs):
+    """Re-read the live data into the plan's own tensors IN PLACE (pointers held by captured hipGraphs stay valid)."""
+    y, node_type, face_type, theta, sigma, uvp_dim, dt = _live_tensors(graphs)
+    for dst, src in ((p.y, y[:, 0:2]), (p.node_type, node_type.reshape(-1)), (p.ftype, face_type.reshape(-1)),
+                     (p.theta, theta), (p.sigma, sigma), (p.uvp_dim, uvp_dim), (p.dt, dt.reshape(-1))):
+        if dst.data_ptr() != src.data_ptr() or dst.dtype != src.dtype:
+            dst.copy_(src.to(dst.dtype).reshape(dst.shape))
+
+
 def get_plan(graphs):
-    """Plan cached on graph_node (keyed by the identity of its index tensors)."""
+    """Plan cached on graph_node.  The structural part is keyed by the identity of the index tensors; the copied
+    caller-owned data (Dirichlet targets `y`, node / face types, theta_PDE, sigma, uvp_dim, dt_graph) by data pointer +
+    in-place version counter: editing a boundary condition or a PDE coefficient of a reused batch in place refreshes the
+    plan's copies on the next call (the reference re-reads graph_node.y / graph_Index on every forward)."""
     graph_node = graphs[0]
     pooled = getattr(graph_node, "_gfv_pool_plan", None)   # batch assembled by gfv.pool.DevicePool: plan comes with it
     if pooled is not None:
@@ -221,7 +244,11 @@ def get_plan(graphs):
            graph_node.x.shape[0], str(graph_node.x.device))
     cached = getattr(graph_node, "_gfv_plan", None)
     if cached is not None and cached[0] == key:
+        live = _live_key(graphs)
+        if cached[2] != live:
+            _refresh_live(cached[1], graphs)
+            graph_node._gfv_plan = (key, cached[1], live)
         return cached[1]
     plan = build_plan(*graphs)
-    graph_node._gfv_plan = (key, plan)
+    graph_node._gfv_plan = (key, plan, _live_key(graphs))
     return plan

@@ -11,6 +11,7 @@ from __future__ import annotations
 
 import torch
 
+from . import cmdlist
 from . import lib as L
 from .engine import GradStore
 from .functions import unused_param_names
@@ -19,17 +20,22 @@ from .plan import get_plan
 
 class TrainStep:
     def __init__(self, model, graphs, *, lr=None, betas=(0.9, 0.999), eps=1e-8, loss_weights=None, world_size=1,
-                 process_group=None, use_graph=False, want_outputs=True):
+                 process_group=None, use_graph=False, want_outputs=True, distributed=None):
         self.model = model
         self.graphs = graphs
         self.plan = get_plan(graphs)
         self.engine = model.engine()
         p = model.params
-        self.lr = p.lr if lr is None else lr
-        self.betas, self.eps = betas, eps
-        self.w_cont, self.w_mom, self.w_press = loss_weights or (p.loss_cont, p.loss_mom, p.loss_press)
+        self._hyper_host = None
+        self._lr = p.lr if lr is None else lr
+        self._betas, self._eps = tuple(betas), eps
+        self._lw = tuple(loss_weights or (p.loss_cont, p.loss_mom, p.loss_press))
         self.world_size, self.pg = world_size, process_group
+        # distributed=True with world_size 1 sends the step through the same collectives (identity all-reduce): the
+        # RCCL path can then be exercised on a single GPU (tests/test_rccl_gpu.py)
+        self.dist_on = (world_size > 1) if distributed is None else bool(distributed)
         self.engine.dist_world, self.engine.dist_group = world_size, process_group
+        self.engine.dist_force = self.dist_on
         self.use_graph = use_graph
         self._split, self._comm, self._work = None, None, None
         self.want_outputs = want_outputs
@@ -46,7 +52,11 @@ class TrainStep:
         self.flat_p = torch.zeros(total, dtype=torch.float32, device=dev)
         self.flat_m = torch.zeros(total, dtype=torch.float32, device=dev)
         self.flat_v = torch.zeros(total, dtype=torch.float32, device=dev)
-        self.step_t = torch.zeros(1, dtype=torch.float32, device=dev)
+        # Adam step counter + derived bias corrections, and the hyper-parameters: device resident (include/gfv.h,
+        # gfv_adam_step_dev), so a captured step follows `ts.lr = ...` (lr_scheduler.step() in the reference drivers)
+        self.adam_state = torch.zeros(4, dtype=torch.float32, device=dev)
+        self.hyper = torch.zeros(8, dtype=torch.float32, device=dev)
+        self._sync_hyper()
         self.P = {}
         for n, t in zip(names, tensors):
             off, k = self.G.off[n], t.numel()
@@ -64,6 +74,104 @@ class TrainStep:
         self.losses = None
         self.uvp_node = None
         self._graphs = {}
+        self._list_warm = {}
+
+    # hyper-parameters: plain attributes on the host, mirrored into `self.hyper` on change --------------------------
+    def _sync_hyper(self):
+        vals = (self._lr, self._betas[0], self._betas[1], self._eps, 1.0 / self.world_size, *self._lw)
+        if vals != self._hyper_host:
+            self.hyper.copy_(torch.tensor(vals, dtype=torch.float32))
+            self._hyper_host = vals
+
+    lr = property(lambda self: self._lr)
+    betas = property(lambda self: self._betas)
+    eps = property(lambda self: self._eps)
+    loss_weights = property(lambda self: self._lw)
+    w_cont = property(lambda self: self._lw[0])
+    w_mom = property(lambda self: self._lw[1])
+    w_press = property(lambda self: self._lw[2])
+
+    @lr.setter
+    def lr(self, v):
+        self._lr = float(v)
+        self._sync_hyper()
+
+    @betas.setter
+    def betas(self, v):
+        self._betas = (float(v[0]), float(v[1]))
+        self._sync_hyper()
+
+    @eps.setter
+    def eps(self, v):
+        self._eps = float(v)
+        self._sync_hyper()
+
+    @loss_weights.setter
+    def loss_weights(self, v):
+        self._lw = tuple(float(x) for x in v)
+        self._sync_hyper()
+
+    def set_lr(self, lr):
+        """What `lr_scheduler.step()` does to the reference's optimizer; eager and hipGraph steps both follow it."""
+        self.lr = lr
+
+    @property
+    def step_t(self):
+        return self.adam_state[0:1]
+
+    # optimizer state in the reference's checkpoint slot (importer.py:292-313 saves `optimizer{i}`) -------------------
+    def state_dict(self):
+        """Same nesting as torch.optim.Adam.state_dict(): per-parameter step / exp_avg / exp_avg_sq keyed by position in
+        `model.parameters()` order, one param group.  `NNmodel.save_checkpoint(path, optimizer=ts)` stores it under
+        `optimizer0`, `load_checkpoint(optimizer=ts, ...)` restores it."""
+        names = list(self.G.off)
+        t = self.adam_state[0:1].detach().cpu().clone().reshape(())
+        state = {}
+        for i, n in enumerate(names):
+            off, k = self.G.off[n], self.G.numel(n)
+            if n in self.G.skip:
+                continue   # parameters without a gradient have no Adam state in torch either
+            state[i] = {"step": t.clone(), "exp_avg": self.flat_m[off:off + k].view(self.G.shape[n]).detach().cpu().clone(),
+                        "exp_avg_sq": self.flat_v[off:off + k].view(self.G.shape[n]).detach().cpu().clone()}
+        group = {"lr": self._lr, "betas": self._betas, "eps": self._eps, "weight_decay": 0, "amsgrad": False,
+                 "maximize": False, "params": list(range(len(names)))}
+        return {"state": state, "param_groups": [group], "gfv_param_names": names, "gfv_loss_weights": self._lw}
+
+    def load_state_dict(self, sd):
+        names = list(self.G.off)
+        if "gfv_param_names" in sd and list(sd["gfv_param_names"]) != names:
+            raise ValueError("optimizer state belongs to a different parameter set")
+        step = None
+        self.flat_m.zero_()
+        self.flat_v.zero_()
+        for i, st in sd["state"].items():
+            n = names[int(i)]
+            off, k = self.G.off[n], self.G.numel(n)
+            self.flat_m[off:off + k].copy_(st["exp_avg"].reshape(-1))
+            self.flat_v[off:off + k].copy_(st["exp_avg_sq"].reshape(-1))
+            step = float(st["step"]) if step is None else step
+            if float(st["step"]) != step:
+                raise ValueError("per-parameter step counts differ: not a state this fused Adam can resume")
+        self.adam_state.zero_()
+        self.adam_state[0] = 0.0 if step is None else step
+        g = sd["param_groups"][0]
+        self._lr, self._betas, self._eps = float(g["lr"]), (float(g["betas"][0]), float(g["betas"][1])), float(g["eps"])
+        if "gfv_loss_weights" in sd:
+            self._lw = tuple(float(x) for x in sd["gfv_loss_weights"])
+        self._sync_hyper()
+
+    def sync_from_model(self):
+        """Call after loading a checkpoint into the model: `load_state_dict` copies into the parameter views of the flat
+        buffer in place, so the values are already there; this re-checks the aliasing and drops captured steps (their
+        weight images belong to the old values' step, the next step rebuilds them anyway)."""
+        for n, t in zip(*self.model.param_names_tensors()):
+            off = self.G.off[n]
+            if t.data_ptr() != self.flat_p.data_ptr() + 4 * off:
+                view = self.flat_p[off:off + t.numel()].view(t.shape)
+                view.copy_(t.data)
+                t.data = view
+                self.P[n] = view
+        self.model.node_norm._host_num_acc = None
 
     def set_batch(self, graphs):
         """Switch to another batch (dataset training: a new batch every step, pre_train_Adam.py:146-156).  Captured
@@ -76,17 +184,18 @@ class TrainStep:
         if self.gloss.shape[0] != self.plan.B:
             self.gloss = torch.zeros((self.plan.B, 4), dtype=torch.float32, device=self.dev)
         self._graphs = {}
+        self._list_warm = {}
 
     # one un-captured step body ------------------------------------------------------------------------------
     def _body(self, accumulate, with_adam=True):
         lib = L.load()
         st = L.stream_ptr()
-        self.x.copy_(self.x_backup)  # solve_with_grad_GPU.py:143 (fresh, un-normalised node state every step)
+        cmdlist.call(self.x.copy_, self.x_backup)  # solve_with_grad_GPU.py:143 (fresh, un-normalised node state every step)
         losses, uvp_node, uvp_cell, _, ctx = self.engine.forward(
             self.P, self.model.node_norm.buffers_dict(), self.x, self.plan, norm_global=True, accumulate=accumulate,
             want_outputs=self.want_outputs, want_edge_attr15=False)
-        L.check(lib.gfv_train_loss(losses.data_ptr(), self.plan.B, self.w_cont, self.w_mom, self.w_press,
-                                   self.loss.data_ptr(), self.gloss.data_ptr(), st), "train_loss")
+        L.check(lib.gfv_train_loss_dev(losses.data_ptr(), self.plan.B, self.hyper.data_ptr(), self.loss.data_ptr(),
+                                       self.gloss.data_ptr(), st), "train_loss")
         self.engine.backward(self.P, ctx, self.gloss, self.G, self.plan)
         self.losses, self.uvp_node, self.uvp_cell = losses, uvp_node, uvp_cell
         if with_adam:
@@ -94,9 +203,9 @@ class TrainStep:
 
     def _adam(self):
         lib = L.load()
-        L.check(lib.gfv_adam_step(self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.flat_m.data_ptr(),
-                                  self.flat_v.data_ptr(), self.n_params, self.step_t.data_ptr(), self.lr, self.betas[0],
-                                  self.betas[1], self.eps, 1.0 / self.world_size, L.stream_ptr()), "adam_step")
+        L.check(lib.gfv_adam_step_dev(self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.flat_m.data_ptr(),
+                                      self.flat_v.data_ptr(), self.n_params, self.adam_state.data_ptr(),
+                                      self.hyper.data_ptr(), L.stream_ptr()), "adam_step")
 
     # data-parallel exchange: the flat gradient is reduced in two buckets.  The upper one (last processor + decoder:
     # their backward runs first) goes out on a communication stream as soon as its last gradient kernel is launched and
@@ -132,23 +241,60 @@ class TrainStep:
         else:
             dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM, group=self.pg)
 
+    def _eager(self, acc, dist_on):
+        self.engine.bucket_hook = self._bucket_ready if dist_on else None
+        try:
+            self._body(acc, with_adam=not dist_on)
+        finally:
+            self.engine.bucket_hook = None
+        if dist_on:
+            self._allreduce()
+            self._adam()
+
     def step(self):
-        """One training iteration.  Returns the (device) scalar loss tensor of this rank's batch."""
+        """One training iteration.  Returns the (device) scalar loss tensor of this rank's batch.
+        `use_graph`: False = eager launches, True = hipGraph replay, "list" = command-list replay."""
         acc = self.model.node_norm.should_accumulate()
-        dist_on = self.world_size > 1
+        dist_on = self.dist_on
         if not self.use_graph or (acc and dist_on):
             # (an accumulating data-parallel step exchanges the Normalizer statistics inside the forward: not captured)
-            self.engine.bucket_hook = self._bucket_ready if dist_on else None
-            try:
-                self._body(acc, with_adam=not dist_on)
-            finally:
-                self.engine.bucket_hook = None
-            if dist_on:
-                self._allreduce()
-                self._adam()
+            self._eager(acc, dist_on)
+        elif self.use_graph == "list":
+            # command-list replay (gfv/cmdlist.py): the eager launch sequence of one step, recorded at the C ABI and
+            # replayed with one ctypes call per launch - same two streams, same event edges, no per-launch Python work
+            key = ("list", acc, dist_on)
+            entry = self._graphs.get(key)
+            sig = self.engine.capture_signature()
+            if entry is not None and entry[1] != sig:
+                self._graphs.pop(key)
+                self._list_warm.pop(key, None)
+                entry = None
+            if entry is None:
+                warm = self._list_warm.get(key, 0)
+                if warm < 2:
+                    # the first steps settle the weight-image set and the persistent workspaces (allocated outside the pool)
+                    self._list_warm[key] = warm + 1
+                    self._eager(acc, dist_on)
+                else:
+                    with cmdlist.record() as cl:
+                        self._body(acc, with_adam=not dist_on)
+                    self._graphs[key] = (cl, self.engine.capture_signature())
+                    if dist_on:
+                        self._allreduce()
+                        self._adam()
+            else:
+                entry[0].replay()
+                if dist_on:
+                    self._allreduce()
+                    self._adam()
         else:
             key = (acc, dist_on)
             g = self._graphs.get(key)
+            if g is not None and g[1] != self.engine.capture_signature():
+                # the captured launches hold raw pointers into the weight-image set / descriptor tables of the engine:
+                # a changed set (model.to(), re-flattened parameters, a new weight block) makes every capture stale
+                self._graphs.clear()
+                g = None
             if g is None:
                 # warm the allocator on a side stream, then capture (PyTorch CUDA-graph recipe)
                 s = torch.cuda.Stream()
@@ -165,9 +311,10 @@ class TrainStep:
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
                     self._body(acc, with_adam=not dist_on)
+                g = (g, self.engine.capture_signature())
                 self._graphs[key] = g
                 self._restore()  # capture does not execute; state is as before this step
-            g.replay()
+            g[0].replay()
             if dist_on:
                 self._allreduce()
                 self._adam()
@@ -178,11 +325,11 @@ class TrainStep:
     # state snapshot so the capture warm-up does not advance training ---------------------------------------
     def _snapshot(self):
         nb = self.model.node_norm
-        self._snap = (self.flat_p.clone(), self.flat_m.clone(), self.flat_v.clone(), self.step_t.clone(),
+        self._snap = (self.flat_p.clone(), self.flat_m.clone(), self.flat_v.clone(), self.adam_state.clone(),
                       nb.acc_count.clone(), nb.num_accumulations.clone(), nb.acc_sum.clone(), nb.acc_sum_squared.clone())
 
     def _restore(self):
         nb = self.model.node_norm
-        for dst, src in zip((self.flat_p, self.flat_m, self.flat_v, self.step_t, nb.acc_count, nb.num_accumulations,
+        for dst, src in zip((self.flat_p, self.flat_m, self.flat_v, self.adam_state, nb.acc_count, nb.num_accumulations,
                              nb.acc_sum, nb.acc_sum_squared), self._snap):
             dst.copy_(src)

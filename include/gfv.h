@@ -120,6 +120,14 @@ typedef struct {
   int32_t padd_ld;
   int32_t pad2_;
   const float* wmax;      /* device scalar max|W| the layers' Wh images were built with (gfv_weight_images) */
+  /* optional, written by the split-fp16 form only (gfv_rowtile_last_path() >= 5): per group of 16 consecutive rows the
+   * exact power of two s with s * max|v| in [2^13, 2^14) of the gradient rows this launch leaves for the weight-gradient
+   * kernel - slot 0: the prologue result (in_save), slot l + 1: layer l's saved GFV_OP_MUL_DGELU product, slot nlayers
+   * (nlayers <= 2): output chunk 0.  Layout gscale[slot * gscale_ld + row / 16], gscale_ld >= ceil(M / 16).
+   * gfv_dw_tile_t.gscale takes a slot: the slab scale of the gradient rows then needs no extra pass over them. */
+  float* gscale;
+  int32_t gscale_ld;
+  int32_t pad3_;
 } gfv_rowtile_args_t;
 
 int gfv_rowtile_tiles(int32_t M); /* number of 64-row tiles = rows of ln_partial */
@@ -160,6 +168,10 @@ int gfv_dw_chunks(int32_t M);
 int gfv_linear_dw(const float* G, int32_t ldg, int32_t n_out, const gfv_seg_t* segs, int32_t nseg,
                   const float* in_add, int32_t a_gelu, int32_t M, float* dW, float* db, float* workspace,
                   int32_t accumulate, void* stream);
+/* same as _ex, with the per-16-row scales of the G rows handed over (gfv_dw_tile_t.gscale; NULL = none) */
+int gfv_linear_dw_gs(const float* G, int32_t ldg, int32_t n_out, const gfv_seg_t* segs, int32_t nseg,
+                     const float* in_add, int32_t a_op, const float* a_gamma, const float* a_beta, int32_t M,
+                     float* dW, const float* gscale, float* db, float* workspace, int32_t accumulate, void* stream);
 size_t gfv_linear_dw_workspace_floats(int32_t M, int32_t n_out, int32_t K);
 /* same, with the input-row op spelled out: a_op 0 none, 1 GELU, 2 LayerNorm(a_gamma, a_beta) (single 128-wide segment) */
 int gfv_linear_dw_ex(const float* G, int32_t ldg, int32_t n_out, const gfv_seg_t* segs, int32_t nseg,
@@ -184,7 +196,17 @@ typedef struct {
   int32_t ld_out;       /* row stride (K of the weight) inside the block */
   int64_t out_off;      /* float offset of dW_t[0, 0] inside the block */
   int64_t db_off;       /* float offset of the bias gradient, or -1 */
+  const float* gscale;  /* optional (split-fp16 form): per-16-row power-of-two scales of the G rows as the chain launch
+                         * that produced them wrote them (gfv_rowtile_args_t.gscale); NULL: one pass over G finds the maximum */
 } gfv_dw_tile_t;
+/* Range of the split-fp16 weight-gradient form.  The gradient rows G carry ONE power of two per slab of rows.  The
+ * activations A carry one power of two per COLUMN and slab when they are raw inputs (a_op == 0; a pass over the slab's A
+ * rows finds the column maxima: encoder inputs hold geometric columns at mesh-spacing scale next to O(1) features);
+ * GELU / LayerNorm outputs (a_op 1 / 2) are split unscaled, and a value beyond the fp16 range raises GFV_FLAG_DW_RANGE
+ * in the device status word instead of being clamped. */
+enum { GFV_FLAG_DW_RANGE = 1 };
+/* device status word: OR of GFV_FLAG_* raised by kernels since the last call; reads (synchronising) and clears it */
+int gfv_status_flags(int32_t* flags_out);
 int gfv_dw_slabs(int32_t M, int32_t ntiles, int32_t* rows_per_slab);
 size_t gfv_dw_multi_workspace_floats(int32_t M, int32_t ntiles, int64_t block_floats);
 int gfv_dw_multi(const gfv_dw_tile_t* tiles, int32_t ntiles, int32_t M, int64_t block_floats, float* workspace,
@@ -336,10 +358,17 @@ int gfv_node_prep(float* x, int32_t ldx, const int32_t* batch, const float* stat
                   const float* mean_std, int32_t norm_global, float* uv_old, int32_t N, void* stream);
 int gfv_edge_attr(const float* x, int32_t ldx, const float* pos, const int32_t* es, const int32_t* er, float* out16,
                   float* out15, int32_t E, void* stream);
-int gfv_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float* step, float lr, float beta1, float beta2,
-                  float eps, float grad_scale, void* stream);
+/* Fused Adam on the flat buffers (torch.optim.Adam defaults; pre_train_Adam.py:115,189-191).  Step counter and
+ * hyper-parameters are DEVICE resident so that a captured hipGraph follows learning-rate changes:
+ *   state[4] = {t, lr / (1 - beta1^t), sqrt(1 - beta2^t), reserved}  (t is advanced by the call; the bias corrections
+ *              are formed in double, as torch's host code does)
+ *   hyper[8] = {lr, beta1, beta2, eps, grad_scale (1 / world size), 0, 0, 0} */
+int gfv_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, float* state, const float* hyper,
+                      void* stream);
 int gfv_train_loss(const float* losses, int32_t B, float w_cont, float w_mom, float w_press, float* loss, float* gloss,
                    void* stream);
+/* same, weights read from the device: hyper[5..7] = {w_cont, w_mom, w_press} of the buffer gfv_adam_step_dev takes */
+int gfv_train_loss_dev(const float* losses, int32_t B, const float* hyper, float* loss, float* gloss, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Optional per-launch HIP-event timing of the main kernels on their own stream (bench.py roofline leg).
@@ -349,6 +378,11 @@ int gfv_train_loss(const float* losses, int32_t B, float w_cont, float w_mom, fl
 int gfv_profile_enable(int on);
 int gfv_profile_collect(int kind, double* out);
 int gfv_profile_reset(void);
+/* kinds: 1 row-tile chain (LDS form), 2 weight gradient, 3 segmented reduce, 4 Transolver slice kernels, 5 finite-volume
+ * kernels, 6 input preparation / loss / Adam, 7-10 register-resident chain instantiations, 11 deterministic second-stage
+ * reductions, 12 per-step weight images and transposed copies.  Sizes an entry point cannot see from its arguments
+ * (directed stencil entries S, (cell, face) incidences Sigma) are given here so the finite-volume kernels can be priced. */
+int gfv_profile_set_sizes(double stencil_entries, double incidences);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,86 @@
+"""Worker of tests/test_rccl_gpu.py (launched with torch.distributed.run --nproc-per-node 1, backend nccl = RCCL):
+TrainStep(distributed=True) on a one-rank RCCL group.  Every collective of the data-parallel step executes under the
+backend it was written for - the early gradient bucket on the communication stream from inside the backward
+(`_bucket_ready`), the late bucket + join (`_allreduce`), the Normalizer statistics exchange inside the forward
+(`allreduce_normalizer`, accumulating Normalizer) - and, a one-rank all-reduce being the identity, the parameters,
+Adam moments and Normalizer buffers must be BIT-IDENTICAL to the non-distributed TrainStep on the same batch.
+Both eager and hipGraph replay (the replay keeps the exchange outside the graph) are checked."""
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "gen-fvgn-steady_amd"), os.path.join(ROOT, "tests", "golden")):
+    sys.path.insert(0, p)
+
+
+def main():
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+    assert dist.get_backend() == "nccl" and dist.get_world_size() == 1
+    import cases
+    from oracle import fvgn_oracle as O
+    from FVMmodel.importer import NNmodel
+    from gfv import meshgen
+    from gfv.graph import build_batch
+    from gfv.params import default_params
+    from gfv.trainer import TrainStep
+    specs = cases.CASES["cyl_b3"][:2]
+    meshes = [meshgen.finish_mesh(getattr(meshgen, fac)(**kw), U=U) for fac, kw, U, _ in specs]
+    fields = [meshgen.random_fields(m, seed=s[3]) for m, s in zip(meshes, specs)]
+    P = O.init_parameters(cases.WEIGHT_SEED)
+
+    def run(distributed, use_graph):
+        model = NNmodel(default_params(dataset_size=3))   # accumulates on the first two steps, then frozen
+        sd = model.state_dict()
+        for k, v in P.items():
+            sd[k].copy_(v)
+        model.load_state_dict(sd)
+        model = model.cuda()
+        g = build_batch(meshes, fields, device="cuda")
+        ts = TrainStep(model, g, world_size=1, use_graph=use_graph, distributed=distributed)
+        calls = {"bucket": 0, "allreduce": 0}
+        if distributed:
+            b0, a0 = ts._bucket_ready, ts._allreduce
+
+            def bucket():
+                calls["bucket"] += 1
+                return b0()
+
+            def allred():
+                calls["allreduce"] += 1
+                # the early bucket must be in flight on the communication stream when the backward returns (eager steps)
+                calls["early_pending"] = calls.get("early_pending", 0) + (1 if ts._work is not None else 0)
+                return a0()
+            ts._bucket_ready, ts._allreduce = bucket, allred
+        for _ in range(5):
+            ts.step()
+        torch.cuda.synchronize()
+        nn_ = model.node_norm
+        parts = dict(p=ts.flat_p, m=ts.flat_m, v=ts.flat_v, t=ts.adam_state[0:1], acc_sum=nn_.acc_sum.reshape(-1),
+                     acc_sq=nn_.acc_sum_squared.reshape(-1), acc_count=nn_.acc_count.reshape(-1), loss=ts.loss.reshape(-1))
+        state = {k: v.detach().cpu().clone() for k, v in parts.items()}
+        return state, calls, ts
+
+    ok = True
+    for use_graph in (False, True, "list"):
+        ref, _, _ = run(False, use_graph)
+        got, calls, ts = run(True, use_graph)
+        diff = {k: float((ref[k].double() - got[k].double()).abs().max()) for k in ref if not torch.equal(ref[k], got[k])}
+        same = not diff
+        if diff:
+            print("RCCLDIFF", use_graph, diff)
+        ok = ok and same and calls["allreduce"] == 5
+        if use_graph is False:
+            # eager: every step started the upper bucket from inside the backward, on the communication stream
+            ok = ok and calls["bucket"] == 5 and calls.get("early_pending", 0) == 5 and ts._comm is not None
+        print(f"RCCLRESULT graph={ {False: 0, True: 1, 'list': 2}[use_graph] } same={int(same)} bucket={calls['bucket']} allreduce={calls['allreduce']} "
+              f"early_pending={calls.get('early_pending', 0)} backend={dist.get_backend()} world={dist.get_world_size()}")
+    print(f"RCCLOK {int(ok)}")
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -49,54 +49,123 @@ def bench_mesh():
     return build_batch([mesh], [field])
 
 
-def test_full_size_forward_backward_matches_oracle(bench_mesh):
-    graphs = bench_mesh
-    assert graphs[3].pos.shape[0] == 50020
-    P = O.init_parameters(cases.WEIGHT_SEED)
-    Pg = {k: v.detach().requires_grad_(True) for k, v in P.items()}
-    og = tuple(g.clone() for g in graphs)
-    oout, inter = O.model_forward(Pg, O.new_normalizer_buffers(), og, hyper={"dataset_size": 1}, return_intermediates=True)
+def graphs_to(graphs, dtype):
+    """Copy of the five graph objects with every floating tensor cast to `dtype` (the oracle computes in its inputs' dtype)."""
+    out = []
+    for g in graphs:
+        c = g.clone()
+        for k, v in list(vars(c).items()):
+            if torch.is_tensor(v) and v.is_floating_point():
+                setattr(c, k, v.to(dtype))
+        out.append(c)
+    return tuple(out)
+
+
+def oracle_run(graphs, P, dtype):
+    """Oracle forward + backward in `dtype`: (outputs, scalar loss, gradients, intermediates)."""
+    Pg = {k: v.detach().to(dtype).requires_grad_(True) for k, v in P.items()}
+    og = graphs_to(graphs, dtype)
+    buf = {k: v.to(dtype) for k, v in O.new_normalizer_buffers().items()}
+    oout, inter = O.model_forward(Pg, buf, og, hyper={"dataset_size": 1}, return_intermediates=True)
     oloss = O.training_loss(oout)
     names = list(Pg)
     ograds = dict(zip(names, torch.autograd.grad(oloss, [Pg[k] for k in names], allow_unused=True)))
+    return [o.detach() for o in oout], oloss.detach(), ograds, inter
+
+
+def hip_run(graphs, P):
     model = _model(P)
     hg = tuple(g.clone().to("cuda") for g in graphs)
     hg[0].norm_uvp, hg[0].norm_global = True, True
     out = model(*hg)
-    # pooled residual norms over 50 020 cells: the oracle (= the reference) pools sequentially in fp32, which at this size
-    # is itself ~1e-4 off the exact sum of its own fp32 terms (tests/test_model_gpu.py::test_reference_example_mesh...):
-    # the HIP pool is held to 1e-5 against the exactly (fp64) pooled oracle residuals and to 5e-4 against the
-    # sequentially rounded values
-    theta, sigma = graphs[4].theta_PDE.double(), graphs[4].sigma.double()
-    exact = [torch.sqrt((inter["div"].detach().double() ** 2).sum()) * theta[0, 1],
-             torch.sqrt((inter["mom"][:, 0].detach().double() ** 2).sum()) * sigma[0, 0],
-             torch.sqrt((inter["mom"][:, 1].detach().double() ** 2).sum()) * sigma[0, 1]]
-    for i, key in enumerate(("loss_cont", "loss_mom_x", "loss_mom_y", "loss_press", "uvp_node", "uvp_cell")):
-        assert rel(out[i], oout[i]) < (5e-4 if i < 4 else TOL), (key, rel(out[i], oout[i]))
-        if i < 3:
-            e = abs(float(out[i]) - float(exact[i])) / float(exact[i])
-            assert e < TOL, (key, "vs exactly pooled fp32 residuals", e)
     loss = _loss(out)
-    assert abs(float(loss) - float(oloss)) < 3 * TOL * abs(float(oloss))   # carries the oracle's pooling error
     loss.backward()
+    grads = {k: (None if p.grad is None else p.grad.detach().cpu()) for k, p in model.named_parameters()}
+    return [o.detach().cpu() for o in out], loss.detach().cpu(), grads
+
+
+def grad_errors(grads, ref):
+    """Element-wise error of every gradient tensor in units of that tensor's scale (max |ref|, floored at 1e-6 of the
+    global gradient scale - tensors whose gradient is rounding noise of the whole computation): {name: error}."""
+    gmax = max(float(g.abs().max()) for g in ref.values() if g is not None)
+    errs = {}
+    for k, g in ref.items():
+        if g is None:
+            assert grads[k] is None, k
+            continue
+        errs[k] = float((grads[k].double() - g.double()).abs().max()) / max(float(g.abs().max()), 1e-6 * gmax)
+    return errs
+
+
+def global_grad_error(grads, ref):
+    num = sum(float(((grads[k].double() - g.double()) ** 2).sum()) for k, g in ref.items() if g is not None)
+    den = sum(float((g.double() ** 2).sum()) for g in ref.values() if g is not None)
+    return (num / den) ** 0.5
+
+
+def check_gradients(report, label):
+    """Every gradient tensor within 1e-4 of its scale of the float64 value, element-wise - except where the reference's
+    own fp32 arithmetic (the fp32 oracle, same inputs) is itself further away than that: there the HIP path has to be at
+    least as close as twice the fp32 oracle's distance (such tensors are ill-conditioned sums - e.g. the 8 slice
+    temperatures, each the sum over all nodes of cancelling terms - and no fp32 evaluation order resolves them better)."""
+    eh, e32 = report["grad_hip"], report["grad_o32"]
+    over = {k: (eh[k], e32[k]) for k in eh if eh[k] >= 1e-4}
+    print(f"[{label}] gradient tensors beyond 1e-4 of scale (HIP | fp32 oracle), {len(over)} of {len(eh)}:")
+    for k, (a, b) in sorted(over.items(), key=lambda kv: -kv[1][0]):
+        print(f"  {k:70s} {a:.2e} | {b:.2e}")
+    for k, (a, b) in over.items():
+        assert a <= 2.0 * b, (k, a, b)
+    assert report["grad_global"][0] < 1e-4, report["grad_global"]
+
+
+def compare_to_fp64(graphs, P, label):
+    """The HIP path and the fp32 oracle, each against the SAME oracle run in float64: the float64 run
+    is the exact value of the reference's algorithm on these inputs; the fp32 oracle's distance to it is the reference's
+    own rounding noise at this size."""
+    o64 = oracle_run(graphs, P, torch.float64)
+    o32 = oracle_run(graphs, P, torch.float32)
+    hip = hip_run(graphs, P)
+    keys = ("loss_cont", "loss_mom_x", "loss_mom_y", "loss_press", "uvp_node", "uvp_cell")
+    report = {}
+    for i, key in enumerate(keys):
+        report[key] = (rel(hip[0][i], o64[0][i]), rel(o32[0][i], o64[0][i]))
+    report["loss"] = (abs(float(hip[1]) - float(o64[1])) / abs(float(o64[1])), abs(float(o32[1]) - float(o64[1])) / abs(float(o64[1])))
+    eh, e32 = grad_errors(hip[2], o64[2]), grad_errors(o32[2], o64[2])
+    report["grad_worst_elementwise"] = (max(eh.values()), max(e32.values()))
+    report["grad_median_elementwise"] = (float(np.median(list(eh.values()))), float(np.median(list(e32.values()))))
+    report["grad_global"] = (global_grad_error(hip[2], o64[2]), global_grad_error(o32[2], o64[2]))
+    print(f"[{label}] distance to the float64 oracle: HIP path | fp32 oracle")
+    for k, (a, b) in report.items():
+        print(f"  {k:24s} {a:.3e} | {b:.3e}")
+    report["grad_hip"], report["grad_o32"] = eh, e32
+    return report, (o64, o32, hip)
+
+
+def test_full_size_forward_backward_matches_fp64_oracle(bench_mesh):
+    """50 020 cells (the bench mesh): fields, residual losses and the scalar loss within 1e-5, every gradient element
+    within 1e-4 of its tensor's scale - against the oracle run in FLOAT64, with the fp32 oracle's own distance beside it."""
+    graphs = bench_mesh
+    assert graphs[3].pos.shape[0] == 50020
+    P = O.init_parameters(cases.WEIGHT_SEED)
+    report, (o64, o32, hip) = compare_to_fp64(graphs, P, "bench mesh, 50 020 cells")
     import os
     from gfv import lib as L
     # the bench configuration in the form bench.py times by default: chain products as split-fp16 on the f16 MFMA pipe
     assert (L.load().gfv_rowtile_last_path() >= 5) == (os.environ.get("GFV_F16SPLIT", "1") != "0")
-    # gradients are sums over 25 k nodes / 75 k edges of mixed-sign terms: the fp32 oracle itself carries ~1e-4 of
-    # summation noise in the small tensors at this size, so the comparison is norm-wise per tensor (3e-3, with a floor
-    # of 1e-4 of the global gradient norm) - the element-wise 1e-4 bar is applied at the sizes of test_model_gpu.py
-    gnorm = float(torch.sqrt(sum((g.double() ** 2).sum() for g in ograds.values() if g is not None)))
-    worst = 0.0
-    for k, p in model.named_parameters():
-        if ograds[k] is None:
-            assert p.grad is None, k
-            continue
-        err = float((p.grad.cpu().double() - ograds[k].double()).norm())
-        ref = float(ograds[k].double().norm())
-        worst = max(worst, err / (ref + 1e-4 * gnorm))
-        assert err < 3e-3 * ref + 1e-4 * gnorm, (k, err, ref, gnorm)
-    print("full-size worst norm-wise gradient error:", worst)
+    for key in ("loss_cont", "loss_mom_x", "loss_mom_y", "loss_press", "uvp_node", "uvp_cell", "loss"):
+        assert report[key][0] < TOL, (key, report[key])
+    check_gradients(report, "bench mesh")
+
+
+def test_reference_example_mesh_matches_fp64_oracle(golden_dir):
+    """The same comparison on the reference's own example mesh (mesh_example/cylinder_flow_full_tri, 15 074 cells; raw
+    reader arrays committed as tests/golden/real_cylinder.npz by make_real_mesh_golden.py)."""
+    graphs, _fx = cases.real_cylinder(golden_dir)
+    P = O.init_parameters(cases.WEIGHT_SEED)
+    report, _ = compare_to_fp64(graphs, P, "reference example mesh, 15 074 cells")
+    for key in ("loss_cont", "loss_mom_x", "loss_mom_y", "loss_press", "uvp_node", "uvp_cell", "loss"):
+        assert report[key][0] < TOL, (key, report[key])
+    check_gradients(report, "reference example mesh")
 
 
 def test_full_size_run_to_run_bit_identity(bench_mesh):

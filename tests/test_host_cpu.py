@@ -32,10 +32,10 @@ def test_ctypes_structs_match_header_layout():
     import ctypes as C
     from gfv import lib
     assert C.sizeof(lib.Seg) == 24 and C.sizeof(lib.Layer) == 64
-    assert C.sizeof(lib.DwTile) == 6 * 8 + 6 * 4 + 2 * 8
+    assert C.sizeof(lib.DwTile) == 6 * 8 + 6 * 4 + 2 * 8 + 8   # (+ gscale)
     assert C.sizeof(lib.RowtileArgs) % 8 == 0
     handle = lib.load()   # the library reports the sizes it was compiled with
-    for which, st in enumerate((lib.Seg, lib.Layer, lib.RowtileArgs, lib.WimgDesc)):
+    for which, st in enumerate((lib.Seg, lib.Layer, lib.RowtileArgs, lib.WimgDesc, lib.DwTile)):
         assert handle.gfv_struct_size(which) == C.sizeof(st), (which, st)
 
 

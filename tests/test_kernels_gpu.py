@@ -456,6 +456,107 @@ def test_rowtile_and_dw_extreme_dynamic_range(dev, chain_mode):
     assert rel(db, G.double().sum(0)) < TOL
 
 
+def test_dw_activation_dynamic_range_per_column(dev, chain_mode):
+    """the ACTIVATION side of the split-fp16 weight gradient.  Raw inputs (a_op 0) carry one
+    power of two per column and slab: (a) columns whose scales span 1e-6 ... 1e+6, (b) an encoder-shaped input (K = 15:
+    O(1) feature differences next to geometric columns at 1e-4 mesh-spacing scale, importer.py:54-78), (c) single columns
+    that themselves span twelve decades over the rows.  Every output element is judged against its own sum |g a|."""
+    if chain_mode != "f32":
+        pytest.skip("one pass is enough (the weight-gradient form follows the process-wide switch, not the fixture)")
+    assert __import__("gfv.lib", fromlist=["load"]).load().gfv_f16split_enabled() == 1
+    from gfv import ops
+    g = torch.Generator().manual_seed(7)
+    d = lambda t: t.to(dev).contiguous()
+
+    def check(G, A, tag, ld=None):
+        K = A.shape[1]
+        At = A if ld is None else torch.cat((A, torch.zeros(A.shape[0], ld - K)), 1)
+        dW, _ = ops.linear_dw(d(G), G.shape[1], [ops.Seg(d(At), width=K, ld=At.shape[1])], G.shape[0])
+        ref = G.double().T @ A.double()
+        mag = G.double().abs().T @ A.double().abs()
+        assert torch.isfinite(dW).all(), tag
+        e = float(((dW.double().cpu() - ref).abs() / (mag + 1e-300)).max())
+        assert e < 2e-6, (tag, e)
+
+    M = 2300
+    G = torch.randn(M, 128, generator=g) * 1e-3
+    col = 10.0 ** torch.linspace(-6, 6, 128)
+    check(G, torch.randn(M, 128, generator=g) * col[None, :], "column scales 1e-6 .. 1e+6")
+    feat = torch.randn(M, 12, generator=g)
+    geo = torch.randn(M, 2, generator=g) * 1e-4
+    ea = torch.cat((feat, geo, geo.norm(dim=1, keepdim=True)), 1)           # [M, 15] edge_attr-shaped
+    check(G, ea, "encoder-shaped, K = 15", ld=16)
+    rows = 10.0 ** (torch.rand(M, 1, generator=g) * 12 - 6)
+    check(G, torch.randn(M, 128, generator=g) * rows, "rows spanning 1e-6 .. 1e+6 inside every column")
+    check(G * rows.flip(0), torch.randn(M, 128, generator=g) * col[None, :], "both operands wide")
+
+
+def test_dw_unscaled_activation_overflow_raises_flag(dev, chain_mode):
+    """GELU / LayerNorm outputs (a_op 1 / 2) are split unscaled; a value beyond the fp16 range used to be clamped silently
+    (csrc/dw.hip r1) - now the device status word reports it."""
+    if chain_mode != "f32":
+        pytest.skip("one pass is enough (the weight-gradient form follows the process-wide switch, not the fixture)")
+    assert __import__("gfv.lib", fromlist=["load"]).load().gfv_f16split_enabled() == 1
+    import ctypes as C
+    from gfv import lib as L, ops
+    lib = L.load()
+    flags = C.c_int32(0)
+    lib.gfv_status_flags(C.byref(flags))                                   # clear
+    g = torch.Generator().manual_seed(8)
+    M = 700
+    d = lambda t: t.to(dev).contiguous()
+    G = torch.randn(M, 128, generator=g)
+    Z = torch.randn(M, 128, generator=g)
+    ops.linear_dw(d(G), 128, [ops.Seg(d(Z))], M, a_op=1)
+    torch.cuda.synchronize()
+    lib.gfv_status_flags(C.byref(flags))
+    assert flags.value == 0
+    Z[5, 7] = 1.0e5                                                          # gelu(1e5) = 1e5 > 65504
+    ops.linear_dw(d(G), 128, [ops.Seg(d(Z))], M, a_op=1)
+    torch.cuda.synchronize()
+    lib.gfv_status_flags(C.byref(flags))
+    assert flags.value & 1, "GFV_FLAG_DW_RANGE"
+    lib.gfv_status_flags(C.byref(flags))
+    assert flags.value == 0, "reading clears the word"
+
+
+def test_chain_group_scales_feed_the_weight_gradient(dev, chain_mode):
+    """The dX chain leaves one power of two per 16 rows for each gradient tensor it writes (gfv_rowtile_args_t.gscale);
+    the weight-gradient launch that takes them (no pass over G) gives bit-identical results to the one that finds the slab
+    maximum itself, since both arrive at the same slab scale."""
+    if chain_mode != "f32":
+        pytest.skip("one pass is enough (this test brings its own weight images)")
+    from gfv import lib as L, ops
+    lib = L.load()
+    g = torch.Generator().manual_seed(21)
+    M = 3001
+    d = lambda t: t.to(dev).contiguous()
+    G = d(torch.randn(M, 128, generator=g) * 10.0 ** (torch.arange(M).float()[:, None] // 500 * 3 - 9))
+    z2, z1 = d(torch.randn(M, 128, generator=g)), d(torch.randn(M, 128, generator=g))
+    W3t, W2t = d(torch.randn(128, 128, generator=g) * 0.1), d(torch.randn(128, 128, generator=g) * 0.1)
+    wi = ops.WeightImages(dev, torch.maximum(W3t.abs().max(), W2t.abs().max()).reshape(1).clone())
+    wi.static = [(0, 1 << 62)]
+    gz2, gz1 = torch.empty(M, 128, device=dev), torch.empty(M, 128, device=dev)
+    gs = torch.zeros(3, ops.gscale_ld(M), device=dev)
+    have = ops.rowtile_chain(M, [ops.Seg(G)], [ops.LayerSpec(W3t, None, L.OP_MUL_DGELU, save=gz2, aux=z2),
+                                              ops.LayerSpec(W2t, None, L.OP_MUL_DGELU, aux=z1)], [gz1], wimg=wi, gscale=gs)
+    assert have and lib.gfv_rowtile_last_path() >= 5
+    torch.cuda.synchronize()
+    for slot, t in ((0, G), (1, gz2), (2, gz1)):
+        n16 = (M + 15) // 16
+        pad = torch.zeros(n16 * 16, 128, device=dev)
+        pad[:M] = t
+        mx = pad.view(n16, 16 * 128).abs().max(1).values
+        s = gs[slot, :n16]
+        ok = (mx == 0) | ((s * mx >= 2.0 ** 13) & (s * mx < 2.0 ** 14))
+        assert bool(ok.all()), (slot, int((~ok).sum()))
+    A = d(torch.randn(M, 128, generator=g))
+    for slot, t in ((0, G), (1, gz2), (2, gz1)):
+        a, _ = ops.linear_dw(t, 128, [ops.Seg(A)], M, a_op=1)
+        b, _ = ops.linear_dw(t, 128, [ops.Seg(A)], M, a_op=1, gscale=gs[slot])
+        assert torch.equal(a, b), slot
+
+
 def test_lds_rowtile_fallback_kernel_still_passes():
     """`GFV_TCHAIN=0` routes every fused-MLP launch to the first implementation (rowtile.hip, 64-row tile in LDS), which
     stays in the library as the fallback.  The switch is read once per process, so the row-tile tests of this file are

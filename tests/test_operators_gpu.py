@@ -180,6 +180,86 @@ def test_trainstep_tracks_oracle(use_graph):
     assert worst < 1e-4, worst
 
 
+def test_step_modes_are_bit_identical():
+    """Eager launches, hipGraph replay and command-list replay (gfv/cmdlist.py) are the SAME launches on the same two
+    streams: parameters, Adam moments and the loss after 8 steps on a 3 000-cell mesh must be bit-identical - with an
+    accumulating Normalizer on the first steps (a second recording once it freezes), with a learning-rate change half way
+    (the hyper-parameters are device resident: replayed steps follow it), and after an in-place edit of a boundary value."""
+    from FVMmodel.importer import NNmodel
+    from gfv import meshgen
+    from gfv.graph import build_batch
+    from gfv.params import default_params
+    from gfv.trainer import TrainStep
+    nx, ny = meshgen.cylinder_grid_for_cells(3000)
+    mesh = meshgen.finish_mesh(meshgen.raw_tri_channel_cylinder(nx=nx, ny=ny, seed=5), U=0.3)
+    graphs = build_batch([mesh], [meshgen.random_fields(mesh, seed=9)])
+    P = O.init_parameters(cases.WEIGHT_SEED)
+    finals = {}
+    for mode in (False, True, "list"):
+        model = NNmodel(default_params(dataset_size=3))
+        sd = model.state_dict()
+        for k, v in P.items():
+            sd[k].copy_(v)
+        model.load_state_dict(sd)
+        model = model.cuda()
+        ts = TrainStep(model, tuple(g.clone().to("cuda") for g in graphs), use_graph=mode)
+        for i in range(8):
+            if i == 5:
+                ts.set_lr(2e-5)
+            ts.step()
+        torch.cuda.synchronize()
+        if mode == "list":
+            assert any(isinstance(k, tuple) and k[0] == "list" for k in ts._graphs), "the command list was never recorded"
+            assert len(next(v for k, v in ts._graphs.items() if k[0] == "list")[0]) > 100
+        finals[mode] = torch.cat([ts.flat_p, ts.flat_m, ts.flat_v, ts.adam_state[0:1], ts.loss.reshape(-1),
+                                  ts.losses.reshape(-1), ts.uvp_node.reshape(-1)]).clone()
+    assert torch.equal(finals[False], finals[True]), "hipGraph replay differs from eager"
+    assert torch.equal(finals[False], finals["list"]), "command-list replay differs from eager"
+
+
+def test_trainstep_state_dict_resume_equals_uninterrupted(tmp_path):
+    """the fused Adam's state (moments, step count, lr) is saved under the reference's `optimizer0`
+    key by NNmodel.save_checkpoint(optimizer=ts) and restored by load_checkpoint: 3 steps + save + load into a fresh
+    model / TrainStep + 3 steps == 6 uninterrupted steps, bit for bit."""
+    from FVMmodel.importer import NNmodel
+    from gfv.params import default_params
+    from gfv.trainer import TrainStep
+    graphs = cases.make_graphs("cavity_mixed_b1")
+    P = O.init_parameters(cases.WEIGHT_SEED)
+
+    def fresh():
+        model = NNmodel(default_params(dataset_size=1))
+        sd = model.state_dict()
+        for k, v in P.items():
+            sd[k].copy_(v)
+        model.load_state_dict(sd)
+        model = model.cuda()
+        return model, TrainStep(model, tuple(g.clone().to("cuda") for g in graphs))
+
+    model, ts = fresh()
+    for _ in range(6):
+        ts.step()
+    torch.cuda.synchronize()
+    want = torch.cat([ts.flat_p, ts.flat_m, ts.flat_v, ts.adam_state[0:1]]).clone()
+
+    model, ts = fresh()
+    ts.set_lr(5e-5)
+    for _ in range(3):
+        ts.step()
+    path = str(tmp_path / "ckpt.pth")
+    model.save_checkpoint(path, optimizer=ts)
+    saved = torch.load(path, map_location="cpu", weights_only=False)
+    assert "optimizer0" in saved and len(saved["optimizer0"]["state"]) > 100
+    model2, ts2 = fresh()
+    model2.load_checkpoint(optimizer=ts2, ckpdir=path, device="cuda")
+    ts2.sync_from_model()
+    for _ in range(3):
+        ts2.step()
+    torch.cuda.synchronize()
+    got = torch.cat([ts2.flat_p, ts2.flat_m, ts2.flat_v, ts2.adam_state[0:1]])
+    assert torch.equal(got, want)
+
+
 def test_side_stream_is_bit_identical_and_repeatable():
     """The side stream only reorders independent launches: parameters after 6 hipGraph-replayed steps on a 3 000-cell
     mesh must be bit-identical with and without it, and from run to run (a buffer-lifetime race between the two
