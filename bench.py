@@ -115,8 +115,9 @@ def main():
     ap.add_argument("--cells", type=int, default=50000)
     ap.add_argument("--meshes-per-gpu", type=int, default=1)
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
-    ap.add_argument("--graph", choices=("auto", "on", "off"), default="auto",
-                    help="hipGraph replay of the step; auto = time both ways (reported as step_modes) and keep the faster")
+    ap.add_argument("--graph", choices=("auto", "on", "off", "list"), default="auto",
+                    help="how the step is launched: off = eager Python launches, on = hipGraph replay, list = command-list "
+                         "replay (gfv/cmdlist.py); auto = time all three (reported as step_modes) and keep the fastest")
     ap.add_argument("--min-time", type=float, default=2.0,
                     help="repeat the timed K-step loop until this many seconds have been timed (0: exactly one loop)")
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU work for the cpu_baseline leg (0 = skip)")
@@ -190,18 +191,20 @@ def main():
     # the timed loops use the faster (all ranks alike: rank 0's decision is broadcast)
     modes = {}
     cal_steps = max(5, min(20, args.steps))
-    for name, flag in (("eager", False), ("hip_graph", True)):
-        if (graph_mode == "off" and flag) or (graph_mode == "on" and not flag):
-            continue
-        ts.use_graph = flag
-        for _ in range(3):
+    flags = {"eager": False, "hip_graph": True, "cmd_list": "list"}
+    want = {"auto": ("eager", "hip_graph", "cmd_list"), "off": ("eager",), "on": ("hip_graph",), "list": ("cmd_list",)}[graph_mode]
+    for name in want:
+        ts.use_graph = flags[name]
+        for _ in range(4):
             ts.step()
         modes[name] = timed(cal_steps) / cal_steps
-    pick = torch.tensor([1 if modes.get("hip_graph", 1e9) <= modes.get("eager", 1e9) else 0], device=device)
+    order = sorted(modes, key=modes.get)
+    pick = torch.tensor([list(flags).index(order[0])], device=device)
     if dist_on:
         dist.broadcast(pick, src=0)
-    ts.use_graph = bool(pick.item())
-    for _ in range(2):
+    used = list(flags)[int(pick.item())]
+    ts.use_graph = flags[used]
+    for _ in range(4):
         ts.step()
 
     reps, elapsed = [], 0.0
@@ -344,13 +347,13 @@ def main():
             "timed": {"loops": len(reps), "steps_per_loop": args.steps, "timed_steps": timed_steps,
                       "timed_seconds": round(elapsed, 4), "min_time": args.min_time,
                       "loop_ms_per_step_min_max": [round(1e3 * min(reps) / args.steps, 4), round(1e3 * max(reps) / args.steps, 4)]},
-            "step_modes": {k + "_ms_per_step": round(1e3 * v, 4) for k, v in modes.items()} | {"used": "hip_graph" if ts.use_graph else "eager"},
+            "step_modes": {k + "_ms_per_step": round(1e3 * v, 4) for k, v in modes.items()} | {"used": used},
             "dtype_note": ("fp32 values end to end; the products of the fused GEMM chains run as 3 f16 MFMAs on exact (hi, lo) "
                            "fp16 splits of the fp32 operands with fp32 accumulation (error <= the f32 MFMA's, parity tests at 1e-5)"
                            if ts.engine.f16split else "fp32 MFMA"),
             "config": {"workload": wl, "cells": sz["C"], "nodes": sz["N"], "faces": sz["E"],
                        "meshes_per_gpu": args.meshes_per_gpu, "global_batch": total_meshes, "parallelism": f"dp{world}",
-                       "hip_graph": bool(ts.use_graph), "final_loss": round(final_loss, 6)},
+                       "hip_graph": ts.use_graph is True, "launch_mode": used, "final_loss": round(final_loss, 6)},
             "rccl_ranks": (dist.get_world_size() if dist_on else 0), "dist_backend": (dist.get_backend() if dist_on else None),
             "distinct_gpus": min(world, ndev),
             "roofline": ({k: roof[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")}
@@ -364,7 +367,8 @@ def main():
             "executed_step_tflops": round(executed_flops / 1e12, 4),
             "step_mfma_frac": round(executed_flops / (ms_per_step * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
             "roofline_note": ("per-kernel durations: HIP events around every launch, ONE stream, eager (profile leg); value: "
-                              + ("hipGraph replay" if ts.use_graph else "eager launches")
+                              + {"eager": "eager launches from Python", "hip_graph": "hipGraph replay",
+                                 "cmd_list": "command-list replay of the eager launch sequence (gfv/cmdlist.py)"}[used]
                               + (" with the weight gradients on a side stream" if ts.engine.overlap else "")),
             "cpu_baseline": cpu,
         }

@@ -1,5 +1,5 @@
-"""`node_based_WLSQ` with the reference's signature (FVMmodel/FVdiscretization/FVgrad.py:235-244), precomputed-moments
-branch, orders 1st .. 4th (M = 2 / 5 / 9 / 14 Taylor terms, FVorder.py:23-72): HIP kernels `gfv_wlsq_fwd_ex` /
+"""`node_based_WLSQ` with the reference's signature (FVMmodel/FVdiscretization/FVgrad.py:235-244), both branches (moments
+handed in, FVgrad.py:295-325, or built here from the node positions, :273-294), `rt_cond`, orders 1st .. 4th (M = 2 / 5 / 9 / 14 Taylor terms, FVorder.py:23-72): HIP kernels `gfv_wlsq_fwd_ex` /
 `gfv_wlsq_bwd_ex` (CSR-ordered stencil gather, per-node M x M LU with partial pivoting on the row-normalised moment matrix,
 transpose solve for the adjoint)."""
 import torch
@@ -44,14 +44,28 @@ def node_based_WLSQ(phi_node=None, edge_index=None, extra_edge_index=None, mesh_
                     precompute_Moments: list = None, periodic_idx=None, rt_cond=False):
     if (order is None) or (order not in ["1st", "2nd", "3rd", "4th"]):
         raise ValueError("order must be specified in [\"1st\", \"2nd\", \"3rd\", \"4th\"]")   # FVgrad.py:261-262
-    if precompute_Moments is None or rt_cond:
-        raise NotImplementedError("only the precomputed-moments branch used by Intergrator.forward (FVscheme.py:648-655) "
-                                  "is built")
+    if precompute_Moments is None:
+        # FVgrad.py:273-294 -> compute_normal_matrix (:183-232) -> moments_order (FVorder.py:7-86): the moment matrices
+        # from the node positions, on the device (gfv/device_prep.py: sorts + prefix sums, no atomics), then the same solve
+        from gfv import device_prep
+        if extra_edge_index is None:
+            extra_edge_index = torch.zeros((2, 0), dtype=edge_index.dtype, device=edge_index.device)
+        A64, B1, Bx = device_prep.wlsq_moments(mesh_pos.to(torch.float64), edge_index, extra_edge_index, order)
+        precompute_Moments = [A64.to(torch.float32), B1.to(torch.float32), Bx.to(torch.float32)]
     terms = {"1st": 2, "2nd": 5, "3rd": 9, "4th": 14}[order]
     if precompute_Moments[0].shape[-1] != terms:
         raise ValueError(f"moment matrices are {precompute_Moments[0].shape[-1]} wide, order {order} needs {terms}")
     if phi_node.shape[1] > 7:
         raise NotImplementedError("at most 7 channels (FVscheme.py:643-646)")
     A, B1, Bx = precompute_Moments
+    if extra_edge_index is None:
+        extra_edge_index = torch.zeros((2, 0), dtype=edge_index.dtype, device=edge_index.device)
+        Bx = Bx[:0]
     plan = wlsq_part(MeshPlan(), edge_index, extra_edge_index, A, B1, Bx, phi_node.shape[0])
-    return _WlsqFn.apply(plan, phi_node)
+    out = _WlsqFn.apply(plan, phi_node)
+    if rt_cond:
+        # FVgrad.py:363-364: the 2-norm condition number of the row-normalised moment matrices (a diagnostic)
+        Af = A.to(torch.float32)
+        An = Af / (torch.norm(Af, p=2, dim=2, keepdim=True) + 1e-8)
+        return out, torch.linalg.cond(An)
+    return out

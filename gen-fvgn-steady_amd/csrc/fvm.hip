@@ -650,6 +650,64 @@ __global__ __launch_bounds__(256) void node_bwd_kernel(const NodeBwdArgs A) {
   og[3] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
+
+// ---- stand-alone 2nd-order interpolation operators (FVInterpolation.py:36-109, 111-185, 218-265) --------------------------
+// One generic gather: out[r, c] = sum_{k in row r} w_k (phi[col_k, c] + (tgt_r - src_{col_k}) . grad[col_k, c, :]) / W_r
+//   mode 0: w_k = 1, W_r = number of entries (clamped at 1)            node -> cell mean, node -> face average
+//   mode 1: w_k = 1 / |tgt_r - src_{col_k}|, W_r = sum_k w_k             cell -> node inverse-distance weights
+// Any channel count C; one thread per (row, channel).  The adjoint runs over the transposed incidence (rows of the
+// SOURCE points: trow / tidx list, per source, the forward entries (r) that read it), so it needs no atomics either.
+__global__ __launch_bounds__(256) void interp2_fwd_kernel(const float* __restrict__ phi, const float* __restrict__ grad,
+                                                          const float* __restrict__ srcpos, const float* __restrict__ tgtpos,
+                                                          const int* __restrict__ rowptr, const int* __restrict__ col,
+                                                          int mode, float* __restrict__ out, float* __restrict__ wsum,
+                                                          int R, int C) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)R * C) return;
+  const int r = (int)(i / C), c = (int)(i % C);
+  const float tx = tgtpos[2 * r], ty = tgtpos[2 * r + 1];
+  const int beg = rowptr[r], end = rowptr[r + 1];
+  float acc = 0.f, W = 0.f;
+  for (int k = beg; k < end; ++k) {
+    const int s = col[k];
+    const float dx = tx - srcpos[2 * s], dy = ty - srcpos[2 * s + 1];
+    float v = phi[(size_t)s * C + c];
+    if (grad) v += dx * grad[((size_t)s * C + c) * 2] + dy * grad[((size_t)s * C + c) * 2 + 1];
+    const float w = mode == 1 ? 1.0f / sqrtf(dx * dx + dy * dy) : 1.0f;
+    acc += w * v;
+    W += w;
+  }
+  if (mode == 0) W = fmaxf(W, 1.0f);
+  out[i] = acc / W;
+  if (wsum && c == 0) wsum[r] = W;
+}
+
+__global__ __launch_bounds__(256) void interp2_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ wsum,
+                                                          const float* __restrict__ srcpos, const float* __restrict__ tgtpos,
+                                                          const int* __restrict__ trow, const int* __restrict__ tidx,
+                                                          int mode, float* __restrict__ gphi, float* __restrict__ ggrad,
+                                                          int S, int C) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)S * C) return;
+  const int s = (int)(i / C), c = (int)(i % C);
+  const float sx = srcpos[2 * s], sy = srcpos[2 * s + 1];
+  float gp = 0.f, gx = 0.f, gy = 0.f;
+  for (int k = trow[s]; k < trow[s + 1]; ++k) {
+    const int r = tidx[k];
+    const float dx = tgtpos[2 * r] - sx, dy = tgtpos[2 * r + 1] - sy;
+    const float w = mode == 1 ? 1.0f / sqrtf(dx * dx + dy * dy) : 1.0f;
+    const float g = gout[(size_t)r * C + c] * (w / wsum[r]);
+    gp += g;
+    gx += g * dx;
+    gy += g * dy;
+  }
+  gphi[i] = gp;
+  if (ggrad) {
+    ggrad[2 * i] = gx;
+    ggrad[2 * i + 1] = gy;
+  }
+}
+
 }  // namespace
 
 #define LAUNCH1D(kernel, n, stream, ...)                                                                    \
@@ -802,4 +860,22 @@ extern "C" int gfv_fvm_bwd(const float* cres, const float* sums, const float* gl
                            float* gFf_ws, float* gphi, float* ggrad, int32_t N, int32_t E, int32_t C, void* stream) {
   return gfv_fvm_bwd_ex(cres, sums, gloss, Ff, cbatch, theta, sigma, dt, frow, fk, kcell, kS, ftype, nfrow, nfcol2, nrow, ncell,
                         crow, pos, fpos, centroid, area, gc_ws, gFf_ws, gphi, ggrad, N, E, C, 0, nullptr, nullptr, stream);
+}
+
+extern "C" int gfv_interp2_fwd(const float* phi, const float* grad, const float* srcpos, const float* tgtpos,
+                               const int32_t* rowptr, const int32_t* col, int32_t mode, float* out, float* wsum, int32_t R,
+                               int32_t C, void* stream) {
+  if (R < 0 || C < 1 || (mode != 0 && mode != 1) || !wsum) return GFV_ERR_ARG;
+  GfvProfScope ps_(GFV_K_FVM, 0, 0, stream);
+  LAUNCH1D(interp2_fwd_kernel, (long)R * C, stream, phi, grad, srcpos, tgtpos, rowptr, col, mode, out, wsum, R, C);
+  return GFV_OK;
+}
+
+extern "C" int gfv_interp2_bwd(const float* gout, const float* wsum, const float* srcpos, const float* tgtpos,
+                               const int32_t* trow, const int32_t* tidx, int32_t mode, float* gphi, float* ggrad, int32_t S,
+                               int32_t C, void* stream) {
+  if (S < 0 || C < 1 || (mode != 0 && mode != 1)) return GFV_ERR_ARG;
+  GfvProfScope ps_(GFV_K_FVM, 0, 0, stream);
+  LAUNCH1D(interp2_bwd_kernel, (long)S * C, stream, gout, wsum, srcpos, tgtpos, trow, tidx, mode, gphi, ggrad, S, C);
+  return GFV_OK;
 }

@@ -538,6 +538,17 @@ extern "C" int gfv_rowtile_chain(const gfv_rowtile_args_t* args, void* stream) {
   if (args->in_op == GFV_IN_LN) rag_t = rag_t && args->seg[0].width == 128 && (args->seg[0].ld % 4 == 0);
   if (args->gadd) rag_t = rag_t && args->seg[0].width == 128 && (args->seg[0].ld % 4 == 0);
   for (int l = 1; l < args->nlayers; ++l) rag_t = rag_t && (args->layer[l].K == 128);
+  // segmented-sum segments / per-segment saves: the plain instantiation of the register-resident chain only
+  {
+    bool csr = false;
+    for (int i = 0; i < args->nseg; ++i) {
+      const gfv_seg_t& sg = args->seg[i];
+      csr = csr || sg.csr_rowptr != nullptr || sg.save != nullptr;
+      if (sg.csr_rowptr && (!sg.idx || (i == 0 && args->in_add))) return GFV_ERR_ARG;
+    }
+    if (csr && (!fast_t || tchain_mode() == 0 || args->in_op == GFV_IN_LNBWD || args->fin_op == GFV_FIN_LNBWD))
+      return GFV_ERR_ARG;
+  }
   // split-fp16 form: every layer carries a weight image; first-layer segments start at 32-k slice boundaries
   bool f16 = (fast_t || rag_t) && tchain_mode() != 0 && f16_mode() != 0 && args->wmax != nullptr;
   for (int l = 0; l < args->nlayers; ++l) f16 = f16 && args->layer[l].Wh != nullptr;

@@ -283,6 +283,55 @@ __global__ __launch_bounds__(1024) void reduce_partials_small_kernel(const float
   }
 }
 
+// ---- several reductions in ONE launch ---------------------------------------------------------------------------------
+// blockIdx.y picks a piece (gfv_reduce_piece_t), blockIdx.x a group of 16 float4 output columns; 16 lanes of chunks per
+// output column, each lane sums every 16th chunk with 4 loads in flight, a fixed-order LDS tree folds the 16 lanes.
+// Serves the slab partials of a weight-gradient launch (hundreds of chunks x 64 KB), the per-tile LayerNorm partials
+// (a thousand chunks x 1 KB) and the small attention / slice-projection partials alike, so the parameter gradients of one
+// MLP need one reduction launch instead of two to five.
+struct ReduceMulti {
+  gfv_reduce_piece_t piece[8];
+};
+__global__ __launch_bounds__(256) void reduce_multi_kernel(const ReduceMulti A) {
+  __shared__ float4 red[16][17];
+  const gfv_reduce_piece_t P = A.piece[blockIdx.y];
+  const int cols4 = P.cols >> 2;
+  const long n4 = (long)P.rows * cols4;
+  const int q = threadIdx.x & 15, cg = threadIdx.x >> 4;
+  const long j = (long)blockIdx.x * 16 + q;
+  if ((long)blockIdx.x * 16 >= n4) return;
+  float4 s[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) s[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (j < n4) {
+    const int r = (int)(j / cols4), cc = (int)(j - (long)r * cols4);
+    const float4* p = reinterpret_cast<const float4*>(P.partial + (size_t)r * P.ld_in) + cc;
+    const size_t cs4 = (size_t)(P.chunk_stride >> 2);
+    int c = cg;
+    for (; c + 48 < P.n_chunks; c += 64) {
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = p[(size_t)(c + 16 * u) * cs4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { s[u].x += v[u].x; s[u].y += v[u].y; s[u].z += v[u].z; s[u].w += v[u].w; }
+    }
+    for (; c < P.n_chunks; c += 16) {
+      const float4 v = p[(size_t)c * cs4];
+      s[0].x += v.x; s[0].y += v.y; s[0].z += v.z; s[0].w += v.w;
+    }
+  }
+  red[cg][q] = make_float4((s[0].x + s[1].x) + (s[2].x + s[3].x), (s[0].y + s[1].y) + (s[2].y + s[3].y),
+                           (s[0].z + s[1].z) + (s[2].z + s[3].z), (s[0].w + s[1].w) + (s[2].w + s[3].w));
+  __syncthreads();
+  if (cg == 0 && j < n4) {
+    float4 t = red[0][q];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) { const float4 o = red[k][q]; t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w; }
+    const int r = (int)(j / cols4), cc = (int)(j - (long)r * cols4);
+    reinterpret_cast<float4*>(P.out + (size_t)r * P.ld_out)[cc] = t;
+  }
+}
+
 __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, int ld_in, float* __restrict__ out,
                                                         int rows, int cols) {
   __shared__ float tile[32][33];
@@ -404,6 +453,27 @@ extern "C" int gfv_reduce_partials_2d(const float* partial, int32_t n_chunks, in
   return GFV_OK;
 }
 
+extern "C" int gfv_reduce_multi(const gfv_reduce_piece_t* pieces, int32_t n_pieces, void* stream) {
+  if (n_pieces < 1 || n_pieces > 8) return GFV_ERR_ARG;
+  ReduceMulti a;
+  long maxn4 = 0;
+  double by = 0;
+  for (int i = 0; i < n_pieces; ++i) {
+    const gfv_reduce_piece_t& p = pieces[i];
+    if (p.n_chunks < 1 || p.rows < 1 || p.cols < 4 || (p.cols & 3) || (p.ld_in & 3) || (p.ld_out & 3) || (p.chunk_stride & 3) ||
+        p.ld_in < p.cols || p.ld_out < p.cols || ((reinterpret_cast<size_t>(p.partial) | reinterpret_cast<size_t>(p.out)) & 15))
+      return GFV_ERR_ARG;
+    a.piece[i] = p;
+    const long n4 = (long)p.rows * (p.cols >> 2);
+    maxn4 = n4 > maxn4 ? n4 : maxn4;
+    by += 4.0 * ((double)p.n_chunks + 1.0) * p.rows * p.cols;
+  }
+  GfvProfScope ps_(GFV_K_REDUCE, 0, by, stream);
+  hipLaunchKernelGGL(reduce_multi_kernel, dim3((unsigned)((maxn4 + 15) / 16), n_pieces), dim3(256), 0, (hipStream_t)stream, a);
+  GFV_CHECK_LAUNCH();
+  return GFV_OK;
+}
+
 extern "C" int gfv_reduce_partials_seg(const float* partial, const int32_t* seg_ptr, int32_t n_seg, int32_t n, float* out,
                                        void* stream) {
   GfvProfScope ps_(GFV_K_REDUCE, 0, 4.0 * 64.0 * n_seg * n, stream);
@@ -461,6 +531,7 @@ extern "C" int gfv_struct_size(int32_t which) {
     case 2: return (int)sizeof(gfv_rowtile_args_t);
     case 3: return (int)sizeof(gfv_wimg_desc_t);
     case 4: return (int)sizeof(gfv_dw_tile_t);
+    case 5: return (int)sizeof(gfv_reduce_piece_t);
     default: return -1;
   }
 }

@@ -324,7 +324,7 @@ __device__ __forceinline__ void to_halves(const float (&v)[8][4], float sc, gfv_
 }
 
 // ---- input segment -> activation registers (gather / concat piece / prologue element ops) -------------------------
-template <int T, int LNM, bool RAG>
+template <int T, int LNM, bool RAG, bool CSR>
 __device__ __forceinline__ void load_segment(const gfv_rowtile_args_t& A, int si, int rowbase, int g, const float* gam,
                                              const float* bet, float (&act)[T][8][4], float (&dgam)[8][4],
                                              float (&dbet)[8][4]) {
@@ -336,9 +336,48 @@ __device__ __forceinline__ void load_segment(const gfv_rowtile_args_t& A, int si
     const int m = rowbase + 16 * tt;
     const bool live = m < A.M;
     const int mc = live ? m : A.M - 1;
-    const size_t srow = s.idx ? (size_t)s.idx[mc] : (size_t)mc;
+    const bool csr = CSR && s.csr_rowptr != nullptr;
+    const size_t srow = (s.idx && !csr) ? (size_t)s.idx[mc] : (size_t)mc;
     const float* rp = s.ptr + srow * (size_t)s.ld + 4 * g;
-    if (RAG && ((s.width & 31) || (s.ld & 3))) {
+    if (csr) {
+      // the segment row is a segmented sum: scale[m] * sum_{k in [rowptr[m], rowptr[m+1])} src[idx[k], :] - the neighbour
+      // aggregation of the GnBlock (blocks.py:25-51,84-99) and the per-side scatter of the factored EdgeBlock's adjoint,
+      // formed right here instead of by a launch of its own that writes the sums out and a chain launch that reads them
+      // back.  Two neighbour rows in flight per lane, entries added in CSR order (fixed: deterministic).
+      const int beg = s.csr_rowptr[mc], end = live ? s.csr_rowptr[mc + 1] : beg;
+#pragma unroll
+      for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) act[tt][t][r] = 0.f;
+      for (int k = beg; k < end; k += 2) {
+        const bool two = (k + 1 < end);
+        const int c0 = s.idx[k], c1 = s.idx[two ? k + 1 : k];
+        const float* p0 = s.ptr + (size_t)c0 * (size_t)s.ld + 4 * g;
+        const float* p1 = s.ptr + (size_t)c1 * (size_t)s.ld + 4 * g;
+        // (unconditional loads - a register array filled under a branch is parked in scratch by the compiler; 16-column
+        // groups past the segment's width re-read group 0 and are not added)
+        float4 v0[8], v1[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          const int tv = t < nt_valid ? t : 0;
+          v0[t] = ld4(p0 + 16 * tv);
+          v1[t] = ld4(p1 + 16 * tv);
+        }
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+          if (t < nt_valid) {
+            act[tt][t][0] += v0[t].x; act[tt][t][1] += v0[t].y; act[tt][t][2] += v0[t].z; act[tt][t][3] += v0[t].w;
+            if (two) { act[tt][t][0] += v1[t].x; act[tt][t][1] += v1[t].y; act[tt][t][2] += v1[t].z; act[tt][t][3] += v1[t].w; }
+          }
+      }
+      if (s.csr_scale) {
+        const float sc = s.csr_scale[mc];
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) act[tt][t][r] *= sc;
+      }
+    } else if (RAG && ((s.width & 31) || (s.ld & 3))) {
       // ragged segment (encoder inputs of 12 / 15 columns, the decoder's 3-wide gradient): element-wise, zero padded
 #pragma unroll
       for (int t = 0; t < 8; ++t)
@@ -416,6 +455,11 @@ __device__ __forceinline__ void load_segment(const gfv_rowtile_args_t& A, int si
 #pragma unroll
       for (int t = 0; t < 8; ++t) st4(sp + 16 * t, act[tt][t]);
     }
+    if (CSR && s.save && live) {   // the assembled rows of THIS segment (the weight-gradient launch reads them)
+      float* sp = s.save + (size_t)m * 128 + 4 * g;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) st4(sp + 16 * t, act[tt][t]);
+    }
   }
 }
 
@@ -429,8 +473,9 @@ __device__ __forceinline__ void load_segment(const gfv_rowtile_args_t& A, int si
 // CU at 2 waves / SIMD, the occupancy of two 4-wave ones) moves half the weight bytes and runs half the barrier rounds
 // per row - and was slower (see the launcher): 8 waves marching in lockstep through the slice barriers hide less latency
 // than two independent groups of 4.  The LayerNorm partials stay per 64-row tile (same sums, same order) either way.
-template <int T, int LNM, bool RAG, bool H, int NW = 4>
+template <int T, int LNM, bool RAG, bool H, int NW = 4, bool CSR = false>
 __global__ __launch_bounds__(64 * NW, NW == 16 ? 4 : 2) void tchain_kernel(const gfv_rowtile_args_t A) {
+  static_assert(!CSR || (LNM == 0 && !RAG && T == 1), "segmented-sum segments exist in the plain instantiation");
   static_assert(!H || T == 1, "the f16 form is instantiated for 16 rows per wave");
   static_assert(NW == 4 || (H && T == 1 && NW == 8), "the wide workgroup exists in the f16 form only");
   constexpr int NT = 64 * NW;
@@ -530,7 +575,7 @@ __global__ __launch_bounds__(64 * NW, NW == 16 ? 4 : 2) void tchain_kernel(const
 #pragma unroll
               for (int r = 0; r < 4; ++r) dgam[t][r] = dbet[t][r] = 0.f;
           }
-          load_segment<T, LNM, RAG>(A, chunk, rowbase, g, par + PAR_GAMMA, par + PAR_BETA, act, dgam, dbet);
+          load_segment<T, LNM, RAG, CSR>(A, chunk, rowbase, g, par + PAR_GAMMA, par + PAR_BETA, act, dgam, dbet);
           if (lnb_in) ln_park(dgam, dbet, red, wave, li, g);
           if (H) {
             // every segment gets its own row scale; the accumulator follows (exact: powers of two)
@@ -761,6 +806,12 @@ __global__ __launch_bounds__(64 * NW, NW == 16 ? 4 : 2) void tchain_kernel(const
 template <int NW>
 static void launch_h(const gfv_rowtile_args_t* args, int ragged, int lnm, hipStream_t stream) {
   const dim3 wgs((args->M + 16 * NW - 1) / (16 * NW)), blk(64 * NW);
+  bool csr = false;
+  for (int i = 0; i < args->nseg; ++i) csr = csr || args->seg[i].csr_rowptr != nullptr || args->seg[i].save != nullptr;
+  if (csr) {   // (the caller checked: plain instantiation only)
+    hipLaunchKernelGGL((tchain_kernel<1, 0, false, true, NW, true>), wgs, blk, 0, stream, *args);
+    return;
+  }
   if (ragged) hipLaunchKernelGGL((tchain_kernel<1, 0, true, true, NW>), wgs, blk, 0, stream, *args);
   else if (lnm == 0) hipLaunchKernelGGL((tchain_kernel<1, 0, false, true, NW>), wgs, blk, 0, stream, *args);
   else if (lnm == 1) hipLaunchKernelGGL((tchain_kernel<1, 1, false, true, NW>), wgs, blk, 0, stream, *args);
@@ -778,7 +829,10 @@ int gfv_internal_tchain_launch(const gfv_rowtile_args_t* args, int ragged, int f
     launch_h<4>(args, ragged, lnm, stream);
     return 0;
   }
-  if (ragged) hipLaunchKernelGGL((tchain_kernel<1, 0, true, false>), wgs, blk, 0, stream, *args);
+  bool csr = false;
+  for (int i = 0; i < args->nseg; ++i) csr = csr || args->seg[i].csr_rowptr != nullptr || args->seg[i].save != nullptr;
+  if (csr) hipLaunchKernelGGL((tchain_kernel<1, 0, false, false, 4, true>), wgs, blk, 0, stream, *args);
+  else if (ragged) hipLaunchKernelGGL((tchain_kernel<1, 0, true, false>), wgs, blk, 0, stream, *args);
   else if (lnm == 0) hipLaunchKernelGGL((tchain_kernel<1, 0, false, false>), wgs, blk, 0, stream, *args);
   else if (lnm == 1) hipLaunchKernelGGL((tchain_kernel<1, 1, false, false>), wgs, blk, 0, stream, *args);
   else hipLaunchKernelGGL((tchain_kernel<1, 2, false, false>), wgs, blk, 0, stream, *args);

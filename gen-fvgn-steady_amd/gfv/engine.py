@@ -64,6 +64,7 @@ class Engine:
                  order="2nd"):
         self._dw_ws, self._dw_ws_main = None, None
         self._pending = []
+        self._defer_mode = os.environ.get("GFV_DEFER", "0") == "1"
         self._wt, self._wt_key, self._wt_live = {}, None, False
         self.mp = message_passing_num
         self.mode = _MODE[integrator]
@@ -82,6 +83,9 @@ class Engine:
         self.factor = os.environ.get("GFV_EDGE_FACTOR", "1") != "0"
         # fp32 products of the chain kernels as split-fp16 on the f16 MFMA pipe (include/gfv.h, gfv_weight_images)
         self.f16split = os.environ.get("GFV_F16SPLIT", "1") != "0"
+        # neighbour sums as the prologue of the chain launch that consumes them (gfv_seg_t.csr_rowptr) instead of launches
+        # of their own: 24 fewer launches per step on the main stream
+        self.csr_fuse = ops.csr_prologue_enabled()
         self._wi, self._wi_key, self._wmax, self._wi_abs = None, None, None, None
         self._pkey_cache = None
         self._zero_e = None
@@ -128,14 +132,19 @@ class Engine:
         return Engine._Fork(self, keep)
 
     def defer(self, fn, *keep):
-        """Queue parameter-gradient work (nothing downstream of the backward chain reads it) for the side stream.  The
-        queue is flushed ONCE per block (`flush`): every fork is an event on the main queue, ~6.5 us of bubble each
-        (rocprofv3 --kernel-trace), and a block used to fork three to five times.  Without the side stream the work runs
-        right here - results do not depend on where it runs (disjoint gradient blocks, fixed summation orders)."""
+        """Parameter-gradient work (nothing downstream of the backward chain reads it): launched on the side stream right
+        away, beside the dX chain that follows.  (Round 2 measured the alternative - queue it and fork once per block, the
+        last block's on the main stream: 6.5 us less bubble per fork, but the weight gradients of a whole block then land
+        on top of the next block's 75 k-row dX chain, 162 us instead of 125-137: 5.00 against 4.90 ms / step.  GFV_DEFER=1
+        selects it.)  Without the side stream the work runs inline - results do not depend on where it runs (disjoint
+        gradient blocks, fixed summation orders)."""
         if not self.overlap:
             fn()
-        else:
+        elif self._defer_mode:
             self._pending.append((fn, keep))
+        else:
+            with self.fork(*keep):
+                fn()
 
     def flush(self, on_main=False):
         """Launch the queued work on the side stream (one fork), or - `on_main` - on the main stream: the last pieces of
@@ -283,7 +292,7 @@ class Engine:
                 f"{lin}.4.bias"] + ([f"{prefix}.1.weight", f"{prefix}.1.bias"] if ln else [])
 
     def mlp3_fwd(self, P, prefix, M, segs, *, ln=True, res=None, in_add=None, want_nores=False, keep=True, w1=None,
-                 padd=None):
+                 padd=None, saved_segs=None):
         """w1: column block of the first weight that multiplies `segs` (default: all of it); padd = (t [*,256], s, r):
         gathered addend t[s[m], :128] + t[r[m], 128:] to the first pre-activation (factored EdgeBlock)."""
         names = self._mlp_names(prefix, ln)
@@ -304,7 +313,9 @@ class Engine:
             fin_gamma=P[names[6]] if ln else None, fin_beta=P[names[7]] if ln else None, fin_presave=y3,
             res=[res] if res is not None else None, out_nores=nores,
             **(dict(padd=padd[0], padd_s=padd[1], padd_r=padd[2]) if padd is not None else {}))
-        saved = dict(z1=z1, z2=z2, y3=y3, segs=segs, in_add=in_add, M=M, ln=ln, prefix=prefix)
+        # (a segmented-sum input segment is kept for the backward in its assembled form, written by the launch itself)
+        saved = dict(z1=z1, z2=z2, y3=y3, segs=segs if saved_segs is None else saved_segs, in_add=in_add, M=M, ln=ln,
+                     prefix=prefix)
         return out, nores, saved
 
     def mlp3_bwd(self, P, sv, G, grads, *, outs=None, res=None, gadd=None, W1t=None, g_ld=None, g_add=None):
@@ -347,10 +358,17 @@ class Engine:
         tiles.append(self._tile(g3, nout, Seg(sv["z2"]), a_op=1, ldg=(G.stride(0) if g_ld is None else g_ld) if not ln else None,
                                 gscale=s0))
         def side():
-            self._dw_block(grads, [(names[0], names[1], len(sv["segs"])), (names[2], names[3], 1), (names[4], names[5], 1)],
-                           tiles, M)
+            # all weight gradients of the MLP in one launch, all their reductions (slab partials -> the gradient block,
+            # per-tile LayerNorm partials -> dgamma | dbeta) in one more
+            wptr, slabs, blen, _ = self._dw_block(
+                grads, [(names[0], names[1], len(sv["segs"])), (names[2], names[3], 1), (names[4], names[5], 1)], tiles, M,
+                reduce=False)
+            off0, _ = grads.block(names[0], names[5])
+            pieces = [dict(partial=wptr, out=grads.flat.data_ptr() + 4 * off0, n_chunks=slabs, chunk_stride=blen, rows=1, cols=blen)]
             if ln:
-                ops.reduce_partials(part, tiles_n, 256, out=self._gview2(grads, names[6], names[7]))
+                pieces.append(dict(partial=part, out=self._gview2(grads, names[6], names[7]), n_chunks=tiles_n, chunk_stride=256,
+                                   rows=1, cols=256))
+            ops.reduce_multi(pieces)
         self.defer(side, gz1, gz2, g3, G, part, gs, sv["z1"], sv["z2"], sv["in_add"], *[sg.t for sg in sv["segs"]],
                    *[sg.idx for sg in sv["segs"]])
 
@@ -370,9 +388,11 @@ class Engine:
             self._dw_ws = torch.zeros(int(n_floats * 1.25) + 1024, dtype=torch.float32, device=dev)
         return self._dw_ws
 
-    def _dw_block(self, grads, layers, tiles, M, row0s=None, reduce=True):
+    def _dw_block(self, grads, layers, tiles, M, row0s=None, reduce=True, ws_offset=0):
         """layers: [(weight name, bias name or None, n tiles of that weight)], in parameter order; tiles in the same
-        order.  One launch + one reduction into the contiguous gradient block of those parameters."""
+        order.  One launch + (reduce=True) one reduction into the contiguous gradient block of those parameters;
+        reduce=False leaves the slab partials in the workspace at float offset `ws_offset` and returns
+        (pointer, slabs, floats per slab, workspace floats used) for a caller that folds several reductions into one launch."""
         lib = L.load()
         first = layers[0][0]
         last = layers[-1][1] if layers[-1][1] is not None else layers[-1][0]
@@ -405,11 +425,12 @@ class Engine:
                 ti += 1
         need = lib.gfv_dw_multi_workspace_floats(M, ti, blen)
         dev = grads.flat.device
-        ws = self._workspace(need, dev)
-        L.check(lib.gfv_dw_multi(ct, ti, M, blen, ws.data_ptr(), (grads.flat.data_ptr() + 4 * off0) if reduce else None, 0,
+        ws = self._workspace(ws_offset + need, dev)
+        wptr = ws.data_ptr() + 4 * ws_offset
+        L.check(lib.gfv_dw_multi(ct, ti, M, blen, wptr, (grads.flat.data_ptr() + 4 * off0) if reduce else None, 0,
                                  L.stream_ptr()), "gfv_dw_multi")
-        if not reduce:   # (workspace, slabs, floats per slab): the caller reduces pieces of it itself
-            return ws, lib.gfv_dw_slabs(M, ti, None), blen
+        if not reduce:
+            return wptr, lib.gfv_dw_slabs(M, ti, None), blen, (need + 3) // 4 * 4
 
     @staticmethod
     def _put(grads, name, value):
@@ -420,21 +441,37 @@ class Engine:
     # ------------------------------------------------------------------------------------------------------------
     def gn_fwd(self, P, prefix, x, e, pl):
         N, E = pl.N, pl.E
-        nb = ops.seg_gather_sum(x, pl.n_rowptr, pl.n_col_node, N)
+        fuse = self.csr_fuse
         if self.factor:
             W1 = P[f"{prefix}.eb_module.net.0.0.weight"]                   # [128, 384] = [W1a | W1b | W1c]
             pab = _empty(x.device, N, 256)                                  # [W1a nb | W1b nb] per node
-            ops.rowtile_chain(N, [Seg(nb)], [LayerSpec(W1[:, 0:128], stack=W1[:, 128:256])],
-                              [(pab, 256), (pab.data_ptr() + 512, 256)])
+            if fuse and ops.stack_ready(W1[:, 0:128], W1[:, 128:256], rows=True):
+                # nb = sum over the neighbours (blocks.py:84-99) formed in the prologue of the launch that multiplies it
+                nb = _empty(x.device, N, 128)
+                ops.rowtile_chain(N, [Seg(x, csr=(pl.n_rowptr, pl.n_col_node), save=nb)],
+                                  [LayerSpec(W1[:, 0:128], stack=W1[:, 128:256])], [(pab, 256), (pab.data_ptr() + 512, 256)])
+            else:
+                nb = ops.seg_gather_sum(x, pl.n_rowptr, pl.n_col_node, N)
+                ops.rowtile_chain(N, [Seg(nb)], [LayerSpec(W1[:, 0:128], stack=W1[:, 128:256])],
+                                  [(pab, 256), (pab.data_ptr() + 512, 256)])
             e_out, e_new, sv_e = self.mlp3_fwd(P, f"{prefix}.eb_module.net", E, [Seg(e)], res=e, want_nores=True,
                                                w1=W1[:, 256:384], padd=(pab, pl.es, pl.er))
             sv_e["nb"] = nb
         else:
+            nb = ops.seg_gather_sum(x, pl.n_rowptr, pl.n_col_node, N)
             e_out, e_new, sv_e = self.mlp3_fwd(P, f"{prefix}.eb_module.net", E, [Seg(nb, pl.es), Seg(nb, pl.er), Seg(e)],
                                                res=e, want_nores=True)
         agg = ops.seg_gather_sum(e_new.view(2 * E, 64), pl.n_rowptr, pl.n_col_edge2, N)
-        nbm = ops.seg_gather_sum(agg, pl.n_rowptr, pl.n_col_node, N, scale=pl.inv_deg)
-        x_out, _, sv_n = self.mlp3_fwd(P, f"{prefix}.nb_module.net", N, [Seg(nbm), Seg(x)], res=x)
+        if fuse:
+            # nbm = mean over the neighbours of the aggregates (blocks.py:44-51), in the node MLP's prologue; the launch
+            # leaves the assembled rows ([N,128] buffer, columns 0:64) for the weight gradient of the first layer
+            nbm = _empty(x.device, N, 128)
+            x_out, _, sv_n = self.mlp3_fwd(P, f"{prefix}.nb_module.net", N,
+                                           [Seg(agg, csr=(pl.n_rowptr, pl.n_col_node), scale=pl.inv_deg, save=nbm), Seg(x)],
+                                           res=x, saved_segs=[Seg(nbm, width=64, ld=128), Seg(x)])
+        else:
+            nbm = ops.seg_gather_sum(agg, pl.n_rowptr, pl.n_col_node, N, scale=pl.inv_deg)
+            x_out, _, sv_n = self.mlp3_fwd(P, f"{prefix}.nb_module.net", N, [Seg(nbm), Seg(x)], res=x)
         return x_out, e_out, dict(sv_e=sv_e, sv_n=sv_n, prefix=prefix)
 
     def _edge_tmp(self, dev):
@@ -463,31 +500,42 @@ class Engine:
                                  ln_partial=part, gadd=gadd[0], gadd_s=gadd[1], gadd_r=gadd[2], gscale=gs)
         s0, s1, s2 = (gs[0], gs[1], gs[2]) if have else (None, None, None)
         # adjoint of the gathers (W1a nb)[s], (W1b nb)[r]: per-side scatter of dz1 to the nodes, then ONE node-level GEMM
-        G_s = ops.seg_gather_sum(gz1, pl.s_rowptr, pl.s_col, N)
-        G_r = ops.seg_gather_sum(gz1, pl.r_rowptr, pl.r_col, N)
         g_nb = _empty(dev, N, 128)
-        ops.rowtile_chain(N, [Seg(G_s), Seg(G_r)], [LayerSpec(Wabt)], [g_nb])
+        if self.csr_fuse:
+            G_s, G_r = _empty(dev, N, 128), _empty(dev, N, 128)
+            ops.rowtile_chain(N, [Seg(gz1, csr=(pl.s_rowptr, pl.s_col), save=G_s), Seg(gz1, csr=(pl.r_rowptr, pl.r_col), save=G_r)],
+                              [LayerSpec(Wabt)], [g_nb])
+        else:
+            G_s = ops.seg_gather_sum(gz1, pl.s_rowptr, pl.s_col, N)
+            G_r = ops.seg_gather_sum(gz1, pl.r_rowptr, pl.r_col, N)
+            ops.rowtile_chain(N, [Seg(G_s), Seg(G_r)], [LayerSpec(Wabt)], [g_nb])
         nb = sv["nb"]
         def side():
-            # slab partials are laid out like small stand-in blocks ([W1c | b1 | W2 | b2 | W3 | b3] and [W1a | W1b]) and
-            # reduced straight into their places of the real gradient block: W1c / W1ab are column blocks of W1 [128, 384]
+            # slab partials are laid out like small stand-in blocks ([W1c | b1 | W2 | b2 | W3 | b3] and [W1a | W1b]), in two
+            # regions of the workspace; ONE launch then reduces every piece straight into its place of the real gradient
+            # block (W1c / W1ab are column blocks of W1 [128, 384]) together with the per-tile LayerNorm partials
             tmpE, tmpN = self._edge_tmp(dev)
             gW1 = grads.view(names[0])
-            ws, slabs, blen = self._dw_block(tmpE, [("W1c", "b1", 1), ("W2", "b2", 1), ("W3", "b3", 1)],
-                                             [self._tile(gz1, 128, Seg(e), gscale=s2),
-                                              self._tile(gz2, 128, Seg(sv["z1"]), a_op=1, gscale=s1),
-                                              self._tile(g3, 128, Seg(sv["z2"]), a_op=1, gscale=s0)], M, reduce=False)
-            red2d = L.load().gfv_reduce_partials_2d
-            L.check(red2d(ws.data_ptr(), slabs, blen, 128, 128, 384, gW1.data_ptr() + 4 * 256, L.stream_ptr()), "reduce_2d")
+            lib = L.load()
+            self._workspace(lib.gfv_dw_multi_workspace_floats(M, 3, tmpE.block("W1c", "b3")[1])
+                            + lib.gfv_dw_multi_workspace_floats(N, 2, tmpN.block("W1ab", "W1ab")[1]) + 8, dev)   # both regions, once
+            w1, slabs1, blen1, used = self._dw_block(tmpE, [("W1c", "b1", 1), ("W2", "b2", 1), ("W3", "b3", 1)],
+                                                     [self._tile(gz1, 128, Seg(e), gscale=s2),
+                                                      self._tile(gz2, 128, Seg(sv["z1"]), a_op=1, gscale=s1),
+                                                      self._tile(g3, 128, Seg(sv["z2"]), a_op=1, gscale=s0)], M, reduce=False)
+            w2, slabs2, blen2, _ = self._dw_block(tmpN, [("W1ab", None, 2)],
+                                                  [self._tile(G_s, 128, Seg(nb)), self._tile(G_r, 128, Seg(nb))], N,
+                                                  reduce=False, ws_offset=used)
+            assert w2 == w1 + 4 * used
             off, length = grads.block(names[1], names[5])
             o2, l2 = tmpE.block("b1", "b3")
             assert l2 == length
-            L.check(red2d(ws.data_ptr() + 4 * o2, slabs, blen, 1, l2, l2, grads.flat.data_ptr() + 4 * off, L.stream_ptr()),
-                    "reduce_2d")
-            ws, slabs, blen = self._dw_block(tmpN, [("W1ab", None, 2)],
-                                             [self._tile(G_s, 128, Seg(nb)), self._tile(G_r, 128, Seg(nb))], N, reduce=False)
-            L.check(red2d(ws.data_ptr(), slabs, blen, 128, 256, 384, gW1.data_ptr(), L.stream_ptr()), "reduce_2d")
-            ops.reduce_partials(part, tiles_n, 256, out=self._gview2(grads, names[6], names[7]))
+            ops.reduce_multi([
+                dict(partial=w1, out=gW1.data_ptr() + 4 * 256, n_chunks=slabs1, chunk_stride=blen1, rows=128, cols=128, ld_out=384),
+                dict(partial=w1 + 4 * o2, out=grads.flat.data_ptr() + 4 * off, n_chunks=slabs1, chunk_stride=blen1, rows=1, cols=l2),
+                dict(partial=w2, out=gW1.data_ptr(), n_chunks=slabs2, chunk_stride=blen2, rows=128, cols=256, ld_out=384),
+                dict(partial=part, out=self._gview2(grads, names[6], names[7]), n_chunks=tiles_n, chunk_stride=256, rows=1,
+                     cols=256)])
         self.defer(side, gz1, gz2, g3, G_s, G_r, nb, e, part, gs, sv["z1"], sv["z2"])
         return g_nb, g_e_in
 
@@ -602,10 +650,16 @@ class Engine:
                           [LayerSpec(self._T(Wpre))], [g_fx1], fin_op=L.FIN_LNBWD, fin_gamma=gam2, fin_aux=fx1,
                           ln_partial=part, res=[g_out])
         def side_pre():
-            self._dw_block(grads, [(f"{prefix}.mlp.linear_pre.0.weight", f"{prefix}.mlp.linear_pre.0.bias", 2)],
-                           [self._tile(g_z, 128, Seg(fx1), a_op=2, a_gamma=gam2, a_beta=bet2, ldg=256, g_offset=128 * h)
-                            for h in range(2)], N, row0s=[0, 128])
-            ops.reduce_partials(part, tiles, 256, out=self._gview2(grads, f"{prefix}.ln_2.weight", f"{prefix}.ln_2.bias"))
+            wn, bn = f"{prefix}.mlp.linear_pre.0.weight", f"{prefix}.mlp.linear_pre.0.bias"
+            wptr, slabs, blen, _ = self._dw_block(
+                grads, [(wn, bn, 2)],
+                [self._tile(g_z, 128, Seg(fx1), a_op=2, a_gamma=gam2, a_beta=bet2, ldg=256, g_offset=128 * h) for h in range(2)],
+                N, row0s=[0, 128], reduce=False)
+            off0, _ = grads.block(wn, bn)
+            ops.reduce_multi([
+                dict(partial=wptr, out=grads.flat.data_ptr() + 4 * off0, n_chunks=slabs, chunk_stride=blen, rows=1, cols=blen),
+                dict(partial=part, out=self._gview2(grads, f"{prefix}.ln_2.weight", f"{prefix}.ln_2.bias"), n_chunks=tiles,
+                     chunk_stride=256, rows=1, cols=256)])
         self.defer(side_pre, g_z, fx1, part)
         # to_out
         g_out_x = _empty(dev, N, 128)
@@ -628,11 +682,9 @@ class Engine:
                                             P[f"{a}.to_v.weight"].data_ptr(), sv["token"].data_ptr(), sv["norm"].data_ptr(),
                                             sv["attn"].data_ptr(), g_raw.data_ptr(), g_norm.data_ptr(), dwp.data_ptr(), st),
                 "slice_attention_bwd")
-        def side_qkv():   # parameter gradients only: off the critical path
-            dqkv = ops.reduce_partials(dwp, B * 8, 768)
-            self._put(grads, f"{a}.to_q.weight", dqkv[0:256])
-            self._put(grads, f"{a}.to_k.weight", dqkv[256:512])
-            self._put(grads, f"{a}.to_v.weight", dqkv[512:768])
+        def side_qkv():   # parameter gradients only: off the critical path; one launch, straight into the three tensors
+            ops.reduce_multi([dict(partial=dwp.data_ptr() + 4 * 256 * i, out=grads.view(f"{a}.{nm}.weight"), n_chunks=B * 8,
+                                   chunk_stride=768, rows=1, cols=256) for i, nm in enumerate(("to_q", "to_k", "to_v"))])
         self.defer(side_qkv, dwp)
         g_fx_mid = _empty(dev, N, 128)
         L.check(lib.gfv_deslice(w.data_ptr(), g_raw.data_ptr(), batch.data_ptr(), g_fx_mid.data_ptr(), N, 0, st), "deslice")
@@ -646,10 +698,10 @@ class Engine:
                                           P[f"{a}.in_project_slice.bias"].data_ptr(), temp.data_ptr(), w.data_ptr(),
                                           gw.data_ptr(), g_x_mid.data_ptr(), sp.data_ptr(), N, st), "slice_softmax_bwd")
         def side_slice():
-            ds = ops.reduce_partials(sp, nblk, 552)
-            self._put(grads, f"{a}.in_project_slice.weight", ds[0:512])
-            self._put(grads, f"{a}.in_project_slice.bias", ds[512:544])
-            self._put(grads, f"{a}.graph_temperature", ds[544:552])
+            ops.reduce_multi([dict(partial=sp.data_ptr() + 4 * o, out=grads.view(nm), n_chunks=nblk, chunk_stride=552, rows=1,
+                                   cols=c)
+                              for o, c, nm in ((0, 512, f"{a}.in_project_slice.weight"), (512, 32, f"{a}.in_project_slice.bias"),
+                                               (544, 8, f"{a}.graph_temperature"))])
         self.defer(side_slice, sp)
         # projections; fx_in also feeds the to_out residual
         t1, g_fx_in = _empty(dev, N, 128), _empty(dev, N, 128)
@@ -849,9 +901,8 @@ class Engine:
                 self.bucket_hook()
         self.mlp3_bwd(P, sv["sv_nenc"], g_x, grads, g_add=pending)
         self.flush()
-        # the last weight gradients have no dX chain left to run beside: on the main stream, while the side stream drains
         self.mlp3_bwd(P, sv["sv_eenc"], g_e, grads)
-        self.flush(on_main=True)
+        self.flush(on_main=self._defer_mode)
 
     # ------------------------------------------------------------------------------------------------------------
     # whole model (importer.py:156-240)

@@ -389,6 +389,11 @@ def tecplot_to_raw(tec, bc_json, **physics):
             "cells_index": cells_index, "cells_face": cells_face, "bc": pb}
 
 
+def load_tecplot_mesh_from(tec, bc_json, **physics):
+    """`tecplot_to_raw` under the name the loaders use (tec: result of `read_tecplot`)."""
+    return tecplot_to_raw(tec, bc_json, **physics)
+
+
 def load_tecplot_mesh(dat_path, bc_json_path, **physics):
     with open(bc_json_path, "r") as f:
         bc_json = json.load(f)

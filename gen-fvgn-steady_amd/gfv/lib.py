@@ -22,7 +22,8 @@ FIN_PLAIN, FIN_LN, FIN_LNBWD = 0, 1, 2
 
 
 class Seg(C.Structure):
-    _fields_ = [("ptr", C.c_void_p), ("idx", C.c_void_p), ("width", C.c_int32), ("ld", C.c_int32)]
+    _fields_ = [("ptr", C.c_void_p), ("idx", C.c_void_p), ("width", C.c_int32), ("ld", C.c_int32),
+                ("csr_rowptr", C.c_void_p), ("csr_scale", C.c_void_p), ("save", C.c_void_p)]
 
 
 class Layer(C.Structure):
@@ -55,6 +56,11 @@ class DwTile(C.Structure):
                 ("a_gamma", C.c_void_p), ("a_beta", C.c_void_p), ("ldg", C.c_int32), ("n_out", C.c_int32),
                 ("width", C.c_int32), ("ld", C.c_int32), ("a_op", C.c_int32), ("ld_out", C.c_int32),
                 ("out_off", C.c_int64), ("db_off", C.c_int64), ("gscale", C.c_void_p)]
+
+
+class ReducePiece(C.Structure):
+    _fields_ = [("partial", C.c_void_p), ("out", C.c_void_p), ("chunk_stride", C.c_int64), ("n_chunks", C.c_int32),
+                ("rows", C.c_int32), ("cols", C.c_int32), ("ld_in", C.c_int32), ("ld_out", C.c_int32), ("reserved", C.c_int32)]
 
 
 _lib = None
@@ -99,6 +105,7 @@ _SIGNATURES = {
     "gfv_weight_absmax": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "gfv_weight_images": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p]),
     "gfv_reduce_partials_2d": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "gfv_reduce_multi": (C.c_int, [C.POINTER(ReducePiece), C.c_int32, C.c_void_p]),
     "gfv_reduce_partials_seg": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "gfv_transpose": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "gfv_slice_softmax_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
@@ -124,6 +131,8 @@ _SIGNATURES = {
     "gfv_cell_to_node": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
     "gfv_fvm_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "gfv_fvm_bwd_ex": (C.c_int, [C.c_void_p] * 26 + [C.c_int32] * 4 + [C.c_void_p] * 3),
+    "gfv_interp2_fwd": (C.c_int, [C.c_void_p] * 6 + [C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    "gfv_interp2_bwd": (C.c_int, [C.c_void_p] * 6 + [C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "gfv_graph_norm_stats": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "gfv_normalizer_blocks": (C.c_int, [C.c_int32]),
     "gfv_normalizer_update": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

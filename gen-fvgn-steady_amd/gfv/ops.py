@@ -61,6 +61,26 @@ def reduce_partials(partial, n_chunks, n, out=None, accumulate=False):
     return out
 
 
+def reduce_multi(pieces):
+    """pieces: list of dicts (partial ptr / tensor, out ptr / tensor, n_chunks, chunk_stride, rows, cols, ld_in, ld_out):
+    one launch for all of them (include/gfv.h, gfv_reduce_multi)."""
+    lib = L.load()
+    arr = (L.ReducePiece * len(pieces))()
+    for a, p in zip(arr, pieces):
+        a.partial = p["partial"].data_ptr() if torch.is_tensor(p["partial"]) else p["partial"]
+        a.out = p["out"].data_ptr() if torch.is_tensor(p["out"]) else p["out"]
+        a.n_chunks, a.chunk_stride, a.rows, a.cols = p["n_chunks"], p["chunk_stride"], p["rows"], p["cols"]
+        a.ld_in = p.get("ld_in", p["cols"])
+        a.ld_out = p.get("ld_out", p["cols"])
+    L.check(lib.gfv_reduce_multi(arr, len(pieces), L.stream_ptr()), "gfv_reduce_multi")
+
+
+def csr_prologue_enabled():
+    """Segmented-sum segments need the register-resident chain (GFV_TCHAIN != 0); GFV_CSR_FUSE=0 keeps the separate launches."""
+    import os
+    return os.environ.get("GFV_TCHAIN", "1") != "0" and os.environ.get("GFV_CSR_FUSE", "1") != "0"
+
+
 def rowtile_tiles(M):
     return (M + 63) // 64
 
@@ -73,17 +93,24 @@ def gscale_ld(M):
 class Seg:
     """Input segment: rows of `t` (optionally gathered by int32 `idx`), `width` valid columns, row stride `ld`."""
 
-    def __init__(self, t, idx=None, width=None, ld=None, offset=0):
+    def __init__(self, t, idx=None, width=None, ld=None, offset=0, csr=None, scale=None, save=None):
+        """csr = (rowptr, col): the segment row is scale[m] * the sum of the rows col[rowptr[m] : rowptr[m+1]] of `t` (a
+        segmented sum formed in the launch's prologue, include/gfv.h gfv_seg_t); save: [M,128] buffer for the assembled rows."""
         self.t, self.idx = t, idx
         self.width = t.shape[-1] if width is None else width
         self.ld = t.stride(0) if ld is None else ld
         self.offset = offset  # column offset (floats) into the row
+        self.csr, self.scale, self.save = csr, scale, save
+        assert csr is None or idx is None
 
     def fill(self, cs):
         cs.ptr = self.t.data_ptr() + 4 * self.offset
-        cs.idx = _p(self.idx)
+        cs.idx = _p(self.idx) if self.csr is None else self.csr[1].data_ptr()
         cs.width = self.width
         cs.ld = self.ld
+        cs.csr_rowptr = None if self.csr is None else self.csr[0].data_ptr()
+        cs.csr_scale = _p(self.scale)
+        cs.save = _p(self.save)
 
 
 class LayerSpec:
@@ -186,7 +213,7 @@ class WeightImages:
 _WI = None   # the WeightImages the chain launches currently consult (set by the engine around forward / backward)
 
 
-def stack_ready(Wa, Wb):
+def stack_ready(Wa, Wb, rows=False):
     """True when a launch may use the virtual layer stacked from the blocks Wa, Wb (split-fp16 form on, images available)."""
     return (_WI is not None and L.load().gfv_f16split_enabled() and Wa.shape == Wb.shape and Wa.shape[0] == 128
             and _WI.lookup(Wa, Wb) != 0)

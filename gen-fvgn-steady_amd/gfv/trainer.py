@@ -160,6 +160,25 @@ class TrainStep:
             self._lw = tuple(float(x) for x in sd["gfv_loss_weights"])
         self._sync_hyper()
 
+    def named_state(self):
+        """{name: (parameter, exp_avg, exp_avg_sq)} views of the flat buffers.  (The alignment padding between tensors is not
+        state: its gradient slots take whatever the shared slab workspace held, see gfv_dw_multi in include/gfv.h.)"""
+        out = {}
+        for n in self.G.off:
+            off, k, sh = self.G.off[n], self.G.numel(n), self.G.shape[n]
+            out[n] = tuple(b[off:off + k].view(sh) for b in (self.flat_p, self.flat_m, self.flat_v))
+        return out
+
+    def advance_time(self):
+        """Time advance of the reference's solve loop (solve_with_grad_GPU.py:180-197): after the inner iterations of a time
+        step the predicted node field becomes the next step's input state, the conditioning columns stay -
+        `graph_node.x = cat(uvp_node_new.detach(), backup[:, 3:])`.  In place on the persistent backup (captured steps keep
+        reading the same tensor)."""
+        if self.uvp_node is None:
+            raise RuntimeError("advance_time() needs the prediction of a step (want_outputs=True)")
+        self.x_backup[:, 0:3].copy_(self.uvp_node)
+        self.x.copy_(self.x_backup)
+
     def sync_from_model(self):
         """Call after loading a checkpoint into the model: `load_state_dict` copies into the parameter views of the flat
         buffer in place, so the values are already there; this re-checks the aliasing and drops captured steps (their

@@ -58,6 +58,14 @@ typedef struct {
   const int32_t* idx; /* optional row gather index [M]; NULL = identity */
   int32_t width;      /* valid columns (<= 128); zero padded to a multiple of 16 inside the kernel */
   int32_t ld;         /* row stride in floats */
+  /* optional segmented-sum segment (register-resident chain, no LayerNorm backward, widths multiples of 32):
+   *   row m = csr_scale[m] * sum_{k in [csr_rowptr[m], csr_rowptr[m+1])} ptr[idx[k] * ld + 0:width]
+   * (idx is then the CSR column list [nnz]; csr_scale may be NULL) - the GnBlock's neighbour aggregation
+   * (blocks.py:25-51,84-99: scatter_add / scatter_mean over the two-way edge list) and the per-side scatter of the factored
+   * EdgeBlock's adjoint as the prologue of the launch that consumes them, entries added in CSR order. */
+  const int32_t* csr_rowptr;
+  const float* csr_scale;
+  float* save;        /* optional [M, 128]: the assembled rows of this segment (columns >= width are written as zeros) */
 } gfv_seg_t;
 
 enum {                /* per-layer element op applied to the accumulator */
@@ -222,6 +230,19 @@ int gfv_reduce_partials(const float* partial, int32_t n_chunks, int32_t n, float
 int gfv_reduce_partials_2d(const float* partial, int32_t n_chunks, int64_t chunk_stride, int32_t rows, int32_t cols,
                            int32_t ld_out, float* out, void* stream);
 
+/* Several such reductions in ONE launch (the parameter gradients of one MLP: slab partials of gfv_dw_multi with
+ * grad_block == NULL, per-tile LayerNorm partials, small per-block partials), each straight into its place:
+ *   out[r * ld_out + c] = sum_{chunk < n_chunks} partial[chunk * chunk_stride + r * ld_in + c]   (r < rows, c < cols)
+ * cols, ld_in, ld_out, chunk_stride multiples of 4 floats, pointers 16-byte aligned; n_pieces <= 8.  Fixed summation
+ * order (16 interleaved chunk lanes, then an ordered fold): deterministic, no atomics. */
+typedef struct {
+  const float* partial;
+  float* out;
+  int64_t chunk_stride; /* floats between consecutive chunks */
+  int32_t n_chunks, rows, cols, ld_in, ld_out, reserved;
+} gfv_reduce_piece_t;
+int gfv_reduce_multi(const gfv_reduce_piece_t* pieces, int32_t n_pieces, void* stream);
+
 /* Segmented form: out[b, 0:n] = sum of the chunk rows seg_ptr[b] .. seg_ptr[b+1]-1 of partial [n_chunks, n] (n % 4 == 0,
  * 16-byte aligned).  Pre-reduces the per-chunk slice tokens of each graph (GraphTransolver.py:64-73 global_add_pool). */
 int gfv_reduce_partials_seg(const float* partial, const int32_t* seg_ptr, int32_t n_seg, int32_t n, float* out,
@@ -369,6 +390,17 @@ int gfv_train_loss(const float* losses, int32_t B, float w_cont, float w_mom, fl
                    void* stream);
 /* same, weights read from the device: hyper[5..7] = {w_cont, w_mom, w_press} of the buffer gfv_adam_step_dev takes */
 int gfv_train_loss_dev(const float* losses, int32_t B, const float* hyper, float* loss, float* gloss, void* stream);
+
+/* Stand-alone 2nd-order interpolation (FVInterpolation.py `Interplot`: node_to_cell_2nd_order :36-109,
+ * node_to_face_2nd_order :111-185, cell_to_node_2nd_order :218-265), any channel count C:
+ *   out[r, c] = sum_{k in row r} w_k (phi[col[k], c] + (tgtpos[r] - srcpos[col[k]]) . grad[col[k], c, 0:2]) / W_r
+ * mode 0: w = 1, W = max(entries, 1) (mean / average); mode 1: w = 1 / |tgtpos[r] - srcpos[col[k]]|, W = sum w
+ * (inverse-distance weights).  grad may be NULL.  wsum [R] receives W (the adjoint needs it).  The adjoint takes the
+ * transposed incidence: for source s the forward rows trow[s] .. trow[s+1]-1 of tidx that read it; ggrad may be NULL. */
+int gfv_interp2_fwd(const float* phi, const float* grad, const float* srcpos, const float* tgtpos, const int32_t* rowptr,
+                    const int32_t* col, int32_t mode, float* out, float* wsum, int32_t R, int32_t C, void* stream);
+int gfv_interp2_bwd(const float* gout, const float* wsum, const float* srcpos, const float* tgtpos, const int32_t* trow,
+                    const int32_t* tidx, int32_t mode, float* gphi, float* ggrad, int32_t S, int32_t C, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Optional per-launch HIP-event timing of the main kernels on their own stream (bench.py roofline leg).

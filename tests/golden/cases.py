@@ -69,3 +69,22 @@ def real_cylinder(golden_dir=None):
     raw["bc"] = json.loads(str(fx["raw.bc"]))
     mesh = meshgen.finish_mesh(raw)
     return build_batch([mesh], [fx["field"]]), fx
+
+
+def poly_cylinder(golden_dir=None):
+    """The reference's polygon example mesh mesh_example/cylinder_flow_poly (Tecplot FEPolygon, cells of 3 ... 9 nodes; raw
+    reader arrays committed as data in poly_cylinder.npz by make_golden_poly.py) -> (graphs, fixture)."""
+    import json
+    from gfv import ingest
+    golden_dir = golden_dir or os.path.dirname(os.path.abspath(__file__))
+    fx = np.load(os.path.join(golden_dir, "poly_cylinder.npz"))
+    tec = {"pos": fx["tec.pos"], "face_node": fx["tec.face_node"].astype(np.int64), "left": fx["tec.left"].astype(np.int64),
+           "right": fx["tec.right"].astype(np.int64), "boundary_pos": fx["tec.boundary_pos"]}
+    bcd = json.loads(str(fx["raw.bc"]))
+    bc_json = {"stencil|khops": bcd["stencil|khops"], "sigma": bcd["sigma"], "inlet_type": bcd["inlet_type"],
+               "theta_PDE": dict(bcd["theta_PDE"], inlet=[bcd["U"]], rho=[bcd["rho"]], mu=[bcd["mu"]], source=[bcd["source"]],
+                                 aoa=[bcd["aoa"]], dt=bcd["dt"], L=bcd["L"])}
+    raw = ingest.tecplot_to_raw(tec, bc_json)
+    raw["bc"] = bcd
+    mesh = meshgen.finish_mesh(raw)
+    return build_batch([mesh], [fx["field"]]), fx, mesh

@@ -59,7 +59,9 @@ def main():
             ts.step()
         torch.cuda.synchronize()
         nn_ = model.node_norm
-        parts = dict(p=ts.flat_p, m=ts.flat_m, v=ts.flat_v, t=ts.adam_state[0:1], acc_sum=nn_.acc_sum.reshape(-1),
+        ns = ts.named_state()   # (named tensors only: the alignment padding of the flat buffers is not state)
+        parts = dict(p=torch.cat([v[0].reshape(-1) for v in ns.values()]), m=torch.cat([v[1].reshape(-1) for v in ns.values()]),
+                     v=torch.cat([v[2].reshape(-1) for v in ns.values()]), t=ts.adam_state[0:1], acc_sum=nn_.acc_sum.reshape(-1),
                      acc_sq=nn_.acc_sum_squared.reshape(-1), acc_count=nn_.acc_count.reshape(-1), loss=ts.loss.reshape(-1))
         state = {k: v.detach().cpu().clone() for k, v in parts.items()}
         return state, calls, ts

@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol():
     handle = lib.load()  # raises if libgfv.so is missing or a bound symbol is absent
     header = open(os.path.join(ROOT, "include", "gfv.h")).read()
     declared = set(re.findall(r"\b(gfv_[a-z0-9_]+)\s*\(", header))
-    declared -= {"gfv_seg_t", "gfv_layer_t", "gfv_rowtile_args_t", "gfv_dw_tile_t", "gfv_wimg_desc_t"}
+    declared -= {"gfv_seg_t", "gfv_layer_t", "gfv_rowtile_args_t", "gfv_dw_tile_t", "gfv_wimg_desc_t", "gfv_reduce_piece_t"}
     assert len(declared) >= 40
     for name in sorted(declared):
         assert hasattr(handle, name), f"{name} declared in include/gfv.h but not exported by libgfv.so"
@@ -31,11 +31,11 @@ def test_library_exports_every_declared_symbol():
 def test_ctypes_structs_match_header_layout():
     import ctypes as C
     from gfv import lib
-    assert C.sizeof(lib.Seg) == 24 and C.sizeof(lib.Layer) == 64
+    assert C.sizeof(lib.Seg) == 48 and C.sizeof(lib.Layer) == 64
     assert C.sizeof(lib.DwTile) == 6 * 8 + 6 * 4 + 2 * 8 + 8   # (+ gscale)
     assert C.sizeof(lib.RowtileArgs) % 8 == 0
     handle = lib.load()   # the library reports the sizes it was compiled with
-    for which, st in enumerate((lib.Seg, lib.Layer, lib.RowtileArgs, lib.WimgDesc, lib.DwTile)):
+    for which, st in enumerate((lib.Seg, lib.Layer, lib.RowtileArgs, lib.WimgDesc, lib.DwTile, lib.ReducePiece)):
         assert handle.gfv_struct_size(which) == C.sizeof(st), (which, st)
 
 

@@ -211,8 +211,8 @@ def test_step_modes_are_bit_identical():
         if mode == "list":
             assert any(isinstance(k, tuple) and k[0] == "list" for k in ts._graphs), "the command list was never recorded"
             assert len(next(v for k, v in ts._graphs.items() if k[0] == "list")[0]) > 100
-        finals[mode] = torch.cat([ts.flat_p, ts.flat_m, ts.flat_v, ts.adam_state[0:1], ts.loss.reshape(-1),
-                                  ts.losses.reshape(-1), ts.uvp_node.reshape(-1)]).clone()
+        finals[mode] = torch.cat([t.reshape(-1) for pmv in ts.named_state().values() for t in pmv]
+                                 + [ts.adam_state[0:1], ts.loss.reshape(-1), ts.losses.reshape(-1), ts.uvp_node.reshape(-1)]).clone()
     assert torch.equal(finals[False], finals[True]), "hipGraph replay differs from eager"
     assert torch.equal(finals[False], finals["list"]), "command-list replay differs from eager"
 
@@ -240,7 +240,7 @@ def test_trainstep_state_dict_resume_equals_uninterrupted(tmp_path):
     for _ in range(6):
         ts.step()
     torch.cuda.synchronize()
-    want = torch.cat([ts.flat_p, ts.flat_m, ts.flat_v, ts.adam_state[0:1]]).clone()
+    want = torch.cat([t.reshape(-1) for pmv in ts.named_state().values() for t in pmv] + [ts.adam_state[0:1]]).clone()
 
     model, ts = fresh()
     ts.set_lr(5e-5)
@@ -256,7 +256,7 @@ def test_trainstep_state_dict_resume_equals_uninterrupted(tmp_path):
     for _ in range(3):
         ts2.step()
     torch.cuda.synchronize()
-    got = torch.cat([ts2.flat_p, ts2.flat_m, ts2.flat_v, ts2.adam_state[0:1]])
+    got = torch.cat([t.reshape(-1) for pmv in ts2.named_state().values() for t in pmv] + [ts2.adam_state[0:1]])
     assert torch.equal(got, want)
 
 
