@@ -122,6 +122,8 @@ def main():
                     help="repeat the timed K-step loop until this many seconds have been timed (0: exactly one loop)")
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU work for the cpu_baseline leg (0 = skip)")
     ap.add_argument("--profile-steps", type=int, default=3)
+    ap.add_argument("--skip-fp32-form", action="store_true",
+                    help="do not time the all-fp32-MFMA form as well (profiling runs: every executed step is then the same form)")
     ap.add_argument("--allow-shared-gpu", action="store_true",
                     help="self-test only: let several ranks share one GPU (the JSON then says so in distinct_gpus)")
     args = ap.parse_args()
@@ -165,6 +167,13 @@ def main():
     model = NNmodel(default_params(dataset_size=1)).to(device)
     graph_mode = "off" if args.no_graph else args.graph
     ts = TrainStep(model, graphs, world_size=world, use_graph=False, distributed=dist_on)
+    executed = [0]
+    _step = ts.step
+
+    def counted_step():
+        executed[0] += 1
+        return _step()
+    ts.step = counted_step
 
     def barrier():
         torch.cuda.synchronize()
@@ -245,14 +254,16 @@ def main():
         # MFMAs per product group (include/gfv.h): their matrix roofline is the f16 MFMA peak / 3 in fp32-equivalent
         # flops; every kernel is priced against BOTH rooflines (algorithmic flops and algorithmic bytes over the measured
         # duration) and reported on the one it sits closer to
-        h = ", true>" if ts.engine.f16split else ", false>"
+        h = "true" if ts.engine.f16split else "false"
         chain_peak = PEAK_F16_MFMA_TFLOPS / 3.0 if ts.engine.f16split else PEAK_F32_MFMA_TFLOPS
-        spec = {7: ("tchain_kernel<1, 0, false" + h, chain_peak, "gnn"), 8: ("tchain_kernel<1, 1, false" + h, chain_peak, "gnn"),
-                9: ("tchain_kernel<1, 2, false" + h, chain_peak, "gnn"), 10: ("tchain_kernel<1, 0, true" + h, chain_peak, "gnn"),
+        tc = lambda lnm, rag, csr="false": f"tchain_kernel<1, {lnm}, {rag}, {h}, 4, {csr}>"
+        spec = {7: (tc(0, "false"), chain_peak, "gnn"), 8: (tc(1, "false"), chain_peak, "gnn"),
+                9: (tc(2, "false"), chain_peak, "gnn"), 10: (tc(0, "true"), chain_peak, "gnn"),
+                13: (tc(0, "false", "true"), chain_peak, "gnn"),
                 1: ("rowtile_chain_kernel", PEAK_F32_MFMA_TFLOPS, "gnn"),
                 2: ("dw_multi_h_kernel" if ts.engine.f16split else "dw_multi_kernel", chain_peak, "gnn"),
                 3: ("seg_gather_sum_vec", None, "gnn"),
-                11: ("reduce_partials_*", None, "gnn"),
+                11: ("reduce_multi_kernel / reduce_partials_*", None, "gnn"),
                 4: ("slice_* / deslice (Transolver slice attention)", None, "slice"),
                 5: ("wlsq_* / face_* / cell_* / node_bwd / graph_loss (finite volume)", None, "fvm"),
                 12: ("wimg / wabsmax / transpose_batch (per-step weight images)", None, "misc"),
@@ -280,7 +291,7 @@ def main():
                              "fp32_equiv_tflops": round(tf, 3), "algorithmic_gbs": round(gbs, 1),
                              "frac_mfma": round(f_mfma, 4), "frac_hbm": round(f_hbm, 4)})
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        traffic_source = None
+        traffic_source, step_traffic = None, None
         # the committed PMC figures were collected on the default workload (one 50 k-cell mesh per GPU)
         if os.path.exists(pmc) and args.meshes_per_gpu == 1 and args.cells == 50000 and args.workload == "cylinder":
             traffic = json.load(open(pmc))
@@ -288,6 +299,7 @@ def main():
                               "command (profiles/collect.sh), bytes per launch; NOT measured in this run")
             for r in roof_all:
                 r["traffic"] = traffic.get(r["kernel"])
+            step_traffic = traffic.get("__step_total__")
         if roof_all:
             roof = max(roof_all, key=lambda r: r["ms_per_step"])
         comp = compulsory_step_bytes(sz)
@@ -301,6 +313,7 @@ def main():
             "priced_ms_per_step": round(priced_ms, 4), "single_stream_eager_ms_per_step": round(single_stream_ms, 4),
             "priced_share_of_single_stream_step": round(priced_ms / single_stream_ms, 4),
             "priced_launch_records_per_step": sum(r["launches_per_step"] for r in roof_all),
+            "pmc_traffic_bytes_per_step": step_traffic, "pmc_traffic_source": traffic_source,
             "convention": "SURVEY.md 8(d): distinct inputs read once, outputs written once, int32 indices; step = 3 x forward",
         }
 
@@ -310,7 +323,7 @@ def main():
 
     # ---- the same step with every GEMM product on the fp32 MFMA (the form without the fp16 split), for the record ----
     fp32_form = None
-    if ts.engine.f16split:
+    if ts.engine.f16split and not args.skip_fp32_form:
         ts_use_graph = ts.use_graph
         ts.use_graph, ts.engine.f16split = False, False
         lib.gfv_set_f16split(0)
@@ -371,6 +384,7 @@ def main():
                                  "cmd_list": "command-list replay of the eager launch sequence (gfv/cmdlist.py)"}[used]
                               + (" with the weight gradients on a side stream" if ts.engine.overlap else "")),
             "cpu_baseline": cpu,
+            "steps_executed": executed[0],   # every training step this process ran (all legs): profiles divide by it
         }
         if cpu:
             line["gpu_over_cpu"] = round(value / cpu["value"], 1)

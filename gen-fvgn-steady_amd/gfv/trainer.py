@@ -328,7 +328,9 @@ class TrainStep:
                 torch.cuda.current_stream().wait_stream(s)
                 torch.cuda.synchronize()
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                # (thread_local: the RCCL watchdog thread of a process group polls events while this thread captures; under
+                # the default global mode that poll invalidates the capture and aborts the process)
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
                     self._body(acc, with_adam=not dist_on)
                 g = (g, self.engine.capture_signature())
                 self._graphs[key] = g

@@ -1,21 +1,31 @@
 #!/bin/bash
 # Collect the round's judged measurements on the GPU box (run through gpurun from the repo root):
-#   gpurun -- 'profiles/collect.sh r01'
-# writes under gpurun_out/<tag>/ : bench.json (default bench.py line), kernel_stats.csv (rocprofv3 --kernel-trace
-# --stats of the same command), hbm_pmc.txt + pmc_traffic.json (separate --pmc FETCH_SIZE / WRITE_SIZE passes).
-# Copy the results into profiles/ afterwards (gpurun_out/ is scratch).
+#   gpurun -- 'bash profiles/collect.sh r02'
+# writes under gpurun_out/<tag>/ : bench.json (the default bench.py line, with cpu_baseline), bench_b8.json (8 meshes per
+# GPU: BASELINE config 4's per-GPU load), bench_cavity.json (config 2: 71 x 71 lid-driven cavity), kernel_stats.csv
+# (rocprofv3 --kernel-trace --stats of the default bench command), hbm_pmc.txt + pmc_traffic.json (separate --pmc FETCH_SIZE /
+# WRITE_SIZE passes of a short eager bench run), parity_fp64.txt (HIP path and fp32 oracle against the float64 oracle, from
+# the -m gpu tests), pytest.log.  Copy the results into profiles/ afterwards (gpurun_out/ is scratch).
 R=${GRAFT_REPO_ROOT:-/root/repo}
-tag=${1:-r01}
+tag=${1:-r02}
 O=$R/gpurun_out/$tag
 mkdir -p $O
+cd $R
+GFV_PARITY_REPORT=$O/parity_fp64.txt timeout 2400 python3 -m pytest tests -m gpu -q > $O/pytest.log 2>&1
 cd /tmp && export TMPDIR=/tmp
 timeout 900 python3 $R/bench.py > $O/bench.json 2> $O/bench.err
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 $R/bench.py --cpu-budget 0 > $O/prof.log 2>&1
+timeout 900 python3 $R/bench.py --meshes-per-gpu 8 --cpu-budget 0 --steps 10 --warmup 4 > $O/bench_b8.json 2> $O/bench_b8.err
+timeout 900 python3 $R/bench.py --workload cavity --cells 5041 --cpu-budget 8 > $O/bench_cavity.json 2> $O/bench_cavity.err
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 $R/bench.py --cpu-budget 0 > $O/prof.log 2>&1
 find $O/prof -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats.csv \;
 rm -rf $O/prof
+# PMC passes: eager launches only, split-fp16 form only; the JSON line says how many steps ran (steps_executed)
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_$c -- python3 $R/bench.py --steps 3 --warmup 1 --no-graph --cpu-budget 0 --profile-steps 1 > $O/pmc_$c.log 2>&1
+  timeout 900 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_$c -- python3 $R/bench.py --steps 5 --warmup 1 --graph off --min-time 0 --cpu-budget 0 --profile-steps 1 --skip-fp32-form > $O/pmc_$c.log 2>&1
 done
-python3 $R/profiles/pmc_aggregate.py $O > $O/hbm_pmc.txt
+NSTEPS=$(python3 -c "import json,sys; print([json.loads(l) for l in open('$O/pmc_FETCH_SIZE.log') if l.startswith('{')][-1]['steps_executed'])")
+python3 $R/profiles/pmc_aggregate.py $O $NSTEPS > $O/hbm_pmc.txt
 rm -rf $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE
-cat $O/hbm_pmc.txt
+tail -3 $O/pytest.log
+head -c 400 $O/bench.json; echo
+tail -4 $O/hbm_pmc.txt

@@ -213,3 +213,40 @@ def test_pre_train_adam_call_sequence_through_reference_import_paths():
     assert rel(model.node_norm.acc_sum, buffers["acc_sum"]) < 1e-6
     worst = max(float((p.detach().cpu() - Po[k]).abs().max()) for k, p in model.named_parameters())
     assert worst < 4 * 2 * params.lr   # (4 Adam steps; see tests/test_config5_gpu.py on why parameters are judged loosely)
+
+
+def test_plain_encoder_processer_decoder_matches_oracle(graphs):
+    """`EncoderProcesserDecoder` (FVMmodel/Models/FVGN/EPD.py:222-270: Encoder, mp GnBlocks, Decoder - the FVGN simulator
+    without Transolver blocks) as the reference composes it from the block operators, forward and backward."""
+    from FVMmodel.Models.FVGN.EPD import EncoderProcesserDecoder
+    from gfv.graph import Data
+    P1 = O.init_parameters(cases.WEIGHT_SEED, hyper={"net": "TransFVGN_v1"})   # holds encoder / GN_block_list / decoder under `simulator.`
+    net = EncoderProcesserDecoder(message_passing_num=3, edge_input_size=15, node_input_size=12, node_output_size=3)
+    sd = net.state_dict()
+    for k in sd:
+        sd[k].copy_(P1["simulator." + k])
+    net.load_state_dict(sd)
+    net = net.cuda()
+    g0 = graphs[0]
+    gen = torch.Generator().manual_seed(2)
+    xin = torch.randn(g0.x.shape[0], 12, generator=gen)
+    ea = O.relative_edge_attr(xin, g0.pos, g0.edge_index)
+    Pg = {k: v.clone().requires_grad_(True) for k, v in P1.items() if "TransBlock" not in k}
+    xn = O.mlp3(Pg, "simulator.encoder.nb_encoder", xin)
+    en = O.mlp3(Pg, "simulator.encoder.eb_encoder", ea)
+    for i in range(3):
+        xn, en = O.gn_block(Pg, f"simulator.GN_block_list.{i}", xn, en, g0.edge_index)
+    ref = O.decoder(Pg, "simulator.decoder", xn)
+    w = torch.randn(ref.shape, generator=gen)
+    (ref * w).sum().backward()
+    gd = Data(x=xin.cuda(), edge_attr=ea.cuda(), edge_index=g0.edge_index.cuda(), face=None, num_graphs=2, batch=g0.batch.cuda())
+    out = net(graph_node=gd, graph_cell=None)
+    assert rel(out, ref) < TOL
+    (out * w.cuda()).sum().backward()
+    gscale = max(float(v.grad.abs().max()) for v in Pg.values() if v.grad is not None)
+    for k, p in net.named_parameters():
+        r = Pg["simulator." + k].grad
+        if r is None:
+            continue
+        err = float((p.grad.cpu().double() - r.double()).abs().max())
+        assert err < 1e-4 * float(r.abs().max()) + 1e-6 * gscale, (k, err)

@@ -20,7 +20,7 @@ def test_trainstep_through_rccl_one_rank_bit_identical():
                        capture_output=True, text=True, timeout=900, env=env)
     lines = re.findall(r"RCCLRESULT graph=(\d) same=(\d) bucket=(\d+) allreduce=(\d+) early_pending=(\d+) backend=(\S+) world=(\d+)",
                        r.stdout)
-    assert r.returncode == 0 and len(lines) == 3 and "RCCLOK 1" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.returncode == 0 and len(lines) == 3 and "RCCLOK 1" in r.stdout, r.stdout[-2000:] + r.stderr[-6000:]
     for graph, same, bucket, allreduce, early, backend, world in lines:
         assert backend == "nccl" and world == "1"
         assert same == "1", "a one-rank RCCL step must be bit-identical to the non-distributed step"
