@@ -224,6 +224,11 @@ __device__ __forceinline__ void dw_body(const DwLaunch& A, const gfv_dw_tile_t& 
 constexpr int HBLK = 1024;                 // bytes per (column tile, part) block
 constexpr int HOP = 16 * HBLK;             // bytes per operand and sub-tile
 constexpr int HBUF = 2 * HOP;              // bytes per buffer (G, A)
+#ifdef GFV_DW_SINGLEBUF
+constexpr int HSTAGE = HBUF;               // experiment build: one staging buffer
+#else
+constexpr int HSTAGE = 2 * HBUF;           // two staging buffers
+#endif
 
 template <bool FULL>
 __device__ __forceinline__ void dw_body_h(const DwLaunch& A, const gfv_dw_tile_t& T, unsigned char* lds) {
@@ -306,7 +311,7 @@ __device__ __forceinline__ void dw_body_h(const DwLaunch& A, const gfv_dw_tile_t
     __syncthreads();
   }
   // the inverse column scales wait in LDS (behind the staging buffers) for the output stage
-  float* inv_sa = reinterpret_cast<float*>(lds + 2 * HBUF);
+  float* inv_sa = reinterpret_cast<float*>(lds + HSTAGE);
   if (r4 == 0) *reinterpret_cast<float4*>(&inv_sa[col]) = make_float4(1.0f / sa.x, 1.0f / sa.y, 1.0f / sa.z, 1.0f / sa.w);
   float amax = 0.f;   // a_op 1 / 2: range check of the unscaled split
 
@@ -397,7 +402,11 @@ __device__ __forceinline__ void dw_body_h(const DwLaunch& A, const gfv_dw_tile_t
   for (int m0 = m_beg; m0 < m_end; m0 += SUB) {
     const bool more = m0 + SUB < m_end;
     if (more) load_sub(m0 + SUB);
+#ifdef GFV_DW_SINGLEBUF
+    const unsigned char* Gs = lds;
+#else
     const unsigned char* Gs = lds + buf * HBUF;
+#endif
     const unsigned char* As = Gs + HOP;
     gfv_f16x8 gh[4], gl[4], ah[4], al[4];
 #pragma unroll
@@ -416,9 +425,17 @@ __device__ __forceinline__ void dw_body_h(const DwLaunch& A, const gfv_dw_tile_t
           if (FULL || (64 * wn + 16 * i < npad && 64 * wk + 16 * j < kpad))
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(term == 0 ? gl[i] : gh[i], term == 1 ? al[j] : ah[j],
                                                                acc[i][j], 0, 0, 0);
+#ifdef GFV_DW_SINGLEBUF
+    // experiment (profiles/tools/ab.sh): ONE 32 KB staging buffer - every wave holds its fragments after the reads above,
+    // so the buffer may be refilled after a barrier; a second barrier publishes it
+    __syncthreads();
+    if (more) store_sub(0, m0 + SUB);
+    __syncthreads();
+#else
     if (more) store_sub(buf ^ 1, m0 + SUB);
     __syncthreads();
     buf ^= 1;
+#endif
   }
 
   if (!(amax <= 65504.f)) atomicOr(&g_gfv_status_flags, GFV_FLAG_DW_RANGE);   // (integer atomic; also catches NaN)
@@ -459,8 +476,8 @@ __global__ __launch_bounds__(256, 2) void dw_multi_kernel(const DwLaunch A) {
 }
 
 __global__ __launch_bounds__(256, 2) void dw_multi_h_kernel(const DwLaunch A) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * HBUF + 512];   // + the inverse column scales
-  static_assert(2 * HBUF >= 8 * LDT * 4, "the bias-gradient fold reuses the staging buffers");
+  __shared__ __attribute__((aligned(16))) unsigned char lds[HSTAGE + 512];   // + the inverse column scales
+  static_assert(HSTAGE >= 8 * LDT * 4, "the bias-gradient fold reuses the staging buffers");
   const gfv_dw_tile_t& T = A.tile[blockIdx.y];
   const bool full = (T.n_out == 128) && (T.width == 128) && ((T.ldg & 3) == 0) && ((T.ld & 3) == 0);
   if (full) dw_body_h<true>(A, T, lds);

@@ -103,22 +103,27 @@ def global_grad_error(grads, ref):
     return (num / den) ** 0.5
 
 
+ILL_CONDITIONED = ".TransBlock.Attn."   # slice-attention parameters: every entry is a sum over ALL nodes of cancelling terms
+
+
 def check_gradients(report, label):
-    """Every gradient tensor within 1e-4 of its scale of the float64 value, element-wise - except where the reference's
-    own fp32 arithmetic (the fp32 oracle, same inputs) is itself not there: such tensors are ill-conditioned sums (the 8
-    slice temperatures, the slice projection, the 16 x 16 attention weights: each entry the sum over all nodes of cancelling
-    terms) that no fp32 evaluation order resolves, and there the HIP path has to stay within 3x the fp32 oracle's own
-    distance.  Norm-wise over ALL gradients the HIP path has to be within 1e-5 of float64, or at least as close as the fp32
-    oracle (measured: bench mesh 2.1e-6 against 4.6e-4 for the fp32 oracle, whose sequential fp32 scatter sums carry most
-    of the noise; the reference's polygon mesh 1.2e-5 against 2.7e-5)."""
+    """Against the float64 oracle.  (1) Norm-wise over all gradients the HIP path is within 1e-5, or at least as close as the
+    reference's own fp32 arithmetic (the fp32 oracle on the same inputs).  (2) Element-wise, every gradient tensor is
+    within 1e-4 of its scale - except tensors of the slice-attention parameter group (temperatures, slice projection,
+    in_project_x, the 16 x 16 q / k weights: sums over all nodes of cancelling terms that no fp32 evaluation order resolves;
+    the fp32 oracle itself is 1e-4 ... 3e-3 away there, and by how much varies from run to run with the thread schedule of
+    its index_add), which are held to 5e-3.  (3) The median tensor is within 2e-5.
+    Measured (profiles/r02_parity_fp64.txt): bench mesh - global 2.1e-6 (fp32 oracle 4.6e-4), median 2.7e-6 (4.2e-4), 9 of
+    154 tensors beyond 1e-4, worst 2.6e-3 (graph_temperature; fp32 oracle 2.7e-3)."""
     eh, e32 = report["grad_hip"], report["grad_o32"]
     over = {k: (eh[k], e32[k]) for k in eh if eh[k] >= 1e-4}
     print(f"[{label}] gradient tensors beyond 1e-4 of scale (HIP | fp32 oracle), {len(over)} of {len(eh)}:")
     for k, (a, b) in sorted(over.items(), key=lambda kv: -kv[1][0]):
         print(f"  {k:70s} {a:.2e} | {b:.2e}")
     for k, (a, b) in over.items():
-        assert a <= 3.0 * b, (k, a, b)
+        assert ILL_CONDITIONED in k and a < 5e-3, (k, a, b)
     assert report["grad_global"][0] < max(1e-5, report["grad_global"][1]), report["grad_global"]
+    assert report["grad_median_elementwise"][0] < 2e-5, report["grad_median_elementwise"]
 
 
 def compare_to_fp64(graphs, P, label):
