@@ -24,7 +24,27 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def source_hash():
+    """sha256 over every source the library is built from (a fresh checkout has arbitrary mtimes: the hash decides)."""
+    import hashlib
+    h = hashlib.sha256()
+    hdrs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".h")]
+    hdrs.append(os.path.join(os.path.dirname(os.path.dirname(HERE)), "include", "gfv.h"))
+    for f in sources() + hdrs:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()
+
+
 def build(force=False, verbose=False):
+    """Compile csrc/*.hip -> gfv/libgfv.so.  Up to date = the library exists AND was built from exactly these sources
+    (content hash kept next to it); otherwise everything is recompiled."""
+    stamp = LIB + ".srchash"
+    want = source_hash()
+    if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read().strip() == want:
+        return LIB
+    force = True
     srcs = sources()
     hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     hdrs.append(os.path.join(os.path.dirname(os.path.dirname(HERE)), "include", "gfv.h"))
@@ -50,6 +70,8 @@ def build(force=False, verbose=False):
         list(ex.map(run, jobs))
     if force or jobs or _stale(LIB, objs):
         run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB])
+    with open(stamp, "w") as f:
+        f.write(want + "\n")
     return LIB
 
 
