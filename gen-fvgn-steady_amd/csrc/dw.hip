@@ -492,13 +492,16 @@ extern "C" int gfv_dw_slabs(int32_t M, int32_t ntiles, int32_t* rows_per_slab) {
   // aim at ~512 workgroups per launch (one full round at 2 per CU; measured best of 384/512/768/1024: fewer slabs =
   // less partial-sum traffic), slabs of a multiple of 32 rows, at least 64 rows
   if (ntiles < 1) ntiles = 1;
-  static int wgs = 0;
+  static int wgs = 0, wgs_small = 0;
   if (wgs == 0) {
     const char* e = getenv("GFV_DW_WGS");
     wgs = e ? atoi(e) : 512;
     if (wgs < 1) wgs = 512;
+    e = getenv("GFV_DW_WGS_SMALL");        // launches of < 40 000 rows (node-level MLPs); default: the same target
+    wgs_small = e ? atoi(e) : wgs;
+    if (wgs_small < 1) wgs_small = wgs;
   }
-  long target = wgs / ntiles;
+  long target = (M < 40000 ? wgs_small : wgs) / ntiles;
   if (target < 1) target = 1;
   long rows = (M + target - 1) / target;
   rows = ((rows + 31) / 32) * 32;

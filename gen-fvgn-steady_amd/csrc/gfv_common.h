@@ -72,3 +72,18 @@ static __device__ __forceinline__ float gfv_half_sum(float v) {
 }
 
 static inline int gfv_div_up(long a, long b) { return (int)((a + b - 1) / b); }
+
+// XCD-aware tile order.  The 256 CUs sit in 8 XCDs with one L2 each and the dispatcher deals consecutive workgroup ids
+// round-robin over the XCDs (id w -> XCD w % 8).  Tiles that are neighbours in row order gather the same rows (an edge tile
+// reads the rows of its end nodes, a node tile those of its neighbours; mesh numbering is spatially local), so giving each
+// XCD a CONTIGUOUS range of tiles lets those gathers hit in its own L2 instead of being fetched once per XCD.
+// Launch with gfv_xcd_grid(tiles) workgroups; a workgroup whose tile is >= tiles has nothing to do.
+static inline int gfv_xcd_grid(int tiles) { return ((tiles + 7) / 8) * 8; }
+static __device__ __forceinline__ int gfv_xcd_tile(int wg, int grid) {
+#ifdef GFV_NO_XCD_REMAP
+  return wg;
+#else
+  const int per = grid >> 3;
+  return (wg & 7) * per + (wg >> 3);
+#endif
+}

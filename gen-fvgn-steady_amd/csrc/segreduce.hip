@@ -21,7 +21,9 @@ __global__ __launch_bounds__(256) void seg_gather_sum_vec(const float* __restric
   constexpr int ROWS_PER_BLOCK = 256 / LPR;
   const int sub = threadIdx.x / LPR;
   const int l = threadIdx.x % LPR;
-  for (int r = blockIdx.x * ROWS_PER_BLOCK + sub; r < n_rows; r += gridDim.x * ROWS_PER_BLOCK) {
+  // XCD-aware order (gfv_common.h): neighbouring destination rows gather the same source rows; the launcher rounds the grid
+  // to a multiple of 8, the map is then a permutation of the block ids
+  for (int r = gfv_xcd_tile(blockIdx.x, gridDim.x) * ROWS_PER_BLOCK + sub; r < n_rows; r += gridDim.x * ROWS_PER_BLOCK) {
     const int beg = rowptr[r], end = rowptr[r + 1];
     float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
     // the column indices of up to 8 entries come back in ONE round trip (clamped reads past the row end are cheap 4-B
@@ -381,7 +383,7 @@ extern "C" int gfv_seg_gather_sum_nnz(const float* src, const int32_t* rowptr, c
     tok = gfv_prof_begin(GFV_K_SEG, (double)nnz_hint * F, by, st);
   }
 #define LAUNCH_VEC(LPR)                                                                                       \
-  hipLaunchKernelGGL((seg_gather_sum_vec<LPR>), dim3(grid_for(n_rows, 256 / LPR)), dim3(256), 0, st, src,     \
+  hipLaunchKernelGGL((seg_gather_sum_vec<LPR>), dim3(gfv_xcd_grid(grid_for(n_rows, 256 / LPR))), dim3(256), 0, st, src, \
                      rowptr, col, scale, src_scale, out, n_rows, accumulate)
   switch (F) {
     case 4: LAUNCH_VEC(1); break;

@@ -483,8 +483,13 @@ __global__ __launch_bounds__(64 * NW, NW == 16 ? 4 : 2) void tchain_kernel(const
   float* red = lds + 2 * WS_FLOATS;
   float* par = red + 256 * NW;  // bias of layer l at 128 l (N_l floats), LayerNorm gamma / beta: read from LDS in the epilogues
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, g = lane >> 4;
-  const int rowbase = blockIdx.x * (16 * NW * T) + wave * (16 * T) + li;
-  const int rowgroup = blockIdx.x * NW + wave;   // H (T = 1): index of this wave's 16 rows
+  // XCD-aware tile order (gfv_common.h) where the prologue gathers neighbour rows; measured (profiles/tools/ab.sh, one box):
+  // segmented-sum instantiation 0.773 -> 0.757 ms / step, seg_gather_sum 0.232 -> 0.227; the streaming instantiations do
+  // not gain (the LayerNorm-backward one loses 1 %) and keep the plain order
+  const int tile = CSR ? gfv_xcd_tile(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+  if (tile * (16 * NW * T) >= A.M) return;
+  const int rowbase = tile * (16 * NW * T) + wave * (16 * T) + li;
+  const int rowgroup = tile * NW + wave;   // H (T = 1): index of this wave's 16 rows
   // weight staging: thread -> row (tid>>3) + 32p, LDS slot tid&7, source chunk slot ^ ((row>>1)&7)
   const int wrow = tid >> 3;
   const int wc = 4 * ((tid & 7) ^ ((tid >> 4) & 7));
@@ -793,11 +798,11 @@ __global__ __launch_bounds__(64 * NW, NW == 16 ? 4 : 2) void tchain_kernel(const
     const int q = tid >> 8, t = tid & 255;
     const float* rq = red + q * 1024;
     const float s = rq[t] + rq[256 + t] + rq[512 + t] + rq[768 + t];
-    const size_t tile = (size_t)blockIdx.x * (NW / 4) * T + q * T;
-    if (tile < (size_t)((A.M + 63) / 64)) A.ln_partial[tile * 256 + t] = s;
+    const size_t tile64 = (size_t)tile * (NW / 4) * T + q * T;
+    if (tile64 < (size_t)((A.M + 63) / 64)) A.ln_partial[tile64 * 256 + t] = s;
 #pragma unroll
     for (int x = 1; x < T; ++x)
-      if (tile + x < (size_t)((A.M + 63) / 64)) A.ln_partial[(tile + x) * 256 + t] = 0.f;
+      if (tile64 + x < (size_t)((A.M + 63) / 64)) A.ln_partial[(tile64 + x) * 256 + t] = 0.f;
   }
 }
 
@@ -805,11 +810,12 @@ __global__ __launch_bounds__(64 * NW, NW == 16 ? 4 : 2) void tchain_kernel(const
 
 template <int NW>
 static void launch_h(const gfv_rowtile_args_t* args, int ragged, int lnm, hipStream_t stream) {
-  const dim3 wgs((args->M + 16 * NW - 1) / (16 * NW)), blk(64 * NW);
+  const int tiles = (args->M + 16 * NW - 1) / (16 * NW);
+  const dim3 wgs(tiles), blk(64 * NW);
   bool csr = false;
   for (int i = 0; i < args->nseg; ++i) csr = csr || args->seg[i].csr_rowptr != nullptr || args->seg[i].save != nullptr;
   if (csr) {   // (the caller checked: plain instantiation only)
-    hipLaunchKernelGGL((tchain_kernel<1, 0, false, true, NW, true>), wgs, blk, 0, stream, *args);
+    hipLaunchKernelGGL((tchain_kernel<1, 0, false, true, NW, true>), dim3(gfv_xcd_grid(tiles)), blk, 0, stream, *args);
     return;
   }
   if (ragged) hipLaunchKernelGGL((tchain_kernel<1, 0, true, true, NW>), wgs, blk, 0, stream, *args);
@@ -831,7 +837,7 @@ int gfv_internal_tchain_launch(const gfv_rowtile_args_t* args, int ragged, int f
   }
   bool csr = false;
   for (int i = 0; i < args->nseg; ++i) csr = csr || args->seg[i].csr_rowptr != nullptr || args->seg[i].save != nullptr;
-  if (csr) hipLaunchKernelGGL((tchain_kernel<1, 0, false, false, 4, true>), wgs, blk, 0, stream, *args);
+  if (csr) hipLaunchKernelGGL((tchain_kernel<1, 0, false, false, 4, true>), dim3(gfv_xcd_grid((args->M + 63) / 64)), blk, 0, stream, *args);
   else if (ragged) hipLaunchKernelGGL((tchain_kernel<1, 0, true, false>), wgs, blk, 0, stream, *args);
   else if (lnm == 0) hipLaunchKernelGGL((tchain_kernel<1, 0, false, false>), wgs, blk, 0, stream, *args);
   else if (lnm == 1) hipLaunchKernelGGL((tchain_kernel<1, 1, false, false>), wgs, blk, 0, stream, *args);

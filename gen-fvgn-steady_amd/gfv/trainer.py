@@ -65,6 +65,7 @@ class TrainStep:
             t.data = view
             self.P[n] = view
         assert all(v.data_ptr() % 16 == 0 for v in self.P.values())
+        self._probes = [(names[i], tensors[i]) for i in sorted({0, len(names) // 2, len(names) - 1})]
         self.n_params = total
         self.x = graphs[0].x
         self.x_backup = self.x.clone()
@@ -270,9 +271,22 @@ class TrainStep:
             self._allreduce()
             self._adam()
 
+    def _check_aliasing(self):
+        """The module's parameters must still be the views of the flat buffer this object made them (a `model.to()`, a
+        `load_state_dict(assign=True)` or a second TrainStep on the same model re-points them): captured steps hold raw
+        pointers, and a replay does not run the host code that would notice.  Three probes per step; on a mismatch the
+        views are re-established from the module's current values and every capture is dropped."""
+        for n, t in self._probes:
+            if t.data_ptr() != self.flat_p.data_ptr() + 4 * self.G.off[n]:
+                self.sync_from_model()
+                self._graphs.clear()
+                self._list_warm.clear()
+                return
+
     def step(self):
         """One training iteration.  Returns the (device) scalar loss tensor of this rank's batch.
         `use_graph`: False = eager launches, True = hipGraph replay, "list" = command-list replay."""
+        self._check_aliasing()
         acc = self.model.node_norm.should_accumulate()
         dist_on = self.dist_on
         if not self.use_graph or (acc and dist_on):
