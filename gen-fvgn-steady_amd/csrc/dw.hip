@@ -57,7 +57,9 @@ __device__ __forceinline__ float4 ld4(const float* base, size_t row, int ld, int
 }
 
 template <bool FULL>
-__device__ __forceinline__ void dw_body(const DwLaunch& A, const gfv_dw_tile_t& T, float* lds) {
+__device__ __forceinline__ void dw_body(const DwLaunch& A, const gfv_dw_tile_t& Tin, float* lds) {
+  gfv_dw_tile_t T = Tin;
+  T.a_op &= 7;   // (GFV_DW_COLSCALE concerns the split-fp16 form only)
   float* Gs0 = lds;
   float* As0 = lds + SUB * LDT;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, nl = lane & 15, q = lane >> 4;
@@ -214,10 +216,12 @@ __device__ __forceinline__ void dw_body(const DwLaunch& A, const gfv_dw_tile_t& 
 // index is the row m, so a scale must be constant over the rows of a sub-tile: the gradient rows are scaled by ONE exact
 // power of two per slab: the minimum of the per-16-row scales the chain launch that produced G left behind (tile.gscale;
 // no extra pass), or, for gradient rows that come from elsewhere, from max|G| over a first pass over the slab's rows.
-// On the activation side the free index is the COLUMN, so raw inputs (a_op == 0: encoder features with geometric columns
-// at mesh-spacing scale next to O(1) ones, latent rows) get one exact power of two per column and slab from a pass over
-// the slab's A rows (they are re-read from L2 right after); GELU / LayerNorm outputs (a_op 1 / 2, O(1) by construction)
-// are split unscaled, and a value beyond the fp16 range raises GFV_FLAG_DW_RANGE instead of being clamped.
+// On the activation side the free index is the COLUMN: with GFV_DW_COLSCALE a tile of raw inputs gets one exact power of two
+// per column and slab from a pass over the slab's A rows (re-read from L2 right after) - the encoders' first layers, whose
+// inputs hold geometric columns at mesh-spacing scale (1e-2 ... 1e-4) next to O(1) features.  Without it (latent rows:
+// LayerNorm outputs and sums of them; GELU / LayerNorm outputs of a_op 1 / 2: O(1) by construction) the activations are split
+// unscaled, and a value beyond the fp16 range raises GFV_FLAG_DW_RANGE instead of being clamped.  (The pass costs one more
+// read of A: 2.5 % of the step when applied to every raw-input tile, profiles/tools/ab.sh - hence per tile.)
 // LDS image per operand and sub-tile: [column tile 8][part 2] blocks of 64 lanes x 16 B in MFMA-fragment order (lane
 // (i, g) holds rows m = 8g..8g+7 of column 16 ct + i); column i of tile ct sits in lane slot i ^ (ct & 3), which spreads
 // the staging writes (a thread owns 4 consecutive rows of 4 columns: one 8-B piece per column and part) over the banks.
@@ -231,7 +235,10 @@ constexpr int HSTAGE = 2 * HBUF;           // two staging buffers
 #endif
 
 template <bool FULL>
-__device__ __forceinline__ void dw_body_h(const DwLaunch& A, const gfv_dw_tile_t& T, unsigned char* lds) {
+__device__ __forceinline__ void dw_body_h(const DwLaunch& A, const gfv_dw_tile_t& Tin, unsigned char* lds) {
+  gfv_dw_tile_t T = Tin;
+  const bool colscale = (T.a_op & GFV_DW_COLSCALE) != 0;
+  T.a_op &= 7;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, nl = lane & 15, q = lane >> 4;
   const int wn = wave >> 1, wk = wave & 1;
   const int slab = blockIdx.x;
@@ -283,7 +290,7 @@ __device__ __forceinline__ void dw_body_h(const DwLaunch& A, const gfv_dw_tile_t
 
   // ---- column scales of raw-input activations ----
   float4 sa = make_float4(1.f, 1.f, 1.f, 1.f);   // this thread's 4 staging columns
-  if (T.a_op == 0 && m_beg < m_end) {
+  if (colscale && m_beg < m_end) {
     float4 cm = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int m = m_beg + r4; m < m_end; m += 64) {
       float4 v[8], b[8];
@@ -313,7 +320,7 @@ __device__ __forceinline__ void dw_body_h(const DwLaunch& A, const gfv_dw_tile_t
   // the inverse column scales wait in LDS (behind the staging buffers) for the output stage
   float* inv_sa = reinterpret_cast<float*>(lds + HSTAGE);
   if (r4 == 0) *reinterpret_cast<float4*>(&inv_sa[col]) = make_float4(1.0f / sa.x, 1.0f / sa.y, 1.0f / sa.z, 1.0f / sa.w);
-  float amax = 0.f;   // a_op 1 / 2: range check of the unscaled split
+  float amax = 0.f;   // range check of what is split (unscaled activations; scaled ones are < 2^14 by construction)
 
   floatx4 acc[4][4];
 #pragma unroll
@@ -379,7 +386,7 @@ __device__ __forceinline__ void dw_body_h(const DwLaunch& A, const gfv_dw_tile_t
       }
       if (!live) { g[p] = zero; a[p] = zero; }
       dbacc.x += g[p].x; dbacc.y += g[p].y; dbacc.z += g[p].z; dbacc.w += g[p].w;
-      a[p].x *= sa.x; a[p].y *= sa.y; a[p].z *= sa.z; a[p].w *= sa.w;   // (1 for a_op 1 / 2)
+      a[p].x *= sa.x; a[p].y *= sa.y; a[p].z *= sa.z; a[p].w *= sa.w;   // (1 without GFV_DW_COLSCALE)
       amax = fmaxf(fmaxf(amax, fmaxf(fabsf(a[p].x), fabsf(a[p].y))), fmaxf(fabsf(a[p].z), fabsf(a[p].w)));
     }
     put4(Gs, col + 0, g[0].x * sg, g[1].x * sg, g[2].x * sg, g[3].x * sg);
@@ -519,7 +526,9 @@ extern "C" int gfv_dw_multi(const gfv_dw_tile_t* tiles, int32_t ntiles, int32_t 
   for (int i = 0; i < ntiles; ++i) {
     const gfv_dw_tile_t& t = tiles[i];
     if (t.n_out < 1 || t.n_out > 128 || t.width < 1 || t.width > 128) return GFV_ERR_ARG;
-    if (t.a_op == 2 && t.width != 128) return GFV_ERR_ARG;
+    if ((t.a_op & 7) > 2 || (t.a_op & ~(7 | GFV_DW_COLSCALE))) return GFV_ERR_ARG;
+    if ((t.a_op & 7) == 2 && t.width != 128) return GFV_ERR_ARG;
+    if ((t.a_op & GFV_DW_COLSCALE) && (t.a_op & 7) != 0) return GFV_ERR_ARG;   // column scales: raw inputs only
     a.tile[i] = t;
     fl += 2.0 * M * (double)t.n_out * t.width;
     by += 4.0 * M * ((double)t.n_out + t.width);

@@ -353,7 +353,10 @@ class Engine:
         s0, s1, s2 = (gs[0], gs[1], gs[2]) if have else (None, None, None)
         if not ln and (gadd is not None or g_add is not None):
             s0 = None   # slot 0 describes the prologue RESULT (= g3 with LayerNorm); without it the weight gradient reads G
-        tiles = [self._tile(gz1, 128, sg, in_add=sv["in_add"] if i == 0 else None, gscale=s2) for i, sg in enumerate(sv["segs"])]
+        # (narrow raw inputs - the encoders' x [N,12] / edge_attr [E,15] with geometric columns at mesh-spacing scale - get
+        # per-column scales in the split-fp16 weight gradient; 128-wide latent segments are O(1) and go unscaled)
+        tiles = [self._tile(gz1, 128, sg, in_add=sv["in_add"] if i == 0 else None, gscale=s2,
+                            a_op=L.DW_COLSCALE if sg.width <= 16 else 0) for i, sg in enumerate(sv["segs"])]
         tiles.append(self._tile(gz2, 128, Seg(sv["z1"]), a_op=1, gscale=s1))
         tiles.append(self._tile(g3, nout, Seg(sv["z2"]), a_op=1, ldg=(G.stride(0) if g_ld is None else g_ld) if not ln else None,
                                 gscale=s0))

@@ -19,6 +19,7 @@ c_int_p = C.c_void_p
 OP_NONE, OP_BIAS_GELU, OP_MUL_DGELU = 0, 1, 2
 IN_NONE, IN_GELU, IN_LN, IN_LNBWD = 0, 1, 2, 3
 FIN_PLAIN, FIN_LN, FIN_LNBWD = 0, 1, 2
+DW_COLSCALE = 8   # gfv_dw_tile_t.a_op flag: per-column power-of-two scales of raw-input activations
 
 
 class Seg(C.Structure):

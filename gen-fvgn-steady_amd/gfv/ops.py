@@ -298,8 +298,12 @@ def rowtile_chain(M, segs, layers, outs, *, in_add=None, in_op=L.IN_NONE, in_gam
 
 
 def linear_dw(G, n_out, segs, M, *, ldg=None, in_add=None, a_op=0, a_gamma=None, a_beta=None, dW=None, db=None,
-              want_db=True, accumulate=False, workspace=None, g_offset=0, gscale=None):
-    """dW[n,k] = sum_m G[m,n] A[m,k]; db[n] = sum_m G[m,n].  Returns (dW [n_out,K], db [n_out] or None)."""
+              want_db=True, accumulate=False, workspace=None, g_offset=0, gscale=None, col_scale=False):
+    """dW[n,k] = sum_m G[m,n] A[m,k]; db[n] = sum_m G[m,n].  Returns (dW [n_out,K], db [n_out] or None).
+    col_scale (a_op 0 only): per-column power-of-two scales of the activations in the split-fp16 form (include/gfv.h)."""
+    if col_scale:
+        assert a_op == 0
+        a_op = L.DW_COLSCALE
     lib = L.load()
     K = sum(s.width for s in segs)
     dev = G.device

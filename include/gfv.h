@@ -200,7 +200,7 @@ typedef struct {
   const float* a_gamma; /* a_op == 2 */
   const float* a_beta;
   int32_t ldg, n_out, width, ld;
-  int32_t a_op;         /* 0 none, 1 GELU, 2 LayerNorm(a_gamma, a_beta) (width 128) */
+  int32_t a_op;         /* 0 none, 1 GELU, 2 LayerNorm(a_gamma, a_beta) (width 128); | GFV_DW_COLSCALE (with 0 only) */
   int32_t ld_out;       /* row stride (K of the weight) inside the block */
   int64_t out_off;      /* float offset of dW_t[0, 0] inside the block */
   int64_t db_off;       /* float offset of the bias gradient, or -1 */
@@ -208,10 +208,11 @@ typedef struct {
                          * that produced them wrote them (gfv_rowtile_args_t.gscale); NULL: one pass over G finds the maximum */
 } gfv_dw_tile_t;
 /* Range of the split-fp16 weight-gradient form.  The gradient rows G carry ONE power of two per slab of rows.  The
- * activations A carry one power of two per COLUMN and slab when they are raw inputs (a_op == 0; a pass over the slab's A
- * rows finds the column maxima: encoder inputs hold geometric columns at mesh-spacing scale next to O(1) features);
- * GELU / LayerNorm outputs (a_op 1 / 2) are split unscaled, and a value beyond the fp16 range raises GFV_FLAG_DW_RANGE
- * in the device status word instead of being clamped. */
+ * activations A carry one power of two per COLUMN and slab when the tile asks for it (a_op = 0 | GFV_DW_COLSCALE: a pass
+ * over the slab's A rows finds the column maxima - encoder inputs hold geometric columns at mesh-spacing scale next to O(1)
+ * features); otherwise they are split unscaled (latent rows, GELU / LayerNorm outputs: O(1)), and a value beyond the fp16
+ * range raises GFV_FLAG_DW_RANGE in the device status word instead of being clamped. */
+enum { GFV_DW_COLSCALE = 8 };
 enum { GFV_FLAG_DW_RANGE = 1 };
 /* device status word: OR of GFV_FLAG_* raised by kernels since the last call; reads (synchronising) and clears it */
 int gfv_status_flags(int32_t* flags_out);

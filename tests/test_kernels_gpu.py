@@ -457,8 +457,9 @@ def test_rowtile_and_dw_extreme_dynamic_range(dev, chain_mode):
 
 
 def test_dw_activation_dynamic_range_per_column(dev, chain_mode):
-    """the ACTIVATION side of the split-fp16 weight gradient.  Raw inputs (a_op 0) carry one
-    power of two per column and slab: (a) columns whose scales span 1e-6 ... 1e+6, (b) an encoder-shaped input (K = 15:
+    """the ACTIVATION side of the split-fp16 weight gradient.  With GFV_DW_COLSCALE (what the
+    engine sets for the encoders' narrow raw inputs) the activations carry one power of two per column and slab: (a)
+    columns whose scales span 1e-6 ... 1e+6, (b) an encoder-shaped input (K = 15:
     O(1) feature differences next to geometric columns at 1e-4 mesh-spacing scale, importer.py:54-78), (c) single columns
     that themselves span twelve decades over the rows.  Every output element is judged against its own sum |g a|."""
     if chain_mode != "f32":
@@ -471,7 +472,7 @@ def test_dw_activation_dynamic_range_per_column(dev, chain_mode):
     def check(G, A, tag, ld=None):
         K = A.shape[1]
         At = A if ld is None else torch.cat((A, torch.zeros(A.shape[0], ld - K)), 1)
-        dW, _ = ops.linear_dw(d(G), G.shape[1], [ops.Seg(d(At), width=K, ld=At.shape[1])], G.shape[0])
+        dW, _ = ops.linear_dw(d(G), G.shape[1], [ops.Seg(d(At), width=K, ld=At.shape[1])], G.shape[0], col_scale=True)
         ref = G.double().T @ A.double()
         mag = G.double().abs().T @ A.double().abs()
         assert torch.isfinite(dW).all(), tag
