@@ -19,7 +19,7 @@ __global__ __launch_bounds__(256) void slice_softmax_fwd_kernel(const float* __r
                                                                 float* __restrict__ w, int N) {
   __shared__ float sW[G * D];
   __shared__ float sB[G];
-  __shared__ float stage[256 * (G + 1)];
+  __shared__ __attribute__((aligned(16))) float stage[256 * (G + 4)];
   const int tid = threadIdx.x;
   for (int i = tid; i < G * D; i += 256) sW[i] = Ws[i];
   if (tid < G) sB[tid] = bs[tid];
@@ -56,13 +56,16 @@ __global__ __launch_bounds__(256) void slice_softmax_fwd_kernel(const float* __r
     }
     const float inv = 1.0f / sum;
 #pragma unroll
-    for (int g = 0; g < G; ++g) stage[tid * (G + 1) + g] = l[g] * inv;
+    for (int g = 0; g < G; g += 4)
+      *reinterpret_cast<float4*>(&stage[tid * (G + 4) + g]) = make_float4(l[g] * inv, l[g + 1] * inv, l[g + 2] * inv, l[g + 3] * inv);
   }
   __syncthreads();
-  // coalesced store of the block's 256 x 32 floats
-  for (int i = tid; i < 256 * G; i += 256) {
-    const long r = row0 + i / G;
-    if (r < nrows) w[r * G + (i % G)] = stage[(i / G) * (G + 1) + (i % G)];
+  // coalesced store of the block's 256 x 32 floats, float4 pieces of consecutive lanes
+  for (int i = tid; i < 256 * (G / 4); i += 256) {
+    const long r = row0 + i / (G / 4);
+    if (r < nrows)
+      reinterpret_cast<float4*>(w + r * G)[i % (G / 4)] =
+          *reinterpret_cast<const float4*>(&stage[(i / (G / 4)) * (G + 4) + 4 * (i % (G / 4))]);
   }
 }
 
@@ -484,7 +487,8 @@ __global__ __launch_bounds__(256) void slice_gw_kernel(const float* __restrict__
                                                        const float* __restrict__ add, const int* __restrict__ batch,
                                                        float* __restrict__ gw, int N, int accumulate) {
   __shared__ __attribute__((aligned(16))) float sT[H * TS];
-  __shared__ float stage[256 * (G + 1)];
+  constexpr int SS = G + 4;   // staging row stride (floats): 16-B aligned rows
+  __shared__ __attribute__((aligned(16))) float stage[256 * SS];
   const bool uniform = stage_T(T, batch, N, sT);
   const int tid = threadIdx.x;
   const long row0 = (long)blockIdx.x * 256;
@@ -500,29 +504,35 @@ __global__ __launch_bounds__(256) void slice_gw_kernel(const float* __restrict__
       const float4 v = ap[i];
       x[4 * i] = v.x; x[4 * i + 1] = v.y; x[4 * i + 2] = v.z; x[4 * i + 3] = v.w;
     }
-    float av[G];   // the per-(graph, head) addend: one round trip up front instead of a load inside every dot product
+    float4 av[G / 4];   // the per-(graph, head) addend: one round trip up front instead of a load inside every dot product
 #pragma unroll
-    for (int g = 0; g < G; ++g) av[g] = add ? add[bh * G + g] : 0.f;
+    for (int i = 0; i < G / 4; ++i)
+      av[i] = add ? reinterpret_cast<const float4*>(add + bh * G)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
     const float* Tp = uniform ? &sT[h * TS] : T + bh * G * D;
 #pragma unroll
-    for (int g = 0; g < G; ++g) {
-      const float4* tp = reinterpret_cast<const float4*>(Tp + g * D);
-      float s = av[g];
+    for (int i = 0; i < G / 4; ++i) {
+      float r[4] = {av[i].x, av[i].y, av[i].z, av[i].w};
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float4 t = tp[j];
-        s += x[4 * j] * t.x + x[4 * j + 1] * t.y + x[4 * j + 2] * t.z + x[4 * j + 3] * t.w;
+      for (int k = 0; k < 4; ++k) {
+        const float4* tp = reinterpret_cast<const float4*>(Tp + (4 * i + k) * D);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float4 t = tp[j];
+          r[k] += x[4 * j] * t.x + x[4 * j + 1] * t.y + x[4 * j + 2] * t.z + x[4 * j + 3] * t.w;
+        }
       }
-      stage[tid * (G + 1) + g] = s;
+      *reinterpret_cast<float4*>(&stage[tid * SS + 4 * i]) = make_float4(r[0], r[1], r[2], r[3]);
     }
   }
   __syncthreads();
-  for (int i = tid; i < 256 * G; i += 256) {
-    const long r = row0 + i / G;
+  // the block's 256 rows x 32 floats leave as float4 pieces of consecutive lanes (8 per row)
+  for (int i = tid; i < 256 * (G / 4); i += 256) {
+    const long r = row0 + i / (G / 4);
     if (r < nrows) {
-      float v = stage[(i / G) * (G + 1) + (i % G)];
-      if (accumulate) v += gw[r * G + (i % G)];
-      gw[r * G + (i % G)] = v;
+      float4 v = *reinterpret_cast<const float4*>(&stage[(i / (G / 4)) * SS + 4 * (i % (G / 4))]);
+      float4* gp = reinterpret_cast<float4*>(gw + r * G) + (i % (G / 4));
+      if (accumulate) { const float4 p = *gp; v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w; }
+      *gp = v;
     }
   }
 }
