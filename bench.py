@@ -28,6 +28,10 @@ import os
 import sys
 import time
 
+# more hardware queues than the runtime's default 4, before HIP initialises: streams are multiplexed onto them round-robin,
+# and RCCL's own streams otherwise push the step's two streams onto one queue (gfv/engine.py pick_concurrent_stream also
+# checks its choice at run time; this keeps the communication stream off the compute queues as well)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "gen-fvgn-steady_amd"))

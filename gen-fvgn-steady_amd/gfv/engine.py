@@ -25,6 +25,45 @@ def _empty(dev, *shape):
     return torch.empty(shape, dtype=torch.float32, device=dev)
 
 
+def pick_concurrent_stream(priority=0, candidates=8):
+    """A stream that really runs beside the current one.  The HIP runtime multiplexes streams onto a few hardware queues
+    (GPU_MAX_HW_QUEUES, default 4) round-robin in creation order, and two streams on one hardware queue execute in order:
+    with an RCCL process group created before the first step (what every multi-GPU run does) the weight-gradient stream
+    landed on the main stream's queue and the step ran at its no-overlap time, 5.65 instead of 4.90 ms
+    (profiles/tools/launch_cost.py).  So the choice is checked, not assumed: two spin kernels, one per stream - a candidate
+    on its own queue finishes them in the time of one."""
+    if torch.cuda.is_current_stream_capturing():
+        return torch.cuda.Stream(priority=priority)
+    main = torch.cuda.current_stream()
+    cycles = 400_000
+
+    def timed(side):
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(main)
+        if side is not None:
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                torch.cuda._sleep(cycles)
+        torch.cuda._sleep(cycles)
+        if side is not None:
+            main.wait_stream(side)
+        e1.record(main)
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1)
+
+    timed(None)
+    alone = min(timed(None) for _ in range(2))
+    first = None
+    for _ in range(candidates):
+        cand = torch.cuda.Stream(priority=priority)
+        first = first or cand
+        timed(cand)
+        if min(timed(cand) for _ in range(2)) < 1.5 * alone:
+            return cand
+    return first   # none overlapped (one hardware queue for everything): the step still runs, at its no-overlap time
+
+
 class GradStore:
     """Flat fp32 gradient storage with named views; every tensor starts on a 16-byte boundary, tensors keep the
     order they were given in (state_dict order), so the gradients of one MLP / Linear form one contiguous block."""
@@ -112,9 +151,7 @@ class Engine:
             if not e.overlap:
                 return self
             if e._side is None:
-                # the dX chains on the main stream are the critical path; the weight-gradient work beside them is not:
-                # a low-priority queue lets the dispatcher prefer main-stream workgroups when both are pending
-                e._side = torch.cuda.Stream(priority=int(os.environ.get("GFV_SIDE_PRIO", "0")))
+                e._side = pick_concurrent_stream(int(os.environ.get("GFV_SIDE_PRIO", "0")))
             cmdlist.call(e._side.wait_stream, torch.cuda.current_stream())
             # tensors the side stream reads must outlive this call: the caching allocator would hand their blocks to
             # the next allocation on the main stream while the side stream is still reading them

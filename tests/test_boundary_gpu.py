@@ -250,3 +250,39 @@ def test_plain_encoder_processer_decoder_matches_oracle(graphs):
             continue
         err = float((p.grad.cpu().double() - r.double()).abs().max())
         assert err < 1e-4 * float(r.abs().max()) + 1e-6 * gscale, (k, err)
+
+
+def test_plan_cache_follows_in_place_edits_of_boundary_data(graphs):
+    """the cached plan holds copies of graph_node.y / node types / PDE coefficients; the reference re-reads them on
+    every forward, so an in-place edit of a reused batch (a re-selected boundary value, another viscosity) must reach the next
+    forward.  Same model, same graph objects: forward, edit in place, forward -> equals a forward on freshly built graphs."""
+    from FVMmodel.importer import NNmodel
+    from gfv.params import default_params
+    P = O.init_parameters(cases.WEIGHT_SEED)
+    model = NNmodel(default_params(dataset_size=1))
+    sd = model.state_dict()
+    for k, v in P.items():
+        sd[k].copy_(v)
+    model.load_state_dict(sd)
+    model = model.cuda()
+
+    def run(gs, x0):
+        gs[0].x = x0.clone()
+        gs[0].norm_uvp, gs[0].norm_global = True, True
+        with torch.no_grad():
+            return [o.clone() for o in model(*gs)]
+
+    hg = tuple(g.clone().to("cuda") for g in graphs)
+    x0 = hg[0].x.clone()
+    first = run(hg, x0)
+    inflow = hg[0].node_type == 1
+    hg[0].y[inflow] *= 1.5                     # in place: another inlet velocity
+    hg[4].theta_PDE[:, 4] *= 2.0               # in place: another diffusion coefficient
+    edited = run(hg, x0)
+    fresh_graphs = tuple(g.clone().to("cuda") for g in graphs)
+    fresh_graphs[0].y[fresh_graphs[0].node_type == 1] *= 1.5
+    fresh_graphs[4].theta_PDE[:, 4] *= 2.0
+    fresh = run(fresh_graphs, x0)
+    for a, b in zip(edited, fresh):
+        assert torch.equal(a, b)
+    assert not torch.equal(edited[1], first[1]), "the edit must change the momentum residual"
