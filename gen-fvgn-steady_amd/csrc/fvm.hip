@@ -651,6 +651,59 @@ __global__ __launch_bounds__(256) void node_bwd_kernel(const NodeBwdArgs A) {
 }
 
 
+// ---- WLSQ moment matrices on the device (row f2; Load_mesh.py:247-272 calc_WLSQ_A_B_normal_matrix -> FVgrad.py:183-232
+// compute_normal_matrix -> FVorder.py:7-86 moments_order), float64 like the host preprocessing -------------------------
+// One thread per receiving node walks its directed stencil entries in CSR order (fixed order: deterministic):
+//   d = pos[out_k] - pos[i];  t = Taylor monomials of d up to the order (MM = 2 / 5 / 9 / 14 terms);  w = 1 / |d|
+//   A[i] += w t t^T   [MM, MM];   B[entry_k] = w t   (written to the entry's ORIGINAL position: edge order, not CSR order)
+template <int MM>
+__device__ __forceinline__ void taylor_terms(double x, double y, double (&t)[MM]) {
+  t[0] = x; t[1] = y;
+  if (MM >= 5) { t[2] = 0.5 * x * x; t[3] = 0.5 * y * y; t[4] = x * y; }
+  if (MM >= 9) { t[5] = x * x * x / 6.0; t[6] = y * y * y / 6.0; t[7] = 0.5 * x * x * y; t[8] = 0.5 * y * y * x; }
+  if (MM >= 14) {
+    t[9] = x * x * x * x / 24.0; t[10] = x * x * x * y / 6.0; t[11] = 0.25 * x * x * y * y; t[12] = x * y * y * y / 6.0;
+    t[13] = y * y * y * y / 24.0;
+  }
+}
+
+template <int MM>
+__global__ __launch_bounds__(128) void wlsq_moments_kernel(const double* __restrict__ pos, const int* __restrict__ rowptr,
+                                                           const int* __restrict__ outn, const int* __restrict__ entry,
+                                                           double* __restrict__ A, double* __restrict__ B, int N) {
+  const int i = blockIdx.x * 128 + threadIdx.x;
+  if (i >= N) return;
+  const double px = pos[2 * i], py = pos[2 * i + 1];
+  double a[MM * (MM + 1) / 2];   // upper triangle of the symmetric sum
+#pragma unroll
+  for (int q = 0; q < MM * (MM + 1) / 2; ++q) a[q] = 0.0;
+  for (int k = rowptr[i]; k < rowptr[i + 1]; ++k) {
+    const int o = outn[k];
+    const double dx = pos[2 * o] - px, dy = pos[2 * o + 1] - py;
+    const double w = 1.0 / sqrt(dx * dx + dy * dy);
+    double t[MM];
+    taylor_terms<MM>(dx, dy, t);
+    double* b = B + (size_t)entry[k] * MM;
+    int q = 0;
+#pragma unroll
+    for (int r = 0; r < MM; ++r) {
+      b[r] = w * t[r];
+#pragma unroll
+      for (int c = r; c < MM; ++c) a[q++] += (w * t[r]) * t[c];
+    }
+  }
+  double* Ai = A + (size_t)i * MM * MM;
+  int q = 0;
+#pragma unroll
+  for (int r = 0; r < MM; ++r)
+#pragma unroll
+    for (int c = r; c < MM; ++c) {
+      Ai[r * MM + c] = a[q];
+      Ai[c * MM + r] = a[q];
+      ++q;
+    }
+}
+
 // ---- stand-alone 2nd-order interpolation operators (FVInterpolation.py:36-109, 111-185, 218-265) --------------------------
 // One generic gather: out[r, c] = sum_{k in row r} w_k (phi[col_k, c] + (tgt_r - src_{col_k}) . grad[col_k, c, :]) / W_r
 //   mode 0: w_k = 1, W_r = number of entries (clamped at 1)            node -> cell mean, node -> face average
@@ -877,5 +930,20 @@ extern "C" int gfv_interp2_bwd(const float* gout, const float* wsum, const float
   if (S < 0 || C < 1 || (mode != 0 && mode != 1)) return GFV_ERR_ARG;
   GfvProfScope ps_(GFV_K_FVM, 0, 0, stream);
   LAUNCH1D(interp2_bwd_kernel, (long)S * C, stream, gout, wsum, srcpos, tgtpos, trow, tidx, mode, gphi, ggrad, S, C);
+  return GFV_OK;
+}
+
+extern "C" int gfv_wlsq_moments(const double* pos, const int32_t* rowptr, const int32_t* outn, const int32_t* entry, double* A,
+                                double* B, int32_t N, int32_t terms, void* stream) {
+  if (N < 0) return GFV_ERR_ARG;
+  if (N == 0) return GFV_OK;
+  switch (terms) {
+    case 2: hipLaunchKernelGGL(wlsq_moments_kernel<2>, dim3(gfv_div_up(N, 128)), dim3(128), 0, (hipStream_t)stream, pos, rowptr, outn, entry, A, B, N); break;
+    case 5: hipLaunchKernelGGL(wlsq_moments_kernel<5>, dim3(gfv_div_up(N, 128)), dim3(128), 0, (hipStream_t)stream, pos, rowptr, outn, entry, A, B, N); break;
+    case 9: hipLaunchKernelGGL(wlsq_moments_kernel<9>, dim3(gfv_div_up(N, 128)), dim3(128), 0, (hipStream_t)stream, pos, rowptr, outn, entry, A, B, N); break;
+    case 14: hipLaunchKernelGGL(wlsq_moments_kernel<14>, dim3(gfv_div_up(N, 128)), dim3(128), 0, (hipStream_t)stream, pos, rowptr, outn, entry, A, B, N); break;
+    default: return GFV_ERR_ARG;
+  }
+  GFV_CHECK_LAUNCH();
   return GFV_OK;
 }

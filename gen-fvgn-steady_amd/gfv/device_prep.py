@@ -1,6 +1,7 @@
 """Per-mesh preprocessing on the device: the k-hop WLSQ stencil (``build_k_hop_edge_index``,
 parse_to_h5.py:228-254 / Load_mesh.py:421-521) and the WLSQ moment matrices A, B (``calc_WLSQ_A_B_normal_matrix``,
-Load_mesh.py:247-272; FVgrad.py:183-232) with torch tensor ops on the GPU - the two steps that dominate the host-side
+Load_mesh.py:247-272; FVgrad.py:183-232) on the GPU - the stencil with torch sorts / uniques, the moments with a HIP
+kernel (`gfv_wlsq_moments`) - the two steps that dominate the host-side
 mesh set-up (1.3 s + 3.4 s of ~6 s for the 50 k-cell mesh with the numpy code of gfv.meshgen, which stays the reference
 implementation and the checker: tests/test_pool_gpu.py::test_device_preprocessing_matches_host).  float64 / int64
 throughout, like the host code; deterministic (sorts, scans and segment differences, no atomics)."""
@@ -55,22 +56,28 @@ def taylor_displacement(d, order="2nd"):
 
 
 def wlsq_moments(pos, face_node_x, support_edge, order="2nd"):
-    """A [N,M,M], one-way B [Ex,M,1], extra B [2,M,1] in float64 (= gfv.meshgen.wlsq_moments)."""
+    """A [N,M,M], one-way B [Ex,M,1], extra B [2,M,1] in float64 (= gfv.meshgen.wlsq_moments): the directed stencil
+    [fx, fx.flip(0), support_edge] in CSR order of the receiving node (one stable sort), then ONE HIP kernel
+    (`gfv_wlsq_moments`, csrc/fvm.hip: a thread per node accumulates w t t^T over its entries in that order and writes
+    w t of every entry back to its place in edge order) - no atomics, deterministic."""
+    from . import lib as L
+    M = {"1st": 2, "2nd": 5, "3rd": 9, "4th": 14}.get(order)
+    if M is None:
+        raise NotImplementedError(f"{order} Order not implemented")
+    if not pos.is_cuda:
+        raise RuntimeError("gfv.device_prep runs on the GPU (gfv.meshgen has the host form)")
     comp = torch.cat((face_node_x, face_node_x.flip(0), support_edge), dim=1)
     out_idx, in_idx = comp[0], comp[1]
-    d = pos[out_idx] - pos[in_idx]
-    disp = taylor_displacement(d, order)                                          # [S,M]
-    M = disp.shape[1]
-    w = 1.0 / torch.linalg.norm(d, dim=1, keepdim=True)
-    left = ((disp * w).unsqueeze(2) * disp.unsqueeze(1)).reshape(-1, M * M)
-    n = int(pos.shape[0])
+    n, S = int(pos.shape[0]), int(in_idx.shape[0])
     perm = torch.argsort(in_idx, stable=True)
-    counts = torch.bincount(in_idx, minlength=n)
-    rp = torch.zeros(n + 1, dtype=torch.int64, device=pos.device)
-    rp[1:] = torch.cumsum(counts, 0)
-    cs = torch.zeros((M * M, left.shape[0] + 1), dtype=torch.float64, device=pos.device)
-    cs[:, 1:] = torch.cumsum(left[perm].t().contiguous(), 1)
-    A = (cs[:, rp[1:]] - cs[:, rp[:-1]]).t().reshape(n, M, M)
-    B = (w * disp).unsqueeze(2)
+    rowptr = torch.zeros(n + 1, dtype=torch.int64, device=pos.device)
+    rowptr[1:] = torch.cumsum(torch.bincount(in_idx, minlength=n), 0)
+    rp32, out32, ent32 = rowptr.to(torch.int32), out_idx[perm].to(torch.int32).contiguous(), perm.to(torch.int32).contiguous()
+    p64 = pos.to(torch.float64).contiguous()
+    A = torch.empty((n, M, M), dtype=torch.float64, device=pos.device)
+    B = torch.empty((S, M), dtype=torch.float64, device=pos.device)
+    L.check(L.load().gfv_wlsq_moments(p64.data_ptr(), rp32.data_ptr(), out32.data_ptr(), ent32.data_ptr(), A.data_ptr(),
+                                      B.data_ptr(), n, M, L.stream_ptr()), "gfv_wlsq_moments")
+    B = B.unsqueeze(2)
     ex = face_node_x.shape[1]
     return A, B[:ex], B[2 * ex:]

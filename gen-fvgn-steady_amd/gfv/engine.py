@@ -129,7 +129,7 @@ class Engine:
         self._pkey_cache = None
         self._zero_e = None
         self._etmp = None
-        self._side = None
+        self._side, self._sides = None, []
         self._keep = []
         # data parallel: (world, process group) set by TrainStep; the Normalizer statistics are exchanged inside the
         # forward, between accumulation and use
@@ -152,6 +152,12 @@ class Engine:
                 return self
             if e._side is None:
                 e._side = pick_concurrent_stream(int(os.environ.get("GFV_SIDE_PRIO", "0")))
+                e._sides = [e._side]
+                for _ in range(int(os.environ.get("GFV_SIDE_STREAMS", "1")) - 1):   # experiment: several side queues
+                    e._sides.append(pick_concurrent_stream(int(os.environ.get("GFV_SIDE_PRIO", "0"))))
+            if len(e._sides) > 1:
+                e._side_rr = (getattr(e, "_side_rr", -1) + 1) % len(e._sides)
+                e._side = e._sides[e._side_rr]
             cmdlist.call(e._side.wait_stream, torch.cuda.current_stream())
             # tensors the side stream reads must outlive this call: the caching allocator would hand their blocks to
             # the next allocation on the main stream while the side stream is still reading them
@@ -205,7 +211,8 @@ class Engine:
         """Main stream waits for the side stream (call before anything reads the gradients)."""
         self.flush()
         if self.overlap and self._side is not None:
-            cmdlist.call(torch.cuda.current_stream().wait_stream, self._side)
+            for sd in self._sides:
+                cmdlist.call(torch.cuda.current_stream().wait_stream, sd)
         self._keep.clear()
 
     # ------------------------------------------------------------------------------------------------------------

@@ -246,8 +246,8 @@ class TrainStep:
         if self._comm is None:
             self._comm = torch.cuda.Stream()
         self._comm.wait_stream(torch.cuda.current_stream())
-        if self.engine._side is not None:
-            self._comm.wait_stream(self.engine._side)      # the weight-gradient kernels run there
+        for sd in self.engine._sides:
+            self._comm.wait_stream(sd)                      # the weight-gradient kernels run there
         with torch.cuda.stream(self._comm):
             self._work = dist.all_reduce(self.flat_g[split:], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
 

@@ -392,6 +392,14 @@ int gfv_train_loss(const float* losses, int32_t B, float w_cont, float w_mom, fl
 /* same, weights read from the device: hyper[5..7] = {w_cont, w_mom, w_press} of the buffer gfv_adam_step_dev takes */
 int gfv_train_loss_dev(const float* losses, int32_t B, const float* hyper, float* loss, float* gloss, void* stream);
 
+/* WLSQ moment matrices of a mesh on the device (per-mesh preprocessing; Load_mesh.py:247-272 ->
+ * FVgrad.py:183-232 -> FVorder.py:7-86), float64: for node i and its directed stencil entries k in CSR order
+ * (rowptr [N+1], outn [S] = the other node of entry k, entry [S] = the entry's position in the caller's edge order):
+ *   d = pos[outn[k]] - pos[i], t = the `terms` (2 / 5 / 9 / 14) Taylor monomials of d, w = 1 / |d|,
+ *   A[i] (+)= w t t^T  [N, terms, terms],   B[entry[k]] = w t  [S, terms]. */
+int gfv_wlsq_moments(const double* pos, const int32_t* rowptr, const int32_t* outn, const int32_t* entry, double* A, double* B,
+                     int32_t N, int32_t terms, void* stream);
+
 /* Stand-alone 2nd-order interpolation (FVInterpolation.py `Interplot`: node_to_cell_2nd_order :36-109,
  * node_to_face_2nd_order :111-185, cell_to_node_2nd_order :218-265), any channel count C:
  *   out[r, c] = sum_{k in row r} w_k (phi[col[k], c] + (tgtpos[r] - srcpos[col[k]]) . grad[col[k], c, 0:2]) / W_r
