@@ -16,36 +16,41 @@
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
 // exact (erf) GELU, nn.GELU() default (reference EPD.py:26).
-// erfc(u), u >= 0, by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7 absolute): branch-free, 2 transcendental + ~12
-// plain VALU ops per value, against ~40 with both divergent branches of the library erff.  The absolute error of
-// 1 + erf is ~2e-7, i.e. GELU values differ from the library form by <= 2e-7 |x| (parity budget: 1e-5 relative).
+// erfc(u), u >= 0, by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7 absolute): branch-free.  The chain kernels are bound by
+// VALU issue as much as by memory latency (profiles/r01_tchain_split_pmc.txt: 8 VALU per MFMA, GELU nearly half of them),
+// so the evaluation is trimmed to 11 plain + 2 transcendental instructions per value:
+//   a = |x| sqrt(log2(e) / 2)  so that  exp(-x^2 / 2) = exp2(-a a)  is ONE multiplication in front of v_exp_f32;
+//   t = 1 / (1 + p u),  u = |x| / sqrt 2 = a / sqrt(log2 e),  by v_rcp_f32 (1 ulp; the correctly rounded reciprocal is a
+//   ten-instruction sequence and cost 2.8 % of the whole training step, profiles/tools/abn.sh frcp);
+//   the polynomial's coefficients carry the factor 0.5 of  0.5 erfc.
+// GELU / GELU' values differ from the exact ones by <= 3.5e-7 absolute, as with the untrimmed form (parity budget: 1e-5 relative).
 // -DGFV_LIBM_ERF selects the library erff instead.
 struct gfv_erfc_t {
-  float y;  // erfc(|x| / sqrt 2)
+  float y;  // 0.5 erfc(|x| / sqrt 2)
   float e;  // exp(-x^2 / 2)
 };
 static __device__ __forceinline__ gfv_erfc_t gfv_erfc_half(float x) {
-  const float u = fabsf(x) * 0.70710678118654752440f;
-  const float t = __frcp_rn(fmaf(0.3275911f, u, 1.0f));
+  const float a = fabsf(x) * 0.84932180028801904272f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.2727374808792225f, a, 1.0f));   // 0.3275911 / sqrt(log2 e)
   gfv_erfc_t r;
-  r.e = __expf(-u * u);
-  float p = fmaf(1.061405429f, t, -1.453152027f);
-  p = fmaf(p, t, 1.421413741f);
-  p = fmaf(p, t, -0.284496736f);
-  p = fmaf(p, t, 0.254829592f);
-  r.y = p * t * r.e;
+  r.e = __builtin_amdgcn_exp2f(-(a * a));
+  float p = fmaf(0.5307027145f, t, -0.7265760135f);
+  p = fmaf(p, t, 0.7107068705f);
+  p = fmaf(p, t, -0.142248368f);
+  p = fmaf(p, t, 0.127414796f);
+  r.y = (p * t) * r.e;
   return r;
 }
 #ifndef GFV_LIBM_ERF
 static __device__ __forceinline__ float gfv_gelu(float x) {
   const gfv_erfc_t r = gfv_erfc_half(x);
-  // x >= 0: 0.5 x (2 - erfc) = x - h;  x < 0: 0.5 x erfc = -h;  h = 0.5 |x| erfc(|x|/sqrt 2)
-  return fmaxf(x, 0.0f) - 0.5f * fabsf(x) * r.y;
+  // x >= 0: 0.5 x (2 - erfc) = x - h;  x < 0: 0.5 x erfc = -h;  h = |x| 0.5 erfc(|x|/sqrt 2)
+  return fmaf(-fabsf(x), r.y, fmaxf(x, 0.0f));
 }
 static __device__ __forceinline__ float gfv_dgelu(float x) {
   const gfv_erfc_t r = gfv_erfc_half(x);
-  const float cdf = x >= 0.0f ? 1.0f - 0.5f * r.y : 0.5f * r.y;
-  return cdf + x * (0.39894228040143267794f * r.e);
+  const float cdf = x >= 0.0f ? 1.0f - r.y : r.y;
+  return fmaf(x * 0.39894228040143267794f, r.e, cdf);
 }
 #else
 static __device__ __forceinline__ float gfv_gelu(float x) {

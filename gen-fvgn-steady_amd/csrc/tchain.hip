@@ -474,7 +474,12 @@ __device__ __forceinline__ void load_segment(const gfv_rowtile_args_t& A, int si
 // per row - and was slower (see the launcher): 8 waves marching in lockstep through the slice barriers hide less latency
 // than two independent groups of 4.  The LayerNorm partials stay per 64-row tile (same sums, same order) either way.
 template <int T, int LNM, bool RAG, bool H, int NW = 4, bool CSR = false>
-__global__ __launch_bounds__(64 * NW, NW == 16 ? 4 : 2) void tchain_kernel(const gfv_rowtile_args_t A) {
+#ifdef GFV_LB3
+#define GFV_CHAIN_WAVES(H, LNM, RAG) ((H) && (LNM) == 0 && !(RAG) ? 3 : 2)
+#else
+#define GFV_CHAIN_WAVES(H, LNM, RAG) 2
+#endif
+__global__ __launch_bounds__(64 * NW, GFV_CHAIN_WAVES(H, LNM, RAG)) void tchain_kernel(const gfv_rowtile_args_t A) {
   static_assert(!CSR || (LNM == 0 && !RAG && T == 1), "segmented-sum segments exist in the plain instantiation");
   static_assert(!H || T == 1, "the f16 form is instantiated for 16 rows per wave");
   static_assert(NW == 4 || (H && T == 1 && NW == 8), "the wide workgroup exists in the f16 form only");
