@@ -17,6 +17,14 @@ def sources():
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
 
 
+def file_flags(src):
+    """Extra hipcc flags a source asks for in its first line: `// gfv-build-flags: <flags>`."""
+    with open(src) as f:
+        first = f.readline()
+    tag = "// gfv-build-flags:"
+    return first[len(tag):].split() if first.startswith(tag) else []
+
+
 def _stale(target, deps):
     if not os.path.exists(target):
         return True
@@ -56,7 +64,7 @@ def build(force=False, verbose=False):
         o = os.path.join(objdir, os.path.basename(s)[:-4] + ".o")
         objs.append(o)
         if force or _stale(o, [s] + hdrs):
-            jobs.append([HIPCC, *FLAGS, "-c", s, "-o", o])
+            jobs.append([HIPCC, *FLAGS, *file_flags(s), "-c", s, "-o", o])
 
     def run(cmd):
         if verbose:

@@ -4,8 +4,8 @@
 cd /root/repo/gen-fvgn-steady_amd/csrc/build
 for v in "BASE:" "NOSEG:-DABL_NOSEG" "NOSTORE:-DABL_NOSTORE" "NOGELU:-DABL_NOGELU" "NOW:-DABL_NOW" "ALL:-DABL_NOSEG -DABL_NOSTORE -DABL_NOGELU -DABL_NOW"; do
   tag=${v%%:*}; fl=${v#*:}
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off $fl -c ../tchain.hip -o /tmp/tchain_$tag.o &&
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC dw.o fvm.o misc.o prof.o rowtile.o segreduce.o slice.o wimg.o /tmp/tchain_$tag.o -o /root/repo/scratch/libgfv_$tag.so &
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off $fl -c ../tchain.hip -o /tmp/tchain_$tag.o && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize $fl -c ../tchain_fwd.hip -o /tmp/tchain_fwd_$tag.o &&
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC dw.o fvm.o misc.o prof.o rowtile.o segreduce.o slice.o wimg.o /tmp/tchain_$tag.o /tmp/tchain_fwd_$tag.o -o /root/repo/scratch/libgfv_$tag.so &
 done
 wait
 ls -la /root/repo/scratch/*.so
