@@ -1,3 +1,4 @@
+// gfv-build-flags: -fno-slp-vectorize
 // Transolver "physics attention" over per-graph slice tokens (gfx950).  Contract: include/gfv.h.
 // Reference: FVMmodel/Models/GraphTransolver/GraphTransolver.py:48-95 (Graph_Physics_Attention_1D.graph_forward).
 //

@@ -13,7 +13,7 @@ for rep in 1 2 3; do
     python3 -c "
 import json
 d=json.load(open('$O/${v}_$rep.json'))
-print('$v', $rep, d['ms_per_step'], [ (r['kernel'][:26], r['ms_per_step']) for r in d['roofline_kernels'][:5]])
+print('$v', $rep, d['ms_per_step'], ' '.join('%s=%.3f' % (r['kernel'].replace('tchain_kernel','tc').replace(', ','')[:18], r['ms_per_step']) for r in d['roofline_kernels'] if r['ms_per_step'] >= 0.02))
 "
   done
 done
