@@ -126,13 +126,34 @@ __device__ __forceinline__ void w_store(float* Wb, int tid, const WRegs& r) {
   *reinterpret_cast<floatx4*>(Wb + 4 * tid + 3072) = r.d;
 }
 
+// Exchange between the 4 lanes (g = 0..3, lane = 16 g + row) that share a row: v_permlane16_swap / v_permlane32_swap (gfx950)
+// swap the odd 16-lane rows / the upper 32 lanes of one register with the even rows / the lower 32 lanes of another - two
+// copies of x in, (x, x of the partner lane) out: a VALU instruction instead of a ds_bpermute round trip through the LDS
+// crossbar on the dependent path of every LayerNorm and every operand split.  (Inline asm: with both operands the same
+// value hipcc 7.2 folds the builtin's two results into one; the s_nop's are the VALU-write -> permlane-read wait states.)
+__device__ __forceinline__ void lane_xor16(float x, float& a, float& b) {
+  a = x; b = x;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ void lane_xor32(float x, float& a, float& b) {
+  a = x; b = x;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+}
 // sum over the 4 lanes (g = 0..3) that share a row
 __device__ __forceinline__ float row_sum(float v) {
-  v += __shfl_xor(v, 16, 64);
-  v += __shfl_xor(v, 32, 64);
-  return v;
+  float a, b;
+  lane_xor16(v, a, b);
+  v = a + b;
+  lane_xor32(v, a, b);
+  return a + b;
 }
-
+__device__ __forceinline__ float row_max4(float v) {
+  float a, b;
+  lane_xor16(v, a, b);
+  v = fmaxf(a, b);
+  lane_xor32(v, a, b);
+  return fmaxf(a, b);
+}
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, const float (&v)[4]) {
   *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
@@ -195,22 +216,26 @@ __device__ __forceinline__ void ln_bwd(float (&v)[8][4], const float (&y)[8][4],
     for (int r = 0; r < 4; ++r) v[t][r] = rstd * (v[t][r] - m1 - ((y[t][r] - mean) * rstd) * m2);
 }
 
+// sum over the 16 lanes of a DPP row (= the 16 rows of the wave's tile at fixed g), total in lane 15 of the row: four
+// v_add_f32 with a row_shr operand (zeros shifted in) instead of four ds_bpermute round trips through the LDS crossbar
+__device__ __forceinline__ float row16_sum_to_last(float x) {
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x111, 0xf, 0xf, true));  // row_shr:1
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x112, 0xf, 0xf, true));  // row_shr:2
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x114, 0xf, 0xf, true));  // row_shr:4
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x118, 0xf, 0xf, true));  // row_shr:8
+  return x;
+}
+
 // fold the lane-private (dgamma, dbeta) sums over the 16 rows of the wave and park them in LDS: red[wave][2][128]
 __device__ __forceinline__ void ln_park(float (&dgam)[8][4], float (&dbet)[8][4], float* red, int wave, int li, int g) {
 #pragma unroll
   for (int t = 0; t < 8; ++t)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      float a = dgam[t][r], b = dbet[t][r];
-#pragma unroll
-      for (int o = 8; o >= 1; o >>= 1) {
-        a += __shfl_xor(a, o, 64);
-        b += __shfl_xor(b, o, 64);
-      }
-      dgam[t][r] = a;
-      dbet[t][r] = b;
+      dgam[t][r] = row16_sum_to_last(dgam[t][r]);
+      dbet[t][r] = row16_sum_to_last(dbet[t][r]);
     }
-  if (li == 0) {
+  if (li == 15) {
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
       st4(red + (wave * 2 + 0) * 128 + 16 * t + 4 * g, dgam[t]);
@@ -299,17 +324,16 @@ __device__ __forceinline__ float row_scale(const float (&v)[8][4]) {
   float m = 0.f;
 #pragma unroll
   for (int t = 0; t < 8; ++t) m = fmaxf(fmaxf(m, fmaxf(fabsf(v[t][0]), fabsf(v[t][1]))), fmaxf(fabsf(v[t][2]), fabsf(v[t][3])));
-  m = fmaxf(m, __shfl_xor(m, 16, 64));
-  m = fmaxf(m, __shfl_xor(m, 32, 64));
-  return gfv_pow2_scale(m);
+  return gfv_pow2_scale(row_max4(m));
 }
 // H: the scale of a group of 16 rows (= this wave's rows) is the smallest of its rows' scales; lane 0 leaves it for the
 // weight-gradient kernel (gfv_rowtile_args_t.gscale)
 __device__ __forceinline__ void group_scale_out(float* dst, float s, int lane) {
-  s = fminf(s, __shfl_xor(s, 1, 64));
-  s = fminf(s, __shfl_xor(s, 2, 64));
-  s = fminf(s, __shfl_xor(s, 4, 64));
-  s = fminf(s, __shfl_xor(s, 8, 64));
+  // minimum over the 16 lanes of a DPP row, every lane gets it: quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror
+  s = fminf(s, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0xB1, 0xf, 0xf, true)));
+  s = fminf(s, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x4E, 0xf, 0xf, true)));
+  s = fminf(s, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x141, 0xf, 0xf, true)));
+  s = fminf(s, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x140, 0xf, 0xf, true)));
   if (lane == 0) *dst = s;
 }
 // H: fp32 activations -> B-operand fragments of the four 32-groups: slots e = 0..3 <- act[2T][.], 4..7 <- act[2T+1][.]
