@@ -263,8 +263,7 @@ __device__ __forceinline__ void dw_body_h(const DwLaunch& A, const gfv_dw_tile_t
     // the producer left one power of two per group of 16 rows: the slab takes the smallest (slabs start at multiples of 32)
     float smin = 8.5070592e37f;
     for (int q = (m_beg >> 4) + tid; q < ((m_end + 15) >> 4); q += 256) smin = fminf(smin, T.gscale[q]);
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) smin = fminf(smin, __shfl_xor(smin, o, 64));
+    smin = gfv_wave_min(smin);
     if (lane == 0) wred[wave] = smin;
     __syncthreads();
     sg = fminf(fminf(wred[0], wred[1]), fminf(wred[2], wred[3]));
@@ -280,8 +279,7 @@ __device__ __forceinline__ void dw_body_h(const DwLaunch& A, const gfv_dw_tile_t
       for (int u = 0; u < 8; ++u)
         gm = fmaxf(fmaxf(gm, fmaxf(fabsf(v[u].x), fabsf(v[u].y))), fmaxf(fabsf(v[u].z), fabsf(v[u].w)));
     }
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) gm = fmaxf(gm, __shfl_xor(gm, o, 64));
+    gm = gfv_wave_max(gm);
     if (lane == 0) wred[wave] = gm;
     __syncthreads();
     sg = gfv_pow2_scale(fmaxf(fmaxf(wred[0], wred[1]), fmaxf(wred[2], wred[3])));

@@ -63,17 +63,69 @@ static __device__ __forceinline__ float gfv_dgelu(float x) {
 }
 #endif
 
-// sum over the 64 lanes of a wave (all lanes get the result)
-static __device__ __forceinline__ float gfv_wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+// ---- cross-lane reductions without the LDS crossbar ---------------------------------------------------------------
+// `__shfl_xor` is a ds_bpermute_b32: an LDS instruction plus an lgkmcnt wait per step.  Within a 16-lane DPP row the xor
+// partners come from a DPP operand (quad_perm [1,0,3,2], [2,3,0,1], then row_half_mirror and row_mirror, which pair the
+// quads / the halves once every lane of a quad / half holds the same partial); across rows gfx950's
+// v_permlane16_swap / v_permlane32_swap exchange the odd and even rows / the two halves of two registers (two copies of
+// x in, x and the partner's x out).  All are VALU instructions; every lane gets the result.
+// (Inline asm for the swaps: with both operands the same value hipcc 7.2 folds the builtin's two results into one; the
+// s_nop's are the VALU-write -> permlane-read wait states.)
+#define GFV_DPP_F(x, ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (x)), (ctrl), 0xf, 0xf, true))
+static __device__ __forceinline__ void gfv_lane_xor16(float x, float& a, float& b) {
+  a = x; b = x;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+}
+static __device__ __forceinline__ void gfv_lane_xor32(float x, float& a, float& b) {
+  a = x; b = x;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+}
+// sum over aligned groups of 16 lanes
+static __device__ __forceinline__ float gfv_row16_sum(float v) {
+  v += GFV_DPP_F(v, 0xB1);
+  v += GFV_DPP_F(v, 0x4E);
+  v += GFV_DPP_F(v, 0x141);
+  v += GFV_DPP_F(v, 0x140);
+  return v;
+}
+static __device__ __forceinline__ float gfv_row16_max(float v) {
+  v = fmaxf(v, GFV_DPP_F(v, 0xB1));
+  v = fmaxf(v, GFV_DPP_F(v, 0x4E));
+  v = fmaxf(v, GFV_DPP_F(v, 0x141));
+  v = fmaxf(v, GFV_DPP_F(v, 0x140));
+  return v;
+}
+static __device__ __forceinline__ float gfv_row16_min(float v) {
+  v = fminf(v, GFV_DPP_F(v, 0xB1));
+  v = fminf(v, GFV_DPP_F(v, 0x4E));
+  v = fminf(v, GFV_DPP_F(v, 0x141));
+  v = fminf(v, GFV_DPP_F(v, 0x140));
   return v;
 }
 // sum over aligned groups of 32 lanes
 static __device__ __forceinline__ float gfv_half_sum(float v) {
-#pragma unroll
-  for (int o = 16; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  float a, b;
+  gfv_lane_xor16(gfv_row16_sum(v), a, b);
+  return a + b;
+}
+// sum / maximum / minimum over the 64 lanes of a wave (all lanes get the result)
+static __device__ __forceinline__ float gfv_wave_sum(float v) {
+  float a, b;
+  gfv_lane_xor16(gfv_row16_sum(v), a, b);
+  gfv_lane_xor32(a + b, a, b);
+  return a + b;
+}
+static __device__ __forceinline__ float gfv_wave_max(float v) {
+  float a, b;
+  gfv_lane_xor16(gfv_row16_max(v), a, b);
+  gfv_lane_xor32(fmaxf(a, b), a, b);
+  return fmaxf(a, b);
+}
+static __device__ __forceinline__ float gfv_wave_min(float v) {
+  float a, b;
+  gfv_lane_xor16(gfv_row16_min(v), a, b);
+  gfv_lane_xor32(fminf(a, b), a, b);
+  return fminf(a, b);
 }
 
 static inline int gfv_div_up(long a, long b) { return (int)((a + b - 1) / b); }

@@ -126,32 +126,20 @@ __device__ __forceinline__ void w_store(float* Wb, int tid, const WRegs& r) {
   *reinterpret_cast<floatx4*>(Wb + 4 * tid + 3072) = r.d;
 }
 
-// Exchange between the 4 lanes (g = 0..3, lane = 16 g + row) that share a row: v_permlane16_swap / v_permlane32_swap (gfx950)
-// swap the odd 16-lane rows / the upper 32 lanes of one register with the even rows / the lower 32 lanes of another - two
-// copies of x in, (x, x of the partner lane) out: a VALU instruction instead of a ds_bpermute round trip through the LDS
-// crossbar on the dependent path of every LayerNorm and every operand split.  (Inline asm: with both operands the same
-// value hipcc 7.2 folds the builtin's two results into one; the s_nop's are the VALU-write -> permlane-read wait states.)
-__device__ __forceinline__ void lane_xor16(float x, float& a, float& b) {
-  a = x; b = x;
-  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
-}
-__device__ __forceinline__ void lane_xor32(float x, float& a, float& b) {
-  a = x; b = x;
-  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
-}
+// (cross-lane helpers: gfv_common.h - DPP within a 16-lane row, v_permlane16/32_swap across rows, no LDS crossbar)
 // sum over the 4 lanes (g = 0..3) that share a row
 __device__ __forceinline__ float row_sum(float v) {
   float a, b;
-  lane_xor16(v, a, b);
+  gfv_lane_xor16(v, a, b);
   v = a + b;
-  lane_xor32(v, a, b);
+  gfv_lane_xor32(v, a, b);
   return a + b;
 }
 __device__ __forceinline__ float row_max4(float v) {
   float a, b;
-  lane_xor16(v, a, b);
+  gfv_lane_xor16(v, a, b);
   v = fmaxf(a, b);
-  lane_xor32(v, a, b);
+  gfv_lane_xor32(v, a, b);
   return fmaxf(a, b);
 }
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
@@ -329,11 +317,7 @@ __device__ __forceinline__ float row_scale(const float (&v)[8][4]) {
 // H: the scale of a group of 16 rows (= this wave's rows) is the smallest of its rows' scales; lane 0 leaves it for the
 // weight-gradient kernel (gfv_rowtile_args_t.gscale)
 __device__ __forceinline__ void group_scale_out(float* dst, float s, int lane) {
-  // minimum over the 16 lanes of a DPP row, every lane gets it: quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror
-  s = fminf(s, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0xB1, 0xf, 0xf, true)));
-  s = fminf(s, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x4E, 0xf, 0xf, true)));
-  s = fminf(s, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x141, 0xf, 0xf, true)));
-  s = fminf(s, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x140, 0xf, 0xf, true)));
+  s = gfv_row16_min(s);
   if (lane == 0) *dst = s;
 }
 // H: fp32 activations -> B-operand fragments of the four 32-groups: slots e = 0..3 <- act[2T][.], 4..7 <- act[2T+1][.]

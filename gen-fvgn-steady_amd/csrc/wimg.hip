@@ -21,8 +21,7 @@ __global__ __launch_bounds__(256) void wabsmax_kernel(const gfv_wimg_desc_t* __r
     for (int n = blockIdx.x * 4 + (threadIdx.x >> 6); n < d.N; n += gridDim.x * 4)
       for (int k = threadIdx.x & 63; k < d.K; k += 64) m = fmaxf(m, fabsf(d.W[(size_t)n * d.ldw + k]));
   }
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  m = gfv_wave_max(m);
   // non-negative floats order like their bit patterns
   if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(reinterpret_cast<unsigned*>(wmax), __float_as_uint(m));
 }
