@@ -1,21 +1,41 @@
 // Launchers of the register-resident chain (kernel template: tchain_kernel.h).  This translation unit holds every
-// instantiation except the plain forward one, which tchain_fwd.hip compiles without the SLP vectoriser.
+// instantiation except the plain ones with compile-time element ops, which tchain_fwd.hip compiles without the SLP vectoriser.
 #include "tchain_kernel.h"
 
-void gfv_internal_tchain_fwd_plain(const gfv_rowtile_args_t* args, int f16, hipStream_t stream);   // tchain_fwd.hip
+void gfv_internal_tchain_fwd_plain(const gfv_rowtile_args_t* args, int f16, int iop, hipStream_t stream);   // tchain_fwd.hip
+
+// 1 / 2: every layer before the last has GFV_OP_BIAS_GELU / GFV_OP_MUL_DGELU and the prologue op is none or the LayerNorm
+// backward (the IOP instantiations, tchain_kernel.h); 0: anything else - the instantiation that reads the ops at run time
+static int chain_iop(const gfv_rowtile_args_t* a) {
+  if (a->in_op != GFV_IN_NONE && a->in_op != GFV_IN_LNBWD) return 0;
+  int iop = 0;
+  for (int l = 0; l + 1 < a->nlayers; ++l) {
+    const int op = a->layer[l].op;
+    if (op != GFV_OP_BIAS_GELU && op != GFV_OP_MUL_DGELU) return 0;
+    if (iop != 0 && iop != op) return 0;
+    iop = op;
+  }
+  return iop ? iop : GFV_OP_BIAS_GELU;   // (a single layer has no inner epilogue: either form)
+}
 
 template <int NW>
 static void launch_h(const gfv_rowtile_args_t* args, int ragged, int lnm, hipStream_t stream) {
   const int tiles = (args->M + 16 * NW - 1) / (16 * NW);
   const dim3 wgs(tiles), blk(64 * NW);
+  const int iop = chain_iop(args);
   bool csr = false;
   for (int i = 0; i < args->nseg; ++i) csr = csr || args->seg[i].csr_rowptr != nullptr || args->seg[i].save != nullptr;
   if (csr) {   // (the caller checked: plain instantiation only)
-    hipLaunchKernelGGL((tchain_kernel<1, 0, false, true, NW, true>), dim3(gfv_xcd_grid(tiles)), blk, 0, stream, *args);
+    if (iop == GFV_OP_BIAS_GELU)
+      hipLaunchKernelGGL((tchain_kernel<1, 0, false, true, NW, true, 1>), dim3(gfv_xcd_grid(tiles)), blk, 0, stream, *args);
+    else
+      hipLaunchKernelGGL((tchain_kernel<1, 0, false, true, NW, true>), dim3(gfv_xcd_grid(tiles)), blk, 0, stream, *args);
     return;
   }
   if (ragged) hipLaunchKernelGGL((tchain_kernel<1, 0, true, true, NW>), wgs, blk, 0, stream, *args);
-  else if (lnm == 0) gfv_internal_tchain_fwd_plain(args, 1, stream);
+  else if (lnm == 0 && iop != 0) gfv_internal_tchain_fwd_plain(args, 1, iop, stream);
+  else if (lnm == 0) hipLaunchKernelGGL((tchain_kernel<1, 0, false, true, NW>), wgs, blk, 0, stream, *args);
+  else if (lnm == 1 && iop == GFV_OP_MUL_DGELU) hipLaunchKernelGGL((tchain_kernel<1, 1, false, true, NW, false, 2>), wgs, blk, 0, stream, *args);
   else if (lnm == 1) hipLaunchKernelGGL((tchain_kernel<1, 1, false, true, NW>), wgs, blk, 0, stream, *args);
   else hipLaunchKernelGGL((tchain_kernel<1, 2, false, true, NW>), wgs, blk, 0, stream, *args);
 }
@@ -31,11 +51,12 @@ int gfv_internal_tchain_launch(const gfv_rowtile_args_t* args, int ragged, int f
     launch_h<4>(args, ragged, lnm, stream);
     return 0;
   }
+  // fp32-MFMA form: the run-time-op instantiations only (it is the reference form of the tests, not the product path)
   bool csr = false;
   for (int i = 0; i < args->nseg; ++i) csr = csr || args->seg[i].csr_rowptr != nullptr || args->seg[i].save != nullptr;
   if (csr) hipLaunchKernelGGL((tchain_kernel<1, 0, false, false, 4, true>), dim3(gfv_xcd_grid((args->M + 63) / 64)), blk, 0, stream, *args);
   else if (ragged) hipLaunchKernelGGL((tchain_kernel<1, 0, true, false>), wgs, blk, 0, stream, *args);
-  else if (lnm == 0) gfv_internal_tchain_fwd_plain(args, 0, stream);
+  else if (lnm == 0) gfv_internal_tchain_fwd_plain(args, 0, 0, stream);
   else if (lnm == 1) hipLaunchKernelGGL((tchain_kernel<1, 1, false, false>), wgs, blk, 0, stream, *args);
   else hipLaunchKernelGGL((tchain_kernel<1, 2, false, false>), wgs, blk, 0, stream, *args);
   return 0;

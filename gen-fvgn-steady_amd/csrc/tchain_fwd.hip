@@ -1,6 +1,6 @@
 // gfv-build-flags: -fno-slp-vectorize
-// The plain forward instantiation of the register-resident chain (no LayerNorm backward, no ragged shapes, no segmented-sum
-// segments), compiled WITHOUT the SLP vectoriser.  hipcc's SLP pass packs neighbouring scalar fp32 operations into
+// The plain instantiations of the register-resident chain (no LayerNorm backward, no ragged shapes, no segmented-sum
+// segments; element ops known at compile time), compiled WITHOUT the SLP vectoriser.  hipcc's SLP pass packs neighbouring scalar fp32 operations into
 // v_pk_* instructions: a quarter fewer VALU instructions, but the operand pairs need aligned register pairs and shuffling
 // moves, and the kernel lands at 205 (f16 form) / 201 (fp32 form) VGPRs = 2 waves per SIMD.  Without the pass the same
 // source needs 164 / 153 registers = 3 waves per SIMD, and that wins for this instantiation: 0.941 -> 0.881 ms per step
@@ -9,8 +9,9 @@
 // default in tchain.hip.
 #include "tchain_kernel.h"
 
-void gfv_internal_tchain_fwd_plain(const gfv_rowtile_args_t* args, int f16, hipStream_t stream) {
+void gfv_internal_tchain_fwd_plain(const gfv_rowtile_args_t* args, int f16, int iop, hipStream_t stream) {
   const dim3 wgs((args->M + 63) / 64), blk(256);
-  if (f16) hipLaunchKernelGGL((tchain_kernel<1, 0, false, true, 4>), wgs, blk, 0, stream, *args);
-  else hipLaunchKernelGGL((tchain_kernel<1, 0, false, false>), wgs, blk, 0, stream, *args);
+  if (!f16) hipLaunchKernelGGL((tchain_kernel<1, 0, false, false>), wgs, blk, 0, stream, *args);
+  else if (iop == GFV_OP_BIAS_GELU) hipLaunchKernelGGL((tchain_kernel<1, 0, false, true, 4, false, 1>), wgs, blk, 0, stream, *args);
+  else hipLaunchKernelGGL((tchain_kernel<1, 0, false, true, 4, false, 2>), wgs, blk, 0, stream, *args);
 }

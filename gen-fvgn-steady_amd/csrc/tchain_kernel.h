@@ -178,6 +178,7 @@ __device__ __forceinline__ void ln_apply(float (&v)[8][4], const float* gamma, c
 
 // LayerNorm backward of one row: y = LN input (pre-normalisation), go = grad wrt LN output (in v, replaced by the
 // grad wrt the LN input); accumulates this lane's 32 columns of dgamma / dbeta.
+template <bool FIRST>   // FIRST: (dgam, dbet) are assigned, not added to (no zero-initialised accumulators for the first tile)
 __device__ __forceinline__ void ln_bwd(float (&v)[8][4], const float (&y)[8][4], const float* gamma, int g,
                                        float (&dgam)[8][4], float (&dbet)[8][4]) {
   float mean, rstd;
@@ -190,8 +191,13 @@ __device__ __forceinline__ void ln_bwd(float (&v)[8][4], const float (&y)[8][4],
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const float xh = (y[t][r] - mean) * rstd;
-      dgam[t][r] += v[t][r] * xh;
-      dbet[t][r] += v[t][r];
+      if (FIRST) {
+        dgam[t][r] = v[t][r] * xh;
+        dbet[t][r] = v[t][r];
+      } else {
+        dgam[t][r] += v[t][r] * xh;
+        dbet[t][r] += v[t][r];
+      }
       v[t][r] *= gv[r];  // gg
       s1 += v[t][r];
       s2 += v[t][r] * xh;
@@ -230,6 +236,41 @@ __device__ __forceinline__ void ln_park(float (&dgam)[8][4], float (&dbet)[8][4]
       st4(red + (wave * 2 + 1) * 128 + 16 * t + 4 * g, dbet[t]);
     }
   }
+}
+
+// LayerNorm backward of ONE row per lane (T = 1) with the (dgamma, dbeta) fold in the same pass: the lane's 32 products
+// dy * xhat and its 32 dy go through the row fold and into LDS four at a time - holding all 64 through the second half of
+// ln_bwd and handing them to ln_park afterwards keeps 64 more registers alive in the most register-hungry phase of the
+// LayerNorm-backward instantiation.
+__device__ __forceinline__ void ln_bwd_park(float (&v)[8][4], const float (&y)[8][4], const float* gamma, int g, float* red,
+                                            int wave, int li) {
+  float mean, rstd;
+  ln_stats(y, mean, rstd);
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    const float4 ga = ld4(gamma + 16 * t + 4 * g);
+    const float gv[4] = {ga.x, ga.y, ga.z, ga.w};
+    float dg[4], db[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float xh = (y[t][r] - mean) * rstd;
+      dg[r] = row16_sum_to_last(v[t][r] * xh);
+      db[r] = row16_sum_to_last(v[t][r]);
+      v[t][r] *= gv[r];  // gg
+      s1 += v[t][r];
+      s2 += v[t][r] * xh;
+    }
+    if (li == 15) {
+      st4(red + (wave * 2 + 0) * 128 + 16 * t + 4 * g, dg);
+      st4(red + (wave * 2 + 1) * 128 + 16 * t + 4 * g, db);
+    }
+  }
+  const float m1 = row_sum(s1) * (1.0f / 128.0f), m2 = row_sum(s2) * (1.0f / 128.0f);
+#pragma unroll
+  for (int t = 0; t < 8; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[t][r] = rstd * (v[t][r] - m1 - ((y[t][r] - mean) * rstd) * m2);
 }
 
 // one 32-wide k slice: acc[tt][nt] += W[16nt + i][k] * act[tt][k], k = 16t + 4g + s for t in {2sl, 2sl+1}
@@ -337,7 +378,7 @@ __device__ __forceinline__ void to_halves(const float (&v)[8][4], float sc, gfv_
 template <int T, int LNM, bool RAG, bool CSR>
 __device__ __forceinline__ void load_segment(const gfv_rowtile_args_t& A, int si, int rowbase, int g, const float* gam,
                                              const float* bet, float (&act)[T][8][4], float (&dgam)[8][4],
-                                             float (&dbet)[8][4]) {
+                                             float (&dbet)[8][4], int in_op, float* red, int wave, int li) {
   const gfv_seg_t& s = A.seg[si];
   const int nt_valid = s.width >> 4;
   const bool first = (si == 0);
@@ -431,14 +472,14 @@ __device__ __forceinline__ void load_segment(const gfv_rowtile_args_t& A, int si
         act[tt][t][0] += v.x; act[tt][t][1] += v.y; act[tt][t][2] += v.z; act[tt][t][3] += v.w;
       }
     }
-    if (A.in_op == GFV_IN_GELU) {
+    if (in_op == GFV_IN_GELU) {
 #pragma unroll
       for (int t = 0; t < 8; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) act[tt][t][r] = gfv_gelu(act[tt][t][r]);
-    } else if (A.in_op == GFV_IN_LN) {
+    } else if (in_op == GFV_IN_LN) {
       ln_apply(act[tt], gam, bet, g);
-    } else if (LNM == 1 && A.in_op == GFV_IN_LNBWD) {
+    } else if (LNM == 1 && in_op == GFV_IN_LNBWD) {
       float y[8][4];
       const float* yp = A.in_aux + (size_t)mc * 128 + 4 * g;
 #pragma unroll
@@ -446,20 +487,21 @@ __device__ __forceinline__ void load_segment(const gfv_rowtile_args_t& A, int si
         const float4 v = ld4(yp + 16 * t);
         y[t][0] = v.x; y[t][1] = v.y; y[t][2] = v.z; y[t][3] = v.w;
       }
-      if (!live) {
-#pragma unroll
-        for (int t = 0; t < 8; ++t)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) act[tt][t][r] = 0.f;
-      }
-      ln_bwd(act[tt], y, gam, g, dgam, dbet);
-    }
-    if (!live) {
+      // rows past M (clamped re-reads of row M - 1) must not reach the (dgamma, dbeta) sums: their incoming gradient is
+      // multiplied by 0 - everything ln_bwd derives from it is then 0 as well.  (A multiplication, not `if (!live) act = 0`:
+      // hipcc turns the conditional assignment of a register array into a copy of all 32 registers plus 32 more moves
+      // under the exec mask, on every tile - 9 % of this instantiation's VALU instructions together with the zeroing
+      // that used to follow every segment load.)
+      const float livef = live ? 1.0f : 0.0f;
 #pragma unroll
       for (int t = 0; t < 8; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) act[tt][t][r] = 0.f;
+        for (int r = 0; r < 4; ++r) act[tt][t][r] *= livef;
+      if (T == 1) ln_bwd_park(act[tt], y, gam, g, red, wave, li);   // (the fold lands in LDS right here)
+      else if (tt == 0) ln_bwd<true>(act[tt], y, gam, g, dgam, dbet);
+      else ln_bwd<false>(act[tt], y, gam, g, dgam, dbet);
     }
+    // (rows past M keep the values of row M - 1 from here on: nothing of theirs is stored, and no other sum runs over rows)
     if (first && A.in_save && live) {
       float* sp = A.in_save + (size_t)m * 128 + 4 * g;
 #pragma unroll
@@ -483,10 +525,13 @@ __device__ __forceinline__ void load_segment(const gfv_rowtile_args_t& A, int si
 // CU at 2 waves / SIMD, the occupancy of two 4-wave ones) moves half the weight bytes and runs half the barrier rounds
 // per row - and was slower (see the launcher): 8 waves marching in lockstep through the slice barriers hide less latency
 // than two independent groups of 4.  The LayerNorm partials stay per 64-row tile (same sums, same order) either way.
-template <int T, int LNM, bool RAG, bool H, int NW = 4, bool CSR = false>
-#ifdef GFV_LB3
-#define GFV_CHAIN_WAVES(H, LNM, RAG) ((H) && (LNM) == 0 && !(RAG) ? 3 : 2)
-#else
+// IOP: 0 = the element ops are read from the arguments at run time; 1 / 2 = every layer before the last has
+// GFV_OP_BIAS_GELU / GFV_OP_MUL_DGELU and the prologue op is none (LNM = 1: the LayerNorm backward) - what all but a
+// handful of the model's launches are.  With the ops known at compile time the epilogues have no branches to merge:
+// hipcc joins the arms of a run-time `switch (op)` over a 32-register activation array with 100 - 150 register moves per
+// layer (a tenth of the kernel's VALU instructions).
+template <int T, int LNM, bool RAG, bool H, int NW = 4, bool CSR = false, int IOP = 0>
+#ifndef GFV_CHAIN_WAVES   // waves per SIMD the register allocation aims at (a translation unit may set its own)
 #define GFV_CHAIN_WAVES(H, LNM, RAG) 2
 #endif
 __global__ __launch_bounds__(64 * NW, GFV_CHAIN_WAVES(H, LNM, RAG)) void tchain_kernel(const gfv_rowtile_args_t A) {
@@ -595,8 +640,9 @@ __global__ __launch_bounds__(64 * NW, GFV_CHAIN_WAVES(H, LNM, RAG)) void tchain_
 #pragma unroll
               for (int r = 0; r < 4; ++r) dgam[t][r] = dbet[t][r] = 0.f;
           }
-          load_segment<T, LNM, RAG, CSR>(A, chunk, rowbase, g, par + PAR_GAMMA, par + PAR_BETA, act, dgam, dbet);
-          if (lnb_in) ln_park(dgam, dbet, red, wave, li, g);
+          load_segment<T, LNM, RAG, CSR>(A, chunk, rowbase, g, par + PAR_GAMMA, par + PAR_BETA, act, dgam, dbet,
+                                         IOP != 0 ? (LNM == 1 ? (int)GFV_IN_LNBWD : (int)GFV_IN_NONE) : A.in_op, red, wave, li);
+          if (lnb_in && T > 1) ln_park(dgam, dbet, red, wave, li, g);
           if (H) {
             // every segment gets its own row scale; the accumulator follows (exact: powers of two)
             float sn = row_scale(act[0]);
@@ -658,6 +704,7 @@ __global__ __launch_bounds__(64 * NW, GFV_CHAIN_WAVES(H, LNM, RAG)) void tchain_
       const float invx = H ? 1.0f / sx : 1.0f, invw = H ? 1.0f / ws : 1.0f;   // H: undo the operand scales (exact)
       if (!last) {
         // ---- intermediate epilogue: accumulators -> next layer's activations, in registers ----
+        const int lop = IOP != 0 ? IOP : L.op;
 #pragma unroll
         for (int tt = 0; tt < T; ++tt) {
           const int m = rowbase + 16 * tt;
@@ -670,7 +717,7 @@ __global__ __launch_bounds__(64 * NW, GFV_CHAIN_WAVES(H, LNM, RAG)) void tchain_
 #pragma unroll
               for (int r = 0; r < 4; ++r) v[r] = (v[r] * invx) * invw;
             }
-            if (L.op == GFV_OP_MUL_DGELU) {
+            if (lop == GFV_OP_MUL_DGELU) {
               const float4 z = ld4(L.aux + mrow + 16 * nt);
               v[0] *= gfv_dgelu(z.x); v[1] *= gfv_dgelu(z.y); v[2] *= gfv_dgelu(z.z); v[3] *= gfv_dgelu(z.w);
               if (L.save && live) st4(L.save + mrow + 16 * nt, v);
@@ -684,7 +731,7 @@ __global__ __launch_bounds__(64 * NW, GFV_CHAIN_WAVES(H, LNM, RAG)) void tchain_
                 const float4 pa = ld4(pad_s[tt] + 16 * nt), pb = ld4(pad_r[tt] + 16 * nt);
                 v[0] += pa.x + pb.x; v[1] += pa.y + pb.y; v[2] += pa.z + pb.z; v[3] += pa.w + pb.w;
               }
-              if (L.op == GFV_OP_BIAS_GELU) {
+              if (lop == GFV_OP_BIAS_GELU) {
 #ifndef ABL_NOSTORE
                 if (L.save && live) st4(L.save + mrow + 16 * nt, v);
 #endif
@@ -700,7 +747,7 @@ __global__ __launch_bounds__(64 * NW, GFV_CHAIN_WAVES(H, LNM, RAG)) void tchain_
         }
         if (H) {
           sx = row_scale(act[0]);
-          if (A.gscale && L.op == GFV_OP_MUL_DGELU) group_scale_out(A.gscale + (size_t)(layer + 1) * A.gscale_ld + rowgroup, sx, lane);
+          if (A.gscale && lop == GFV_OP_MUL_DGELU) group_scale_out(A.gscale + (size_t)(layer + 1) * A.gscale_ld + rowgroup, sx, lane);
           to_halves(act[0], sx, xh, xl);
         }
         TS_WAIT();
@@ -754,9 +801,11 @@ __global__ __launch_bounds__(64 * NW, GFV_CHAIN_WAVES(H, LNM, RAG)) void tchain_
             for (int nt = 0; nt < 8; ++nt) {
               const float4 yy = ld4(A.fin_aux + mc * 128 + 16 * nt + 4 * g);
               y[nt][0] = yy.x; y[nt][1] = yy.y; y[nt][2] = yy.z; y[nt][3] = yy.w;
-              if (!live) v[nt][0] = v[nt][1] = v[nt][2] = v[nt][3] = 0.f;
+              const float livef = live ? 1.0f : 0.0f;   // (rows past M: see the prologue form)
+              v[nt][0] *= livef; v[nt][1] *= livef; v[nt][2] *= livef; v[nt][3] *= livef;
             }
-            ln_bwd(v, y, par + PAR_GAMMA, g, dgam, dbet);
+            if (tt == 0) ln_bwd<true>(v, y, par + PAR_GAMMA, g, dgam, dbet);
+            else ln_bwd<false>(v, y, par + PAR_GAMMA, g, dgam, dbet);
           }
           if (H && A.gscale && npass == 1 && A.nlayers <= 2 && L.op == GFV_OP_MUL_DGELU && !res) {
             float rs = row_scale(v);             // (all lanes take part in the row / group reductions)
