@@ -502,9 +502,12 @@ extern "C" int gfv_dw_slabs(int32_t M, int32_t ntiles, int32_t* rows_per_slab) {
     const char* e = getenv("GFV_DW_WGS");
     wgs = e ? atoi(e) : 512;
     if (wgs < 1) wgs = 512;
-    e = getenv("GFV_DW_WGS_SMALL");        // launches of < 40 000 rows (node-level MLPs); default: the same target
-    wgs_small = e ? atoi(e) : wgs;
-    if (wgs_small < 1) wgs_small = wgs;
+    // launches of < 40 000 rows (node-level MLPs): half as many, longer slabs - half the partial-sum traffic and one
+    // workgroup per CU beside the dX chain of the next block (A/B on one box, profiles/tools/ab_env.sh, step time with
+    // 128 / 192 / 256 / 320 / 512: 4.61 / 4.38 / 4.37 / 4.42 / 4.46 ms)
+    e = getenv("GFV_DW_WGS_SMALL");
+    wgs_small = e ? atoi(e) : 256;
+    if (wgs_small < 1) wgs_small = 256;
   }
   long target = (M < 40000 ? wgs_small : wgs) / ntiles;
   if (target < 1) target = 1;
