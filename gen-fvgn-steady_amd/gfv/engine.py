@@ -103,7 +103,7 @@ class Engine:
                  order="2nd"):
         self._dw_ws, self._dw_ws_main = None, None
         self._pending = []
-        self._defer_mode = os.environ.get("GFV_DEFER", "0") == "1"
+        self._defer_mode = os.environ.get("GFV_DEFER", "1") == "1"
         self._wt, self._wt_key, self._wt_live = {}, None, False
         self.mp = message_passing_num
         self.mode = _MODE[integrator]
@@ -175,12 +175,13 @@ class Engine:
         return Engine._Fork(self, keep)
 
     def defer(self, fn, *keep):
-        """Parameter-gradient work (nothing downstream of the backward chain reads it): launched on the side stream right
-        away, beside the dX chain that follows.  (Round 2 measured the alternative - queue it and fork once per block, the
-        last block's on the main stream: 6.5 us less bubble per fork, but the weight gradients of a whole block then land
-        on top of the next block's 75 k-row dX chain, 162 us instead of 125-137: 5.00 against 4.90 ms / step.  GFV_DEFER=1
-        selects it.)  Without the side stream the work runs inline - results do not depend on where it runs (disjoint
-        gradient blocks, fixed summation orders)."""
+        """Parameter-gradient work (nothing downstream of the backward chain reads it): queued and launched on the side
+        stream with one fork per block (`flush`), the last block's on the main stream - 6.5 us less bubble per fork.
+        (GFV_DEFER=0 forks at once for every piece instead.  Which of the two wins moved with the kernels: with the
+        round-1 chain kernels the immediate fork was ahead, 4.90 against 5.00 ms / step - a whole block's weight gradients
+        on top of the next block's 75 k-row dX chain; with the round-2 ones the queued form is, 4.29 against 4.33.)
+        Without the side stream the work runs inline - results do not depend on where it runs (disjoint gradient blocks,
+        fixed summation orders)."""
         if not self.overlap:
             fn()
         elif self._defer_mode:
