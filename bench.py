@@ -260,7 +260,8 @@ def main():
         # duration) and reported on the one it sits closer to
         h = "true" if ts.engine.f16split else "false"
         chain_peak = PEAK_F16_MFMA_TFLOPS / 3.0 if ts.engine.f16split else PEAK_F32_MFMA_TFLOPS
-        tc = lambda lnm, rag, csr="false": f"tchain_kernel<1, {lnm}, {rag}, {h}, 4, {csr}>"
+        # (the 7th template argument - element ops fixed at compile time, 0 / 1 / 2 - is folded into the class: `*`)
+        tc = lambda lnm, rag, csr="false": f"tchain_kernel<1, {lnm}, {rag}, {h}, 4, {csr}, *>"
         spec = {7: (tc(0, "false"), chain_peak, "gnn"), 8: (tc(1, "false"), chain_peak, "gnn"),
                 9: (tc(2, "false"), chain_peak, "gnn"), 10: (tc(0, "true"), chain_peak, "gnn"),
                 13: (tc(0, "false", "true"), chain_peak, "gnn"),
