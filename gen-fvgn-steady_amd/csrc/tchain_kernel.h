@@ -400,9 +400,15 @@ __device__ __forceinline__ void load_segment(const gfv_rowtile_args_t& A, int si
       for (int t = 0; t < 8; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) act[tt][t][r] = 0.f;
+      // (the column indices run one iteration ahead of the rows they address: one dependent round trip per iteration, not two)
+      int cn0 = beg < end ? s.idx[beg] : 0, cn1 = beg + 1 < end ? s.idx[beg + 1] : cn0;
       for (int k = beg; k < end; k += 2) {
         const bool two = (k + 1 < end);
-        const int c0 = s.idx[k], c1 = s.idx[two ? k + 1 : k];
+        const int c0 = cn0, c1 = cn1;
+        if (k + 2 < end) {
+          cn0 = s.idx[k + 2];
+          cn1 = s.idx[k + 3 < end ? k + 3 : k + 2];
+        }
         const float* p0 = s.ptr + (size_t)c0 * (size_t)s.ld + 4 * g;
         const float* p1 = s.ptr + (size_t)c1 * (size_t)s.ld + 4 * g;
         // (unconditional loads - a register array filled under a branch is parked in scratch by the compiler; 16-column
