@@ -340,6 +340,23 @@ def main():
         fp32_form = {"value": round(world * args.meshes_per_gpu * nf / el, 3), "ms_per_step": round(1e3 * el / nf, 4),
                      "steps": nf, "note": "eager launches, all products on v_mfma_f32_16x16x4_f32 (GFV_F16SPLIT=0)"}
 
+    # ---- and with ONE fp16 x fp16 product per term (the reduced-precision form, include/gfv.h gfv_set_f16split(2)): the
+    # counterpart of the reference's autocast runs (BASELINE configs 3 / 5), reported beside the headline, never as it ----
+    f16_form = None
+    if ts.engine.f16split and not args.skip_fp32_form:
+        ts_use_graph = ts.use_graph
+        ts.use_graph = False
+        lib.gfv_set_f16split(2)
+        for _ in range(3):
+            ts.step()
+        nf = max(5, min(20, args.steps))
+        el = timed(nf)
+        lib.gfv_set_f16split(1)
+        ts.use_graph = ts_use_graph
+        f16_form = {"value": round(world * args.meshes_per_gpu * nf / el, 3), "ms_per_step": round(1e3 * el / nf, 4),
+                    "steps": nf, "note": "eager launches, single fp16 x fp16 products with fp32 accumulation (GFV_F16SPLIT=2): "
+                                         "agrees with the fp32 forms to ~1e-3, NOT the form `value` is measured on"}
+
     cpu = None
     if rank == 0 and world == 1 and args.cpu_budget > 0:
         # 16 threads is the fastest setting for this launch-bound eager workload on the GPU box's host
@@ -378,6 +395,7 @@ def main():
             "roofline_step": step_roof,
             "roofline_kernels": roof_all,
             "fp32_mfma_form": fp32_form,
+            "f16_products_form": f16_form,
             # reference algorithm vs what the launches execute (EdgeBlock first layer factored through
             # the nodes, gfv/engine.py): the fraction of the fp32 MFMA peak is quoted on the EXECUTED flops
             "algorithmic_step_tflops": round(algorithmic_step_flops(sz) / 1e12, 4),

@@ -40,6 +40,7 @@ struct DwLaunch {
   int rows_per_slab;  // multiple of 32
   long ws_stride;     // floats per slab in the workspace
   float* ws;
+  int lowp;           // split form: 1 = reduced precision (gfv_set_f16split(2)): the hi x hi products only
 };
 
 __device__ __forceinline__ float4 ld4(const float* base, size_t row, int ld, int col, int width, bool vec) {
@@ -423,13 +424,14 @@ __device__ __forceinline__ void dw_body_h(const DwLaunch& A, const gfv_dw_tile_t
     }
 #pragma unroll
     for (int term = 0; term < 3; ++term)
+      if (term == 2 || !A.lowp)   // (uniform)
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (FULL || (64 * wn + 16 * i < npad && 64 * wk + 16 * j < kpad))
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(term == 0 ? gl[i] : gh[i], term == 1 ? al[j] : ah[j],
-                                                               acc[i][j], 0, 0, 0);
+          for (int j = 0; j < 4; ++j)
+            if (FULL || (64 * wn + 16 * i < npad && 64 * wk + 16 * j < kpad))
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(term == 0 ? gl[i] : gh[i], term == 1 ? al[j] : ah[j],
+                                                                 acc[i][j], 0, 0, 0);
 #ifdef GFV_DW_SINGLEBUF
     // experiment (profiles/tools/ab.sh): ONE 32 KB staging buffer - every wave holds its fragments after the reads above,
     // so the buffer may be refilled after a barrier; a second barrier publishes it
@@ -535,6 +537,7 @@ extern "C" int gfv_dw_multi(const gfv_dw_tile_t* tiles, int32_t ntiles, int32_t 
     by += 4.0 * M * ((double)t.n_out + t.width);
   }
   a.ntiles = ntiles;
+  a.lowp = gfv_f16split_enabled() == 2 ? 1 : 0;
   a.M = M;
   int rows = 0;
   const int slabs = gfv_dw_slabs(M, ntiles, &rows);

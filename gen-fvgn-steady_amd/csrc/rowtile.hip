@@ -470,17 +470,18 @@ static int tchain_mode() {
 }
 
 // GFV_F16SPLIT (or gfv_set_f16split): 0 = every GEMM product on the fp32 MFMA, even when a launch carries split-fp16
-// weight images; shared with dw.hip
+// weight images; 1 (default) = split-fp16 products; 2 = the reduced-precision form, ONE fp16 x fp16 product with fp32
+// accumulation (the high parts only); shared with dw.hip
 static int g_f16split = -1;
 extern "C" int gfv_f16split_enabled(void) {
   if (g_f16split < 0) {
     const char* e = getenv("GFV_F16SPLIT");
-    g_f16split = e ? (atoi(e) != 0) : 1;
+    g_f16split = e ? (atoi(e) == 2 ? 2 : (atoi(e) != 0)) : 1;
   }
   return g_f16split;
 }
 extern "C" int gfv_set_f16split(int32_t on) {
-  g_f16split = on ? 1 : 0;
+  g_f16split = on == 2 ? 2 : (on ? 1 : 0);
   return GFV_OK;
 }
 static int f16_mode() { return gfv_f16split_enabled(); }

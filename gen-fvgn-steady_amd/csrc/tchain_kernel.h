@@ -326,22 +326,24 @@ __device__ __forceinline__ void w_store_n(float* Wb, int tid, const WRegs& r) {
 
 // H: one 32-wide k group on the f16 pipe; LDS slice image [nt 8][part 2][lane 64] x 16 B; n-tiles >= 4 are skipped for
 // the 64-wide tail chunk of a 192-wide last layer (nth = number of 4-tile halves with valid rows)
+// lowp (gfv_set_f16split(2)): the hi x hi term only
 __device__ __forceinline__ void mma_slice_h(floatx4 (&acc)[8], const gfv_f16x8& xh, const gfv_f16x8& xl, const float* Wb,
-                                            int lane, int nth) {
+                                            int lane, int nth, bool lowp) {
   const gfv_f16x8* wp = reinterpret_cast<const gfv_f16x8*>(Wb) + lane;
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     if (h < nth) {
       gfv_f16x8 w0[4], w1[4];
 #pragma unroll
-      for (int n = 0; n < 4; ++n) {
-        w0[n] = wp[((4 * h + n) * 2 + 0) * 64];
-        w1[n] = wp[((4 * h + n) * 2 + 1) * 64];
+      for (int n = 0; n < 4; ++n) w0[n] = wp[((4 * h + n) * 2 + 0) * 64];
+      if (!lowp) {   // (uniform branch)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) w1[n] = wp[((4 * h + n) * 2 + 1) * 64];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[4 * h + n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[n], xh, acc[4 * h + n], 0, 0, 0);
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[4 * h + n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0[n], xl, acc[4 * h + n], 0, 0, 0);
       }
-#pragma unroll
-      for (int n = 0; n < 4; ++n) acc[4 * h + n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[n], xh, acc[4 * h + n], 0, 0, 0);
-#pragma unroll
-      for (int n = 0; n < 4; ++n) acc[4 * h + n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0[n], xl, acc[4 * h + n], 0, 0, 0);
 #pragma unroll
       for (int n = 0; n < 4; ++n) acc[4 * h + n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0[n], xh, acc[4 * h + n], 0, 0, 0);
     }
@@ -568,6 +570,7 @@ __global__ __launch_bounds__(64 * NW, GFV_CHAIN_WAVES(H, LNM, RAG)) void tchain_
   gfv_f16x8 xh[4], xl[4];                                    // H: the activations as (hi, lo) B fragments
   float sx = 1.f;                                            // H: this row's current power-of-two scale
   const float ws = H ? gfv_pow2_scale(*A.wmax) : 1.f;        // H: the images' weight scale
+  const bool lowp = H && A.pad3_ != 0;                       // H: reduced-precision form (hi x hi products only)
 
   // gather rows of the factored first-layer addend: index round trip issued first thing, used in the first epilogue
   const float* pad_s[T];
@@ -689,7 +692,7 @@ __global__ __launch_bounds__(64 * NW, GFV_CHAIN_WAVES(H, LNM, RAG)) void tchain_
             __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ABOVE the MFMAs (the scheduler sinks it otherwise)
 #endif
             TS(2);
-            if (H) mma_slice_h(acc[0], xh[sl], xl[sl], lds + wbuf * WS_FLOATS, lane, (cur.nrows + 63) >> 6);
+            if (H) mma_slice_h(acc[0], xh[sl], xl[sl], lds + wbuf * WS_FLOATS, lane, (cur.nrows + 63) >> 6, lowp);
             else mma_slice<T>(acc, act, 2 * sl, lds + wbuf * WS_FLOATS, off0);
             TS(3);
 #ifndef NO_SCHEDB

@@ -135,7 +135,7 @@ typedef struct {
    * gfv_dw_tile_t.gscale takes a slot: the slab scale of the gradient rows then needs no extra pass over them. */
   float* gscale;
   int32_t gscale_ld;
-  int32_t pad3_;
+  int32_t pad3_;          /* reserved: leave 0 (the launcher passes the product form to the kernel here) */
 } gfv_rowtile_args_t;
 
 int gfv_rowtile_tiles(int32_t M); /* number of 64-row tiles = rows of ln_partial */
@@ -159,8 +159,12 @@ typedef struct {
 } gfv_wimg_desc_t;
 size_t gfv_weight_image_bytes(int32_t N, int32_t K);
 /* wmax[0] = max |W| over all described blocks (device scalar, overwritten) */
-/* the process-wide switch between the two product forms (initial value: environment GFV_F16SPLIT, default 1);
- * 0 = fp32 MFMA everywhere (chain launches ignore their images, weight gradients take the fp32 kernel) */
+/* the process-wide switch between the product forms (initial value: environment GFV_F16SPLIT, default 1);
+ * 0 = fp32 MFMA everywhere (chain launches ignore their images, weight gradients take the fp32 kernel);
+ * 1 = split-fp16 products (fp32 accuracy);
+ * 2 = reduced precision: one fp16 x fp16 product per term with fp32 accumulation - the high parts of the same operands
+ *     (11 significand bits: results agree with the fp32 forms to ~1e-3; the counterpart of the reference's autocast runs,
+ *     BASELINE configs 3 / 5 - never the form the parity claims or bench.py's `value` are made on) */
 int gfv_f16split_enabled(void);
 int gfv_set_f16split(int32_t on);
 int gfv_weight_absmax(const gfv_wimg_desc_t* descs_dev, int32_t n_desc, float* wmax, void* stream);
