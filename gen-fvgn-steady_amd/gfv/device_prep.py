@@ -1,43 +1,35 @@
 """Per-mesh preprocessing on the device: the k-hop WLSQ stencil (``build_k_hop_edge_index``,
 parse_to_h5.py:228-254 / Load_mesh.py:421-521) and the WLSQ moment matrices A, B (``calc_WLSQ_A_B_normal_matrix``,
-Load_mesh.py:247-272; FVgrad.py:183-232) on the GPU - the stencil with torch sorts / uniques, the moments with a HIP
-kernel (`gfv_wlsq_moments`) - the two steps that dominate the host-side
-mesh set-up (1.3 s + 3.4 s of ~6 s for the 50 k-cell mesh with the numpy code of gfv.meshgen, which stays the reference
-implementation and the checker: tests/test_pool_gpu.py::test_device_preprocessing_matches_host).  float64 / int64
-throughout, like the host code; deterministic (sorts, scans and segment differences, no atomics)."""
+Load_mesh.py:247-272; FVgrad.py:183-232) on the GPU, both as HIP kernels (`gfv_khop_count` / `gfv_khop_fill`,
+csrc/prep.hip; `gfv_wlsq_moments`, csrc/fvm.hip) - the two steps that dominate the host-side mesh set-up (1.3 s + 3.4 s of
+~6 s for the 50 k-cell mesh with the numpy code of gfv.meshgen, which stays the reference implementation and the checker:
+tests/test_pool_gpu.py::test_device_preprocessing_matches_host).  float64 / int64 throughout, like the host code;
+deterministic (integer atomics only where the order does not reach the result, fixed summation orders)."""
 from __future__ import annotations
 
 import torch
 
 
-def _csr_neighbours(face_node, n_nodes):
-    two = torch.cat((face_node, face_node.flip(0)), dim=1)
-    two = torch.unique(two, dim=1)                          # sorted by row, then column; duplicates dropped
-    counts = torch.bincount(two[0], minlength=n_nodes)
-    rowptr = torch.zeros(n_nodes + 1, dtype=torch.int64, device=face_node.device)
-    rowptr[1:] = torch.cumsum(counts, 0)
-    return rowptr, two[1], two
-
-
 def k_hop_pairs(face_node, n_nodes, k_hop):
     """Unordered node pairs (i < j) within k_hop edges of each other, columns sorted lexicographically
-    (= gfv.meshgen.k_hop_pairs / np.unique(axis=1))."""
-    rowptr, nbr, two = _csr_neighbours(face_node, n_nodes)
-    deg = rowptr[1:] - rowptr[:-1]
-    cur = two
-    out = [two]
-    for _ in range(1, k_hop):
-        # extend every path (i ... j) by the neighbours of j
-        dj = deg[cur[1]]
-        src = torch.repeat_interleave(cur[0], dj)
-        start = torch.repeat_interleave(rowptr[cur[1]], dj)
-        within = torch.arange(src.shape[0], device=src.device) - torch.repeat_interleave(torch.cumsum(dj, 0) - dj, dj)
-        cur = torch.unique(torch.stack((src, nbr[start + within])), dim=1)
-        out.append(cur)
-    e = torch.cat(out, dim=1)
-    e = e[:, e[0] != e[1]]
-    e = torch.stack((torch.minimum(e[0], e[1]), torch.maximum(e[0], e[1])))
-    return torch.unique(e, dim=1)
+    (= gfv.meshgen.k_hop_pairs / np.unique(axis=1)): HIP kernels (`gfv_khop_count` / `gfv_khop_fill`, csrc/prep.hip - CSR
+    adjacency by integer atomics, a thread per node walks its neighbourhood breadth first and sorts its partners), one
+    device-to-host read of the pair count in between."""
+    from . import lib as L
+    if not face_node.is_cuda:
+        raise RuntimeError("gfv.device_prep runs on the GPU (gfv.meshgen has the host form)")
+    lib = L.load()
+    fn = face_node.to(torch.int64).contiguous()
+    F, n = int(fn.shape[1]), int(n_nodes)
+    ws = torch.empty(int(lib.gfv_khop_workspace_ints(n, F)), dtype=torch.int32, device=fn.device)
+    L.check(lib.gfv_khop_count(fn[0].data_ptr(), fn[1].data_ptr(), F, n, int(k_hop), ws.data_ptr(), L.stream_ptr()), "gfv_khop_count")
+    total, flag = (int(v) for v in ws[4 * (n + 1) - 1:4 * (n + 1) + 1].tolist())
+    if flag:
+        raise RuntimeError(f"a {k_hop}-hop neighbourhood of this mesh has more than 512 nodes")
+    out = torch.empty((2, total), dtype=torch.int64, device=fn.device)
+    if total:
+        L.check(lib.gfv_khop_fill(n, int(k_hop), ws.data_ptr(), out[0].data_ptr(), out[1].data_ptr(), L.stream_ptr()), "gfv_khop_fill")
+    return out
 
 
 def taylor_displacement(d, order="2nd"):

@@ -396,6 +396,16 @@ int gfv_train_loss(const float* losses, int32_t B, float w_cont, float w_mom, fl
 /* same, weights read from the device: hyper[5..7] = {w_cont, w_mom, w_press} of the buffer gfv_adam_step_dev takes */
 int gfv_train_loss_dev(const float* losses, int32_t B, const float* hyper, float* loss, float* gloss, void* stream);
 
+/* k-hop reconstruction stencil of a mesh on the device (per-mesh preprocessing; parse_to_h5.py:228-254,
+ * Load_mesh.py:421-521): the unordered node pairs (i < j) with j within k edges of i, as np.unique(axis=1) orders them
+ * (by i, then j).  face0 / face1 [F]: the end nodes of every face (int64, as the mesh files hold them; duplicates allowed).
+ *   gfv_khop_count builds the CSR adjacency and counts; the number of pairs is then ws[4 (N + 1) - 1] (device memory:
+ *   read it back, allocate out0 / out1 [pairs] int64), ws[4 (N + 1)] != 0 says a neighbourhood exceeded 512 nodes (error);
+ *   gfv_khop_fill writes the pairs.  ws: gfv_khop_workspace_ints(N, F) int32, untouched between the two calls. */
+size_t gfv_khop_workspace_ints(int32_t N, int32_t F);
+int gfv_khop_count(const int64_t* face0, const int64_t* face1, int32_t F, int32_t N, int32_t k, int32_t* ws, void* stream);
+int gfv_khop_fill(int32_t N, int32_t k, const int32_t* ws, int64_t* out0, int64_t* out1, void* stream);
+
 /* WLSQ moment matrices of a mesh on the device (per-mesh preprocessing; Load_mesh.py:247-272 ->
  * FVgrad.py:183-232 -> FVorder.py:7-86), float64: for node i and its directed stencil entries k in CSR order
  * (rowptr [N+1], outn [S] = the other node of entry k, entry [S] = the entry's position in the caller's edge order):

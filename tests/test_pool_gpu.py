@@ -96,7 +96,7 @@ def test_pooled_batch_through_the_model_and_payback():
 
 
 def test_device_preprocessing_matches_host():
-    """k-hop stencil and WLSQ moments computed with torch ops on the GPU vs the host (numpy) code of
+    """k-hop stencil and WLSQ moments computed by HIP kernels on the GPU vs the host (numpy) code of
     gfv.meshgen, which is validated against the reference's pipeline: stencil pairs identical, float64 moments to 1e-10
     (prefix-sum differences; the consumers use them in fp32)."""
     import numpy as np
@@ -108,6 +108,14 @@ def test_device_preprocessing_matches_host():
     host_pairs = meshgen.k_hop_pairs(fn, n, 2)
     dev_pairs = device_prep.k_hop_pairs(torch.from_numpy(fn).cuda(), n, 2)
     assert np.array_equal(dev_pairs.cpu().numpy(), host_pairs)
+    # 1 and 3 hops, and a face list with repeated faces (the HIP kernels build their own adjacency: csrc/prep.hip)
+    sx, sy = meshgen.cylinder_grid_for_cells(2500)
+    ms = meshgen.derive_geometry(meshgen.raw_tri_channel_cylinder(nx=sx, ny=sy, quad_fraction=0.3, seed=3))
+    fs, ns = ms["face|face_node"], ms["node|pos"].shape[0]
+    for k in (1, 3):
+        assert np.array_equal(device_prep.k_hop_pairs(torch.from_numpy(fs).cuda(), ns, k).cpu().numpy(), meshgen.k_hop_pairs(fs, ns, k))
+    dup = np.concatenate((fs, fs[:, ::7], fs[::-1, ::5]), axis=1)
+    assert np.array_equal(device_prep.k_hop_pairs(torch.from_numpy(dup).cuda(), ns, 2).cpu().numpy(), meshgen.k_hop_pairs(fs, ns, 2))
     fx = np.concatenate((m["face_node_x_base"], host_pairs), axis=1)
     sup = np.array([[0, 1], [1, 0]], dtype=np.int64)
     for order in ("2nd", "1st", "3rd", "4th"):
