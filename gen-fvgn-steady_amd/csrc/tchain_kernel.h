@@ -351,11 +351,21 @@ __device__ __forceinline__ void mma_slice_h(floatx4 (&acc)[8], const gfv_f16x8& 
 }
 
 // H: power-of-two scale of one row (max over the lane's 32 values and the 4 lanes of the row)
+// (v_max3_f32 with |.| source modifiers, two independent chains: 16 instructions for the 32 values.  `fmaxf(m, fabsf(x))`
+// costs hipcc 2.6 per value - IEEE mode makes it canonicalise every operand with a v_max_f32 x, x first.)
+__device__ __forceinline__ float max3_abs(float m, float a, float b) {
+  float r;
+  asm("v_max3_f32 %0, %1, |%2|, |%3|" : "=v"(r) : "v"(m), "v"(a), "v"(b));
+  return r;
+}
 __device__ __forceinline__ float row_scale(const float (&v)[8][4]) {
-  float m = 0.f;
+  float m0 = 0.f, m1 = 0.f;
 #pragma unroll
-  for (int t = 0; t < 8; ++t) m = fmaxf(fmaxf(m, fmaxf(fabsf(v[t][0]), fabsf(v[t][1]))), fmaxf(fabsf(v[t][2]), fabsf(v[t][3])));
-  return gfv_pow2_scale(row_max4(m));
+  for (int t = 0; t < 8; ++t) {
+    m0 = max3_abs(m0, v[t][0], v[t][1]);
+    m1 = max3_abs(m1, v[t][2], v[t][3]);
+  }
+  return gfv_pow2_scale(row_max4(max3_abs(0.f, m0, m1)));
 }
 // H: the scale of a group of 16 rows (= this wave's rows) is the smallest of its rows' scales; lane 0 leaves it for the
 // weight-gradient kernel (gfv_rowtile_args_t.gscale)
