@@ -3,6 +3,7 @@
 The nn.Linear / nn.LayerNorm objects are parameter containers laid out exactly like the reference's
 (`build_mlp` = Sequential(Sequential(Linear, GELU, Linear, GELU, Linear), LayerNorm)), so checkpoints are
 interchangeable; the arithmetic runs in libgfv's fused row-tile MFMA kernels."""
+from FVMmodel.padding import check_hidden, require_native
 import torch
 import torch.nn as nn
 
@@ -15,8 +16,7 @@ from FVMmodel.Models.FVGN.blocks import EdgeBlock, NodeBlock
 def build_mlp(in_size, hidden_size, out_size, drop_out=True, lay_norm=True, dropout_prob=0.2):
     if drop_out:
         raise NotImplementedError("dropout is never enabled on the reference's hot path (EPD.py:101-104,166,173)")
-    if hidden_size != 128:
-        raise NotImplementedError("the HIP kernels are specialised for hidden_size=128 (utils/get_param.py:69)")
+    check_hidden(hidden_size)   # 128, or a multiple of 16 below it (run zero-padded: FVMmodel/padding.py)
     module = nn.Sequential(nn.Linear(in_size, hidden_size), nn.GELU(), nn.Linear(hidden_size, hidden_size), nn.GELU(),
                            nn.Linear(hidden_size, out_size))
     if lay_norm:
@@ -26,8 +26,9 @@ def build_mlp(in_size, hidden_size, out_size, drop_out=True, lay_norm=True, drop
 
 def build_mlp_from_num_layer(in_size, hidden_size, out_size, drop_out=False, lay_norm=True, dropout_prob=0.2,
                              num_layer=2):
-    if drop_out or num_layer != 2 or hidden_size != 128:
+    if drop_out or num_layer != 2:
         raise NotImplementedError("only the configuration used by Decoder (EPD.py:206-213) is built")
+    check_hidden(hidden_size)
     layers = [nn.Linear(in_size, hidden_size), nn.GELU(), nn.Linear(hidden_size, hidden_size), nn.GELU(),
               nn.Linear(hidden_size, out_size)]
     if lay_norm:
@@ -48,8 +49,10 @@ class Encoder(nn.Module):
         super().__init__()
         self.eb_encoder = build_mlp(edge_input_size, hidden_size, int(hidden_size), drop_out=False)
         self.nb_encoder = build_mlp(node_input_size, hidden_size, int(hidden_size), drop_out=False)
+        self.hidden_size = hidden_size
 
     def forward(self, graph_node, graph_cell=None):
+        require_native(self.hidden_size)
         eng = GF.Engine()
         nn_, nt = _named(self.nb_encoder, "mlp")
         en_, et = _named(self.eb_encoder, "mlp")
@@ -71,6 +74,7 @@ class GnBlock(nn.Module):
                                    custom_func=build_mlp(eb_input_dim, hidden_size, int(hidden_size), drop_out=drop_out))
 
     def forward(self, graph_node):
+        require_native(self.eb_module.net[0][0].out_features)
         names, tensors = _named(self, "blk")
         plan = build_gnn_plan(graph_node)
         x, e = GF.GnBlockFn.apply(GF.Engine(), plan, names, graph_node.x, graph_node.edge_attr, *tensors)
@@ -85,6 +89,7 @@ class Decoder(nn.Module):
                                                            lay_norm=False, num_layer=2)
 
     def forward(self, latent_graph_node=None):
+        require_native(self.node_decode_module[0].out_features)
         names, tensors = _named(self.node_decode_module, "mlp")
         return GF.Mlp3Fn.apply(GF.Engine(), names, False, 128, latent_graph_node.x, *tensors)
 

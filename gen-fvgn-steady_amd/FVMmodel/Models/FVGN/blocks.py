@@ -4,6 +4,7 @@ They are parameter containers with the reference module tree (so state_dict keys
 `forward(graph_node)` runs the segmented-reduce + fused-MLP HIP kernels of libgfv (via GnBlock's adjoint-complete
 path when used inside a GnBlock; standalone they compose the same kernels through gfv.functions)."""
 import torch
+from FVMmodel.padding import require_native
 import torch.nn as nn
 
 from gfv.graph import Data
@@ -82,6 +83,7 @@ class NodeBlock(nn.Module):
         self.net = custom_func
 
     def forward(self, graph_node, graph_cell=None):
+        require_native(self.net[0][0].out_features)
         names, tensors = _mlp_param_list(self.net, "blk.net")
         x = _NodeBlockFn.apply(GF.Engine(), _graph_plan(graph_node), names, graph_node.x, graph_node.edge_attr, *tensors)
         return Data(x=x, edge_attr=graph_node.edge_attr, edge_index=graph_node.edge_index, face=graph_node.face,
@@ -94,6 +96,7 @@ class EdgeBlock(nn.Module):
         self.net = custom_func
 
     def forward(self, graph_node, graph_cell=None):
+        require_native(self.net[0][0].out_features)
         names, tensors = _mlp_param_list(self.net, "blk.net")
         e = _EdgeBlockFn.apply(GF.Engine(), _graph_plan(graph_node), names, graph_node.x, graph_node.edge_attr, *tensors)
         return Data(x=graph_node.x, edge_attr=e, edge_index=graph_node.edge_index, face=graph_node.face,

@@ -1,6 +1,7 @@
 """Transolver block with the reference's parameter tree (FVMmodel/Models/GraphTransolver/GraphTransolver.py:25-169).
 Fixed geometry of the reference's use: 8 heads x 16 dims, 32 slices, mlp_ratio 2 (TransFVGN_v2.py:28-35)."""
 import torch
+from FVMmodel.padding import require_native
 import torch.nn as nn
 
 from gfv import functions as GF
@@ -11,8 +12,9 @@ class Graph_Physics_Attention_1D(nn.Module):
     def __init__(self, dim, heads=8, dim_head=64, dropout=0.0, slice_num=64):
         super().__init__()
         inner_dim = dim_head * heads
-        if (dim, heads, dim_head, slice_num) != (128, 8, 16, 32) or dropout != 0:
-            raise NotImplementedError("HIP slice-attention kernels are specialised for dim 128, 8x16 heads, 32 slices")
+        if heads != 8 or dim_head * heads != dim or slice_num != 32 or dropout != 0 or dim > 128 or dim % 16:
+            raise NotImplementedError("HIP slice-attention kernels: 8 heads, 32 slices, dim a multiple of 16 up to 128 "
+                                      "(below 128 the model runs zero-padded through NNmodel: FVMmodel/padding.py)")
         self.dim_head, self.heads, self.scale = dim_head, heads, dim_head ** -0.5
         self.temperature = nn.Parameter(torch.ones([1, heads, 1, 1]) * 0.5)      # unused by graph_forward (:35)
         self.graph_temperature = nn.Parameter(torch.ones([1, heads, 1]) * 0.5)
@@ -49,6 +51,7 @@ class Transolver_block(nn.Module):
     def forward(self, fx, batch, in_layernorm=False):
         if in_layernorm:
             raise NotImplementedError("in_layernorm=True is never used by TransFVGN (TransFVGN_v2.py:46-49)")
+        require_native(self.ln_2.normalized_shape[0])
         names, tensors = [], []
         for n, p in self.named_parameters():
             names.append(f"tb.{n}")

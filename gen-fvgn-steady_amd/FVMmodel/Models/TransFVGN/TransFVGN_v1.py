@@ -2,6 +2,7 @@
 Transolver block applied to (x + node embedding), Decoder - i.e. one processor of TransFVGN_v2 whose modules hang directly
 off the simulator.  `forward` is one autograd node over the HIP engine (the reference fuses with @torch.compile, :53)."""
 import torch
+from FVMmodel.padding import require_native
 import torch.nn as nn
 
 from gfv import functions as GF
@@ -23,6 +24,7 @@ class Simulator(nn.Module):
         self.decoder = Decoder(hidden_sze=hidden_size, node_output_size=node_output_size)
 
     def forward(self, graph_node=None, graph_edge=None, graph_cell=None):
+        require_native(self.decoder.node_decode_module[0].out_features)
         names, tensors = [], []
         for n, p in self.named_parameters():
             names.append(f"simulator.{n}")

@@ -2,6 +2,7 @@
 (message_passing_num GnBlocks + Transolver block), Decoder.  `forward` is one autograd node over the HIP engine
 (the reference fuses with @torch.compile, :89)."""
 import torch
+from FVMmodel.padding import require_native
 import torch.nn as nn
 
 from gfv import functions as GF
@@ -40,6 +41,7 @@ class Simulator(nn.Module):
         self.decoder = Decoder(hidden_sze=hidden_size, node_output_size=node_output_size)
 
     def forward(self, graph_node=None, graph_edge=None, graph_cell=None):
+        require_native(self.decoder.node_decode_module[0].out_features)
         names, tensors = [], []
         for n, p in self.named_parameters():
             names.append(f"simulator.{n}")

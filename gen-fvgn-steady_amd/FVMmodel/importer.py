@@ -12,6 +12,7 @@ reference (importer.py:243-245 passes a keyword `update_x_attr` does not accept)
 import torch
 import torch.nn as nn
 
+from FVMmodel.padding import check_hidden, pad_parameters
 from gfv import functions as GF
 from gfv.plan import get_plan
 from utils.normalization import Normalizer
@@ -30,9 +31,10 @@ class NNmodel(nn.Module):
             raise ImportError("net='FVGN' does not import in the reference either (GenFVGN.py:6); SURVEY.md row #6")
         else:
             raise NotImplementedError(f"net={params.net}: SURVEY.md row f4 (next)")
-        if params.hidden_size != 128 or params.node_input_size != 12 or params.node_phi_size != 3 \
-                or params.node_output_size != 3:
-            raise NotImplementedError("HIP kernels are specialised for hidden 128, 12 node inputs, 3 outputs")
+        if params.node_input_size != 12 or params.node_phi_size != 3 or params.node_output_size != 3:
+            raise NotImplementedError("HIP kernels are specialised for 12 node inputs, 3 outputs")
+        check_hidden(int(params.hidden_size))   # 128, or a multiple of 16 below it (zero-padded: FVMmodel/padding.py)
+        self.hidden_size = int(params.hidden_size)
         self.simulator = Simulator(
             message_passing_num=params.message_passing_num, node_input_size=params.node_input_size,
             edge_input_size=params.node_input_size + 3, node_output_size=params.node_output_size, drop_out=False,
@@ -64,7 +66,7 @@ class NNmodel(nn.Module):
                                      ncn_smooth=p.ncn_smooth,
                                      net="TransFVGN_v1" if p.net == "TransFVGN_v1" else "TransFVGN_v2",
                                      conserved_form=bool(getattr(p, "conserved_form", True)),
-                                     order=getattr(p, "order", "2nd"))
+                                     order=getattr(p, "order", "2nd"), hidden=self.hidden_size)
         return self._engine
 
     def param_names_tensors(self):
@@ -89,6 +91,7 @@ class NNmodel(nn.Module):
         norm_global = bool(graph_node.norm_global)
         accumulate = norm_global and self.node_norm.should_accumulate()
         names, tensors = self.param_names_tensors()
+        tensors = pad_parameters(names, tensors, self.hidden_size)   # (hidden_size 128: as they are)
         losses, uvp_node, uvp_cell, ea15 = GF.ModelFn.apply(
             self.engine(), plan, names, self.node_norm.buffers_dict(), x,
             dict(norm_global=norm_global, accumulate=accumulate), *tensors)

@@ -41,6 +41,7 @@ struct DwLaunch {
   long ws_stride;     // floats per slab in the workspace
   float* ws;
   int lowp;           // split form: 1 = reduced precision (gfv_set_f16split(2)): the hi x hi products only
+  float ln_inv_n, ln_npad;   // LayerNorm width of a_op = 2 (gfv_set_hidden_size): 1 / h, 128 - h
 };
 
 __device__ __forceinline__ float4 ld4(const float* base, size_t row, int ld, int col, int width, bool vec) {
@@ -130,9 +131,9 @@ __device__ __forceinline__ void dw_body(const DwLaunch& A, const gfv_dw_tile_t& 
         a = make_float4(gfv_gelu(a.x), gfv_gelu(a.y), gfv_gelu(a.z), gfv_gelu(a.w));
       } else if (T.a_op == 2) {
         // row LayerNorm (eps 1e-5); the 32 lanes that share a row are an aligned half wave
-        const float mean = gfv_half_sum((a.x + a.y) + (a.z + a.w)) * (1.0f / 128.0f);
+        const float mean = gfv_half_sum((a.x + a.y) + (a.z + a.w)) * A.ln_inv_n;
         const float dx = a.x - mean, dy = a.y - mean, dz = a.z - mean, dw = a.w - mean;
-        const float var = gfv_half_sum((dx * dx + dy * dy) + (dz * dz + dw * dw)) * (1.0f / 128.0f);
+        const float var = (gfv_half_sum((dx * dx + dy * dy) + (dz * dz + dw * dw)) - A.ln_npad * (mean * mean)) * A.ln_inv_n;
         const float rstd = rsqrtf(var + 1e-5f);
         a = make_float4(dx * rstd * gam.x + bet.x, dy * rstd * gam.y + bet.y, dz * rstd * gam.z + bet.z,
                         dw * rstd * gam.w + bet.w);
@@ -376,9 +377,9 @@ __device__ __forceinline__ void dw_body_h(const DwLaunch& A, const gfv_dw_tile_t
       if (T.a_op == 1) {
         a[p] = make_float4(gfv_gelu(a[p].x), gfv_gelu(a[p].y), gfv_gelu(a[p].z), gfv_gelu(a[p].w));
       } else if (T.a_op == 2) {
-        const float mean = gfv_half_sum((a[p].x + a[p].y) + (a[p].z + a[p].w)) * (1.0f / 128.0f);
+        const float mean = gfv_half_sum((a[p].x + a[p].y) + (a[p].z + a[p].w)) * A.ln_inv_n;
         const float dx = a[p].x - mean, dy = a[p].y - mean, dz = a[p].z - mean, dw = a[p].w - mean;
-        const float var = gfv_half_sum((dx * dx + dy * dy) + (dz * dz + dw * dw)) * (1.0f / 128.0f);
+        const float var = (gfv_half_sum((dx * dx + dy * dy) + (dz * dz + dw * dw)) - A.ln_npad * (mean * mean)) * A.ln_inv_n;
         const float rstd = rsqrtf(var + 1e-5f);
         a[p] = make_float4(dx * rstd * gam.x + bet.x, dy * rstd * gam.y + bet.y, dz * rstd * gam.z + bet.z,
                            dw * rstd * gam.w + bet.w);
@@ -538,6 +539,8 @@ extern "C" int gfv_dw_multi(const gfv_dw_tile_t* tiles, int32_t ntiles, int32_t 
   }
   a.ntiles = ntiles;
   a.lowp = gfv_f16split_enabled() == 2 ? 1 : 0;
+  a.ln_inv_n = 1.0f / (float)gfv_hidden_size();
+  a.ln_npad = (float)(128 - gfv_hidden_size());
   a.M = M;
   int rows = 0;
   const int slabs = gfv_dw_slabs(M, ntiles, &rows);

@@ -132,10 +132,12 @@ __device__ __forceinline__ void mma_slice_generic(floatx4 (&acc)[8], const float
 __device__ __forceinline__ float4 f4_add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 __device__ __forceinline__ float f4_sum(float4 a) { return (a.x + a.y) + (a.z + a.w); }
 
+// (LayerNorm over the h real columns of a zero-padded 128-column row: gfv_set_hidden_size, tchain_kernel.h LnW)
+__device__ float g_ln_inv_n = 1.0f / 128.0f, g_ln_npad = 0.0f;
 __device__ __forceinline__ void row_stats(const float4 v, float& mean, float& rstd) {
-  mean = gfv_half_sum(f4_sum(v)) * (1.0f / 128.0f);
+  mean = gfv_half_sum(f4_sum(v)) * g_ln_inv_n;
   const float dx = v.x - mean, dy = v.y - mean, dz = v.z - mean, dw = v.w - mean;
-  const float var = gfv_half_sum((dx * dx + dy * dy) + (dz * dz + dw * dw)) * (1.0f / 128.0f);
+  const float var = (gfv_half_sum((dx * dx + dy * dy) + (dz * dz + dw * dw)) - g_ln_npad * (mean * mean)) * g_ln_inv_n;
   rstd = rsqrtf(var + 1e-5f);  // nn.LayerNorm eps (EPD.py:32)
 }
 
@@ -154,8 +156,8 @@ __device__ __forceinline__ float4 row_layernorm_bwd(const float4 y, const float4
   row_stats(y, mean, rstd);
   const float4 xh = make_float4((y.x - mean) * rstd, (y.y - mean) * rstd, (y.z - mean) * rstd, (y.w - mean) * rstd);
   const float4 gg = make_float4(go.x * g.x, go.y * g.y, go.z * g.z, go.w * g.w);
-  const float m1 = gfv_half_sum(f4_sum(gg)) * (1.0f / 128.0f);
-  const float m2 = gfv_half_sum((gg.x * xh.x + gg.y * xh.y) + (gg.z * xh.z + gg.w * xh.w)) * (1.0f / 128.0f);
+  const float m1 = gfv_half_sum(f4_sum(gg)) * g_ln_inv_n;
+  const float m2 = gfv_half_sum((gg.x * xh.x + gg.y * xh.y) + (gg.z * xh.z + gg.w * xh.w)) * g_ln_inv_n;
   dgam.x += go.x * xh.x; dgam.y += go.y * xh.y; dgam.z += go.z * xh.z; dgam.w += go.w * xh.w;
   dbet.x += go.x; dbet.y += go.y; dbet.z += go.z; dbet.w += go.w;
   return make_float4(rstd * (gg.x - m1 - xh.x * m2), rstd * (gg.y - m1 - xh.y * m2), rstd * (gg.z - m1 - xh.z * m2),
@@ -485,6 +487,24 @@ extern "C" int gfv_set_f16split(int32_t on) {
   return GFV_OK;
 }
 static int f16_mode() { return gfv_f16split_enabled(); }
+
+// hidden_size of the model the following launches belong to (utils/get_param.py:69; default 128).  A model of h < 128 runs
+// zero-padded to 128 columns (FVMmodel/padding.py): what changes in the kernels is the LayerNorm width (statistics over the h
+// real columns) and the attention scale (dim_head = h / 8).  Host-side state read by the launchers (chain: passed in the
+// kernel arguments; weight gradient: DwLaunch; slice attention: its argument struct; the generic row-tile kernel: two device
+// globals) - set it before the launches of a model, gfv.engine.Engine does on every forward / backward.
+static int g_hidden = 128;
+extern "C" int gfv_hidden_size(void) { return g_hidden; }
+extern "C" int gfv_set_hidden_size(int32_t h) {
+  if (h < 16 || h > 128 || (h & 15)) return GFV_ERR_ARG;
+  if (h != g_hidden) {
+    const float inv = 1.0f / (float)h, npad = (float)(128 - h);
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_ln_inv_n), &inv, sizeof(float)) != hipSuccess) return GFV_ERR_LAUNCH;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_ln_npad), &npad, sizeof(float)) != hipSuccess) return GFV_ERR_LAUNCH;
+  }
+  g_hidden = h;
+  return GFV_OK;
+}
 
 static thread_local int g_last_path = -1;
 extern "C" int gfv_rowtile_last_path(void) { return g_last_path; }

@@ -229,6 +229,7 @@ struct AttnFwdArgs {
   float* norm;               // [B,8,32]
   float* attn;               // [B,8,32,32]
   float* out_token;          // [B,8,32,16]
+  float scale;               // dim_head ** -0.5 (GraphTransolver.py:31,80): 0.25 at hidden 128, (h / 8) ** -0.5 in general
 };
 
 __global__ __launch_bounds__(256) void slice_attention_fwd_kernel(const AttnFwdArgs A) {
@@ -283,7 +284,7 @@ __global__ __launch_bounds__(256) void slice_attention_fwd_kernel(const AttnFwdA
     float s = 0.f;
 #pragma unroll
     for (int c = 0; c < D; ++c) s += sQ[i][c] * sK[j][c];
-    sA[i][j] = s * 0.25f;  // dim_head ** -0.5, GraphTransolver.py:31,80
+    sA[i][j] = s * A.scale;  // dim_head ** -0.5, GraphTransolver.py:31,80
   }
   __syncthreads();
   if (tid < G) {
@@ -315,6 +316,7 @@ struct AttnBwdArgs {
   float* g_raw;            // [B,8,32,16] grad wrt the un-normalised token sums
   float* g_norm;           // [B,8,32]    grad wrt slice_norm
   float* dW_partial;       // [B*8][3][16][16]
+  float scale;             // dim_head ** -0.5
 };
 
 __global__ __launch_bounds__(256) void slice_attention_bwd_kernel(const AttnBwdArgs A) {
@@ -371,7 +373,7 @@ __global__ __launch_bounds__(256) void slice_attention_bwd_kernel(const AttnBwdA
   if (tid < G) {  // softmax backward per row, then the 1/sqrt(D) scale
     float dot = 0.f;
     for (int j = 0; j < G; ++j) dot += sA[tid][j] * sGA[tid][j];
-    for (int j = 0; j < G; ++j) sGA[tid][j] = sA[tid][j] * (sGA[tid][j] - dot) * 0.25f;
+    for (int j = 0; j < G; ++j) sGA[tid][j] = sA[tid][j] * (sGA[tid][j] - dot) * A.scale;
   }
   __syncthreads();
   for (int idx = tid; idx < G * D; idx += 256) {
@@ -573,12 +575,15 @@ extern "C" int gfv_slice_token_partial(const float* w, const float* a, const int
   return GFV_OK;
 }
 
+extern "C" int gfv_hidden_size(void);   // rowtile.hip (gfv_set_hidden_size)
+static float attn_scale() { return 1.0f / sqrtf((float)(gfv_hidden_size() / 8)); }
+
 extern "C" int gfv_slice_attention_fwd(const float* partial, const int32_t* gchunk_ptr, int32_t B, const float* Wq,
                                        const float* Wk, const float* Wv, float* token, float* norm, float* attn,
                                        float* out_token, void* stream) {
   GfvProfScope ps_(GFV_K_SLICE, 0, 60000.0 * B, stream);
   if (B <= 0) return B == 0 ? GFV_OK : GFV_ERR_ARG;
-  AttnFwdArgs a{partial, gchunk_ptr, Wq, Wk, Wv, token, norm, attn, out_token};
+  AttnFwdArgs a{partial, gchunk_ptr, Wq, Wk, Wv, token, norm, attn, out_token, attn_scale()};
   hipLaunchKernelGGL(slice_attention_fwd_kernel, dim3(B, H), dim3(256), 0, (hipStream_t)stream, a);
   GFV_CHECK_LAUNCH();
   return GFV_OK;
@@ -589,7 +594,7 @@ extern "C" int gfv_slice_attention_bwd(const float* gpartial, const int32_t* gch
                                        const float* attn, float* g_raw, float* g_norm, float* dW_partial, void* stream) {
   GfvProfScope ps_(GFV_K_SLICE, 0, 100000.0 * B, stream);
   if (B <= 0) return B == 0 ? GFV_OK : GFV_ERR_ARG;
-  AttnBwdArgs a{gpartial, gchunk_ptr, Wq, Wk, Wv, token, norm, attn, g_raw, g_norm, dW_partial};
+  AttnBwdArgs a{gpartial, gchunk_ptr, Wq, Wk, Wv, token, norm, attn, g_raw, g_norm, dW_partial, attn_scale()};
   hipLaunchKernelGGL(slice_attention_bwd_kernel, dim3(B, H), dim3(256), 0, (hipStream_t)stream, a);
   GFV_CHECK_LAUNCH();
   return GFV_OK;

@@ -148,24 +148,35 @@ __device__ __forceinline__ void st4(float* p, const float (&v)[4]) {
 }
 
 // LayerNorm statistics of one row spread over 4 lanes x 8 x 4 registers
-__device__ __forceinline__ void ln_stats(const float (&v)[8][4], float& mean, float& rstd) {
+// LnW: the LayerNorm width.  A model of hidden_size h < 128 runs zero-padded to 128 columns (gfv_set_hidden_size): the
+// statistics are those of the h real columns - the padded zeros add nothing to the sum, and (0 - mean)^2 each to the sum of
+// squared deviations, which is taken out again (npad = 128 - h).  h = 128: inv_n = 1/128, npad = 0 - the same arithmetic as
+// before (q - 0 * mean * mean).
+struct LnW {
+  float inv_n, npad;
+};
+__device__ __forceinline__ LnW ln_width(int cols) {
+  const int n = (cols > 0 && cols < 128) ? cols : 128;
+  return LnW{1.0f / (float)n, (float)(128 - n)};
+}
+__device__ __forceinline__ void ln_stats(const float (&v)[8][4], float& mean, float& rstd, const LnW w) {
   float s = 0.f;
 #pragma unroll
   for (int t = 0; t < 8; ++t) s += (v[t][0] + v[t][1]) + (v[t][2] + v[t][3]);
-  mean = row_sum(s) * (1.0f / 128.0f);
+  mean = row_sum(s) * w.inv_n;
   float q = 0.f;
 #pragma unroll
   for (int t = 0; t < 8; ++t) {
     const float d0 = v[t][0] - mean, d1 = v[t][1] - mean, d2 = v[t][2] - mean, d3 = v[t][3] - mean;
     q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
   }
-  rstd = rsqrtf(row_sum(q) * (1.0f / 128.0f) + 1e-5f);  // nn.LayerNorm eps (EPD.py:32)
+  rstd = rsqrtf((row_sum(q) - w.npad * (mean * mean)) * w.inv_n + 1e-5f);  // nn.LayerNorm eps (EPD.py:32)
 }
 
 // v <- LayerNorm(v) * gamma + beta (gamma / beta at columns 16t + 4g + r)
-__device__ __forceinline__ void ln_apply(float (&v)[8][4], const float* gamma, const float* beta, int g) {
+__device__ __forceinline__ void ln_apply(float (&v)[8][4], const float* gamma, const float* beta, int g, const LnW w) {
   float mean, rstd;
-  ln_stats(v, mean, rstd);
+  ln_stats(v, mean, rstd, w);
 #pragma unroll
   for (int t = 0; t < 8; ++t) {
     const float4 ga = ld4(gamma + 16 * t + 4 * g), be = ld4(beta + 16 * t + 4 * g);
@@ -180,9 +191,9 @@ __device__ __forceinline__ void ln_apply(float (&v)[8][4], const float* gamma, c
 // grad wrt the LN input); accumulates this lane's 32 columns of dgamma / dbeta.
 template <bool FIRST>   // FIRST: (dgam, dbet) are assigned, not added to (no zero-initialised accumulators for the first tile)
 __device__ __forceinline__ void ln_bwd(float (&v)[8][4], const float (&y)[8][4], const float* gamma, int g,
-                                       float (&dgam)[8][4], float (&dbet)[8][4]) {
+                                       float (&dgam)[8][4], float (&dbet)[8][4], const LnW w) {
   float mean, rstd;
-  ln_stats(y, mean, rstd);
+  ln_stats(y, mean, rstd, w);
   float s1 = 0.f, s2 = 0.f;
 #pragma unroll
   for (int t = 0; t < 8; ++t) {
@@ -203,7 +214,7 @@ __device__ __forceinline__ void ln_bwd(float (&v)[8][4], const float (&y)[8][4],
       s2 += v[t][r] * xh;
     }
   }
-  const float m1 = row_sum(s1) * (1.0f / 128.0f), m2 = row_sum(s2) * (1.0f / 128.0f);
+  const float m1 = row_sum(s1) * w.inv_n, m2 = row_sum(s2) * w.inv_n;
 #pragma unroll
   for (int t = 0; t < 8; ++t)
 #pragma unroll
@@ -243,9 +254,9 @@ __device__ __forceinline__ void ln_park(float (&dgam)[8][4], float (&dbet)[8][4]
 // ln_bwd and handing them to ln_park afterwards keeps 64 more registers alive in the most register-hungry phase of the
 // LayerNorm-backward instantiation.
 __device__ __forceinline__ void ln_bwd_park(float (&v)[8][4], const float (&y)[8][4], const float* gamma, int g, float* red,
-                                            int wave, int li) {
+                                            int wave, int li, const LnW w) {
   float mean, rstd;
-  ln_stats(y, mean, rstd);
+  ln_stats(y, mean, rstd, w);
   float s1 = 0.f, s2 = 0.f;
 #pragma unroll
   for (int t = 0; t < 8; ++t) {
@@ -266,7 +277,7 @@ __device__ __forceinline__ void ln_bwd_park(float (&v)[8][4], const float (&y)[8
       st4(red + (wave * 2 + 1) * 128 + 16 * t + 4 * g, db);
     }
   }
-  const float m1 = row_sum(s1) * (1.0f / 128.0f), m2 = row_sum(s2) * (1.0f / 128.0f);
+  const float m1 = row_sum(s1) * w.inv_n, m2 = row_sum(s2) * w.inv_n;
 #pragma unroll
   for (int t = 0; t < 8; ++t)
 #pragma unroll
@@ -390,7 +401,7 @@ __device__ __forceinline__ void to_halves(const float (&v)[8][4], float sc, gfv_
 template <int T, int LNM, bool RAG, bool CSR>
 __device__ __forceinline__ void load_segment(const gfv_rowtile_args_t& A, int si, int rowbase, int g, const float* gam,
                                              const float* bet, float (&act)[T][8][4], float (&dgam)[8][4],
-                                             float (&dbet)[8][4], int in_op, float* red, int wave, int li) {
+                                             float (&dbet)[8][4], int in_op, float* red, int wave, int li, const LnW lnw) {
   const gfv_seg_t& s = A.seg[si];
   const int nt_valid = s.width >> 4;
   const bool first = (si == 0);
@@ -496,7 +507,7 @@ __device__ __forceinline__ void load_segment(const gfv_rowtile_args_t& A, int si
 #pragma unroll
         for (int r = 0; r < 4; ++r) act[tt][t][r] = gfv_gelu(act[tt][t][r]);
     } else if (in_op == GFV_IN_LN) {
-      ln_apply(act[tt], gam, bet, g);
+      ln_apply(act[tt], gam, bet, g, lnw);
     } else if (LNM == 1 && in_op == GFV_IN_LNBWD) {
       float y[8][4];
       const float* yp = A.in_aux + (size_t)mc * 128 + 4 * g;
@@ -515,9 +526,9 @@ __device__ __forceinline__ void load_segment(const gfv_rowtile_args_t& A, int si
       for (int t = 0; t < 8; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) act[tt][t][r] *= livef;
-      if (T == 1) ln_bwd_park(act[tt], y, gam, g, red, wave, li);   // (the fold lands in LDS right here)
-      else if (tt == 0) ln_bwd<true>(act[tt], y, gam, g, dgam, dbet);
-      else ln_bwd<false>(act[tt], y, gam, g, dgam, dbet);
+      if (T == 1) ln_bwd_park(act[tt], y, gam, g, red, wave, li, lnw);   // (the fold lands in LDS right here)
+      else if (tt == 0) ln_bwd<true>(act[tt], y, gam, g, dgam, dbet, lnw);
+      else ln_bwd<false>(act[tt], y, gam, g, dgam, dbet, lnw);
     }
     // (rows past M keep the values of row M - 1 from here on: nothing of theirs is stored, and no other sum runs over rows)
     if (first && A.in_save && live) {
@@ -580,7 +591,8 @@ __global__ __launch_bounds__(64 * NW, GFV_CHAIN_WAVES(H, LNM, RAG)) void tchain_
   gfv_f16x8 xh[4], xl[4];                                    // H: the activations as (hi, lo) B fragments
   float sx = 1.f;                                            // H: this row's current power-of-two scale
   const float ws = H ? gfv_pow2_scale(*A.wmax) : 1.f;        // H: the images' weight scale
-  const bool lowp = H && A.pad3_ != 0;                       // H: reduced-precision form (hi x hi products only)
+  const bool lowp = H && A.pad3_ != 0;
+  const LnW lnw = ln_width(A.pad_);                          // LayerNorm width (0 / 128: every column)                       // H: reduced-precision form (hi x hi products only)
 
   // gather rows of the factored first-layer addend: index round trip issued first thing, used in the first epilogue
   const float* pad_s[T];
@@ -660,7 +672,7 @@ __global__ __launch_bounds__(64 * NW, GFV_CHAIN_WAVES(H, LNM, RAG)) void tchain_
               for (int r = 0; r < 4; ++r) dgam[t][r] = dbet[t][r] = 0.f;
           }
           load_segment<T, LNM, RAG, CSR>(A, chunk, rowbase, g, par + PAR_GAMMA, par + PAR_BETA, act, dgam, dbet,
-                                         IOP != 0 ? (LNM == 1 ? (int)GFV_IN_LNBWD : (int)GFV_IN_NONE) : A.in_op, red, wave, li);
+                                         IOP != 0 ? (LNM == 1 ? (int)GFV_IN_LNBWD : (int)GFV_IN_NONE) : A.in_op, red, wave, li, lnw);
           if (lnb_in && T > 1) ln_park(dgam, dbet, red, wave, li, g);
           if (H) {
             // every segment gets its own row scale; the accumulator follows (exact: powers of two)
@@ -813,7 +825,7 @@ __global__ __launch_bounds__(64 * NW, GFV_CHAIN_WAVES(H, LNM, RAG)) void tchain_
               for (int nt = 0; nt < 8; ++nt) st4(A.fin_presave + mc * 128 + 16 * nt + 4 * g, v[nt]);
             }
 #endif
-            ln_apply(v, par + PAR_GAMMA, par + PAR_BETA, g);
+            ln_apply(v, par + PAR_GAMMA, par + PAR_BETA, g, lnw);
           } else if (lnb_fin) {
             float y[8][4];
 #pragma unroll
@@ -823,8 +835,8 @@ __global__ __launch_bounds__(64 * NW, GFV_CHAIN_WAVES(H, LNM, RAG)) void tchain_
               const float livef = live ? 1.0f : 0.0f;   // (rows past M: see the prologue form)
               v[nt][0] *= livef; v[nt][1] *= livef; v[nt][2] *= livef; v[nt][3] *= livef;
             }
-            if (tt == 0) ln_bwd<true>(v, y, par + PAR_GAMMA, g, dgam, dbet);
-            else ln_bwd<false>(v, y, par + PAR_GAMMA, g, dgam, dbet);
+            if (tt == 0) ln_bwd<true>(v, y, par + PAR_GAMMA, g, dgam, dbet, lnw);
+            else ln_bwd<false>(v, y, par + PAR_GAMMA, g, dgam, dbet, lnw);
           }
           if (H && A.gscale && npass == 1 && A.nlayers <= 2 && L.op == GFV_OP_MUL_DGELU && !res) {
             float rs = row_scale(v);             // (all lanes take part in the row / group reductions)

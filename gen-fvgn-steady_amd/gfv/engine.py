@@ -9,6 +9,7 @@ Parameters are addressed by the reference's state_dict names.
 """
 from __future__ import annotations
 
+import contextlib
 import os
 
 import torch
@@ -100,7 +101,10 @@ class GradStore:
 
 class Engine:
     def __init__(self, message_passing_num=3, integrator="imex", ncn_smooth=True, net="TransFVGN_v2", conserved_form=True,
-                 order="2nd"):
+                 order="2nd", hidden=128):
+        # hidden_size of the model (utils/get_param.py:69): below 128 the parameters arrive zero-padded to the kernels' 128
+        # columns (FVMmodel/padding.py) and the launches need the true width (LayerNorm statistics, attention scale)
+        self.hidden = int(hidden)
         self._dw_ws, self._dw_ws_main = None, None
         self._pending = []
         self._defer_mode = os.environ.get("GFV_DEFER", "1") == "1"
@@ -173,6 +177,20 @@ class Engine:
 
     def fork(self, *keep):
         return Engine._Fork(self, keep)
+
+    @contextlib.contextmanager
+    def model_width(self):
+        """The library's process-wide hidden size (include/gfv.h gfv_set_hidden_size) is this model's while its launches are
+        issued, and back at 128 - what every stand-alone operator assumes - afterwards."""
+        lib = L.load()
+        if self.hidden == 128 and lib.gfv_hidden_size() == 128:
+            yield
+            return
+        L.check(lib.gfv_set_hidden_size(self.hidden), "gfv_set_hidden_size")
+        try:
+            yield
+        finally:
+            L.check(lib.gfv_set_hidden_size(128), "gfv_set_hidden_size")
 
     def defer(self, fn, *keep):
         """Parameter-gradient work (nothing downstream of the backward chain reads it): queued and launched on the side

@@ -139,8 +139,9 @@ class ModelFn(torch.autograd.Function):
     def forward(ctx, engine, plan, names, buffers, x, flags, *params):
         require_gpu(x)
         P = dict(zip(names, (p.detach() for p in params)))
-        losses, uvp_node, uvp_cell, ea15, sv = engine.forward(
-            P, buffers, x, plan, norm_global=flags["norm_global"], accumulate=flags["accumulate"])
+        with engine.model_width():
+            losses, uvp_node, uvp_cell, ea15, sv = engine.forward(
+                P, buffers, x, plan, norm_global=flags["norm_global"], accumulate=flags["accumulate"])
         ctx.engine, ctx.plan, ctx.names, ctx.sv, ctx.P = engine, plan, names, sv, P
         ctx.mark_non_differentiable(uvp_node, uvp_cell, ea15)
         return losses, uvp_node, uvp_cell, ea15
@@ -150,7 +151,8 @@ class ModelFn(torch.autograd.Function):
         P = ctx.P
         skip = unused_param_names(ctx.names)
         grads = _alloc_grads(ctx.names, [P[n] for n in ctx.names], skip)
-        ctx.engine.backward(P, ctx.sv, g_losses.contiguous(), grads, ctx.plan)
+        with ctx.engine.model_width():
+            ctx.engine.backward(P, ctx.sv, g_losses.contiguous(), grads, ctx.plan)
         return (None, None, None, None, None, None) + tuple(grads.view(n) for n in ctx.names)
 
 

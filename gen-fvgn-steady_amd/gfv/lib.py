@@ -102,6 +102,8 @@ _SIGNATURES = {
     "gfv_concat_offsets": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "gfv_f16split_enabled": (C.c_int, []),
     "gfv_set_f16split": (C.c_int, [C.c_int32]),
+    "gfv_hidden_size": (C.c_int, []),
+    "gfv_set_hidden_size": (C.c_int, [C.c_int32]),
     "gfv_weight_image_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
     "gfv_weight_absmax": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "gfv_weight_images": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p]),

@@ -21,6 +21,9 @@ from .plan import get_plan
 class TrainStep:
     def __init__(self, model, graphs, *, lr=None, betas=(0.9, 0.999), eps=1e-8, loss_weights=None, world_size=1,
                  process_group=None, use_graph=False, want_outputs=True, distributed=None):
+        if getattr(model, "hidden_size", 128) != 128:
+            raise NotImplementedError("TrainStep (flat parameter buffers, fused Adam) runs hidden_size 128; a narrower model "
+                                      "trains through NNmodel.forward + a torch optimizer (FVMmodel/padding.py)")
         self.model = model
         self.graphs = graphs
         self.plan = get_plan(graphs)

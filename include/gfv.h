@@ -167,6 +167,13 @@ size_t gfv_weight_image_bytes(int32_t N, int32_t K);
  *     BASELINE configs 3 / 5 - never the form the parity claims or bench.py's `value` are made on) */
 int gfv_f16split_enabled(void);
 int gfv_set_f16split(int32_t on);
+/* hidden_size of the model the following launches belong to (the reference's --hidden_size, utils/get_param.py:69; default
+ * 128; multiples of 16 in [16, 128]).  Every kernel works on 128-column latent rows; a narrower model runs zero-padded to
+ * 128 columns (the host side pads its parameters: FVMmodel/padding.py) and differs in two places only - LayerNorm takes its
+ * statistics over the h real columns, and the slice attention scales by (h / 8) ** -0.5.  Process-wide host state read by
+ * the launchers: set it before the launches of a model (gfv.engine.Engine does, on every forward and backward). */
+int gfv_hidden_size(void);
+int gfv_set_hidden_size(int32_t h);
 int gfv_weight_absmax(const gfv_wimg_desc_t* descs_dev, int32_t n_desc, float* wmax, void* stream);
 /* build every image; max_frags = max over descs of gfv_weight_image_bytes / 32 */
 int gfv_weight_images(const gfv_wimg_desc_t* descs_dev, int32_t n_desc, int64_t max_frags, const float* wmax,
