@@ -86,7 +86,7 @@ def test_forward_backward_matches_oracle(name, golden_dir):
 
 
 @pytest.mark.parametrize("hidden", [32, 64, 112])
-def test_hidden_size_below_128_matches_oracle(hidden):
+def test_hidden_size_below_128_matches_oracle(hidden, golden_dir):
     """VERDICT r1 missing 7 (`--hidden_size`, utils/get_param.py:69): a model of hidden size h < 128 keeps parameters of its
     true shapes and runs zero-padded to the kernels' 128 columns (FVMmodel/padding.py; LayerNorm over the h real columns,
     attention scale (h / 8) ** -0.5: gfv_set_hidden_size).  Forward tensors, losses and every parameter gradient against the
@@ -109,6 +109,10 @@ def test_hidden_size_below_128_matches_oracle(hidden):
     out = model(*hg)
     for i, key in enumerate(("loss_cont", "loss_mom_x", "loss_mom_y", "loss_press", "uvp_node", "uvp_cell")):
         assert rel(out[i], oout[i]) < TOL, (key, rel(out[i], oout[i]))
+    if hidden == 64:   # the reference's own outputs at this width (tests/golden/make_golden_hidden.py)
+        fx = np.load(os.path.join(golden_dir, "hidden64_cyl_cavity_b2.npz"))
+        for i, key in enumerate(("loss_cont", "loss_mom_x", "loss_mom_y", "loss_press", "uvp_node", "uvp_cell")):
+            assert rel(out[i], torch.from_numpy(fx[key])) < TOL, key
     hp = O.DEFAULT_HYPER
     loss = torch.mean(torch.log(hp["loss_press"] * out[3] + hp["loss_cont"] * out[0] + hp["loss_mom"] * out[1]
                                 + hp["loss_mom"] * out[2]))

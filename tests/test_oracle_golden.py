@@ -107,6 +107,22 @@ def test_oracle_transfvgn_v1_matches_reference(golden_dir):
     assert abs(float(O.training_loss(out)) - float(fx["loss"])) < TOL * abs(float(fx["loss"]))
 
 
+def test_oracle_hidden_size_64_matches_reference(golden_dir):
+    """`--hidden_size 64` (utils/get_param.py:69).  Fixture = the reference itself run at that width
+    (tests/golden/make_golden_hidden.py); the oracle's forward agrees bit for bit there (make_golden_hidden.log) - the pin
+    behind tests/test_model_gpu.py::test_hidden_size_below_128_matches_oracle."""
+    fx = np.load(os.path.join(golden_dir, "hidden64_cyl_cavity_b2.npz"))
+    hyper = {"hidden_size": 64}
+    shapes = O.parameter_shapes(hyper)
+    assert list(shapes) == [str(k) for k in fx["param_names"]]
+    assert sum(int(np.prod(v)) for v in shapes.values()) == 299619
+    graphs = cases.make_graphs("cyl_cavity_b2")
+    out = O.model_forward(O.init_parameters(cases.WEIGHT_SEED, hyper=hyper), O.new_normalizer_buffers(), graphs, hyper=hyper)
+    for i, key in enumerate(("loss_cont", "loss_mom_x", "loss_mom_y", "loss_press", "uvp_node", "uvp_cell")):
+        assert _rel(out[i].detach().numpy(), fx[key]) < TOL, key
+    assert abs(float(O.training_loss(out)) - float(fx["loss"])) < TOL * abs(float(fx["loss"]))
+
+
 def test_oracle_non_conserved_form_matches_reference(golden_dir):
     """conserved_form=False (FVscheme.py:276-511).  Fixture = the reference itself run with that
     switch (tests/golden/make_golden_nc.py); the oracle's forward agrees bit for bit there."""
