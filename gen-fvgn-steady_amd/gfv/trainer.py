@@ -18,12 +18,13 @@ from .functions import unused_param_names
 from .plan import get_plan
 
 
+def _gather(src, index, out):
+    torch.index_select(src, 0, index, out=out)
+
+
 class TrainStep:
     def __init__(self, model, graphs, *, lr=None, betas=(0.9, 0.999), eps=1e-8, loss_weights=None, world_size=1,
                  process_group=None, use_graph=False, want_outputs=True, distributed=None):
-        if getattr(model, "hidden_size", 128) != 128:
-            raise NotImplementedError("TrainStep (flat parameter buffers, fused Adam) runs hidden_size 128; a narrower model "
-                                      "trains through NNmodel.forward + a torch optimizer (FVMmodel/padding.py)")
         self.model = model
         self.graphs = graphs
         self.plan = get_plan(graphs)
@@ -52,7 +53,7 @@ class TrainStep:
         self.G = GradStore(names, [t.shape for t in tensors], dev, skip=skip)
         self.flat_g = self.G.flat
         total = self.G.total
-        self.flat_p = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat_p = torch.zeros(total + 4, dtype=torch.float32, device=dev)[:total + 1]   # (+ one zero the padding maps read)
         self.flat_m = torch.zeros(total, dtype=torch.float32, device=dev)
         self.flat_v = torch.zeros(total, dtype=torch.float32, device=dev)
         # Adam step counter + derived bias corrections, and the hyper-parameters: device resident (include/gfv.h,
@@ -68,6 +69,7 @@ class TrainStep:
             t.data = view
             self.P[n] = view
         assert all(v.data_ptr() % 16 == 0 for v in self.P.values())
+        self._setup_padding(names, tensors, skip)
         self._probes = [(names[i], tensors[i]) for i in sorted({0, len(names) // 2, len(names) - 1})]
         self.n_params = total
         self.x = graphs[0].x
@@ -79,6 +81,35 @@ class TrainStep:
         self.uvp_node = None
         self._graphs = {}
         self._list_warm = {}
+
+    # hidden_size below 128 (FVMmodel/padding.py): parameters, moments and gradients of the TRUE shapes stay the state
+    # (flat_p / flat_m / flat_v / flat_g, what Adam and the checkpoints see); every step gathers the parameters into the
+    # kernels' 128-column shapes with one index_select, runs forward / backward on those, and gathers the gradients back
+    # with another.  The two index maps come from padding the flat offsets themselves.
+    def _setup_padding(self, names, tensors, skip):
+        from FVMmodel.padding import pad_parameters
+        h = int(getattr(self.model, "hidden_size", 128))
+        self.padded = h != 128
+        if not self.padded:
+            self.P_run, self.G_run = self.P, self.G
+            return
+        dev, total = self.dev, self.G.total
+        offs = [torch.arange(t.numel(), device=dev, dtype=torch.int64).view(t.shape) + (self.G.off[n] + 1)
+                for n, t in zip(names, tensors)]                       # flat offset + 1 of every true element (0 = padding)
+        padded = pad_parameters(names, offs, h)
+        self.G_run = GradStore(names, [t.shape for t in padded], dev, skip=skip)
+        fwd = torch.full((self.G_run.total,), total, dtype=torch.int64, device=dev)   # -> the zero behind flat_p
+        back = torch.zeros(total, dtype=torch.int64, device=dev)
+        for n, t in zip(names, padded):
+            o = self.G_run.off[n]
+            flat = t.reshape(-1)
+            real = flat > 0
+            fwd[o:o + flat.numel()] = torch.where(real, flat - 1, torch.full_like(flat, total))
+            back[(flat[real] - 1)] = o + torch.nonzero(real).reshape(-1)
+        self._pad_map, self._unpad_map = fwd, back
+        self.flat_pp = torch.zeros(self.G_run.total, dtype=torch.float32, device=dev)
+        self.P_run = {n: self.flat_pp[self.G_run.off[n]:self.G_run.off[n] + self.G_run.numel(n)].view(self.G_run.shape[n])
+                      for n in names}
 
     # hyper-parameters: plain attributes on the host, mirrored into `self.hyper` on change --------------------------
     def _sync_hyper(self):
@@ -214,12 +245,17 @@ class TrainStep:
         lib = L.load()
         st = L.stream_ptr()
         cmdlist.call(self.x.copy_, self.x_backup)  # solve_with_grad_GPU.py:143 (fresh, un-normalised node state every step)
-        losses, uvp_node, uvp_cell, _, ctx = self.engine.forward(
-            self.P, self.model.node_norm.buffers_dict(), self.x, self.plan, norm_global=True, accumulate=accumulate,
-            want_outputs=self.want_outputs, want_edge_attr15=False)
-        L.check(lib.gfv_train_loss_dev(losses.data_ptr(), self.plan.B, self.hyper.data_ptr(), self.loss.data_ptr(),
-                                       self.gloss.data_ptr(), st), "train_loss")
-        self.engine.backward(self.P, ctx, self.gloss, self.G, self.plan)
+        if self.padded:
+            cmdlist.call(_gather, self.flat_p, self._pad_map, self.flat_pp)
+        with self.engine.model_width():
+            losses, uvp_node, uvp_cell, _, ctx = self.engine.forward(
+                self.P_run, self.model.node_norm.buffers_dict(), self.x, self.plan, norm_global=True, accumulate=accumulate,
+                want_outputs=self.want_outputs, want_edge_attr15=False)
+            L.check(lib.gfv_train_loss_dev(losses.data_ptr(), self.plan.B, self.hyper.data_ptr(), self.loss.data_ptr(),
+                                           self.gloss.data_ptr(), st), "train_loss")
+            self.engine.backward(self.P_run, ctx, self.gloss, self.G_run, self.plan)
+        if self.padded:
+            cmdlist.call(_gather, self.G_run.flat, self._unpad_map, self.flat_g)
         self.losses, self.uvp_node, self.uvp_cell = losses, uvp_node, uvp_cell
         if with_adam:
             self._adam()
@@ -265,7 +301,8 @@ class TrainStep:
             dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM, group=self.pg)
 
     def _eager(self, acc, dist_on):
-        self.engine.bucket_hook = self._bucket_ready if dist_on else None
+        # (a padded model's true-shape gradient exists only after the gather at the end of the backward: one all-reduce)
+        self.engine.bucket_hook = self._bucket_ready if (dist_on and not self.padded) else None
         try:
             self._body(acc, with_adam=not dist_on)
         finally:

@@ -127,9 +127,24 @@ def test_hidden_size_below_128_matches_oracle(hidden, golden_dir):
         err = float((p.grad.cpu().double() - ograds[k].double()).abs().max())
         bound = 1e-4 * float(ograds[k].abs().max()) + 1e-6 * gscale
         assert err < bound, (k, err, bound)
+    # the fused TrainStep on the same narrow model: true-shape Adam state, one gather into the 128-column shapes per step
+    # and one back - its first step must move the parameters exactly as torch.optim.Adam moves them on these gradients
     from gfv.trainer import TrainStep
-    with pytest.raises(NotImplementedError):
-        TrainStep(model, hg)
+    model2 = _hip_model(P, hidden_size=hidden)
+    opt = torch.optim.Adam(model.parameters(), lr=5e-5)
+    opt.step()
+    hg2 = tuple(g.clone().to("cuda") for g in graphs)
+    ts = TrainStep(model2, hg2, lr=5e-5, use_graph="list" if hidden == 64 else False)
+    ts.step()
+    torch.cuda.synchronize()
+    assert abs(float(ts.loss) - float(oloss)) < TOL * abs(float(oloss))
+    for (k, p), (k2, p2) in zip(model.named_parameters(), model2.named_parameters()):
+        assert k == k2 and p2.shape == p.shape
+        step = 5e-5   # |Adam's first step| = lr for every entry with a gradient
+        assert float((p2 - p).abs().max()) <= 0.02 * step + 1e-9, (k, float((p2 - p).abs().max()))
+    for _ in range(3):   # (and the replayed steps run)
+        ts.step()
+    assert L.load().gfv_hidden_size() == 128
 
 
 def test_adam_training_steps_track_oracle():
