@@ -85,15 +85,15 @@ def test_forward_backward_matches_oracle(name, golden_dir):
         model(*hg)
 
 
-@pytest.mark.parametrize("hidden", [32, 64, 112])
-def test_hidden_size_below_128_matches_oracle(hidden, golden_dir):
+@pytest.mark.parametrize("hidden,net", [(32, "TransFVGN_v2"), (64, "TransFVGN_v2"), (112, "TransFVGN_v2"), (64, "TransFVGN_v1")])
+def test_hidden_size_below_128_matches_oracle(hidden, net, golden_dir):
     """VERDICT r1 missing 7 (`--hidden_size`, utils/get_param.py:69): a model of hidden size h < 128 keeps parameters of its
     true shapes and runs zero-padded to the kernels' 128 columns (FVMmodel/padding.py; LayerNorm over the h real columns,
     attention scale (h / 8) ** -0.5: gfv_set_hidden_size).  Forward tensors, losses and every parameter gradient against the
     oracle at that hidden size, same tolerances as the 128 case; and the library is back at 128 afterwards."""
     from gfv import lib as L
     graphs = cases.make_graphs("cyl_cavity_b2")
-    hyper = {"hidden_size": hidden}
+    hyper = {"hidden_size": hidden, "net": net}
     P = O.init_parameters(cases.WEIGHT_SEED, hyper)
     buffers = O.new_normalizer_buffers()
     Pg = {k: v.detach().requires_grad_(True) for k, v in P.items()}
@@ -102,14 +102,14 @@ def test_hidden_size_below_128_matches_oracle(hidden, golden_dir):
     oloss = O.training_loss(oout, hyper)
     names = list(Pg)
     ograds = dict(zip(names, torch.autograd.grad(oloss, [Pg[k] for k in names], allow_unused=True)))
-    model = _hip_model(P, hidden_size=hidden)
+    model = _hip_model(P, hidden_size=hidden, net=net)
     assert model.state_dict()["simulator.encoder.nb_encoder.0.2.weight"].shape == (hidden, hidden)
     hg = tuple(g.clone().to("cuda") for g in graphs)
     hg[0].norm_uvp, hg[0].norm_global = True, True
     out = model(*hg)
     for i, key in enumerate(("loss_cont", "loss_mom_x", "loss_mom_y", "loss_press", "uvp_node", "uvp_cell")):
         assert rel(out[i], oout[i]) < TOL, (key, rel(out[i], oout[i]))
-    if hidden == 64:   # the reference's own outputs at this width (tests/golden/make_golden_hidden.py)
+    if hidden == 64 and net == "TransFVGN_v2":   # the reference's own outputs at this width (tests/golden/make_golden_hidden.py)
         fx = np.load(os.path.join(golden_dir, "hidden64_cyl_cavity_b2.npz"))
         for i, key in enumerate(("loss_cont", "loss_mom_x", "loss_mom_y", "loss_press", "uvp_node", "uvp_cell")):
             assert rel(out[i], torch.from_numpy(fx[key])) < TOL, key
@@ -130,7 +130,7 @@ def test_hidden_size_below_128_matches_oracle(hidden, golden_dir):
     # the fused TrainStep on the same narrow model: true-shape Adam state, one gather into the 128-column shapes per step
     # and one back - its first step must move the parameters exactly as torch.optim.Adam moves them on these gradients
     from gfv.trainer import TrainStep
-    model2 = _hip_model(P, hidden_size=hidden)
+    model2 = _hip_model(P, hidden_size=hidden, net=net)
     opt = torch.optim.Adam(model.parameters(), lr=5e-5)
     opt.step()
     hg2 = tuple(g.clone().to("cuda") for g in graphs)
