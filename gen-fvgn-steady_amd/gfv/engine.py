@@ -129,6 +129,11 @@ class Engine:
         # neighbour sums as the prologue of the chain launch that consumes them (gfv_seg_t.csr_rowptr) instead of launches
         # of their own: 24 fewer launches per step on the main stream
         self.csr_fuse = ops.csr_prologue_enabled()
+        # ... where it pays (GFV_CSR_FUSE_MASK: 1 = the EdgeBlock's node-level projection, 2 = the NodeBlock MLP, 4 = the
+        # per-side scatter of the factored EdgeBlock's adjoint).  Since the plain forward instantiation runs at 3 waves per
+        # SIMD (tchain_fwd.hip) the two forward uses lose to a seg_gather_sum launch + a plain chain; step time, one-box
+        # A/B, masks 7 / 3 / 1 / 2 / 0 / 6 / 5 / 4: 4.313 / 4.345 / 4.310 / 4.308 / 4.273 / 4.282 / 4.275 / 4.252 ms
+        self._fuse_mask = int(os.environ.get("GFV_CSR_FUSE_MASK", "4"))
         self._wi, self._wi_key, self._wmax, self._wi_abs = None, None, None, None
         self._pkey_cache = None
         self._zero_e = None
@@ -511,7 +516,7 @@ class Engine:
         if self.factor:
             W1 = P[f"{prefix}.eb_module.net.0.0.weight"]                   # [128, 384] = [W1a | W1b | W1c]
             pab = _empty(x.device, N, 256)                                  # [W1a nb | W1b nb] per node
-            if fuse and ops.stack_ready(W1[:, 0:128], W1[:, 128:256], rows=True):
+            if fuse and (self._fuse_mask & 1) and ops.stack_ready(W1[:, 0:128], W1[:, 128:256], rows=True):
                 # nb = sum over the neighbours (blocks.py:84-99) formed in the prologue of the launch that multiplies it
                 nb = _empty(x.device, N, 128)
                 ops.rowtile_chain(N, [Seg(x, csr=(pl.n_rowptr, pl.n_col_node), save=nb)],
@@ -528,7 +533,7 @@ class Engine:
             e_out, e_new, sv_e = self.mlp3_fwd(P, f"{prefix}.eb_module.net", E, [Seg(nb, pl.es), Seg(nb, pl.er), Seg(e)],
                                                res=e, want_nores=True)
         agg = ops.seg_gather_sum(e_new.view(2 * E, 64), pl.n_rowptr, pl.n_col_edge2, N)
-        if fuse:
+        if fuse and (self._fuse_mask & 2):
             # nbm = mean over the neighbours of the aggregates (blocks.py:44-51), in the node MLP's prologue; the launch
             # leaves the assembled rows ([N,128] buffer, columns 0:64) for the weight gradient of the first layer
             nbm = _empty(x.device, N, 128)
@@ -567,7 +572,7 @@ class Engine:
         s0, s1, s2 = (gs[0], gs[1], gs[2]) if have else (None, None, None)
         # adjoint of the gathers (W1a nb)[s], (W1b nb)[r]: per-side scatter of dz1 to the nodes, then ONE node-level GEMM
         g_nb = _empty(dev, N, 128)
-        if self.csr_fuse:
+        if self.csr_fuse and (self._fuse_mask & 4):
             G_s, G_r = _empty(dev, N, 128), _empty(dev, N, 128)
             ops.rowtile_chain(N, [Seg(gz1, csr=(pl.s_rowptr, pl.s_col), save=G_s), Seg(gz1, csr=(pl.r_rowptr, pl.r_col), save=G_r)],
                               [LayerSpec(Wabt)], [g_nb])
