@@ -21,10 +21,15 @@ __device__ __forceinline__ unsigned gfv_pk_f16(float a, float b) {
   return __builtin_bit_cast(unsigned, v);
 }
 // (a, b) -> packed hi halves, packed lo halves (lo = fp16(x - hi), exact residual before the rounding)
+// The residual x - float(hi) is ONE v_fma_mix_f32 per value (x * 1.0 + (-hi) with the fp16 half read in place; exact, so the
+// same bits as converting back and subtracting - checked on the GPU over 65 k random pairs): 4 instructions per pair
+// instead of 5 (6 without the SLP vectoriser's packed subtraction).
 __device__ __forceinline__ void gfv_split_pair(float a, float b, unsigned& hi, unsigned& lo) {
   hi = gfv_pk_f16(a, b);
-  const gfv_f16x2 h = __builtin_bit_cast(gfv_f16x2, hi);
-  lo = gfv_pk_f16(a - (float)h[0], b - (float)h[1]);
+  float r0, r1;
+  asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(r0) : "v"(a), "v"(hi));
+  asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r1) : "v"(b), "v"(hi));
+  lo = gfv_pk_f16(r0, r1);
 }
 __device__ __forceinline__ void gfv_split8(const float (&v)[8], gfv_uint4& hi, gfv_uint4& lo) {
   unsigned h0, h1, h2, h3, l0, l1, l2, l3;
