@@ -159,3 +159,31 @@ def test_state_dict_layout_transfvgn_v1():
     assert list(sd) == list(shapes)
     for k, v in sd.items():
         assert tuple(v.shape) == tuple(shapes[k]), k
+
+
+@pytest.mark.parametrize("hidden", [16, 64, 112])
+def test_padding_maps_place_every_parameter_once(hidden):
+    """FVMmodel/padding.py (`--hidden_size` below 128): the padded tensors have exactly the shapes of the 128 model, every true
+    element lands in exactly one padded slot (the rest is zero), and gradients flow back to the true parameters."""
+    import torch
+    from FVMmodel.importer import NNmodel
+    from FVMmodel.padding import pad_parameters
+    from gfv.params import default_params
+    for net in ("TransFVGN_v2", "TransFVGN_v1"):
+        model = NNmodel(default_params(hidden_size=hidden, net=net))
+        names, tensors = model.param_names_tensors()
+        ref_names, ref_tensors = NNmodel(default_params(net=net)).param_names_tensors()
+        assert names == ref_names
+        marks = [torch.arange(1, t.numel() + 1, dtype=torch.float64).view(t.shape) for t in tensors]
+        padded = pad_parameters(names, marks, hidden)
+        for n, p, m, r in zip(names, padded, marks, ref_tensors):
+            assert p.shape == r.shape, n
+            nz = p[p != 0]
+            assert nz.numel() == m.numel() and torch.equal(torch.sort(nz).values, m.reshape(-1)), n
+        out = pad_parameters(names, tensors, hidden)
+        sum((q * q).sum() for q in out).backward()
+        assert all(t.grad is not None and torch.allclose(t.grad, 2 * t.detach()) for t in tensors)
+    with pytest.raises(NotImplementedError):
+        NNmodel(default_params(hidden_size=72))
+    with pytest.raises(NotImplementedError):
+        NNmodel(default_params(hidden_size=256))
