@@ -44,11 +44,32 @@ PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec
 N_PARAMS = 1181539             # TransFVGN_v2, hidden 128, mp 3
 
 
+def polygon_example_mesh():
+    """BASELINE.json configs[4] stand-in that can travel: the reference's polygon example mesh (cylinder_flow_poly, Tecplot
+    FEPolygon, 17 436 cells of 3 ... 9 nodes) from the reader arrays committed as test data (tests/golden/poly_cylinder.npz,
+    made by tests/golden/make_golden_poly.py), through the product's own ingest (gfv.ingest.tecplot_to_raw)."""
+    import json
+    from gfv import ingest, meshgen
+    fx = np.load(os.path.join(ROOT, "tests", "golden", "poly_cylinder.npz"))
+    tec = {"pos": fx["tec.pos"], "face_node": fx["tec.face_node"].astype(np.int64), "left": fx["tec.left"].astype(np.int64),
+           "right": fx["tec.right"].astype(np.int64), "boundary_pos": fx["tec.boundary_pos"]}
+    bcd = json.loads(str(fx["raw.bc"]))
+    bc_json = {"stencil|khops": bcd["stencil|khops"], "sigma": bcd["sigma"], "inlet_type": bcd["inlet_type"],
+               "theta_PDE": dict(bcd["theta_PDE"], inlet=[bcd["U"]], rho=[bcd["rho"]], mu=[bcd["mu"]], source=[bcd["source"]],
+                                 aoa=[bcd["aoa"]], dt=bcd["dt"], L=bcd["L"])}
+    raw = ingest.tecplot_to_raw(tec, bc_json)
+    raw["bc"] = bcd
+    return meshgen.finish_mesh(raw), fx["field"]
+
+
 def build_workload(workload, cells, meshes, rank, device):
     from gfv import meshgen
     from gfv.graph import build_batch
     ms, fs = [], []
-    for i in range(meshes):
+    if workload == "poly":
+        m, f = polygon_example_mesh()
+        ms, fs = [m] * meshes, [f] * meshes
+    for i in range(meshes if workload != "poly" else 0):
         seed = 1234 + rank * meshes + i
         if workload == "cavity":      # BASELINE.json configs[1]: lid-driven cavity, n x n quads (71 x 71 = 5 041 cells)
             n = max(2, int(round(cells ** 0.5)))
@@ -113,7 +134,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", choices=("cylinder", "cavity"), default="cylinder",
+    ap.add_argument("--inner-steps", type=int, default=0,
+                    help="unsteady solve loop (solve_with_grad_GPU.py:133-197): after every N training iterations the predicted "
+                         "field becomes the next time step's state (TrainStep.advance_time); 0 = steady (default; 20 with "
+                         "--workload poly)")
+    ap.add_argument("--workload", choices=("cylinder", "cavity", "poly"), default="cylinder",
                     help="cylinder: BASELINE configs[2] (~50k-cell tri mesh, the headline); cavity: configs[1] (use --cells 5041)")
     ap.add_argument("--cells", type=int, default=50000)
     ap.add_argument("--meshes-per-gpu", type=int, default=1)
@@ -184,11 +209,19 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    inner = args.inner_steps if args.inner_steps > 0 else (20 if args.workload == "poly" else 0)
+    since_advance = [0]
+
     def timed(n):
         barrier()
         tc = time.perf_counter()
         for _ in range(n):
             ts.step()
+            if inner:
+                since_advance[0] += 1
+                if since_advance[0] >= inner:   # time advance of the unsteady solve loop: inside the timed region
+                    ts.advance_time()
+                    since_advance[0] = 0
         barrier()
         el = time.perf_counter() - tc
         if dist_on:
@@ -371,13 +404,16 @@ def main():
     if rank == 0:
         total_meshes = world * args.meshes_per_gpu
         value = total_meshes * timed_steps / elapsed
-        wl = ("cylinder_flow tri mesh" if args.workload == "cylinder" else "lid_driven_cavity quad mesh") + \
+        wl = {"cylinder": "cylinder_flow tri mesh", "cavity": "lid_driven_cavity quad mesh",
+              "poly": f"cylinder_flow_poly polygon mesh (reference example, cells of 3 ... 9 nodes), unsteady: time advance "
+                      f"every {inner} iterations"}[args.workload] + \
             ", TransFVGN_v2 (hidden 128, mp 3), 2nd-order WLSQ, conserved form"
         line = {
             "metric": f"training iters/sec, {sz['C'] // 1000}k-cell {args.workload} mesh (fwd + loss + bwd + Adam, batch resident in HBM)",
             "value": round(value, 3), "unit": "mesh-train-iters/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic" if args.workload != "poly" else "reference example mesh (tests/golden/poly_cylinder.npz), synthetic fields",
             "timed": {"loops": len(reps), "steps_per_loop": args.steps, "timed_steps": timed_steps,
                       "timed_seconds": round(elapsed, 4), "min_time": args.min_time,
                       "loop_ms_per_step_min_max": [round(1e3 * min(reps) / args.steps, 4), round(1e3 * max(reps) / args.steps, 4)]},

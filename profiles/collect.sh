@@ -2,7 +2,8 @@
 # Collect the round's judged measurements on the GPU box (run through gpurun from the repo root):
 #   gpurun -- 'bash profiles/collect.sh r02'
 # writes under gpurun_out/<tag>/ : bench.json (the default bench.py line, with cpu_baseline), bench_b8.json (8 meshes per
-# GPU: BASELINE config 4's per-GPU load), bench_cavity.json (config 2: 71 x 71 lid-driven cavity), kernel_stats.csv
+# GPU: BASELINE config 4's per-GPU load), bench_cavity.json (config 2: 71 x 71 lid-driven cavity), bench_poly.json (config 5's shape: the reference's polygon example mesh,
+# unsteady solve loop with a time advance every 20 iterations), kernel_stats.csv
 # (rocprofv3 --kernel-trace --stats of the default bench command), hbm_pmc.txt + pmc_traffic.json (separate --pmc FETCH_SIZE /
 # WRITE_SIZE passes of a short eager bench run), parity_fp64.txt (HIP path and fp32 oracle against the float64 oracle, from
 # the -m gpu tests), pytest.log.  Copy the results into profiles/ afterwards (gpurun_out/ is scratch).
@@ -16,6 +17,7 @@ cd /tmp && export TMPDIR=/tmp
 timeout 900 python3 $R/bench.py > $O/bench.json 2> $O/bench.err
 timeout 900 python3 $R/bench.py --meshes-per-gpu 8 --cpu-budget 0 --steps 10 --warmup 4 > $O/bench_b8.json 2> $O/bench_b8.err
 timeout 900 python3 $R/bench.py --workload cavity --cells 5041 --cpu-budget 8 > $O/bench_cavity.json 2> $O/bench_cavity.err
+timeout 900 python3 $R/bench.py --workload poly --cpu-budget 8 > $O/bench_poly.json 2> $O/bench_poly.err
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 $R/bench.py --cpu-budget 0 > $O/prof.log 2>&1
 find $O/prof -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats.csv \;
 rm -rf $O/prof
