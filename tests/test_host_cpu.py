@@ -187,3 +187,15 @@ def test_padding_maps_place_every_parameter_once(hidden):
         NNmodel(default_params(hidden_size=72))
     with pytest.raises(NotImplementedError):
         NNmodel(default_params(hidden_size=256))
+
+
+def test_bench_polygon_workload_builds_on_the_host():
+    """`bench.py --workload poly`: the reference's polygon example mesh from the committed reader arrays through the product's
+    ingest - the batch the GPU box will time (sizes pinned; no GPU needed to build it)."""
+    import importlib
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    bench = importlib.import_module("bench")
+    graphs, sz = bench.build_workload("poly", 0, 1, 0, "cpu")
+    assert (sz["C"], sz["N"], sz["E"]) == (17436, 27778, 45214) and sz["B"] == 1
+    assert graphs[0].x.shape == (27778, 12)
