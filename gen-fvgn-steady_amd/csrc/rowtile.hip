@@ -132,18 +132,25 @@ __device__ __forceinline__ void mma_slice_generic(floatx4 (&acc)[8], const float
 __device__ __forceinline__ float4 f4_add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 __device__ __forceinline__ float f4_sum(float4 a) { return (a.x + a.y) + (a.z + a.w); }
 
-// (LayerNorm over the h real columns of a zero-padded 128-column row: gfv_set_hidden_size, tchain_kernel.h LnW)
-__device__ float g_ln_inv_n = 1.0f / 128.0f, g_ln_npad = 0.0f;
-__device__ __forceinline__ void row_stats(const float4 v, float& mean, float& rstd) {
-  mean = gfv_half_sum(f4_sum(v)) * g_ln_inv_n;
+// (LayerNorm over the h real columns of a zero-padded 128-column row: gfv_set_hidden_size; the launcher passes h in the
+// kernel arguments' pad_ field, as for the register-resident chain - tchain_kernel.h LnW)
+struct LnW {
+  float inv_n, npad;
+};
+__device__ __forceinline__ LnW ln_width(int cols) {
+  const int n = (cols > 0 && cols < 128) ? cols : 128;
+  return LnW{1.0f / (float)n, (float)(128 - n)};
+}
+__device__ __forceinline__ void row_stats(const float4 v, float& mean, float& rstd, const LnW w) {
+  mean = gfv_half_sum(f4_sum(v)) * w.inv_n;
   const float dx = v.x - mean, dy = v.y - mean, dz = v.z - mean, dw = v.w - mean;
-  const float var = (gfv_half_sum((dx * dx + dy * dy) + (dz * dz + dw * dw)) - g_ln_npad * (mean * mean)) * g_ln_inv_n;
+  const float var = (gfv_half_sum((dx * dx + dy * dy) + (dz * dz + dw * dw)) - w.npad * (mean * mean)) * w.inv_n;
   rstd = rsqrtf(var + 1e-5f);  // nn.LayerNorm eps (EPD.py:32)
 }
 
-__device__ __forceinline__ float4 row_layernorm(const float4 v, const float4 g, const float4 b) {
+__device__ __forceinline__ float4 row_layernorm(const float4 v, const float4 g, const float4 b, const LnW w) {
   float mean, rstd;
-  row_stats(v, mean, rstd);
+  row_stats(v, mean, rstd, w);
   return make_float4((v.x - mean) * rstd * g.x + b.x, (v.y - mean) * rstd * g.y + b.y,
                      (v.z - mean) * rstd * g.z + b.z, (v.w - mean) * rstd * g.w + b.w);
 }
@@ -151,13 +158,13 @@ __device__ __forceinline__ float4 row_layernorm(const float4 v, const float4 g, 
 // LayerNorm backward for one row: y = LN input row, go = grad wrt LN output; returns grad wrt LN input and
 // accumulates the lane's 4 columns of dgamma / dbeta.
 __device__ __forceinline__ float4 row_layernorm_bwd(const float4 y, const float4 go, const float4 g, float4& dgam,
-                                                    float4& dbet) {
+                                                    float4& dbet, const LnW w) {
   float mean, rstd;
-  row_stats(y, mean, rstd);
+  row_stats(y, mean, rstd, w);
   const float4 xh = make_float4((y.x - mean) * rstd, (y.y - mean) * rstd, (y.z - mean) * rstd, (y.w - mean) * rstd);
   const float4 gg = make_float4(go.x * g.x, go.y * g.y, go.z * g.z, go.w * g.w);
-  const float m1 = gfv_half_sum(f4_sum(gg)) * g_ln_inv_n;
-  const float m2 = gfv_half_sum((gg.x * xh.x + gg.y * xh.y) + (gg.z * xh.z + gg.w * xh.w)) * g_ln_inv_n;
+  const float m1 = gfv_half_sum(f4_sum(gg)) * w.inv_n;
+  const float m2 = gfv_half_sum((gg.x * xh.x + gg.y * xh.y) + (gg.z * xh.z + gg.w * xh.w)) * w.inv_n;
   dgam.x += go.x * xh.x; dgam.y += go.y * xh.y; dgam.z += go.z * xh.z; dgam.w += go.w * xh.w;
   dbet.x += go.x; dbet.y += go.y; dbet.z += go.z; dbet.w += go.w;
   return make_float4(rstd * (gg.x - m1 - xh.x * m2), rstd * (gg.y - m1 - xh.y * m2), rstd * (gg.z - m1 - xh.z * m2),
@@ -217,11 +224,11 @@ __device__ void stage_input(const gfv_rowtile_args_t& A, int si, float* Xs, cons
     if (A.in_op == GFV_IN_GELU) {
       v = make_float4(gfv_gelu(v.x), gfv_gelu(v.y), gfv_gelu(v.z), gfv_gelu(v.w));
     } else if (A.in_op == GFV_IN_LN) {
-      v = row_layernorm(v, gam, bet);
+      v = row_layernorm(v, gam, bet, ln_width(A.pad_));
     } else if (A.in_op == GFV_IN_LNBWD) {
       float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
       if (m < c.M) y = *reinterpret_cast<const float4*>(A.in_aux + (size_t)m * 128 + col);
-      v = row_layernorm_bwd(y, v, gam, dgam, dbet);
+      v = row_layernorm_bwd(y, v, gam, dgam, dbet, ln_width(A.pad_));
     }
     if (m >= c.M) v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (si == 0 && A.in_save && m < c.M) *reinterpret_cast<float4*>(A.in_save + (size_t)m * 128 + col) = v;
@@ -304,12 +311,12 @@ __device__ void final_epilogue(const gfv_rowtile_args_t& A, const gfv_layer_t& L
       }
       if (A.fin_op == GFV_FIN_LN) {
         if (A.fin_presave && live) *reinterpret_cast<float4*>(A.fin_presave + (size_t)m * 128 + col) = v;
-        v = row_layernorm(v, gam, bet);
+        v = row_layernorm(v, gam, bet, ln_width(A.pad_));
       } else if (A.fin_op == GFV_FIN_LNBWD) {
         float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
         if (live) y = *reinterpret_cast<const float4*>(A.fin_aux + (size_t)m * 128 + col);
         if (!live) v = make_float4(0.f, 0.f, 0.f, 0.f);
-        v = row_layernorm_bwd(y, v, gam, dgam, dbet);
+        v = row_layernorm_bwd(y, v, gam, dgam, dbet, ln_width(A.pad_));
       }
       if (live) {
         if (chunk == 0 && A.out_nores) *reinterpret_cast<float4*>(A.out_nores + (size_t)m * 128 + col) = v;
@@ -491,18 +498,13 @@ static int f16_mode() { return gfv_f16split_enabled(); }
 // hidden_size of the model the following launches belong to (utils/get_param.py:69; default 128).  A model of h < 128 runs
 // zero-padded to 128 columns (FVMmodel/padding.py): what changes in the kernels is the LayerNorm width (statistics over the h
 // real columns) and the attention scale (dim_head = h / 8).  Host-side state read by the launchers (chain: passed in the
-// kernel arguments; weight gradient: DwLaunch; slice attention: its argument struct; the generic row-tile kernel: two device
-// globals) - set it before the launches of a model, gfv.engine.Engine does on every forward / backward.
+// kernel arguments, also of the generic row-tile kernel; weight gradient: DwLaunch; slice attention: its argument struct) -
+// set it before the launches of a model, gfv.engine.Engine does on every forward / backward.
 static int g_hidden = 128;
 extern "C" int gfv_hidden_size(void) { return g_hidden; }
 extern "C" int gfv_set_hidden_size(int32_t h) {
   if (h < 16 || h > 128 || (h & 15)) return GFV_ERR_ARG;
-  if (h != g_hidden) {
-    const float inv = 1.0f / (float)h, npad = (float)(128 - h);
-    if (hipMemcpyToSymbol(HIP_SYMBOL(g_ln_inv_n), &inv, sizeof(float)) != hipSuccess) return GFV_ERR_LAUNCH;
-    if (hipMemcpyToSymbol(HIP_SYMBOL(g_ln_npad), &npad, sizeof(float)) != hipSuccess) return GFV_ERR_LAUNCH;
-  }
-  g_hidden = h;
+  g_hidden = h;   // (host state only: safe inside a stream capture)
   return GFV_OK;
 }
 
@@ -613,10 +615,12 @@ extern "C" int gfv_rowtile_chain(const gfv_rowtile_args_t* args, void* stream) {
     gfv_internal_tchain_launch(args, 0, f16 ? 1 : 0, (hipStream_t)stream);
   else if (rag_t && tchain_mode() != 0)
     gfv_internal_tchain_launch(args, 1, f16 ? 1 : 0, (hipStream_t)stream);
-  else if (fast)
-    hipLaunchKernelGGL(rowtile_chain_kernel<true>, dim3(tiles), dim3(256), 0, (hipStream_t)stream, *args);
-  else
-    hipLaunchKernelGGL(rowtile_chain_kernel<false>, dim3(tiles), dim3(256), 0, (hipStream_t)stream, *args);
+  else {
+    gfv_rowtile_args_t local = *args;
+    local.pad_ = g_hidden;   // LayerNorm width (gfv_set_hidden_size)
+    if (fast) hipLaunchKernelGGL(rowtile_chain_kernel<true>, dim3(tiles), dim3(256), 0, (hipStream_t)stream, local);
+    else hipLaunchKernelGGL(rowtile_chain_kernel<false>, dim3(tiles), dim3(256), 0, (hipStream_t)stream, local);
+  }
   gfv_prof_end(tok, (hipStream_t)stream);
   GFV_CHECK_LAUNCH();
   return GFV_OK;

@@ -134,7 +134,7 @@ def test_hidden_size_below_128_matches_oracle(hidden, net, golden_dir):
     opt = torch.optim.Adam(model.parameters(), lr=5e-5)
     opt.step()
     hg2 = tuple(g.clone().to("cuda") for g in graphs)
-    ts = TrainStep(model2, hg2, lr=5e-5, use_graph="list" if hidden == 64 else False)
+    ts = TrainStep(model2, hg2, lr=5e-5, use_graph={32: False, 64: "list", 112: True}[hidden])   # eager / command list / hipGraph
     ts.step()
     torch.cuda.synchronize()
     assert abs(float(ts.loss) - float(oloss)) < TOL * abs(float(oloss))
