@@ -34,7 +34,17 @@ def require_native(h):
                                   "NNmodel, which pads the parameters (FVMmodel/padding.py)")
 
 
+_MAP_CACHE = {}
+
+
 def _maps(h, device):
+    key = (h, str(device))
+    if key not in _MAP_CACHE:
+        _MAP_CACHE[key] = _build_maps(h, device)
+    return _MAP_CACHE[key]
+
+
+def _build_maps(h, device):
     ar = lambda n, o=0: torch.arange(n, device=device) + o
     half = h // 2
     dh = h // 8
