@@ -364,6 +364,79 @@ def test_lbfgs_closure_driver_runs_on_the_drop_in_model():
     assert min(history) < history[0] - 1e-3, history
 
 
+def test_lbfgs_loop_tracks_the_oracle_under_the_same_optimizer():
+    """Row f4, LBFGS: the closure loop of solve_with_grad_GPU_LBFGS.py:67-160 on the drop-in module and the SAME
+    torch.optim.LBFGS (strong Wolfe) on the oracle, from the same weights: the closure evaluations - the line search's trial
+    points included - see the same losses (first one to 1e-5, the following ones to 1e-3: each depends on every gradient
+    before it)."""
+    from FVMmodel.importer import NNmodel
+    from gfv.params import default_params
+    cpu_graphs = cases.make_graphs("cavity_mixed_b1")
+    P = O.init_parameters(cases.WEIGHT_SEED)
+    params = default_params(dataset_size=1)
+    hyper = {"dataset_size": 1}
+    kw = dict(max_iter=4, history_size=10, tolerance_grad=1e-9, tolerance_change=1e-12, line_search_fn="strong_wolfe")
+
+    # oracle
+    Pg = {k: v.detach().clone().requires_grad_(True) for k, v in P.items()}
+    buffers = O.new_normalizer_buffers()
+    x0 = cpu_graphs[0].x.clone()
+    oh = []
+    used = [p for k, p in Pg.items()]
+    oopt = torch.optim.LBFGS(used, **kw)
+
+    def oclosure():
+        oopt.zero_grad()
+        g = tuple(t.clone() for t in cpu_graphs)
+        g[0].x = x0.clone()
+        out = O.model_forward(Pg, buffers, g, hyper)
+        lb = params.loss_press * out[3] + params.loss_cont * out[0] + params.loss_mom * out[1] + params.loss_mom * out[2]
+        loss = torch.mean(torch.log(torch.clamp(lb, min=1e-10, max=1e10)))
+        loss.backward()
+        for p_ in used:          # parameters the forward never touches (ln_1, temperature): LBFGS needs a gradient tensor
+            if p_.grad is None:
+                p_.grad = torch.zeros_like(p_)
+        oh.append(float(loss))
+        return loss
+
+    oopt.step(oclosure)
+
+    # HIP
+    model = NNmodel(params)
+    sd = model.state_dict()
+    for k, v in P.items():
+        sd[k].copy_(v)
+    model.load_state_dict(sd)
+    model = model.cuda()
+    graphs = tuple(g.clone().to("cuda") for g in cpu_graphs)
+    gn = graphs[0]
+    xg = gn.x.clone()
+    hh = []
+    hopt = torch.optim.LBFGS(model.parameters(), **kw)
+
+    def hclosure():
+        hopt.zero_grad()
+        gn.x = xg.clone()
+        gn.norm_uvp, gn.norm_global = params.norm_uvp, params.norm_global
+        lc, lmx, lmy, lp, _, _ = model(*graphs)
+        lb = params.loss_press * lp + params.loss_cont * lc + params.loss_mom * lmx + params.loss_mom * lmy
+        loss = torch.mean(torch.log(torch.clamp(lb, min=1e-10, max=1e10)))
+        loss.backward()
+        for p_ in model.parameters():
+            if p_.grad is None:
+                p_.grad = torch.zeros_like(p_)
+        hh.append(float(loss))
+        return loss
+
+    hopt.step(hclosure)
+    n = min(len(oh), len(hh), 5)
+    assert n >= 3, (oh, hh)
+    assert abs(hh[0] - oh[0]) < 1e-5 * abs(oh[0]), (hh[0], oh[0])
+    for a, b in zip(hh[:n], oh[:n]):
+        assert abs(a - b) < 1e-3 * abs(b), (hh[:n], oh[:n])
+    assert min(hh) < hh[0] - 1e-3
+
+
 def test_data_parallel_trainstep_two_ranks():
     """SURVEY.md 8e on the device path: two ranks (one mesh each, sharing this GPU, gloo) run the sharded TrainStep with an
     accumulating Normalizer; both ranks must end bit-identical, and equal (to rounding) to a single process stepping on
