@@ -28,6 +28,16 @@ extern "C" int gfv_status_flags(int32_t* flags_out) {
   return GFV_OK;
 }
 
+// device address of the status word for kernels of other translation units (the chain families raise their range flags there)
+int* gfv_internal_status_ptr() {
+  static int* p = nullptr;
+  if (!p) {
+    void* q = nullptr;
+    if (hipGetSymbolAddress(&q, HIP_SYMBOL(g_gfv_status_flags)) == hipSuccess) p = static_cast<int*>(q);
+  }
+  return p;
+}
+
 namespace {
 
 constexpr int SUB = 32;   // rows per staged sub-tile

@@ -612,7 +612,7 @@ extern "C" int gfv_rowtile_chain(const gfv_rowtile_args_t* args, void* stream) {
   }
   g_last_path = (tchain_mode() != 0 && (fast_t || rag_t)) ? ((fast_t ? 1 : 2) + (f16 ? 4 : 0)) : 0;
   if (fast_t && tchain_mode() != 0)
-    gfv_internal_tchain_launch(args, 0, f16 ? 1 : 0, (hipStream_t)stream);
+    g_last_path += 8 * gfv_internal_tchain_launch(args, 0, f16 ? 1 : 0, (hipStream_t)stream);   // (1: the column-owner family took it)
   else if (rag_t && tchain_mode() != 0)
     gfv_internal_tchain_launch(args, 1, f16 ? 1 : 0, (hipStream_t)stream);
   else {

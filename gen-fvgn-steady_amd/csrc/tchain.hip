@@ -3,6 +3,7 @@
 #include "tchain_kernel.h"
 
 void gfv_internal_tchain_fwd_plain(const gfv_rowtile_args_t* args, int f16, int iop, hipStream_t stream);   // tchain_fwd.hip
+int gfv_internal_colchain_try(const gfv_rowtile_args_t* args, hipStream_t stream);                              // colchain.hip
 
 // 1 / 2: every layer before the last has GFV_OP_BIAS_GELU / GFV_OP_MUL_DGELU and the prologue op is none or the LayerNorm
 // backward (the IOP instantiations, tchain_kernel.h); 0: anything else - the instantiation that reads the ops at run time
@@ -52,6 +53,7 @@ int gfv_internal_tchain_launch(const gfv_rowtile_args_t* args_in, int ragged, in
   const gfv_rowtile_args_t* args = &local;
   const int lnm = args->in_op == GFV_IN_LNBWD ? 1 : (args->fin_op == GFV_FIN_LNBWD ? 2 : 0);
   const dim3 wgs((args->M + 63) / 64), blk(256);
+  if (f16 && !ragged && gfv_internal_colchain_try(args, stream)) return 1;   // the column-owner persistent family
   if (f16) {
     // (an 8-wave workgroup sharing one weight stream over 128 rows - launch_h<8> - was measured in round 2: 5.28 ms / step
     // against 4.96 with it on the 75 k-row launches, 5.29 with it everywhere; the 4-wave form stays)

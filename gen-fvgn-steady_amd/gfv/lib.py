@@ -19,6 +19,7 @@ c_int_p = C.c_void_p
 OP_NONE, OP_BIAS_GELU, OP_MUL_DGELU = 0, 1, 2
 IN_NONE, IN_GELU, IN_LN, IN_LNBWD = 0, 1, 2, 3
 FIN_PLAIN, FIN_LN, FIN_LNBWD = 0, 1, 2
+CHAIN_ROW_OWNER, CHAIN_COLUMN_OWNER = 1, 2   # gfv_rowtile_args_t.flags
 DW_COLSCALE = 8   # gfv_dw_tile_t.a_op flag: per-column power-of-two scales of raw-input activations
 
 
@@ -42,7 +43,7 @@ class RowtileArgs(C.Structure):
         ("fin_gamma", C.c_void_p), ("fin_beta", C.c_void_p), ("fin_aux", C.c_void_p), ("fin_presave", C.c_void_p),
         ("res", C.c_void_p * 3), ("res_ld", C.c_int32 * 3), ("out_ld", C.c_int32 * 3), ("out", C.c_void_p * 3),
         ("out_nores", C.c_void_p), ("padd", C.c_void_p), ("padd_s", C.c_void_p), ("padd_r", C.c_void_p),
-        ("padd_ld", C.c_int32), ("pad2_", C.c_int32), ("wmax", C.c_void_p),
+        ("padd_ld", C.c_int32), ("flags", C.c_int32), ("wmax", C.c_void_p),
         ("gscale", C.c_void_p), ("gscale_ld", C.c_int32), ("pad3_", C.c_int32),
     ]
 

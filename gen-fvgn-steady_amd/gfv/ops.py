@@ -228,11 +228,12 @@ def set_weight_images(wi):
 def rowtile_chain(M, segs, layers, outs, *, in_add=None, in_op=L.IN_NONE, in_gamma=None, in_beta=None, in_aux=None,
                   gadd=None, gadd_s=None, gadd_r=None, in_save=None, ln_partial=None, fin_op=L.FIN_PLAIN,
                   fin_gamma=None, fin_beta=None, fin_aux=None, fin_presave=None, res=None, out_nores=None,
-                  padd=None, padd_s=None, padd_r=None, wimg=None, gscale=None):
+                  padd=None, padd_s=None, padd_r=None, wimg=None, gscale=None, family=0):
     """Launch the fused row-tile GEMM chain.  outs / res: list (per 128-wide chunk of the last layer) of
     (tensor, ld) or tensors; see include/gfv.h for the semantics of every field.  gscale: [3, ld] buffer for the
     per-16-row scales of the gradient rows the launch leaves behind; returns True when the launch wrote it (split-fp16
-    form), so the weight-gradient launch may take its slots instead of a pass over the rows."""
+    form), so the weight-gradient launch may take its slots instead of a pass over the rows.  family: 0 = the library picks
+    the kernel family, lib.CHAIN_ROW_OWNER / lib.CHAIN_COLUMN_OWNER pin it (include/gfv.h, gfv_rowtile_args_t.flags)."""
     lib = L.load()
     wi = wimg if wimg is not None else _WI
     if layers[-1].stack is not None:
@@ -287,6 +288,7 @@ def rowtile_chain(M, segs, layers, outs, *, in_add=None, in_op=L.IN_NONE, in_gam
             a.res[i] = t.data_ptr() if torch.is_tensor(t) else t
             a.res_ld[i] = ld
     a.out_nores = _p(out_nores)
+    a.flags = family
     if padd is not None:
         a.padd, a.padd_s, a.padd_r, a.padd_ld = _p(padd), _p(padd_s), _p(padd_r), padd.stride(0)
     if gscale is not None:

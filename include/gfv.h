@@ -74,6 +74,11 @@ enum {                /* per-layer element op applied to the accumulator */
   GFV_OP_MUL_DGELU = 2  /* v = acc * gelu'(aux); save v; next input = v     */
 };
 enum { GFV_IN_NONE = 0, GFV_IN_GELU = 1, GFV_IN_LN = 2, GFV_IN_LNBWD = 3 };
+/* gfv_rowtile_args_t.flags: the split-fp16 form has two kernel families - the row-owner chain (a wave owns 16 rows, weights
+ * stream through LDS) and the column-owner persistent chain (a wave owns 16 columns, weights stay in registers for the whole
+ * launch; 3-layer MLP launches).  By default big launches of a covered shape take the second. */
+enum { GFV_CHAIN_ROW_OWNER = 1,     /* never the column-owner family */
+       GFV_CHAIN_COLUMN_OWNER = 2   /* the column-owner family whatever the row count (if the shape is covered) */ };
 enum { GFV_FIN_PLAIN = 0, GFV_FIN_LN = 1, GFV_FIN_LNBWD = 2 };
 
 typedef struct {
@@ -126,7 +131,7 @@ typedef struct {
   const int32_t* padd_s;
   const int32_t* padd_r;
   int32_t padd_ld;
-  int32_t pad2_;
+  int32_t flags;          /* GFV_CHAIN_*: which kernel family may take the launch (0: the library decides by shape and size) */
   const float* wmax;      /* device scalar max|W| the layers' Wh images were built with (gfv_weight_images) */
   /* optional, written by the split-fp16 form only (gfv_rowtile_last_path() >= 5): per group of 16 consecutive rows the
    * exact power of two s with s * max|v| in [2^13, 2^14) of the gradient rows this launch leaves for the weight-gradient
@@ -141,7 +146,8 @@ typedef struct {
 int gfv_rowtile_tiles(int32_t M); /* number of 64-row tiles = rows of ln_partial */
 int gfv_rowtile_chain(const gfv_rowtile_args_t* args, void* stream);
 /* which kernel the calling thread's last gfv_rowtile_chain launch took: 0 generic LDS row-tile, 1 register-resident
- * chain, 2 its ragged-shape instantiation; + 4 when the products ran as split-fp16 (tests assert the path they mean) */
+ * chain, 2 its ragged-shape instantiation; + 4 when the products ran as split-fp16; + 8 when the column-owner persistent
+ * family took the launch (tests assert the path they mean) */
 int gfv_rowtile_last_path(void);
 
 /* fp32 products on the f16 MFMA pipe (v_mfma_f32_16x16x32_f16, 16x the f32 MFMA rate): every fp32 operand is split
@@ -224,7 +230,10 @@ typedef struct {
  * features); otherwise they are split unscaled (latent rows, GELU / LayerNorm outputs: O(1)), and a value beyond the fp16
  * range raises GFV_FLAG_DW_RANGE in the device status word instead of being clamped. */
 enum { GFV_DW_COLSCALE = 8 };
-enum { GFV_FLAG_DW_RANGE = 1 };
+enum { GFV_FLAG_DW_RANGE = 1,
+       /* column-owner chain family: a hidden activation beyond 2^11 (they are split after a fixed scale, see
+        * csrc/colchain_kernel.h; GFV_COLCHAIN=0 keeps every launch on the row-scaled family) */
+       GFV_FLAG_CHAIN_RANGE = 2 };
 /* device status word: OR of GFV_FLAG_* raised by kernels since the last call; reads (synchronising) and clears it */
 int gfv_status_flags(int32_t* flags_out);
 int gfv_dw_slabs(int32_t M, int32_t ntiles, int32_t* rows_per_slab);

@@ -1,0 +1,134 @@
+"""GPU: the column-owner persistent chain family (csrc/colchain_kernel.h) against a float64 torch restatement of the
+fused MLP (EPD.py:10-33 build_mlp inside blocks.py EdgeBlock / NodeBlock) and against the row-owner family on the same
+launch; tolerance 1e-5 relative (fp32), as for every other kernel (tests/test_kernels_gpu.py)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need the MI355X"
+    from gfv import lib
+    lib.load()
+    return torch.device("cuda:0")
+
+
+def _params(g, kin, scale=0.3):
+    return dict(W1=torch.randn(128, kin, generator=g) * scale / kin ** 0.5 * 4, b1=torch.randn(128, generator=g) * 0.1,
+                W2=torch.randn(128, 128, generator=g) * scale / 3, b2=torch.randn(128, generator=g) * 0.1,
+                W3=torch.randn(128, 128, generator=g) * scale / 3, b3=torch.randn(128, generator=g) * 0.1,
+                gamma=1 + 0.1 * torch.randn(128, generator=g), beta=0.1 * torch.randn(128, generator=g))
+
+
+def _ref(P, X, add=None):
+    P = {k: v.double() for k, v in P.items()}
+    z1 = F.linear(X, P["W1"], P["b1"])
+    if add is not None:
+        z1 = z1 + add
+    z2 = F.linear(F.gelu(z1), P["W2"], P["b2"])
+    y3 = F.linear(F.gelu(z2), P["W3"], P["b3"])
+    return z1, z2, y3, F.layer_norm(y3, (128,), P["gamma"], P["beta"], 1e-5)
+
+
+def _images(dev, Ws):
+    from gfv import ops
+    wmax = torch.stack([w.abs().max() for w in Ws]).max().reshape(1).to(dev)
+    wi = ops.WeightImages(dev, wmax)
+    wi.static = [(0, 1 << 62)]
+    return wi
+
+
+@pytest.mark.parametrize("M", [5000, 2049, 16, 129])
+@pytest.mark.parametrize("padd", [True, False])
+def test_column_owner_edge_mlp_forward(dev, M, padd):
+    """EdgeBlock forward in its factored form: one 128-wide segment + the gathered first-layer addend, every saved tensor."""
+    from gfv import lib as L, ops
+    g = torch.Generator().manual_seed(M + padd)
+    n_nodes = 700
+    e = torch.randn(M, 128, generator=g) * (1 + 3 * torch.rand(M, 1, generator=g))
+    e[3] *= 1e-4          # a tiny row and a big row: the input rows carry their own power-of-two scale
+    e[min(5, M - 1)] *= 30.0
+    pab = torch.randn(n_nodes, 256, generator=g)
+    s = torch.randint(0, n_nodes, (M,), generator=g)
+    r = torch.randint(0, n_nodes, (M,), generator=g)
+    P = _params(g, 128)
+    add = (pab[s, :128] + pab[r, 128:]).double() if padd else None
+    z1, z2, y3, ln = _ref(P, e.double(), add)
+    d = lambda t: t.to(dev).contiguous()
+    Pd = {k: d(v) for k, v in P.items()}
+    ed, pabd, sd, rd = d(e), d(pab), d(s.int()), d(r.int())
+    wi = _images(dev, [P["W1"], P["W2"], P["W3"]])
+    res = {}
+    for fam in (L.CHAIN_COLUMN_OWNER, L.CHAIN_ROW_OWNER):
+        z1d, z2d, y3d, outd, enew = (torch.full((M, 128), float("nan"), device=dev) for _ in range(5))
+        ops.rowtile_chain(
+            M, [ops.Seg(ed)],
+            [ops.LayerSpec(Pd["W1"], Pd["b1"], L.OP_BIAS_GELU, save=z1d),
+             ops.LayerSpec(Pd["W2"], Pd["b2"], L.OP_BIAS_GELU, save=z2d), ops.LayerSpec(Pd["W3"], Pd["b3"])],
+            [outd], fin_op=L.FIN_LN, fin_gamma=Pd["gamma"], fin_beta=Pd["beta"], fin_presave=y3d, res=[ed], out_nores=enew,
+            wimg=wi, family=fam, **(dict(padd=pabd, padd_s=sd, padd_r=rd) if padd else {}))
+        path = L.load().gfv_rowtile_last_path()
+        assert path == (13 if fam == L.CHAIN_COLUMN_OWNER else 5), path
+        for mine, want, name in ((z1d, z1, "z1"), (z2d, z2, "z2"), (y3d, y3, "y3"), (enew, ln, "ln"), (outd, ln + e.double(), "out")):
+            assert rel(mine, want) < TOL, (fam, name, rel(mine, want))
+        res[fam] = outd
+    assert rel(res[L.CHAIN_COLUMN_OWNER], res[L.CHAIN_ROW_OWNER]) < 2e-6
+    flags = L.C.c_int32(0)
+    L.check(L.load().gfv_status_flags(L.C.byref(flags)), "gfv_status_flags")
+    assert flags.value == 0
+
+
+@pytest.mark.parametrize("M", [3000, 97])
+def test_column_owner_node_mlp_forward(dev, M):
+    """NodeBlock forward: input [nbm (64) | x (128)], K = 192, row-gathered first segment."""
+    from gfv import lib as L, ops
+    g = torch.Generator().manual_seed(M)
+    nbm, x = torch.randn(M + 50, 64, generator=g), torch.randn(M, 128, generator=g)
+    idx = torch.randperm(M + 50, generator=g)[:M]
+    P = _params(g, 192)
+    z1, z2, y3, ln = _ref(P, torch.cat((nbm[idx], x), 1).double())
+    d = lambda t: t.to(dev).contiguous()
+    Pd = {k: d(v) for k, v in P.items()}
+    xd, nbmd = d(x), d(nbm)
+    wi = _images(dev, [P["W1"], P["W2"], P["W3"]])
+    z1d, z2d, y3d, outd = (torch.full((M, 128), float("nan"), device=dev) for _ in range(4))
+    ops.rowtile_chain(M, [ops.Seg(nbmd, d(idx.int())), ops.Seg(xd)],
+                      [ops.LayerSpec(Pd["W1"], Pd["b1"], L.OP_BIAS_GELU, save=z1d),
+                       ops.LayerSpec(Pd["W2"], Pd["b2"], L.OP_BIAS_GELU, save=z2d), ops.LayerSpec(Pd["W3"], Pd["b3"])],
+                      [outd], fin_op=L.FIN_LN, fin_gamma=Pd["gamma"], fin_beta=Pd["beta"], fin_presave=y3d, res=[xd],
+                      wimg=wi, family=L.CHAIN_COLUMN_OWNER)
+    assert L.load().gfv_rowtile_last_path() == 13
+    for mine, want, name in ((z1d, z1, "z1"), (z2d, z2, "z2"), (y3d, y3, "y3"), (outd, ln + x.double(), "out")):
+        assert rel(mine, want) < TOL, (name, rel(mine, want))
+
+
+def test_column_owner_hidden_range_flag(dev):
+    """Hidden activations are split after a fixed scale: beyond 2^11 the status word says so (include/gfv.h)."""
+    from gfv import lib as L, ops
+    g = torch.Generator().manual_seed(0)
+    M = 64
+    P = _params(g, 128)
+    P["b1"] = P["b1"] + 5000.0
+    d = lambda t: t.to(dev).contiguous()
+    Pd = {k: d(v) for k, v in P.items()}
+    ed = d(torch.randn(M, 128, generator=g))
+    out = torch.empty(M, 128, device=dev)
+    wi = _images(dev, [P["W1"], P["W2"], P["W3"]])
+    flags = L.C.c_int32(0)
+    L.check(L.load().gfv_status_flags(L.C.byref(flags)), "gfv_status_flags")
+    ops.rowtile_chain(M, [ops.Seg(ed)],
+                      [ops.LayerSpec(Pd["W1"], Pd["b1"], L.OP_BIAS_GELU), ops.LayerSpec(Pd["W2"], Pd["b2"], L.OP_BIAS_GELU),
+                       ops.LayerSpec(Pd["W3"], Pd["b3"])], [out], fin_op=L.FIN_LN, fin_gamma=Pd["gamma"],
+                      fin_beta=Pd["beta"], wimg=wi, family=L.CHAIN_COLUMN_OWNER)
+    L.check(L.load().gfv_status_flags(L.C.byref(flags)), "gfv_status_flags")
+    assert flags.value & 2
