@@ -24,9 +24,53 @@ static int cc_cus() {
   return n;
 }
 
-// 1: launched; 0: not this family's launch
+// the backward form with fused weight gradients (colchain_bwd_kernel): does the launch qualify?
+static bool cc_bwd_ok(const gfv_rowtile_args_t* a) {
+  static const int on = cc_env("GFV_COLCHAIN_BWD", 1);
+  static const int min_m = cc_env("GFV_COLCHAIN_BWD_MIN_M", 16384);
+  if (a->flags & GFV_CHAIN_ROW_OWNER) return false;
+  if (!(a->flags & GFV_CHAIN_COLUMN_OWNER) && (!on || a->M < min_m)) return false;
+  if (!a->dw_partial || a->dw_partial_stride < GFV_DW_FUSED_FLOATS || !a->in_stats || !a->wmax) return false;
+  if (a->nlayers != 3 || a->in_op != GFV_IN_LNBWD || a->fin_op != GFV_FIN_PLAIN || a->nseg != 1) return false;
+  if (a->seg[0].width != 128 || a->seg[0].idx || a->seg[0].csr_rowptr || a->seg[0].save || (a->seg[0].ld & 3) || !al16(a->seg[0].ptr)) return false;
+  if (a->layer[0].op != GFV_OP_MUL_DGELU || a->layer[1].op != GFV_OP_MUL_DGELU || a->layer[2].op != GFV_OP_NONE) return false;
+  for (int l = 0; l < 3; ++l) {
+    const gfv_layer_t& L = a->layer[l];
+    if (!L.Wh || L.N != 128 || L.K != 128 || L.bias || L.bias2) return false;
+    if (l < 2 && (!L.aux || !al16(L.aux))) return false;
+    if (L.save && !al16(L.save)) return false;
+  }
+  if (!a->in_aux || !al16(a->in_aux) || !a->in_gamma || !al16(a->in_gamma) || a->ln_partial || a->gscale || a->padd) return false;
+  if (!a->out[0] || a->out[1] || a->out[2] || a->res[1] || a->res[2] || a->out_nores) return false;
+  if ((a->out_ld[0] & 3) || !al16(a->out[0]) || (a->res[0] && ((a->res_ld[0] & 3) || !al16(a->res[0])))) return false;
+  if (a->in_add && !al16(a->in_add)) return false;
+  if (a->gadd && (!al16(a->gadd) || !a->gadd_s || !a->gadd_r)) return false;
+  if (a->in_save && !al16(a->in_save)) return false;
+  if ((reinterpret_cast<size_t>(a->in_stats) & 7) || !al16(a->dw_partial) || (a->dw_partial_stride & 3)) return false;
+  return true;
+}
+extern "C" int gfv_hidden_size(void);
+extern "C" int gfv_f16split_enabled(void);
+extern "C" int gfv_rowtile_dw_partials(void) { return cc_cus(); }
+extern "C" int gfv_rowtile_fuses_dw(const gfv_rowtile_args_t* a) {
+  if (!a || gfv_hidden_size() != 128 || gfv_f16split_enabled() == 0) return 0;
+  gfv_rowtile_args_t t = *a;
+  t.pad_ = 128;
+  return cc_bwd_ok(&t) ? 1 : 0;
+}
+
+// 1: launched; 2: launched with fused weight gradients; 0: not this family's launch
 int gfv_internal_colchain_try(const gfv_rowtile_args_t* a, hipStream_t stream) {
-  static const int on = cc_env("GFV_COLCHAIN", 1);
+  if (a->pad_ == 128 && cc_bwd_ok(a)) {
+    int* st = gfv_internal_status_ptr();
+    if (!st) return 0;
+    const dim3 grid(cc_cus()), blk(64 * CC_W);
+    if (a->pad3_ != 0) hipLaunchKernelGGL((colchain_bwd_kernel<true>), grid, blk, 0, stream, *a, st);
+    else hipLaunchKernelGGL((colchain_bwd_kernel<false>), grid, blk, 0, stream, *a, st);
+    return 2;
+  }
+  if (a->dw_partial) return 0;   // (the caller asked gfv_rowtile_fuses_dw first; anything else is an argument error upstream)
+  static const int on = cc_env("GFV_COLCHAIN", 0);
   static const int min_m = cc_env("GFV_COLCHAIN_MIN_M", 16384);
   if (a->flags & GFV_CHAIN_ROW_OWNER) return 0;
   if (!(a->flags & GFV_CHAIN_COLUMN_OWNER) && (!on || a->M < min_m)) return 0;
@@ -58,16 +102,24 @@ int gfv_internal_colchain_try(const gfv_rowtile_args_t* a, hipStream_t stream) {
   if (!fwd) return 0;
   if (!al16(a->fin_gamma) || !al16(a->fin_beta) || (a->fin_presave && !al16(a->fin_presave))) return 0;
   if (node && a->padd) return 0;
-  const dim3 grid(cc_cus()), blk(64 * CC_W);
+  static const int lite = cc_env("GFV_COLCHAIN_LITE", 1);   // 1: the high-occupancy form (2 workgroups per CU), 0: resident weights
+  const dim3 blk(64 * CC_W);
   const bool lowp = a->pad3_ != 0;
-#define CC_LAUNCH(KT0, N0, TG, PADD)                                                                                          \
+#define CC_LAUNCH(KT0, N0, TG, PADD, LITE)                                                                                    \
   do {                                                                                                                        \
-    if (lowp) hipLaunchKernelGGL((colchain_fwd_kernel<KT0, N0, TG, PADD, true>), grid, blk, 0, stream, *a, status);           \
-    else hipLaunchKernelGGL((colchain_fwd_kernel<KT0, N0, TG, PADD, false>), grid, blk, 0, stream, *a, status);               \
+    const dim3 grid(cc_cus() * (LITE ? 2 : 1));                                                                               \
+    if (lowp) hipLaunchKernelGGL((colchain_fwd_kernel<KT0, N0, TG, PADD, true, LITE>), grid, blk, 0, stream, *a, status);     \
+    else hipLaunchKernelGGL((colchain_fwd_kernel<KT0, N0, TG, PADD, false, LITE>), grid, blk, 0, stream, *a, status);         \
   } while (0)
-  if (edge && a->padd) CC_LAUNCH(4, 8, 8, true);
-  else if (edge) CC_LAUNCH(4, 8, 8, false);
-  else CC_LAUNCH(6, 4, 6, false);
+  if (lite) {
+    if (edge && a->padd) CC_LAUNCH(4, 8, 4, true, true);
+    else if (edge) CC_LAUNCH(4, 8, 4, false, true);
+    else CC_LAUNCH(6, 4, 2, false, true);
+  } else {
+    if (edge && a->padd) CC_LAUNCH(4, 8, 8, true, false);
+    else if (edge) CC_LAUNCH(4, 8, 8, false, false);
+    else CC_LAUNCH(6, 4, 6, false, false);
+  }
 #undef CC_LAUNCH
   return 1;
 }

@@ -36,6 +36,10 @@ constexpr int CC_W = 8;                  // waves per workgroup
 constexpr float CC_SH = 16.0f;           // fixed scale of hidden activations ahead of the fp16 split
 constexpr float CC_SH_INV = 1.0f / 16.0f;
 constexpr float CC_SH_LIMIT = 2048.0f;   // |a| beyond this raises GFV_FLAG_CHAIN_RANGE
+#ifndef GFV_CC_SPLIT
+#define GFV_CC_SPLIT 0
+#endif
+constexpr bool SPLIT = GFV_CC_SPLIT != 0;   // fragment reads | epilogue of the previous pair | MFMAs (else reads + MFMAs | epilogue)
 
 // LDS carve (bytes).  XIN: the tile's input fragments (KT0 k-groups), later the second hidden layer's (4 k-groups);
 // XMID: the first hidden layer's fragments, later each wave's stash of its last-layer values (TG x 1 KB per wave).
@@ -50,6 +54,15 @@ struct CcLds {
   static constexpr int TOTAL = LNP + TG * 16 * 8 * 8;
 };
 
+// -DGFV_CC_TIMING: per wave, cycles spent in each phase and at each barrier, written through fin_presave's ... no:
+// through `status` + 64 (a debug build takes a bigger status buffer; scratch experiments only)
+#ifdef GFV_CC_TIMING
+#define CT_DECL long long ct_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; long long ct_prev_ = clock64();
+#define CT(k) do { __builtin_amdgcn_s_waitcnt(0xc07f); const long long now_ = clock64(); ct_[k] += now_ - ct_prev_; ct_prev_ = now_; } while (0)
+#else
+#define CT_DECL
+#define CT(k)
+#endif
 __device__ __forceinline__ void cc_barrier() {
   // LDS only: the tile-ahead global loads and the epilogue stores stay in flight across it (a __syncthreads() drains vmcnt)
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -65,7 +78,7 @@ struct CcCtx {
 };
 
 // one pair of groups against this wave's resident weights: acc_q += W[16 w + i][k] x_q[row][k] over KT k-groups
-template <int KT, bool LOWP>
+template <int KT, bool LOWP, bool FENCE = false>
 __device__ __forceinline__ void cc_mma_pair(const char* xbuf, int pair, const gfv_f16x8 (&wh)[KT], const gfv_f16x8 (&wl)[KT],
                                             int lane, floatx4& a0, floatx4& a1) {
   const gfv_f16x8* f0 = reinterpret_cast<const gfv_f16x8*>(xbuf + (size_t)(2 * pair) * KT * 2048) + lane;
@@ -84,6 +97,47 @@ __device__ __forceinline__ void cc_mma_pair(const char* xbuf, int pair, const gf
     }
     a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[T], xh0, a0, 0, 0, 0);
     a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[T], xh1, a1, 0, 0, 0);
+    // (FENCE: the scheduler may not hoist the next k-group's four fragment reads above this one's MFMAs - at a budget of 128
+    // registers sixteen fragments in flight are 64 of them)
+    if (FENCE) __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// the same in two steps, so that the epilogue arithmetic of the previous pair sits between the fragment reads and the MFMAs
+// that consume them (the LDS latency of 16 reads is ~ 1 k cycles for a wave that has nothing else to issue)
+template <int KT, bool LOWP>
+struct CcFrags {
+  gfv_f16x8 h0[KT], h1[KT], l0[LOWP ? 1 : KT], l1[LOWP ? 1 : KT];
+};
+template <int KT, bool LOWP>
+__device__ __forceinline__ void cc_frag_load(const char* xbuf, int pair, int lane, CcFrags<KT, LOWP>& f) {
+  const gfv_f16x8* f0 = reinterpret_cast<const gfv_f16x8*>(xbuf + (size_t)(2 * pair) * KT * 2048) + lane;
+  const gfv_f16x8* f1 = f0 + KT * 128;
+#pragma unroll
+  for (int T = 0; T < KT; ++T) {
+    f.h0[T] = f0[(2 * T) * 64];
+    f.h1[T] = f1[(2 * T) * 64];
+    if (!LOWP) {
+      f.l0[T] = f0[(2 * T + 1) * 64];
+      f.l1[T] = f1[(2 * T + 1) * 64];
+    }
+  }
+}
+template <int KT, bool LOWP>
+__device__ __forceinline__ void cc_mma_frags(const CcFrags<KT, LOWP>& f, const gfv_f16x8 (&wh)[KT], const gfv_f16x8 (&wl)[KT],
+                                             floatx4& a0, floatx4& a1) {
+  a0 = floatx4{0.f, 0.f, 0.f, 0.f};
+  a1 = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int T = 0; T < KT; ++T) {
+    if (!LOWP) {
+      a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[T], f.h0[T], a0, 0, 0, 0);
+      a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[T], f.h1[T], a1, 0, 0, 0);
+      a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[T], f.l0[T], a0, 0, 0, 0);
+      a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[T], f.l1[T], a1, 0, 0, 0);
+    }
+    a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[T], f.h0[T], a0, 0, 0, 0);
+    a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[T], f.h1[T], a1, 0, 0, 0);
   }
 }
 
@@ -203,8 +257,13 @@ __device__ __forceinline__ void cc_park_input(const CcCtx& c, const CcPre<KT0>& 
 // (plain or row-gathered), optional gathered first-layer addend.  KT0 = k-groups of the first layer (K / 32), N0 = 16-column
 // pieces of the first segment,
 // TG = groups of 16 rows per tile (<= 8: one loader wave per group).
-template <int KT0, int N0, int TG, bool PADD, bool LOWP>
-__global__ __launch_bounds__(64 * CC_W, 2) void colchain_fwd_kernel(const gfv_rowtile_args_t A, int* status) {
+// LITE: the high-occupancy form.  The kernels of this family are bound by instruction issue per wave, not by memory or the
+// matrix pipe (profiles/tools/colchain_ablate.py: with every output stream but one removed a launch still takes 58 % of its
+// time), so waves per SIMD are what buys throughput: a wave keeps only the CURRENT layer's weight slice in registers (reloaded
+// from L2 per phase, 4 KB per wave, issued ahead of the barrier that starts the phase), rows are loaded where they are consumed
+// (the second workgroup of the CU covers the latency), the register budget is 128 and two workgroups of 8 waves share a CU.
+template <int KT0, int N0, int TG, bool PADD, bool LOWP, bool LITE>
+__global__ __launch_bounds__(64 * CC_W, LITE ? 4 : 2) void colchain_fwd_kernel(const gfv_rowtile_args_t A, int* status) {
   static_assert(TG <= CC_W && (TG & 1) == 0, "one loader wave per group, groups in pairs");
   using LY = CcLds<KT0, TG>;
   __shared__ __attribute__((aligned(16))) char lds[LY::TOTAL];
@@ -234,14 +293,15 @@ __global__ __launch_bounds__(64 * CC_W, 2) void colchain_fwd_kernel(const gfv_ro
 
   // tile-ahead loads of the first tile go out before anything else
   CcPre<KT0> pre;
-  cc_prefetch<KT0, N0>(A, c, 16 * g_beg, pre);
+  if (!LITE) cc_prefetch<KT0, N0>(A, c, 16 * g_beg, pre);
 
-  // resident weights: this wave's n-tile of every layer's image ([pass][T][nt][part][lane] x 16 B, include/gfv.h)
+  // this wave's n-tile of every layer's image ([pass][T][nt][part][lane] x 16 B, include/gfv.h): resident for the whole launch,
+  // or (LITE) one layer at a time in (wh0, wl0) / (wh1, wl1)
   gfv_f16x8 wh0[KT0], wl0[KT0], wh1[4], wl1[4], wh2[4], wl2[4];
-  {
-    const gfv_f16x8* i0 = reinterpret_cast<const gfv_f16x8*>(A.layer[0].Wh) + (size_t)c.w * 128 + c.lane;
-    const gfv_f16x8* i1 = reinterpret_cast<const gfv_f16x8*>(A.layer[1].Wh) + (size_t)c.w * 128 + c.lane;
-    const gfv_f16x8* i2 = reinterpret_cast<const gfv_f16x8*>(A.layer[2].Wh) + (size_t)c.w * 128 + c.lane;
+  const gfv_f16x8* i0 = reinterpret_cast<const gfv_f16x8*>(A.layer[0].Wh) + (size_t)c.w * 128 + c.lane;
+  const gfv_f16x8* i1 = reinterpret_cast<const gfv_f16x8*>(A.layer[1].Wh) + (size_t)c.w * 128 + c.lane;
+  const gfv_f16x8* i2 = reinterpret_cast<const gfv_f16x8*>(A.layer[2].Wh) + (size_t)c.w * 128 + c.lane;
+  if (!LITE) {
 #pragma unroll
     for (int T = 0; T < KT0; ++T) { wh0[T] = i0[T * 1024]; wl0[T] = i0[T * 1024 + 64]; }
 #pragma unroll
@@ -258,30 +318,44 @@ __global__ __launch_bounds__(64 * CC_W, 2) void colchain_fwd_kernel(const gfv_ro
   const float4 bet = ld4(A.fin_beta + c.col0);
   const float hsc = CC_SH_INV;
 
+  CT_DECL
   for (int t0 = g_beg; t0 < g_end; t0 += TG) {
     c.row0 = 16 * t0;
     c.ngt = min(TG, g_end - t0);
     const int np = (c.ngt + 1) >> 1;
     // ---- P0: the prefetched rows become the tile's input fragments ----
-    if (c.w < TG) cc_park_input<KT0>(c, pre, xin, sinv, idxs, idxr);
+    if (LITE) {
+#pragma unroll
+      for (int T = 0; T < KT0; ++T) { wh0[T] = i0[T * 1024]; wl0[T] = i0[T * 1024 + 64]; }   // layer 0's slice: lands behind the barrier
+      if (c.w < TG) {
+        cc_prefetch<KT0, N0>(A, c, c.row0, pre);
+        cc_park_input<KT0>(c, pre, xin, sinv, idxs, idxr);
+      }
+    } else if (c.w < TG) {
+      cc_park_input<KT0>(c, pre, xin, sinv, idxs, idxr);
+    }
+    CT(0);
     cc_barrier();
+    CT(1);
     // next tile's rows: in flight through the whole tile (after the last tile: every lane re-reads row M - 1, a few cached
     // lines - the loads stay unconditional, a register array filled under a branch is parked in scratch by the compiler)
-    cc_prefetch<KT0, N0>(A, c, t0 + TG < g_end ? 16 * (t0 + TG) : A.M, pre);
+    if (!LITE) cc_prefetch<KT0, N0>(A, c, t0 + TG < g_end ? 16 * (t0 + TG) : A.M, pre);
 
     // ---- P1: layer 0, xin -> xmid ----
     {
       floatx4 a0, a1;
-      cc_mma_pair<KT0, LOWP>(xin, 0, wh0, wl0, c.lane, a0, a1);
+      cc_mma_pair<KT0, LOWP, LITE>(xin, 0, wh0, wl0, c.lane, a0, a1);
       CcAdd pn;
       pn.s0 = pn.r0 = pn.s1 = pn.r1 = zero4;
-      if (PADD) pn = cc_padd_load(A, c, idxs, idxr, 0);
+      if (PADD && !LITE) pn = cc_padd_load(A, c, idxs, idxr, 0);
       for (int p = 0; p < np; ++p) {
         const int pnext = min(p + 1, TG / 2 - 1);
-        const CcAdd pc = pn;
-        if (PADD) pn = cc_padd_load(A, c, idxs, idxr, pnext);
+        // (LITE: the addend rows of THIS pair, loaded ahead of the next pair's MFMAs; else one pair ahead)
+        const CcAdd pc = (LITE && PADD) ? cc_padd_load(A, c, idxs, idxr, p) : pn;
+        if (PADD && !LITE) pn = cc_padd_load(A, c, idxs, idxr, pnext);
         floatx4 n0, n1;
-        cc_mma_pair<KT0, LOWP>(xin, pnext, wh0, wl0, c.lane, n0, n1);
+        cc_mma_pair<KT0, LOWP, LITE>(xin, pnext, wh0, wl0, c.lane, n0, n1);
+
         float v0[4], v1[4];
         cc_hidden_fwd<0, PADD>(c, 2 * p, a0, b0, sinv, pc.s0, pc.r0, xmid, v0);
         cc_hidden_fwd<0, PADD>(c, 2 * p + 1, a1, b0, sinv, pc.s1, pc.r1, xmid, v1);
@@ -289,32 +363,54 @@ __global__ __launch_bounds__(64 * CC_W, 2) void colchain_fwd_kernel(const gfv_ro
         a0 = n0; a1 = n1;
       }
     }
+    if (LITE) {   // layer 1's slice goes out ahead of the barrier
+#pragma unroll
+      for (int T = 0; T < 4; ++T) { wh1[T] = i1[T * 1024]; wl1[T] = i1[T * 1024 + 64]; }
+    }
+    CT(2);
     cc_barrier();
+    CT(3);
     // ---- P2: layer 1, xmid -> xin ----
     {
       floatx4 a0, a1;
-      cc_mma_pair<4, LOWP>(xmid, 0, wh1, wl1, c.lane, a0, a1);
+      cc_mma_pair<4, LOWP, LITE>(xmid, 0, wh1, wl1, c.lane, a0, a1);
       for (int p = 0; p < np; ++p) {
         const int pnext = min(p + 1, TG / 2 - 1);
         floatx4 n0, n1;
-        cc_mma_pair<4, LOWP>(xmid, pnext, wh1, wl1, c.lane, n0, n1);
         float v0[4], v1[4];
-        cc_hidden_fwd<1, false>(c, 2 * p, a0, b1, sinv, zero4, zero4, xin, v0);
-        cc_hidden_fwd<1, false>(c, 2 * p + 1, a1, b1, sinv, zero4, zero4, xin, v1);
+        if (SPLIT && !LITE) {
+          CcFrags<4, LOWP> fr;
+          cc_frag_load<4, LOWP>(xmid, pnext, c.lane, fr);
+          __builtin_amdgcn_sched_barrier(0);
+          cc_hidden_fwd<1, false>(c, 2 * p, a0, b1, sinv, zero4, zero4, xin, v0);
+          cc_hidden_fwd<1, false>(c, 2 * p + 1, a1, b1, sinv, zero4, zero4, xin, v1);
+          __builtin_amdgcn_sched_barrier(0);
+          cc_mma_frags<4, LOWP>(fr, wh1, wl1, n0, n1);
+        } else {
+          cc_mma_pair<4, LOWP, LITE>(xmid, pnext, wh1, wl1, c.lane, n0, n1);
+          cc_hidden_fwd<1, false>(c, 2 * p, a0, b1, sinv, zero4, zero4, xin, v0);
+          cc_hidden_fwd<1, false>(c, 2 * p + 1, a1, b1, sinv, zero4, zero4, xin, v1);
+        }
         cc_save_pair(A.layer[1].save, c, p, v0, v1);
         a0 = n0; a1 = n1;
       }
     }
+    if (LITE) {
+#pragma unroll
+      for (int T = 0; T < 4; ++T) { wh2[T] = i2[T * 1024]; wl2[T] = i2[T * 1024 + 64]; }
+    }
+    CT(4);
     cc_barrier();
+    CT(5);
     // ---- P3: layer 2, xin -> values; LayerNorm partials; the values wait in this wave's stash (xmid is free) ----
     float4* stash = reinterpret_cast<float4*>(xmid + (size_t)c.w * TG * 1024) + c.lane;
     {
       floatx4 a0, a1;
-      cc_mma_pair<4, LOWP>(xin, 0, wh2, wl2, c.lane, a0, a1);
+      cc_mma_pair<4, LOWP, LITE>(xin, 0, wh2, wl2, c.lane, a0, a1);
       for (int p = 0; p < np; ++p) {
         const int pnext = min(p + 1, TG / 2 - 1);
         floatx4 n0, n1;
-        cc_mma_pair<4, LOWP>(xin, pnext, wh2, wl2, c.lane, n0, n1);
+        cc_mma_pair<4, LOWP, LITE>(xin, pnext, wh2, wl2, c.lane, n0, n1);
         float y0[4], y1[4];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -334,15 +430,27 @@ __global__ __launch_bounds__(64 * CC_W, 2) void colchain_fwd_kernel(const gfv_ro
         a0 = n0; a1 = n1;
       }
     }
+    // the residual rows of the whole tile go out ahead of the barrier and ahead of P4's stores (the memory counter is in order:
+    // a load waited for behind stores waits for their acknowledgement too)
+    float4 rres[LITE ? 1 : TG];
+    if (!LITE && A.res[0]) {
+#pragma unroll
+      for (int q = 0; q < TG; ++q)
+        rres[q] = ld4(A.res[0] + (size_t)min(c.row0 + 16 * q + c.j, c.M - 1) * A.res_ld[0] + c.col0);
+    }
+    CT(6);
     cc_barrier();   // (also the write-after-read guard of xin for the next tile's P0)
+    CT(7);
     {
       // ---- P4: LayerNorm over the eight waves' partials, affine, residual, stores ----
-      for (int q = 0; q < c.ngt; ++q) {
+#pragma unroll
+      for (int q = 0; q < TG; ++q) {
+        if (q >= c.ngt) break;
         const int row = c.row0 + 16 * q + c.j;
         const bool live = row < c.M;
         const int rc = live ? row : c.M - 1;
         float4 rv = zero4;
-        if (A.res[0]) rv = ld4(A.res[0] + (size_t)rc * A.res_ld[0] + c.col0);
+        if (A.res[0]) rv = LITE ? ld4(A.res[0] + (size_t)rc * A.res_ld[0] + c.col0) : rres[LITE ? 0 : q];
         const float4* pp = reinterpret_cast<const float4*>(lnp + (q * 16 + c.j) * 16);
         const float4 p0 = pp[0], p1 = pp[1], p2 = pp[2], p3 = pp[3];   // (mean, M2) x 8 waves
         const float mean = (((p0.x + p0.z) + (p1.x + p1.z)) + ((p2.x + p2.z) + (p3.x + p3.z))) * 0.125f;
@@ -351,6 +459,7 @@ __global__ __launch_bounds__(64 * CC_W, 2) void colchain_fwd_kernel(const gfv_ro
         const float m2 = (((p0.y + p0.w) + (p1.y + p1.w)) + ((p2.y + p2.w) + (p3.y + p3.w))) +
                          16.0f * (((e0 * e0 + e1 * e1) + (e2 * e2 + e3 * e3)) + ((e4 * e4 + e5 * e5) + (e6 * e6 + e7 * e7)));
         const float rstd = rsqrtf(m2 * 0.0078125f + 1e-5f);   // nn.LayerNorm eps (EPD.py:32)
+        if (A.fin_stats && live && c.w == 0 && c.g == 0) *reinterpret_cast<float2*>(A.fin_stats + 2 * (size_t)row) = make_float2(mean, rstd);
         const float4 yv = stash[q * 64];
         float o[4] = {(yv.x - mean) * rstd * gam.x + bet.x, (yv.y - mean) * rstd * gam.y + bet.y,
                       (yv.z - mean) * rstd * gam.z + bet.z, (yv.w - mean) * rstd * gam.w + bet.w};
@@ -364,7 +473,371 @@ __global__ __launch_bounds__(64 * CC_W, 2) void colchain_fwd_kernel(const gfv_ro
     // (no barrier here: the next tile's P0 writes xin / sinv / idx, last read before the P3 / P1 barriers; xmid's stash is
     // rewritten as fragments only after the next tile's first barrier)
   }
+#ifdef GFV_CC_TIMING
+  CT(8);
+  if (c.lane == 0 && A.in_aux) {
+    long long* dbg = reinterpret_cast<long long*>(const_cast<float*>(A.in_aux)) + ((size_t)blockIdx.x * CC_W + c.w) * 12;
+    for (int k = 0; k < 12; ++k) dbg[k] = ct_[k];
+  }
+#endif
   if (c.mabs > CC_SH_LIMIT) atomicOr(status, 2);
+}
+
+
+// =====================================================================================================================
+// Backward form: LayerNorm backward -> [W3^T, x gelu'(z2)] -> [W2^T, x gelu'(z1)] -> [W1^T] (+ residual), with the weight
+// gradients of the forward's third and second Linear, their bias gradients and the LayerNorm's (dgamma, dbeta) accumulated on
+// the way (include/gfv.h, gfv_rowtile_args_t.dw_partial).  Replaces, for the big MLP launches, the dX chain of
+// tchain_kernel.h AND two of the three tiles of dw_multi_h_kernel (dw.hip) AND their reads of what the chain wrote:
+// per row the pair moved 4 x 512 B in + 4 x 512 B out (chain) and 4 x 512 B in (the two tiles); this kernel reads
+// dy, y3, z2, z1 and writes gz1 and the input gradient - g3 and gz2 never leave the CU.
+//
+// Everything is column-owner (a wave owns columns 16 w .. 16 w + 15 of every row of the tile):
+//   P0   dy (+ gathered / plain addends), y3 and the row statistics of the forward (in_stats) -> xhat, gg = dy gamma,
+//        (dgamma, dbeta) into lane-private sums, the row sums of the LayerNorm backward as per-wave partials in LDS
+//   P0b  (barrier) g3 = rstd (gg - m1 - xhat m2) -> fragments with ONE power-of-two scale per tile (the weight gradient
+//        contracts over rows: a per-row scale would not factor out of its sums)
+//   P3   (barrier) chain layer 0; epilogue: z2 -> gelu'(z2) for gz2, gelu(z2) = a2 for the weight gradient; both -> fragments
+//   dW3  (barrier) D[n][k] += sum_rows g3[row][n] a2[row][k]: both operands are the transposes of what the fragments hold
+//        (lane = row there, lane = column here) - ds_read_b64_tr_b16 reads them out of the SAME fragment buffers: each 16-lane
+//        group fetches the 8-byte pieces of 4 rows x 16 columns and the hardware transposes them; a wave owns n-tile w
+//        and walks the 8 k-tiles; contraction over 32 rows (two groups) per MFMA, hi / lo split as in the chain
+//   P2   (barrier) chain layer 1; epilogue: z1 -> gz1 (stored: the node-level scatter reads it), a1 -> fragments
+//   P1   (barrier) chain layer 2 -> input gradient (+ residual) stored;  dW2 from (gz2, a1)
+// Three fragment buffers (g3 | gz1, gz2, a2 | a1); tiles of TG = 4 groups (64 rows): 96 KB + 4 KB of partials.
+// Scales: g3 fragments carry s3 = 2^k with s3 max|g3| <= 2^14 over the tile (from a bound taken before the barrier, two
+// orders of magnitude of slack cost nothing: the split keeps 2^13 of headroom below the maximum); gz2 / gz1 carry s3 / 32,
+// s3 / 1024 (growth through a layer beyond 32 x raises GFV_FLAG_CHAIN_RANGE); a2 / a1 the fixed CC_SH.  The weight-gradient
+// accumulators live in units of the current tile's scale and are rescaled (exactly: powers of two) when it changes; the
+// scale may not rise more than 2^20 above the smallest one seen (rows that small add nothing to sums dominated by rows a
+// million times larger).
+constexpr int CB_TG = 4;
+struct CbLds {
+  static constexpr int BUF = CB_TG * 8192;
+  static constexpr int B0 = 0, B1 = BUF, B2 = 2 * BUF;
+  static constexpr int PART = 3 * BUF;                        // float2 [TG][16][8]: per-wave partial (s1, s2) of a row
+  static constexpr int SMAX = PART + CB_TG * 16 * 8 * 8;      // float [8]: per-wave bound of max |g3| over the tile
+  static constexpr int TOTAL = SMAX + 64;
+};
+
+// transposed operand of the weight gradient: columns 16 ct .. 16 ct + 15 of the two groups (q0, q0 + 1) of a fragment buffer,
+// lane (i = column, g') slots e = 4 h + r <- row 4 g' + r of group q0 + h.  One ds_read_b64_tr_b16 per (group, part).
+__device__ __forceinline__ void cb_tr_operand(const char* xbuf, int q0, int ct, int lane, gfv_f16x8& hi, gfv_f16x8& lo) {
+  typedef short s4 __attribute__((ext_vector_type(4)));
+  typedef __attribute__((address_space(3))) s4* lds_s4;
+  const int s = lane & 15, gp = lane >> 4;
+  // source piece of this lane: row 4 g' + (s >> 2), column quad s & 3 of the tile = producer lane group g = s & 3
+  const int off = ((q0 * 4 + (ct >> 1)) * 2) * 1024 + (16 * (s & 3) + 4 * gp + (s >> 2)) * 16 + (ct & 1) * 8;
+  const char* p = xbuf + off;
+  const s4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(p));
+  const s4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(p + 1024));
+  const s4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(p + 8192));
+  const s4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(p + 8192 + 1024));
+  typedef short s8 __attribute__((ext_vector_type(8)));
+  const s8 h = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+  const s8 l = {l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+  hi = __builtin_bit_cast(gfv_f16x8, h);
+  lo = __builtin_bit_cast(gfv_f16x8, l);
+}
+
+// one tile's contribution to a fused weight gradient: acc[kt] += G^T (n-tile w) x A (k-tile kt) over the tile's row pairs;
+// accb += G^T x ones (the bias gradient: every column of the result is the column sum of G)
+template <bool LOWP>
+__device__ __forceinline__ void cb_dw_tile(const char* gbuf, const char* abuf, int npairs, int w, int lane, floatx4 (&acc)[8],
+                                           floatx4& accb) {
+  const _Float16 one = (_Float16)1.0f;
+  const gfv_f16x8 ones = {one, one, one, one, one, one, one, one};
+  for (int pr = 0; pr < npairs; ++pr) {
+    gfv_f16x8 gh, gl;
+    cb_tr_operand(gbuf, 2 * pr, w, lane, gh, gl);
+    if (!LOWP) accb = __builtin_amdgcn_mfma_f32_16x16x32_f16(gl, ones, accb, 0, 0, 0);
+    accb = __builtin_amdgcn_mfma_f32_16x16x32_f16(gh, ones, accb, 0, 0, 0);
+#pragma unroll
+    for (int kt = 0; kt < 8; ++kt) {
+      gfv_f16x8 ah, al;
+      cb_tr_operand(abuf, 2 * pr, kt, lane, ah, al);
+      if (!LOWP) {
+        acc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(gl, ah, acc[kt], 0, 0, 0);
+        acc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(gh, al, acc[kt], 0, 0, 0);
+      }
+      acc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(gh, ah, acc[kt], 0, 0, 0);
+    }
+  }
+}
+
+// chain-layer epilogue of one group in the backward form (GFV_OP_MUL_DGELU): v = acc / scales x gelu'(z) -> fragments with
+// the scale `sg`; a = gelu(z) -> fragments with CC_SH (the weight gradient's other operand); v is handed back for the save
+__device__ __forceinline__ void cb_hidden_bwd(CcCtx& c, int q, const floatx4& acc, float inv_in, const float4& z, float sg,
+                                              char* gout, char* aout, float (&v)[4]) {
+  const float zz[4] = {z.x, z.y, z.z, z.w};
+  float a[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    // gelu and gelu' share the erfc evaluation (gfv_common.h)
+    const gfv_erfc_t e = gfv_erfc_half(zz[r]);
+    const float cdf = zz[r] >= 0.0f ? 1.0f - e.y : e.y;
+    const float dg = fmaf(zz[r] * 0.39894228040143267794f, e.e, cdf);
+    a[r] = fmaf(-fabsf(zz[r]), e.y, fmaxf(zz[r], 0.0f));
+    v[r] = ((acc[r] * inv_in) * c.invw) * dg;
+  }
+  const float mq = max3_abs(max3_abs(0.f, v[0], v[1]), v[2], v[3]) * sg;
+  const float ma = max3_abs(max3_abs(0.f, a[0], a[1]), a[2], a[3]) * (CC_SH * (1.0f / 32.0f));   // (a against CC_SH_LIMIT x 32 = 65536)
+  c.mabs = fmaxf(c.mabs, q < c.ngt ? fmaxf(mq, ma) : 0.f);
+  cc_put_frag(gout, q, c, v, sg);
+  cc_put_frag(aout, q, c, a, CC_SH);
+}
+
+template <bool LOWP>
+__global__ __launch_bounds__(64 * CC_W, 2) void colchain_bwd_kernel(const gfv_rowtile_args_t A, int* status) {
+  constexpr int TG = CB_TG;
+  __shared__ __attribute__((aligned(16))) char lds[CbLds::TOTAL];
+  char* b0 = lds + CbLds::B0;
+  char* b1 = lds + CbLds::B1;
+  char* b2 = lds + CbLds::B2;
+  float* part = reinterpret_cast<float*>(lds + CbLds::PART);
+  float* smax = reinterpret_cast<float*>(lds + CbLds::SMAX);
+
+  CcCtx c;
+  c.w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  c.lane = threadIdx.x & 63;
+  c.j = c.lane & 15;
+  c.g = c.lane >> 4;
+  c.col0 = 16 * c.w + 4 * c.g;
+  c.M = A.M;
+  c.mabs = 0.f;
+  c.invw = 1.0f / gfv_pow2_scale(*A.wmax);
+
+  const int nwg = gridDim.x;
+  const int wg = (nwg & 7) == 0 ? (int)(blockIdx.x & 7) * (nwg >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  const int NG = (A.M + 15) >> 4;
+  const int g_beg = (int)((long)NG * wg / nwg), g_end = (int)((long)NG * (wg + 1) / nwg);
+
+  // resident weights: this wave's n-tile of the three transposed layers' images
+  gfv_f16x8 wh0[4], wl0[4], wh1[4], wl1[4], wh2[4], wl2[4];
+  {
+    const gfv_f16x8* i0 = reinterpret_cast<const gfv_f16x8*>(A.layer[0].Wh) + (size_t)c.w * 128 + c.lane;
+    const gfv_f16x8* i1 = reinterpret_cast<const gfv_f16x8*>(A.layer[1].Wh) + (size_t)c.w * 128 + c.lane;
+    const gfv_f16x8* i2 = reinterpret_cast<const gfv_f16x8*>(A.layer[2].Wh) + (size_t)c.w * 128 + c.lane;
+#pragma unroll
+    for (int T = 0; T < 4; ++T) {
+      wh0[T] = i0[T * 1024]; wl0[T] = i0[T * 1024 + 64];
+      wh1[T] = i1[T * 1024]; wl1[T] = i1[T * 1024 + 64];
+      wh2[T] = i2[T * 1024]; wl2[T] = i2[T * 1024 + 64];
+    }
+  }
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float4 gam = ld4(A.in_gamma + c.col0);
+  // fused weight gradients: D[n = 16 w + 4 g + r][k = 16 kt + j] in lane (j, g) of acc[kt][r]
+  floatx4 dw3[8], dw2[8], db3 = floatx4{0.f, 0.f, 0.f, 0.f}, db2 = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int kt = 0; kt < 8; ++kt) dw3[kt] = dw2[kt] = floatx4{0.f, 0.f, 0.f, 0.f};
+  float dgam[4] = {0.f, 0.f, 0.f, 0.f}, dbet[4] = {0.f, 0.f, 0.f, 0.f};
+  float sacc = 0.f;          // scale the g3-side accumulators are in (0: nothing accumulated yet); the gz2 side: sacc / 32
+  float scap = 3.0e38f;      // 2^20 x the smallest tile scale so far
+  const bool have_res = A.res[0] != nullptr;
+
+  for (int t0 = g_beg; t0 < g_end; t0 += TG) {
+    c.row0 = 16 * t0;
+    c.ngt = min(TG, g_end - t0);
+    const int np = (c.ngt + 1) >> 1;
+    // ---- P0: LayerNorm backward, first half ----
+    float gg[TG][4], xh[TG][4], rs[TG];
+    {
+      float bmax = 0.f;
+      float4 dy[TG], yv[TG];
+      float2 st[TG];
+#pragma unroll
+      for (int q = 0; q < TG; ++q) {
+        const int row = min(c.row0 + 16 * q + c.j, c.M - 1);
+        dy[q] = ld4(A.seg[0].ptr + (size_t)row * A.seg[0].ld + c.col0);
+        yv[q] = ld4(A.in_aux + (size_t)row * 128 + c.col0);
+        st[q] = *reinterpret_cast<const float2*>(A.in_stats + 2 * (size_t)row);
+      }
+      if (A.in_add) {
+#pragma unroll
+        for (int q = 0; q < TG; ++q) {
+          const int row = min(c.row0 + 16 * q + c.j, c.M - 1);
+          const float4 t = ld4(A.in_add + (size_t)row * A.seg[0].ld + c.col0);
+          dy[q].x += t.x; dy[q].y += t.y; dy[q].z += t.z; dy[q].w += t.w;
+        }
+      }
+      if (A.gadd) {
+        // + [gadd[s] (64) | gadd[r] (64)]: this wave's 16 columns lie in one half
+        const int* gi = c.w < 4 ? A.gadd_s : A.gadd_r;
+        const int gc = (c.col0 & 63);
+#pragma unroll
+        for (int q = 0; q < TG; ++q) {
+          const int row = min(c.row0 + 16 * q + c.j, c.M - 1);
+          const float4 t = ld4(A.gadd + (size_t)gi[row] * 64 + gc);
+          dy[q].x += t.x; dy[q].y += t.y; dy[q].z += t.z; dy[q].w += t.w;
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < TG; ++q) {
+        const bool live = q < c.ngt && c.row0 + 16 * q + c.j < c.M;
+        const float lf = live ? 1.0f : 0.0f;   // rows past M / dead groups must not reach any sum over rows
+        const float d[4] = {dy[q].x * lf, dy[q].y * lf, dy[q].z * lf, dy[q].w * lf};
+        const float y[4] = {yv[q].x, yv[q].y, yv[q].z, yv[q].w};
+        const float gm[4] = {gam.x, gam.y, gam.z, gam.w};
+        const float mean = st[q].x, rstd = st[q].y;
+        rs[q] = rstd;
+        float s1 = 0.f, s2 = 0.f, am = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          xh[q][r] = (y[r] - mean) * rstd;
+          dgam[r] += d[r] * xh[q][r];
+          dbet[r] += d[r];
+          gg[q][r] = d[r] * gm[r];
+          s1 += gg[q][r];
+          s2 += gg[q][r] * xh[q][r];
+          am = fmaxf(am, fabsf(gg[q][r]));
+        }
+        s1 = row_sum(s1);
+        s2 = row_sum(s2);
+        if (c.g == 0) *reinterpret_cast<float2*>(part + ((q * 16 + c.j) * 8 + c.w) * 2) = make_float2(s1, s2);
+        bmax = fmaxf(bmax, live ? am * fabsf(rstd) : 0.f);
+      }
+      bmax = gfv_wave_max(bmax);
+      if (c.lane == 0) smax[c.w] = bmax;
+    }
+    cc_barrier();
+    // ---- P0b: g3 and its fragments ----
+    float s3;
+    {
+      const float4 ma = *reinterpret_cast<const float4*>(smax), mb = *reinterpret_cast<const float4*>(smax + 4);
+      const float mx = fmaxf(fmaxf(fmaxf(ma.x, ma.y), fmaxf(ma.z, ma.w)), fmaxf(fmaxf(mb.x, mb.y), fmaxf(mb.z, mb.w)));
+      // |g3| <= rstd (|gg| + |m1| + |xhat| |m2|) <= rstd max|gg| (2 + 128): the bound, not the maximum, sets the scale
+      s3 = fminf(gfv_pow2_scale(mx * 130.0f) * 2.0f, scap);
+      scap = fminf(scap, s3 * 1048576.0f);
+#pragma unroll
+      for (int q = 0; q < TG; ++q) {
+        const float4* pp = reinterpret_cast<const float4*>(part + (q * 16 + c.j) * 16);
+        const float4 p0 = pp[0], p1 = pp[1], p2 = pp[2], p3 = pp[3];   // (s1, s2) x 8 waves
+        const float m1 = (((p0.x + p0.z) + (p1.x + p1.z)) + ((p2.x + p2.z) + (p3.x + p3.z))) * 0.0078125f;
+        const float m2 = (((p0.y + p0.w) + (p1.y + p1.w)) + ((p2.y + p2.w) + (p3.y + p3.w))) * 0.0078125f;
+        float g3[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) g3[r] = rs[q] * (gg[q][r] - m1 - xh[q][r] * m2);
+        const int row = c.row0 + 16 * q + c.j;
+        if (A.in_save && q < c.ngt && row < c.M) st4(A.in_save + (size_t)row * 128 + c.col0, g3);
+        cc_put_frag(b0, q, c, g3, s3);
+      }
+    }
+    // the accumulators move to this tile's units
+    if (sacc != 0.f && sacc != s3) {
+      const float ratio = s3 / sacc;
+#pragma unroll
+      for (int kt = 0; kt < 8; ++kt) { dw3[kt] *= ratio; dw2[kt] *= ratio; }
+      db3 *= ratio;
+      db2 *= ratio;
+    }
+    sacc = s3;
+    const float s2s = s3 * 0.03125f, s1s = s3 * 0.0009765625f;
+    cc_barrier();
+    // ---- P3: chain layer 0 (b0 -> gz2 in b1, a2 in b2) ----
+    {
+      const float inv_in = 1.0f / s3;
+      floatx4 a0, a1;
+      cc_mma_pair<4, LOWP>(b0, 0, wh0, wl0, c.lane, a0, a1);
+      for (int p = 0; p < np; ++p) {
+        const int pnext = min(p + 1, TG / 2 - 1);
+        const int r0 = min(c.row0 + 32 * p + c.j, c.M - 1), r1 = min(c.row0 + 32 * p + 16 + c.j, c.M - 1);
+        const float4 z0 = ld4(A.layer[0].aux + (size_t)r0 * 128 + c.col0), z1 = ld4(A.layer[0].aux + (size_t)r1 * 128 + c.col0);
+        floatx4 n0, n1;
+        cc_mma_pair<4, LOWP>(b0, pnext, wh0, wl0, c.lane, n0, n1);
+        float v0[4], v1[4];
+        cb_hidden_bwd(c, 2 * p, a0, inv_in, z0, s2s, b1, b2, v0);
+        cb_hidden_bwd(c, 2 * p + 1, a1, inv_in, z1, s2s, b1, b2, v1);
+        cc_save_pair(A.layer[0].save, c, p, v0, v1);
+        a0 = n0; a1 = n1;
+      }
+    }
+    cc_barrier();
+    // ---- dW3 += g3^T a2 ----
+    cb_dw_tile<LOWP>(b0, b2, np, c.w, c.lane, dw3, db3);
+    cc_barrier();
+    // ---- P2: chain layer 1 (b1 -> gz1 in b0, a1 in b2) ----
+    {
+      const float inv_in = 1.0f / s2s;
+      floatx4 a0, a1;
+      cc_mma_pair<4, LOWP>(b1, 0, wh1, wl1, c.lane, a0, a1);
+      for (int p = 0; p < np; ++p) {
+        const int pnext = min(p + 1, TG / 2 - 1);
+        const int r0 = min(c.row0 + 32 * p + c.j, c.M - 1), r1 = min(c.row0 + 32 * p + 16 + c.j, c.M - 1);
+        const float4 z0 = ld4(A.layer[1].aux + (size_t)r0 * 128 + c.col0), z1 = ld4(A.layer[1].aux + (size_t)r1 * 128 + c.col0);
+        floatx4 n0, n1;
+        cc_mma_pair<4, LOWP>(b1, pnext, wh1, wl1, c.lane, n0, n1);
+        float v0[4], v1[4];
+        cb_hidden_bwd(c, 2 * p, a0, inv_in, z0, s1s, b0, b2, v0);
+        cb_hidden_bwd(c, 2 * p + 1, a1, inv_in, z1, s1s, b0, b2, v1);
+        cc_save_pair(A.layer[1].save, c, p, v0, v1);
+        a0 = n0; a1 = n1;
+      }
+    }
+    cc_barrier();
+    // ---- P1: chain layer 2 (b0 -> the input gradient) and dW2 += gz2^T a1 ----
+    {
+      const float inv_in = 1.0f / s1s;
+      floatx4 a0, a1;
+      cc_mma_pair<4, LOWP>(b0, 0, wh2, wl2, c.lane, a0, a1);
+      for (int p = 0; p < np; ++p) {
+        const int pnext = min(p + 1, TG / 2 - 1);
+        const int r0 = c.row0 + 32 * p + c.j, r1 = r0 + 16;
+        float4 x0 = zero4, x1 = zero4;
+        if (have_res) {
+          x0 = ld4(A.res[0] + (size_t)min(r0, c.M - 1) * A.res_ld[0] + c.col0);
+          x1 = ld4(A.res[0] + (size_t)min(r1, c.M - 1) * A.res_ld[0] + c.col0);
+        }
+        floatx4 n0, n1;
+        cc_mma_pair<4, LOWP>(b0, pnext, wh2, wl2, c.lane, n0, n1);
+        float o0[4], o1[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          o0[r] = (a0[r] * inv_in) * c.invw;
+          o1[r] = (a1[r] * inv_in) * c.invw;
+        }
+        o0[0] += x0.x; o0[1] += x0.y; o0[2] += x0.z; o0[3] += x0.w;
+        o1[0] += x1.x; o1[1] += x1.y; o1[2] += x1.z; o1[3] += x1.w;
+        if (2 * p < c.ngt && r0 < c.M) st4(A.out[0] + (size_t)r0 * A.out_ld[0] + c.col0, o0);
+        if (2 * p + 1 < c.ngt && r1 < c.M) st4(A.out[0] + (size_t)r1 * A.out_ld[0] + c.col0, o1);
+        a0 = n0; a1 = n1;
+      }
+    }
+    cb_dw_tile<LOWP>(b1, b2, np, c.w, c.lane, dw2, db2);
+    // (the next tile's P0 writes only `part` / `smax`, last read in P0b; its P0b writes b0 behind the barrier that follows P0)
+  }
+
+  // ---- the workgroup's partial block: [dW3 | db3 | dW2 | db2 | dgamma | dbeta] (include/gfv.h) ----
+  if (A.dw_partial) {
+    float* blk = A.dw_partial + (size_t)blockIdx.x * A.dw_partial_stride;
+    const float u3 = sacc != 0.f ? (1.0f / sacc) * CC_SH_INV : 0.f, u2 = sacc != 0.f ? (32.0f / sacc) * CC_SH_INV : 0.f;
+    const float ub3 = sacc != 0.f ? 1.0f / sacc : 0.f, ub2 = sacc != 0.f ? 32.0f / sacc : 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 8; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = 16 * c.w + 4 * c.g + r, k = 16 * kt + c.j;
+        blk[n * 128 + k] = dw3[kt][r] * u3;
+        blk[16384 + 128 + n * 128 + k] = dw2[kt][r] * u2;
+      }
+    if (c.j == 0) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        blk[16384 + 16 * c.w + 4 * c.g + r] = db3[r] * ub3;
+        blk[2 * 16384 + 128 + 16 * c.w + 4 * c.g + r] = db2[r] * ub2;
+      }
+    }
+    // (dgamma, dbeta): lane-private sums over the rows j and the groups this lane saw -> sum over the 16 lanes of a DPP row
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float dg = gfv_row16_sum(dgam[r]), db = gfv_row16_sum(dbet[r]);
+      if (c.j == 0) {
+        blk[2 * 16384 + 256 + c.col0 + r] = dg;
+        blk[2 * 16384 + 384 + c.col0 + r] = db;
+      }
+    }
+  }
+  if (c.mabs > 60000.0f) atomicOr(status, 2);
 }
 
 }  // namespace

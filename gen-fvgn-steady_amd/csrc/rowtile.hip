@@ -611,11 +611,16 @@ extern "C" int gfv_rowtile_chain(const gfv_rowtile_args_t* args, void* stream) {
     tok = gfv_prof_begin(kind, fl, by, (hipStream_t)stream);
   }
   g_last_path = (tchain_mode() != 0 && (fast_t || rag_t)) ? ((fast_t ? 1 : 2) + (f16 ? 4 : 0)) : 0;
-  if (fast_t && tchain_mode() != 0)
-    g_last_path += 8 * gfv_internal_tchain_launch(args, 0, f16 ? 1 : 0, (hipStream_t)stream);   // (1: the column-owner family took it)
+  if (args->dw_partial && !(fast_t && tchain_mode() != 0 && f16)) return GFV_ERR_ARG;   // (fused weight gradients: ask gfv_rowtile_fuses_dw first)
+  if (fast_t && tchain_mode() != 0) {
+    const int took = gfv_internal_tchain_launch(args, 0, f16 ? 1 : 0, (hipStream_t)stream);   // 1: the column-owner family, 2: with fused dW
+    if (args->dw_partial && took != 2) return GFV_ERR_ARG;
+    g_last_path += 8 * took;
+  }
   else if (rag_t && tchain_mode() != 0)
     gfv_internal_tchain_launch(args, 1, f16 ? 1 : 0, (hipStream_t)stream);
   else {
+    if (args->fin_stats) return GFV_ERR_ARG;   // (the generic row-tile kernel does not write them)
     gfv_rowtile_args_t local = *args;
     local.pad_ = g_hidden;   // LayerNorm width (gfv_set_hidden_size)
     if (fast) hipLaunchKernelGGL(rowtile_chain_kernel<true>, dim3(tiles), dim3(256), 0, (hipStream_t)stream, local);

@@ -53,7 +53,10 @@ int gfv_internal_tchain_launch(const gfv_rowtile_args_t* args_in, int ragged, in
   const gfv_rowtile_args_t* args = &local;
   const int lnm = args->in_op == GFV_IN_LNBWD ? 1 : (args->fin_op == GFV_FIN_LNBWD ? 2 : 0);
   const dim3 wgs((args->M + 63) / 64), blk(256);
-  if (f16 && !ragged && gfv_internal_colchain_try(args, stream)) return 1;   // the column-owner persistent family
+  if (f16 && !ragged) {   // the column-owner persistent family
+    const int took = gfv_internal_colchain_try(args, stream);
+    if (took) return took;
+  }
   if (f16) {
     // (an 8-wave workgroup sharing one weight stream over 128 rows - launch_h<8> - was measured in round 2: 5.28 ms / step
     // against 4.96 with it on the 75 k-row launches, 5.29 with it everywhere; the 4-wave form stays)

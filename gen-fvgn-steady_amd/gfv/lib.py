@@ -45,7 +45,11 @@ class RowtileArgs(C.Structure):
         ("out_nores", C.c_void_p), ("padd", C.c_void_p), ("padd_s", C.c_void_p), ("padd_r", C.c_void_p),
         ("padd_ld", C.c_int32), ("flags", C.c_int32), ("wmax", C.c_void_p),
         ("gscale", C.c_void_p), ("gscale_ld", C.c_int32), ("pad3_", C.c_int32),
+        ("fin_stats", C.c_void_p), ("in_stats", C.c_void_p), ("dw_partial", C.c_void_p), ("dw_partial_stride", C.c_int64),
     ]
+
+
+DW_FUSED_FLOATS = 2 * 128 * 128 + 4 * 128   # floats per workgroup block of a fused weight-gradient launch (include/gfv.h)
 
 
 class WimgDesc(C.Structure):
@@ -85,6 +89,8 @@ _SIGNATURES = {
     "gfv_rowtile_tiles": (C.c_int, [C.c_int32]),
     "gfv_rowtile_chain": (C.c_int, [C.POINTER(RowtileArgs), C.c_void_p]),
     "gfv_rowtile_last_path": (C.c_int, []),
+    "gfv_rowtile_dw_partials": (C.c_int, []),
+    "gfv_rowtile_fuses_dw": (C.c_int, [C.POINTER(RowtileArgs)]),
     "gfv_dw_chunks": (C.c_int, [C.c_int32]),
     "gfv_linear_dw_workspace_floats": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     "gfv_linear_dw": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(Seg), C.c_int32, C.c_void_p, C.c_int32,

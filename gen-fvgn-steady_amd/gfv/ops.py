@@ -228,12 +228,16 @@ def set_weight_images(wi):
 def rowtile_chain(M, segs, layers, outs, *, in_add=None, in_op=L.IN_NONE, in_gamma=None, in_beta=None, in_aux=None,
                   gadd=None, gadd_s=None, gadd_r=None, in_save=None, ln_partial=None, fin_op=L.FIN_PLAIN,
                   fin_gamma=None, fin_beta=None, fin_aux=None, fin_presave=None, res=None, out_nores=None,
-                  padd=None, padd_s=None, padd_r=None, wimg=None, gscale=None, family=0):
+                  padd=None, padd_s=None, padd_r=None, wimg=None, gscale=None, family=0, fin_stats=None, in_stats=None,
+                  dw_partial=None, query_fused=False):
     """Launch the fused row-tile GEMM chain.  outs / res: list (per 128-wide chunk of the last layer) of
     (tensor, ld) or tensors; see include/gfv.h for the semantics of every field.  gscale: [3, ld] buffer for the
     per-16-row scales of the gradient rows the launch leaves behind; returns True when the launch wrote it (split-fp16
     form), so the weight-gradient launch may take its slots instead of a pass over the rows.  family: 0 = the library picks
-    the kernel family, lib.CHAIN_ROW_OWNER / lib.CHAIN_COLUMN_OWNER pin it (include/gfv.h, gfv_rowtile_args_t.flags)."""
+    the kernel family, lib.CHAIN_ROW_OWNER / lib.CHAIN_COLUMN_OWNER pin it (include/gfv.h, gfv_rowtile_args_t.flags).
+    fin_stats / in_stats: [M, 2] LayerNorm row statistics out of a forward / into a backward launch; dw_partial:
+    [gfv_rowtile_dw_partials(), DW_FUSED_FLOATS] workspace of a backward chain with fused weight gradients; query_fused:
+    do not launch, return whether the library would run this launch with fused weight gradients (gfv_rowtile_fuses_dw)."""
     lib = L.load()
     wi = wimg if wimg is not None else _WI
     if layers[-1].stack is not None:
@@ -289,11 +293,16 @@ def rowtile_chain(M, segs, layers, outs, *, in_add=None, in_op=L.IN_NONE, in_gam
             a.res_ld[i] = ld
     a.out_nores = _p(out_nores)
     a.flags = family
+    a.fin_stats, a.in_stats = _p(fin_stats), _p(in_stats)
+    if dw_partial is not None:
+        a.dw_partial, a.dw_partial_stride = dw_partial.data_ptr(), dw_partial.stride(0)
     if padd is not None:
         a.padd, a.padd_s, a.padd_r, a.padd_ld = _p(padd), _p(padd_s), _p(padd_r), padd.stride(0)
     if gscale is not None:
         assert gscale.dim() == 2 and gscale.shape[0] >= 3 and gscale.shape[1] >= gscale_ld(M)
         a.gscale, a.gscale_ld = gscale.data_ptr(), gscale.stride(0)
+    if query_fused:
+        return bool(lib.gfv_rowtile_fuses_dw(C.byref(a)))
     rc = lib.gfv_rowtile_chain(C.byref(a), L.stream_ptr())
     L.check(rc, "gfv_rowtile_chain")
     return gscale is not None and lib.gfv_rowtile_last_path() >= 5

@@ -141,13 +141,31 @@ typedef struct {
   float* gscale;
   int32_t gscale_ld;
   int32_t pad3_;          /* reserved: leave 0 (the launcher passes the product form to the kernel here) */
+  /* LayerNorm statistics of the rows, [M, 2] = (mean, 1 / sqrt(var + eps)): written by a GFV_FIN_LN launch when fin_stats is
+   * given, read by a GFV_IN_LNBWD launch when in_stats is given (the column-owner backward needs them: its LayerNorm backward
+   * is spread over eight waves and takes the row statistics as they were in the forward instead of recomputing them) */
+  float* fin_stats;
+  const float* in_stats;
+  /* Weight gradients fused into a dX chain (column-owner family only; gfv_rowtile_fuses_dw() tells whether a launch takes
+   * it).  A backward chain [W3^T (x gelu'(z2)), W2^T (x gelu'(z1)), W1^T] holds, tile by tile, exactly the operands of the
+   * weight gradients of the forward's third and second Linear:  dW3 = g3^T gelu(z2),  dW2 = gz2^T gelu(z1)  (g3 = the
+   * prologue result, gz2 = layer 0's product, z2 / z1 = layer[0].aux / layer[1].aux), their bias gradients (column sums of
+   * g3 / gz2) and the LayerNorm's (dgamma, dbeta).  With dw_partial set the launch accumulates them per workgroup - no float
+   * atomics - and leaves  dw_partial[wg * dw_partial_stride + ...] = [dW3 (128 x 128, row n, column k) | db3 (128) | dW2 |
+   * db2 | dgamma | dbeta]  (GFV_DW_FUSED_FLOATS floats) for wg < gfv_rowtile_dw_partials(); sum them with gfv_reduce_multi.
+   * layer[0].save / in_save / ln_partial may then be NULL (nothing else reads g3 / gz2). */
+  float* dw_partial;
+  int64_t dw_partial_stride;
 } gfv_rowtile_args_t;
+enum { GFV_DW_FUSED_FLOATS = 2 * 128 * 128 + 4 * 128 };
+int gfv_rowtile_dw_partials(void);                              /* workgroups (= partial blocks) of a fused launch */
+int gfv_rowtile_fuses_dw(const gfv_rowtile_args_t* args);       /* 1: gfv_rowtile_chain would run this launch with fused weight gradients */
 
 int gfv_rowtile_tiles(int32_t M); /* number of 64-row tiles = rows of ln_partial */
 int gfv_rowtile_chain(const gfv_rowtile_args_t* args, void* stream);
 /* which kernel the calling thread's last gfv_rowtile_chain launch took: 0 generic LDS row-tile, 1 register-resident
  * chain, 2 its ragged-shape instantiation; + 4 when the products ran as split-fp16; + 8 when the column-owner persistent
- * family took the launch (tests assert the path they mean) */
+ * family took the launch, + 16 when it ran with fused weight gradients (tests assert the path they mean) */
 int gfv_rowtile_last_path(void);
 
 /* fp32 products on the f16 MFMA pipe (v_mfma_f32_16x16x32_f16, 16x the f32 MFMA rate): every fp32 operand is split

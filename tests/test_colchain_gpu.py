@@ -132,3 +132,65 @@ def test_column_owner_hidden_range_flag(dev):
                       fin_beta=Pd["beta"], wimg=wi, family=L.CHAIN_COLUMN_OWNER)
     L.check(L.load().gfv_status_flags(L.C.byref(flags)), "gfv_status_flags")
     assert flags.value & 2
+
+
+@pytest.mark.parametrize("M", [4000, 97, 1024])
+@pytest.mark.parametrize("extras", [True, False])
+def test_column_owner_backward_with_fused_weight_gradients(dev, M, extras):
+    """EdgeBlock backward in its factored form: LayerNorm backward, the three transposed layers, residual; with the weight
+    gradients of the third and second Linear, their bias gradients and (dgamma, dbeta) accumulated by the same launch
+    (include/gfv.h, gfv_rowtile_args_t.dw_partial) - every piece against float64 autograd."""
+    from gfv import lib as L, ops
+    g = torch.Generator().manual_seed(M + 7 * extras)
+    n_nodes = 300
+    e = torch.randn(M, 128, generator=g)
+    P = _params(g, 128)
+    Pg = {k: v.double().requires_grad_(True) for k, v in P.items()}
+    X = e.double().requires_grad_(True)
+    z1, z2, y3, ln = _ref(Pg, X)
+    go = torch.randn(M, 128, generator=g) * torch.logspace(-5, 0, M)[:, None]     # gradient rows over five decades
+    gagg = torch.randn(n_nodes, 64, generator=g) * 1e-2
+    s = torch.randint(0, n_nodes, (M,), generator=g)
+    r = torch.randint(0, n_nodes, (M,), generator=g)
+    gadd2 = torch.randn(M, 128, generator=g) * 1e-3
+    go_total = go.double()
+    if extras:
+        go_total = go_total + torch.cat((gagg[s], gagg[r]), 1).double() + gadd2.double()
+    (ln * go_total).sum().backward()
+    d = lambda t: t.to(dev).contiguous()
+    Pd = {k: d(v) for k, v in P.items()}
+    z1d, z2d, y3d = d(z1.detach().float()), d(z2.detach().float()), d(y3.detach().float())
+    mean = y3.detach().mean(1)
+    rstd = (y3.detach().var(1, unbiased=False) + 1e-5).rsqrt()
+    stats = d(torch.stack((mean, rstd), 1).float())
+    W3t, W2t, W1t = ops.transpose(Pd["W3"]), ops.transpose(Pd["W2"]), ops.transpose(Pd["W1"])
+    wi = _images(dev, [P["W1"], P["W2"], P["W3"]])
+    god = d(go)
+    gz1 = torch.full((M, 128), float("nan"), device=dev)
+    ge = torch.full((M, 128), float("nan"), device=dev)
+    nwg = L.load().gfv_rowtile_dw_partials()
+    part = torch.full((nwg, L.DW_FUSED_FLOATS), float("nan"), device=dev)
+    kw = dict(gadd=d(gagg), gadd_s=d(s.int()), gadd_r=d(r.int()), in_add=d(gadd2)) if extras else {}
+    args = dict(in_op=L.IN_LNBWD, in_gamma=Pd["gamma"], in_aux=y3d, in_stats=stats, res=[god], dw_partial=part, wimg=wi,
+                family=L.CHAIN_COLUMN_OWNER, **kw)
+    layers = [ops.LayerSpec(W3t, None, L.OP_MUL_DGELU, aux=z2d), ops.LayerSpec(W2t, None, L.OP_MUL_DGELU, save=gz1, aux=z1d),
+              ops.LayerSpec(W1t)]
+    assert ops.rowtile_chain(M, [ops.Seg(god)], layers, [ge], query_fused=True, **args)
+    ops.rowtile_chain(M, [ops.Seg(god)], layers, [ge], **args)
+    assert L.load().gfv_rowtile_last_path() == 5 + 16, L.load().gfv_rowtile_last_path()
+    # the chain's own results
+    gz1_ref = torch.autograd.grad((ln * go_total).sum(), z1, retain_graph=True)[0] if False else None
+    assert rel(ge, X.grad + go.double()) < TOL
+    # fused weight gradients: sum of the workgroups' blocks
+    tot = part.double().sum(0).cpu()
+    dW3, db3 = tot[:16384].view(128, 128), tot[16384:16512]
+    dW2, db2 = tot[16512:16512 + 16384].view(128, 128), tot[16512 + 16384:16512 + 16384 + 128]
+    dgam, dbet = tot[-256:-128], tot[-128:]
+    for mine, name in ((dW3, "W3"), (db3, "b3"), (dW2, "W2"), (db2, "b2"), (dgam, "gamma"), (dbet, "beta")):
+        assert rel(mine, Pg[name].grad) < TOL, (name, rel(mine, Pg[name].grad))
+    # gz1 feeds the separate first-layer weight gradient and the node-level scatter
+    dW1, db1 = ops.linear_dw(gz1, 128, [ops.Seg(d(e))], M)
+    assert rel(dW1, Pg["W1"].grad) < TOL and rel(db1, Pg["b1"].grad) < TOL
+    flags = L.C.c_int32(0)
+    L.check(L.load().gfv_status_flags(L.C.byref(flags)), "gfv_status_flags")
+    assert flags.value == 0
