@@ -30,18 +30,24 @@ static bool cc_bwd_ok(const gfv_rowtile_args_t* a) {
   static const int min_m = cc_env("GFV_COLCHAIN_BWD_MIN_M", 16384);
   if (a->flags & GFV_CHAIN_ROW_OWNER) return false;
   if (!(a->flags & GFV_CHAIN_COLUMN_OWNER) && (!on || a->M < min_m)) return false;
-  if (!a->dw_partial || a->dw_partial_stride < GFV_DW_FUSED_FLOATS || !a->in_stats || !a->wmax) return false;
+  if (!a->dw_partial || a->dw_partial_stride < (a->dw_in ? GFV_DW_FUSED_FLOATS_IN : GFV_DW_FUSED_FLOATS) || !a->in_stats || !a->wmax) return false;
+  if (a->dw_in && (!al16(a->dw_in) || (a->dw_in_ld & 3) || a->dw_in_ld < 128)) return false;
   if (a->nlayers != 3 || a->in_op != GFV_IN_LNBWD || a->fin_op != GFV_FIN_PLAIN || a->nseg != 1) return false;
-  if (a->seg[0].width != 128 || a->seg[0].idx || a->seg[0].csr_rowptr || a->seg[0].save || (a->seg[0].ld & 3) || !al16(a->seg[0].ptr)) return false;
+  // (every [M, 128] array of the launch shares one byte offset per row: row stride 128 everywhere, at most 2^22 rows)
+  if (a->seg[0].width != 128 || a->seg[0].idx || a->seg[0].csr_rowptr || a->seg[0].save || a->seg[0].ld != 128 || !al16(a->seg[0].ptr)) return false;
+  if (a->M > (1 << 22) || a->out_ld[0] != 128 || (a->res[0] && a->res_ld[0] != 128) || (a->dw_in && a->dw_in_ld != 128)) return false;
   if (a->layer[0].op != GFV_OP_MUL_DGELU || a->layer[1].op != GFV_OP_MUL_DGELU || a->layer[2].op != GFV_OP_NONE) return false;
   for (int l = 0; l < 3; ++l) {
     const gfv_layer_t& L = a->layer[l];
-    if (!L.Wh || L.N != 128 || L.K != 128 || L.bias || L.bias2) return false;
+    if (!L.Wh || (L.N != 128 && !(l == 2 && L.N == 192)) || L.K != 128 || L.bias || L.bias2) return false;
     if (l < 2 && (!L.aux || !al16(L.aux))) return false;
     if (L.save && !al16(L.save)) return false;
   }
-  if (!a->in_aux || !al16(a->in_aux) || !a->in_gamma || !al16(a->in_gamma) || a->ln_partial || a->gscale || a->padd) return false;
-  if (!a->out[0] || a->out[1] || a->out[2] || a->res[1] || a->res[2] || a->out_nores) return false;
+  if (!a->in_aux || !al16(a->in_aux) || !a->in_gamma || !al16(a->in_gamma) || a->ln_partial || a->padd) return false;
+  const bool out2 = a->layer[2].N == 192;   // [x part 128 (+ residual) | neighbour-mean part 64]
+  if (!a->out[0] || (out2 ? (!a->out[1] || a->out_ld[1] != 64 || !al16(a->out[1]) || a->dw_in) : a->out[1] != nullptr) || a->out[2] ||
+      a->res[1] || a->res[2] || a->out_nores)
+    return false;
   if ((a->out_ld[0] & 3) || !al16(a->out[0]) || (a->res[0] && ((a->res_ld[0] & 3) || !al16(a->res[0])))) return false;
   if (a->in_add && !al16(a->in_add)) return false;
   if (a->gadd && (!al16(a->gadd) || !a->gadd_s || !a->gadd_r)) return false;
@@ -65,8 +71,18 @@ int gfv_internal_colchain_try(const gfv_rowtile_args_t* a, hipStream_t stream) {
     int* st = gfv_internal_status_ptr();
     if (!st) return 0;
     const dim3 grid(cc_cus()), blk(64 * CC_W);
-    if (a->pad3_ != 0) hipLaunchKernelGGL((colchain_bwd_kernel<true>), grid, blk, 0, stream, *a, st);
-    else hipLaunchKernelGGL((colchain_bwd_kernel<false>), grid, blk, 0, stream, *a, st);
+#define CB_LAUNCH(LOWP)                                                                                                          \
+  do {                                                                                                                           \
+    if (a->layer[2].N == 192 && a->gadd) hipLaunchKernelGGL((colchain_bwd_kernel<LOWP, true, false, true>), grid, blk, 0, stream, *a, st);   \
+    else if (a->layer[2].N == 192) hipLaunchKernelGGL((colchain_bwd_kernel<LOWP, false, false, true>), grid, blk, 0, stream, *a, st);        \
+    else if (a->gadd && a->dw_in) hipLaunchKernelGGL((colchain_bwd_kernel<LOWP, true, true>), grid, blk, 0, stream, *a, st);      \
+    else if (a->gadd) hipLaunchKernelGGL((colchain_bwd_kernel<LOWP, true, false>), grid, blk, 0, stream, *a, st);                 \
+    else if (a->dw_in) hipLaunchKernelGGL((colchain_bwd_kernel<LOWP, false, true>), grid, blk, 0, stream, *a, st);                \
+    else hipLaunchKernelGGL((colchain_bwd_kernel<LOWP, false, false>), grid, blk, 0, stream, *a, st);                             \
+  } while (0)
+    if (a->pad3_ != 0) CB_LAUNCH(true);
+    else CB_LAUNCH(false);
+#undef CB_LAUNCH
     return 2;
   }
   if (a->dw_partial) return 0;   // (the caller asked gfv_rowtile_fuses_dw first; anything else is an argument error upstream)

@@ -505,9 +505,9 @@ __global__ __launch_bounds__(64 * CC_W, LITE ? 4 : 2) void colchain_fwd_kernel(c
 //   P2   (barrier) chain layer 1; epilogue: z1 -> gz1 (stored: the node-level scatter reads it), a1 -> fragments
 //   P1   (barrier) chain layer 2 -> input gradient (+ residual) stored;  dW2 from (gz2, a1)
 // Three fragment buffers (g3 | gz1, gz2, a2 | a1); tiles of TG = 4 groups (64 rows): 96 KB + 4 KB of partials.
-// Scales: g3 fragments carry s3 = 2^k with s3 max|g3| <= 2^14 over the tile (from a bound taken before the barrier, two
-// orders of magnitude of slack cost nothing: the split keeps 2^13 of headroom below the maximum); gz2 / gz1 carry s3 / 32,
-// s3 / 1024 (growth through a layer beyond 32 x raises GFV_FLAG_CHAIN_RANGE); a2 / a1 the fixed CC_SH.  The weight-gradient
+// Scales: g3 fragments carry s3 = 2^k with s3 max|g3| <= 2^15 over the tile (from a bound taken before the barrier; an
+// order of magnitude of slack costs nothing: the split keeps 2^13 of headroom below the maximum); gz2 / gz1 step down from it by
+// the layers' guaranteed growth bounds (row 1-norms of the weight images, taken at kernel start); a2 / a1 carry the fixed CC_SH.  The weight-gradient
 // accumulators live in units of the current tile's scale and are rescaled (exactly: powers of two) when it changes; the
 // scale may not rise more than 2^20 above the smallest one seen (rows that small add nothing to sums dominated by rows a
 // million times larger).
@@ -561,6 +561,7 @@ __device__ __forceinline__ void cb_dw_tile(const char* gbuf, const char* abuf, i
         acc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(gh, al, acc[kt], 0, 0, 0);
       }
       acc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(gh, ah, acc[kt], 0, 0, 0);
+      if ((kt & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // (four k-tiles' operands in flight, not eight: the register budget)
     }
   }
 }
@@ -587,13 +588,85 @@ __device__ __forceinline__ void cb_hidden_bwd(CcCtx& c, int q, const floatx4& ac
   cc_put_frag(aout, q, c, a, CC_SH);
 }
 
-template <bool LOWP>
+// ---- buffer addressing ---------------------------------------------------------------------------------------------
+// Every [M, 128] array of a launch is addressed through a buffer descriptor (4 SGPRs, built from the kernel arguments) and
+// ONE 32-bit byte offset per row group that all of them share (row x 512 + first column x 4): no 64-bit address per access
+// (flat addressing cost the first version of this kernel ~140 address computations and two registers per live pointer,
+// which is what made it spill).  The bounds check of the descriptor does the predication: a store whose offset lies
+// beyond the array - rows past M, the dead groups of a partial tile get such an offset - is dropped, an absent array
+// (NULL: zero records) reads as zeros and swallows its stores.
+typedef int cb_i32x4 __attribute__((ext_vector_type(4)));
+typedef int cb_i32x2 __attribute__((ext_vector_type(2)));
+typedef __amdgpu_buffer_rsrc_t cb_rsrc;
+constexpr int CB_OFF_DEAD = 0x7ffffff0;
+__device__ __forceinline__ cb_rsrc cb_buf(const void* p, size_t bytes) {
+  const size_t n = p ? (bytes < 0x7fffffe0ull ? bytes : 0x7fffffe0ull) : 0;
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)n, 0x00020000);
+}
+// (the loaded vector is cast to floats as a WHOLE: hipcc 7.2 narrows the load to one dword when the four lanes of the integer
+// vector are bit-cast one by one - found by the parity test, profiles/tools/tr)
+typedef float cb_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float4 cb_ld4(cb_rsrc r, int off) {
+  const floatx4 f = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+  return make_float4(f[0], f[1], f[2], f[3]);
+}
+__device__ __forceinline__ float2 cb_ld2(cb_rsrc r, int off) {
+  const cb_f32x2 f = __builtin_bit_cast(cb_f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0));
+  return make_float2(f[0], f[1]);
+}
+__device__ __forceinline__ void cb_st4(cb_rsrc r, int off, const float (&v)[4]) {
+  const floatx4 f = {v[0], v[1], v[2], v[3]};
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(cb_i32x4, f), r, off, 0, 0);
+}
+
+// the rows a tile's LayerNorm backward starts from, loaded one tile ahead (issued behind the previous tile's second chain
+// layer, consumed in P0): this wave's 16 columns of dy, y3, the gathered addend, and the rows' forward statistics
+struct CbIn {
+  float4 dy[CB_TG], yv[CB_TG], ga[CB_TG];
+  float2 st[CB_TG];
+};
+struct CbBufs {
+  cb_rsrc dy, y3, stats, z2, z1, gadd, gidx, save1, res, out;   // (the rarely used ones are built where they are used: SGPR budget)
+};
+// byte offset of this lane's 16 bytes of row (row0 + 16 q + j) in an [M, 128] array, clamped to the last row
+__device__ __forceinline__ int cb_off(const CcCtx& c, int row0, int q) { return min(row0 + 16 * q + c.j, c.M - 1) * 512 + c.col0 * 4; }
+
+template <bool GADD>
+__device__ __forceinline__ void cb_load_gidx(const CbBufs& B, const CcCtx& c, int row0, int (&gidx)[CB_TG]) {
+  if (GADD) {
+#pragma unroll
+    for (int q = 0; q < CB_TG; ++q) gidx[q] = __builtin_amdgcn_raw_buffer_load_b32(B.gidx, min(row0 + 16 * q + c.j, c.M - 1) * 4, 0, 0);
+  }
+}
+__device__ __forceinline__ void cb_load_inputs(const CbBufs& B, const CcCtx& c, int row0, CbIn& in) {
+#pragma unroll
+  for (int q = 0; q < CB_TG; ++q) {
+    const int off = cb_off(c, row0, q);
+    in.dy[q] = cb_ld4(B.dy, off);
+    in.yv[q] = cb_ld4(B.y3, off);
+    in.st[q] = cb_ld2(B.stats, min(row0 + 16 * q + c.j, c.M - 1) * 8);
+  }
+}
+template <bool GADD>
+__device__ __forceinline__ void cb_load_gathers(const CbBufs& B, const CcCtx& c, const int (&gidx)[CB_TG], CbIn& in) {
+  if (GADD) {   // [gadd[s] (64) | gadd[r] (64)]: this wave's 16 columns lie in one half
+#pragma unroll
+    for (int q = 0; q < CB_TG; ++q) in.ga[q] = cb_ld4(B.gadd, gidx[q] * 256 + (c.col0 & 63) * 4);
+  }
+}
+
+// GADD: the gathered addend [gadd[s] | gadd[r]] of the incoming gradient exists; DW1: the forward's first Linear is 128 deep
+// and its input rows are given (dw_in): its weight gradient is fused as well (a fourth fragment buffer, 36 more registers)
+// OUT2: the last chain layer is 192 wide (NodeBlock: W1^T with the rows for x first, then the 64 for the neighbour mean,
+// blocks.py:54): waves 0..3 own a second n-tile and write out[1] ([M, 64], no residual)
+template <bool LOWP, bool GADD, bool DW1, bool OUT2 = false>
 __global__ __launch_bounds__(64 * CC_W, 2) void colchain_bwd_kernel(const gfv_rowtile_args_t A, int* status) {
   constexpr int TG = CB_TG;
-  __shared__ __attribute__((aligned(16))) char lds[CbLds::TOTAL];
+  __shared__ __attribute__((aligned(16))) char lds[CbLds::TOTAL + (DW1 ? CbLds::BUF : 0)];
   char* b0 = lds + CbLds::B0;
   char* b1 = lds + CbLds::B1;
   char* b2 = lds + CbLds::B2;
+  char* b3 = lds + CbLds::TOTAL;   // (DW1) fragments of the first Linear's input rows
   float* part = reinterpret_cast<float*>(lds + CbLds::PART);
   float* smax = reinterpret_cast<float*>(lds + CbLds::SMAX);
 
@@ -612,78 +685,115 @@ __global__ __launch_bounds__(64 * CC_W, 2) void colchain_bwd_kernel(const gfv_ro
   const int NG = (A.M + 15) >> 4;
   const int g_beg = (int)((long)NG * wg / nwg), g_end = (int)((long)NG * (wg + 1) / nwg);
 
-  // resident weights: this wave's n-tile of the three transposed layers' images
-  gfv_f16x8 wh0[4], wl0[4], wh1[4], wl1[4], wh2[4], wl2[4];
-  {
-    const gfv_f16x8* i0 = reinterpret_cast<const gfv_f16x8*>(A.layer[0].Wh) + (size_t)c.w * 128 + c.lane;
-    const gfv_f16x8* i1 = reinterpret_cast<const gfv_f16x8*>(A.layer[1].Wh) + (size_t)c.w * 128 + c.lane;
-    const gfv_f16x8* i2 = reinterpret_cast<const gfv_f16x8*>(A.layer[2].Wh) + (size_t)c.w * 128 + c.lane;
-#pragma unroll
-    for (int T = 0; T < 4; ++T) {
-      wh0[T] = i0[T * 1024]; wl0[T] = i0[T * 1024 + 64];
-      wh1[T] = i1[T * 1024]; wl1[T] = i1[T * 1024 + 64];
-      wh2[T] = i2[T * 1024]; wl2[T] = i2[T * 1024 + 64];
-    }
-  }
-  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  const float4 gam = ld4(A.in_gamma + c.col0);
+  const size_t rows128 = (size_t)A.M * 512;
+  CbBufs B;
+  B.dy = cb_buf(A.seg[0].ptr, rows128);
+  B.y3 = cb_buf(A.in_aux, rows128);
+  B.stats = cb_buf(A.in_stats, (size_t)A.M * 8);
+  B.z2 = cb_buf(A.layer[0].aux, rows128);
+  B.z1 = cb_buf(A.layer[1].aux, rows128);
+  B.gadd = cb_buf(A.gadd, 0x7fffffe0ull);   // (its row count is not an argument; the gather rows come from the index arrays)
+  B.gidx = cb_buf(c.w < 4 ? A.gadd_s : A.gadd_r, (size_t)A.M * 4);
+  B.save1 = cb_buf(A.layer[1].save, rows128);
+  B.res = cb_buf(A.res[0], rows128);
+  B.out = cb_buf(A.out[0], rows128);
+  const cb_rsrc out2 = cb_buf(OUT2 ? A.out[1] : nullptr, (size_t)A.M * 256);
+
+  // this wave's n-tile of the three transposed layers' images.  The weight-gradient accumulators take 72 (DW1: 108) registers
+  // for the whole launch, so the chain's weights are NOT resident here: every tile fetches each layer's slice (4 KB per wave,
+  // L2 hits) one phase ahead of its use - 12 KB per wave and 64-row tile next to 230 KB of activation traffic - and the
+  // LayerNorm-backward phase, where the register pressure peaks, holds none of them.
+  const cb_rsrc w0 = cb_buf(A.layer[0].Wh, 65536), w1 = cb_buf(A.layer[1].Wh, 65536), w2 = cb_buf(A.layer[2].Wh, OUT2 ? 131072 : 65536);
+  const int woff = (c.w * 128 + c.lane) * 16;   // + T * 16384 (+ 1024: the lo part)
   // fused weight gradients: D[n = 16 w + 4 g + r][k = 16 kt + j] in lane (j, g) of acc[kt][r]
-  floatx4 dw3[8], dw2[8], db3 = floatx4{0.f, 0.f, 0.f, 0.f}, db2 = floatx4{0.f, 0.f, 0.f, 0.f};
+  floatx4 dw3[8], dw2[8], dw1[DW1 ? 8 : 1], db3 = floatx4{0.f, 0.f, 0.f, 0.f}, db2 = db3, db1 = db3;
 #pragma unroll
   for (int kt = 0; kt < 8; ++kt) dw3[kt] = dw2[kt] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int kt = 0; kt < (DW1 ? 8 : 1); ++kt) dw1[kt] = floatx4{0.f, 0.f, 0.f, 0.f};
   float dgam[4] = {0.f, 0.f, 0.f, 0.f}, dbet[4] = {0.f, 0.f, 0.f, 0.f};
-  float sacc = 0.f;          // scale the g3-side accumulators are in (0: nothing accumulated yet); the gz2 side: sacc / 32
+  float sacc = 0.f;          // scale the g3-side accumulators are in (0: nothing accumulated yet); gz2 side: / 32, gz1 side: / 1024
   float scap = 3.0e38f;      // 2^20 x the smallest tile scale so far
-  const bool have_res = A.res[0] != nullptr;
 
+  // How much a chain layer can enlarge its input rows: |(g W^T)[n]| <= max|g| sum_k |W^T[n][k]|, x gelu' <= 1.13.  The largest
+  // row 1-norm of each of the first two layers' images (this wave's 16 rows from its fragments, the workgroup's maximum through
+  // LDS; in units of the weight scale) gives the power of two by which the next layer's fragment scale steps down from this
+  // one's: a guaranteed bound, so the gradient fragments cannot overflow - and for weights as the reference initialises them
+  // (trunc_normal 0.02: row norms ~ 2) it costs two bits where a fixed allowance for the worst case would cost seven.
+  float step1, step2;   // s2 = s3 * step1, s1 = s2 * step2
+  {
+    float l1[2];
+#pragma unroll
+    for (int l = 0; l < 2; ++l) {
+      const cb_rsrc wb = l == 0 ? w0 : w1;
+      float acc = 0.f;
+#pragma unroll
+      for (int T = 0; T < 4; ++T) {
+        const gfv_f16x8 h = __builtin_bit_cast(gfv_f16x8, __builtin_amdgcn_raw_buffer_load_b128(wb, woff + T * 16384, 0, 0));
+        const gfv_f16x8 lo = __builtin_bit_cast(gfv_f16x8, __builtin_amdgcn_raw_buffer_load_b128(wb, woff + T * 16384 + 1024, 0, 0));
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc += fabsf((float)h[e] + (float)lo[e]);
+      }
+      l1[l] = gfv_wave_max(row_sum(acc));   // row_sum: the 4 lane groups that share a weight row; then the 16 rows
+    }
+    if (c.lane == 0) { smax[c.w] = l1[0]; part[c.w] = l1[1]; }
+    cc_barrier();
+    float m0 = 0.f, m1 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { m0 = fmaxf(m0, smax[k]); m1 = fmaxf(m1, part[k]); }
+    cc_barrier();
+    // step = 2^-ceil(log2(1.13 * L1 / ws)): an exact power of two at most 1 / growth
+    const float g0 = 1.13f * m0 * c.invw, g1 = 1.13f * m1 * c.invw;
+    step1 = 1.0f / gfv_pow2_ceil(g0);
+    step2 = 1.0f / gfv_pow2_ceil(g1);
+  }
+
+  int gidx[TG] = {0, 0, 0, 0};
+  CbIn in;
+  if (g_beg < g_end) {
+    cb_load_gidx<GADD>(B, c, 16 * g_beg, gidx);
+    cb_load_inputs(B, c, 16 * g_beg, in);
+    cb_load_gathers<GADD>(B, c, gidx, in);
+  }
+  CT_DECL
   for (int t0 = g_beg; t0 < g_end; t0 += TG) {
     c.row0 = 16 * t0;
     c.ngt = min(TG, g_end - t0);
     const int np = (c.ngt + 1) >> 1;
-    // ---- P0: LayerNorm backward, first half ----
+    const int next_row0 = t0 + TG < g_end ? 16 * (t0 + TG) : c.M;   // (behind the last tile: every lane re-reads row M - 1)
+    int offL[TG], offS[TG];   // this tile's byte offsets: loads (clamped rows), stores (dead rows / groups: out of bounds)
+#pragma unroll
+    for (int q = 0; q < TG; ++q) {
+      const int row = c.row0 + 16 * q + c.j;
+      offL[q] = cb_off(c, c.row0, q);
+      offS[q] = (q < c.ngt && row < c.M) ? row * 512 + c.col0 * 4 : CB_OFF_DEAD;
+    }
+    // ---- P0: LayerNorm backward, first half (the rows were loaded one tile ahead) ----
     float gg[TG][4], xh[TG][4], rs[TG];
     {
       float bmax = 0.f;
-      float4 dy[TG], yv[TG];
-      float2 st[TG];
-#pragma unroll
-      for (int q = 0; q < TG; ++q) {
-        const int row = min(c.row0 + 16 * q + c.j, c.M - 1);
-        dy[q] = ld4(A.seg[0].ptr + (size_t)row * A.seg[0].ld + c.col0);
-        yv[q] = ld4(A.in_aux + (size_t)row * 128 + c.col0);
-        st[q] = *reinterpret_cast<const float2*>(A.in_stats + 2 * (size_t)row);
-      }
       if (A.in_add) {
+        const cb_rsrc ia = cb_buf(A.in_add, rows128);
 #pragma unroll
         for (int q = 0; q < TG; ++q) {
-          const int row = min(c.row0 + 16 * q + c.j, c.M - 1);
-          const float4 t = ld4(A.in_add + (size_t)row * A.seg[0].ld + c.col0);
-          dy[q].x += t.x; dy[q].y += t.y; dy[q].z += t.z; dy[q].w += t.w;
+          const float4 t = cb_ld4(ia, offL[q]);
+          in.dy[q].x += t.x; in.dy[q].y += t.y; in.dy[q].z += t.z; in.dy[q].w += t.w;
         }
       }
-      if (A.gadd) {
-        // + [gadd[s] (64) | gadd[r] (64)]: this wave's 16 columns lie in one half
-        const int* gi = c.w < 4 ? A.gadd_s : A.gadd_r;
-        const int gc = (c.col0 & 63);
-#pragma unroll
-        for (int q = 0; q < TG; ++q) {
-          const int row = min(c.row0 + 16 * q + c.j, c.M - 1);
-          const float4 t = ld4(A.gadd + (size_t)gi[row] * 64 + gc);
-          dy[q].x += t.x; dy[q].y += t.y; dy[q].z += t.z; dy[q].w += t.w;
-        }
-      }
+      const float4 gam = ld4(A.in_gamma + c.col0);
 #pragma unroll
       for (int q = 0; q < TG; ++q) {
-        const bool live = q < c.ngt && c.row0 + 16 * q + c.j < c.M;
-        const float lf = live ? 1.0f : 0.0f;   // rows past M / dead groups must not reach any sum over rows
-        const float d[4] = {dy[q].x * lf, dy[q].y * lf, dy[q].z * lf, dy[q].w * lf};
-        const float y[4] = {yv[q].x, yv[q].y, yv[q].z, yv[q].w};
+        const float lf = offS[q] != CB_OFF_DEAD ? 1.0f : 0.0f;   // rows past M / dead groups must not reach any sum over rows
+        float d[4] = {in.dy[q].x, in.dy[q].y, in.dy[q].z, in.dy[q].w};
+        if (GADD) { d[0] += in.ga[q].x; d[1] += in.ga[q].y; d[2] += in.ga[q].z; d[3] += in.ga[q].w; }
+        const float y[4] = {in.yv[q].x, in.yv[q].y, in.yv[q].z, in.yv[q].w};
         const float gm[4] = {gam.x, gam.y, gam.z, gam.w};
-        const float mean = st[q].x, rstd = st[q].y;
+        const float mean = in.st[q].x, rstd = in.st[q].y;
         rs[q] = rstd;
         float s1 = 0.f, s2 = 0.f, am = 0.f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
+          d[r] *= lf;
           xh[q][r] = (y[r] - mean) * rstd;
           dgam[r] += d[r] * xh[q][r];
           dbet[r] += d[r];
@@ -695,19 +805,32 @@ __global__ __launch_bounds__(64 * CC_W, 2) void colchain_bwd_kernel(const gfv_ro
         s1 = row_sum(s1);
         s2 = row_sum(s2);
         if (c.g == 0) *reinterpret_cast<float2*>(part + ((q * 16 + c.j) * 8 + c.w) * 2) = make_float2(s1, s2);
-        bmax = fmaxf(bmax, live ? am * fabsf(rstd) : 0.f);
+        bmax = fmaxf(bmax, am * fabsf(rstd) * lf);
       }
       bmax = gfv_wave_max(bmax);
       if (c.lane == 0) smax[c.w] = bmax;
     }
+    gfv_f16x8 wh[4], wl[4];   // the current chain layer's slice
+#pragma unroll
+    for (int T = 0; T < 4; ++T) {
+      wh[T] = __builtin_bit_cast(gfv_f16x8, __builtin_amdgcn_raw_buffer_load_b128(w0, woff + T * 16384, 0, 0));
+      wl[T] = __builtin_bit_cast(gfv_f16x8, __builtin_amdgcn_raw_buffer_load_b128(w0, woff + T * 16384 + 1024, 0, 0));
+    }
+    // the saved pre-activations the first chain layer's epilogue needs: in flight through P0b
+    float4 zq[TG];
+#pragma unroll
+    for (int q = 0; q < TG; ++q) zq[q] = cb_ld4(B.z2, offL[q]);
+    CT(0);
     cc_barrier();
+    CT(1);
     // ---- P0b: g3 and its fragments ----
     float s3;
     {
       const float4 ma = *reinterpret_cast<const float4*>(smax), mb = *reinterpret_cast<const float4*>(smax + 4);
       const float mx = fmaxf(fmaxf(fmaxf(ma.x, ma.y), fmaxf(ma.z, ma.w)), fmaxf(fmaxf(mb.x, mb.y), fmaxf(mb.z, mb.w)));
-      // |g3| <= rstd (|gg| + |m1| + |xhat| |m2|) <= rstd max|gg| (2 + 128): the bound, not the maximum, sets the scale
-      s3 = fminf(gfv_pow2_scale(mx * 130.0f) * 2.0f, scap);
+      // |g3| <= rstd (|gg| + |m1| + |xhat| |m2|) with |m1| <= max|gg|, |m2| <= max|gg| mean|xhat| <= max|gg| (mean xhat^2 = 1)
+      // and |xhat| <= sqrt(127): rstd max|gg| (2 + 11.3) - the bound, not the maximum, sets the scale
+      s3 = fminf(gfv_pow2_scale(mx * 13.5f) * 2.0f, scap);
       scap = fminf(scap, s3 * 1048576.0f);
 #pragma unroll
       for (int q = 0; q < TG; ++q) {
@@ -718,8 +841,7 @@ __global__ __launch_bounds__(64 * CC_W, 2) void colchain_bwd_kernel(const gfv_ro
         float g3[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) g3[r] = rs[q] * (gg[q][r] - m1 - xh[q][r] * m2);
-        const int row = c.row0 + 16 * q + c.j;
-        if (A.in_save && q < c.ngt && row < c.M) st4(A.in_save + (size_t)row * 128 + c.col0, g3);
+        if (A.in_save) cb_st4(cb_buf(A.in_save, rows128), offS[q], g3);
         cc_put_frag(b0, q, c, g3, s3);
       }
     }
@@ -728,90 +850,178 @@ __global__ __launch_bounds__(64 * CC_W, 2) void colchain_bwd_kernel(const gfv_ro
       const float ratio = s3 / sacc;
 #pragma unroll
       for (int kt = 0; kt < 8; ++kt) { dw3[kt] *= ratio; dw2[kt] *= ratio; }
+#pragma unroll
+      for (int kt = 0; kt < (DW1 ? 8 : 1); ++kt) dw1[kt] *= ratio;
       db3 *= ratio;
       db2 *= ratio;
+      db1 *= ratio;
     }
     sacc = s3;
-    const float s2s = s3 * 0.03125f, s1s = s3 * 0.0009765625f;
+    const float s2s = s3 * step1, s1s = s2s * step2;
+    // per-16-row scales of the rows this launch leaves for a weight-gradient launch of its own (gfv_rowtile_args_t.gscale):
+    // the tile's fragment scales, a quarter of them (a slab scale s wants s max|v| <= 2^14, the fragments allow 2^16)
+    if (A.gscale && c.w == 0 && c.lane < c.ngt) {
+      const size_t grp = (size_t)(c.row0 >> 4) + c.lane;
+      A.gscale[grp] = s3 * 0.25f;
+      A.gscale[(size_t)A.gscale_ld + grp] = s2s * 0.25f;
+      A.gscale[2 * (size_t)A.gscale_ld + grp] = s1s * 0.25f;
+    }
+    CT(2);
     cc_barrier();
+    CT(3);
     // ---- P3: chain layer 0 (b0 -> gz2 in b1, a2 in b2) ----
+    cb_load_gidx<GADD>(B, c, next_row0, gidx);   // the next tile's gather rows: the gathers go out behind P1
     {
       const float inv_in = 1.0f / s3;
       floatx4 a0, a1;
-      cc_mma_pair<4, LOWP>(b0, 0, wh0, wl0, c.lane, a0, a1);
-      for (int p = 0; p < np; ++p) {
-        const int pnext = min(p + 1, TG / 2 - 1);
-        const int r0 = min(c.row0 + 32 * p + c.j, c.M - 1), r1 = min(c.row0 + 32 * p + 16 + c.j, c.M - 1);
-        const float4 z0 = ld4(A.layer[0].aux + (size_t)r0 * 128 + c.col0), z1 = ld4(A.layer[0].aux + (size_t)r1 * 128 + c.col0);
-        floatx4 n0, n1;
-        cc_mma_pair<4, LOWP>(b0, pnext, wh0, wl0, c.lane, n0, n1);
+      cc_mma_pair<4, LOWP, true>(b0, 0, wh, wl, c.lane, a0, a1);
+#pragma unroll
+      for (int p = 0; p < TG / 2; ++p) {
+        if (p >= np) break;
+        floatx4 n0 = a0, n1 = a1;
+        if (p + 1 < TG / 2) cc_mma_pair<4, LOWP, true>(b0, p + 1, wh, wl, c.lane, n0, n1);
         float v0[4], v1[4];
-        cb_hidden_bwd(c, 2 * p, a0, inv_in, z0, s2s, b1, b2, v0);
-        cb_hidden_bwd(c, 2 * p + 1, a1, inv_in, z1, s2s, b1, b2, v1);
-        cc_save_pair(A.layer[0].save, c, p, v0, v1);
+        cb_hidden_bwd(c, 2 * p, a0, inv_in, zq[2 * p], s2s, b1, b2, v0);
+        cb_hidden_bwd(c, 2 * p + 1, a1, inv_in, zq[2 * p + 1], s2s, b1, b2, v1);
+        if (A.layer[0].save) {
+          const cb_rsrc s0 = cb_buf(A.layer[0].save, rows128);
+          cb_st4(s0, offS[2 * p], v0);
+          cb_st4(s0, offS[2 * p + 1], v1);
+        }
         a0 = n0; a1 = n1;
       }
     }
+#pragma unroll
+    for (int T = 0; T < 4; ++T) {
+      wh[T] = __builtin_bit_cast(gfv_f16x8, __builtin_amdgcn_raw_buffer_load_b128(w1, woff + T * 16384, 0, 0));
+      wl[T] = __builtin_bit_cast(gfv_f16x8, __builtin_amdgcn_raw_buffer_load_b128(w1, woff + T * 16384 + 1024, 0, 0));
+    }
+    // the second chain layer's saved pre-activations (and the first Linear's input rows): in flight through dW3
+#pragma unroll
+    for (int q = 0; q < TG; ++q) zq[q] = cb_ld4(B.z1, offL[q]);
+    CT(4);
     cc_barrier();
+    CT(5);
     // ---- dW3 += g3^T a2 ----
+    float4 ev[DW1 ? TG : 1];   // (DW1) the first Linear's input rows: in flight through this phase, fragments at its end
+    if (DW1) {
+#pragma unroll
+      for (int q = 0; q < TG; ++q) ev[q] = cb_ld4(cb_buf(A.dw_in, rows128), offL[q]);
+    }
     cb_dw_tile<LOWP>(b0, b2, np, c.w, c.lane, dw3, db3);
+    if (DW1) {
+#pragma unroll
+      for (int q = 0; q < TG; ++q) {
+        const float e4[4] = {ev[q].x, ev[q].y, ev[q].z, ev[q].w};
+        const float me = max3_abs(max3_abs(0.f, e4[0], e4[1]), e4[2], e4[3]) * (CC_SH * (1.0f / 32.0f));
+        c.mabs = fmaxf(c.mabs, q < c.ngt ? me : 0.f);
+        cc_put_frag(b3, q, c, e4, CC_SH);
+      }
+    }
+    CT(6);
     cc_barrier();
+    CT(7);
     // ---- P2: chain layer 1 (b1 -> gz1 in b0, a1 in b2) ----
     {
       const float inv_in = 1.0f / s2s;
       floatx4 a0, a1;
-      cc_mma_pair<4, LOWP>(b1, 0, wh1, wl1, c.lane, a0, a1);
-      for (int p = 0; p < np; ++p) {
-        const int pnext = min(p + 1, TG / 2 - 1);
-        const int r0 = min(c.row0 + 32 * p + c.j, c.M - 1), r1 = min(c.row0 + 32 * p + 16 + c.j, c.M - 1);
-        const float4 z0 = ld4(A.layer[1].aux + (size_t)r0 * 128 + c.col0), z1 = ld4(A.layer[1].aux + (size_t)r1 * 128 + c.col0);
-        floatx4 n0, n1;
-        cc_mma_pair<4, LOWP>(b1, pnext, wh1, wl1, c.lane, n0, n1);
+      cc_mma_pair<4, LOWP, true>(b1, 0, wh, wl, c.lane, a0, a1);
+#pragma unroll
+      for (int p = 0; p < TG / 2; ++p) {
+        if (p >= np) break;
+        floatx4 n0 = a0, n1 = a1;
+        if (p + 1 < TG / 2) cc_mma_pair<4, LOWP, true>(b1, p + 1, wh, wl, c.lane, n0, n1);
         float v0[4], v1[4];
-        cb_hidden_bwd(c, 2 * p, a0, inv_in, z0, s1s, b0, b2, v0);
-        cb_hidden_bwd(c, 2 * p + 1, a1, inv_in, z1, s1s, b0, b2, v1);
-        cc_save_pair(A.layer[1].save, c, p, v0, v1);
+        cb_hidden_bwd(c, 2 * p, a0, inv_in, zq[2 * p], s1s, b0, b2, v0);
+        cb_hidden_bwd(c, 2 * p + 1, a1, inv_in, zq[2 * p + 1], s1s, b0, b2, v1);
+        cb_st4(B.save1, offS[2 * p], v0);
+        cb_st4(B.save1, offS[2 * p + 1], v1);
         a0 = n0; a1 = n1;
       }
     }
+#pragma unroll
+    for (int T = 0; T < 4; ++T) {
+      wh[T] = __builtin_bit_cast(gfv_f16x8, __builtin_amdgcn_raw_buffer_load_b128(w2, woff + T * 16384, 0, 0));
+      wl[T] = __builtin_bit_cast(gfv_f16x8, __builtin_amdgcn_raw_buffer_load_b128(w2, woff + T * 16384 + 1024, 0, 0));
+    }
+    // this tile's residual rows go out here: in flight through the barrier
+    float4 rr[TG];
+#pragma unroll
+    for (int q = 0; q < TG; ++q) rr[q] = cb_ld4(B.res, offL[q]);
+    CT(8);
     cc_barrier();
-    // ---- P1: chain layer 2 (b0 -> the input gradient) and dW2 += gz2^T a1 ----
+    CT(9);
+    // ---- P1: chain layer 2 (b0 -> the input gradient) and dW2 += gz2^T a1 (and dW1 += gz1^T x) ----
     {
       const float inv_in = 1.0f / s1s;
       floatx4 a0, a1;
-      cc_mma_pair<4, LOWP>(b0, 0, wh2, wl2, c.lane, a0, a1);
-      for (int p = 0; p < np; ++p) {
-        const int pnext = min(p + 1, TG / 2 - 1);
-        const int r0 = c.row0 + 32 * p + c.j, r1 = r0 + 16;
-        float4 x0 = zero4, x1 = zero4;
-        if (have_res) {
-          x0 = ld4(A.res[0] + (size_t)min(r0, c.M - 1) * A.res_ld[0] + c.col0);
-          x1 = ld4(A.res[0] + (size_t)min(r1, c.M - 1) * A.res_ld[0] + c.col0);
-        }
-        floatx4 n0, n1;
-        cc_mma_pair<4, LOWP>(b0, pnext, wh2, wl2, c.lane, n0, n1);
+      cc_mma_pair<4, LOWP, true>(b0, 0, wh, wl, c.lane, a0, a1);
+#pragma unroll
+      for (int p = 0; p < TG / 2; ++p) {
+        if (p >= np) break;
+        floatx4 n0 = a0, n1 = a1;
+        if (p + 1 < TG / 2) cc_mma_pair<4, LOWP, true>(b0, p + 1, wh, wl, c.lane, n0, n1);
         float o0[4], o1[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           o0[r] = (a0[r] * inv_in) * c.invw;
           o1[r] = (a1[r] * inv_in) * c.invw;
         }
-        o0[0] += x0.x; o0[1] += x0.y; o0[2] += x0.z; o0[3] += x0.w;
-        o1[0] += x1.x; o1[1] += x1.y; o1[2] += x1.z; o1[3] += x1.w;
-        if (2 * p < c.ngt && r0 < c.M) st4(A.out[0] + (size_t)r0 * A.out_ld[0] + c.col0, o0);
-        if (2 * p + 1 < c.ngt && r1 < c.M) st4(A.out[0] + (size_t)r1 * A.out_ld[0] + c.col0, o1);
+        o0[0] += rr[2 * p].x; o0[1] += rr[2 * p].y; o0[2] += rr[2 * p].z; o0[3] += rr[2 * p].w;
+        o1[0] += rr[2 * p + 1].x; o1[1] += rr[2 * p + 1].y; o1[2] += rr[2 * p + 1].z; o1[3] += rr[2 * p + 1].w;
+        cb_st4(B.out, offS[2 * p], o0);
+        cb_st4(B.out, offS[2 * p + 1], o1);
         a0 = n0; a1 = n1;
       }
+      if constexpr (OUT2) {
+        if (c.w < 4) {   // (wave-uniform) output columns 128 + 16 w ..: the image's second pass, n-tile w
+          gfv_f16x8 xh2[4], xl2[4];
+#pragma unroll
+          for (int T = 0; T < 4; ++T) {
+            xh2[T] = __builtin_bit_cast(gfv_f16x8, __builtin_amdgcn_raw_buffer_load_b128(w2, 65536 + woff + T * 16384, 0, 0));
+            xl2[T] = __builtin_bit_cast(gfv_f16x8, __builtin_amdgcn_raw_buffer_load_b128(w2, 65536 + woff + T * 16384 + 1024, 0, 0));
+          }
+#pragma unroll
+          for (int p = 0; p < TG / 2; ++p) {
+            if (p >= np) break;
+            floatx4 e0, e1;
+            cc_mma_pair<4, LOWP, true>(b0, p, xh2, xl2, c.lane, e0, e1);
+            float o0[4], o1[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              o0[r] = (e0[r] * inv_in) * c.invw;
+              o1[r] = (e1[r] * inv_in) * c.invw;
+            }
+            const int ra = c.row0 + 32 * p + c.j, rb = ra + 16;
+            cb_st4(out2, (2 * p < c.ngt && ra < c.M) ? ra * 256 + c.col0 * 4 : CB_OFF_DEAD, o0);
+            cb_st4(out2, (2 * p + 1 < c.ngt && rb < c.M) ? rb * 256 + c.col0 * 4 : CB_OFF_DEAD, o1);
+          }
+        }
+      }
     }
+    CT(10);
+    // the next tile's rows (and its gathered addend rows): in flight through the last weight gradients.  (Issued any earlier
+    // they sit in 56 registers beside a chain phase, and the kernel spills: a scratch reload waits for every load in flight.)
+    cb_load_inputs(B, c, next_row0, in);
+    cb_load_gathers<GADD>(B, c, gidx, in);
     cb_dw_tile<LOWP>(b1, b2, np, c.w, c.lane, dw2, db2);
+    if constexpr (DW1) cb_dw_tile<LOWP>(b0, b3, np, c.w, c.lane, dw1, db1);
+    CT(11);
     // (the next tile's P0 writes only `part` / `smax`, last read in P0b; its P0b writes b0 behind the barrier that follows P0)
   }
 
-  // ---- the workgroup's partial block: [dW3 | db3 | dW2 | db2 | dgamma | dbeta] (include/gfv.h) ----
+#ifdef GFV_CC_TIMING
+  if (c.lane == 0 && A.fin_aux) {
+    long long* dbg = reinterpret_cast<long long*>(const_cast<float*>(A.fin_aux)) + ((size_t)blockIdx.x * CC_W + c.w) * 12;
+    for (int kk = 0; kk < 12; ++kk) dbg[kk] = ct_[kk];
+  }
+#endif
+  // ---- the workgroup's partial block: [dW3 | db3 | dW2 | db2 | dgamma | dbeta | dW1 | db1] (include/gfv.h) ----
   if (A.dw_partial) {
     float* blk = A.dw_partial + (size_t)blockIdx.x * A.dw_partial_stride;
-    const float u3 = sacc != 0.f ? (1.0f / sacc) * CC_SH_INV : 0.f, u2 = sacc != 0.f ? (32.0f / sacc) * CC_SH_INV : 0.f;
-    const float ub3 = sacc != 0.f ? 1.0f / sacc : 0.f, ub2 = sacc != 0.f ? 32.0f / sacc : 0.f;
+    const float is = sacc != 0.f ? 1.0f / sacc : 0.f;
+    const float r2 = 1.0f / step1, r1 = r2 / step2;   // the gz2 / gz1 sides are in units of sacc * step1 (* step2)
+    const float u3 = is * CC_SH_INV, u2 = (is * r2) * CC_SH_INV, u1 = (is * r1) * CC_SH_INV;
 #pragma unroll
     for (int kt = 0; kt < 8; ++kt)
 #pragma unroll
@@ -819,12 +1029,14 @@ __global__ __launch_bounds__(64 * CC_W, 2) void colchain_bwd_kernel(const gfv_ro
         const int n = 16 * c.w + 4 * c.g + r, k = 16 * kt + c.j;
         blk[n * 128 + k] = dw3[kt][r] * u3;
         blk[16384 + 128 + n * 128 + k] = dw2[kt][r] * u2;
+        if (DW1) blk[2 * 16384 + 512 + n * 128 + k] = dw1[kt][r] * u1;
       }
     if (c.j == 0) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        blk[16384 + 16 * c.w + 4 * c.g + r] = db3[r] * ub3;
-        blk[2 * 16384 + 128 + 16 * c.w + 4 * c.g + r] = db2[r] * ub2;
+        blk[16384 + 16 * c.w + 4 * c.g + r] = db3[r] * is;
+        blk[2 * 16384 + 128 + 16 * c.w + 4 * c.g + r] = db2[r] * (is * r2);
+        if (DW1) blk[3 * 16384 + 512 + 16 * c.w + 4 * c.g + r] = db1[r] * (is * r1);
       }
     }
     // (dgamma, dbeta): lane-private sums over the rows j and the groups this lane saw -> sum over the 16 lanes of a DPP row

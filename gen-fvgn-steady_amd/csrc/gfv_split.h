@@ -16,6 +16,14 @@ __device__ __forceinline__ float gfv_pow2_scale(float m) {
   return __uint_as_float((unsigned)se << 23);
 }
 
+// smallest power of two >= x (x > 0, finite; clamped to [2^-20, 2^40])
+__device__ __forceinline__ float gfv_pow2_ceil(float x) {
+  const unsigned u = __float_as_uint(x);
+  int e = (int)((u >> 23) & 255u) + ((u & 0x7fffffu) ? 1 : 0);
+  e = min(max(e, 107), 167);
+  return __uint_as_float((unsigned)e << 23);
+}
+
 __device__ __forceinline__ unsigned gfv_pk_f16(float a, float b) {
   const gfv_f16x2 v = __builtin_convertvector(gfv_float2{a, b}, gfv_f16x2);
   return __builtin_bit_cast(unsigned, v);

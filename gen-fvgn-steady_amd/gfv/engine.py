@@ -134,6 +134,11 @@ class Engine:
         # SIMD (tchain_fwd.hip) the two forward uses lose to a seg_gather_sum launch + a plain chain; step time, one-box
         # A/B, masks 7 / 3 / 1 / 2 / 0 / 6 / 5 / 4: 4.313 / 4.345 / 4.310 / 4.308 / 4.273 / 4.282 / 4.275 / 4.252 ms
         self._fuse_mask = int(os.environ.get("GFV_CSR_FUSE_MASK", "4"))
+        # weight gradients fused into the dX chain of the big MLP launches (column-owner backward family, include/gfv.h
+        # gfv_rowtile_args_t.dw_partial): the chain launch accumulates dW3, dW2 (and dW1 of a 128-deep first layer), the bias
+        # gradients and the LayerNorm's per workgroup; one reduction launch per MLP sums the blocks
+        self.fuse_dw = os.environ.get("GFV_FUSE_DW", "1") != "0"
+        self._fuse_dw_min = int(os.environ.get("GFV_COLCHAIN_BWD_MIN_M", "16384"))
         self._wi, self._wi_key, self._wmax, self._wi_abs = None, None, None, None
         self._pkey_cache = None
         self._zero_e = None
@@ -374,16 +379,19 @@ class Engine:
         y3 = _empty(dev, M, 128) if (keep and ln) else None
         out = _empty(dev, M, nout)
         nores = _empty(dev, M, 128) if want_nores else None
+        # (mean, 1 / std) of the LayerNorm rows for a backward launch that fuses the weight gradients (it does not recompute them)
+        stats = _empty(dev, M, 2) if (keep and ln and self.fuse_dw and self.f16split and self.hidden == 128 and nout == 128
+                                      and M >= self._fuse_dw_min and all(sg.width % 32 == 0 for sg in segs)) else None
         ops.rowtile_chain(
             M, segs,
             [LayerSpec(W1, b1, L.OP_BIAS_GELU, save=z1), LayerSpec(W2, b2, L.OP_BIAS_GELU, save=z2), LayerSpec(W3, b3)],
             [out], in_add=in_add, fin_op=L.FIN_LN if ln else L.FIN_PLAIN,
             fin_gamma=P[names[6]] if ln else None, fin_beta=P[names[7]] if ln else None, fin_presave=y3,
-            res=[res] if res is not None else None, out_nores=nores,
+            res=[res] if res is not None else None, out_nores=nores, fin_stats=stats,
             **(dict(padd=padd[0], padd_s=padd[1], padd_r=padd[2]) if padd is not None else {}))
         # (a segmented-sum input segment is kept for the backward in its assembled form, written by the launch itself)
         saved = dict(z1=z1, z2=z2, y3=y3, segs=segs if saved_segs is None else saved_segs, in_add=in_add, M=M, ln=ln,
-                     prefix=prefix)
+                     prefix=prefix, stats=stats)
         return out, nores, saved
 
     def mlp3_bwd(self, P, sv, G, grads, *, outs=None, res=None, gadd=None, W1t=None, g_ld=None, g_add=None):
@@ -395,6 +403,10 @@ class Engine:
         dev = W1.device
         nout = W3.shape[0]
         W3t, W2t = self._T(W3), self._T(W2)
+        if (self.fuse_dw and ln and sv.get("stats") is not None and outs is not None and G.stride(0) == 128 and g_ld is None
+                and gadd is None and self._mlp3_bwd_fused(P, sv, G, grads, names, W3t, W2t, W1t if W1t is not None else self._T(W1),
+                                                          outs, res, g_add)):
+            return
         gz2, gz1 = _empty(dev, M, 128), _empty(dev, M, 128)
         tiles_n = ops.rowtile_tiles(M)
         part = _empty(dev, tiles_n, 2, 128) if ln else None
@@ -442,6 +454,43 @@ class Engine:
             ops.reduce_multi(pieces)
         self.defer(side, gz1, gz2, g3, G, part, gs, sv["z1"], sv["z2"], sv["in_add"], *[sg.t for sg in sv["segs"]],
                    *[sg.idx for sg in sv["segs"]])
+
+    def _mlp3_bwd_fused(self, P, sv, G, grads, names, W3t, W2t, W1t, outs, res, g_add):
+        """mlp3_bwd with the weight gradients of the third and second Linear (and their bias / LayerNorm gradients) fused into
+        the chain launch (column-owner backward family); the first layer's by the weight-gradient kernel over its input segments,
+        with the row scales the chain leaves behind.  False: the library would not run this launch fused."""
+        M = sv["M"]
+        dev = G.device
+        lib = L.load()
+        nwg = lib.gfv_rowtile_dw_partials()
+        FL = L.DW_FUSED_FLOATS
+        dwp = _empty(dev, nwg, FL)
+        gz1 = _empty(dev, M, 128)
+        gs = _empty(dev, 3, ops.gscale_ld(M))
+        layers = [LayerSpec(W3t, None, L.OP_MUL_DGELU, aux=sv["z2"]), LayerSpec(W2t, None, L.OP_MUL_DGELU, save=gz1, aux=sv["z1"]),
+                  LayerSpec(W1t)]
+        kw = dict(res=res, in_op=L.IN_LNBWD, in_gamma=P[names[6]], in_aux=sv["y3"], in_stats=sv["stats"], dw_partial=dwp, gscale=gs,
+                  in_add=g_add)
+        if not ops.rowtile_chain(M, [Seg(G)], layers, outs, query_fused=True, **kw):
+            return False
+        ops.rowtile_chain(M, [Seg(G)], layers, outs, **kw)
+        segs = sv["segs"]
+
+        def side():
+            lay = [(names[0], names[1], len(segs))]
+            tiles = [self._tile(gz1, 128, sg, in_add=sv["in_add"] if i == 0 else None, gscale=gs[2],
+                                a_op=L.DW_COLSCALE if sg.width <= 16 else 0) for i, sg in enumerate(segs)]
+            w1, slabs1, blen1, _ = self._dw_block(grads, lay, tiles, M, reduce=False)
+            off0, _ = grads.block(names[0], names[1])
+            base = dwp.data_ptr()
+            piece = lambda off, out, cols: dict(partial=base + 4 * off, out=out, n_chunks=nwg, chunk_stride=FL, rows=1, cols=cols)
+            ops.reduce_multi([
+                dict(partial=w1, out=grads.flat.data_ptr() + 4 * off0, n_chunks=slabs1, chunk_stride=blen1, rows=1, cols=blen1),
+                piece(16384 + 128, self._gview2(grads, names[2], names[3]), 16384 + 128),   # dW2 | db2
+                piece(0, self._gview2(grads, names[4], names[5]), 16384 + 128),             # dW3 | db3
+                piece(2 * 16384 + 256, self._gview2(grads, names[6], names[7]), 256)])      # dgamma | dbeta
+        self.defer(side, dwp, gz1, gs, sv["in_add"], *[sg.t for sg in segs], *[sg.idx for sg in segs])
+        return True
 
     @staticmethod
     def _gview2(grads, n0, n1):
@@ -559,10 +608,14 @@ class Engine:
         W1, W2, W3 = P[names[0]], P[names[2]], P[names[4]]
         dev = W1.device
         W3t, W2t, W1ct, Wabt = self._T(W3), self._T(W2), self._T(W1, perm="c"), self._T(W1, perm="ab")
+        e = sv["segs"][0].t
+        if self.fuse_dw and sv.get("stats") is not None and e.stride(0) == 128 and G.stride(0) == 128:
+            fused = self._edge_bwd_fused(P, sv, G, grads, pl, gadd, names, (W3t, W2t, W1ct, Wabt))
+            if fused is not None:
+                return fused
         gz2, gz1, g3, g_e_in = (_empty(dev, M, 128) for _ in range(4))
         tiles_n = ops.rowtile_tiles(M)
         part = _empty(dev, tiles_n, 2, 128)
-        e = sv["segs"][0].t
         gs = _empty(dev, 3, ops.gscale_ld(M))
         have = ops.rowtile_chain(M, [Seg(G)],
                                  [LayerSpec(W3t, None, L.OP_MUL_DGELU, save=gz2, aux=sv["z2"]),
@@ -608,6 +661,72 @@ class Engine:
                 dict(partial=part, out=self._gview2(grads, names[6], names[7]), n_chunks=tiles_n, chunk_stride=256, rows=1,
                      cols=256)])
         self.defer(side, gz1, gz2, g3, G_s, G_r, nb, e, part, gs, sv["z1"], sv["z2"])
+        return g_nb, g_e_in
+
+    def _edge_bwd_fused(self, P, sv, G, grads, pl, gadd, names, Wt):
+        """edge_bwd_factored with every edge-level weight gradient fused into the chain launch (column-owner backward family):
+        one chain launch over the E rows leaves per-workgroup blocks [dW3 | db3 | dW2 | db2 | dgamma | dbeta | dW1c | db1]; the
+        side stream then needs only the node-level pair of W1a / W1b tiles and ONE reduction launch.  None: the library would not
+        run this launch fused (shape / size / product form) - the caller takes the separate path."""
+        M, N = sv["M"], pl.N
+        W3t, W2t, W1ct, Wabt = Wt
+        dev = G.device
+        e = sv["segs"][0].t
+        lib = L.load()
+        nwg = lib.gfv_rowtile_dw_partials()
+        fuse1 = os.environ.get("GFV_FUSE_DW1", "0") == "1"   # the first layer's gradient in the chain launch too (it spills: off)
+        FL = L.DW_FUSED_FLOATS_IN if fuse1 else L.DW_FUSED_FLOATS
+        dwp = _empty(dev, nwg, FL)
+        gz1, g_e_in = _empty(dev, M, 128), _empty(dev, M, 128)
+        layers = [LayerSpec(W3t, None, L.OP_MUL_DGELU, aux=sv["z2"]), LayerSpec(W2t, None, L.OP_MUL_DGELU, save=gz1, aux=sv["z1"]),
+                  LayerSpec(W1ct)]
+        gs = _empty(dev, 3, ops.gscale_ld(M))   # slot 2: the scales of gz1's rows for the first layer's weight-gradient launch
+        kw = dict(res=[G], in_op=L.IN_LNBWD, in_gamma=P[names[6]], in_aux=sv["y3"], in_stats=sv["stats"], gadd=gadd[0], gadd_s=gadd[1],
+                  gadd_r=gadd[2], dw_partial=dwp, dw_in=e if fuse1 else None, gscale=gs)
+        if not ops.rowtile_chain(M, [Seg(G)], layers, [g_e_in], query_fused=True, **kw):
+            return None
+        ops.rowtile_chain(M, [Seg(G)], layers, [g_e_in], **kw)
+        # adjoint of the gathers (W1a nb)[s], (W1b nb)[r]: per-side scatter of dz1 to the nodes, then ONE node-level GEMM
+        g_nb = _empty(dev, N, 128)
+        if self.csr_fuse and (self._fuse_mask & 4):
+            G_s, G_r = _empty(dev, N, 128), _empty(dev, N, 128)
+            ops.rowtile_chain(N, [Seg(gz1, csr=(pl.s_rowptr, pl.s_col), save=G_s), Seg(gz1, csr=(pl.r_rowptr, pl.r_col), save=G_r)],
+                              [LayerSpec(Wabt)], [g_nb])
+        else:
+            G_s = ops.seg_gather_sum(gz1, pl.s_rowptr, pl.s_col, N)
+            G_r = ops.seg_gather_sum(gz1, pl.r_rowptr, pl.r_col, N)
+            ops.rowtile_chain(N, [Seg(G_s), Seg(G_r)], [LayerSpec(Wabt)], [g_nb])
+        nb = sv["nb"]
+
+        def side():
+            tmpE, tmpN = self._edge_tmp(dev)
+            gW1 = grads.view(names[0])
+            base = dwp.data_ptr()
+            piece = lambda off, out, rows, cols, ld_out=None: dict(partial=base + 4 * off, out=out, n_chunks=nwg, chunk_stride=FL,
+                                                                   rows=rows, cols=cols, ld_in=cols, ld_out=cols if ld_out is None else ld_out)
+            pieces = [piece(16384 + 128, self._gview2(grads, names[2], names[3]), 1, 16384 + 128),   # dW2 | db2
+                      piece(0, self._gview2(grads, names[4], names[5]), 1, 16384 + 128),             # dW3 | db3
+                      piece(2 * 16384 + 256, self._gview2(grads, names[6], names[7]), 1, 256)]       # dgamma | dbeta
+            used = 0
+            if fuse1:
+                pieces += [piece(2 * 16384 + 512, gW1.data_ptr() + 4 * 256, 128, 128, 384),           # dW1c -> W1[:, 256:384]
+                           piece(3 * 16384 + 512, grads.view(names[1]), 1, 128)]                      # db1
+            else:
+                # the first layer's c block by the weight-gradient kernel (one tile over the E rows): slab partials laid out
+                # like a stand-in [W1c | b1] block
+                lay = [("W1c", "b1", 1)]
+                self._workspace(lib.gfv_dw_multi_workspace_floats(M, 1, tmpE.block("W1c", "b1")[1])
+                                + lib.gfv_dw_multi_workspace_floats(N, 2, tmpN.block("W1ab", "W1ab")[1]) + 8, dev)   # both regions, once
+                w1, slabs1, blen1, used = self._dw_block(tmpE, lay, [self._tile(gz1, 128, Seg(e), gscale=gs[2])], M, reduce=False)
+                ob1, lb1 = tmpE.block("b1", "b1")
+                pieces += [dict(partial=w1, out=gW1.data_ptr() + 4 * 256, n_chunks=slabs1, chunk_stride=blen1, rows=128, cols=128, ld_out=384),
+                           dict(partial=w1 + 4 * ob1, out=grads.view(names[1]), n_chunks=slabs1, chunk_stride=blen1, rows=1, cols=128)]
+            w2, slabs2, blen2, _ = self._dw_block(tmpN, [("W1ab", None, 2)],
+                                                  [self._tile(G_s, 128, Seg(nb)), self._tile(G_r, 128, Seg(nb))], N, reduce=False,
+                                                  ws_offset=used)
+            pieces.append(dict(partial=w2, out=gW1.data_ptr(), n_chunks=slabs2, chunk_stride=blen2, rows=128, cols=256, ld_out=384))
+            ops.reduce_multi(pieces)
+        self.defer(side, dwp, gz1, e, G_s, G_r, nb, gs)
         return g_nb, g_e_in
 
     def gn_bwd(self, P, sv, g_x_out, g_e_out, grads, pl):

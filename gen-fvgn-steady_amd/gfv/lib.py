@@ -46,10 +46,12 @@ class RowtileArgs(C.Structure):
         ("padd_ld", C.c_int32), ("flags", C.c_int32), ("wmax", C.c_void_p),
         ("gscale", C.c_void_p), ("gscale_ld", C.c_int32), ("pad3_", C.c_int32),
         ("fin_stats", C.c_void_p), ("in_stats", C.c_void_p), ("dw_partial", C.c_void_p), ("dw_partial_stride", C.c_int64),
+        ("dw_in", C.c_void_p), ("dw_in_ld", C.c_int32), ("reserved2_", C.c_int32),
     ]
 
 
 DW_FUSED_FLOATS = 2 * 128 * 128 + 4 * 128   # floats per workgroup block of a fused weight-gradient launch (include/gfv.h)
+DW_FUSED_FLOATS_IN = 3 * 128 * 128 + 5 * 128   # ... with the first Linear's weight gradient fused as well (dw_in)
 
 
 class WimgDesc(C.Structure):

@@ -156,8 +156,15 @@ typedef struct {
    * layer[0].save / in_save / ln_partial may then be NULL (nothing else reads g3 / gz2). */
   float* dw_partial;
   int64_t dw_partial_stride;
+  /* optional with dw_partial: the input rows [M, dw_in_ld] of the forward's FIRST Linear when it is 128 deep (a plain
+   * [M, 128] row block: the EdgeBlock's edge latents in the factored form).  The launch then fuses that weight gradient as
+   * well,  dW1 = gz1^T x  (gz1 = layer 1's product) and its bias gradient, appended to the block: [... | dW1 | db1]
+   * (GFV_DW_FUSED_FLOATS_IN floats). */
+  const float* dw_in;
+  int32_t dw_in_ld;
+  int32_t reserved2_;
 } gfv_rowtile_args_t;
-enum { GFV_DW_FUSED_FLOATS = 2 * 128 * 128 + 4 * 128 };
+enum { GFV_DW_FUSED_FLOATS = 2 * 128 * 128 + 4 * 128, GFV_DW_FUSED_FLOATS_IN = 3 * 128 * 128 + 5 * 128 };
 int gfv_rowtile_dw_partials(void);                              /* workgroups (= partial blocks) of a fused launch */
 int gfv_rowtile_fuses_dw(const gfv_rowtile_args_t* args);       /* 1: gfv_rowtile_chain would run this launch with fused weight gradients */
 

@@ -136,7 +136,8 @@ def test_column_owner_hidden_range_flag(dev):
 
 @pytest.mark.parametrize("M", [4000, 97, 1024])
 @pytest.mark.parametrize("extras", [True, False])
-def test_column_owner_backward_with_fused_weight_gradients(dev, M, extras):
+@pytest.mark.parametrize("dw1", [True, False])
+def test_column_owner_backward_with_fused_weight_gradients(dev, M, extras, dw1):
     """EdgeBlock backward in its factored form: LayerNorm backward, the three transposed layers, residual; with the weight
     gradients of the third and second Linear, their bias gradients and (dgamma, dbeta) accumulated by the same launch
     (include/gfv.h, gfv_rowtile_args_t.dw_partial) - every piece against float64 autograd."""
@@ -169,8 +170,10 @@ def test_column_owner_backward_with_fused_weight_gradients(dev, M, extras):
     gz1 = torch.full((M, 128), float("nan"), device=dev)
     ge = torch.full((M, 128), float("nan"), device=dev)
     nwg = L.load().gfv_rowtile_dw_partials()
-    part = torch.full((nwg, L.DW_FUSED_FLOATS), float("nan"), device=dev)
+    part = torch.full((nwg, L.DW_FUSED_FLOATS_IN if dw1 else L.DW_FUSED_FLOATS), float("nan"), device=dev)
     kw = dict(gadd=d(gagg), gadd_s=d(s.int()), gadd_r=d(r.int()), in_add=d(gadd2)) if extras else {}
+    if dw1:
+        kw["dw_in"] = d(e)
     args = dict(in_op=L.IN_LNBWD, in_gamma=Pd["gamma"], in_aux=y3d, in_stats=stats, res=[god], dw_partial=part, wimg=wi,
                 family=L.CHAIN_COLUMN_OWNER, **kw)
     layers = [ops.LayerSpec(W3t, None, L.OP_MUL_DGELU, aux=z2d), ops.LayerSpec(W2t, None, L.OP_MUL_DGELU, save=gz1, aux=z1d),
@@ -185,8 +188,11 @@ def test_column_owner_backward_with_fused_weight_gradients(dev, M, extras):
     tot = part.double().sum(0).cpu()
     dW3, db3 = tot[:16384].view(128, 128), tot[16384:16512]
     dW2, db2 = tot[16512:16512 + 16384].view(128, 128), tot[16512 + 16384:16512 + 16384 + 128]
-    dgam, dbet = tot[-256:-128], tot[-128:]
-    for mine, name in ((dW3, "W3"), (db3, "b3"), (dW2, "W2"), (db2, "b2"), (dgam, "gamma"), (dbet, "beta")):
+    dgam, dbet = tot[2 * 16384 + 256:2 * 16384 + 384], tot[2 * 16384 + 384:2 * 16384 + 512]
+    pieces = [(dW3, "W3"), (db3, "b3"), (dW2, "W2"), (db2, "b2"), (dgam, "gamma"), (dbet, "beta")]
+    if dw1:
+        pieces += [(tot[2 * 16384 + 512:3 * 16384 + 512].view(128, 128), "W1"), (tot[3 * 16384 + 512:], "b1")]
+    for mine, name in pieces:
         assert rel(mine, Pg[name].grad) < TOL, (name, rel(mine, Pg[name].grad))
     # gz1 feeds the separate first-layer weight gradient and the node-level scatter
     dW1, db1 = ops.linear_dw(gz1, 128, [ops.Seg(d(e))], M)
@@ -194,3 +200,47 @@ def test_column_owner_backward_with_fused_weight_gradients(dev, M, extras):
     flags = L.C.c_int32(0)
     L.check(L.load().gfv_status_flags(L.C.byref(flags)), "gfv_status_flags")
     assert flags.value == 0
+
+
+@pytest.mark.parametrize("M", [3000, 333])
+def test_column_owner_backward_node_mlp_192_wide(dev, M):
+    """NodeBlock dX chain: last layer 192 wide, written as [x part 128 (+ residual) | neighbour-mean part 64] (blocks.py:54
+    adjoint); weight gradients of the third and second Linear fused, the first one's by the weight-gradient kernel with the
+    row scales the chain launch leaves behind."""
+    from gfv import lib as L, ops
+    g = torch.Generator().manual_seed(M)
+    nbm, x = torch.randn(M, 64, generator=g), torch.randn(M, 128, generator=g)
+    P = _params(g, 192)
+    Pg = {k: v.double().requires_grad_(True) for k, v in P.items()}
+    X = torch.cat((nbm, x), 1).double().requires_grad_(True)
+    z1, z2, y3, ln = _ref(Pg, X)
+    go = torch.randn(M, 128, generator=g) * torch.logspace(-3, 0, M)[:, None]
+    (ln * go.double()).sum().backward()
+    d = lambda t: t.to(dev).contiguous()
+    Pd = {k: d(v) for k, v in P.items()}
+    z1d, z2d, y3d = d(z1.detach().float()), d(z2.detach().float()), d(y3.detach().float())
+    stats = d(torch.stack((y3.detach().mean(1), (y3.detach().var(1, unbiased=False) + 1e-5).rsqrt()), 1).float())
+    W1t = torch.empty(192, 128, device=dev)          # rows for x first, then nbm (engine._T(perm=True))
+    ops.transpose(Pd["W1"], out=W1t[0:128], col0=64, ncols=128)
+    ops.transpose(Pd["W1"], out=W1t[128:192], col0=0, ncols=64)
+    wi = _images(dev, [P["W1"], P["W2"], P["W3"]])
+    gx, gnbm = torch.full((M, 128), float("nan"), device=dev), torch.full((M, 64), float("nan"), device=dev)
+    gz1 = torch.full((M, 128), float("nan"), device=dev)
+    part = torch.full((L.load().gfv_rowtile_dw_partials(), L.DW_FUSED_FLOATS), float("nan"), device=dev)
+    gs = torch.zeros(3, ops.gscale_ld(M), device=dev)
+    god = d(go)
+    layers = [ops.LayerSpec(ops.transpose(Pd["W3"]), None, L.OP_MUL_DGELU, aux=z2d),
+              ops.LayerSpec(ops.transpose(Pd["W2"]), None, L.OP_MUL_DGELU, save=gz1, aux=z1d), ops.LayerSpec(W1t)]
+    kw = dict(res=[god, None], in_op=L.IN_LNBWD, in_gamma=Pd["gamma"], in_aux=y3d, in_stats=stats, dw_partial=part, gscale=gs,
+              wimg=wi, family=L.CHAIN_COLUMN_OWNER)
+    assert ops.rowtile_chain(M, [ops.Seg(god)], layers, [gx, (gnbm, 64)], query_fused=True, **kw)
+    ops.rowtile_chain(M, [ops.Seg(god)], layers, [gx, (gnbm, 64)], **kw)
+    assert L.load().gfv_rowtile_last_path() == 5 + 16
+    assert rel(gx, X.grad[:, 64:] + go.double()) < TOL and rel(gnbm, X.grad[:, :64]) < TOL
+    tot = part.double().sum(0).cpu()
+    for mine, name in ((tot[:16384].view(128, 128), "W3"), (tot[16384:16512], "b3"), (tot[16512:16512 + 16384].view(128, 128), "W2"),
+                       (tot[16512 + 16384:16512 + 16384 + 128], "b2"), (tot[2 * 16384 + 256:2 * 16384 + 384], "gamma"),
+                       (tot[2 * 16384 + 384:2 * 16384 + 512], "beta")):
+        assert rel(mine, Pg[name].grad) < TOL, (name, rel(mine, Pg[name].grad))
+    dW1, db1 = ops.linear_dw(gz1, 128, [ops.Seg(d(nbm)), ops.Seg(d(x))], M, gscale=gs[2])
+    assert rel(dW1, Pg["W1"].grad) < TOL and rel(db1, Pg["b1"].grad) < TOL
