@@ -61,13 +61,13 @@ extern "C" int gfv_rowtile_dw_partials(void) { return cc_cus(); }
 extern "C" int gfv_rowtile_fuses_dw(const gfv_rowtile_args_t* a) {
   if (!a || gfv_hidden_size() != 128 || gfv_f16split_enabled() == 0) return 0;
   gfv_rowtile_args_t t = *a;
-  t.pad_ = 128;
+  t.hidden = 128;
   return cc_bwd_ok(&t) ? 1 : 0;
 }
 
 // 1: launched; 2: launched with fused weight gradients; 0: not this family's launch
 int gfv_internal_colchain_try(const gfv_rowtile_args_t* a, hipStream_t stream) {
-  if (a->pad_ == 128 && cc_bwd_ok(a)) {
+  if (a->hidden == 128 && cc_bwd_ok(a)) {
     int* st = gfv_internal_status_ptr();
     if (!st) return 0;
     const dim3 grid(cc_cus()), blk(64 * CC_W);
@@ -80,7 +80,7 @@ int gfv_internal_colchain_try(const gfv_rowtile_args_t* a, hipStream_t stream) {
     else if (a->dw_in) hipLaunchKernelGGL((colchain_bwd_kernel<LOWP, false, true>), grid, blk, 0, stream, *a, st);                \
     else hipLaunchKernelGGL((colchain_bwd_kernel<LOWP, false, false>), grid, blk, 0, stream, *a, st);                             \
   } while (0)
-    if (a->pad3_ != 0) CB_LAUNCH(true);
+    if (a->product_form != 0) CB_LAUNCH(true);
     else CB_LAUNCH(false);
 #undef CB_LAUNCH
     return 2;
@@ -90,7 +90,7 @@ int gfv_internal_colchain_try(const gfv_rowtile_args_t* a, hipStream_t stream) {
   static const int min_m = cc_env("GFV_COLCHAIN_MIN_M", 16384);
   if (a->flags & GFV_CHAIN_ROW_OWNER) return 0;
   if (!(a->flags & GFV_CHAIN_COLUMN_OWNER) && (!on || a->M < min_m)) return 0;
-  if (a->nlayers != 3 || a->pad_ != 128 || !a->wmax) return 0;
+  if (a->nlayers != 3 || a->hidden != 128 || !a->wmax) return 0;
   for (int l = 0; l < 3; ++l) {
     const gfv_layer_t& L = a->layer[l];
     if (!L.Wh || L.N != 128 || L.bias2 || (l > 0 && L.K != 128)) return 0;
@@ -118,9 +118,26 @@ int gfv_internal_colchain_try(const gfv_rowtile_args_t* a, hipStream_t stream) {
   if (!fwd) return 0;
   if (!al16(a->fin_gamma) || !al16(a->fin_beta) || (a->fin_presave && !al16(a->fin_presave))) return 0;
   if (node && a->padd) return 0;
+  // second generation (colchain_fwd2_kernel): the edge shape (one 128-wide segment), every [M,128] array with row stride 128
+  static const int gen2 = cc_env("GFV_COLCHAIN_GEN2", 1);   // 0: first generation; 2 / 4: waves per SIMD the allocation aims at
+  if (gen2 && edge && a->M <= (1 << 22) && !a->seg[0].idx && a->seg[0].ld == 128 && a->out_ld[0] == 128 &&
+      (!a->res[0] || a->res_ld[0] == 128) && (!a->padd || a->padd_ld <= 4096)) {
+    const dim3 blk2(64 * CC_W);
+    const bool lp = a->product_form != 0;
+#define CF2(PADD, LP, WPS) hipLaunchKernelGGL((colchain_fwd2_kernel<PADD, LP, WPS>), dim3(cc_cus() * (WPS == 4 ? 2 : 1)), blk2, 0, stream, *a, status)
+    if (gen2 == 4) {
+      if (a->padd) { if (lp) CF2(true, true, 4); else CF2(true, false, 4); }
+      else { if (lp) CF2(false, true, 4); else CF2(false, false, 4); }
+    } else {
+      if (a->padd) { if (lp) CF2(true, true, 2); else CF2(true, false, 2); }
+      else { if (lp) CF2(false, true, 2); else CF2(false, false, 2); }
+    }
+#undef CF2
+    return 1;
+  }
   static const int lite = cc_env("GFV_COLCHAIN_LITE", 1);   // 1: the high-occupancy form (2 workgroups per CU), 0: resident weights
   const dim3 blk(64 * CC_W);
-  const bool lowp = a->pad3_ != 0;
+  const bool lowp = a->product_form != 0;
 #define CC_LAUNCH(KT0, N0, TG, PADD, LITE)                                                                                    \
   do {                                                                                                                        \
     const dim3 grid(cc_cus() * (LITE ? 2 : 1));                                                                               \

@@ -748,12 +748,16 @@ __global__ __launch_bounds__(64 * CC_W, 2) void colchain_bwd_kernel(const gfv_ro
     step2 = 1.0f / gfv_pow2_ceil(g1);
   }
 
+  // (DW1: the 36 registers of the third accumulator set leave no room for rows in flight a tile ahead - they are loaded in P0)
+  constexpr bool PRE = !DW1;
   int gidx[TG] = {0, 0, 0, 0};
   CbIn in;
   if (g_beg < g_end) {
     cb_load_gidx<GADD>(B, c, 16 * g_beg, gidx);
-    cb_load_inputs(B, c, 16 * g_beg, in);
-    cb_load_gathers<GADD>(B, c, gidx, in);
+    if (PRE) {
+      cb_load_inputs(B, c, 16 * g_beg, in);
+      cb_load_gathers<GADD>(B, c, gidx, in);
+    }
   }
   CT_DECL
   for (int t0 = g_beg; t0 < g_end; t0 += TG) {
@@ -772,6 +776,10 @@ __global__ __launch_bounds__(64 * CC_W, 2) void colchain_bwd_kernel(const gfv_ro
     float gg[TG][4], xh[TG][4], rs[TG];
     {
       float bmax = 0.f;
+      if (!PRE) {
+        cb_load_inputs(B, c, c.row0, in);
+        cb_load_gathers<GADD>(B, c, gidx, in);
+      }
       if (A.in_add) {
         const cb_rsrc ia = cb_buf(A.in_add, rows128);
 #pragma unroll
@@ -1002,8 +1010,10 @@ __global__ __launch_bounds__(64 * CC_W, 2) void colchain_bwd_kernel(const gfv_ro
     CT(10);
     // the next tile's rows (and its gathered addend rows): in flight through the last weight gradients.  (Issued any earlier
     // they sit in 56 registers beside a chain phase, and the kernel spills: a scratch reload waits for every load in flight.)
-    cb_load_inputs(B, c, next_row0, in);
-    cb_load_gathers<GADD>(B, c, gidx, in);
+    if (PRE) {
+      cb_load_inputs(B, c, next_row0, in);
+      cb_load_gathers<GADD>(B, c, gidx, in);
+    }
     cb_dw_tile<LOWP>(b1, b2, np, c.w, c.lane, dw2, db2);
     if constexpr (DW1) cb_dw_tile<LOWP>(b0, b3, np, c.w, c.lane, dw1, db1);
     CT(11);
@@ -1050,6 +1060,269 @@ __global__ __launch_bounds__(64 * CC_W, 2) void colchain_bwd_kernel(const gfv_ro
     }
   }
   if (c.mabs > 60000.0f) atomicOr(status, 2);
+}
+
+
+// =====================================================================================================================
+// Forward form, second generation: the structure that made the backward kernel fast, applied to the forward chain.
+// Against colchain_fwd_kernel above: no loader roles (every wave loads ITS 16 columns of the tile's input rows, the row
+// maxima for the row scales are combined through LDS behind the barrier the phase needs anyway), buffer addressing (one
+// 32-bit offset per row group for every [M, 128] array, bounds-checked stores instead of exec-masked ones), the layers'
+// weight slices fetched one phase ahead instead of resident, the gathered first-layer addend and the next tile's rows in
+// flight a phase / a tile ahead, the last layer's values kept in registers through the LayerNorm barrier.  Tiles of
+// TG = 4 groups (64 rows), five barriers per tile; WPS = waves per SIMD the register allocation aims at (2: one workgroup
+// per CU; 4: two, 128 registers).
+//   P0   (rows loaded a tile ahead) per-wave row maxima -> LDS;  the addend gathers and layer 0's slice go out
+//   P0b  row scale from the eight partial maxima; input fragments
+//   P1   layer 0 -> z1 (+ bias + addend) saved, gelu -> fragments;  P2  layer 1 likewise;  P3  layer 2 -> y3 saved,
+//        (mean, M2) partials of the LayerNorm -> LDS, values stay in registers
+//   P4   LayerNorm from the eight partials, statistics / pre-residual / output rows stored; next tile's rows requested
+struct CfLds {
+  static constexpr int XIN = 0;
+  static constexpr int XMID = CB_TG * 8192;
+  static constexpr int RMAX = 2 * CB_TG * 8192;                 // float [TG][16][8]: per-wave max |x| of a row's 16 columns
+  static constexpr int LNP = RMAX + CB_TG * 16 * 8 * 4;        // float2 [TG][16][8]
+  static constexpr int TOTAL = LNP + CB_TG * 16 * 8 * 8;
+};
+
+template <bool PADD, bool LOWP, int WPS>
+__global__ __launch_bounds__(64 * CC_W, WPS) void colchain_fwd2_kernel(const gfv_rowtile_args_t A, int* status) {
+  constexpr int TG = CB_TG;
+  __shared__ __attribute__((aligned(16))) char lds[CfLds::TOTAL];
+  char* xin = lds + CfLds::XIN;
+  char* xmid = lds + CfLds::XMID;
+  float* rmax = reinterpret_cast<float*>(lds + CfLds::RMAX);
+  float* lnp = reinterpret_cast<float*>(lds + CfLds::LNP);
+
+  CcCtx c;
+  c.w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  c.lane = threadIdx.x & 63;
+  c.j = c.lane & 15;
+  c.g = c.lane >> 4;
+  c.col0 = 16 * c.w + 4 * c.g;
+  c.M = A.M;
+  c.mabs = 0.f;
+  c.invw = 1.0f / gfv_pow2_scale(*A.wmax);
+
+  const int nwg = gridDim.x;
+  const int wg = (nwg & 7) == 0 ? (int)(blockIdx.x & 7) * (nwg >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  const int NG = (A.M + 15) >> 4;
+  const int g_beg = (int)((long)NG * wg / nwg), g_end = (int)((long)NG * (wg + 1) / nwg);
+
+  const size_t rows128 = (size_t)A.M * 512;
+  const cb_rsrc bx = cb_buf(A.seg[0].ptr, rows128), bz1 = cb_buf(A.layer[0].save, rows128), bz2 = cb_buf(A.layer[1].save, rows128),
+                by3 = cb_buf(A.fin_presave, rows128), bnr = cb_buf(A.out_nores, rows128), bres = cb_buf(A.res[0], rows128),
+                bout = cb_buf(A.out[0], rows128), bst = cb_buf(A.fin_stats, (size_t)A.M * 8),
+                bpad = cb_buf(A.padd, 0x7fffffe0ull), bis = cb_buf(A.padd_s, (size_t)A.M * 4), bir = cb_buf(A.padd_r, (size_t)A.M * 4);
+  const cb_rsrc w0 = cb_buf(A.layer[0].Wh, 65536), w1 = cb_buf(A.layer[1].Wh, 65536), w2 = cb_buf(A.layer[2].Wh, 65536);
+  const int woff = (c.w * 128 + c.lane) * 16;
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float4 bi0 = A.layer[0].bias ? ld4(A.layer[0].bias + c.col0) : zero4;
+  const float4 bi1 = A.layer[1].bias ? ld4(A.layer[1].bias + c.col0) : zero4;
+  const float4 bi2 = A.layer[2].bias ? ld4(A.layer[2].bias + c.col0) : zero4;
+  const int padld4 = A.padd_ld * 4;
+
+  // the first tile's rows and gather rows
+  float4 xv[TG];
+  int is[TG], ir[TG];
+#pragma unroll
+  for (int q = 0; q < TG; ++q) {
+    xv[q] = cb_ld4(bx, cb_off(c, 16 * g_beg, q));
+    if (PADD) {
+      const int ro = min(16 * g_beg + 16 * q + c.j, c.M - 1) * 4;
+      is[q] = __builtin_amdgcn_raw_buffer_load_b32(bis, ro, 0, 0);
+      ir[q] = __builtin_amdgcn_raw_buffer_load_b32(bir, ro, 0, 0);
+    }
+  }
+
+  for (int t0 = g_beg; t0 < g_end; t0 += TG) {
+    c.row0 = 16 * t0;
+    c.ngt = min(TG, g_end - t0);
+    const int np = (c.ngt + 1) >> 1;
+    const int next_row0 = t0 + TG < g_end ? 16 * (t0 + TG) : c.M;
+    int offL[TG], offS[TG];
+#pragma unroll
+    for (int q = 0; q < TG; ++q) {
+      const int row = c.row0 + 16 * q + c.j;
+      offL[q] = cb_off(c, c.row0, q);
+      offS[q] = (q < c.ngt && row < c.M) ? row * 512 + c.col0 * 4 : CB_OFF_DEAD;
+#ifdef GFV_CF_LINEAR_HACK   // experiment only (wrong results): the same bytes stored as whole 512-byte rows, two per instruction
+      const int lrow = c.row0 + 16 * q + 2 * c.w + (c.lane >> 5);
+      offS[q] = (q < c.ngt && lrow < c.M) ? lrow * 512 + (c.lane & 31) * 16 : CB_OFF_DEAD;
+#endif
+    }
+    // ---- P0: this wave's share of the row maxima; the addend rows and layer 0's slice go out ----
+#pragma unroll
+    for (int q = 0; q < TG; ++q) {
+      const float m = row_max4(max3_abs(max3_abs(0.f, xv[q].x, xv[q].y), xv[q].z, xv[q].w));
+      if (c.g == 0) rmax[(q * 16 + c.j) * 8 + c.w] = m;
+    }
+    float4 ps[PADD ? TG : 1], pr[PADD ? TG : 1];
+    if (PADD) {
+#pragma unroll
+      for (int q = 0; q < TG; ++q) {
+        ps[q] = cb_ld4(bpad, is[q] * padld4 + c.col0 * 4);
+        pr[q] = cb_ld4(bpad, ir[q] * padld4 + 512 + c.col0 * 4);
+      }
+    }
+    gfv_f16x8 wh[4], wl[4];
+#pragma unroll
+    for (int T = 0; T < 4; ++T) {
+      wh[T] = __builtin_bit_cast(gfv_f16x8, __builtin_amdgcn_raw_buffer_load_b128(w0, woff + T * 16384, 0, 0));
+      wl[T] = __builtin_bit_cast(gfv_f16x8, __builtin_amdgcn_raw_buffer_load_b128(w0, woff + T * 16384 + 1024, 0, 0));
+    }
+    cc_barrier();
+    // ---- P0b: row scales, input fragments ----
+    float sinv[TG];
+#pragma unroll
+    for (int q = 0; q < TG; ++q) {
+      const float4* pp = reinterpret_cast<const float4*>(rmax + (q * 16 + c.j) * 8);
+      const float4 a = pp[0], b = pp[1];
+      const float sc = gfv_pow2_scale(fmaxf(fmaxf(fmaxf(a.x, a.y), fmaxf(a.z, a.w)), fmaxf(fmaxf(b.x, b.y), fmaxf(b.z, b.w))));
+      sinv[q] = 1.0f / sc;
+      const float x4[4] = {xv[q].x, xv[q].y, xv[q].z, xv[q].w};
+      cc_put_frag(xin, q, c, x4, sc);
+    }
+    cc_barrier();
+    // ---- P1: layer 0, xin -> xmid ----
+    {
+      floatx4 a0, a1;
+      cc_mma_pair<4, LOWP, true>(xin, 0, wh, wl, c.lane, a0, a1);
+#pragma unroll
+      for (int p = 0; p < TG / 2; ++p) {
+        if (p >= np) break;
+        floatx4 n0 = a0, n1 = a1;
+        if (p + 1 < TG / 2) cc_mma_pair<4, LOWP, true>(xin, p + 1, wh, wl, c.lane, n0, n1);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int q = 2 * p + h;
+          const floatx4& acc = h ? a1 : a0;
+          float v[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = (acc[r] * sinv[q]) * c.invw;
+          v[0] += bi0.x; v[1] += bi0.y; v[2] += bi0.z; v[3] += bi0.w;
+          if (PADD) {
+            v[0] += ps[q].x + pr[q].x; v[1] += ps[q].y + pr[q].y; v[2] += ps[q].z + pr[q].z; v[3] += ps[q].w + pr[q].w;
+          }
+          cb_st4(bz1, offS[q], v);
+          float a[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) a[r] = gfv_gelu(v[r]);
+          const float mq = max3_abs(max3_abs(0.f, a[0], a[1]), a[2], a[3]);
+          c.mabs = fmaxf(c.mabs, q < c.ngt ? mq : 0.f);
+          cc_put_frag(xmid, q, c, a, CC_SH);
+        }
+        a0 = n0; a1 = n1;
+      }
+    }
+#pragma unroll
+    for (int T = 0; T < 4; ++T) {
+      wh[T] = __builtin_bit_cast(gfv_f16x8, __builtin_amdgcn_raw_buffer_load_b128(w1, woff + T * 16384, 0, 0));
+      wl[T] = __builtin_bit_cast(gfv_f16x8, __builtin_amdgcn_raw_buffer_load_b128(w1, woff + T * 16384 + 1024, 0, 0));
+    }
+    cc_barrier();
+    // ---- P2: layer 1, xmid -> xin ----
+    {
+      floatx4 a0, a1;
+      cc_mma_pair<4, LOWP, true>(xmid, 0, wh, wl, c.lane, a0, a1);
+#pragma unroll
+      for (int p = 0; p < TG / 2; ++p) {
+        if (p >= np) break;
+        floatx4 n0 = a0, n1 = a1;
+        if (p + 1 < TG / 2) cc_mma_pair<4, LOWP, true>(xmid, p + 1, wh, wl, c.lane, n0, n1);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int q = 2 * p + h;
+          const floatx4& acc = h ? a1 : a0;
+          float v[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = (acc[r] * CC_SH_INV) * c.invw;
+          v[0] += bi1.x; v[1] += bi1.y; v[2] += bi1.z; v[3] += bi1.w;
+          cb_st4(bz2, offS[q], v);
+          float a[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) a[r] = gfv_gelu(v[r]);
+          const float mq = max3_abs(max3_abs(0.f, a[0], a[1]), a[2], a[3]);
+          c.mabs = fmaxf(c.mabs, q < c.ngt ? mq : 0.f);
+          cc_put_frag(xin, q, c, a, CC_SH);
+        }
+        a0 = n0; a1 = n1;
+      }
+    }
+#pragma unroll
+    for (int T = 0; T < 4; ++T) {
+      wh[T] = __builtin_bit_cast(gfv_f16x8, __builtin_amdgcn_raw_buffer_load_b128(w2, woff + T * 16384, 0, 0));
+      wl[T] = __builtin_bit_cast(gfv_f16x8, __builtin_amdgcn_raw_buffer_load_b128(w2, woff + T * 16384 + 1024, 0, 0));
+    }
+    // the residual rows: in flight through P3
+    float4 rr[TG];
+#pragma unroll
+    for (int q = 0; q < TG; ++q) rr[q] = cb_ld4(bres, offL[q]);
+    cc_barrier();
+    // ---- P3: layer 2, xin -> y3 (saved), LayerNorm partials; the values stay in registers ----
+    float y[TG][4];
+    {
+      floatx4 a0, a1;
+      cc_mma_pair<4, LOWP, true>(xin, 0, wh, wl, c.lane, a0, a1);
+#pragma unroll
+      for (int p = 0; p < TG / 2; ++p) {
+        floatx4 n0 = a0, n1 = a1;
+        if (p + 1 < TG / 2) cc_mma_pair<4, LOWP, true>(xin, p + 1, wh, wl, c.lane, n0, n1);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int q = 2 * p + h;
+          const floatx4& acc = h ? a1 : a0;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) y[q][r] = (acc[r] * CC_SH_INV) * c.invw;
+          y[q][0] += bi2.x; y[q][1] += bi2.y; y[q][2] += bi2.z; y[q][3] += bi2.w;
+          cb_st4(by3, offS[q], y[q]);
+          const float mw = row_sum((y[q][0] + y[q][1]) + (y[q][2] + y[q][3])) * 0.0625f;
+          const float d0 = y[q][0] - mw, d1 = y[q][1] - mw, d2 = y[q][2] - mw, d3 = y[q][3] - mw;
+          const float m2 = row_sum((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3));
+          if (c.g == 0) *reinterpret_cast<float2*>(lnp + ((q * 16 + c.j) * 8 + c.w) * 2) = make_float2(mw, m2);
+        }
+        a0 = n0; a1 = n1;
+      }
+    }
+    // the next tile's rows and gather rows: requested here, in flight through P4 and the next tile's P0
+#pragma unroll
+    for (int q = 0; q < TG; ++q) {
+      xv[q] = cb_ld4(bx, cb_off(c, next_row0, q));
+      if (PADD) {
+        const int ro = min(next_row0 + 16 * q + c.j, c.M - 1) * 4;
+        is[q] = __builtin_amdgcn_raw_buffer_load_b32(bis, ro, 0, 0);
+        ir[q] = __builtin_amdgcn_raw_buffer_load_b32(bir, ro, 0, 0);
+      }
+    }
+    cc_barrier();
+    // ---- P4: LayerNorm over the eight waves' partials, affine, residual, stores ----
+    {
+      const float4 gam = ld4(A.fin_gamma + c.col0), bet = ld4(A.fin_beta + c.col0);
+#pragma unroll
+      for (int q = 0; q < TG; ++q) {
+        const float4* pp = reinterpret_cast<const float4*>(lnp + (q * 16 + c.j) * 16);
+        const float4 p0 = pp[0], p1 = pp[1], p2 = pp[2], p3 = pp[3];   // (mean, M2) x 8 waves
+        const float mean = (((p0.x + p0.z) + (p1.x + p1.z)) + ((p2.x + p2.z) + (p3.x + p3.z))) * 0.125f;
+        const float e0 = p0.x - mean, e1 = p0.z - mean, e2 = p1.x - mean, e3 = p1.z - mean, e4 = p2.x - mean,
+                    e5 = p2.z - mean, e6 = p3.x - mean, e7 = p3.z - mean;
+        const float m2 = (((p0.y + p0.w) + (p1.y + p1.w)) + ((p2.y + p2.w) + (p3.y + p3.w))) +
+                         16.0f * (((e0 * e0 + e1 * e1) + (e2 * e2 + e3 * e3)) + ((e4 * e4 + e5 * e5) + (e6 * e6 + e7 * e7)));
+        const float rstd = rsqrtf(m2 * 0.0078125f + 1e-5f);   // nn.LayerNorm eps (EPD.py:32)
+        if (c.w == 0 && c.g == 0) {
+          const int row = c.row0 + 16 * q + c.j;
+          const cb_f32x2 st = {mean, rstd};
+          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(cb_i32x2, st), bst, (q < c.ngt && row < c.M) ? row * 8 : CB_OFF_DEAD, 0, 0);
+        }
+        float o[4] = {(y[q][0] - mean) * rstd * gam.x + bet.x, (y[q][1] - mean) * rstd * gam.y + bet.y,
+                      (y[q][2] - mean) * rstd * gam.z + bet.z, (y[q][3] - mean) * rstd * gam.w + bet.w};
+        cb_st4(bnr, offS[q], o);
+        o[0] += rr[q].x; o[1] += rr[q].y; o[2] += rr[q].z; o[3] += rr[q].w;
+        cb_st4(bout, offS[q], o);
+      }
+    }
+    // (the next tile's P0 writes only rmax, last read in P0b; xin / xmid / lnp are rewritten behind its barriers)
+  }
+  if (c.mabs > CC_SH_LIMIT) atomicOr(status, 2);
 }
 
 }  // namespace

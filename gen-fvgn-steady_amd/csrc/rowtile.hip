@@ -224,11 +224,11 @@ __device__ void stage_input(const gfv_rowtile_args_t& A, int si, float* Xs, cons
     if (A.in_op == GFV_IN_GELU) {
       v = make_float4(gfv_gelu(v.x), gfv_gelu(v.y), gfv_gelu(v.z), gfv_gelu(v.w));
     } else if (A.in_op == GFV_IN_LN) {
-      v = row_layernorm(v, gam, bet, ln_width(A.pad_));
+      v = row_layernorm(v, gam, bet, ln_width(A.hidden));
     } else if (A.in_op == GFV_IN_LNBWD) {
       float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
       if (m < c.M) y = *reinterpret_cast<const float4*>(A.in_aux + (size_t)m * 128 + col);
-      v = row_layernorm_bwd(y, v, gam, dgam, dbet, ln_width(A.pad_));
+      v = row_layernorm_bwd(y, v, gam, dgam, dbet, ln_width(A.hidden));
     }
     if (m >= c.M) v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (si == 0 && A.in_save && m < c.M) *reinterpret_cast<float4*>(A.in_save + (size_t)m * 128 + col) = v;
@@ -311,12 +311,12 @@ __device__ void final_epilogue(const gfv_rowtile_args_t& A, const gfv_layer_t& L
       }
       if (A.fin_op == GFV_FIN_LN) {
         if (A.fin_presave && live) *reinterpret_cast<float4*>(A.fin_presave + (size_t)m * 128 + col) = v;
-        v = row_layernorm(v, gam, bet, ln_width(A.pad_));
+        v = row_layernorm(v, gam, bet, ln_width(A.hidden));
       } else if (A.fin_op == GFV_FIN_LNBWD) {
         float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
         if (live) y = *reinterpret_cast<const float4*>(A.fin_aux + (size_t)m * 128 + col);
         if (!live) v = make_float4(0.f, 0.f, 0.f, 0.f);
-        v = row_layernorm_bwd(y, v, gam, dgam, dbet, ln_width(A.pad_));
+        v = row_layernorm_bwd(y, v, gam, dgam, dbet, ln_width(A.hidden));
       }
       if (live) {
         if (chunk == 0 && A.out_nores) *reinterpret_cast<float4*>(A.out_nores + (size_t)m * 128 + col) = v;
@@ -481,7 +481,9 @@ static int tchain_mode() {
 // GFV_F16SPLIT (or gfv_set_f16split): 0 = every GEMM product on the fp32 MFMA, even when a launch carries split-fp16
 // weight images; 1 (default) = split-fp16 products; 2 = the reduced-precision form, ONE fp16 x fp16 product with fp32
 // accumulation (the high parts only); shared with dw.hip
-static int g_f16split = -1;
+// (thread-local: a launch context of the calling thread, like the HIP runtime's current device - two host threads driving two
+// models do not see each other's settings; a launch may also carry its own, gfv_rowtile_args_t.product_form / .hidden)
+static thread_local int g_f16split = -1;
 extern "C" int gfv_f16split_enabled(void) {
   if (g_f16split < 0) {
     const char* e = getenv("GFV_F16SPLIT");
@@ -500,7 +502,7 @@ static int f16_mode() { return gfv_f16split_enabled(); }
 // real columns) and the attention scale (dim_head = h / 8).  Host-side state read by the launchers (chain: passed in the
 // kernel arguments, also of the generic row-tile kernel; weight gradient: DwLaunch; slice attention: its argument struct) -
 // set it before the launches of a model, gfv.engine.Engine does on every forward / backward.
-static int g_hidden = 128;
+static thread_local int g_hidden = 128;
 extern "C" int gfv_hidden_size(void) { return g_hidden; }
 extern "C" int gfv_set_hidden_size(int32_t h) {
   if (h < 16 || h > 128 || (h & 15)) return GFV_ERR_ARG;
@@ -513,7 +515,22 @@ extern "C" int gfv_rowtile_last_path(void) { return g_last_path; }
 
 extern "C" int gfv_rowtile_tiles(int32_t M) { return (M + BM - 1) / BM; }
 
+static int rowtile_chain_impl(const gfv_rowtile_args_t* args, void* stream);
 extern "C" int gfv_rowtile_chain(const gfv_rowtile_args_t* args, void* stream) {
+  if (!args) return GFV_ERR_ARG;
+  // the launch's own product form / hidden size (0: the calling thread's context)
+  if (args->product_form < 0 || args->product_form > 3 || (args->hidden != 0 && (args->hidden < 16 || args->hidden > 128 || (args->hidden & 15))))
+    return GFV_ERR_ARG;
+  if (args->product_form == 0 && args->hidden == 0) return rowtile_chain_impl(args, stream);
+  const int f0 = g_f16split, h0 = g_hidden;
+  if (args->product_form) g_f16split = args->product_form - 1;   // 1 fp32 MFMA, 2 split-fp16, 3 reduced precision
+  if (args->hidden) g_hidden = args->hidden;
+  const int rc = rowtile_chain_impl(args, stream);
+  g_f16split = f0;
+  g_hidden = h0;
+  return rc;
+}
+static int rowtile_chain_impl(const gfv_rowtile_args_t* args, void* stream) {
   if (!args || args->M < 0 || args->nlayers < 1 || args->nlayers > 3 || args->nseg < 1 || args->nseg > 3) return GFV_ERR_ARG;
   if (args->M == 0) return GFV_OK;
   for (int i = 0; i < args->nseg; ++i)
@@ -622,7 +639,7 @@ extern "C" int gfv_rowtile_chain(const gfv_rowtile_args_t* args, void* stream) {
   else {
     if (args->fin_stats) return GFV_ERR_ARG;   // (the generic row-tile kernel does not write them)
     gfv_rowtile_args_t local = *args;
-    local.pad_ = g_hidden;   // LayerNorm width (gfv_set_hidden_size)
+    local.hidden = g_hidden;   // LayerNorm width (gfv_set_hidden_size)
     if (fast) hipLaunchKernelGGL(rowtile_chain_kernel<true>, dim3(tiles), dim3(256), 0, (hipStream_t)stream, local);
     else hipLaunchKernelGGL(rowtile_chain_kernel<false>, dim3(tiles), dim3(256), 0, (hipStream_t)stream, local);
   }

@@ -48,8 +48,8 @@ extern "C" int gfv_hidden_size(void);         // rowtile.hip
 
 int gfv_internal_tchain_launch(const gfv_rowtile_args_t* args_in, int ragged, int f16, hipStream_t stream) {
   gfv_rowtile_args_t local = *args_in;
-  local.pad3_ = (f16 && gfv_f16split_enabled() == 2) ? 1 : 0;
-  local.pad_ = gfv_hidden_size();   // LayerNorm width (gfv_set_hidden_size)
+  local.product_form = (f16 && gfv_f16split_enabled() == 2) ? 1 : 0;
+  local.hidden = gfv_hidden_size();   // LayerNorm width (gfv_set_hidden_size)
   const gfv_rowtile_args_t* args = &local;
   const int lnm = args->in_op == GFV_IN_LNBWD ? 1 : (args->fin_op == GFV_FIN_LNBWD ? 2 : 0);
   const dim3 wgs((args->M + 63) / 64), blk(256);

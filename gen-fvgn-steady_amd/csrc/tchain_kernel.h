@@ -704,8 +704,8 @@ __global__ __launch_bounds__(64 * NW, GFV_CHAIN_WAVES(H, LNM, RAG)) void tchain_
   gfv_f16x8 xh[4], xl[4];                                    // H: the activations as (hi, lo) B fragments
   float sx = 1.f;                                            // H: this row's current power-of-two scale
   const float ws = H ? gfv_pow2_scale(*A.wmax) : 1.f;        // H: the images' weight scale
-  const bool lowp = H && A.pad3_ != 0;
-  const LnW lnw = ln_width(A.pad_);                          // LayerNorm width (0 / 128: every column)                       // H: reduced-precision form (hi x hi products only)
+  const bool lowp = H && A.product_form != 0;
+  const LnW lnw = ln_width(A.hidden);                          // LayerNorm width (0 / 128: every column)                       // H: reduced-precision form (hi x hi products only)
 
   // gather rows of the factored first-layer addend: index round trip issued first thing, used in the first epilogue
   const float* pad_s[T];

@@ -39,12 +39,12 @@ class RowtileArgs(C.Structure):
         ("M", C.c_int32), ("nseg", C.c_int32), ("seg", Seg * 3), ("in_add", C.c_void_p), ("in_op", C.c_int32),
         ("nlayers", C.c_int32), ("in_gamma", C.c_void_p), ("in_beta", C.c_void_p), ("in_aux", C.c_void_p),
         ("gadd", C.c_void_p), ("gadd_s", C.c_void_p), ("gadd_r", C.c_void_p), ("in_save", C.c_void_p),
-        ("ln_partial", C.c_void_p), ("layer", Layer * 3), ("fin_op", C.c_int32), ("pad_", C.c_int32),
+        ("ln_partial", C.c_void_p), ("layer", Layer * 3), ("fin_op", C.c_int32), ("hidden", C.c_int32),
         ("fin_gamma", C.c_void_p), ("fin_beta", C.c_void_p), ("fin_aux", C.c_void_p), ("fin_presave", C.c_void_p),
         ("res", C.c_void_p * 3), ("res_ld", C.c_int32 * 3), ("out_ld", C.c_int32 * 3), ("out", C.c_void_p * 3),
         ("out_nores", C.c_void_p), ("padd", C.c_void_p), ("padd_s", C.c_void_p), ("padd_r", C.c_void_p),
         ("padd_ld", C.c_int32), ("flags", C.c_int32), ("wmax", C.c_void_p),
-        ("gscale", C.c_void_p), ("gscale_ld", C.c_int32), ("pad3_", C.c_int32),
+        ("gscale", C.c_void_p), ("gscale_ld", C.c_int32), ("product_form", C.c_int32),
         ("fin_stats", C.c_void_p), ("in_stats", C.c_void_p), ("dw_partial", C.c_void_p), ("dw_partial_stride", C.c_int64),
         ("dw_in", C.c_void_p), ("dw_in_ld", C.c_int32), ("reserved2_", C.c_int32),
     ]

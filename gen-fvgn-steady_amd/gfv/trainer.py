@@ -15,7 +15,7 @@ from . import cmdlist
 from . import lib as L
 from .engine import GradStore
 from .functions import unused_param_names
-from .plan import get_plan
+from .plan import _live_key, _refresh_live, get_plan
 
 
 def _gather(src, index, out):
@@ -28,6 +28,7 @@ class TrainStep:
         self.model = model
         self.graphs = graphs
         self.plan = get_plan(graphs)
+        self._live = _live_key(graphs)
         self.engine = model.engine()
         p = model.params
         self._hyper_host = None
@@ -233,6 +234,7 @@ class TrainStep:
         small launch."""
         self.graphs = graphs
         self.plan = get_plan(graphs)
+        self._live = _live_key(graphs)
         self.x = graphs[0].x
         self.x_backup = self.x.clone()
         if self.gloss.shape[0] != self.plan.B:
@@ -327,6 +329,14 @@ class TrainStep:
         """One training iteration.  Returns the (device) scalar loss tensor of this rank's batch.
         `use_graph`: False = eager launches, True = hipGraph replay, "list" = command-list replay."""
         self._check_aliasing()
+        # caller-owned data the plan holds copies of (Dirichlet targets, node / face types, theta_PDE, sigma, uvp_dim, dt_graph):
+        # an in-place edit between two steps reaches the plan's tensors here - copied in place, so the pointers a captured step
+        # holds stay valid (the reference re-reads graph_node.y / graph_Index on every forward, importer.py:141-154,168).
+        # Batches of a DevicePool carry their plan with them and are refreshed the same way.
+        live = _live_key(self.graphs)
+        if live != self._live:
+            _refresh_live(self.plan, self.graphs)
+            self._live = live
         acc = self.model.node_norm.should_accumulate()
         dist_on = self.dist_on
         if not self.use_graph or (acc and dist_on):
@@ -367,6 +377,7 @@ class TrainStep:
                 # the captured launches hold raw pointers into the weight-image set / descriptor tables of the engine:
                 # a changed set (model.to(), re-flattened parameters, a new weight block) makes every capture stale
                 self._graphs.clear()
+                self._list_warm.clear()   # (command lists were dropped with it: they re-record only after new warm-up steps)
                 g = None
             if g is None:
                 # warm the allocator on a side stream, then capture (PyTorch CUDA-graph recipe)

@@ -1,8 +1,11 @@
 /* libgfv - C ABI of the MI355X-native (gfx950) Gen-FVGN hot path.
  *
  * Every entry point is `extern "C"`, takes plain device pointers + sizes + a hipStream_t (as void*), allocates
- * nothing, keeps no global state, is asynchronous on the given stream and returns 0 (GFV_OK) or a negative
- * error code.  All floating point data is fp32, all index data int32 (plans are narrowed from the reference's
+ * nothing, is asynchronous on the given stream and returns 0 (GFV_OK) or a negative error code.  State the library keeps:
+ * two THREAD-LOCAL launch-context values (the product form, gfv_set_f16split, and the model's hidden size,
+ * gfv_set_hidden_size - like the HIP runtime's current device; a chain launch may carry its own in its argument struct),
+ * the device status word (gfv_status_flags), the optional profiling records (gfv_profile_*) and the mesh plans a caller
+ * creates and destroys (gfv_plan_create / gfv_plan_destroy).  All floating point data is fp32, all index data int32 (plans are narrowed from the reference's
  * int64 once per mesh batch).
  *
  * What each entry replaces in the reference (paths relative to /root/reference/src) is cited per function; the
@@ -113,7 +116,8 @@ typedef struct {
   float* ln_partial;      /* GFV_IN_LNBWD / GFV_FIN_LNBWD: [n_tiles, 2, 128] per-tile (dgamma, dbeta) partial sums */
   gfv_layer_t layer[3];
   int32_t fin_op;
-  int32_t pad_;
+  int32_t hidden;         /* hidden_size of the model this launch belongs to (LayerNorm width; gfv_set_hidden_size); 0 = the calling
+                           * thread's setting.  (Inside the library the launcher always fills it in for the kernel.) */
   const float* fin_gamma;
   const float* fin_beta;
   const float* fin_aux;   /* GFV_FIN_LNBWD: the LayerNorm input rows [M,128] */
@@ -140,7 +144,7 @@ typedef struct {
    * gfv_dw_tile_t.gscale takes a slot: the slab scale of the gradient rows then needs no extra pass over them. */
   float* gscale;
   int32_t gscale_ld;
-  int32_t pad3_;          /* reserved: leave 0 (the launcher passes the product form to the kernel here) */
+  int32_t product_form;   /* 0 = the calling thread's setting (gfv_set_f16split); 1 fp32 MFMA, 2 split-fp16, 3 reduced precision */
   /* LayerNorm statistics of the rows, [M, 2] = (mean, 1 / sqrt(var + eps)): written by a GFV_FIN_LN launch when fin_stats is
    * given, read by a GFV_IN_LNBWD launch when in_stats is given (the column-owner backward needs them: its LayerNorm backward
    * is spread over eight waves and takes the row statistics as they were in the forward instead of recomputing them) */
@@ -190,7 +194,7 @@ typedef struct {
 } gfv_wimg_desc_t;
 size_t gfv_weight_image_bytes(int32_t N, int32_t K);
 /* wmax[0] = max |W| over all described blocks (device scalar, overwritten) */
-/* the process-wide switch between the product forms (initial value: environment GFV_F16SPLIT, default 1);
+/* the calling thread's product form (thread-local; initial value: environment GFV_F16SPLIT, default 1);
  * 0 = fp32 MFMA everywhere (chain launches ignore their images, weight gradients take the fp32 kernel);
  * 1 = split-fp16 products (fp32 accuracy);
  * 2 = reduced precision: one fp16 x fp16 product per term with fp32 accumulation - the high parts of the same operands
@@ -201,8 +205,9 @@ int gfv_set_f16split(int32_t on);
 /* hidden_size of the model the following launches belong to (the reference's --hidden_size, utils/get_param.py:69; default
  * 128; multiples of 16 in [16, 128]).  Every kernel works on 128-column latent rows; a narrower model runs zero-padded to
  * 128 columns (the host side pads its parameters: FVMmodel/padding.py) and differs in two places only - LayerNorm takes its
- * statistics over the h real columns, and the slice attention scales by (h / 8) ** -0.5.  Process-wide host state read by
- * the launchers: set it before the launches of a model (gfv.engine.Engine does, on every forward and backward). */
+ * statistics over the h real columns, and the slice attention scales by (h / 8) ** -0.5.  Thread-local host state read by
+ * the launchers: set it before the launches of a model (gfv.engine.Engine does, on every forward and backward); a chain
+ * launch may name its own (gfv_rowtile_args_t.hidden). */
 int gfv_hidden_size(void);
 int gfv_set_hidden_size(int32_t h);
 int gfv_weight_absmax(const gfv_wimg_desc_t* descs_dev, int32_t n_desc, float* wmax, void* stream);

@@ -39,4 +39,20 @@ for p,n in zip(rs[:-1],rs[1:]):
     g=int(n["Start_Timestamp"])-int(p["End_Timestamp"])
     if g>3000: print("gap %.1f us after %s before %s" % (g/1e3,p["Kernel_Name"][:50].replace("(anonymous namespace)::",""),n["Kernel_Name"][:50].replace("(anonymous namespace)::","")))
 PY
+# the same step, both queues in time order (offsets in us from the step's first kernel): what the side queue does and when
+python3 - "$f" <<'PY'
+import csv,sys
+rows=list(csv.DictReader(open(sys.argv[1])))
+rows.sort(key=lambda r:int(r["Start_Timestamp"]))
+idx=[i for i,r in enumerate(rows) if "adam_kernel" in r["Kernel_Name"]]
+a,b=idx[-22],idx[-21]
+seg=rows[a+1:b+1]
+t0=int(seg[0]["Start_Timestamp"])
+qs=sorted({r["Queue_Id"] for r in seg})
+print("queues",qs)
+for r in seg:
+    n=r["Kernel_Name"].replace("(anonymous namespace)::","").replace("void ","")[:46]
+    s=(int(r["Start_Timestamp"])-t0)/1e3; d=(int(r["End_Timestamp"])-int(r["Start_Timestamp"]))/1e3
+    print("%s %8.1f %7.1f  %s%s" % (r["Queue_Id"], s, d, "" if r["Queue_Id"]==qs[0] else "            ", n))
+PY
 rm -rf $O/prof

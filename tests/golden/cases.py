@@ -88,3 +88,9 @@ def poly_cylinder(golden_dir=None):
     raw["bc"] = bcd
     mesh = meshgen.finish_mesh(raw)
     return build_batch([mesh], [fx["field"]]), fx, mesh
+
+
+# Stated tolerances of the reduced-precision product form (gfv_set_f16split(2): BASELINE configs 3 / 5) against the fp32
+# oracle, relative: fields (of the field's maximum), each residual loss, the scalar log-loss, all gradients norm-wise
+# (tests/test_model_gpu.py::test_reduced_precision_form_against_the_fp32_oracle, tests/test_fullsize_gpu.py)
+LOWP_TOL = dict(field=2e-4, losses=2e-3, logloss=1e-5, grad_norm=2e-3)

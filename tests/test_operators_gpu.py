@@ -194,8 +194,9 @@ def test_step_modes_are_bit_identical():
     mesh = meshgen.finish_mesh(meshgen.raw_tri_channel_cylinder(nx=nx, ny=ny, seed=5), U=0.3)
     graphs = build_batch([mesh], [meshgen.random_fields(mesh, seed=9)])
     P = O.init_parameters(cases.WEIGHT_SEED)
-    finals = {}
-    for mode in (False, True, "list"):
+    finals, losses_seen = {}, {}
+    for mode in (False, True, "list", "no-edit"):
+        edit, mode = mode != "no-edit", (False if mode == "no-edit" else mode)
         model = NNmodel(default_params(dataset_size=3))
         sd = model.state_dict()
         for k, v in P.items():
@@ -206,8 +207,17 @@ def test_step_modes_are_bit_identical():
         for i in range(8):
             if i == 5:
                 ts.set_lr(2e-5)
+            if i == 6 and edit:
+                # a Dirichlet target and a PDE coefficient edited IN PLACE between two steps: the plan's copies follow
+                # (TrainStep.step compares data pointers / version counters; the reference re-reads them every forward)
+                ts.graphs[0].y.mul_(1.25)
+                ts.graphs[4].theta_PDE[:, 4].mul_(0.5)
             ts.step()
         torch.cuda.synchronize()
+        if not edit:
+            finals["no-edit"] = ts.loss.reshape(-1).clone()
+            continue
+        losses_seen[mode] = ts.loss.reshape(-1).clone()
         if mode == "list":
             assert any(isinstance(k, tuple) and k[0] == "list" for k in ts._graphs), "the command list was never recorded"
             assert len(next(v for k, v in ts._graphs.items() if k[0] == "list")[0]) > 100
@@ -215,6 +225,7 @@ def test_step_modes_are_bit_identical():
                                  + [ts.adam_state[0:1], ts.loss.reshape(-1), ts.losses.reshape(-1), ts.uvp_node.reshape(-1)]).clone()
     assert torch.equal(finals[False], finals[True]), "hipGraph replay differs from eager"
     assert torch.equal(finals[False], finals["list"]), "command-list replay differs from eager"
+    assert float(losses_seen[False]) != float(finals["no-edit"]), "the in-place edit never reached the step"
 
 
 def test_reduced_precision_form_tracks_the_fp32_forms():
