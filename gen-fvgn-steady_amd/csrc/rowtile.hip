@@ -625,6 +625,14 @@ static int rowtile_chain_impl(const gfv_rowtile_args_t* args, void* stream) {
     int kind = (fast_t && tchain_mode() != 0) ? GFV_K_TCHAIN0 + lnm : ((rag_t && tchain_mode() != 0) ? GFV_K_TCHAIN_RAG : GFV_K_ROWTILE);
     for (int i = 0; i < args->nseg; ++i)
       if (args->seg[i].csr_rowptr || args->seg[i].save) kind = GFV_K_TCHAIN_CSR;
+    if (args->dw_partial) {
+      // dX chain with fused weight gradients (column-owner backward family): + the two (three) weight-gradient GEMMs, the
+      // forward's row statistics read, the first Linear's input rows read, the per-workgroup blocks written
+      kind = GFV_K_COLCHAIN_BWD;
+      const int nfused = args->dw_in ? 3 : 2;
+      fl += nfused * 2.0 * args->M * 128.0 * 128.0;
+      by += 8.0 * args->M + (args->dw_in ? 4.0 * args->M * 128.0 : 0.0) + 4.0 * (double)gfv_rowtile_dw_partials() * (double)args->dw_partial_stride;
+    }
     tok = gfv_prof_begin(kind, fl, by, (hipStream_t)stream);
   }
   g_last_path = (tchain_mode() != 0 && (fast_t || rag_t)) ? ((fast_t ? 1 : 2) + (f16 ? 4 : 0)) : 0;

@@ -372,15 +372,26 @@ extern "C" int gfv_seg_gather_sum(const float* src, const int32_t* rowptr, const
 extern "C" int gfv_seg_gather_sum_nnz(const float* src, const int32_t* rowptr, const int32_t* col, const float* scale,
                                       const float* src_scale, float* out, int32_t n_rows, int32_t F, int32_t accumulate,
                                       int64_t nnz_hint, void* stream) {
+  return gfv_seg_gather_sum_ex(src, rowptr, col, scale, src_scale, out, n_rows, F, accumulate, nnz_hint, -1, stream);
+}
+
+// n_src_hint: rows of `src` (distinct source rows a gather can touch; -1 = unknown: priced as if every gathered row were
+// its own).  Profiler bookkeeping only.
+extern "C" int gfv_seg_gather_sum_ex(const float* src, const int32_t* rowptr, const int32_t* col, const float* scale,
+                                     const float* src_scale, float* out, int32_t n_rows, int32_t F, int32_t accumulate,
+                                     int64_t nnz_hint, int64_t n_src_hint, void* stream) {
   if (n_rows < 0 || F < 1) return GFV_ERR_ARG;
   if (n_rows == 0) return GFV_OK;
   hipStream_t st = (hipStream_t)stream;
   void* tok = nullptr;
   if (gfv_prof_enabled() && nnz_hint >= 0) {
-    // 4*M*F (gathered rows) + w*M (indices) + 4*R*F (output rows), M = nnz, w = 4
-    const double by = 4.0 * (double)nnz_hint * F + 4.0 * (double)nnz_hint + 4.0 * (double)n_rows * F * (accumulate ? 2 : 1) +
-                      4.0 * (double)n_rows;
-    tok = gfv_prof_begin(GFV_K_SEG, (double)nnz_hint * F, by, st);
+    // every DISTINCT input element read once, every output element written once: 4 R_src F (distinct source
+    // rows, at most the gathered ones) + w nnz (indices, w = 4) + 4 R F (output rows; read too when accumulating) + 4 R (row
+    // pointers).  The gathered-row figure 4 nnz F - what the L2 / Infinity-Cache side serves - travels in the record's flops
+    // field (bench.py reports it as l2_side_gbs; the kernel has no flops worth pricing).
+    const double rsrc = (n_src_hint >= 0 && n_src_hint < nnz_hint) ? (double)n_src_hint : (double)nnz_hint;
+    const double by = 4.0 * rsrc * F + 4.0 * (double)nnz_hint + 4.0 * (double)n_rows * F * (accumulate ? 2 : 1) + 4.0 * (double)n_rows;
+    tok = gfv_prof_begin(GFV_K_SEG, 4.0 * (double)nnz_hint * F, by, st);
   }
 #define LAUNCH_VEC(LPR)                                                                                       \
   hipLaunchKernelGGL((seg_gather_sum_vec<LPR>), dim3(gfv_xcd_grid(grid_for(n_rows, 256 / LPR))), dim3(256), 0, st, src, \

@@ -23,8 +23,8 @@ def seg_gather_sum(src, rowptr, col, n_rows, scale=None, src_scale=None, out=Non
     if out is None:
         assert not accumulate
         out = torch.empty((n_rows, F), dtype=torch.float32, device=src.device)
-    rc = lib.gfv_seg_gather_sum_nnz(_p(src), _p(L.i32c(rowptr)), _p(L.i32c(col)), _p(scale), _p(src_scale), _p(out),
-                                    n_rows, F, 1 if accumulate else 0, col.shape[0], L.stream_ptr())
+    rc = lib.gfv_seg_gather_sum_ex(_p(src), _p(L.i32c(rowptr)), _p(L.i32c(col)), _p(scale), _p(src_scale), _p(out),
+                                   n_rows, F, 1 if accumulate else 0, col.shape[0], src.shape[0], L.stream_ptr())
     L.check(rc, "gfv_seg_gather_sum")
     return out
 

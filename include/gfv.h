@@ -43,6 +43,11 @@ int gfv_seg_gather_sum_nnz(const float* src, const int32_t* rowptr, const int32_
                            const float* src_scale, float* out, int32_t n_rows, int32_t F, int32_t accumulate,
                            int64_t nnz_hint, void* stream);
 
+/* same; n_src_hint = rows of src (the distinct source rows: what SURVEY.md 8(d) prices a gather by); profiler only */
+int gfv_seg_gather_sum_ex(const float* src, const int32_t* rowptr, const int32_t* col, const float* scale,
+                          const float* src_scale, float* out, int32_t n_rows, int32_t F, int32_t accumulate,
+                          int64_t nnz_hint, int64_t n_src_hint, void* stream);
+
 /* out[e, 0:F] = a[s[e], :], out[e, F:2F] = a[r[e], :]  (+ base[e,:] if base != NULL).  Adjoint of the
  * chunked edge->node scatter at blocks.py:34-42. */
 int gfv_gather_pair(const float* a, const int32_t* s, const int32_t* r, const float* base, float* out,

@@ -1,6 +1,7 @@
 #!/bin/bash
 # Collect the round's judged measurements on the GPU box (run through gpurun from the repo root):
 #   gpurun -- 'bash profiles/collect.sh r02'
+# (r03: + kernel_stats_in_step.json - the in-step kernel averages bench.py prices as frac_in_step -, hbm_pmc_b8.txt)
 # writes under gpurun_out/<tag>/ : bench.json (the default bench.py line, with cpu_baseline), bench_b8.json (8 meshes per
 # GPU: BASELINE config 4's per-GPU load), bench_cavity.json (config 2: 71 x 71 lid-driven cavity), bench_poly.json (config 5's shape: the reference's polygon example mesh,
 # unsteady solve loop with a time advance every 20 iterations), kernel_stats.csv
@@ -21,6 +22,7 @@ timeout 900 python3 $R/bench.py --workload poly --cpu-budget 8 > $O/bench_poly.j
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 $R/bench.py --cpu-budget 0 > $O/prof.log 2>&1
 find $O/prof -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats.csv \;
 rm -rf $O/prof
+python3 $R/profiles/instep_aggregate.py $O/kernel_stats.csv $O/kernel_stats_in_step.json > $O/kernel_stats_in_step.txt
 # PMC passes: eager launches only, split-fp16 form only; the JSON line says how many steps ran (steps_executed)
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 900 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_$c -- python3 $R/bench.py --steps 5 --warmup 1 --graph off --min-time 0 --cpu-budget 0 --profile-steps 1 --skip-fp32-form > $O/pmc_$c.log 2>&1
@@ -28,6 +30,14 @@ done
 NSTEPS=$(python3 -c "import json,sys; print([json.loads(l) for l in open('$O/pmc_FETCH_SIZE.log') if l.startswith('{')][-1]['steps_executed'])")
 python3 $R/profiles/pmc_aggregate.py $O $NSTEPS > $O/hbm_pmc.txt
 rm -rf $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE
+# the same two passes with 8 meshes per GPU (BASELINE config 4's per-GPU load; the working set no longer fits the Infinity Cache)
+mkdir -p $O/b8
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout 900 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/b8/pmc_$c -- python3 $R/bench.py --meshes-per-gpu 8 --steps 3 --warmup 1 --graph off --min-time 0 --cpu-budget 0 --profile-steps 1 --skip-fp32-form > $O/b8/pmc_$c.log 2>&1
+done
+NSTEPS8=$(python3 -c "import json,sys; print([json.loads(l) for l in open('$O/b8/pmc_FETCH_SIZE.log') if l.startswith('{')][-1]['steps_executed'])")
+python3 $R/profiles/pmc_aggregate.py $O/b8 $NSTEPS8 > $O/hbm_pmc_b8.txt
+rm -rf $O/b8/pmc_FETCH_SIZE $O/b8/pmc_WRITE_SIZE
 tail -3 $O/pytest.log
 head -c 400 $O/bench.json; echo
 tail -4 $O/hbm_pmc.txt

@@ -1,0 +1,33 @@
+"""rocprofv3 --kernel-trace --stats of the bench command -> average duration (us) of every kernel class INSIDE the two-stream
+training step, keyed by the kernel names bench.py reports (profiles/pmc_aggregate.py's naming): kernel_stats_in_step.json.
+usage: instep_aggregate.py <kernel_stats.csv> <out.json>"""
+import csv
+import json
+import re
+import sys
+
+
+def key_of(name):
+    name = name.replace("(anonymous namespace)::", "").replace("void ", "")
+    m = re.match(r"tchain_kernel<([^>]*)>", name)
+    if m:
+        return "tchain_kernel<" + ", ".join(a.strip() for a in m.group(1).split(",")[:6]) + ", *>"
+    m = re.match(r"([A-Za-z_0-9]+)", name)
+    base = m.group(1) if m else name
+    if base.startswith("seg_gather_sum"):
+        return "seg_gather_sum_vec"
+    if base.startswith("colchain_fwd"):
+        return "colchain_fwd_kernel"
+    return base
+
+
+acc = {}
+for r in csv.DictReader(open(sys.argv[1])):
+    k = key_of(r["Name"])
+    a = acc.setdefault(k, [0.0, 0])
+    a[0] += float(r["TotalDurationNs"])
+    a[1] += int(r["Calls"])
+out = {k: v[0] / v[1] / 1e3 for k, v in acc.items() if v[1]}
+json.dump(out, open(sys.argv[2], "w"), indent=0, sort_keys=True)
+for k, v in sorted(out.items(), key=lambda kv: -acc[kv[0]][0])[:14]:
+    print(f"{k:60s} {acc[k][1]:7d} launches  {v:8.1f} us")

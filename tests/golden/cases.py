@@ -58,6 +58,28 @@ def fingerprint(a):
     return np.array([a.sum(), np.sqrt((a * a).sum()), (a * projection(a.size)).sum()])
 
 
+# The reference's own example meshes (mesh_example/..., COMSOL .mphtxt): raw reader arrays + the reference's outputs on
+# them, committed as data by make_real_mesh_golden.py.  name: (nodes, faces, cells, what it is)
+REAL_MESHES = {
+    "real_cylinder": (7798, 22872, 15074, "cylinder_flow_full_tri (all triangles, parabolic inlet)"),
+    "real_cavity101": (10404, 20604, 10201, "lid_driven_cavity_101x101-Re=100 (all quads, pressure point)"),
+    "real_poisson_quad_tri": (2497, 6192, 3696, "poisson/cavity_poisson_quad_tri (Poisson: continuity/convection/grad_p off)"),
+    "real_naca0012": (16861, 47545, 30684, "airfoil_L=1/farfield_NACA0012_with_quad_bc (tri + quad boundary layer, unsteady=1)"),
+}
+
+
+def real_mesh(name, golden_dir=None):
+    """One of REAL_MESHES -> (graphs, fixture, mesh dict)."""
+    import json
+    golden_dir = golden_dir or os.path.dirname(os.path.abspath(__file__))
+    fx = np.load(os.path.join(golden_dir, name + ".npz"))
+    raw = {k[4:]: (fx[k].astype(np.int64) if fx[k].dtype.kind == "i" else fx[k]) for k in fx.files
+           if k.startswith("raw.") and k != "raw.bc"}
+    raw["bc"] = json.loads(str(fx["raw.bc"]))
+    mesh = meshgen.finish_mesh(raw)
+    return build_batch([mesh], [fx["field"]]), fx, mesh
+
+
 def real_cylinder(golden_dir=None):
     """The reference's own example mesh mesh_example/cylinder_flow_full_tri (raw reader arrays committed as data in
     real_cylinder.npz by make_real_mesh_golden.py) -> (graphs, fixture)."""

@@ -21,21 +21,31 @@ from oracle import fvgn_oracle as O  # noqa: E402
 from gfv.graph import build_batch  # noqa: E402
 import make_golden as MG  # noqa: E402
 
-MESH_DIR = "/root/reference/mesh_example/cylinder_flow_full_tri"
+MESH_ROOT = "/root/reference/mesh_example"
+# (directory under mesh_example, mesh file, fixture name, random seed of the PDE-parameter draw, field seed)
+MESHES = {
+    "real_cylinder": ("cylinder_flow_full_tri", "mesh_full_tri.mphtxt", 7, 99),
+    "real_cavity101": ("lid_driven_cavity/lid_driven_cavity_101x101-Re=100", "mesh.mphtxt", 8, 100),
+    "real_poisson_quad_tri": ("poisson/cavity_poisson_quad_tri", "mesh_tri.mphtxt", 9, 101),
+    "real_naca0012": ("airfoil_L=1/farfield_NACA0012_with_quad_bc", "mesh_2.mphtxt", 10, 102),
+}
 
 
-def main():
+def generate(fixture):
     import importlib
     import json
+    sub, mesh_file, pde_seed, field_seed = MESHES[fixture]
+    MESH_DIR = os.path.join(MESH_ROOT, sub)
+    case_name = os.path.basename(sub)
     R = ref_import.reference_modules()
     M = ref_import.reference_mesh_modules()
     pc = importlib.import_module("Extract_mesh.parse_comsol")
     pc.write_vtp_file = lambda *a, **k: None
     pc.Cosmol_manager.save_to_vtu = lambda *a, **k: None
-    path = {"file_dir": "/tmp/real_mesh_out", "case_name": "cylinder_flow_full_tri"}
+    path = {"file_dir": "/tmp/real_mesh_out/" + fixture, "case_name": case_name}
     os.makedirs(path["file_dir"], exist_ok=True)
-    mgr = pc.Cosmol_manager(mesh_file=f"{MESH_DIR}/mesh_full_tri.mphtxt", data_file=None, file_dir=MESH_DIR,
-                            case_name="cylinder_flow_full_tri", path=path)
+    mgr = pc.Cosmol_manager(mesh_file=f"{MESH_DIR}/{mesh_file}", data_file=None, file_dir=MESH_DIR,
+                            case_name=case_name, path=path)
     mgr.file_dir = path["file_dir"]
     captured = {}
     orig_ems = pc.extract_mesh_state
@@ -49,13 +59,13 @@ def main():
     mesh = dict(mgr.extract_mesh())
     bc = json.load(open(f"{MESH_DIR}/BC.json"))
     mesh.update(bc)
-    mesh["case_name"] = "cylinder_flow_full_tri"
+    mesh["case_name"] = case_name
     mesh["theta_PDE_bak"] = mesh["theta_PDE"]
     th = mesh["theta_PDE_bak"]
     mesh["theta_PDE_list"] = R.get_param.generate_combinations(
         U_range=th["inlet"], rho_range=th["rho"], mu_range=th["mu"], source_range=th["source"], aoa_range=th["aoa"],
         dt=th["dt"], L=th["L"], Re_max=th["Re_max"], Re_min=th["Re_min"])
-    random.seed(7)
+    random.seed(pde_seed)
     params = R.get_param.params()
     mesh, init_uvp = M.Load_mesh.CFDdatasetBase.transform_mesh(mesh, params)
     n = lambda k: np.asarray(mesh[k])
@@ -73,7 +83,7 @@ def main():
         "uvp_dim": n("uvp_dim").astype(np.float32), "sigma": n("sigma").astype(np.float32),
         "target|uvp": n("target|uvp").astype(np.float32), "init_uvp": init_uvp.numpy().astype(np.float32),
     }
-    rng = np.random.default_rng(99)
+    rng = np.random.default_rng(field_seed)
     field = (rng.uniform(-1, 1, size=(md["node|pos"].shape[0], 3)) * md["uvp_dim"].astype(np.float64)).astype(np.float32)
     graphs = build_batch([md], [field])
 
@@ -95,7 +105,7 @@ def main():
     # oracle on the same inputs
     og = tuple(g.clone() for g in graphs)
     oout = O.model_forward({k: v.clone() for k, v in P0.items()}, O.new_normalizer_buffers(), og)
-    print("real mesh: N", md["node|pos"].shape[0], "E", md["face|face_node"].shape[1], "C", md["cell|centroid"].shape[0],
+    print(fixture, "N", md["node|pos"].shape[0], "E", md["face|face_node"].shape[1], "C", md["cell|centroid"].shape[0],
           "Ex", md["face_node_x"].shape[1])
     print("loss ref", float(loss))
     for nm, a, b in (("loss_cont", oout[0], lc), ("loss_mom_x", oout[1], lmx), ("loss_mom_y", oout[2], lmy),
@@ -132,9 +142,10 @@ def main():
                  "uvp_node": uvp_node.detach().numpy(), "uvp_cell": uvp_cell.detach().numpy(),
                  "grad_fp": np.stack([cases.fingerprint(grads[k].numpy()) if grads[k] is not None else np.full(3, np.nan)
                                       for k in names])})
-    np.savez_compressed(os.path.join(HERE, "real_cylinder.npz"), **save)
-    print("saved", os.path.getsize(os.path.join(HERE, "real_cylinder.npz")) / 1e6, "MB")
+    np.savez_compressed(os.path.join(HERE, fixture + ".npz"), **save)
+    print("saved", os.path.getsize(os.path.join(HERE, fixture + ".npz")) / 1e6, "MB")
 
 
 if __name__ == "__main__":
-    main()
+    for name in (sys.argv[1:] or list(MESHES)):
+        generate(name)
