@@ -55,9 +55,17 @@ __global__ __launch_bounds__(256) void phi_bwd_kernel(const float* __restrict__ 
 
 // ---- M x M LU with partial pivoting (LAPACK getf2 order), solve and transpose-solve; M = Taylor terms of the WLSQ
 // reconstruction order: 2 (1st), 5 (2nd, the default), 9 (3rd), 14 (4th) (FVorder.py:23-72) ------------------------------
+//
+// The factorisation and the two triangular solves run in DOUBLE.  The moment matrices of stretched cells are badly
+// conditioned (boundary-layer nodes of mesh_example/airfoil_L=1: cond(A_n) = 4e5), where ANY fp32 elimination returns
+// rounding noise of size cond * 2^-24 - the reference's LAPACK call, an FMA build of the same loop and this kernel's former
+// fp32 loop land 0.009, 0.17 and 1.7 away from the exact gradient 1833 at such a node (profiles/r03_wlsq_conditioning.txt).
+// Solving the system exactly (right-hand side accumulated in double from the fp32 data, A normalised in double) puts the
+// result in the middle of that noise ball: its distance to the reference's value is the reference's own rounding error.
+typedef double lu_t;
 template <int M>
 struct LU {
-  float a[M][M];
+  lu_t a[M][M];
   int piv[M];
 };
 
@@ -66,10 +74,10 @@ __device__ __forceinline__ void lu_factor(LU<M>& m) {
 #pragma unroll
   for (int k = 0; k < M; ++k) {
     int p = k;
-    float mx = fabsf(m.a[k][k]);
+    lu_t mx = fabs(m.a[k][k]);
 #pragma unroll
     for (int r = k + 1; r < M; ++r) {
-      const float v = fabsf(m.a[r][k]);
+      const lu_t v = fabs(m.a[r][k]);
       if (v > mx) { mx = v; p = r; }
     }
     m.piv[k] = p;
@@ -79,12 +87,12 @@ __device__ __forceinline__ void lu_factor(LU<M>& m) {
       const bool sw = (p == r);
 #pragma unroll
       for (int c = 0; c < M; ++c) {
-        const float tk = m.a[k][c], tr = m.a[r][c];
+        const lu_t tk = m.a[k][c], tr = m.a[r][c];
         m.a[k][c] = sw ? tr : tk;
         m.a[r][c] = sw ? tk : tr;
       }
     }
-    const float inv = 1.0f / m.a[k][k];
+    const lu_t inv = 1.0 / m.a[k][k];
 #pragma unroll
     for (int r = k + 1; r < M; ++r) {
       m.a[r][k] *= inv;
@@ -95,14 +103,14 @@ __device__ __forceinline__ void lu_factor(LU<M>& m) {
 }
 
 template <int M>
-__device__ __forceinline__ void lu_solve(const LU<M>& m, float (&b)[M]) {
+__device__ __forceinline__ void lu_solve(const LU<M>& m, lu_t (&b)[M]) {
 #pragma unroll
   for (int k = 0; k < M; ++k) {
     const int p = m.piv[k];
 #pragma unroll
     for (int r = k + 1; r < M; ++r) {
       const bool sw = (p == r);
-      const float tk = b[k], tr = b[r];
+      const lu_t tk = b[k], tr = b[r];
       b[k] = sw ? tr : tk;
       b[r] = sw ? tk : tr;
     }
@@ -121,7 +129,7 @@ __device__ __forceinline__ void lu_solve(const LU<M>& m, float (&b)[M]) {
 
 // solve A^T x = b with A = P^T L U
 template <int M>
-__device__ __forceinline__ void lu_solve_t(const LU<M>& m, float (&b)[M]) {
+__device__ __forceinline__ void lu_solve_t(const LU<M>& m, lu_t (&b)[M]) {
 #pragma unroll
   for (int k = 0; k < M; ++k) {  // U^T w = b
 #pragma unroll
@@ -138,20 +146,23 @@ __device__ __forceinline__ void lu_solve_t(const LU<M>& m, float (&b)[M]) {
 #pragma unroll
     for (int r = k + 1; r < M; ++r) {
       const bool sw = (p == r);
-      const float tk = b[k], tr = b[r];
+      const lu_t tk = b[k], tr = b[r];
       b[k] = sw ? tr : tk;
       b[r] = sw ? tk : tr;
     }
   }
 }
 
+// A_n = A / (row norm + 1e-8) (FVgrad.py:335-336), formed in double from the moment matrix as the reference stores it
 template <int M>
-__device__ __forceinline__ void load_An(const float* An, int i, LU<M>& m) {
-  const float* p = An + (size_t)i * (M * M);
+__device__ __forceinline__ void load_An(const float* A, const float* rn, int i, LU<M>& m) {
+  const float* p = A + (size_t)i * (M * M);
 #pragma unroll
-  for (int r = 0; r < M; ++r)
+  for (int r = 0; r < M; ++r) {
+    const lu_t inv = 1.0 / (lu_t)rn[(size_t)i * M + r];
 #pragma unroll
-    for (int c = 0; c < M; ++c) m.a[r][c] = p[M * r + c];
+    for (int c = 0; c < M; ++c) m.a[r][c] = (lu_t)p[M * r + c] * inv;
+  }
 }
 
 // WLSQ forward (FVgrad.py:295-359): lane (node i, channel c), 8 lanes per node
@@ -163,43 +174,43 @@ __global__ __launch_bounds__(256) void wlsq_fwd_kernel(const float* __restrict__
   const int t = blockIdx.x * 256 + threadIdx.x;
   const int i = t >> 3, c = t & 7;
   if (i >= N) return;
-  float rhs[M];
+  lu_t rhs[M];
 #pragma unroll
-  for (int j = 0; j < M; ++j) rhs[j] = 0.f;
+  for (int j = 0; j < M; ++j) rhs[j] = 0.0;
   if (c < 7) {
-    const float pi = phi[(size_t)i * 8 + c];
+    const lu_t pi = (lu_t)phi[(size_t)i * 8 + c];
     const int beg = rowptr[i], end = rowptr[i + 1];
     // 4 stencil entries per trip: index, neighbour value and moment vector of all four are requested before the first
     // dependent multiply (the loop was one memory round trip per entry); the accumulation order stays entry by entry
     int k = beg;
     for (; k + 4 <= end; k += 4) {
-      float dv[4];
+      lu_t dv[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) dv[u] = phi[(size_t)outn[k + u] * 8 + c] - pi;
+      for (int u = 0; u < 4; ++u) dv[u] = (lu_t)phi[(size_t)outn[k + u] * 8 + c] - pi;
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const float* b = Bp + (size_t)(k + u) * M;
 #pragma unroll
-        for (int j = 0; j < M; ++j) rhs[j] += b[j] * dv[u];
+        for (int j = 0; j < M; ++j) rhs[j] += (lu_t)b[j] * dv[u];
       }
     }
     for (; k < end; ++k) {
-      const float d = phi[(size_t)outn[k] * 8 + c] - pi;
+      const lu_t d = (lu_t)phi[(size_t)outn[k] * 8 + c] - pi;
       const float* b = Bp + (size_t)k * M;
 #pragma unroll
-      for (int j = 0; j < M; ++j) rhs[j] += b[j] * d;
+      for (int j = 0; j < M; ++j) rhs[j] += (lu_t)b[j] * d;
     }
     LU<M> m;
-    load_An(An, i, m);
+    load_An(An, rn, i, m);
 #pragma unroll
-    for (int j = 0; j < M; ++j) rhs[j] = rhs[j] / rn[(size_t)i * M + j];
+    for (int j = 0; j < M; ++j) rhs[j] = rhs[j] / (lu_t)rn[(size_t)i * M + j];
     lu_factor(m);
     lu_solve(m, rhs);
-    grad[(size_t)i * 16 + 2 * c] = rhs[0];
-    grad[(size_t)i * 16 + 2 * c + 1] = rhs[1];
+    grad[(size_t)i * 16 + 2 * c] = (float)rhs[0];
+    grad[(size_t)i * 16 + 2 * c + 1] = (float)rhs[1];
     if (full) {
 #pragma unroll
-      for (int j = 0; j < M; ++j) full[((size_t)i * 8 + c) * M + j] = rhs[j];
+      for (int j = 0; j < M; ++j) full[((size_t)i * 8 + c) * M + j] = (float)rhs[j];
     }
   } else {
     grad[(size_t)i * 16 + 14] = 0.f;
@@ -215,26 +226,26 @@ __global__ __launch_bounds__(256) void wlsq_bwd_solve_kernel(const float* __rest
   const int t = blockIdx.x * 256 + threadIdx.x;
   const int i = t >> 3, c = t & 7;
   if (i >= N) return;
-  float b[M];
+  lu_t b[M];
 #pragma unroll
-  for (int j = 0; j < M; ++j) b[j] = 0.f;
+  for (int j = 0; j < M; ++j) b[j] = 0.0;
   if (c < nch) {  // fused path: channels 5,6 (uv_old) carry no gradient
     if (gfull) {
 #pragma unroll
-      for (int j = 0; j < M; ++j) b[j] = gfull[((size_t)i * 8 + c) * M + j];
+      for (int j = 0; j < M; ++j) b[j] = (lu_t)gfull[((size_t)i * 8 + c) * M + j];
     } else {
-      b[0] = ggrad[(size_t)i * 16 + 2 * c];
-      b[1] = ggrad[(size_t)i * 16 + 2 * c + 1];
+      b[0] = (lu_t)ggrad[(size_t)i * 16 + 2 * c];
+      b[1] = (lu_t)ggrad[(size_t)i * 16 + 2 * c + 1];
     }
     LU<M> m;
-    load_An(An, i, m);
+    load_An(An, rn, i, m);
     lu_factor(m);
     lu_solve_t(m, b);
 #pragma unroll
-    for (int j = 0; j < M; ++j) b[j] = b[j] / rn[(size_t)i * M + j];
+    for (int j = 0; j < M; ++j) b[j] = b[j] / (lu_t)rn[(size_t)i * M + j];
   }
 #pragma unroll
-  for (int j = 0; j < M; ++j) grhs[((size_t)i * 8 + c) * M + j] = b[j];
+  for (int j = 0; j < M; ++j) grhs[((size_t)i * 8 + c) * M + j] = (float)b[j];
 }
 
 // dot product of two M-vectors, paired like the 5-term form this kernel started with

@@ -545,6 +545,7 @@ extern "C" int gfv_struct_size(int32_t which) {
     case 3: return (int)sizeof(gfv_wimg_desc_t);
     case 4: return (int)sizeof(gfv_dw_tile_t);
     case 5: return (int)sizeof(gfv_reduce_piece_t);
+    case 6: return (int)sizeof(gfv_plan_desc_t);
     default: return -1;
   }
 }

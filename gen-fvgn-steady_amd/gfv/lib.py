@@ -159,7 +159,25 @@ _SIGNATURES = {
     "gfv_adam_step_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gfv_train_loss_dev": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gfv_train_loss": (C.c_int, [C.c_void_p, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gfv_plan_create": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_void_p]),
+    "gfv_plan_destroy": (C.c_int, [C.c_void_p]),
+    "gfv_plan_table": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
+    "gfv_plan_sizes": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
 }
+
+
+class PlanDesc(C.Structure):
+    """gfv_plan_desc_t (include/gfv.h)."""
+    _fields_ = [("n_nodes", C.c_int64), ("n_faces", C.c_int64), ("n_cells", C.c_int64), ("n_incidences", C.c_int64),
+                ("n_stencil_pairs", C.c_int64), ("n_support_pairs", C.c_int64),
+                ("edge_index", C.c_void_p), ("cells_node", C.c_void_p), ("cells_face", C.c_void_p),
+                ("cells_index", C.c_void_p), ("face_node_x", C.c_void_p), ("support_edge", C.c_void_p)]
+
+
+# table ids of gfv_plan_table, in the order of the enum in include/gfv.h
+PLAN_TABLES = ("ES", "ER", "N_ROWPTR", "N_COL_NODE", "N_COL_EDGE2", "INV_DEG", "S_ROWPTR", "S_COL", "R_ROWPTR", "R_COL",
+               "X_ROWPTR", "X_OUT", "X_ORDER", "XO_ROWPTR", "XO_IN", "XO_ORDER", "CROW", "K_ORDER", "KFACE", "KNODE", "KCELL",
+               "FROW", "FK", "NROW", "NCELL")
 
 
 def declared_symbols():

@@ -36,12 +36,63 @@ class MeshPlan:
     pass
 
 
+# The index tables come from the C ABI's plan handle (gfv_plan_create, csrc/plan.hip) when the batch is on the GPU; the
+# torch-op construction below is the same algorithm (stable sorts by destination row) and stays as the CPU-side builder
+# (host tests, gloo ranks) - tests/test_plan_gpu.py holds the two bit-identical.  GFV_NATIVE_PLAN=0 forces the torch form.
+NATIVE = __import__("os").environ.get("GFV_NATIVE_PLAN", "1") != "0"
+
+
+class _DevArray:
+    def __init__(self, ptr, count, typestr):
+        self.__cuda_array_interface__ = {"shape": (int(count),), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+
+
+def native_tables(N, C, edge_index, cells_node=None, cells_face=None, cells_index=None, face_node_x=None, support_edge=None):
+    """{table name: tensor} from gfv_plan_create on the current stream (tables copied out, handle destroyed)."""
+    import ctypes as Ct
+    from . import lib as L
+    lib = L.load(raw=True)
+    dev = edge_index.device
+    i64 = lambda t: None if t is None else t.to(torch.int64).contiguous()
+    ei, cn, cf, ci, fx, sup = map(i64, (edge_index, cells_node, cells_face, cells_index, face_node_x, support_edge))
+    ptr = lambda t: None if t is None or t.numel() == 0 else t.data_ptr()
+    d = L.PlanDesc(n_nodes=N, n_faces=ei.shape[1], n_cells=C, n_incidences=0 if ci is None else ci.numel(),
+                   n_stencil_pairs=0 if fx is None else fx.shape[1], n_support_pairs=0 if sup is None else sup.shape[1],
+                   edge_index=ptr(ei), cells_node=ptr(cn), cells_face=ptr(cf), cells_index=ptr(ci), face_node_x=ptr(fx),
+                   support_edge=ptr(sup))
+    handle = Ct.c_void_p()
+    with torch.cuda.device(dev):
+        rc = lib.gfv_plan_create(Ct.byref(d), Ct.byref(handle), torch.cuda.current_stream().cuda_stream)
+        if rc != 0:
+            raise RuntimeError(f"gfv_plan_create failed ({rc}): an index tensor holds an entry outside its range" if rc == -1
+                               else f"gfv_plan_create failed ({rc})")
+        try:
+            out = {}
+            for which, name in enumerate(L.PLAN_TABLES):
+                p_, n_ = Ct.c_void_p(), Ct.c_int64()
+                assert lib.gfv_plan_table(handle, which, Ct.byref(p_), Ct.byref(n_)) == 0
+                if n_.value == 0 or not p_.value:
+                    out[name] = torch.empty(0, dtype=torch.float32 if name == "INV_DEG" else torch.int32, device=dev)
+                    continue
+                view = torch.as_tensor(_DevArray(p_.value, n_.value, "<f4" if name == "INV_DEG" else "<i4"), device=dev)
+                out[name] = view.clone()
+            torch.cuda.current_stream().synchronize()
+        finally:
+            lib.gfv_plan_destroy(handle)
+    return out
+
+
 def _gnn_part(p, edge_index, N):
     """Two-way node adjacency in CSR order of the receiving node (blocks.py:24-31,82-90)."""
     dev = edge_index.device
     E = edge_index.shape[1]
     i32 = lambda t: t.to(torch.int32).contiguous()
     p.N, p.E, p.device = N, E, dev
+    if NATIVE and dev.type == "cuda":
+        t = getattr(p, "_native", None) or native_tables(N, 0, edge_index)
+        p.es, p.er, p.n_rowptr, p.n_col_node, p.n_col_edge2 = t["ES"], t["ER"], t["N_ROWPTR"], t["N_COL_NODE"], t["N_COL_EDGE2"]
+        p.inv_deg, p.s_rowptr, p.s_col, p.r_rowptr, p.r_col = t["INV_DEG"], t["S_ROWPTR"], t["S_COL"], t["R_ROWPTR"], t["R_COL"]
+        return p
     s, r = edge_index[0], edge_index[1]
     p.es, p.er = i32(s), i32(r)
     indeg = torch.cat((s, r))
@@ -135,11 +186,16 @@ def wlsq_part(p, face_node_x, support_edge, A, B1, Bx, N):
     if M >= 9:                    # 3rd-order terms are odd too (FVgrad.py:309-310)
         Brev[:, 5:9] *= -1
     Bfull = torch.cat((B1, Brev, Bx.reshape(-1, M)), 0).to(torch.float32)
-    p.x_rowptr, o_in = _csr(in_idx, N)
-    p.x_out = i32(out_idx[o_in])
+    t = getattr(p, "_native", None)
+    if t is not None:
+        p.x_rowptr, p.x_out, o_in = t["X_ROWPTR"], t["X_OUT"], t["X_ORDER"].long()
+        p.xo_rowptr, p.xo_in, o_out = t["XO_ROWPTR"], t["XO_IN"], t["XO_ORDER"].long()
+    else:
+        p.x_rowptr, o_in = _csr(in_idx, N)
+        p.x_out = i32(out_idx[o_in])
+        p.xo_rowptr, o_out = _csr(out_idx, N)
+        p.xo_in = i32(in_idx[o_out])
     p.x_B = Bfull[o_in].contiguous()
-    p.xo_rowptr, o_out = _csr(out_idx, N)
-    p.xo_in = i32(in_idx[o_out])
     p.xo_B = Bfull[o_out].contiguous()
     # per-receiver sum of the moment vectors: exact fixed-point (2^-40) prefix sum in int64 and a difference per CSR row.
     # Integer arithmetic is associative and wraps modulo 2^64, so the row sums are exact whatever precedes them:
@@ -153,7 +209,8 @@ def wlsq_part(p, face_node_x, support_edge, A, B1, Bx, N):
     A = A.to(torch.float32)
     row_norms = torch.norm(A, p=2, dim=2, keepdim=True)          # FVgrad.py:335
     p.rn = (row_norms + 1e-8).reshape(N, M).contiguous()
-    p.An = (A / (row_norms + 1e-8)).reshape(N, M * M).contiguous()  # FVgrad.py:336
+    # the kernels divide A by rn themselves, in double (FVgrad.py:336; csrc/fvm.hip load_An): `An` holds A as stored
+    p.An = A.reshape(N, M * M).contiguous()
     p.S, p.M = int(in_idx.shape[0]), M
     return p
 
@@ -168,6 +225,9 @@ def build_plan(graph_node, graph_node_x, graph_edge, graph_cell, graph_Index):
     C = graph_cell.pos.shape[0]
     B = int(graph_Index.theta_PDE.shape[0])
     p.N, p.E, p.C, p.B, p.device = N, E, C, B, dev
+    if NATIVE and dev.type == "cuda":
+        p._native = native_tables(N, C, graph_node.edge_index, graph_node.face, graph_edge.face, graph_cell.face,
+                                  graph_node_x.face_node_x, graph_node_x.support_edge)
     _gnn_part(p, graph_node.edge_index, N)
     _batch_part(p, graph_node.batch.reshape(-1), B)
 
@@ -188,14 +248,20 @@ def build_plan(graph_node, graph_node_x, graph_edge, graph_cell, graph_Index):
     # ---- cells: (cell, face, node) incidences -----------------------------------------------------------------
     cells_node, cells_face, cells_index = graph_node.face, graph_edge.face, graph_cell.face
     Svec = graph_cell.cells_face_unv.to(torch.float32).reshape(-1, 2) * face_area[cells_face]  # FVscheme.py:89
-    p.crow, oc = _csr(cells_index, C)
-    kface, knode, kcell = cells_face[oc], cells_node[oc], cells_index[oc]
-    p.kface, p.knode, p.kcell = i32(kface), i32(knode), i32(kcell)
+    t = getattr(p, "_native", None)
+    if t is not None:
+        p.crow, oc, p.kface, p.knode, p.kcell = t["CROW"], t["K_ORDER"].long(), t["KFACE"], t["KNODE"], t["KCELL"]
+        p.frow, p.fk, p.nrow, p.ncell = t["FROW"], t["FK"], t["NROW"], t["NCELL"]
+        del p._native
+    else:
+        p.crow, oc = _csr(cells_index, C)
+        kface, knode, kcell = cells_face[oc], cells_node[oc], cells_index[oc]
+        p.kface, p.knode, p.kcell = i32(kface), i32(knode), i32(kcell)
+        p.frow, of = _csr(kface, E)
+        p.fk = i32(of)
+        p.nrow, on = _csr(knode, N)
+        p.ncell = i32(kcell[on])
     p.kS = Svec[oc].contiguous()
-    p.frow, of = _csr(kface, E)
-    p.fk = i32(of)
-    p.nrow, on = _csr(knode, N)
-    p.ncell = i32(kcell[on])
     p.Sg = int(cells_index.shape[0])
     p.centroid = f32(graph_cell.pos)
     p.area = f32(graph_cell.cells_area.reshape(-1))

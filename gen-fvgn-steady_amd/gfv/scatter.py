@@ -9,10 +9,15 @@ FVgrad.py:2,320; FVorder.py:2,81; FVInterpolation.py:19,193,261; utils/utilities
 
 A scatter with index `idx` over rows is `out[r] = sum_{m: idx[m] = r} src[m]` = the segmented reduce over the CSR of `idx`
 (stable sort: the reference's summation order inside a segment is kept, so results do not depend on launch order and
-there are no floating-point atomics).  The CSR of an index tensor is cached on its identity (data pointer, length,
-in-place version).  Backward of a scatter is a gather (`gout[idx]`), the same kernel over the identity CSR.
+there are no floating-point atomics).  The CSR of an index tensor is cached on the identity of its STORAGE window (data
+pointer, length, stride, in-place version - a fresh view or slice of the same index hits the cache; the cached entry
+holds the tensor, so the pointer cannot be recycled under the key).  Backward of a scatter is a gather (`gout[idx]`),
+the same kernel over the identity CSR.
 Only what the reference's call sites use is built: reduction over dim 0 (or the first dim of a 1-D index), a 1-D index,
-float32 CUDA tensors, reduce in {"sum", "add", "mean"}.
+CUDA tensors, reduce in {"sum", "add", "mean"}.  The kernels compute in float32: a float64 / float16 / bfloat16 `src` is
+converted on the way in and the RESULT IS CAST BACK to src.dtype (torch_scatter preserves the dtype; the arithmetic
+here is fp32 whatever the input - a float64 caller gets fp32 accuracy in a float64 tensor); integer `src` is refused.
+An index entry outside [0, dim_size) raises a ValueError that says so.
 """
 from __future__ import annotations
 
@@ -25,11 +30,17 @@ _CSR_CACHE_MAX = 64
 
 
 def _csr_of(index, n_rows):
-    key = (index.data_ptr(), int(index.numel()), index._version, int(n_rows), str(index.device))
+    key = (index.data_ptr(), int(index.numel()), tuple(index.stride()), index.dtype, index._version, int(n_rows),
+           str(index.device))
     hit = _CSR_CACHE.get(key)
-    if hit is not None and hit[0] is index:
+    if hit is not None:
         return hit[1]
     idx = index.reshape(-1).to(torch.int64)
+    if idx.numel():
+        lo, hi = int(idx.min()), int(idx.max())       # (one host sync per NEW index tensor; cached afterwards)
+        if lo < 0 or hi >= n_rows:
+            raise ValueError(f"gfv.scatter: index holds entries in [{lo}, {hi}] but the output has {n_rows} rows "
+                             "(dim_size / out.shape[0])")
     order = torch.argsort(idx, stable=True)
     counts = torch.bincount(idx, minlength=n_rows)
     rowptr = torch.zeros(n_rows + 1, dtype=torch.int64, device=index.device)
@@ -78,12 +89,17 @@ def _scatter(src, index, dim, out, dim_size, mean):
         n_rows = int(dim_size)
     else:
         n_rows = int(index.max()) + 1 if index.numel() else 0      # (host sync, as in torch_scatter)
+    if not src.is_floating_point():
+        raise TypeError(f"gfv.scatter: floating-point src only (got {src.dtype}); the kernels sum in float32")
     tail = tuple(src.shape[1:])
     src2d = src.reshape(src.shape[0], -1).to(torch.float32).contiguous()
     if src2d.shape[1] == 0 or n_rows == 0:
+        if n_rows == 0 and index.numel():
+            raise ValueError("gfv.scatter: a non-empty index with an output of 0 rows")
         res = torch.zeros((n_rows,) + tail, dtype=torch.float32, device=src.device)
     else:
         res = _ScatterFn.apply(src2d, _csr_of(index, n_rows), n_rows, mean).reshape((n_rows,) + tail)
+    res = res.to(src.dtype)
     if out is not None:
         if mean:
             raise NotImplementedError("scatter_mean into `out`")

