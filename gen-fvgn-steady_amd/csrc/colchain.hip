@@ -32,19 +32,22 @@ static bool cc_bwd_ok(const gfv_rowtile_args_t* a) {
   if (!(a->flags & GFV_CHAIN_COLUMN_OWNER) && (!on || a->M < min_m)) return false;
   if (!a->dw_partial || a->dw_partial_stride < (a->dw_in ? GFV_DW_FUSED_FLOATS_IN : GFV_DW_FUSED_FLOATS) || !a->in_stats || !a->wmax) return false;
   if (a->dw_in && (!al16(a->dw_in) || (a->dw_in_ld & 3) || a->dw_in_ld < 128)) return false;
-  if (a->nlayers != 3 || a->in_op != GFV_IN_LNBWD || a->fin_op != GFV_FIN_PLAIN || a->nseg != 1) return false;
+  // (two layers: the input needs no gradient - the encoders; out[0] then receives gz1, the last layer's op is the second DGELU)
+  const bool noout = a->nlayers == 2;
+  if ((a->nlayers != 3 && !noout) || a->in_op != GFV_IN_LNBWD || a->fin_op != GFV_FIN_PLAIN || a->nseg != 1) return false;
+  if (noout && (a->layer[1].op != GFV_OP_MUL_DGELU || a->layer[1].save || a->res[0] || a->gadd || a->dw_in || !a->out[0])) return false;
   // (every [M, 128] array of the launch shares one byte offset per row: row stride 128 everywhere, at most 2^22 rows)
   if (a->seg[0].width != 128 || a->seg[0].idx || a->seg[0].csr_rowptr || a->seg[0].save || a->seg[0].ld != 128 || !al16(a->seg[0].ptr)) return false;
   if (a->M > (1 << 22) || a->out_ld[0] != 128 || (a->res[0] && a->res_ld[0] != 128) || (a->dw_in && a->dw_in_ld != 128)) return false;
-  if (a->layer[0].op != GFV_OP_MUL_DGELU || a->layer[1].op != GFV_OP_MUL_DGELU || a->layer[2].op != GFV_OP_NONE) return false;
-  for (int l = 0; l < 3; ++l) {
+  if (a->layer[0].op != GFV_OP_MUL_DGELU || a->layer[1].op != GFV_OP_MUL_DGELU || (!noout && a->layer[2].op != GFV_OP_NONE)) return false;
+  for (int l = 0; l < a->nlayers; ++l) {
     const gfv_layer_t& L = a->layer[l];
     if (!L.Wh || (L.N != 128 && !(l == 2 && L.N == 192)) || L.K != 128 || L.bias || L.bias2) return false;
     if (l < 2 && (!L.aux || !al16(L.aux))) return false;
     if (L.save && !al16(L.save)) return false;
   }
   if (!a->in_aux || !al16(a->in_aux) || !a->in_gamma || !al16(a->in_gamma) || a->ln_partial || a->padd) return false;
-  const bool out2 = a->layer[2].N == 192;   // [x part 128 (+ residual) | neighbour-mean part 64]
+  const bool out2 = !noout && a->layer[2].N == 192;   // [x part 128 (+ residual) | neighbour-mean part 64]
   if (!a->out[0] || (out2 ? (!a->out[1] || a->out_ld[1] != 64 || !al16(a->out[1]) || a->dw_in) : a->out[1] != nullptr) || a->out[2] ||
       a->res[1] || a->res[2] || a->out_nores)
     return false;
@@ -73,7 +76,8 @@ int gfv_internal_colchain_try(const gfv_rowtile_args_t* a, hipStream_t stream) {
     const dim3 grid(cc_cus()), blk(64 * CC_W);
 #define CB_LAUNCH(LOWP)                                                                                                          \
   do {                                                                                                                           \
-    if (a->layer[2].N == 192 && a->gadd) hipLaunchKernelGGL((colchain_bwd_kernel<LOWP, true, false, true>), grid, blk, 0, stream, *a, st);   \
+    if (a->nlayers == 2) hipLaunchKernelGGL((colchain_bwd_kernel<LOWP, false, false, false, true>), grid, blk, 0, stream, *a, st);           \
+    else if (a->layer[2].N == 192 && a->gadd) hipLaunchKernelGGL((colchain_bwd_kernel<LOWP, true, false, true>), grid, blk, 0, stream, *a, st);   \
     else if (a->layer[2].N == 192) hipLaunchKernelGGL((colchain_bwd_kernel<LOWP, false, false, true>), grid, blk, 0, stream, *a, st);        \
     else if (a->gadd && a->dw_in) hipLaunchKernelGGL((colchain_bwd_kernel<LOWP, true, true>), grid, blk, 0, stream, *a, st);      \
     else if (a->gadd) hipLaunchKernelGGL((colchain_bwd_kernel<LOWP, true, false>), grid, blk, 0, stream, *a, st);                 \

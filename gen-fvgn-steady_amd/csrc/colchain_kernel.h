@@ -659,7 +659,9 @@ __device__ __forceinline__ void cb_load_gathers(const CbBufs& B, const CcCtx& c,
 // and its input rows are given (dw_in): its weight gradient is fused as well (a fourth fragment buffer, 36 more registers)
 // OUT2: the last chain layer is 192 wide (NodeBlock: W1^T with the rows for x first, then the 64 for the neighbour mean,
 // blocks.py:54): waves 0..3 own a second n-tile and write out[1] ([M, 64], no residual)
-template <bool LOWP, bool GADD, bool DW1, bool OUT2 = false>
+// NOOUT: the MLP's input needs no gradient (the encoders, EPD.py:92-119): a two-layer launch whose out[0] receives gz1 (what the
+// first Linear's weight-gradient launch reads); the third chain phase is only the weight gradient of the second Linear
+template <bool LOWP, bool GADD, bool DW1, bool OUT2 = false, bool NOOUT = false>
 __global__ __launch_bounds__(64 * CC_W, 2) void colchain_bwd_kernel(const gfv_rowtile_args_t A, int* status) {
   constexpr int TG = CB_TG;
   __shared__ __attribute__((aligned(16))) char lds[CbLds::TOTAL + (DW1 ? CbLds::BUF : 0)];
@@ -694,16 +696,17 @@ __global__ __launch_bounds__(64 * CC_W, 2) void colchain_bwd_kernel(const gfv_ro
   B.z1 = cb_buf(A.layer[1].aux, rows128);
   B.gadd = cb_buf(A.gadd, 0x7fffffe0ull);   // (its row count is not an argument; the gather rows come from the index arrays)
   B.gidx = cb_buf(c.w < 4 ? A.gadd_s : A.gadd_r, (size_t)A.M * 4);
-  B.save1 = cb_buf(A.layer[1].save, rows128);
-  B.res = cb_buf(A.res[0], rows128);
-  B.out = cb_buf(A.out[0], rows128);
+  B.save1 = cb_buf(NOOUT ? A.out[0] : A.layer[1].save, rows128);
+  B.res = cb_buf(NOOUT ? nullptr : A.res[0], rows128);
+  B.out = cb_buf(NOOUT ? nullptr : A.out[0], rows128);
   const cb_rsrc out2 = cb_buf(OUT2 ? A.out[1] : nullptr, (size_t)A.M * 256);
 
   // this wave's n-tile of the three transposed layers' images.  The weight-gradient accumulators take 72 (DW1: 108) registers
   // for the whole launch, so the chain's weights are NOT resident here: every tile fetches each layer's slice (4 KB per wave,
   // L2 hits) one phase ahead of its use - 12 KB per wave and 64-row tile next to 230 KB of activation traffic - and the
   // LayerNorm-backward phase, where the register pressure peaks, holds none of them.
-  const cb_rsrc w0 = cb_buf(A.layer[0].Wh, 65536), w1 = cb_buf(A.layer[1].Wh, 65536), w2 = cb_buf(A.layer[2].Wh, OUT2 ? 131072 : 65536);
+  const cb_rsrc w0 = cb_buf(A.layer[0].Wh, 65536), w1 = cb_buf(A.layer[1].Wh, 65536),
+                w2 = cb_buf(NOOUT ? nullptr : A.layer[2].Wh, OUT2 ? 131072 : 65536);
   const int woff = (c.w * 128 + c.lane) * 16;   // + T * 16384 (+ 1024: the lo part)
   // fused weight gradients: D[n = 16 w + 4 g + r][k = 16 kt + j] in lane (j, g) of acc[kt][r]
   floatx4 dw3[8], dw2[8], dw1[DW1 ? 8 : 1], db3 = floatx4{0.f, 0.f, 0.f, 0.f}, db2 = db3, db1 = db3;
@@ -947,20 +950,24 @@ __global__ __launch_bounds__(64 * CC_W, 2) void colchain_bwd_kernel(const gfv_ro
         a0 = n0; a1 = n1;
       }
     }
+    if constexpr (!NOOUT) {
 #pragma unroll
-    for (int T = 0; T < 4; ++T) {
-      wh[T] = __builtin_bit_cast(gfv_f16x8, __builtin_amdgcn_raw_buffer_load_b128(w2, woff + T * 16384, 0, 0));
-      wl[T] = __builtin_bit_cast(gfv_f16x8, __builtin_amdgcn_raw_buffer_load_b128(w2, woff + T * 16384 + 1024, 0, 0));
+      for (int T = 0; T < 4; ++T) {
+        wh[T] = __builtin_bit_cast(gfv_f16x8, __builtin_amdgcn_raw_buffer_load_b128(w2, woff + T * 16384, 0, 0));
+        wl[T] = __builtin_bit_cast(gfv_f16x8, __builtin_amdgcn_raw_buffer_load_b128(w2, woff + T * 16384 + 1024, 0, 0));
+      }
     }
     // this tile's residual rows go out here: in flight through the barrier
-    float4 rr[TG];
+    float4 rr[NOOUT ? 1 : TG];
+    if constexpr (!NOOUT) {
 #pragma unroll
-    for (int q = 0; q < TG; ++q) rr[q] = cb_ld4(B.res, offL[q]);
+      for (int q = 0; q < TG; ++q) rr[q] = cb_ld4(B.res, offL[q]);
+    }
     CT(8);
     cc_barrier();
     CT(9);
     // ---- P1: chain layer 2 (b0 -> the input gradient) and dW2 += gz2^T a1 (and dW1 += gz1^T x) ----
-    {
+    if constexpr (!NOOUT) {
       const float inv_in = 1.0f / s1s;
       floatx4 a0, a1;
       cc_mma_pair<4, LOWP, true>(b0, 0, wh, wl, c.lane, a0, a1);

@@ -138,6 +138,9 @@ class Engine:
         # gfv_rowtile_args_t.dw_partial): the chain launch accumulates dW3, dW2 (and dW1 of a 128-deep first layer), the bias
         # gradients and the LayerNorm's per workgroup; one reduction launch per MLP sums the blocks
         self.fuse_dw = os.environ.get("GFV_FUSE_DW", "1") != "0"
+        self._tail_main = int(os.environ.get("GFV_TAIL_MAIN", "2"))
+        self._enc_order = int(os.environ.get("GFV_ENC_ORDER", "1"))
+        self._fuse_noout = os.environ.get("GFV_FUSE_NOOUT", "1") != "0"   # ... also where the input needs no gradient (encoders)
         self._fuse_dw_min = int(os.environ.get("GFV_COLCHAIN_BWD_MIN_M", "16384"))
         self._wi, self._wi_key, self._wmax, self._wi_abs = None, None, None, None
         self._pkey_cache = None
@@ -381,7 +384,8 @@ class Engine:
         nores = _empty(dev, M, 128) if want_nores else None
         # (mean, 1 / std) of the LayerNorm rows for a backward launch that fuses the weight gradients (it does not recompute them)
         stats = _empty(dev, M, 2) if (keep and ln and self.fuse_dw and self.f16split and self.hidden == 128 and nout == 128
-                                      and M >= self._fuse_dw_min and all(sg.width % 32 == 0 for sg in segs)) else None
+                                      and M >= self._fuse_dw_min
+                                      and (self._fuse_noout or all(sg.width % 32 == 0 for sg in segs))) else None
         ops.rowtile_chain(
             M, segs,
             [LayerSpec(W1, b1, L.OP_BIAS_GELU, save=z1), LayerSpec(W2, b2, L.OP_BIAS_GELU, save=z2), LayerSpec(W3, b3)],
@@ -403,9 +407,10 @@ class Engine:
         dev = W1.device
         nout = W3.shape[0]
         W3t, W2t = self._T(W3), self._T(W2)
-        if (self.fuse_dw and ln and sv.get("stats") is not None and outs is not None and G.stride(0) == 128 and g_ld is None
-                and gadd is None and self._mlp3_bwd_fused(P, sv, G, grads, names, W3t, W2t, W1t if W1t is not None else self._T(W1),
-                                                          outs, res, g_add)):
+        if (self.fuse_dw and ln and sv.get("stats") is not None and G.stride(0) == 128 and g_ld is None and gadd is None
+                and (outs is not None or (res is None and self._fuse_noout))
+                and self._mlp3_bwd_fused(P, sv, G, grads, names, W3t, W2t,
+                                         None if outs is None else (W1t if W1t is not None else self._T(W1)), outs, res, g_add)):
             return
         gz2, gz1 = _empty(dev, M, 128), _empty(dev, M, 128)
         tiles_n = ops.rowtile_tiles(M)
@@ -467,8 +472,13 @@ class Engine:
         dwp = _empty(dev, nwg, FL)
         gz1 = _empty(dev, M, 128)
         gs = _empty(dev, 3, ops.gscale_ld(M))
-        layers = [LayerSpec(W3t, None, L.OP_MUL_DGELU, aux=sv["z2"]), LayerSpec(W2t, None, L.OP_MUL_DGELU, save=gz1, aux=sv["z1"]),
-                  LayerSpec(W1t)]
+        if outs is None:
+            # the input needs no gradient (the encoders): two chain layers, the launch's output is gz1
+            layers = [LayerSpec(W3t, None, L.OP_MUL_DGELU, aux=sv["z2"]), LayerSpec(W2t, None, L.OP_MUL_DGELU, aux=sv["z1"])]
+            outs = [gz1]
+        else:
+            layers = [LayerSpec(W3t, None, L.OP_MUL_DGELU, aux=sv["z2"]),
+                      LayerSpec(W2t, None, L.OP_MUL_DGELU, save=gz1, aux=sv["z1"]), LayerSpec(W1t)]
         kw = dict(res=res, in_op=L.IN_LNBWD, in_gamma=P[names[6]], in_aux=sv["y3"], in_stats=sv["stats"], dw_partial=dwp, gscale=gs,
                   in_add=g_add)
         if not ops.rowtile_chain(M, [Seg(G)], layers, outs, query_fused=True, **kw):
@@ -746,7 +756,8 @@ class Engine:
                           res=[None, None, g_e_out], gadd=(g_agg, pl.es, pl.er))
             g_nb = ops.seg_gather_sum(gnb2.view(2 * E, 128), pl.n_rowptr, pl.n_col_edge2, N)
         ops.seg_gather_sum(g_nb, pl.n_rowptr, pl.n_col_node, N, out=g_x_in, accumulate=True)
-        self.flush()   # the block's weight gradients: one fork
+        # the block's weight gradients: one fork (the last block's may go to the main stream: GFV_TAIL_MAIN >= 3)
+        self.flush(on_main=self._defer_mode and self._tail_main >= 3 and getattr(self, "_last_gn", False))
         return g_x_in, g_e_in
 
     # ------------------------------------------------------------------------------------------------------------
@@ -1083,6 +1094,7 @@ class Engine:
                     if self._zero_e is None or self._zero_e.shape[0] != E or self._zero_e.device != dev:
                         self._zero_e = torch.zeros((E, 128), dtype=torch.float32, device=dev)
                     g_e = self._zero_e
+                self._last_gn = proc is sv["procs"][0] and blk is proc["blocks"][0]
                 g_x, g_e = self.gn_bwd(P, blk, g_x, g_e, grads, pl)
             if g_emb is not None:
                 pending = g_emb  # the processor input also entered the Transolver residual (TransFVGN_v2.py:46-49)
@@ -1091,10 +1103,16 @@ class Engine:
                 self.bucket_hook()
         # (the two encoders end the backward; running the big one - edge encoder, 75 k rows - first so that its weight
         # gradient overlaps the node encoder's chain was measured: 4.892 against 4.877 ms / step in this order)
-        self.mlp3_bwd(P, sv["sv_nenc"], g_x, grads, g_add=pending)
-        self.flush()
-        self.mlp3_bwd(P, sv["sv_eenc"], g_e, grads)
-        self.flush(on_main=self._defer_mode)
+        tail = self._tail_main if self._defer_mode else 0   # how many of the trailing flushes run on the main stream
+        if self._enc_order == 0:
+            self.mlp3_bwd(P, sv["sv_nenc"], g_x, grads, g_add=pending)
+            self.flush(on_main=tail >= 2)
+            self.mlp3_bwd(P, sv["sv_eenc"], g_e, grads)
+        else:
+            self.mlp3_bwd(P, sv["sv_eenc"], g_e, grads)
+            self.flush(on_main=tail >= 2)
+            self.mlp3_bwd(P, sv["sv_nenc"], g_x, grads, g_add=pending)
+        self.flush(on_main=tail >= 1)
 
     # ------------------------------------------------------------------------------------------------------------
     # whole model (importer.py:156-240)

@@ -244,3 +244,44 @@ def test_column_owner_backward_node_mlp_192_wide(dev, M):
         assert rel(mine, Pg[name].grad) < TOL, (name, rel(mine, Pg[name].grad))
     dW1, db1 = ops.linear_dw(gz1, 128, [ops.Seg(d(nbm)), ops.Seg(d(x))], M, gscale=gs[2])
     assert rel(dW1, Pg["W1"].grad) < TOL and rel(db1, Pg["b1"].grad) < TOL
+
+
+@pytest.mark.parametrize("M", [3000, 333, 16])
+def test_column_owner_backward_without_input_gradient(dev, M):
+    """Encoder backward (EPD.py:92-119: the raw inputs need no gradient): a TWO-layer launch whose output is gz1; weight
+    gradients of the third and second Linear, bias and LayerNorm gradients fused; the narrow first Linear's (16 input
+    columns) by the weight-gradient kernel with the row scales the chain launch leaves behind."""
+    from gfv import lib as L, ops
+    g = torch.Generator().manual_seed(M + 1)
+    x = torch.randn(M, 16, generator=g) * torch.tensor([1.0] * 12 + [1e-3] * 4)     # geometric columns at mesh-spacing scale
+    P = _params(g, 16)
+    Pg = {k: v.double().requires_grad_(True) for k, v in P.items()}
+    z1, z2, y3, ln = _ref(Pg, x.double())
+    go = torch.randn(M, 128, generator=g) * torch.logspace(-4, 0, M)[:, None]
+    (ln * go.double()).sum().backward()
+    d = lambda t: t.to(dev).contiguous()
+    Pd = {k: d(v) for k, v in P.items()}
+    z1d, z2d, y3d = d(z1.detach().float()), d(z2.detach().float()), d(y3.detach().float())
+    stats = d(torch.stack((y3.detach().mean(1), (y3.detach().var(1, unbiased=False) + 1e-5).rsqrt()), 1).float())
+    wi = _images(dev, [P["W2"], P["W3"]])
+    gz1 = torch.full((M, 128), float("nan"), device=dev)
+    part = torch.full((L.load().gfv_rowtile_dw_partials(), L.DW_FUSED_FLOATS), float("nan"), device=dev)
+    gs = torch.zeros(3, ops.gscale_ld(M), device=dev)
+    god = d(go)
+    layers = [ops.LayerSpec(ops.transpose(Pd["W3"]), None, L.OP_MUL_DGELU, aux=z2d),
+              ops.LayerSpec(ops.transpose(Pd["W2"]), None, L.OP_MUL_DGELU, aux=z1d)]
+    kw = dict(in_op=L.IN_LNBWD, in_gamma=Pd["gamma"], in_aux=y3d, in_stats=stats, dw_partial=part, gscale=gs, wimg=wi,
+              family=L.CHAIN_COLUMN_OWNER)
+    assert ops.rowtile_chain(M, [ops.Seg(god)], layers, [gz1], query_fused=True, **kw)
+    ops.rowtile_chain(M, [ops.Seg(god)], layers, [gz1], **kw)
+    assert L.load().gfv_rowtile_last_path() == 5 + 16
+    tot = part.double().sum(0).cpu()
+    for mine, name in ((tot[:16384].view(128, 128), "W3"), (tot[16384:16512], "b3"), (tot[16512:16512 + 16384].view(128, 128), "W2"),
+                       (tot[16512 + 16384:16512 + 16384 + 128], "b2"), (tot[2 * 16384 + 256:2 * 16384 + 384], "gamma"),
+                       (tot[2 * 16384 + 384:2 * 16384 + 512], "beta")):
+        assert rel(mine, Pg[name].grad) < TOL, (name, rel(mine, Pg[name].grad))
+    dW1, db1 = ops.linear_dw(gz1, 128, [ops.Seg(d(x), width=16, ld=16)], M, gscale=gs[2], col_scale=True)
+    assert rel(dW1, Pg["W1"].grad) < TOL and rel(db1, Pg["b1"].grad) < TOL
+    flags = L.C.c_int32(0)
+    L.check(L.load().gfv_status_flags(L.C.byref(flags)), "gfv_status_flags")
+    assert flags.value == 0
