@@ -7,6 +7,16 @@ and either mean or inverse-distance weights; hand-written adjoint over the trans
     node_to_face_2nd_order   :111-185  face value = average of the two end nodes' extrapolations (grad may be None)
     cell_to_node_2nd_order   :218-265  node value = inverse-distance weighted mean of the adjacent cells (+ cell_grad)
 
+DELIBERATE DEVIATION (cell_to_node_2nd_order with `cell_grad`): the reference gathers the correction's gradient as
+`cell_grad[cells_node]` (FVInterpolation.py:248) - a [C, .., 2] CELL array indexed by NODE ids, which pairs every
+(cell, node) incidence with the gradient of an unrelated cell (and reads out of bounds when a node id exceeds the cell
+count).  Here the gradient of the incidence's own cell is used, `cell_grad[cells_index]`: the first-order Taylor
+correction phi_c + (x_n - x_c) . grad_c the method's name and its two siblings describe.  No caller in the reference
+passes `cell_grad` (FVscheme.py:257, importer.py: cell_grad=None), so no result of the training / solve paths depends on
+it; tests/test_operators_gpu.py::test_cell_to_node_with_cell_grad_uses_the_cells_own_gradient pins the behaviour.
+All inputs are computed in float32 (float64 inputs are converted); positions receive no gradient (mesh geometry is
+constant in every caller).
+
 Inside `NNmodel` the same arithmetic runs fused with the fluxes (csrc/fvm.hip face_fwd / cell_fwd / cell_to_node); these are
 the operator-API forms.  Hessian corrections (`node_hessian`) are not built: no caller of the reference passes one
 (FVscheme.py:101-122 passes None)."""

@@ -540,6 +540,180 @@ __global__ __launch_bounds__(256) void slice_gw_kernel(const float* __restrict__
   }
 }
 
+// ---- everything behind the attention adjoint in ONE pass over the nodes ------------------------------------------------------
+//   gw[n,h,g]   = sum_c g_out_x[n,h,c] T1[b,h,g,c] + sum_c fx_mid[n,h,c] T2[b,h,g,c] + g_norm[b,h,g]   (T1 = out_token, T2 = g_raw)
+//   g_fx_mid    = de-slice of g_raw by w
+//   g_x_mid, per-block partials of (dWs, dbs, dT): the slice-softmax adjoint from gw
+// = slice_gw, deslice, slice_gw (accumulate) and slice_softmax_bwd of the four-launch form, term for term in the same
+// order (the results are bit-identical, tests/test_kernels_gpu.py), without gw [N,8,32] ever leaving the registers:
+// 182 MB of traffic per Transolver block become 78 MB, four launches one.  The two slice tensors of the block's graph are
+// staged in LDS; the region is reused for the dWs product once every thread is through with them.
+struct SlicePostArgs {
+  const float* xmid; const float* Ws; const float* bs; const float* temp; const float* w; const float* gox;
+  const float* T1; const float* fxm; const float* T2; const float* gnorm; const int* batch;
+  float* gxmid; float* gfxmid; float* partial; int N;
+};
+
+__global__ __launch_bounds__(256, 2) void slice_post_bwd_kernel(const SlicePostArgs A) {
+  __shared__ float sW[G * D];
+  __shared__ float sB[G];
+  __shared__ float sDT[256];
+  __shared__ __attribute__((aligned(16))) float u[256 * (G + 1) + 256 * (D + 1)];
+  static_assert(2 * H * TS <= 256 * (G + 1) + 256 * (D + 1), "the two slice tensors fit the region of the dWs operands");
+  float* sT1 = u;
+  float* sT2 = u + H * TS;
+  float* sGL = u;                    // d logits (pre-temperature) per row, stride G + 1
+  float* sX = u + 256 * (G + 1);     // x_mid rows, stride D + 1
+  const int tid = threadIdx.x;
+  for (int i = tid; i < G * D; i += 256) sW[i] = A.Ws[i];
+  if (tid < G) sB[tid] = A.bs[tid];
+  const int n_first = blockIdx.x * 32;
+  const int n_last = min(n_first + 31, A.N - 1);
+  const int b0 = A.batch[n_first];
+  const bool uniform = (A.batch[n_last] == b0);
+  if (uniform) {
+    const float4* s1 = reinterpret_cast<const float4*>(A.T1 + (size_t)b0 * H * G * D);
+    const float4* s2 = reinterpret_cast<const float4*>(A.T2 + (size_t)b0 * H * G * D);
+    for (int i = tid; i < H * G * D / 4; i += 256) {
+      const int h = i / (G * D / 4), r = i % (G * D / 4);
+      *reinterpret_cast<float4*>(&sT1[h * TS + 4 * r]) = s1[i];
+      *reinterpret_cast<float4*>(&sT2[h * TS + 4 * r]) = s2[i];
+    }
+  }
+  __syncthreads();
+  const long row = (long)blockIdx.x * 256 + tid;
+  const long nrows = (long)A.N * H;
+  const bool live = row < nrows;
+  float wv[G], gv[G];
+  float dT = 0.f, invT = 0.f;
+  if (live) {
+    const int n = (int)(row >> 3), h = (int)(row & 7);
+    const size_t bh = (size_t)A.batch[n] * H + h;
+    invT = 1.0f / A.temp[h];
+    float go[D], fx[D];
+    const float4* gp = reinterpret_cast<const float4*>(A.gox + row * D);
+    const float4* fp = reinterpret_cast<const float4*>(A.fxm + row * D);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float4 a = gp[i], b = fp[i];
+      go[4 * i] = a.x; go[4 * i + 1] = a.y; go[4 * i + 2] = a.z; go[4 * i + 3] = a.w;
+      fx[4 * i] = b.x; fx[4 * i + 1] = b.y; fx[4 * i + 2] = b.z; fx[4 * i + 3] = b.w;
+    }
+    const float4* wp = reinterpret_cast<const float4*>(A.w + row * G);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float4 a = wp[i];
+      wv[4 * i] = a.x; wv[4 * i + 1] = a.y; wv[4 * i + 2] = a.z; wv[4 * i + 3] = a.w;
+    }
+    float4 av[G / 4];
+#pragma unroll
+    for (int i = 0; i < G / 4; ++i) av[i] = reinterpret_cast<const float4*>(A.gnorm + bh * G)[i];
+    const float* T1p = uniform ? &sT1[h * TS] : A.T1 + bh * G * D;
+    const float* T2p = uniform ? &sT2[h * TS] : A.T2 + bh * G * D;
+    // per slice g: gw = (g_norm + fx_mid . T2[g]) + (0 + g_out_x . T1[g])  (slice_gw twice: the first product from zero, the
+    // second on top of the per-(graph, head) addend, then their sum) and the de-slice term w[g] T2[g] (deslice_row's order);
+    // a scheduling fence per group of four slices keeps the loads of later groups out of this one's registers
+    float acc[D];
+#pragma unroll
+    for (int c = 0; c < D; ++c) acc[c] = 0.f;
+#pragma unroll
+    for (int i = 0; i < G / 4; ++i) {
+      float r1[4] = {0.f, 0.f, 0.f, 0.f};
+      float r2[4] = {av[i].x, av[i].y, av[i].z, av[i].w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float4* t1 = reinterpret_cast<const float4*>(T1p + (4 * i + k) * D);
+        const float4* t2 = reinterpret_cast<const float4*>(T2p + (4 * i + k) * D);
+        const float wg = wv[4 * i + k];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float4 t = t1[j];
+          r1[k] += go[4 * j] * t.x + go[4 * j + 1] * t.y + go[4 * j + 2] * t.z + go[4 * j + 3] * t.w;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float4 t = t2[j];
+          r2[k] += fx[4 * j] * t.x + fx[4 * j + 1] * t.y + fx[4 * j + 2] * t.z + fx[4 * j + 3] * t.w;
+          acc[4 * j] += wg * t.x; acc[4 * j + 1] += wg * t.y; acc[4 * j + 2] += wg * t.z; acc[4 * j + 3] += wg * t.w;
+        }
+        gv[4 * i + k] = r2[k] + r1[k];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    float4* op = reinterpret_cast<float4*>(A.gfxmid + row * D);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) op[j] = make_float4(acc[4 * j], acc[4 * j + 1], acc[4 * j + 2], acc[4 * j + 3]);
+  }
+  __syncthreads();   // every thread is through with the slice tensors: their region becomes (sGL, sX)
+  if (live) {
+    float x[D];
+    const float4* xp = reinterpret_cast<const float4*>(A.xmid + row * D);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float4 v = xp[i];
+      x[4 * i] = v.x; x[4 * i + 1] = v.y; x[4 * i + 2] = v.z; x[4 * i + 3] = v.w;
+    }
+    float dot = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      dot += wv[4 * i] * gv[4 * i] + wv[4 * i + 1] * gv[4 * i + 1] + wv[4 * i + 2] * gv[4 * i + 2] + wv[4 * i + 3] * gv[4 * i + 3];
+    float gx[D];
+#pragma unroll
+    for (int c = 0; c < D; ++c) gx[c] = 0.f;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const float gz = wv[g] * (gv[g] - dot);  // grad wrt z = logit / T
+      float lg = 0.f;
+#pragma unroll
+      for (int c = 0; c < D; ++c) lg += x[c] * sW[g * D + c];
+      lg += sB[g];
+      dT -= gz * lg * invT * invT;
+      const float gl = gz * invT;  // grad wrt the raw logit
+      sGL[tid * (G + 1) + g] = gl;
+#pragma unroll
+      for (int c = 0; c < D; ++c) gx[c] += gl * sW[g * D + c];
+    }
+    float4* op = reinterpret_cast<float4*>(A.gxmid + row * D);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) op[i] = make_float4(gx[4 * i], gx[4 * i + 1], gx[4 * i + 2], gx[4 * i + 3]);
+#pragma unroll
+    for (int c = 0; c < D; ++c) sX[tid * (D + 1) + c] = x[c];
+  } else {
+#pragma unroll
+    for (int g = 0; g < G; ++g) sGL[tid * (G + 1) + g] = 0.f;
+#pragma unroll
+    for (int c = 0; c < D; ++c) sX[tid * (D + 1) + c] = 0.f;
+  }
+  sDT[tid] = dT;
+  __syncthreads();
+  float* out = A.partial + (size_t)blockIdx.x * 552;
+  {
+    const int wave = tid >> 6, lane = tid & 63, li = lane & 15, kq = lane >> 4;
+    if (wave < 2) {
+      floatx4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+      for (int ks = 0; ks < 64; ++ks) {
+        const int r = 4 * ks + kq;
+        const float a = sGL[r * (G + 1) + 16 * wave + li];
+        const float b = sX[r * (D + 1) + li];
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) out[(16 * wave + 4 * kq + reg) * D + li] = acc[reg];
+    }
+  }
+  if (tid < G) {
+    float s = 0.f;
+    for (int r = 0; r < 256; ++r) s += sGL[r * (G + 1) + tid];
+    out[512 + tid] = s;
+  }
+  if (tid < H) {
+    float s = 0.f;
+    for (int r = tid; r < 256; r += H) s += sDT[r];
+    out[544 + tid] = s;
+  }
+}
+
 }  // namespace
 
 extern "C" int gfv_slice_softmax_fwd(const float* xmid, const float* Ws, const float* bs, const float* temp, float* w,
@@ -616,6 +790,19 @@ extern "C" int gfv_slice_gw(const float* a, const float* T, const float* add, co
   if (N <= 0) return N == 0 ? GFV_OK : GFV_ERR_ARG;
   hipLaunchKernelGGL(slice_gw_kernel, dim3(gfv_div_up((long)N * H, 256)), dim3(256), 0, (hipStream_t)stream, a, T, add,
                      batch, gw, N, accumulate);
+  GFV_CHECK_LAUNCH();
+  return GFV_OK;
+}
+
+extern "C" int gfv_slice_post_bwd(const float* xmid, const float* Ws, const float* bs, const float* temp, const float* w,
+                                  const float* g_out_x, const float* out_token, const float* fx_mid, const float* g_raw,
+                                  const float* g_norm, const int32_t* batch, float* g_x_mid, float* g_fx_mid, float* partial,
+                                  int32_t N, void* stream) {
+  // x_mid, g_out_x, fx_mid [N,128] + w [N,8,32] in, g_x_mid + g_fx_mid out
+  GfvProfScope ps_(GFV_K_SLICE, 0, (3 * 512.0 + 1024.0 + 2 * 512.0) * N, stream);
+  if (N <= 0) return N == 0 ? GFV_OK : GFV_ERR_ARG;
+  SlicePostArgs a{xmid, Ws, bs, temp, w, g_out_x, out_token, fx_mid, g_raw, g_norm, batch, g_x_mid, g_fx_mid, partial, N};
+  hipLaunchKernelGGL(slice_post_bwd_kernel, dim3(gfv_div_up((long)N * H, 256)), dim3(256), 0, (hipStream_t)stream, a);
   GFV_CHECK_LAUNCH();
   return GFV_OK;
 }

@@ -146,6 +146,19 @@ __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast
 __device__ __forceinline__ void st4(float* p, const float (&v)[4]) {
   *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
 }
+// rows saved for the backward (pre-activations, the pre-LayerNorm values): written once, read a millisecond later.
+// -DGFV_NT_SAVE=1 stores them non-temporally (experiment: profiles/tools/build_variant.sh)
+#ifndef GFV_NT_SAVE
+#define GFV_NT_SAVE 0
+#endif
+__device__ __forceinline__ void st4_save(float* p, const float (&v)[4]) {
+#if GFV_NT_SAVE
+  typedef float nt_f4 __attribute__((ext_vector_type(4)));
+  __builtin_nontemporal_store(nt_f4{v[0], v[1], v[2], v[3]}, reinterpret_cast<nt_f4*>(p));
+#else
+  st4(p, v);
+#endif
+}
 
 // ---- 128-byte runs ------------------------------------------------------------------------------------------------
 // The accumulator layout puts the 4 lanes g = 0..3 of a row on 64 contiguous bytes, so a plain float4 access of a wave touches
@@ -919,7 +932,7 @@ __global__ __launch_bounds__(64 * NW, GFV_CHAIN_WAVES(H, LNM, RAG)) void tchain_
             if (lop == GFV_OP_MUL_DGELU) {
               const float4 z = ld4(L.aux + mrow + 16 * nt);
               v[0] *= gfv_dgelu(z.x); v[1] *= gfv_dgelu(z.y); v[2] *= gfv_dgelu(z.z); v[3] *= gfv_dgelu(z.w);
-              if (L.save && live) st4(L.save + mrow + 16 * nt, v);
+              if (L.save && live) st4_save(L.save + mrow + 16 * nt, v);
             } else {
               {
                 const float4 b = ld4(par + 128 * layer + 16 * nt + 4 * g);
@@ -932,7 +945,7 @@ __global__ __launch_bounds__(64 * NW, GFV_CHAIN_WAVES(H, LNM, RAG)) void tchain_
               }
               if (lop == GFV_OP_BIAS_GELU) {
 #ifndef ABL_NOSTORE
-                if (L.save && live) st4(L.save + mrow + 16 * nt, v);
+                if (L.save && live) st4_save(L.save + mrow + 16 * nt, v);
 #endif
 #ifndef ABL_NOGELU
 #pragma unroll
@@ -1008,7 +1021,7 @@ __global__ __launch_bounds__(64 * NW, GFV_CHAIN_WAVES(H, LNM, RAG)) void tchain_
               }
             } else if (A.fin_presave && live) {
 #pragma unroll
-              for (int nt = 0; nt < 8; ++nt) st4(A.fin_presave + mc * 128 + 16 * nt + 4 * g, v[nt]);
+              for (int nt = 0; nt < 8; ++nt) st4_save(A.fin_presave + mc * 128 + 16 * nt + 4 * g, v[nt]);
             }
 #endif
             ln_apply(v, par + PAR_GAMMA, par + PAR_BETA, g, lnw, (A.fin_stats && live) ? A.fin_stats + 2 * mc : nullptr);

@@ -26,7 +26,8 @@ _QUERIES = frozenset((
     "gfv_abi_version", "gfv_struct_size", "gfv_rowtile_tiles", "gfv_rowtile_last_path", "gfv_dw_chunks", "gfv_dw_slabs",
     "gfv_linear_dw_workspace_floats", "gfv_dw_multi_workspace_floats", "gfv_f16split_enabled", "gfv_set_f16split", "gfv_hidden_size",
     "gfv_weight_image_bytes", "gfv_normalizer_blocks", "gfv_slice_softmax_bwd_blocks", "gfv_profile_enable",
-    "gfv_profile_collect", "gfv_profile_reset", "gfv_profile_set_sizes", "gfv_status_flags"))
+    "gfv_profile_collect", "gfv_profile_reset", "gfv_profile_set_sizes", "gfv_status_flags", "gfv_rowtile_dw_partials",
+    "gfv_rowtile_fuses_dw", "gfv_plan_create", "gfv_plan_destroy", "gfv_plan_table", "gfv_plan_sizes"))
 
 
 class CommandList:
@@ -58,13 +59,52 @@ def active():
     return _ACTIVE
 
 
+_IN_CALL = 0     # depth of cmdlist.call frames: torch ops issued inside them ARE recorded (as the call)
+
+
 def call(fn, *args):
     """Run a host-side callable that enqueues device work (tensor copy, stream wait) and, while recording, note it with
     the stream it ran under."""
-    r = fn(*args)
+    global _IN_CALL
+    _IN_CALL += 1
+    try:
+        r = fn(*args)
+    finally:
+        _IN_CALL -= 1
     if _ACTIVE is not None:
         _ACTIVE.cmds.append((fn, args, torch.cuda.current_stream()))
     return r
+
+
+# torch ops that enqueue nothing on the device: allocation from the recording pool, views
+_NO_KERNEL = frozenset((
+    "aten::empty.memory_format", "aten::empty_strided", "aten::empty_like", "aten::new_empty", "aten::new_empty_strided",
+    "aten::detach", "aten::alias", "aten::lift_fresh", "aten::_unsafe_view", "aten::is_pinned", "aten::resize_",
+    "aten::set_.source_Storage", "aten::set_.source_Storage_storage_offset", "aten::set_.source_Tensor", "aten::_local_scalar_dense",
+    "aten::is_same_size", "aten::stride", "aten::sym_size", "aten::sym_stride", "aten::sym_numel", "aten::sym_storage_offset"))
+
+
+def _guard_mode():
+    """A torch op that launches device work while a step is being recorded - and does not go through `call` or the library
+    proxy - runs now and is silently MISSING from every replay.  The guard turns that into an error at record time
+    (GFV_CMDLIST_GUARD=0 disables it)."""
+    from torch.utils._python_dispatch import TorchDispatchMode
+    from torch.utils._pytree import tree_leaves
+
+    class Guard(TorchDispatchMode):
+        def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+            out = func(*args, **(kwargs or {}))
+            if _IN_CALL == 0:
+                name = func._schema.name + ("." + func._overloadname if func._overloadname and func._overloadname != "default" else "")
+                if name not in _NO_KERNEL and not getattr(func, "is_view", False):
+                    leaves = tree_leaves((args, kwargs, out))
+                    if any(isinstance(t, torch.Tensor) and t.is_cuda for t in leaves):
+                        raise RuntimeError(
+                            f"cmdlist: torch op {name} enqueued device work outside cmdlist.call while a step was being "
+                            "recorded; it would be dropped on replay (wrap it in cmdlist.call, move it to set-up, or run the "
+                            "step with use_graph=False)")
+            return out
+    return Guard()
 
 
 class _RecordingLib:
@@ -109,11 +149,17 @@ class record:
         self._ctx.__enter__()
         _ACTIVE = self.cl
         L._recording = _RecordingLib(L.load(raw=True), self.cl)
+        self._guard = None
+        if __import__("os").environ.get("GFV_CMDLIST_GUARD", "1") != "0":
+            self._guard = _guard_mode()
+            self._guard.__enter__()
         return self.cl
 
     def __exit__(self, *exc):
         global _ACTIVE
         from . import lib as L
+        if self._guard is not None:
+            self._guard.__exit__(*exc)
         L._recording = None
         _ACTIVE = None
         self._ctx.__exit__(*exc)

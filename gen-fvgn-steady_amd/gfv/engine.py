@@ -138,6 +138,7 @@ class Engine:
         # gfv_rowtile_args_t.dw_partial): the chain launch accumulates dW3, dW2 (and dW1 of a 128-deep first layer), the bias
         # gradients and the LayerNorm's per workgroup; one reduction launch per MLP sums the blocks
         self.fuse_dw = os.environ.get("GFV_FUSE_DW", "1") != "0"
+        self._slice_fuse = os.environ.get("GFV_SLICE_FUSE", "1") != "0"   # Transolver adjoint: one pass behind the attention
         self._tail_main = int(os.environ.get("GFV_TAIL_MAIN", "2"))
         self._enc_order = int(os.environ.get("GFV_ENC_ORDER", "1"))
         self._fuse_noout = os.environ.get("GFV_FUSE_NOOUT", "1") != "0"   # ... also where the input needs no gradient (encoders)
@@ -169,12 +170,9 @@ class Engine:
                 return self
             if e._side is None:
                 e._side = pick_concurrent_stream(int(os.environ.get("GFV_SIDE_PRIO", "0")))
+                # ONE side queue: the weight-gradient launches share one slab workspace and the stand-in gradient blocks, so
+                # two side queues would race on them (the several-queues experiment of round 2 is gone with its knob)
                 e._sides = [e._side]
-                for _ in range(int(os.environ.get("GFV_SIDE_STREAMS", "1")) - 1):   # experiment: several side queues
-                    e._sides.append(pick_concurrent_stream(int(os.environ.get("GFV_SIDE_PRIO", "0"))))
-            if len(e._sides) > 1:
-                e._side_rr = (getattr(e, "_side_rr", -1) + 1) % len(e._sides)
-                e._side = e._sides[e._side_rr]
             cmdlist.call(e._side.wait_stream, torch.cuda.current_stream())
             # tensors the side stream reads must outlive this call: the caching allocator would hand their blocks to
             # the next allocation on the main stream while the side stream is still reading them
@@ -869,9 +867,11 @@ class Engine:
                                           [self._tile(g_fx1, 128, Seg(sv["out_x"]))], N), g_fx1, sv["out_x"])
         # de-slice / attention / slice
         w, batch = sv["w"], pl.batch
-        gw = _empty(dev, N, 256)
-        L.check(lib.gfv_slice_gw(g_out_x.data_ptr(), sv["out_token"].data_ptr(), None, batch.data_ptr(), gw.data_ptr(), N,
-                                 0, st), "slice_gw")
+        fused_post = self._slice_fuse
+        if not fused_post:
+            gw = _empty(dev, N, 256)
+            L.check(lib.gfv_slice_gw(g_out_x.data_ptr(), sv["out_token"].data_ptr(), None, batch.data_ptr(), gw.data_ptr(), N,
+                                     0, st), "slice_gw")
         gpartial = _empty(dev, pl.n_chunks, 256, 17)
         L.check(lib.gfv_slice_token_partial(w.data_ptr(), g_out_x.data_ptr(), pl.chunk_beg.data_ptr(),
                                             pl.chunk_end.data_ptr(), pl.n_chunks, gpartial.data_ptr(), st), "token_partial")
@@ -888,16 +888,24 @@ class Engine:
                                    chunk_stride=768, rows=1, cols=256) for i, nm in enumerate(("to_q", "to_k", "to_v"))])
         self.defer(side_qkv, dwp)
         g_fx_mid = _empty(dev, N, 128)
-        L.check(lib.gfv_deslice(w.data_ptr(), g_raw.data_ptr(), batch.data_ptr(), g_fx_mid.data_ptr(), N, 0, st), "deslice")
-        L.check(lib.gfv_slice_gw(sv["fx_mid"].data_ptr(), g_raw.data_ptr(), g_norm.data_ptr(), batch.data_ptr(),
-                                 gw.data_ptr(), N, 1, st), "slice_gw")
         nblk = lib.gfv_slice_softmax_bwd_blocks(N)
         sp = _empty(dev, nblk, 552)
         g_x_mid = _empty(dev, N, 128)
         temp = P[f"{a}.graph_temperature"]
-        L.check(lib.gfv_slice_softmax_bwd(sv["x_mid"].data_ptr(), P[f"{a}.in_project_slice.weight"].data_ptr(),
-                                          P[f"{a}.in_project_slice.bias"].data_ptr(), temp.data_ptr(), w.data_ptr(),
-                                          gw.data_ptr(), g_x_mid.data_ptr(), sp.data_ptr(), N, st), "slice_softmax_bwd")
+        if fused_post:
+            # de-slice of g_raw, both slice_gw products and the slice-softmax adjoint in one pass (gw stays in registers)
+            L.check(lib.gfv_slice_post_bwd(sv["x_mid"].data_ptr(), P[f"{a}.in_project_slice.weight"].data_ptr(),
+                                           P[f"{a}.in_project_slice.bias"].data_ptr(), temp.data_ptr(), w.data_ptr(),
+                                           g_out_x.data_ptr(), sv["out_token"].data_ptr(), sv["fx_mid"].data_ptr(),
+                                           g_raw.data_ptr(), g_norm.data_ptr(), batch.data_ptr(), g_x_mid.data_ptr(),
+                                           g_fx_mid.data_ptr(), sp.data_ptr(), N, st), "slice_post_bwd")
+        else:
+            L.check(lib.gfv_deslice(w.data_ptr(), g_raw.data_ptr(), batch.data_ptr(), g_fx_mid.data_ptr(), N, 0, st), "deslice")
+            L.check(lib.gfv_slice_gw(sv["fx_mid"].data_ptr(), g_raw.data_ptr(), g_norm.data_ptr(), batch.data_ptr(),
+                                     gw.data_ptr(), N, 1, st), "slice_gw")
+            L.check(lib.gfv_slice_softmax_bwd(sv["x_mid"].data_ptr(), P[f"{a}.in_project_slice.weight"].data_ptr(),
+                                              P[f"{a}.in_project_slice.bias"].data_ptr(), temp.data_ptr(), w.data_ptr(),
+                                              gw.data_ptr(), g_x_mid.data_ptr(), sp.data_ptr(), N, st), "slice_softmax_bwd")
         def side_slice():
             ops.reduce_multi([dict(partial=sp.data_ptr() + 4 * o, out=grads.view(nm), n_chunks=nblk, chunk_stride=552, rows=1,
                                    cols=c)

@@ -14,9 +14,25 @@ for p in (ROOT, os.path.join(ROOT, "gen-fvgn-steady_amd"), os.path.join(ROOT, "t
 
 
 def main():
-    dist.init_process_group("gloo")
-    rank, world = dist.get_rank(), dist.get_world_size()
-    torch.cuda.set_device(0)
+    backend = os.environ.get("GFV_TEST_BACKEND", "gloo")
+    rank = int(os.environ["RANK"])
+    # gloo: both ranks share GPU 0 (the collectives go through host memory).  nccl (= RCCL): one GPU per rank when the box has
+    # them; on a one-GPU box both ranks name GPU 0 and RCCL itself decides whether it takes that (it refuses duplicate devices)
+    dev = rank % max(torch.cuda.device_count(), 1) if backend == "nccl" else 0
+    torch.cuda.set_device(dev)
+    try:
+        if backend == "nccl":
+            import datetime
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev), timeout=datetime.timedelta(seconds=90))
+            probe = torch.ones(4, device="cuda")
+            dist.all_reduce(probe)      # communicator creation happens here
+            torch.cuda.synchronize()
+        else:
+            dist.init_process_group("gloo")
+    except Exception as exc:   # noqa: BLE001 - reported to the parent test, which decides
+        print(f"DPUNSUPPORTED rank={rank} devices={torch.cuda.device_count()} {type(exc).__name__}: {str(exc)[:600]}", flush=True)
+        os._exit(0)
+    world = dist.get_world_size()
     import cases
     from oracle import fvgn_oracle as O
     from FVMmodel.importer import NNmodel
@@ -49,8 +65,14 @@ def main():
     mine = torch.cat([ts.P[k].reshape(-1) for k in ts.P] + [model.node_norm.acc_sum.reshape(-1),
                                                           model.node_norm.acc_sum_squared.reshape(-1),
                                                           model.node_norm.acc_count.reshape(-1)]).cpu()
-    gathered = [torch.zeros_like(mine) for _ in range(world)]
-    dist.all_gather(gathered, mine)
+    if backend == "nccl":
+        mine_d = mine.cuda()
+        gathered = [torch.zeros_like(mine_d) for _ in range(world)]
+        dist.all_gather(gathered, mine_d)
+        gathered = [t.cpu() for t in gathered]
+    else:
+        gathered = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine)
     same = all(torch.equal(gathered[0], t) for t in gathered)
     if rank == 0:
         ref_model, ref_ts = make([0, 1], 1)
@@ -63,7 +85,8 @@ def main():
         n = sum(v.numel() for v in ts.P.values())
         perr = float((mine[:n] - ref[:n]).abs().max() / ref[:n].abs().max())
         nerr = float((mine[n:] - ref[n:]).abs().max() / ref[n:].abs().max())
-        print(f"DPRESULT same={int(same)} param_err={perr:.3e} norm_err={nerr:.3e}")
+        print(f"DPRESULT same={int(same)} param_err={perr:.3e} norm_err={nerr:.3e} backend={dist.get_backend()} "
+              f"gpus={torch.cuda.device_count()}")
     dist.destroy_process_group()
 
 

@@ -465,3 +465,54 @@ def test_data_parallel_trainstep_two_ranks():
     assert r.returncode == 0 and m, r.stdout[-1500:] + r.stderr[-1500:]
     assert m.group(1) == "1", "ranks diverged"
     assert float(m.group(2)) < 2e-5 and float(m.group(3)) < 1e-6, m.group(0)
+
+
+def test_command_list_recording_refuses_stray_torch_ops():
+    """A torch op that launches device work during recording without going through cmdlist.call would run once and be
+    missing from every replay: the recording guard (gfv/cmdlist.py) raises instead; views and pool allocations pass."""
+    from gfv import cmdlist
+    x = torch.ones(8, device="cuda")
+    with pytest.raises(RuntimeError, match="dropped on replay"):
+        with cmdlist.record():
+            _ = x + 1
+    assert cmdlist.active() is None
+    with cmdlist.record() as cl:
+        cmdlist.call(x.add_, 1.0)            # recorded with its stream
+        _v = x[2:4]                          # a view: nothing to record
+        _e = torch.empty(16, device="cuda")  # allocation from the recording pool: no kernel
+    assert len(cl) == 1
+    cl.replay()
+    torch.cuda.synchronize()
+    assert float(x[0]) == 3.0
+
+
+def test_cell_to_node_with_cell_grad_uses_the_cells_own_gradient():
+    """Interplot.cell_to_node_2nd_order with `cell_grad`: the correction is the gradient of the incidence's OWN cell
+    (cell_grad[cells_index]); the reference's line FVInterpolation.py:248 indexes the cell array with node ids
+    (cell_grad[cells_node]) - documented as a deliberate deviation in the module docstring; no caller passes cell_grad."""
+    from FVMmodel.FVdiscretization.FVInterpolation import Interplot
+    graphs = cases.make_graphs("cyl_cavity_b2")
+    gn, gc = graphs[0], graphs[3]
+    gen = torch.Generator().manual_seed(11)
+    C = gc.pos.shape[0]
+    cphi = torch.randn(C, 3, generator=gen)
+    cgrad = torch.randn(C, 3, 2, generator=gen)
+    cells_node, cells_index = gn.face, gc.face
+    d = (gn.pos[cells_node] - gc.pos[cells_index]).double()
+    w = 1.0 / d.norm(dim=-1, keepdim=True)
+    corr = (cgrad.double()[cells_index] * d.unsqueeze(1)).sum(-1)
+    num = torch.zeros(gn.pos.shape[0], 3, dtype=torch.float64).index_add_(0, cells_node, (cphi.double()[cells_index] + corr) * w)
+    den = torch.zeros(gn.pos.shape[0], 1, dtype=torch.float64).index_add_(0, cells_node, w)
+    ref = num / den
+    cg = tuple(g.clone().to("cuda") for g in graphs)
+    pd, gd = cphi.cuda().requires_grad_(True), cgrad.cuda().requires_grad_(True)
+    out = Interplot().cell_to_node_2nd_order(cell_phi=pd, cell_grad=gd, cells_node=cg[0].face, cells_index=cg[3].face,
+                                             centroid=cg[3].pos, mesh_pos=cg[0].pos)
+    assert rel(out, ref) < TOL
+    wgt = torch.randn(out.shape, generator=gen)
+    (out * wgt.cuda()).sum().backward()
+    pr, gr = cphi.double().requires_grad_(True), cgrad.double().requires_grad_(True)
+    corr = (gr[cells_index] * d.unsqueeze(1)).sum(-1)
+    ref2 = torch.zeros(gn.pos.shape[0], 3, dtype=torch.float64).index_add(0, cells_node, (pr[cells_index] + corr) * w) / den
+    (ref2 * wgt.double()).sum().backward()
+    assert rel(pd.grad, pr.grad) < 1e-4 and rel(gd.grad, gr.grad) < 1e-4
