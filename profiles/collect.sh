@@ -13,7 +13,7 @@ tag=${1:-r02}
 O=$R/gpurun_out/$tag
 mkdir -p $O
 cd $R
-GFV_PARITY_REPORT=$O/parity_fp64.txt timeout 2400 python3 -m pytest tests -m gpu -q > $O/pytest.log 2>&1
+GFV_RCCL_REPORT=$O/rccl_two_ranks.txt GFV_PARITY_REPORT=$O/parity_fp64.txt timeout 2400 python3 -m pytest tests -m gpu -q > $O/pytest.log 2>&1
 cd /tmp && export TMPDIR=/tmp
 timeout 900 python3 $R/bench.py > $O/bench.json 2> $O/bench.err
 timeout 900 python3 $R/bench.py --meshes-per-gpu 8 --cpu-budget 0 --steps 10 --warmup 4 > $O/bench_b8.json 2> $O/bench_b8.err
