@@ -1,4 +1,4 @@
-// gfv-build-flags: -fno-slp-vectorize
+// gfv-build-flags: -fno-slp-vectorize -ffp-contract=fast
 // Transolver "physics attention" over per-graph slice tokens (gfx950).  Contract: include/gfv.h.
 // Reference: FVMmodel/Models/GraphTransolver/GraphTransolver.py:48-95 (Graph_Physics_Attention_1D.graph_forward).
 //
@@ -554,11 +554,12 @@ struct SlicePostArgs {
   float* gxmid; float* gfxmid; float* partial; int N;
 };
 
-__global__ __launch_bounds__(256, 2) void slice_post_bwd_kernel(const SlicePostArgs A) {
+__global__ __launch_bounds__(256, 3) void slice_post_bwd_kernel(const SlicePostArgs A) {
+  // 53 376 B of LDS: three workgroups per CU (the 796 workgroups of the 25 k-node bench mesh then run in one round, not 1.55)
   __shared__ float sW[G * D];
   __shared__ float sB[G];
-  __shared__ float sDT[256];
   __shared__ __attribute__((aligned(16))) float u[256 * (G + 1) + 256 * (D + 1)];
+  float* sDT = sW;   // the per-row temperature gradients take sW's place once every thread is through with it
   static_assert(2 * H * TS <= 256 * (G + 1) + 256 * (D + 1), "the two slice tensors fit the region of the dWs operands");
   float* sT1 = u;
   float* sT2 = u + H * TS;
@@ -684,6 +685,7 @@ __global__ __launch_bounds__(256, 2) void slice_post_bwd_kernel(const SlicePostA
 #pragma unroll
     for (int c = 0; c < D; ++c) sX[tid * (D + 1) + c] = 0.f;
   }
+  __syncthreads();   // (sW is free)
   sDT[tid] = dT;
   __syncthreads();
   float* out = A.partial + (size_t)blockIdx.x * 552;
