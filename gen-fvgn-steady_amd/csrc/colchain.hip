@@ -92,8 +92,9 @@ int gfv_internal_colchain_try(const gfv_rowtile_args_t* a, hipStream_t stream) {
   if (a->dw_partial) return 0;   // (the caller asked gfv_rowtile_fuses_dw first; anything else is an argument error upstream)
   static const int on = cc_env("GFV_COLCHAIN", 0);
   static const int min_m = cc_env("GFV_COLCHAIN_MIN_M", 16384);
+  static const int max_m = cc_env("GFV_COLCHAIN_MAX_M", 1 << 30);
   if (a->flags & GFV_CHAIN_ROW_OWNER) return 0;
-  if (!(a->flags & GFV_CHAIN_COLUMN_OWNER) && (!on || a->M < min_m)) return 0;
+  if (!(a->flags & GFV_CHAIN_COLUMN_OWNER) && (!on || a->M < min_m || a->M > max_m)) return 0;
   if (a->nlayers != 3 || a->hidden != 128 || !a->wmax) return 0;
   for (int l = 0; l < 3; ++l) {
     const gfv_layer_t& L = a->layer[l];
