@@ -5,6 +5,7 @@
 // Fixed geometry of the reference's block: H = 8 heads, D = 16 dims per head, G = 32 slices (TransFVGN_v2.py:28-35).
 // The reference materialises [N,8,32,16] products twice per forward (28 % of its CPU time); here the per-node
 // work stays in registers and only w [N,8,32] and the per-graph tokens [B,8,32,16] touch memory.
+#include <cstdlib>
 #include "gfv_common.h"
 #include "gfv_prof.h"
 #include "../../include/gfv.h"
@@ -552,6 +553,7 @@ struct SlicePostArgs {
   const float* xmid; const float* Ws; const float* bs; const float* temp; const float* w; const float* gox;
   const float* T1; const float* fxm; const float* T2; const float* gnorm; const int* batch;
   float* gxmid; float* gfxmid; float* partial; int N;
+  int only_straddling;   // 1: take only the workgroups whose 32 nodes span two graphs (the matrix-core form takes the others)
 };
 
 __global__ __launch_bounds__(256, 3) void slice_post_bwd_kernel(const SlicePostArgs A) {
@@ -572,6 +574,7 @@ __global__ __launch_bounds__(256, 3) void slice_post_bwd_kernel(const SlicePostA
   const int n_last = min(n_first + 31, A.N - 1);
   const int b0 = A.batch[n_first];
   const bool uniform = (A.batch[n_last] == b0);
+  if (A.only_straddling && uniform) return;
   if (uniform) {
     const float4* s1 = reinterpret_cast<const float4*>(A.T1 + (size_t)b0 * H * G * D);
     const float4* s2 = reinterpret_cast<const float4*>(A.T2 + (size_t)b0 * H * G * D);
@@ -716,6 +719,175 @@ __global__ __launch_bounds__(256, 3) void slice_post_bwd_kernel(const SlicePostA
   }
 }
 
+// The same pass on the matrix cores (v_mfma_f32_16x16x4_f32: exact fp32 products).  A workgroup takes 32 nodes of ONE graph
+// (workgroups that straddle two graphs are left to slice_post_bwd_kernel), wave w the heads 2w, 2w + 1; per (head, 16-node
+// tile) every product of the pass is a 16-row tile product with the contraction index permuted so that ONE float4 per lane
+// feeds the four k-steps of an operand:
+//   gw  [16 x 32] = fx_mid [16 x 16] T2^T + g_out_x [16 x 16] T1^T + g_norm         lg [16 x 32] = x_mid Ws^T + bs
+//   gl = w (gw - <w, gw>) / T  (accumulator layout: lane (g, q) holds rows 4q .. 4q+3; the row sum is a DPP row reduction)
+//   g_x_mid [16 x 16] = gl Ws   (gl to operand layout through 2 KB of wave-private LDS)      g_fx_mid [16 x 16] = w T2
+//   dWs [32 x 16] += gl^T x_mid (the accumulator registers ARE the operand fragments), dbs, dT lane-private
+// 48 MFMAs per tile against ~5 000 vector instructions per 64 (node, head) rows in the scalar form.
+__global__ __launch_bounds__(256, 2) void slice_post_bwd_mfma_kernel(const SlicePostArgs A) {
+  __shared__ __attribute__((aligned(16))) float sT1[H * TS];
+  __shared__ __attribute__((aligned(16))) float sT2[H * TS];
+  __shared__ __attribute__((aligned(16))) float sWs[G * D];
+  __shared__ float sBs[G];
+  constexpr int TRS = G + 4;                                   // row stride of the transposition tile (16-B aligned rows)
+  __shared__ __attribute__((aligned(16))) float sTr[4][16 * TRS];
+  __shared__ float sRed[4][552];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, q = lane >> 4;
+  const int n_first = blockIdx.x * 32;
+  const int n_last = min(n_first + 31, A.N - 1);
+  const int b0 = A.batch[n_first];
+  if (A.batch[n_last] != b0) return;   // (block-uniform) two graphs: the scalar kernel's workgroup
+  {
+    const float4* s1 = reinterpret_cast<const float4*>(A.T1 + (size_t)b0 * H * G * D);
+    const float4* s2 = reinterpret_cast<const float4*>(A.T2 + (size_t)b0 * H * G * D);
+    for (int i = tid; i < H * G * D / 4; i += 256) {
+      const int h = i / (G * D / 4), r = i % (G * D / 4);
+      *reinterpret_cast<float4*>(&sT1[h * TS + 4 * r]) = s1[i];
+      *reinterpret_cast<float4*>(&sT2[h * TS + 4 * r]) = s2[i];
+    }
+    for (int i = tid; i < G * D; i += 256) sWs[i] = A.Ws[i];
+    if (tid < G) sBs[tid] = A.bs[tid];
+  }
+  __syncthreads();
+  // head-independent operands: Ws as the B operand of lg (slice li of tile t, columns 4q ..) and of g_x_mid (slice 16u+4q+s, column li)
+  float bws[2][4], wsd[2][4], bsv[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const float4 v = *reinterpret_cast<const float4*>(&sWs[(16 * t + li) * D + 4 * q]);
+    bws[t][0] = v.x; bws[t][1] = v.y; bws[t][2] = v.z; bws[t][3] = v.w;
+    bsv[t] = sBs[16 * t + li];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) wsd[t][s] = sWs[(16 * t + 4 * q + s) * D + li];
+  }
+  floatx4 dws[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  float dbs[2] = {0.f, 0.f}, dTw[2] = {0.f, 0.f};
+  float* tr = sTr[wave];
+#pragma unroll 1
+  for (int hh = 0; hh < 2; ++hh) {
+    const int h = 2 * wave + hh;
+    const float invT = 1.0f / A.temp[h];
+    float b1[2][4], b2[2][4], t2d[2][4], gnv[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const float4 u1 = *reinterpret_cast<const float4*>(&sT1[h * TS + (16 * t + li) * D + 4 * q]);
+      const float4 u2 = *reinterpret_cast<const float4*>(&sT2[h * TS + (16 * t + li) * D + 4 * q]);
+      b1[t][0] = u1.x; b1[t][1] = u1.y; b1[t][2] = u1.z; b1[t][3] = u1.w;
+      b2[t][0] = u2.x; b2[t][1] = u2.y; b2[t][2] = u2.z; b2[t][3] = u2.w;
+      gnv[t] = A.gnorm[((size_t)b0 * H + h) * G + 16 * t + li];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) t2d[t][s] = sT2[h * TS + (16 * t + 4 * q + s) * D + li];
+    }
+#pragma unroll 1
+    for (int nt = 0; nt < 2; ++nt) {
+      const int n0 = n_first + 16 * nt;
+      // operand layout: lane (row li, columns 4q ..)
+      const int nodeA = n0 + li;
+      const bool liveA = nodeA < A.N;
+      const size_t rowA = (size_t)(liveA ? nodeA : A.N - 1) * H + h;
+      const float mA = liveA ? 1.0f : 0.0f;
+      float4 vgo = *reinterpret_cast<const float4*>(A.gox + rowA * D + 4 * q);
+      float4 vfx = *reinterpret_cast<const float4*>(A.fxm + rowA * D + 4 * q);
+      float4 vx = *reinterpret_cast<const float4*>(A.xmid + rowA * D + 4 * q);
+      float4 vw0 = *reinterpret_cast<const float4*>(A.w + rowA * G + 4 * q);
+      float4 vw1 = *reinterpret_cast<const float4*>(A.w + rowA * G + 16 + 4 * q);
+      const float ago[4] = {vgo.x * mA, vgo.y * mA, vgo.z * mA, vgo.w * mA};
+      const float afx[4] = {vfx.x * mA, vfx.y * mA, vfx.z * mA, vfx.w * mA};
+      const float ax[4] = {vx.x * mA, vx.y * mA, vx.z * mA, vx.w * mA};
+      const float aw[2][4] = {{vw0.x * mA, vw0.y * mA, vw0.z * mA, vw0.w * mA}, {vw1.x * mA, vw1.y * mA, vw1.z * mA, vw1.w * mA}};
+      // accumulator layout: lane (column li, rows 4q + r)
+      float wd[2][4], xb[4];
+      size_t rowD[4];
+      bool liveD[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int nd = n0 + 4 * q + r;
+        liveD[r] = nd < A.N;
+        rowD[r] = (size_t)(liveD[r] ? nd : A.N - 1) * H + h;
+        const float m = liveD[r] ? 1.0f : 0.0f;
+        wd[0][r] = A.w[rowD[r] * G + li] * m;
+        wd[1][r] = A.w[rowD[r] * G + 16 + li] * m;
+        xb[r] = A.xmid[rowD[r] * D + li] * m;
+      }
+      floatx4 g2[2], g1[2], lg[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        g2[t] = floatx4{gnv[t], gnv[t], gnv[t], gnv[t]};
+        g1[t] = floatx4{0.f, 0.f, 0.f, 0.f};
+        lg[t] = floatx4{bsv[t], bsv[t], bsv[t], bsv[t]};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          g2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(afx[s], b2[t][s], g2[t], 0, 0, 0);
+          g1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ago[s], b1[t][s], g1[t], 0, 0, 0);
+          lg[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[s], bws[t][s], lg[t], 0, 0, 0);
+        }
+      }
+      float gl[2][4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float gw0 = g2[0][r] + g1[0][r], gw1 = g2[1][r] + g1[1][r];
+        const float dot = gfv_row16_sum(wd[0][r] * gw0 + wd[1][r] * gw1);
+        const float gz0 = wd[0][r] * (gw0 - dot), gz1 = wd[1][r] * (gw1 - dot);
+        dTw[hh] -= (gz0 * lg[0][r] + gz1 * lg[1][r]) * invT * invT;
+        gl[0][r] = gz0 * invT;
+        gl[1][r] = gz1 * invT;
+      }
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) dws[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(gl[t][s], xb[s], dws[t], 0, 0, 0);
+        dbs[t] += (gl[t][0] + gl[t][1]) + (gl[t][2] + gl[t][3]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) tr[(4 * q + r) * TRS + 16 * t + li] = gl[t][r];
+      }
+      __builtin_amdgcn_wave_barrier();
+      floatx4 gxa = {0.f, 0.f, 0.f, 0.f}, gfa = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const float4 v = *reinterpret_cast<const float4*>(&tr[li * TRS + 16 * u + 4 * q]);
+        const float agl[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          gxa = __builtin_amdgcn_mfma_f32_16x16x4f32(agl[s], wsd[u][s], gxa, 0, 0, 0);
+          gfa = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[u][s], t2d[u][s], gfa, 0, 0, 0);
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (liveD[r]) {
+          A.gxmid[rowD[r] * D + li] = gxa[r];
+          A.gfxmid[rowD[r] * D + li] = gfa[r];
+        }
+      }
+    }
+  }
+  // this wave's share of the block's partials (dWs [32,16] | dbs [32] | dT [8])
+  float* red = sRed[wave];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[(16 * t + 4 * q + r) * D + li] = dws[t][r];
+    float a, b;
+    gfv_lane_xor16(dbs[t], a, b);
+    const float v = a + b;
+    gfv_lane_xor32(v, a, b);
+    if (q == 0) red[512 + 16 * t + li] = a + b;
+  }
+#pragma unroll
+  for (int hh = 0; hh < 2; ++hh) {
+    const float v = gfv_wave_sum(dTw[hh]);
+    if (lane == 0) red[544 + hh] = v;
+  }
+  __syncthreads();
+  float* out = A.partial + (size_t)blockIdx.x * 552;
+  for (int i = tid; i < 544; i += 256) out[i] = (sRed[0][i] + sRed[1][i]) + (sRed[2][i] + sRed[3][i]);
+  if (tid < H) out[544 + tid] = sRed[tid >> 1][544 + (tid & 1)];
+}
+
 }  // namespace
 
 extern "C" int gfv_slice_softmax_fwd(const float* xmid, const float* Ws, const float* bs, const float* temp, float* w,
@@ -799,12 +971,23 @@ extern "C" int gfv_slice_gw(const float* a, const float* T, const float* add, co
 extern "C" int gfv_slice_post_bwd(const float* xmid, const float* Ws, const float* bs, const float* temp, const float* w,
                                   const float* g_out_x, const float* out_token, const float* fx_mid, const float* g_raw,
                                   const float* g_norm, const int32_t* batch, float* g_x_mid, float* g_fx_mid, float* partial,
-                                  int32_t N, void* stream) {
+                                  int32_t N, int32_t n_graphs, void* stream) {
   // x_mid, g_out_x, fx_mid [N,128] + w [N,8,32] in, g_x_mid + g_fx_mid out
   GfvProfScope ps_(GFV_K_SLICE, 0, (3 * 512.0 + 1024.0 + 2 * 512.0) * N, stream);
   if (N <= 0) return N == 0 ? GFV_OK : GFV_ERR_ARG;
-  SlicePostArgs a{xmid, Ws, bs, temp, w, g_out_x, out_token, fx_mid, g_raw, g_norm, batch, g_x_mid, g_fx_mid, partial, N};
-  hipLaunchKernelGGL(slice_post_bwd_kernel, dim3(gfv_div_up((long)N * H, 256)), dim3(256), 0, (hipStream_t)stream, a);
+  SlicePostArgs a{xmid, Ws, bs, temp, w, g_out_x, out_token, fx_mid, g_raw, g_norm, batch, g_x_mid, g_fx_mid, partial, N, 0};
+  static const int mfma = [] { const char* e = getenv("GFV_SLICE_MFMA"); return e ? atoi(e) : 1; }();
+  const dim3 grid(gfv_div_up((long)N * H, 256));
+  if (mfma) {
+    // workgroups of one graph on the matrix cores; the ones that straddle two graphs (none in a one-graph batch) by the scalar form
+    hipLaunchKernelGGL(slice_post_bwd_mfma_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+    if (n_graphs != 1) {
+      a.only_straddling = 1;
+      hipLaunchKernelGGL(slice_post_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+    }
+  } else {
+    hipLaunchKernelGGL(slice_post_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+  }
   GFV_CHECK_LAUNCH();
   return GFV_OK;
 }

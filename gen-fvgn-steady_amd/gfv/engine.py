@@ -898,7 +898,7 @@ class Engine:
                                            P[f"{a}.in_project_slice.bias"].data_ptr(), temp.data_ptr(), w.data_ptr(),
                                            g_out_x.data_ptr(), sv["out_token"].data_ptr(), sv["fx_mid"].data_ptr(),
                                            g_raw.data_ptr(), g_norm.data_ptr(), batch.data_ptr(), g_x_mid.data_ptr(),
-                                           g_fx_mid.data_ptr(), sp.data_ptr(), N, st), "slice_post_bwd")
+                                           g_fx_mid.data_ptr(), sp.data_ptr(), N, B, st), "slice_post_bwd")
         else:
             L.check(lib.gfv_deslice(w.data_ptr(), g_raw.data_ptr(), batch.data_ptr(), g_fx_mid.data_ptr(), N, 0, st), "deslice")
             L.check(lib.gfv_slice_gw(sv["fx_mid"].data_ptr(), g_raw.data_ptr(), g_norm.data_ptr(), batch.data_ptr(),

@@ -359,11 +359,13 @@ int gfv_slice_gw(const float* a, const float* T, const float* add, const int32_t
 /* Everything behind the attention adjoint of a Transolver block in one pass over the nodes (GraphTransolver.py:64-92,
  * backward): gw = gfv_slice_gw(g_out_x, out_token) + gfv_slice_gw(fx_mid, g_raw, g_norm) stays in registers, g_fx_mid =
  * gfv_deslice(w, g_raw), (g_x_mid, partial) = gfv_slice_softmax_bwd(.., gw) - the same terms in the same order as those
- * four launches (bit-identical results).  partial: gfv_slice_softmax_bwd_blocks(N) x 552 floats. */
+ * four launches (equal to rounding).  partial: gfv_slice_softmax_bwd_blocks(N) x 552 floats.  n_graphs: graphs in the batch
+ * (1: every workgroup of 32 nodes lies in one graph and runs on the matrix cores, v_mfma_f32_16x16x4_f32 - exact fp32
+ * products; otherwise the workgroups that straddle two graphs are taken by a second, scalar launch). */
 int gfv_slice_post_bwd(const float* xmid, const float* Ws, const float* bs, const float* temp, const float* w,
                        const float* g_out_x, const float* out_token, const float* fx_mid, const float* g_raw,
                        const float* g_norm, const int32_t* batch, float* g_x_mid, float* g_fx_mid, float* partial,
-                       int32_t N, void* stream);
+                       int32_t N, int32_t n_graphs, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Finite-volume discretisation (conserved form).  Replaces FVMmodel/FVdiscretization/FVscheme.py:618-724,50-274,

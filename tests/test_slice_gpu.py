@@ -40,7 +40,7 @@ def test_one_pass_slice_adjoint_equals_the_four_launches(N, sizes):
     gx1, gfx1 = torch.full((N, 128), float("nan"), device="cuda"), torch.full((N, 128), float("nan"), device="cuda")
     sp1 = torch.full((nblk, 552), float("nan"), device="cuda")
     L.check(lib.gfv_slice_post_bwd(p(c["xmid"]), p(c["Ws"]), p(c["bs"]), p(c["temp"]), p(c["w"]), p(c["gox"]), p(c["T1"]),
-                                   p(c["fxm"]), p(c["T2"]), p(c["gn"]), p(c["batch"]), p(gx1), p(gfx1), p(sp1), N, st), "post_bwd")
+                                   p(c["fxm"]), p(c["T2"]), p(c["gn"]), p(c["batch"]), p(gx1), p(gfx1), p(sp1), N, len(sizes), st), "post_bwd")
     torch.cuda.synchronize()
     # the same terms in the same order; the compiler contracts a * b + c into fused multiply-adds where it sees them (slice.hip
     # is built with -ffp-contract=fast), not necessarily at the same places in both forms: equal to rounding, not to the bit
