@@ -140,6 +140,8 @@ class Engine:
         self.fuse_dw = os.environ.get("GFV_FUSE_DW", "1") != "0"
         self._slice_fuse = os.environ.get("GFV_SLICE_FUSE", "1") != "0"   # Transolver adjoint: one pass behind the attention
         self._tail_main = int(os.environ.get("GFV_TAIL_MAIN", "2"))
+        self._split_all = int(os.environ.get("GFV_SPLIT_ALL", "0"))     # (experiment) the same split for every GnBlock's flush
+        self._tail_split = int(os.environ.get("GFV_TAIL_SPLIT", "1"))   # last GnBlock's flush: 1 / 2 = its first / its other pieces on main
         self._enc_order = int(os.environ.get("GFV_ENC_ORDER", "1"))
         self._fuse_noout = os.environ.get("GFV_FUSE_NOOUT", "1") != "0"   # ... also where the input needs no gradient (encoders)
         self._fuse_dw_min = int(os.environ.get("GFV_COLCHAIN_BWD_MIN_M", "16384"))
@@ -219,12 +221,21 @@ class Engine:
             with self.fork(*keep):
                 fn()
 
-    def flush(self, on_main=False):
+    def flush(self, on_main=False, split=0):
         """Launch the queued work on the side stream (one fork), or - `on_main` - on the main stream: the last pieces of
         the backward have nothing left to hide behind, both queues then drain together."""
         if not self._pending:
             return
         pend, self._pending = self._pending, []
+        if split and len(pend) > 1:
+            # part of the queue on each stream (the end of the backward: both queues should drain together)
+            k = 1 if split == 1 else len(pend) - 1
+            main_part, side_part = (pend[:k], pend[k:]) if split == 1 else (pend[k:], pend[:k])
+            self._pending = side_part
+            self.flush()
+            self._pending = main_part
+            self.flush(on_main=True)
+            return
         if on_main:
             ws, self._dw_ws = self._dw_ws, self._dw_ws_main   # the side stream may still be using its workspace
             try:
@@ -755,7 +766,8 @@ class Engine:
             g_nb = ops.seg_gather_sum(gnb2.view(2 * E, 128), pl.n_rowptr, pl.n_col_edge2, N)
         ops.seg_gather_sum(g_nb, pl.n_rowptr, pl.n_col_node, N, out=g_x_in, accumulate=True)
         # the block's weight gradients: one fork (the last block's may go to the main stream: GFV_TAIL_MAIN >= 3)
-        self.flush(on_main=self._defer_mode and self._tail_main >= 3 and getattr(self, "_last_gn", False))
+        last = self._defer_mode and getattr(self, "_last_gn", False)
+        self.flush(on_main=last and self._tail_main >= 3, split=self._tail_split if last else (self._split_all if self._defer_mode else 0))
         return g_x_in, g_e_in
 
     # ------------------------------------------------------------------------------------------------------------
