@@ -1153,10 +1153,6 @@ __global__ __launch_bounds__(64 * CC_W, WPS) void colchain_fwd2_kernel(const gfv
       const int row = c.row0 + 16 * q + c.j;
       offL[q] = cb_off(c, c.row0, q);
       offS[q] = (q < c.ngt && row < c.M) ? row * 512 + c.col0 * 4 : CB_OFF_DEAD;
-#ifdef GFV_CF_LINEAR_HACK   // experiment only (wrong results): the same bytes stored as whole 512-byte rows, two per instruction
-      const int lrow = c.row0 + 16 * q + 2 * c.w + (c.lane >> 5);
-      offS[q] = (q < c.ngt && lrow < c.M) ? lrow * 512 + (c.lane & 31) * 16 : CB_OFF_DEAD;
-#endif
     }
     // ---- P0: this wave's share of the row maxima; the addend rows and layer 0's slice go out ----
 #pragma unroll

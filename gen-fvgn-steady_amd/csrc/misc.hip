@@ -29,7 +29,20 @@ __global__ __launch_bounds__(1024) void graph_norm_stats_kernel(const float* __r
   float mean[3];
   {
     float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-    for (int i = beg + tid; i < end; i += 1024) {
+    // four rows in flight per thread (the loop was one memory round trip per row: 25 dependent trips per pass at 25 k nodes,
+    // 23 us at the very start of the step), added in row order
+    int i = beg + tid;
+    for (; i + 3 * 1024 < end; i += 4 * 1024) {
+      float v[4][3];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float* r = x + (size_t)(i + 1024 * u) * ldx;
+        v[u][0] = r[0]; v[u][1] = r[1]; v[u][2] = r[2];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { s0 += v[u][0]; s1 += v[u][1]; s2 += v[u][2]; }
+    }
+    for (; i < end; i += 1024) {
       const float* r = x + (size_t)i * ldx;
       s0 += r[0]; s1 += r[1]; s2 += r[2];
     }
@@ -38,7 +51,21 @@ __global__ __launch_bounds__(1024) void graph_norm_stats_kernel(const float* __r
     mean[2] = block_sum(s2, red) / cnt;
   }
   float q0 = 0.f, q1 = 0.f, q2 = 0.f;
-  for (int i = beg + tid; i < end; i += 1024) {
+  int i = beg + tid;
+  for (; i + 3 * 1024 < end; i += 4 * 1024) {
+    float v[4][3];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float* r = x + (size_t)(i + 1024 * u) * ldx;
+      v[u][0] = r[0]; v[u][1] = r[1]; v[u][2] = r[2];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float d0 = v[u][0] - mean[0], d1 = v[u][1] - mean[1], d2 = v[u][2] - mean[2];
+      q0 += d0 * d0; q1 += d1 * d1; q2 += d2 * d2;
+    }
+  }
+  for (; i < end; i += 1024) {
     const float* r = x + (size_t)i * ldx;
     const float d0 = r[0] - mean[0], d1 = r[1] - mean[1], d2 = r[2] - mean[2];
     q0 += d0 * d0; q1 += d1 * d1; q2 += d2 * d2;

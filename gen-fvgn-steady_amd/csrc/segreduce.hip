@@ -223,10 +223,13 @@ __global__ __launch_bounds__(256) void reduce_partials_2d_kernel(const float* __
 // segmented form: out[b, :] = sum of the chunk rows seg_ptr[b] .. seg_ptr[b+1]-1 (blockIdx.y = b); same thread layout
 // and summation order as reduce_partials_vec_kernel.  Used to pre-reduce the per-chunk slice tokens of every graph, so
 // that the (graph, head) attention blocks - only 8 per graph - do not walk hundreds of chunk partials serially.
-__global__ __launch_bounds__(256) void reduce_partials_seg_kernel(const float* __restrict__ partial,
-                                                                  const int* __restrict__ seg_ptr, int n4,
-                                                                  float* __restrict__ out) {
-  __shared__ float4 red[4][64];
+// (1 024 threads: 16 chunk groups per column.  With the 4 groups of the first version a graph of 398 chunks was 100
+// dependent round trips per thread on 17 workgroups - 12 us for 7 MB, four times per step.)
+__global__ __launch_bounds__(1024) void reduce_partials_seg_kernel(const float* __restrict__ partial,
+                                                                   const int* __restrict__ seg_ptr, int n4,
+                                                                   float* __restrict__ out) {
+  constexpr int CG = 16;
+  __shared__ float4 red[CG][64];
   const int q = threadIdx.x & 63, cg = threadIdx.x >> 6, b = blockIdx.y;
   const int j = blockIdx.x * 64 + q;
   const int c0 = seg_ptr[b], c1 = seg_ptr[b + 1];
@@ -236,14 +239,14 @@ __global__ __launch_bounds__(256) void reduce_partials_seg_kernel(const float* _
   if (j < n4) {
     const float4* p = reinterpret_cast<const float4*>(partial) + j;
     int c = c0 + cg;
-    for (; c + 12 < c1; c += 16) {
+    for (; c + 3 * CG < c1; c += 4 * CG) {
       float4 v[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) v[u] = p[(size_t)(c + 4 * u) * n4];
+      for (int u = 0; u < 4; ++u) v[u] = p[(size_t)(c + CG * u) * n4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) { s[u].x += v[u].x; s[u].y += v[u].y; s[u].z += v[u].z; s[u].w += v[u].w; }
     }
-    for (; c < c1; c += 4) {
+    for (; c < c1; c += CG) {
       const float4 v = p[(size_t)c * n4];
       s[0].x += v.x; s[0].y += v.y; s[0].z += v.z; s[0].w += v.w;
     }
@@ -252,9 +255,15 @@ __global__ __launch_bounds__(256) void reduce_partials_seg_kernel(const float* _
                            (s[0].z + s[1].z) + (s[2].z + s[3].z), (s[0].w + s[1].w) + (s[2].w + s[3].w));
   __syncthreads();
   if (cg == 0 && j < n4) {
-    const float4 a = red[0][q], bb = red[1][q], c = red[2][q], d = red[3][q];
+    float4 t[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {   // fixed order: ((0+1)+(2+3)) per group of four, then the four groups pairwise
+      const float4 a = red[4 * u][q], bb = red[4 * u + 1][q], c = red[4 * u + 2][q], d = red[4 * u + 3][q];
+      t[u] = make_float4((a.x + bb.x) + (c.x + d.x), (a.y + bb.y) + (c.y + d.y), (a.z + bb.z) + (c.z + d.z), (a.w + bb.w) + (c.w + d.w));
+    }
     reinterpret_cast<float4*>(out)[(size_t)b * n4 + j] =
-        make_float4((a.x + bb.x) + (c.x + d.x), (a.y + bb.y) + (c.y + d.y), (a.z + bb.z) + (c.z + d.z), (a.w + bb.w) + (c.w + d.w));
+        make_float4((t[0].x + t[1].x) + (t[2].x + t[3].x), (t[0].y + t[1].y) + (t[2].y + t[3].y),
+                    (t[0].z + t[1].z) + (t[2].z + t[3].z), (t[0].w + t[1].w) + (t[2].w + t[3].w));
   }
 }
 
@@ -492,7 +501,7 @@ extern "C" int gfv_reduce_partials_seg(const float* partial, const int32_t* seg_
   GfvProfScope ps_(GFV_K_REDUCE, 0, 4.0 * 64.0 * n_seg * n, stream);
   if (n_seg <= 0 || n <= 0) return GFV_OK;
   if ((n & 3) || ((reinterpret_cast<size_t>(partial) | reinterpret_cast<size_t>(out)) & 15)) return GFV_ERR_ARG;
-  hipLaunchKernelGGL(reduce_partials_seg_kernel, dim3((n / 4 + 63) / 64, n_seg), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(reduce_partials_seg_kernel, dim3((n / 4 + 63) / 64, n_seg), dim3(1024), 0, (hipStream_t)stream,
                      partial, seg_ptr, n / 4, out);
   GFV_CHECK_LAUNCH();
   return GFV_OK;
