@@ -1,0 +1,241 @@
+// gfv-build-flags: -fno-slp-vectorize
+// Lean single-layer launches of gfv_rowtile_chain in the split-fp16 form (round 3).
+//
+// Sixteen launches of a training step are ONE Linear over the N node rows with a light prologue / epilogue - the EdgeBlock's
+// node-level projection (blocks.py:54 factored through the nodes) and five of the eight launches of a Transolver block
+// (GraphTransolver.py:51-62,93-95,163-169: in_project_fx | in_project_x, to_out, linear_post and the adjoints of to_out and
+// of the two input projections).  In the general chain kernel (tchain_kernel.h) such a launch costs one tile life of the
+// three-layer machinery - 15 - 26 us for 13 - 26 MB: the weight image streams through LDS in four barrier-separated slices
+// per layer, every workgroup of 64 rows pulls the whole 64 KB image for 32 KB of activations.  Here a workgroup takes 128
+// rows (8 waves x 16), stages the layer's image in LDS ONCE (64 KB, or 128 KB for a 256-wide input or output) while its
+// waves load and split their rows, and runs the products - the same three f16 MFMAs per fragment pair on the same (hi, lo)
+// operands as the chain (gfv_split.h, wimg.hip's fragment order), so the results carry the chain's accuracy.
+//   out_p[m, :] = sum_s op_in(seg_s[m, :] (+ in_add[m, :])) W_p,s^T + bias_p (+ res_p[m, :]),   p < N / 128, s < K / 128
+// Covered: 128-wide segments without gather, in_op none / GELU, in_add + in_save on a one-segment input, bias / bias2,
+// residual addends, 128 or 256 outputs (256 inputs with 128 outputs).  Anything else stays with the chain kernel.
+#include <cstdlib>
+
+#include "../../include/gfv.h"
+#include "gfv_common.h"
+#include "gfv_split.h"
+
+int* gfv_internal_status_ptr();
+
+namespace {
+
+__device__ __forceinline__ float l1_max3_abs(float m, float a, float b) {
+  float r;
+  asm("v_max3_f32 %0, %1, |%2|, |%3|" : "=v"(r) : "v"(m), "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float l1_row_max4(float v) {   // over the 4 lanes (g = 0..3) that share a row
+  float a, b;
+  gfv_lane_xor16(v, a, b);
+  v = fmaxf(a, b);
+  gfv_lane_xor32(v, a, b);
+  return fmaxf(a, b);
+}
+
+struct Lin1Args {
+  const float* seg[2];
+  int seg_ld[2];
+  const float* in_add;
+  float* in_save;
+  const void* img;       // [pass][T][nt][hi 64 lanes | lo 64 lanes] x 16 B (gfv_weight_images)
+  const float* wmax;
+  const float* bias[2];
+  const float* res[2];
+  int res_ld[2];
+  float* out[2];
+  int out_ld[2];
+  int M;
+};
+
+// KS: 32-wide k-steps (4: one 128-wide segment, 8: two); NP: 128-row passes of the image = 128-wide output chunks
+template <int KS, int NP, bool GELU_IN, bool LOWP>
+__global__ __launch_bounds__(512, 2) void lin1_kernel(const Lin1Args A, int* status) {
+  extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+  gfv_uint4* img = reinterpret_cast<gfv_uint4*>(lds_raw);
+  constexpr int FRAGS = NP * KS * 8 * 128;   // 16-byte units of the image
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, g = lane >> 4;
+  // ---- the image goes to LDS (the loads are issued first, the row loads follow: both are in flight together) ----
+  {
+    const gfv_uint4* src = reinterpret_cast<const gfv_uint4*>(A.img);
+    constexpr int PER = FRAGS / 512;   // 8 (64 KB) or 16 (128 KB): all of a thread's loads go out before the first LDS write
+    gfv_uint4 t[PER];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) t[u] = src[(size_t)u * 512 + tid];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) img[u * 512 + tid] = t[u];
+  }
+  // ---- this wave's 16 rows: lane (row li, column group g) holds columns 32 T + 4 g + (0..3) and 32 T + 16 + 4 g + (0..3) ----
+  const int m = blockIdx.x * 128 + 16 * wave + li;
+  const bool live = m < A.M;
+  const size_t mr = (size_t)(live ? m : A.M - 1);
+  float v[KS][8];
+#pragma unroll
+  for (int T = 0; T < KS; ++T) {
+    const int s = T >> 2, c = 32 * (T & 3) + 4 * g;
+    const float* rp = A.seg[s] + mr * A.seg_ld[s] + c;
+    const float4 a = *reinterpret_cast<const float4*>(rp), b = *reinterpret_cast<const float4*>(rp + 16);
+    v[T][0] = a.x; v[T][1] = a.y; v[T][2] = a.z; v[T][3] = a.w;
+    v[T][4] = b.x; v[T][5] = b.y; v[T][6] = b.z; v[T][7] = b.w;
+  }
+  if (A.in_add) {   // (one-segment inputs only)
+#pragma unroll
+    for (int T = 0; T < (KS < 4 ? KS : 4); ++T) {
+      const float* rp = A.in_add + mr * A.seg_ld[0] + 32 * T + 4 * g;
+      const float4 a = *reinterpret_cast<const float4*>(rp), b = *reinterpret_cast<const float4*>(rp + 16);
+      v[T][0] += a.x; v[T][1] += a.y; v[T][2] += a.z; v[T][3] += a.w;
+      v[T][4] += b.x; v[T][5] += b.y; v[T][6] += b.z; v[T][7] += b.w;
+    }
+  }
+  if (A.in_save && live) {
+#pragma unroll
+    for (int T = 0; T < (KS < 4 ? KS : 4); ++T) {
+      float* sp = A.in_save + mr * 128 + 32 * T + 4 * g;
+      *reinterpret_cast<float4*>(sp) = make_float4(v[T][0], v[T][1], v[T][2], v[T][3]);
+      *reinterpret_cast<float4*>(sp + 16) = make_float4(v[T][4], v[T][5], v[T][6], v[T][7]);
+    }
+  }
+  if (GELU_IN) {
+#pragma unroll
+    for (int T = 0; T < KS; ++T)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[T][e] = gfv_gelu(v[T][e]);
+  }
+  // power-of-two scale of the row, operand split (the chain's row_scale / to_halves)
+  float m0 = 0.f, m1 = 0.f;
+#pragma unroll
+  for (int T = 0; T < KS; ++T) {
+    m0 = l1_max3_abs(m0, v[T][0], v[T][1]);
+    m1 = l1_max3_abs(m1, v[T][2], v[T][3]);
+    m0 = l1_max3_abs(m0, v[T][4], v[T][5]);
+    m1 = l1_max3_abs(m1, v[T][6], v[T][7]);
+  }
+  const float sx = gfv_pow2_scale(l1_row_max4(fmaxf(m0, m1)));
+  gfv_f16x8 xh[KS], xl[KS];
+#pragma unroll
+  for (int T = 0; T < KS; ++T) {
+    float e[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) e[i] = v[T][i] * sx;
+    gfv_uint4 hi, lo;
+    gfv_split8(e, hi, lo);
+    xh[T] = __builtin_bit_cast(gfv_f16x8, hi);
+    xl[T] = __builtin_bit_cast(gfv_f16x8, lo);
+  }
+  const float inv = (1.0f / sx), invw = 1.0f / gfv_pow2_scale(*A.wmax);
+  __syncthreads();   // the image is in LDS
+  // ---- products: D[n = 16 nt + 4 g + r][row li] ----
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    float* outp = A.out[p];
+    const float* resp = A.res[p];
+    const float* bp = A.bias[p];
+#pragma unroll 2
+    for (int nt = 0; nt < 8; ++nt) {
+      floatx4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int T = 0; T < KS; ++T) {
+        const gfv_uint4* f = img + ((p * KS + T) * 8 + nt) * 128 + lane;
+        const gfv_f16x8 wh = __builtin_bit_cast(gfv_f16x8, f[0]);
+        if (!LOWP) {
+          const gfv_f16x8 wl = __builtin_bit_cast(gfv_f16x8, f[64]);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh[T], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl[T], acc, 0, 0, 0);
+        }
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh[T], acc, 0, 0, 0);
+      }
+      const int col = 16 * nt + 4 * g;
+      float4 o = make_float4((acc[0] * inv) * invw, (acc[1] * inv) * invw, (acc[2] * inv) * invw, (acc[3] * inv) * invw);
+      if (bp) {
+        const float4 b = *reinterpret_cast<const float4*>(bp + col);
+        o.x += b.x; o.y += b.y; o.z += b.z; o.w += b.w;
+      }
+      if (resp) {
+        const float4 r = *reinterpret_cast<const float4*>(resp + mr * A.res_ld[p] + col);
+        o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+      }
+      if (live) *reinterpret_cast<float4*>(outp + mr * A.out_ld[p] + col) = o;
+    }
+  }
+  (void)status;
+}
+
+inline bool al16(const void* p) { return (reinterpret_cast<size_t>(p) & 15) == 0; }
+int l1_env(const char* n, int dflt) {
+  const char* e = getenv(n);
+  return e ? atoi(e) : dflt;
+}
+
+}  // namespace
+
+// 1: launched; 0: not a launch of this family.  lowp: the reduced-precision product form (one product per term).
+int gfv_internal_lin1_try(const gfv_rowtile_args_t* a, int lowp, hipStream_t stream) {
+  static const int on = l1_env("GFV_LIN1", 1);
+  static const int min_m = l1_env("GFV_LIN1_MIN_M", 1024);
+  if (!on || a->nlayers != 1 || a->M < min_m || (a->flags & (GFV_CHAIN_ROW_OWNER | GFV_CHAIN_COLUMN_OWNER))) return 0;
+  const gfv_layer_t& L = a->layer[0];
+  if (!L.Wh || !a->wmax || L.op != GFV_OP_NONE || L.save || L.aux) return 0;
+  if (a->in_op != GFV_IN_NONE && a->in_op != GFV_IN_GELU) return 0;
+  if (a->fin_op != GFV_FIN_PLAIN || a->fin_presave || a->fin_stats || a->in_stats || a->dw_partial || a->ln_partial || a->gadd || a->padd ||
+      a->in_aux || a->out_nores || a->gscale)
+    return 0;
+  if (a->nseg < 1 || a->nseg > 2 || L.K != 128 * a->nseg || (L.N != 128 && L.N != 256) || (a->nseg == 2 && L.N != 128)) return 0;
+  for (int i = 0; i < a->nseg; ++i) {
+    const gfv_seg_t& s = a->seg[i];
+    if (s.width != 128 || s.idx || s.csr_rowptr || s.csr_scale || s.save || (s.ld & 3) || !al16(s.ptr)) return 0;
+  }
+  if (a->in_add && (a->nseg != 1 || !al16(a->in_add))) return 0;
+  if (a->in_save && (a->nseg != 1 || !al16(a->in_save))) return 0;
+  const int np = L.N / 128;
+  for (int p = 0; p < 3; ++p) {
+    if (p < np) {
+      if (!a->out[p] || (a->out_ld[p] & 3) || !al16(a->out[p])) return 0;
+      if (a->res[p] && ((a->res_ld[p] & 3) || !al16(a->res[p]))) return 0;
+    } else if (a->out[p] || a->res[p]) {
+      return 0;
+    }
+  }
+  if (L.bias && !al16(L.bias)) return 0;
+  if (L.bias2 && !al16(L.bias2)) return 0;
+  Lin1Args A{};
+  for (int i = 0; i < a->nseg; ++i) { A.seg[i] = a->seg[i].ptr; A.seg_ld[i] = a->seg[i].ld; }
+  A.in_add = a->in_add;
+  A.in_save = a->in_save;
+  A.img = L.Wh;
+  A.wmax = a->wmax;
+  A.bias[0] = L.bias;
+  A.bias[1] = np > 1 ? (L.bias2 ? L.bias2 : (L.bias ? L.bias + 128 : nullptr)) : nullptr;
+  for (int p = 0; p < np; ++p) { A.res[p] = a->res[p]; A.res_ld[p] = a->res_ld[p]; A.out[p] = a->out[p]; A.out_ld[p] = a->out_ld[p]; }
+  A.M = a->M;
+  int* st = gfv_internal_status_ptr();
+  const dim3 grid((a->M + 127) / 128), blk(512);
+  const bool gelu = a->in_op == GFV_IN_GELU;
+#define L1_ATTR(KS, NP, G, LP)                                                                                                  \
+  do {                                                                                                                          \
+    static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(&lin1_kernel<KS, NP, G, LP>),             \
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (NP) * (KS) * 16384);       \
+    if (once != hipSuccess) return 0;                                                                                           \
+  } while (0)
+#define L1_LAUNCH(KS, NP)                                                                                                       \
+  do {                                                                                                                          \
+    const size_t lds = (size_t)(NP) * (KS) * 16384;                                                                             \
+    if (lowp) { if (gelu) L1_ATTR(KS, NP, true, true); else L1_ATTR(KS, NP, false, true); }                                     \
+    else { if (gelu) L1_ATTR(KS, NP, true, false); else L1_ATTR(KS, NP, false, false); }                                        \
+    if (lowp) {                                                                                                                 \
+      if (gelu) hipLaunchKernelGGL((lin1_kernel<KS, NP, true, true>), grid, blk, lds, stream, A, st);                           \
+      else hipLaunchKernelGGL((lin1_kernel<KS, NP, false, true>), grid, blk, lds, stream, A, st);                               \
+    } else {                                                                                                                    \
+      if (gelu) hipLaunchKernelGGL((lin1_kernel<KS, NP, true, false>), grid, blk, lds, stream, A, st);                          \
+      else hipLaunchKernelGGL((lin1_kernel<KS, NP, false, false>), grid, blk, lds, stream, A, st);                              \
+    }                                                                                                                           \
+  } while (0)
+  if (a->nseg == 2) L1_LAUNCH(8, 1);
+  else if (np == 2) L1_LAUNCH(4, 2);
+  else L1_LAUNCH(4, 1);
+#undef L1_LAUNCH
+#undef L1_ATTR
+  return 1;
+}

@@ -530,6 +530,7 @@ extern "C" int gfv_rowtile_chain(const gfv_rowtile_args_t* args, void* stream) {
   g_hidden = h0;
   return rc;
 }
+int gfv_internal_lin1_try(const gfv_rowtile_args_t* a, int lowp, hipStream_t stream);   // lin1.hip
 static int rowtile_chain_impl(const gfv_rowtile_args_t* args, void* stream) {
   if (!args || args->M < 0 || args->nlayers < 1 || args->nlayers > 3 || args->nseg < 1 || args->nseg > 3) return GFV_ERR_ARG;
   if (args->M == 0) return GFV_OK;
@@ -637,7 +638,9 @@ static int rowtile_chain_impl(const gfv_rowtile_args_t* args, void* stream) {
   }
   g_last_path = (tchain_mode() != 0 && (fast_t || rag_t)) ? ((fast_t ? 1 : 2) + (f16 ? 4 : 0)) : 0;
   if (args->dw_partial && !(fast_t && tchain_mode() != 0 && f16)) return GFV_ERR_ARG;   // (fused weight gradients: ask gfv_rowtile_fuses_dw first)
-  if (fast_t && tchain_mode() != 0) {
+  if (fast_t && f16 && args->nlayers == 1 && gfv_internal_lin1_try(args, f16_mode() == 2 ? 1 : 0, (hipStream_t)stream)) {
+    g_last_path += 32;   // the lean single-layer kernel (lin1.hip)
+  } else if (fast_t && tchain_mode() != 0) {
     const int took = gfv_internal_tchain_launch(args, 0, f16 ? 1 : 0, (hipStream_t)stream);   // 1: the column-owner family, 2: with fused dW
     if (args->dw_partial && took != 2) return GFV_ERR_ARG;
     g_last_path += 8 * took;

@@ -1,0 +1,109 @@
+"""The lean single-layer kernel (csrc/lin1.hip: one Linear over the node rows, image staged in LDS once per 128-row workgroup)
+against the chain kernel it stands in for (pinned with family=CHAIN_ROW_OWNER) and against float64: plain Linear + bias +
+residual, two row-stacked Linears of one input with in_add / in_save (in_project_fx | in_project_x, the EdgeBlock's node
+projection), two column-stacked Linears of two inputs (their adjoint), a 256-wide input behind a GELU (linear_post)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def _wi(ws):
+    from gfv import ops
+    wmax = torch.stack([w.abs().max() for w in ws]).max().reshape(1).cuda()
+    wi = ops.WeightImages(torch.device("cuda"), wmax)
+    wi.static = [(0, 1 << 62)]
+    return wi
+
+
+def _both(M, segs, layer, outs, wi, per_run=None, **kw):
+    """Run the launch on the lean kernel (outs[0]) and on the chain kernel (outs[1]); returns the last-path codes.
+    per_run: {keyword: [value for the lean run, value for the chain run]}."""
+    from gfv import lib as L, ops
+    paths = []
+    for i, fam in enumerate((0, L.CHAIN_ROW_OWNER)):
+        extra = {k: v[i] for k, v in (per_run or {}).items()}
+        ops.rowtile_chain(M, segs, [layer], outs[i], wimg=wi, family=fam, **kw, **extra)
+        paths.append(L.load().gfv_rowtile_last_path())
+    torch.cuda.synchronize()
+    return paths
+
+
+@pytest.mark.parametrize("M", [5000, 1025, 2048])
+def test_lean_single_layer_kernel_against_the_chain_kernel_and_float64(M):
+    from gfv import ops
+    g = torch.Generator().manual_seed(M)
+    d = lambda t: t.cuda().contiguous()
+    x = torch.randn(M, 128, generator=g) * torch.logspace(-3, 1, M)[:, None]      # rows over four decades
+    e = torch.randn(M, 128, generator=g)
+    r = torch.randn(M, 128, generator=g)
+    W = torch.randn(128, 384, generator=g) * 0.1
+    Wp = torch.randn(128, 256, generator=g) * 0.1
+    b1, b2 = torch.randn(128, generator=g), torch.randn(128, generator=g)
+    Wd, Wpd, b1d, b2d, xd, ed, rd = d(W), d(Wp), d(b1), d(b2), d(x), d(e), d(r)
+    wi = _wi([W, Wp])
+    new = lambda *s: [torch.full(s, float("nan"), device="cuda") for _ in range(2)]
+
+    # (1) plain Linear + bias + residual (to_out)
+    o = new(M, 128)
+    paths = _both(M, [ops.Seg(xd)], ops.LayerSpec(Wd[:, 0:128], b1d), [[o[0]], [o[1]]], wi, res=[rd])
+    assert paths == [5 + 32, 5], paths
+    ref = x.double() @ W[:, 0:128].double().T + b1.double() + r.double()
+    assert rel(o[0], ref) < TOL and rel(o[0], o[1]) < 2e-6
+
+    # (2) two Linears of one input, in_add + in_save, outputs side by side in one [M, 256] buffer (node projection / in_project)
+    o, xs = new(M, 256), new(M, 128)
+    paths = _both(M, [ops.Seg(xd)], ops.LayerSpec(Wd[:, 0:128], b1d, stack=Wd[:, 128:256], bias2=b2d),
+                  [[(o[0], 256), (o[0].data_ptr() + 512, 256)], [(o[1], 256), (o[1].data_ptr() + 512, 256)]], wi,
+                  per_run={"in_save": xs}, in_add=ed)
+    assert paths == [5 + 32, 5], paths
+    xin = (x + e).double()
+    ref = torch.cat((xin @ W[:, 0:128].double().T + b1.double(), xin @ W[:, 128:256].double().T + b2.double()), 1)
+    assert rel(o[0], ref) < TOL and rel(o[0], o[1]) < 2e-6 and rel(xs[0], xin) < 1e-7 and torch.equal(xs[0], xs[1])
+
+    # (3) the adjoint: two inputs, two column-stacked blocks, residual
+    o = new(M, 128)
+    paths = _both(M, [ops.Seg(xd), ops.Seg(ed)], ops.LayerSpec(Wd[:, 0:128], stack_cols=Wd[:, 256:384]), [[o[0]], [o[1]]], wi, res=[rd])
+    assert paths == [5 + 32, 5], paths
+    ref = x.double() @ W[:, 0:128].double().T + e.double() @ W[:, 256:384].double().T + r.double()
+    assert rel(o[0], ref) < TOL and rel(o[0], o[1]) < 2e-6
+
+    # (4) a 256-wide input (two halves of one [M, 256] buffer) behind a GELU, bias, residual (linear_post)
+    from gfv import lib as L
+    z = torch.cat((x, e), 1)
+    zd = d(z)
+    o = new(M, 128)
+    segs = [ops.Seg(zd, width=128, ld=256), ops.Seg(zd, width=128, ld=256, offset=128)]
+    paths = _both(M, segs, ops.LayerSpec(Wpd, b1d), [[o[0]], [o[1]]], wi, in_op=L.IN_GELU, res=[rd])
+    assert paths == [5 + 32, 5], paths
+    ref = F.gelu(z.double()) @ Wp.double().T + b1.double() + r.double()
+    assert rel(o[0], ref) < TOL and rel(o[0], o[1]) < 2e-6
+
+
+def test_lean_kernel_leaves_what_it_does_not_cover_to_the_chain():
+    """A launch that asks for the per-16-row scales (gscale), a gathered segment or fewer rows than GFV_LIN1_MIN_M stays on
+    the chain kernel."""
+    from gfv import lib as L, ops
+    g = torch.Generator().manual_seed(3)
+    M = 3000
+    x = (torch.randn(M, 128, generator=g)).cuda()
+    W = (torch.randn(128, 128, generator=g) * 0.1).cuda()
+    wi = _wi([W])
+    o = torch.empty(M, 128, device="cuda")
+    gs = torch.zeros(3, ops.gscale_ld(M), device="cuda")
+    ops.rowtile_chain(M, [ops.Seg(x)], [ops.LayerSpec(W)], [o], wimg=wi, gscale=gs)
+    assert L.load().gfv_rowtile_last_path() == 5
+    idx = torch.randint(0, M, (M,), generator=g).int().cuda()
+    ops.rowtile_chain(M, [ops.Seg(x, idx)], [ops.LayerSpec(W)], [o], wimg=wi)
+    assert L.load().gfv_rowtile_last_path() == 5
+    ops.rowtile_chain(512, [ops.Seg(x)], [ops.LayerSpec(W)], [o], wimg=wi)
+    assert L.load().gfv_rowtile_last_path() == 5
+    ops.rowtile_chain(M, [ops.Seg(x)], [ops.LayerSpec(W)], [o], wimg=wi)
+    assert L.load().gfv_rowtile_last_path() == 5 + 32
