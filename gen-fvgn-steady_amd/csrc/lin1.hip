@@ -11,8 +11,10 @@
 // waves load and split their rows, and runs the products - the same three f16 MFMAs per fragment pair on the same (hi, lo)
 // operands as the chain (gfv_split.h, wimg.hip's fragment order), so the results carry the chain's accuracy.
 //   out_p[m, :] = sum_s op_in(seg_s[m, :] (+ in_add[m, :])) W_p,s^T + bias_p (+ res_p[m, :]),   p < N / 128, s < K / 128
-// Covered: 128-wide segments without gather, in_op none / GELU, in_add + in_save on a one-segment input, bias / bias2,
-// residual addends, 128 or 256 outputs (256 inputs with 128 outputs).  Anything else stays with the chain kernel.
+// Covered: 128-wide segments without gather, in_op none / GELU / LayerNorm, in_add + in_save on a one-segment input (+ the
+// per-16-row scales of those rows for the weight-gradient launch: gscale slot 0), bias / bias2, the GELU' epilogue with its
+// saved pre-activations, residual addends, 128 or 256 outputs (256 inputs with 128 outputs).  Anything else stays with the
+// chain kernel.
 #include <cstdlib>
 
 #include "../../include/gfv.h"
@@ -20,6 +22,7 @@
 #include "gfv_split.h"
 
 int* gfv_internal_status_ptr();
+extern "C" int gfv_hidden_size(void);
 
 namespace {
 
@@ -49,10 +52,16 @@ struct Lin1Args {
   float* out[2];
   int out_ld[2];
   int M;
+  const float* gamma;    // IN_OP 2 (LayerNorm prologue)
+  const float* beta;
+  float ln_inv_n, ln_npad;   // 1 / hidden, 128 - hidden (tchain_kernel.h ln_stats)
+  const float* aux;      // DGELU: the saved pre-activations [M, 128 NP]
+  float* gscale;         // optional: per-16-row scale of the prologue result (slot 0 of gfv_rowtile_args_t.gscale)
 };
 
 // KS: 32-wide k-steps (4: one 128-wide segment, 8: two); NP: 128-row passes of the image = 128-wide output chunks
-template <int KS, int NP, bool GELU_IN, bool LOWP>
+// IN_OP: 0 none, 1 GELU, 2 LayerNorm (one segment); DGELU: out = (acc) * gelu'(aux)
+template <int KS, int NP, int IN_OP, bool DGELU, bool LOWP>
 __global__ __launch_bounds__(512, 2) void lin1_kernel(const Lin1Args A, int* status) {
   extern __shared__ __attribute__((aligned(16))) char lds_raw[];
   gfv_uint4* img = reinterpret_cast<gfv_uint4*>(lds_raw);
@@ -98,11 +107,47 @@ __global__ __launch_bounds__(512, 2) void lin1_kernel(const Lin1Args A, int* sta
       *reinterpret_cast<float4*>(sp + 16) = make_float4(v[T][4], v[T][5], v[T][6], v[T][7]);
     }
   }
-  if (GELU_IN) {
+  if (IN_OP == 1) {
 #pragma unroll
     for (int T = 0; T < KS; ++T)
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[T][e] = gfv_gelu(v[T][e]);
+  }
+  if (IN_OP == 2) {
+    // LayerNorm of the row (tchain_kernel.h ln_stats / ln_apply: the same sums in the same order; the lane's 32 columns are
+    // 16 t + 4 g + r with t = 2 T (e < 4), 2 T + 1 (e >= 4))
+    float sm = 0.f;
+#pragma unroll
+    for (int T = 0; T < KS; ++T) {
+      sm += (v[T][0] + v[T][1]) + (v[T][2] + v[T][3]);
+      sm += (v[T][4] + v[T][5]) + (v[T][6] + v[T][7]);
+    }
+    float a, b;
+    gfv_lane_xor16(sm, a, b);
+    sm = a + b;
+    gfv_lane_xor32(sm, a, b);
+    const float mean = (a + b) * A.ln_inv_n;
+    float qq = 0.f;
+#pragma unroll
+    for (int T = 0; T < KS; ++T) {
+      const float d0 = v[T][0] - mean, d1 = v[T][1] - mean, d2 = v[T][2] - mean, d3 = v[T][3] - mean;
+      qq += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+      const float d4 = v[T][4] - mean, d5 = v[T][5] - mean, d6 = v[T][6] - mean, d7 = v[T][7] - mean;
+      qq += (d4 * d4 + d5 * d5) + (d6 * d6 + d7 * d7);
+    }
+    gfv_lane_xor16(qq, a, b);
+    qq = a + b;
+    gfv_lane_xor32(qq, a, b);
+    const float rstd = rsqrtf(((a + b) - A.ln_npad * (mean * mean)) * A.ln_inv_n + 1e-5f);
+#pragma unroll
+    for (int T = 0; T < KS; ++T) {
+      const float4 ga0 = *reinterpret_cast<const float4*>(A.gamma + 32 * T + 4 * g), ga1 = *reinterpret_cast<const float4*>(A.gamma + 32 * T + 16 + 4 * g);
+      const float4 be0 = *reinterpret_cast<const float4*>(A.beta + 32 * T + 4 * g), be1 = *reinterpret_cast<const float4*>(A.beta + 32 * T + 16 + 4 * g);
+      v[T][0] = (v[T][0] - mean) * rstd * ga0.x + be0.x; v[T][1] = (v[T][1] - mean) * rstd * ga0.y + be0.y;
+      v[T][2] = (v[T][2] - mean) * rstd * ga0.z + be0.z; v[T][3] = (v[T][3] - mean) * rstd * ga0.w + be0.w;
+      v[T][4] = (v[T][4] - mean) * rstd * ga1.x + be1.x; v[T][5] = (v[T][5] - mean) * rstd * ga1.y + be1.y;
+      v[T][6] = (v[T][6] - mean) * rstd * ga1.z + be1.z; v[T][7] = (v[T][7] - mean) * rstd * ga1.w + be1.w;
+    }
   }
   // power-of-two scale of the row, operand split (the chain's row_scale / to_halves)
   float m0 = 0.f, m1 = 0.f;
@@ -114,6 +159,10 @@ __global__ __launch_bounds__(512, 2) void lin1_kernel(const Lin1Args A, int* sta
     m1 = l1_max3_abs(m1, v[T][6], v[T][7]);
   }
   const float sx = gfv_pow2_scale(l1_row_max4(fmaxf(m0, m1)));
+  if (A.gscale) {   // the group's scale = the smallest of its 16 rows' (tchain_kernel.h group_scale_out)
+    const float sg = gfv_row16_min(sx);
+    if (lane == 0) A.gscale[blockIdx.x * 8 + wave] = sg;
+  }
   gfv_f16x8 xh[KS], xl[KS];
 #pragma unroll
   for (int T = 0; T < KS; ++T) {
@@ -153,6 +202,10 @@ __global__ __launch_bounds__(512, 2) void lin1_kernel(const Lin1Args A, int* sta
         const float4 b = *reinterpret_cast<const float4*>(bp + col);
         o.x += b.x; o.y += b.y; o.z += b.z; o.w += b.w;
       }
+      if (DGELU) {
+        const float4 z = *reinterpret_cast<const float4*>(A.aux + mr * (128 * NP) + 128 * p + col);
+        o.x *= gfv_dgelu(z.x); o.y *= gfv_dgelu(z.y); o.z *= gfv_dgelu(z.z); o.w *= gfv_dgelu(z.w);
+      }
       if (resp) {
         const float4 r = *reinterpret_cast<const float4*>(resp + mr * A.res_ld[p] + col);
         o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
@@ -177,11 +230,18 @@ int gfv_internal_lin1_try(const gfv_rowtile_args_t* a, int lowp, hipStream_t str
   static const int min_m = l1_env("GFV_LIN1_MIN_M", 1024);
   if (!on || a->nlayers != 1 || a->M < min_m || (a->flags & (GFV_CHAIN_ROW_OWNER | GFV_CHAIN_COLUMN_OWNER))) return 0;
   const gfv_layer_t& L = a->layer[0];
-  if (!L.Wh || !a->wmax || L.op != GFV_OP_NONE || L.save || L.aux) return 0;
-  if (a->in_op != GFV_IN_NONE && a->in_op != GFV_IN_GELU) return 0;
-  if (a->fin_op != GFV_FIN_PLAIN || a->fin_presave || a->fin_stats || a->in_stats || a->dw_partial || a->ln_partial || a->gadd || a->padd ||
-      a->in_aux || a->out_nores || a->gscale)
+  const bool dgelu = L.op == GFV_OP_MUL_DGELU;
+  if (!L.Wh || !a->wmax || (L.op != GFV_OP_NONE && !dgelu) || L.save) return 0;
+  if (dgelu ? (!L.aux || !al16(L.aux) || L.bias || L.bias2 || a->in_op != GFV_IN_NONE) : (L.aux != nullptr)) return 0;
+  if (a->in_op != GFV_IN_NONE && a->in_op != GFV_IN_GELU && a->in_op != GFV_IN_LN) return 0;
+  if (a->in_op == GFV_IN_LN && (a->nseg != 1 || !a->in_gamma || !a->in_beta || !al16(a->in_gamma) || !al16(a->in_beta) || a->in_add || a->in_save))
     return 0;
+  if (a->fin_op != GFV_FIN_PLAIN || a->fin_presave || a->fin_stats || a->in_stats || a->dw_partial || a->ln_partial || a->gadd || a->padd ||
+      a->in_aux || a->out_nores)
+    return 0;
+  // gscale: slot 0 (the prologue result's rows) is written here; the chain kernel also fills slot 1 of a one-pass GELU' launch
+  // without residual (the scale of its OUTPUT rows) - such a launch stays there
+  if (a->gscale && (a->nseg != 1 || (dgelu && L.N == 128 && !a->res[0]))) return 0;
   if (a->nseg < 1 || a->nseg > 2 || L.K != 128 * a->nseg || (L.N != 128 && L.N != 256) || (a->nseg == 2 && L.N != 128)) return 0;
   for (int i = 0; i < a->nseg; ++i) {
     const gfv_seg_t& s = a->seg[i];
@@ -210,32 +270,44 @@ int gfv_internal_lin1_try(const gfv_rowtile_args_t* a, int lowp, hipStream_t str
   A.bias[1] = np > 1 ? (L.bias2 ? L.bias2 : (L.bias ? L.bias + 128 : nullptr)) : nullptr;
   for (int p = 0; p < np; ++p) { A.res[p] = a->res[p]; A.res_ld[p] = a->res_ld[p]; A.out[p] = a->out[p]; A.out_ld[p] = a->out_ld[p]; }
   A.M = a->M;
+  A.gamma = a->in_gamma;
+  A.beta = a->in_beta;
+  {
+    const int hs = gfv_hidden_size();   // the launch's LayerNorm width (the calling thread's context; rowtile.hip has set it from args->hidden)
+    const int h = (hs > 0 && hs < 128) ? hs : 128;
+    A.ln_inv_n = 1.0f / (float)h;
+    A.ln_npad = (float)(128 - h);
+  }
+  A.aux = L.aux;
+  A.gscale = a->gscale;
   int* st = gfv_internal_status_ptr();
   const dim3 grid((a->M + 127) / 128), blk(512);
-  const bool gelu = a->in_op == GFV_IN_GELU;
-#define L1_ATTR(KS, NP, G, LP)                                                                                                  \
+  // instantiated: (in_op none | GELU | LayerNorm) without the GELU' epilogue, in_op none with it
+  const int iop = a->in_op == GFV_IN_GELU ? 1 : (a->in_op == GFV_IN_LN ? 2 : 0);
+#define L1_ONE(KS, NP, IOP, DG, LP)                                                                                             \
   do {                                                                                                                          \
-    static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(&lin1_kernel<KS, NP, G, LP>),             \
+    static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(&lin1_kernel<KS, NP, IOP, DG, LP>),       \
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (NP) * (KS) * 16384);       \
     if (once != hipSuccess) return 0;                                                                                           \
+    hipLaunchKernelGGL((lin1_kernel<KS, NP, IOP, DG, LP>), grid, blk, (size_t)(NP) * (KS) * 16384, stream, A, st);              \
+  } while (0)
+#define L1_FORM(KS, NP, LP)                                                                                                     \
+  do {                                                                                                                          \
+    if (dgelu) L1_ONE(KS, NP, 0, true, LP);                                                                                     \
+    else if (iop == 0) L1_ONE(KS, NP, 0, false, LP);                                                                            \
+    else if (iop == 1) L1_ONE(KS, NP, 1, false, LP);                                                                            \
+    else L1_ONE(KS, NP, 2, false, LP);                                                                                          \
   } while (0)
 #define L1_LAUNCH(KS, NP)                                                                                                       \
   do {                                                                                                                          \
-    const size_t lds = (size_t)(NP) * (KS) * 16384;                                                                             \
-    if (lowp) { if (gelu) L1_ATTR(KS, NP, true, true); else L1_ATTR(KS, NP, false, true); }                                     \
-    else { if (gelu) L1_ATTR(KS, NP, true, false); else L1_ATTR(KS, NP, false, false); }                                        \
-    if (lowp) {                                                                                                                 \
-      if (gelu) hipLaunchKernelGGL((lin1_kernel<KS, NP, true, true>), grid, blk, lds, stream, A, st);                           \
-      else hipLaunchKernelGGL((lin1_kernel<KS, NP, false, true>), grid, blk, lds, stream, A, st);                               \
-    } else {                                                                                                                    \
-      if (gelu) hipLaunchKernelGGL((lin1_kernel<KS, NP, true, false>), grid, blk, lds, stream, A, st);                          \
-      else hipLaunchKernelGGL((lin1_kernel<KS, NP, false, false>), grid, blk, lds, stream, A, st);                              \
-    }                                                                                                                           \
+    if (lowp) L1_FORM(KS, NP, true);                                                                                            \
+    else L1_FORM(KS, NP, false);                                                                                                \
   } while (0)
   if (a->nseg == 2) L1_LAUNCH(8, 1);
   else if (np == 2) L1_LAUNCH(4, 2);
   else L1_LAUNCH(4, 1);
 #undef L1_LAUNCH
-#undef L1_ATTR
+#undef L1_FORM
+#undef L1_ONE
   return 1;
 }

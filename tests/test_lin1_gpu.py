@@ -88,8 +88,8 @@ def test_lean_single_layer_kernel_against_the_chain_kernel_and_float64(M):
 
 
 def test_lean_kernel_leaves_what_it_does_not_cover_to_the_chain():
-    """A launch that asks for the per-16-row scales (gscale), a gathered segment or fewer rows than GFV_LIN1_MIN_M stays on
-    the chain kernel."""
+    """A one-pass GELU' launch that asks for the scales of its output rows, a gathered segment or fewer rows than
+    GFV_LIN1_MIN_M stays on the chain kernel."""
     from gfv import lib as L, ops
     g = torch.Generator().manual_seed(3)
     M = 3000
@@ -98,7 +98,9 @@ def test_lean_kernel_leaves_what_it_does_not_cover_to_the_chain():
     wi = _wi([W])
     o = torch.empty(M, 128, device="cuda")
     gs = torch.zeros(3, ops.gscale_ld(M), device="cuda")
-    ops.rowtile_chain(M, [ops.Seg(x)], [ops.LayerSpec(W)], [o], wimg=wi, gscale=gs)
+    z = torch.randn(M, 128, generator=g).cuda()
+    # a one-pass GELU' launch without residual also leaves the scales of its OUTPUT rows (slot 1): the chain kernel's
+    ops.rowtile_chain(M, [ops.Seg(x)], [ops.LayerSpec(W, None, L.OP_MUL_DGELU, aux=z)], [o], wimg=wi, gscale=gs)
     assert L.load().gfv_rowtile_last_path() == 5
     idx = torch.randint(0, M, (M,), generator=g).int().cuda()
     ops.rowtile_chain(M, [ops.Seg(x, idx)], [ops.LayerSpec(W)], [o], wimg=wi)
@@ -107,3 +109,45 @@ def test_lean_kernel_leaves_what_it_does_not_cover_to_the_chain():
     assert L.load().gfv_rowtile_last_path() == 5
     ops.rowtile_chain(M, [ops.Seg(x)], [ops.LayerSpec(W)], [o], wimg=wi)
     assert L.load().gfv_rowtile_last_path() == 5 + 32
+
+
+@pytest.mark.parametrize("M", [3000, 1100])
+def test_lean_kernel_layernorm_prologue_and_gelu_prime_epilogue(M):
+    """The two remaining Transolver launches the lean kernel takes: linear_pre behind LayerNorm ln_2 (128 -> 256) and the
+    adjoint of linear_post (gradient (+ addend, kept) x W_post -> 256 wide, x gelu'(z)), with the per-16-row scales of the
+    kept gradient rows for the weight-gradient launch - against the chain kernel and float64."""
+    from gfv import lib as L, ops
+    g = torch.Generator().manual_seed(M + 9)
+    d = lambda t: t.cuda().contiguous()
+    x = torch.randn(M, 128, generator=g) * torch.logspace(-2, 1, M)[:, None] + 0.3
+    Wpre = torch.randn(256, 128, generator=g) * 0.1
+    bpre = torch.randn(256, generator=g)
+    gam, bet = 1 + 0.1 * torch.randn(128, generator=g), 0.1 * torch.randn(128, generator=g)
+    wi = _wi([Wpre])
+    Wd, bd, gd, btd, xd = d(Wpre), d(bpre), d(gam), d(bet), d(x)
+    o = [torch.full((M, 256), float("nan"), device="cuda") for _ in range(2)]
+    paths = _both(M, [ops.Seg(xd)], ops.LayerSpec(Wd, bd),
+                  [[(o[0], 256), (o[0].data_ptr() + 512, 256)], [(o[1], 256), (o[1].data_ptr() + 512, 256)]], wi,
+                  in_op=L.IN_LN, in_gamma=gd, in_beta=btd)
+    assert paths == [5 + 32, 5], paths
+    ref = F.layer_norm(x.double(), (128,), gam.double(), bet.double(), 1e-5) @ Wpre.double().T + bpre.double()
+    assert rel(o[0], ref) < TOL and rel(o[0], o[1]) < 2e-6
+    # adjoint of linear_post: [M,128] gradient + addend -> [M,256], times gelu'(z)
+    go = torch.randn(M, 128, generator=g) * torch.logspace(-4, 0, M)[:, None]
+    ga = torch.randn(M, 128, generator=g) * 1e-2
+    z = torch.randn(M, 256, generator=g)
+    Wpost_t = torch.randn(256, 128, generator=g) * 0.1          # = W_post^T: [256 outputs of this launch, 128 inputs]
+    wi2 = _wi([Wpost_t])
+    Wt, god, gad, zd = d(Wpost_t), d(go), d(ga), d(z)
+    o = [torch.full((M, 256), float("nan"), device="cuda") for _ in range(2)]
+    gsum = [torch.full((M, 128), float("nan"), device="cuda") for _ in range(2)]
+    gs = [torch.zeros(3, ops.gscale_ld(M), device="cuda") for _ in range(2)]
+    paths = _both(M, [ops.Seg(god)], ops.LayerSpec(Wt, None, L.OP_MUL_DGELU, aux=zd),
+                  [[(o[0], 256), (o[0].data_ptr() + 512, 256)], [(o[1], 256), (o[1].data_ptr() + 512, 256)]], wi2,
+                  per_run={"in_save": gsum, "gscale": gs}, in_add=gad)
+    assert paths == [5 + 32, 5], paths
+    zz = z.double().requires_grad_(True)
+    dg = torch.autograd.grad(F.gelu(zz).sum(), zz)[0]
+    ref = ((go + ga).double() @ Wpost_t.double().T) * dg
+    assert rel(o[0], ref) < TOL and rel(o[0], o[1]) < 2e-6
+    assert torch.equal(gsum[0], gsum[1]) and torch.equal(gs[0][0, :(M + 15) // 16], gs[1][0, :(M + 15) // 16])
