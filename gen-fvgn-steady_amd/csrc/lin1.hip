@@ -216,6 +216,176 @@ __global__ __launch_bounds__(512, 2) void lin1_kernel(const Lin1Args A, int* sta
   (void)status;
 }
 
+// The adjoint of linear_pre behind LayerNorm ln_2 (GraphTransolver.py:163-166): out = LNbwd(g_z [M,256] W^T; fx1, gamma) + res, with
+// the per-64-row-tile (dgamma, dbeta) partials the chain kernel leaves for the reduction launch (gfv_rowtile_args_t.ln_partial).
+struct Lin1LnbArgs {
+  Lin1Args a;
+  const float* y;        // fin_aux: the LayerNorm's input rows [M,128]
+  const float* fgamma;   // fin_gamma
+  float* ln_partial;     // [n_tiles, 2, 128]
+  int n_tiles;
+};
+template <bool LOWP>
+__global__ __launch_bounds__(512, 2) void lin1_lnbwd_kernel(const Lin1LnbArgs B, int* status) {
+  constexpr int KS = 8;
+  const Lin1Args& A = B.a;
+  extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+  gfv_uint4* img = reinterpret_cast<gfv_uint4*>(lds_raw);
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, g = lane >> 4;
+  {
+    const gfv_uint4* src = reinterpret_cast<const gfv_uint4*>(A.img);
+    gfv_uint4 t[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) t[u] = src[(size_t)u * 512 + tid];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) img[u * 512 + tid] = t[u];
+  }
+  const int m = blockIdx.x * 128 + 16 * wave + li;
+  const bool live = m < A.M;
+  const size_t mr = (size_t)(live ? m : A.M - 1);
+  gfv_f16x8 xh[KS], xl[KS];
+  float inv;
+  {
+    float v[KS][8];
+#pragma unroll
+    for (int T = 0; T < KS; ++T) {
+      const int s = T >> 2, c = 32 * (T & 3) + 4 * g;
+      const float* rp = A.seg[s] + mr * A.seg_ld[s] + c;
+      const float4 a = *reinterpret_cast<const float4*>(rp), b = *reinterpret_cast<const float4*>(rp + 16);
+      v[T][0] = a.x; v[T][1] = a.y; v[T][2] = a.z; v[T][3] = a.w;
+      v[T][4] = b.x; v[T][5] = b.y; v[T][6] = b.z; v[T][7] = b.w;
+    }
+    float m0 = 0.f, m1 = 0.f;
+#pragma unroll
+    for (int T = 0; T < KS; ++T) {
+      m0 = l1_max3_abs(m0, v[T][0], v[T][1]);
+      m1 = l1_max3_abs(m1, v[T][2], v[T][3]);
+      m0 = l1_max3_abs(m0, v[T][4], v[T][5]);
+      m1 = l1_max3_abs(m1, v[T][6], v[T][7]);
+    }
+    const float sx = gfv_pow2_scale(l1_row_max4(fmaxf(m0, m1)));
+    inv = 1.0f / sx;
+#pragma unroll
+    for (int T = 0; T < KS; ++T) {
+      float e[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) e[i] = v[T][i] * sx;
+      gfv_uint4 hi, lo;
+      gfv_split8(e, hi, lo);
+      xh[T] = __builtin_bit_cast(gfv_f16x8, hi);
+      xl[T] = __builtin_bit_cast(gfv_f16x8, lo);
+    }
+  }
+  const float invw = 1.0f / gfv_pow2_scale(*A.wmax);
+  // the LayerNorm input rows: in flight through the products
+  float y[8][4];
+#pragma unroll
+  for (int nt = 0; nt < 8; ++nt) {
+    const float4 t = *reinterpret_cast<const float4*>(B.y + mr * 128 + 16 * nt + 4 * g);
+    y[nt][0] = t.x; y[nt][1] = t.y; y[nt][2] = t.z; y[nt][3] = t.w;
+  }
+  __syncthreads();
+  floatx4 acc[8];
+#pragma unroll
+  for (int nt = 0; nt < 8; ++nt) {
+    acc[nt] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int T = 0; T < KS; ++T) {
+      const gfv_uint4* f = img + (T * 8 + nt) * 128 + lane;
+      const gfv_f16x8 wh = __builtin_bit_cast(gfv_f16x8, f[0]);
+      if (!LOWP) {
+        const gfv_f16x8 wl = __builtin_bit_cast(gfv_f16x8, f[64]);
+        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh[T], acc[nt], 0, 0, 0);
+        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl[T], acc[nt], 0, 0, 0);
+      }
+      acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh[T], acc[nt], 0, 0, 0);
+    }
+  }
+  // ---- LayerNorm backward of the row (tchain_kernel.h ln_stats / ln_bwd) ----
+  float a, b;
+  float sm = 0.f;
+#pragma unroll
+  for (int nt = 0; nt < 8; ++nt) sm += (y[nt][0] + y[nt][1]) + (y[nt][2] + y[nt][3]);
+  gfv_lane_xor16(sm, a, b);
+  sm = a + b;
+  gfv_lane_xor32(sm, a, b);
+  const float mean = (a + b) * A.ln_inv_n;
+  float qq = 0.f;
+#pragma unroll
+  for (int nt = 0; nt < 8; ++nt) {
+    const float d0 = y[nt][0] - mean, d1 = y[nt][1] - mean, d2 = y[nt][2] - mean, d3 = y[nt][3] - mean;
+    qq += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+  }
+  gfv_lane_xor16(qq, a, b);
+  qq = a + b;
+  gfv_lane_xor32(qq, a, b);
+  const float rstd = rsqrtf(((a + b) - A.ln_npad * (mean * mean)) * A.ln_inv_n + 1e-5f);
+  const float livef = live ? 1.0f : 0.0f;   // rows past M must not reach the (dgamma, dbeta) sums
+  float vv[8][4], dgam[8][4], dbet[8][4];
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int nt = 0; nt < 8; ++nt) {
+    const float4 ga = *reinterpret_cast<const float4*>(B.fgamma + 16 * nt + 4 * g);
+    const float gv[4] = {ga.x, ga.y, ga.z, ga.w};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float v = ((acc[nt][r] * inv) * invw) * livef;
+      const float xhat = (y[nt][r] - mean) * rstd;
+      dgam[nt][r] = v * xhat;
+      dbet[nt][r] = v;
+      vv[nt][r] = v * gv[r];
+      s1 += vv[nt][r];
+      s2 += vv[nt][r] * xhat;
+    }
+  }
+  gfv_lane_xor16(s1, a, b);
+  s1 = a + b;
+  gfv_lane_xor32(s1, a, b);
+  const float mm1 = (a + b) * A.ln_inv_n;
+  gfv_lane_xor16(s2, a, b);
+  s2 = a + b;
+  gfv_lane_xor32(s2, a, b);
+  const float mm2 = (a + b) * A.ln_inv_n;
+  const float* resp = A.res[0];
+#pragma unroll
+  for (int nt = 0; nt < 8; ++nt) {
+    const int col = 16 * nt + 4 * g;
+    float o[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r] = rstd * (vv[nt][r] - mm1 - ((y[nt][r] - mean) * rstd) * mm2);
+    if (resp) {
+      const float4 rr = *reinterpret_cast<const float4*>(resp + mr * A.res_ld[0] + col);
+      o[0] += rr.x; o[1] += rr.y; o[2] += rr.z; o[3] += rr.w;
+    }
+    if (live) *reinterpret_cast<float4*>(A.out[0] + mr * A.out_ld[0] + col) = make_float4(o[0], o[1], o[2], o[3]);
+  }
+  // ---- (dgamma, dbeta): over the wave's 16 rows by DPP, over the four waves of a 64-row tile through LDS (the image is done) ----
+  __syncthreads();
+  float* red = reinterpret_cast<float*>(lds_raw);   // [8 waves][2][128]
+#pragma unroll
+  for (int nt = 0; nt < 8; ++nt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float dg = gfv_row16_sum(dgam[nt][r]), db = gfv_row16_sum(dbet[nt][r]);
+      if (li == 0) {
+        red[(wave * 2 + 0) * 128 + 16 * nt + 4 * g + r] = dg;
+        red[(wave * 2 + 1) * 128 + 16 * nt + 4 * g + r] = db;
+      }
+    }
+  __syncthreads();
+  {
+    const int half = tid >> 8, j = tid & 255;   // tile 2 b + half; j: dgamma 0..127 | dbeta 128..255
+    const int tile = 2 * blockIdx.x + half;
+    if (tile < B.n_tiles && B.ln_partial) {
+      const int w0 = 4 * half, which = j >> 7, c = j & 127;
+      const float s = (red[((w0 + 0) * 2 + which) * 128 + c] + red[((w0 + 1) * 2 + which) * 128 + c]) +
+                      (red[((w0 + 2) * 2 + which) * 128 + c] + red[((w0 + 3) * 2 + which) * 128 + c]);
+      B.ln_partial[(size_t)tile * 256 + j] = s;
+    }
+  }
+  (void)status;
+}
+
 inline bool al16(const void* p) { return (reinterpret_cast<size_t>(p) & 15) == 0; }
 int l1_env(const char* n, int dflt) {
   const char* e = getenv(n);
@@ -230,6 +400,50 @@ int gfv_internal_lin1_try(const gfv_rowtile_args_t* a, int lowp, hipStream_t str
   static const int min_m = l1_env("GFV_LIN1_MIN_M", 1024);
   if (!on || a->nlayers != 1 || a->M < min_m || (a->flags & (GFV_CHAIN_ROW_OWNER | GFV_CHAIN_COLUMN_OWNER))) return 0;
   const gfv_layer_t& L = a->layer[0];
+  if (a->fin_op == GFV_FIN_LNBWD) {
+    // [M,256] x W^T -> LayerNorm backward (+ residual), per-tile (dgamma, dbeta) partials
+    static const int lnb_on = l1_env("GFV_LIN1_LNBWD", 1);
+    if (!lnb_on || !L.Wh || !a->wmax || L.op != GFV_OP_NONE || L.save || L.aux || L.bias || L.bias2 || a->in_op != GFV_IN_NONE) return 0;
+    if (a->nseg != 2 || L.K != 256 || L.N != 128 || a->in_add || a->in_save || a->gscale || a->fin_presave || a->fin_stats || a->in_stats ||
+        a->dw_partial || a->gadd || a->padd || a->in_aux || a->out_nores || !a->fin_aux || !a->fin_gamma || !a->ln_partial)
+      return 0;
+    for (int i = 0; i < 2; ++i) {
+      const gfv_seg_t& sg = a->seg[i];
+      if (sg.width != 128 || sg.idx || sg.csr_rowptr || sg.csr_scale || sg.save || (sg.ld & 3) || !al16(sg.ptr)) return 0;
+    }
+    if (!a->out[0] || a->out[1] || a->out[2] || (a->out_ld[0] & 3) || !al16(a->out[0]) || a->res[1] || a->res[2]) return 0;
+    if (a->res[0] && ((a->res_ld[0] & 3) || !al16(a->res[0]))) return 0;
+    if (!al16(a->fin_aux) || !al16(a->fin_gamma) || !al16(a->ln_partial)) return 0;
+    Lin1LnbArgs B{};
+    for (int i = 0; i < 2; ++i) { B.a.seg[i] = a->seg[i].ptr; B.a.seg_ld[i] = a->seg[i].ld; }
+    B.a.img = L.Wh;
+    B.a.wmax = a->wmax;
+    B.a.res[0] = a->res[0]; B.a.res_ld[0] = a->res_ld[0];
+    B.a.out[0] = a->out[0]; B.a.out_ld[0] = a->out_ld[0];
+    B.a.M = a->M;
+    {
+      const int hs = gfv_hidden_size();
+      const int h = (hs > 0 && hs < 128) ? hs : 128;
+      B.a.ln_inv_n = 1.0f / (float)h;
+      B.a.ln_npad = (float)(128 - h);
+    }
+    B.y = a->fin_aux;
+    B.fgamma = a->fin_gamma;
+    B.ln_partial = a->ln_partial;
+    B.n_tiles = (a->M + 63) / 64;
+    int* st = gfv_internal_status_ptr();
+    const dim3 grid((a->M + 127) / 128), blk(512);
+    if (lowp) {
+      static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(&lin1_lnbwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+      if (once != hipSuccess) return 0;
+      hipLaunchKernelGGL((lin1_lnbwd_kernel<true>), grid, blk, 131072, stream, B, st);
+    } else {
+      static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(&lin1_lnbwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+      if (once != hipSuccess) return 0;
+      hipLaunchKernelGGL((lin1_lnbwd_kernel<false>), grid, blk, 131072, stream, B, st);
+    }
+    return 1;
+  }
   const bool dgelu = L.op == GFV_OP_MUL_DGELU;
   if (!L.Wh || !a->wmax || (L.op != GFV_OP_NONE && !dgelu) || L.save) return 0;
   if (dgelu ? (!L.aux || !al16(L.aux) || L.bias || L.bias2 || a->in_op != GFV_IN_NONE) : (L.aux != nullptr)) return 0;

@@ -151,3 +151,36 @@ def test_lean_kernel_layernorm_prologue_and_gelu_prime_epilogue(M):
     ref = ((go + ga).double() @ Wpost_t.double().T) * dg
     assert rel(o[0], ref) < TOL and rel(o[0], o[1]) < 2e-6
     assert torch.equal(gsum[0], gsum[1]) and torch.equal(gs[0][0, :(M + 15) // 16], gs[1][0, :(M + 15) // 16])
+
+
+@pytest.mark.parametrize("M", [3000, 1100, 1089])
+def test_lean_kernel_layernorm_backward_epilogue(M):
+    """The adjoint of linear_pre behind LayerNorm ln_2: g_fx1 = LNbwd(g_z [M,256] W; fx1, gamma) + residual, and the per-tile
+    (dgamma, dbeta) partials for the reduction launch - against the chain kernel and float64 autograd."""
+    from gfv import lib as L, ops
+    g = torch.Generator().manual_seed(M + 21)
+    d = lambda t: t.cuda().contiguous()
+    fx1 = torch.randn(M, 128, generator=g) * 2 + 0.5
+    gz = torch.randn(M, 256, generator=g) * torch.logspace(-4, 0, M)[:, None]
+    gout = torch.randn(M, 128, generator=g) * 1e-2
+    Wpre = torch.randn(256, 128, generator=g) * 0.1                 # linear_pre.weight [256, 128]; the launch multiplies by W^T's transpose
+    gam = 1 + 0.1 * torch.randn(128, generator=g)
+    Wt = Wpre.t().contiguous()                                      # [128, 256]: out[n] = sum_k g_z[k] Wpre[k, n]
+    wi = _wi([Wt])
+    Wd, gzd, fxd, gd, god = d(Wt), d(gz), d(fx1), d(gam), d(gout)
+    tiles = ops.rowtile_tiles(M)
+    o = [torch.full((M, 128), float("nan"), device="cuda") for _ in range(2)]
+    part = [torch.full((tiles, 2, 128), float("nan"), device="cuda") for _ in range(2)]
+    segs = [ops.Seg(gzd, width=128, ld=256), ops.Seg(gzd, width=128, ld=256, offset=128)]
+    paths = _both(M, segs, ops.LayerSpec(Wd), [[o[0]], [o[1]]], wi, per_run={"ln_partial": part},
+                  fin_op=L.FIN_LNBWD, fin_gamma=gd, fin_aux=fxd, res=[god])
+    assert paths == [5 + 32, 5], paths
+    x = fx1.double().requires_grad_(True)
+    gm = gam.double().requires_grad_(True)
+    bt = torch.zeros(128, dtype=torch.float64, requires_grad=True)
+    yln = F.layer_norm(x, (128,), gm, bt, 1e-5)
+    gy = gz.double() @ Wpre.double()                                # gradient wrt the LayerNorm output
+    gx, ggam, gbet = torch.autograd.grad(yln, (x, gm, bt), gy)
+    assert rel(o[0], gx + gout.double()) < TOL and rel(o[0], o[1]) < 2e-6
+    assert rel(part[0][:, 0].sum(0), ggam) < TOL and rel(part[0][:, 1].sum(0), gbet) < TOL
+    assert rel(part[0].sum(0), part[1].sum(0)) < 2e-6
