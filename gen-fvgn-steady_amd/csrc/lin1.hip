@@ -386,6 +386,128 @@ __global__ __launch_bounds__(512, 2) void lin1_lnbwd_kernel(const Lin1LnbArgs B,
   (void)status;
 }
 
+// Two segmented-sum segments (gfv_seg_t.csr_rowptr: the per-side scatter of the factored EdgeBlock's adjoint, blocks.py:24-31 adjoint)
+// in front of one Linear [256 -> 128]: row m of segment s = sum of the rows col_s[rowptr_s[m] .. rowptr_s[m+1]) of src_s, entries
+// added in CSR order, two neighbour rows in flight per lane (the chain kernel's prologue, tchain_kernel.h load_segment); the
+// assembled rows are written out for the weight-gradient launch (gfv_seg_t.save).
+struct Lin1CsrArgs {
+  const float* src[2];
+  int src_ld[2];
+  const int* rowptr[2];
+  const int* col[2];
+  float* save[2];
+  const void* img;
+  const float* wmax;
+  float* out;
+  int out_ld;
+  int M;
+};
+template <bool LOWP>
+__global__ __launch_bounds__(512, 2) void lin1_csr_kernel(const Lin1CsrArgs A, int* status) {
+  constexpr int KS = 8;
+  extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+  gfv_uint4* img = reinterpret_cast<gfv_uint4*>(lds_raw);
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, g = lane >> 4;
+  {
+    const gfv_uint4* src = reinterpret_cast<const gfv_uint4*>(A.img);
+    gfv_uint4 t[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) t[u] = src[(size_t)u * 512 + tid];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) img[u * 512 + tid] = t[u];
+  }
+  // XCD-aware order of the 128-row workgroups (consecutive row blocks share neighbour rows in the same L2)
+  const int nwg = gridDim.x;
+  const int wg = (nwg & 7) == 0 ? (int)(blockIdx.x & 7) * (nwg >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  const int m = wg * 128 + 16 * wave + li;
+  const bool live = m < A.M;
+  const int mc = live ? m : A.M - 1;
+  float v[KS][8];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int beg = A.rowptr[s][mc], end = live ? A.rowptr[s][mc + 1] : beg;
+#pragma unroll
+    for (int T = 0; T < 4; ++T)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[4 * s + T][e] = 0.f;
+    const int* cidx = A.col[s];
+    int cn0 = beg < end ? cidx[beg] : 0, cn1 = beg + 1 < end ? cidx[beg + 1] : cn0;
+    for (int k = beg; k < end; k += 2) {
+      const bool two = (k + 1 < end);
+      const int c0 = cn0, c1 = cn1;
+      if (k + 2 < end) {
+        cn0 = cidx[k + 2];
+        cn1 = cidx[k + 3 < end ? k + 3 : k + 2];
+      }
+      const float* p0 = A.src[s] + (size_t)c0 * (size_t)A.src_ld[s] + 4 * g;
+      const float* p1 = A.src[s] + (size_t)c1 * (size_t)A.src_ld[s] + 4 * g;
+      float4 a0[8], a1[8];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        a0[t] = *reinterpret_cast<const float4*>(p0 + 16 * t);
+        a1[t] = *reinterpret_cast<const float4*>(p1 + 16 * t);
+      }
+      const float w1 = two ? 1.0f : 0.0f;   // (the second row of an odd tail is the first one again: added with weight 0)
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        float* d = &v[4 * s + (t >> 1)][4 * (t & 1)];
+        d[0] += a0[t].x; d[1] += a0[t].y; d[2] += a0[t].z; d[3] += a0[t].w;
+        if (two) { d[0] += a1[t].x; d[1] += a1[t].y; d[2] += a1[t].z; d[3] += a1[t].w; }
+      }
+      (void)w1;
+    }
+    if (A.save[s] && live) {
+#pragma unroll
+      for (int T = 0; T < 4; ++T) {
+        float* sp = A.save[s] + (size_t)m * 128 + 32 * T + 4 * g;
+        *reinterpret_cast<float4*>(sp) = make_float4(v[4 * s + T][0], v[4 * s + T][1], v[4 * s + T][2], v[4 * s + T][3]);
+        *reinterpret_cast<float4*>(sp + 16) = make_float4(v[4 * s + T][4], v[4 * s + T][5], v[4 * s + T][6], v[4 * s + T][7]);
+      }
+    }
+  }
+  float m0 = 0.f, m1 = 0.f;
+#pragma unroll
+  for (int T = 0; T < KS; ++T) {
+    m0 = l1_max3_abs(m0, v[T][0], v[T][1]);
+    m1 = l1_max3_abs(m1, v[T][2], v[T][3]);
+    m0 = l1_max3_abs(m0, v[T][4], v[T][5]);
+    m1 = l1_max3_abs(m1, v[T][6], v[T][7]);
+  }
+  const float sx = gfv_pow2_scale(l1_row_max4(fmaxf(m0, m1)));
+  gfv_f16x8 xh[KS], xl[KS];
+#pragma unroll
+  for (int T = 0; T < KS; ++T) {
+    float e[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) e[i] = v[T][i] * sx;
+    gfv_uint4 hi, lo;
+    gfv_split8(e, hi, lo);
+    xh[T] = __builtin_bit_cast(gfv_f16x8, hi);
+    xl[T] = __builtin_bit_cast(gfv_f16x8, lo);
+  }
+  const float inv = 1.0f / sx, invw = 1.0f / gfv_pow2_scale(*A.wmax);
+  __syncthreads();
+#pragma unroll 2
+  for (int nt = 0; nt < 8; ++nt) {
+    floatx4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int T = 0; T < KS; ++T) {
+      const gfv_uint4* f = img + (T * 8 + nt) * 128 + lane;
+      const gfv_f16x8 wh = __builtin_bit_cast(gfv_f16x8, f[0]);
+      if (!LOWP) {
+        const gfv_f16x8 wl = __builtin_bit_cast(gfv_f16x8, f[64]);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh[T], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl[T], acc, 0, 0, 0);
+      }
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh[T], acc, 0, 0, 0);
+    }
+    if (live)
+      *reinterpret_cast<float4*>(A.out + (size_t)m * A.out_ld + 16 * nt + 4 * g) =
+          make_float4((acc[0] * inv) * invw, (acc[1] * inv) * invw, (acc[2] * inv) * invw, (acc[3] * inv) * invw);
+  }
+  (void)status;
+}
+
 inline bool al16(const void* p) { return (reinterpret_cast<size_t>(p) & 15) == 0; }
 int l1_env(const char* n, int dflt) {
   const char* e = getenv(n);
@@ -400,6 +522,39 @@ int gfv_internal_lin1_try(const gfv_rowtile_args_t* a, int lowp, hipStream_t str
   static const int min_m = l1_env("GFV_LIN1_MIN_M", 1024);
   if (!on || a->nlayers != 1 || a->M < min_m || (a->flags & (GFV_CHAIN_ROW_OWNER | GFV_CHAIN_COLUMN_OWNER))) return 0;
   const gfv_layer_t& L = a->layer[0];
+  if (a->nseg == 2 && a->seg[0].csr_rowptr && a->seg[1].csr_rowptr) {
+    static const int csr_on = l1_env("GFV_LIN1_CSR", 1);
+    if (!csr_on || !L.Wh || !a->wmax || L.op != GFV_OP_NONE || L.save || L.aux || L.bias || L.bias2 || a->in_op != GFV_IN_NONE ||
+        a->fin_op != GFV_FIN_PLAIN || L.K != 256 || L.N != 128)
+      return 0;
+    if (a->in_add || a->in_save || a->gscale || a->fin_presave || a->fin_stats || a->in_stats || a->dw_partial || a->gadd || a->padd ||
+        a->in_aux || a->out_nores || a->ln_partial || a->res[0] || a->res[1] || a->res[2])
+      return 0;
+    if (!a->out[0] || a->out[1] || a->out[2] || (a->out_ld[0] & 3) || !al16(a->out[0])) return 0;
+    Lin1CsrArgs B{};
+    for (int i = 0; i < 2; ++i) {
+      const gfv_seg_t& sg = a->seg[i];
+      if (sg.width != 128 || !sg.idx || sg.csr_scale || (sg.ld & 3) || !al16(sg.ptr) || (sg.save && !al16(sg.save))) return 0;
+      B.src[i] = sg.ptr; B.src_ld[i] = sg.ld; B.rowptr[i] = sg.csr_rowptr; B.col[i] = sg.idx; B.save[i] = sg.save;
+    }
+    B.img = L.Wh;
+    B.wmax = a->wmax;
+    B.out = a->out[0];
+    B.out_ld = a->out_ld[0];
+    B.M = a->M;
+    int* st = gfv_internal_status_ptr();
+    const dim3 grid((a->M + 127) / 128), blk(512);
+    if (lowp) {
+      static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(&lin1_csr_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+      if (once != hipSuccess) return 0;
+      hipLaunchKernelGGL((lin1_csr_kernel<true>), grid, blk, 131072, stream, B, st);
+    } else {
+      static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(&lin1_csr_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+      if (once != hipSuccess) return 0;
+      hipLaunchKernelGGL((lin1_csr_kernel<false>), grid, blk, 131072, stream, B, st);
+    }
+    return 1;
+  }
   if (a->fin_op == GFV_FIN_LNBWD) {
     // [M,256] x W^T -> LayerNorm backward (+ residual), per-tile (dgamma, dbeta) partials
     static const int lnb_on = l1_env("GFV_LIN1_LNBWD", 1);

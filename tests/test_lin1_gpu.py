@@ -184,3 +184,38 @@ def test_lean_kernel_layernorm_backward_epilogue(M):
     assert rel(o[0], gx + gout.double()) < TOL and rel(o[0], o[1]) < 2e-6
     assert rel(part[0][:, 0].sum(0), ggam) < TOL and rel(part[0][:, 1].sum(0), gbet) < TOL
     assert rel(part[0].sum(0), part[1].sum(0)) < 2e-6
+
+
+@pytest.mark.parametrize("M,E", [(3000, 9000), (1100, 2500)])
+def test_lean_kernel_segmented_sum_prologue(M, E):
+    """The per-side scatter of the factored EdgeBlock's adjoint in front of its node-level Linear: rows = sums of gz1 rows by
+    sender / by receiver (CSR, some rows empty), the assembled rows written out - against the chain kernel and float64."""
+    from gfv import ops
+    g = torch.Generator().manual_seed(M)
+    d = lambda t: t.cuda().contiguous()
+    gz1 = torch.randn(E, 128, generator=g) * torch.logspace(-3, 0, E)[:, None]
+    W = torch.randn(128, 256, generator=g) * 0.1
+    wi = _wi([W])
+    csrs, dense = [], []
+    for side in range(2):
+        idx = torch.randint(0, M - 7, (E,), generator=g)           # the last rows stay empty
+        order = torch.argsort(idx, stable=True)
+        rowptr = torch.zeros(M + 1, dtype=torch.int64)
+        rowptr[1:] = torch.cumsum(torch.bincount(idx, minlength=M), 0)
+        csrs.append((d(rowptr.int()), d(order.int())))
+        dense.append(torch.zeros(M, 128, dtype=torch.float64).index_add_(0, idx, gz1.double()))
+    gzd, Wd = d(gz1), d(W)
+    o = [torch.full((M, 128), float("nan"), device="cuda") for _ in range(2)]
+    sv = [[torch.full((M, 128), float("nan"), device="cuda") for _ in range(2)] for _ in range(2)]
+    from gfv import lib as L
+    paths = []
+    for i, fam in enumerate((0, L.CHAIN_ROW_OWNER)):
+        ops.rowtile_chain(M, [ops.Seg(gzd, csr=csrs[0], save=sv[i][0]), ops.Seg(gzd, csr=csrs[1], save=sv[i][1])],
+                          [ops.LayerSpec(Wd)], [o[i]], wimg=wi, family=fam)
+        paths.append(L.load().gfv_rowtile_last_path())
+    torch.cuda.synchronize()
+    assert paths == [5 + 32, 5], paths
+    ref = dense[0] @ W[:, 0:128].double().T + dense[1] @ W[:, 128:256].double().T
+    assert rel(o[0], ref) < TOL and rel(o[0], o[1]) < 2e-6
+    for side in range(2):
+        assert rel(sv[0][side], dense[side]) < 1e-6 and torch.equal(sv[0][side], sv[1][side])
