@@ -181,7 +181,9 @@ int gfv_rowtile_tiles(int32_t M); /* number of 64-row tiles = rows of ln_partial
 int gfv_rowtile_chain(const gfv_rowtile_args_t* args, void* stream);
 /* which kernel the calling thread's last gfv_rowtile_chain launch took: 0 generic LDS row-tile, 1 register-resident
  * chain, 2 its ragged-shape instantiation; + 4 when the products ran as split-fp16; + 8 when the column-owner persistent
- * family took the launch, + 16 when it ran with fused weight gradients (tests assert the path they mean) */
+ * family took the launch, + 16 when it ran with fused weight gradients, + 32 when a single-layer launch ran on the lean
+ * one-Linear kernel (csrc/lin1.hip: the layer's image staged in LDS once per 128-row workgroup; same products, same
+ * results to rounding) (tests assert the path they mean) */
 int gfv_rowtile_last_path(void);
 
 /* fp32 products on the f16 MFMA pipe (v_mfma_f32_16x16x32_f16, 16x the f32 MFMA rate): every fp32 operand is split
