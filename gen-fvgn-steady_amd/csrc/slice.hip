@@ -463,6 +463,11 @@ __global__ __launch_bounds__(256) void deslice_kernel(const float* __restrict__ 
                                                       const int* __restrict__ batch, float* __restrict__ out, int N,
                                                       int accumulate) {
   __shared__ __attribute__((aligned(16))) float sT[H * TS];
+  if (accumulate & 2) {   // only the workgroups whose 32 nodes span two graphs (deslice_mfma_kernel took the others)
+    const int n_first = blockIdx.x * 32;
+    if (batch[min(n_first + 31, N - 1)] == batch[n_first]) return;
+    accumulate = 0;
+  }
   const bool uniform = stage_T(T, batch, N, sT);
   const long row = (long)blockIdx.x * 256 + threadIdx.x;
   if (row >= (long)N * H) return;
@@ -888,6 +893,144 @@ __global__ __launch_bounds__(256, 2) void slice_post_bwd_mfma_kernel(const Slice
   if (tid < H) out[544 + tid] = sRed[tid >> 1][544 + (tid & 1)];
 }
 
+// ---- slice weights and per-chunk slice tokens on the matrix cores ------------------------------------------------------------
+// SOFTMAX: w = softmax((x_mid Ws^T + bs) / T_h) is formed here (and written out) - slice_softmax_fwd and slice_token_partial
+// in one pass, without the 26 MB round trip of w in between; else w is read.  One workgroup per chunk (a node range inside one
+// graph), wave v the heads 2 v, 2 v + 1.  Per (head, 16-node tile): logits [16 x 32] = x Ws^T on v_mfma_f32_16x16x4_f32 (one
+// float4 per lane per operand: the contraction index is permuted), the row maxima / sums of the softmax are DPP row
+// reductions over the 16 lanes that hold a row's slices, and the token sums T[g][c] += w^T a take the accumulator-layout
+// registers of w as their operand fragments directly (lane (g, q) holds rows 4 q .. 4 q + 3 = the four k-steps).
+template <bool SOFTMAX>
+__global__ __launch_bounds__(256, 2) void slice_token_mfma_kernel(const float* __restrict__ xmid, const float* __restrict__ Ws,
+                                                                  const float* __restrict__ bs, const float* __restrict__ temp,
+                                                                  float* __restrict__ w, const float* __restrict__ a,
+                                                                  const int* __restrict__ chunk_beg, const int* __restrict__ chunk_end,
+                                                                  float* __restrict__ partial) {
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, q = lane >> 4;
+  const int beg = chunk_beg[blockIdx.x], end = chunk_end[blockIdx.x];
+  float bws[2][4], bsv[2];
+  if (SOFTMAX) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const float4 v = *reinterpret_cast<const float4*>(Ws + (16 * t + li) * D + 4 * q);
+      bws[t][0] = v.x; bws[t][1] = v.y; bws[t][2] = v.z; bws[t][3] = v.w;
+      bsv[t] = bs[16 * t + li];
+    }
+  }
+  float* out = partial + (size_t)blockIdx.x * 256 * 17;
+#pragma unroll 1
+  for (int hh = 0; hh < 2; ++hh) {
+    const int h = 2 * wave + hh;
+    const float invT = SOFTMAX ? 1.0f / temp[h] : 0.f;
+    floatx4 tok[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    float nrm[2] = {0.f, 0.f};
+#pragma unroll 1
+    for (int n0 = beg; n0 < end; n0 += 16) {
+      // accumulator layout: lane (column li, rows 4 q + r)
+      float wd[2][4], ab[4];
+      size_t rowD[4];
+      bool liveD[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int nd = n0 + 4 * q + r;
+        liveD[r] = nd < end;
+        rowD[r] = (size_t)(liveD[r] ? nd : end - 1) * H + h;
+        ab[r] = liveD[r] ? a[rowD[r] * D + li] : 0.f;
+      }
+      if (SOFTMAX) {
+        const int nA = n0 + li;
+        const bool liveA = nA < end;
+        const size_t rowA = (size_t)(liveA ? nA : end - 1) * H + h;
+        const float4 vx = *reinterpret_cast<const float4*>(xmid + rowA * D + 4 * q);
+        const float ax[4] = {vx.x, vx.y, vx.z, vx.w};
+        floatx4 lg[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          lg[t] = floatx4{bsv[t], bsv[t], bsv[t], bsv[t]};
+#pragma unroll
+          for (int s = 0; s < 4; ++s) lg[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[s], bws[t][s], lg[t], 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float z0 = lg[0][r] * invT, z1 = lg[1][r] * invT;
+          const float mx = gfv_row16_max(fmaxf(z0, z1));
+          const float e0 = __expf(z0 - mx), e1 = __expf(z1 - mx);
+          const float inv = 1.0f / gfv_row16_sum(e0 + e1);
+          const float m = liveD[r] ? 1.0f : 0.0f;
+          wd[0][r] = e0 * inv * m;
+          wd[1][r] = e1 * inv * m;
+          if (liveD[r]) {
+            w[rowD[r] * G + li] = wd[0][r];
+            w[rowD[r] * G + 16 + li] = wd[1][r];
+          }
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          wd[0][r] = liveD[r] ? w[rowD[r] * G + li] : 0.f;
+          wd[1][r] = liveD[r] ? w[rowD[r] * G + 16 + li] : 0.f;
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) tok[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wd[t][s], ab[s], tok[t], 0, 0, 0);
+        nrm[t] += (wd[t][0] + wd[t][1]) + (wd[t][2] + wd[t][3]);
+      }
+    }
+    // T[g = 16 t + 4 q + r][c = li], norm[g = 16 t + li] (summed over the four row groups)
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) out[(size_t)(h * G + 16 * t + 4 * q + r) * 17 + li] = tok[t][r];
+      float x0, x1;
+      gfv_lane_xor16(nrm[t], x0, x1);
+      const float v = x0 + x1;
+      gfv_lane_xor32(v, x0, x1);
+      if (q == 0) out[(size_t)(h * G + 16 * t + li) * 17 + 16] = x0 + x1;
+    }
+  }
+}
+
+// ---- de-slice on the matrix cores: out[n, h, c] = sum_g w[n, h, g] T[b(n), h, g, c] (workgroups of one graph; the others: deslice_kernel) ----
+__global__ __launch_bounds__(256, 2) void deslice_mfma_kernel(const float* __restrict__ w, const float* __restrict__ T,
+                                                              const int* __restrict__ batch, float* __restrict__ out, int N) {
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, q = lane >> 4;
+  const int n_first = blockIdx.x * 32;
+  const int n_last = min(n_first + 31, N - 1);
+  const int b0 = batch[n_first];
+  if (batch[n_last] != b0) return;
+#pragma unroll 1
+  for (int hh = 0; hh < 2; ++hh) {
+    const int h = 2 * wave + hh;
+    const float* Tp = T + ((size_t)b0 * H + h) * G * D;
+    float t2d[2][4];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) t2d[u][s] = Tp[(16 * u + 4 * q + s) * D + li];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const int nA = n_first + 16 * nt + li;
+      const bool liveA = nA < N;
+      const size_t rowA = (size_t)(liveA ? nA : N - 1) * H + h;
+      const float4 v0 = *reinterpret_cast<const float4*>(w + rowA * G + 4 * q);
+      const float4 v1 = *reinterpret_cast<const float4*>(w + rowA * G + 16 + 4 * q);
+      const float aw[2][4] = {{v0.x, v0.y, v0.z, v0.w}, {v1.x, v1.y, v1.z, v1.w}};
+      floatx4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[u][s], t2d[u][s], acc, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int nd = n_first + 16 * nt + 4 * q + r;
+        if (nd < N) out[((size_t)nd * H + h) * D + li] = acc[r];
+      }
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int gfv_slice_softmax_fwd(const float* xmid, const float* Ws, const float* bs, const float* temp, float* w,
@@ -913,12 +1056,32 @@ extern "C" int gfv_slice_softmax_bwd(const float* xmid, const float* Ws, const f
   return GFV_OK;
 }
 
+static int slice_mfma_on() {
+  static const int on = [] { const char* e = getenv("GFV_SLICE_MFMA"); return e ? atoi(e) : 1; }();
+  return on;
+}
+
 extern "C" int gfv_slice_token_partial(const float* w, const float* a, const int32_t* chunk_beg, const int32_t* chunk_end,
                                        int32_t n_chunks, float* partial, void* stream) {
   GfvProfScope ps_(GFV_K_SLICE, 0, 64.0 * 1536.0 * n_chunks, stream);   // 64-node chunks: w + a rows in
   if (n_chunks <= 0) return n_chunks == 0 ? GFV_OK : GFV_ERR_ARG;
-  hipLaunchKernelGGL(slice_token_partial_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, w, a, chunk_beg,
-                     chunk_end, partial);
+  if (slice_mfma_on())
+    hipLaunchKernelGGL((slice_token_mfma_kernel<false>), dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, nullptr, nullptr, nullptr,
+                       nullptr, const_cast<float*>(w), a, chunk_beg, chunk_end, partial);
+  else
+    hipLaunchKernelGGL(slice_token_partial_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, w, a, chunk_beg,
+                       chunk_end, partial);
+  GFV_CHECK_LAUNCH();
+  return GFV_OK;
+}
+
+extern "C" int gfv_slice_softmax_token(const float* xmid, const float* Ws, const float* bs, const float* temp, const float* a,
+                                       const int32_t* chunk_beg, const int32_t* chunk_end, int32_t n_chunks, float* w,
+                                       float* partial, void* stream) {
+  GfvProfScope ps_(GFV_K_SLICE, 0, 64.0 * 2048.0 * n_chunks, stream);   // x_mid + a rows in, w out
+  if (n_chunks <= 0) return n_chunks == 0 ? GFV_OK : GFV_ERR_ARG;
+  hipLaunchKernelGGL((slice_token_mfma_kernel<true>), dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, xmid, Ws, bs, temp, w, a,
+                     chunk_beg, chunk_end, partial);
   GFV_CHECK_LAUNCH();
   return GFV_OK;
 }
@@ -952,8 +1115,18 @@ extern "C" int gfv_deslice(const float* w, const float* T, const int32_t* batch,
                            void* stream) {
   GfvProfScope ps_(GFV_K_SLICE, 0, 1536.0 * N, stream);   // w in, out [N,128]
   if (N <= 0) return N == 0 ? GFV_OK : GFV_ERR_ARG;
-  hipLaunchKernelGGL(deslice_kernel, dim3(gfv_div_up((long)N * H, 256)), dim3(256), 0, (hipStream_t)stream, w, T, batch,
-                     out, N, accumulate);
+  static const int dmfma = [] { const char* e = getenv("GFV_DESLICE_MFMA"); return e ? atoi(e) : 1; }();
+  if (dmfma && slice_mfma_on() && !(accumulate & 1)) {
+    // workgroups of one graph on the matrix cores, then (unless the caller says the batch is ONE graph: accumulate bit 2) the
+    // ones that straddle two graphs
+    hipLaunchKernelGGL(deslice_mfma_kernel, dim3(gfv_div_up((long)N * H, 256)), dim3(256), 0, (hipStream_t)stream, w, T, batch, out, N);
+    if (!(accumulate & 4))
+      hipLaunchKernelGGL(deslice_kernel, dim3(gfv_div_up((long)N * H, 256)), dim3(256), 0, (hipStream_t)stream, w, T, batch, out, N, 2);
+  } else {
+    accumulate &= 1;
+    hipLaunchKernelGGL(deslice_kernel, dim3(gfv_div_up((long)N * H, 256)), dim3(256), 0, (hipStream_t)stream, w, T, batch,
+                       out, N, accumulate);
+  }
   GFV_CHECK_LAUNCH();
   return GFV_OK;
 }

@@ -787,12 +787,19 @@ class Engine:
                           [fx_mid, x_mid], in_add=emb, in_save=fx_in)
         w = _empty(dev, N, 256)
         temp = P[f"{a}.graph_temperature"]
-        L.check(lib.gfv_slice_softmax_fwd(x_mid.data_ptr(), P[f"{a}.in_project_slice.weight"].data_ptr(),
-                                          P[f"{a}.in_project_slice.bias"].data_ptr(), temp.data_ptr(), w.data_ptr(), N,
-                                          st), "slice_softmax_fwd")
         partial = _empty(dev, pl.n_chunks, 256, 17)
-        L.check(lib.gfv_slice_token_partial(w.data_ptr(), fx_mid.data_ptr(), pl.chunk_beg.data_ptr(),
-                                            pl.chunk_end.data_ptr(), pl.n_chunks, partial.data_ptr(), st), "token_partial")
+        if self._slice_fuse:
+            # slice softmax + per-chunk token sums in one pass (w is written on the way, not re-read)
+            L.check(lib.gfv_slice_softmax_token(x_mid.data_ptr(), P[f"{a}.in_project_slice.weight"].data_ptr(),
+                                                P[f"{a}.in_project_slice.bias"].data_ptr(), temp.data_ptr(), fx_mid.data_ptr(),
+                                                pl.chunk_beg.data_ptr(), pl.chunk_end.data_ptr(), pl.n_chunks, w.data_ptr(),
+                                                partial.data_ptr(), st), "slice_softmax_token")
+        else:
+            L.check(lib.gfv_slice_softmax_fwd(x_mid.data_ptr(), P[f"{a}.in_project_slice.weight"].data_ptr(),
+                                              P[f"{a}.in_project_slice.bias"].data_ptr(), temp.data_ptr(), w.data_ptr(), N,
+                                              st), "slice_softmax_fwd")
+            L.check(lib.gfv_slice_token_partial(w.data_ptr(), fx_mid.data_ptr(), pl.chunk_beg.data_ptr(),
+                                                pl.chunk_end.data_ptr(), pl.n_chunks, partial.data_ptr(), st), "token_partial")
         partial = self._graph_partials(partial, pl)
         token, norm = _empty(dev, B, 8, 32, 16), _empty(dev, B, 8, 32)
         attn, out_token = _empty(dev, B, 8, 32, 32), _empty(dev, B, 8, 32, 16)
@@ -801,8 +808,8 @@ class Engine:
                                             token.data_ptr(), norm.data_ptr(), attn.data_ptr(), out_token.data_ptr(), st),
                 "slice_attention_fwd")
         out_x = _empty(dev, N, 128)
-        L.check(lib.gfv_deslice(w.data_ptr(), out_token.data_ptr(), pl.batch.data_ptr(), out_x.data_ptr(), N, 0, st),
-                "deslice")
+        L.check(lib.gfv_deslice(w.data_ptr(), out_token.data_ptr(), pl.batch.data_ptr(), out_x.data_ptr(), N,
+                                4 if B == 1 else 0, st), "deslice")
         fx1 = _empty(dev, N, 128)
         ops.rowtile_chain(N, [Seg(out_x)], [LayerSpec(P[f"{a}.to_out.0.weight"], P[f"{a}.to_out.0.bias"])], [fx1],
                           res=[fx_in])

@@ -130,6 +130,7 @@ _SIGNATURES = {
     "gfv_slice_attention_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gfv_deslice": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "gfv_slice_gw": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    "gfv_slice_softmax_token": (C.c_int, [C.c_void_p] * 7 + [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gfv_slice_post_bwd": (C.c_int, [C.c_void_p] * 14 + [C.c_int32, C.c_int32, C.c_void_p]),
     "gfv_phi_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "gfv_phi_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),

@@ -352,7 +352,13 @@ int gfv_slice_attention_fwd(const float* partial, const int32_t* gchunk_ptr, int
 int gfv_slice_attention_bwd(const float* gpartial, const int32_t* gchunk_ptr, int32_t B, const float* Wq, const float* Wk,
                             const float* Wv, const float* token, const float* norm, const float* attn, float* g_raw,
                             float* g_norm, float* dW_partial, void* stream);
-/* out[n,h,:] (+)= sum_g w[n,h,g] T[batch[n],h,g,:] */
+/* gfv_slice_softmax_fwd followed by gfv_slice_token_partial(w, a) in one pass (w is written out as well): the forward of
+ * GraphTransolver.py:64-73 up to the per-chunk slice tokens, on the matrix cores (v_mfma_f32_16x16x4_f32, exact fp32) */
+int gfv_slice_softmax_token(const float* xmid, const float* Ws, const float* bs, const float* temp, const float* a,
+                            const int32_t* chunk_beg, const int32_t* chunk_end, int32_t n_chunks, float* w, float* partial,
+                            void* stream);
+/* out[n,h,:] (+)= sum_g w[n,h,g] T[batch[n],h,g,:].  accumulate: bit 0 = add into out; bit 2 (value 4) = the batch is ONE
+ * graph (spares the pass over workgroups that straddle two graphs) */
 int gfv_deslice(const float* w, const float* T, const int32_t* batch, float* out, int32_t N, int32_t accumulate,
                 void* stream);
 /* gw[n,h,g] (+)= sum_c a[n,h,c] T[batch[n],h,g,c] + add[batch[n],h,g] */

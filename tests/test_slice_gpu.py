@@ -62,3 +62,49 @@ def test_one_pass_slice_adjoint_equals_the_four_launches(N, sizes):
     dWs = torch.einsum("nhg,nhc->gc", gl, x)
     assert rel(sp1[:, :512].sum(0).view(32, 16), dWs) < 1e-5
     assert rel(sp1[:, 512:544].sum(0), gl.sum((0, 1))) < 1e-5
+
+
+@pytest.mark.parametrize("N,sizes", [(5000, [1700, 2100, 1200]), (77, [77]), (1000, [3, 500, 497])])
+def test_matrix_core_token_and_deslice_kernels_equal_the_scalar_ones(N, sizes, monkeypatch):
+    """gfv_slice_softmax_token (softmax + per-chunk token sums in one pass), the matrix-core form of gfv_slice_token_partial
+    and of gfv_deslice against float64 statements of GraphTransolver.py:64-73,90-92."""
+    from gfv import lib as L
+    lib = L.load()
+    st = L.stream_ptr()
+    c = _case(N, sizes, N + 1)
+    p = lambda t: t.data_ptr()
+    # chunks of 64 nodes inside each graph (gfv/plan.py _batch_part)
+    cb, ce, start = [], [], 0
+    for n in sizes:
+        for s0 in range(start, start + n, 64):
+            cb.append(s0)
+            ce.append(min(s0 + 64, start + n))
+        start += n
+    cbd, ced = torch.tensor(cb, dtype=torch.int32).cuda(), torch.tensor(ce, dtype=torch.int32).cuda()
+    nch = len(cb)
+    w1 = torch.full((N, 256), float("nan"), device="cuda")
+    part1 = torch.full((nch, 256, 17), float("nan"), device="cuda")
+    L.check(lib.gfv_slice_softmax_token(p(c["xmid"]), p(c["Ws"]), p(c["bs"]), p(c["temp"]), p(c["fxm"]), p(cbd), p(ced), nch,
+                                        p(w1), p(part1), st), "softmax_token")
+    part2 = torch.full((nch, 256, 17), float("nan"), device="cuda")
+    L.check(lib.gfv_slice_token_partial(p(w1), p(c["gox"]), p(cbd), p(ced), nch, p(part2), st), "token_partial")
+    out = torch.full((N, 128), float("nan"), device="cuda")
+    L.check(lib.gfv_deslice(p(w1), p(c["T1"]), p(c["batch"]), p(out), N, 4 if len(sizes) == 1 else 0, st), "deslice")
+    torch.cuda.synchronize()
+    d = lambda t: t.double().cpu()
+    x = d(c["xmid"]).view(N, 8, 16)
+    logits = (torch.einsum("nhc,gc->nhg", x, d(c["Ws"])) + d(c["bs"])) / d(c["temp"]).view(1, 8, 1)
+    wref = torch.softmax(logits, -1)
+    rel = lambda a, r: float((a.double().cpu() - r).abs().max() / r.abs().max())
+    assert rel(w1.view(N, 8, 32), wref) < 1e-5
+    wd = d(w1).view(N, 8, 32)
+    for part, a in ((part1, c["fxm"]), (part2, c["gox"])):
+        av = d(a).view(N, 8, 16)
+        for k in range(nch):
+            sl = slice(cb[k], ce[k])
+            tok = torch.einsum("nhg,nhc->hgc", wd[sl], av[sl]).reshape(256, 16)
+            assert rel(part[k, :, :16], tok) < 1e-5, k
+            assert rel(part[k, :, 16], wd[sl].sum(0).reshape(256)) < 1e-5, k
+    b = c["batch"].long().cpu()
+    ref = torch.einsum("nhg,nhgc->nhc", wd, d(c["T1"])[b]).reshape(N, 128)
+    assert rel(out, ref) < 1e-5
