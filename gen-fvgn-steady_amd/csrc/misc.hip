@@ -79,6 +79,57 @@ __global__ __launch_bounds__(1024) void graph_norm_stats_kernel(const float* __r
   }
 }
 
+// The same statistics over many workgroups (one workgroup reads a 25 k-node graph at the bandwidth of ONE CU: 2 x 8 us): each
+// of NB blocks per graph sums x and x^2 of its share of the rows in double, a second small launch folds the NB partials in
+// a fixed order.  mean and E[x^2] - mean^2 in double are the exact statistics of the fp32 data (the reference's two fp32
+// sweeps are one rounding error of that away).
+constexpr int NORM_NB = 64;
+__global__ __launch_bounds__(256) void graph_norm_partial_kernel(const float* __restrict__ x, int ldx, const int* __restrict__ gnode_ptr,
+                                                                 double* __restrict__ ws) {
+  __shared__ double red[4][6];
+  const int b = blockIdx.y, blk = blockIdx.x, tid = threadIdx.x;
+  const int beg = gnode_ptr[b], end = gnode_ptr[b + 1];
+  double s[3] = {0.0, 0.0, 0.0}, q[3] = {0.0, 0.0, 0.0};
+  for (int i = beg + blk * 256 + tid; i < end; i += NORM_NB * 256) {
+    const float* r = x + (size_t)i * ldx;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const double v = (double)r[c];
+      s[c] += v;
+      q[c] += v * v;
+    }
+  }
+  // fixed-order fold: lanes of a wave (xor butterflies are order-symmetric), then the four waves
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+      s[c] += __shfl_xor(s[c], o);
+      q[c] += __shfl_xor(q[c], o);
+    }
+  }
+  if ((tid & 63) == 0) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { red[tid >> 6][c] = s[c]; red[tid >> 6][3 + c] = q[c]; }
+  }
+  __syncthreads();
+  if (tid < 6) ws[((size_t)b * NORM_NB + blk) * 6 + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+}
+__global__ __launch_bounds__(64) void graph_norm_final_kernel(const double* __restrict__ ws, const int* __restrict__ gnode_ptr,
+                                                              float* __restrict__ stats) {
+  const int b = blockIdx.x, tid = threadIdx.x;
+  if (tid >= 3) return;
+  const double cnt = fmax((double)(gnode_ptr[b + 1] - gnode_ptr[b]), 1.0);
+  double s = 0.0, q = 0.0;
+  for (int k = 0; k < NORM_NB; ++k) {
+    s += ws[((size_t)b * NORM_NB + k) * 6 + tid];
+    q += ws[((size_t)b * NORM_NB + k) * 6 + 3 + tid];
+  }
+  const double mean = s / cnt, var = fmax(q / cnt - mean * mean, 0.0);
+  stats[6 * b + tid] = (float)mean;
+  stats[6 * b + 3 + tid] = (float)sqrt(var);
+}
+
 // column sums / sums of squares of x[:, 3:12] -> per-block partials [nblocks][18]
 __global__ __launch_bounds__(256) void normalizer_partial_kernel(const float* __restrict__ x, int ldx, int N,
                                                                  float* __restrict__ partial) {
@@ -228,6 +279,20 @@ extern "C" int gfv_graph_norm_stats(const float* x, int32_t ldx, const int32_t* 
   GfvProfScope ps_(GFV_K_MISC, 0, 12.0 * 0.0, stream);
   if (B <= 0) return GFV_OK;
   hipLaunchKernelGGL(graph_norm_stats_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, x, ldx, gnode_ptr, stats);
+  GFV_CHECK_LAUNCH();
+  return GFV_OK;
+}
+
+extern "C" size_t gfv_graph_norm_workspace_bytes(int32_t B) { return (size_t)(B > 0 ? B : 0) * NORM_NB * 6 * sizeof(double); }
+extern "C" int gfv_graph_norm_stats_ws(const float* x, int32_t ldx, const int32_t* gnode_ptr, int32_t B, float* stats,
+                                       void* workspace, void* stream) {
+  GfvProfScope ps_(GFV_K_MISC, 0, 12.0 * 0.0, stream);
+  if (B <= 0) return GFV_OK;
+  if (!workspace || (reinterpret_cast<size_t>(workspace) & 7)) return GFV_ERR_ARG;
+  hipLaunchKernelGGL(graph_norm_partial_kernel, dim3(NORM_NB, B), dim3(256), 0, (hipStream_t)stream, x, ldx, gnode_ptr,
+                     reinterpret_cast<double*>(workspace));
+  hipLaunchKernelGGL(graph_norm_final_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, reinterpret_cast<const double*>(workspace),
+                     gnode_ptr, stats);
   GFV_CHECK_LAUNCH();
   return GFV_OK;
 }

@@ -1040,7 +1040,10 @@ class Engine:
         dev = x.device
         assert x.is_contiguous() and x.shape[1] == 12
         stats = _empty(dev, B, 6)
-        L.check(lib.gfv_graph_norm_stats(x.data_ptr(), 12, pl.gnode_ptr.data_ptr(), B, stats.data_ptr(), st), "norm_stats")
+        # per-graph mean / std over 64 workgroups per graph (double partial sums, folded in a fixed order)
+        nws = _empty(dev, B, 64 * 12)   # = gfv_graph_norm_workspace_bytes(B) / 4 floats (64 x 6 doubles per graph)
+        L.check(lib.gfv_graph_norm_stats_ws(x.data_ptr(), 12, pl.gnode_ptr.data_ptr(), B, stats.data_ptr(), nws.data_ptr(), st),
+                "norm_stats")
         mean_std = _empty(dev, 18)
         if norm_global:
             nb = lib.gfv_normalizer_blocks(N)

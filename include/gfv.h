@@ -449,6 +449,11 @@ int gfv_fvm_bwd_ex(const float* cres, const float* sums, const float* gloss, con
  * pre_train_Adam.py:177-184.
  * ---------------------------------------------------------------------------------------------------------- */
 int gfv_graph_norm_stats(const float* x, int32_t ldx, const int32_t* gnode_ptr, int32_t B, float* stats, void* stream);
+/* the same over 64 workgroups per graph (a single workgroup reads at the bandwidth of one CU): sums of x and x^2 in double per
+ * workgroup, folded in a fixed order by a second small launch; workspace: gfv_graph_norm_workspace_bytes(B) bytes */
+size_t gfv_graph_norm_workspace_bytes(int32_t B);
+int gfv_graph_norm_stats_ws(const float* x, int32_t ldx, const int32_t* gnode_ptr, int32_t B, float* stats, void* workspace,
+                            void* stream);
 int gfv_normalizer_blocks(int32_t N);
 int gfv_normalizer_update(const float* x, int32_t ldx, int32_t N, int32_t accumulate, float* acc_count, float* num_acc,
                           float* acc_sum, float* acc_sq, float* partial_ws, float* mean_std, void* stream);

@@ -516,3 +516,33 @@ def test_cell_to_node_with_cell_grad_uses_the_cells_own_gradient():
     ref2 = torch.zeros(gn.pos.shape[0], 3, dtype=torch.float64).index_add(0, cells_node, (pr[cells_index] + corr) * w) / den
     (ref2 * wgt.double()).sum().backward()
     assert rel(pd.grad, pr.grad) < 1e-4 and rel(gd.grad, gr.grad) < 1e-4
+
+
+def test_per_graph_norm_statistics_many_workgroup_form():
+    """gfv_graph_norm_stats_ws (64 workgroups per graph, double partial sums) against the one-workgroup form and float64:
+    mean and population std of x[:, 0:3] per graph (importer.py:80-93), graphs of very different sizes, a large offset."""
+    from gfv import lib as L
+    lib = L.load()
+    st = L.stream_ptr()
+    g = torch.Generator().manual_seed(2)
+    sizes = [25479, 7, 3000, 1]
+    N = sum(sizes)
+    x = torch.randn(N, 12, generator=g)
+    x[:, 2] = x[:, 2] * 1e-3 + 50.0            # a column whose mean dwarfs its spread
+    ptr = torch.tensor([0] + list(torch.tensor(sizes).cumsum(0)), dtype=torch.int32).cuda()
+    xd = x.cuda()
+    B = len(sizes)
+    s1, s2 = torch.empty(B, 6, device="cuda"), torch.empty(B, 6, device="cuda")
+    ws = torch.empty(lib.gfv_graph_norm_workspace_bytes(B) // 4, device="cuda")
+    L.check(lib.gfv_graph_norm_stats(xd.data_ptr(), 12, ptr.data_ptr(), B, s1.data_ptr(), st), "one workgroup")
+    L.check(lib.gfv_graph_norm_stats_ws(xd.data_ptr(), 12, ptr.data_ptr(), B, s2.data_ptr(), ws.data_ptr(), st), "many")
+    torch.cuda.synchronize()
+    o = 0
+    for b, n in enumerate(sizes):
+        seg = x[o:o + n, 0:3].double()
+        mean, std = seg.mean(0), seg.var(0, unbiased=False).sqrt()
+        for c in range(3):
+            assert abs(float(s2[b, c]) - float(mean[c])) <= 1e-6 * max(1.0, abs(float(mean[c])))
+            assert abs(float(s2[b, 3 + c]) - float(std[c])) <= 1e-5 * float(std[c]) + 1e-9
+            assert abs(float(s1[b, 3 + c]) - float(std[c])) <= 2e-3 * float(std[c]) + 1e-9   # (two fp32 sweeps: looser)
+        o += n
