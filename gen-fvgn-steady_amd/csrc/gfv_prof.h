@@ -8,7 +8,8 @@ enum { GFV_K_ROWTILE = 1, GFV_K_DW = 2, GFV_K_SEG = 3, GFV_K_SLICE = 4, GFV_K_FV
        GFV_K_TCHAIN_CSR = 13,                                    // tchain_kernel<1, 0, false, H, 4, true>: segmented-sum segments
        GFV_K_COLCHAIN_BWD = 14,                                  // colchain_bwd_kernel: dX chain with fused weight gradients
        GFV_K_COLCHAIN_FWD = 15,                                  // colchain_fwd*_kernel (column-owner forward family)
-       GFV_K_COUNT = 16 };
+       GFV_K_LIN1 = 16,                                          // lin1_*_kernel: single-layer launches of gfv_rowtile_chain on the lean kernel
+       GFV_K_COUNT = 17 };
 bool gfv_prof_enabled();
 void* gfv_prof_begin(int kind, double flops, double bytes, hipStream_t st);
 void gfv_prof_end(void* tok, hipStream_t st);

@@ -517,7 +517,8 @@ int l1_env(const char* n, int dflt) {
 }  // namespace
 
 // 1: launched; 0: not a launch of this family.  lowp: the reduced-precision product form (one product per term).
-int gfv_internal_lin1_try(const gfv_rowtile_args_t* a, int lowp, hipStream_t stream) {
+// dry != 0: only tell whether the launch would be taken (the profiler prices it as this family's before it is issued)
+int gfv_internal_lin1_try(const gfv_rowtile_args_t* a, int lowp, hipStream_t stream, int dry) {
   static const int on = l1_env("GFV_LIN1", 1);
   static const int min_m = l1_env("GFV_LIN1_MIN_M", 1024);
   if (!on || a->nlayers != 1 || a->M < min_m || (a->flags & (GFV_CHAIN_ROW_OWNER | GFV_CHAIN_COLUMN_OWNER))) return 0;
@@ -542,6 +543,7 @@ int gfv_internal_lin1_try(const gfv_rowtile_args_t* a, int lowp, hipStream_t str
     B.out = a->out[0];
     B.out_ld = a->out_ld[0];
     B.M = a->M;
+    if (dry) return 1;
     int* st = gfv_internal_status_ptr();
     const dim3 grid((a->M + 127) / 128), blk(512);
     if (lowp) {
@@ -586,6 +588,7 @@ int gfv_internal_lin1_try(const gfv_rowtile_args_t* a, int lowp, hipStream_t str
     B.fgamma = a->fin_gamma;
     B.ln_partial = a->ln_partial;
     B.n_tiles = (a->M + 63) / 64;
+    if (dry) return 1;
     int* st = gfv_internal_status_ptr();
     const dim3 grid((a->M + 127) / 128), blk(512);
     if (lowp) {
@@ -649,6 +652,7 @@ int gfv_internal_lin1_try(const gfv_rowtile_args_t* a, int lowp, hipStream_t str
   }
   A.aux = L.aux;
   A.gscale = a->gscale;
+  if (dry) return 1;
   int* st = gfv_internal_status_ptr();
   const dim3 grid((a->M + 127) / 128), blk(512);
   // instantiated: (in_op none | GELU | LayerNorm) without the GELU' epilogue, in_op none with it

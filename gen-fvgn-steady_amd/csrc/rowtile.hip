@@ -530,7 +530,7 @@ extern "C" int gfv_rowtile_chain(const gfv_rowtile_args_t* args, void* stream) {
   g_hidden = h0;
   return rc;
 }
-int gfv_internal_lin1_try(const gfv_rowtile_args_t* a, int lowp, hipStream_t stream);   // lin1.hip
+int gfv_internal_lin1_try(const gfv_rowtile_args_t* a, int lowp, hipStream_t stream, int dry);   // lin1.hip
 static int rowtile_chain_impl(const gfv_rowtile_args_t* args, void* stream) {
   if (!args || args->M < 0 || args->nlayers < 1 || args->nlayers > 3 || args->nseg < 1 || args->nseg > 3) return GFV_ERR_ARG;
   if (args->M == 0) return GFV_OK;
@@ -626,6 +626,8 @@ static int rowtile_chain_impl(const gfv_rowtile_args_t* args, void* stream) {
     int kind = (fast_t && tchain_mode() != 0) ? GFV_K_TCHAIN0 + lnm : ((rag_t && tchain_mode() != 0) ? GFV_K_TCHAIN_RAG : GFV_K_ROWTILE);
     for (int i = 0; i < args->nseg; ++i)
       if (args->seg[i].csr_rowptr || args->seg[i].save) kind = GFV_K_TCHAIN_CSR;
+    if (fast_t && f16 && args->nlayers == 1 && gfv_internal_lin1_try(args, f16_mode() == 2 ? 1 : 0, (hipStream_t)stream, 1))
+      kind = GFV_K_LIN1;   // the lean single-layer kernel (same algorithmic work as the chain launch it stands in for)
     if (args->dw_partial) {
       // dX chain with fused weight gradients (column-owner backward family): + the two (three) weight-gradient GEMMs, the
       // forward's row statistics read, the first Linear's input rows read, the per-workgroup blocks written
@@ -638,7 +640,7 @@ static int rowtile_chain_impl(const gfv_rowtile_args_t* args, void* stream) {
   }
   g_last_path = (tchain_mode() != 0 && (fast_t || rag_t)) ? ((fast_t ? 1 : 2) + (f16 ? 4 : 0)) : 0;
   if (args->dw_partial && !(fast_t && tchain_mode() != 0 && f16)) return GFV_ERR_ARG;   // (fused weight gradients: ask gfv_rowtile_fuses_dw first)
-  if (fast_t && f16 && args->nlayers == 1 && gfv_internal_lin1_try(args, f16_mode() == 2 ? 1 : 0, (hipStream_t)stream)) {
+  if (fast_t && f16 && args->nlayers == 1 && gfv_internal_lin1_try(args, f16_mode() == 2 ? 1 : 0, (hipStream_t)stream, 0)) {
     g_last_path += 32;   // the lean single-layer kernel (lin1.hip)
   } else if (fast_t && tchain_mode() != 0) {
     const int took = gfv_internal_tchain_launch(args, 0, f16 ? 1 : 0, (hipStream_t)stream);   // 1: the column-owner family, 2: with fused dW

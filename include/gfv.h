@@ -512,7 +512,8 @@ int gfv_profile_collect(int kind, double* out);
 int gfv_profile_reset(void);
 /* kinds: 1 row-tile chain (LDS form), 2 weight gradient, 3 segmented reduce, 4 Transolver slice kernels, 5 finite-volume
  * kernels, 6 input preparation / loss / Adam, 7-10 register-resident chain instantiations, 11 deterministic second-stage
- * reductions, 12 per-step weight images and transposed copies.  Sizes an entry point cannot see from its arguments
+ * reductions, 12 per-step weight images and transposed copies, 13 chain launches with segmented-sum segments, 14 / 15 the
+ * column-owner backward (fused weight gradients) / forward family, 16 single-layer launches on the lean kernel.  Sizes an entry point cannot see from its arguments
  * (directed stencil entries S, (cell, face) incidences Sigma) are given here so the finite-volume kernels can be priced. */
 int gfv_profile_set_sizes(double stencil_entries, double incidences);
 
