@@ -54,9 +54,12 @@ int gfv_gather_pair(const float* a, const int32_t* s, const int32_t* r, const fl
                     int32_t n_edges, int32_t F, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
- * Row-tile fused GEMM chain on fp32 MFMA (v_mfma_f32_16x16x4_f32): up to three Linear layers applied to a tile
- * of 64 rows that stays in LDS, with gather/concat/LayerNorm prologues and bias/GELU/LayerNorm/residual
- * epilogues.  Forward and the dX-chain of the backward are the same kernel with different element ops.
+ * Fused GEMM chain: up to three Linear layers applied to a tile of rows, with gather / concat / segmented-sum / LayerNorm
+ * prologues and bias / GELU / LayerNorm / residual epilogues; forward and the dX chain of the backward are the same entry
+ * with different element ops.  One entry point, several kernel families behind it (gfv_rowtile_last_path tells which):
+ * the register-resident row-owner chain (a wave owns 16 rows; split-fp16 products from per-step weight images, or fp32
+ * MFMA), the column-owner persistent backward with fused weight gradients (dw_partial), the lean kernel for single-layer
+ * launches, and - for shapes none of them takes - a generic kernel whose 64-row tile stays in LDS (fp32 MFMA).
  * Replaces nn.Linear/GELU/LayerNorm inside build_mlp (FVMmodel/Models/FVGN/EPD.py:10-63), the concat + MLP of
  * EdgeBlock/NodeBlock (blocks.py:54,101-111) and the Linear layers of the Transolver block
  * (FVMmodel/Models/GraphTransolver/GraphTransolver.py:54-59,95,98-128,163-169).
