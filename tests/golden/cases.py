@@ -68,15 +68,22 @@ REAL_MESHES = {
 }
 
 
-def real_mesh(name, golden_dir=None):
-    """One of REAL_MESHES -> (graphs, fixture, mesh dict)."""
+def int_fingerprint(a):
+    """[columns, sum of row 0, sum of row 1, position-dependent checksum] of a [2, n] int64 index array."""
+    a = np.asarray(a, dtype=np.int64)
+    pos = np.arange(a.shape[1], dtype=np.int64) % 8191
+    return np.array([a.shape[1], int(a[0].sum()), int(a[1].sum()), int(((a[0] * 31 + a[1] * 17 + pos) % 1000003).sum())], dtype=np.int64)
+
+
+def real_mesh(name, golden_dir=None, device=None):
+    """One of REAL_MESHES -> (graphs, fixture, mesh dict).  device: prepare the stencil / moments with gfv.device_prep there."""
     import json
     golden_dir = golden_dir or os.path.dirname(os.path.abspath(__file__))
     fx = np.load(os.path.join(golden_dir, name + ".npz"))
     raw = {k[4:]: (fx[k].astype(np.int64) if fx[k].dtype.kind == "i" else fx[k]) for k in fx.files
            if k.startswith("raw.") and k != "raw.bc"}
     raw["bc"] = json.loads(str(fx["raw.bc"]))
-    mesh = meshgen.finish_mesh(raw)
+    mesh = meshgen.finish_mesh(raw, device=device)
     return build_batch([mesh], [fx["field"]]), fx, mesh
 
 

@@ -31,7 +31,9 @@ MESHES = {
 }
 
 
-def generate(fixture):
+def reference_arrays(fixture):
+    """The reference's own mesh pipeline on one of its example meshes: (R, md, captured, mesh, bc, th, params, init_uvp) -
+    md holds every array `transform_mesh` produced (what make_prep_golden.py fingerprints)."""
     import importlib
     import json
     sub, mesh_file, pde_seed, field_seed = MESHES[fixture]
@@ -83,6 +85,13 @@ def generate(fixture):
         "uvp_dim": n("uvp_dim").astype(np.float32), "sigma": n("sigma").astype(np.float32),
         "target|uvp": n("target|uvp").astype(np.float32), "init_uvp": init_uvp.numpy().astype(np.float32),
     }
+    return R, md, captured, mesh, bc, th, params, init_uvp
+
+
+def generate(fixture):
+    import json
+    _sub, _mesh_file, _pde_seed, field_seed = MESHES[fixture]
+    R, md, captured, mesh, bc, th, params, init_uvp = reference_arrays(fixture)
     rng = np.random.default_rng(field_seed)
     field = (rng.uniform(-1, 1, size=(md["node|pos"].shape[0], 3)) * md["uvp_dim"].astype(np.float64)).astype(np.float32)
     graphs = build_batch([md], [field])

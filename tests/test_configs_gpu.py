@@ -257,3 +257,15 @@ def test_unsteady_twenty_inner_iterations_on_the_naca0012_mesh(golden_dir):
           f"|delta| {perr:.2e}; loss {first:.4f} -> {last:.4f}")
     assert last < first
     assert worst < 1e-4 and xerr < 1e-3 and perr < 20 * 2 * 5e-5
+
+
+@pytest.mark.parametrize("name", sorted(cases.REAL_MESHES))
+def test_device_preprocessing_matches_reference_generated_fingerprints(golden_dir, name):
+    """Row f2 on the device: the HIP kernels behind gfv.device_prep (gfv_khop_count / gfv_khop_fill, gfv_wlsq_moments) on the
+    reference's own example meshes against the stencil and the moment arrays the REFERENCE's pipeline produced
+    (tests/golden/make_prep_golden.py) - not against the build's host code."""
+    import os
+    from test_oracle_golden import _check_prep_against_reference
+    fp = np.load(os.path.join(golden_dir, "real_prep_fp.npz"))
+    _g, _fx, mesh = cases.real_mesh(name, golden_dir, device="cuda")
+    _check_prep_against_reference(mesh, fp, name)

@@ -482,3 +482,19 @@ def test_reduced_precision_form_against_the_fp32_oracle(name):
     assert meas["grad_norm"] < LOWP_TOL["grad_norm"], meas
     assert max(meas.values()) > 1e-6, "the reduced-precision switch did not reach the kernels"
     print("reduced-precision form vs fp32 oracle,", name, {k: f"{v:.2e}" for k, v in meas.items()})
+
+
+@pytest.mark.parametrize("case", ["cavity_mixed_b1", "cyl_cavity_b2", "poisson_b1", "cyl_b3"])
+def test_small_fixtures_against_the_float64_oracle(case):
+    """The float64 comparison of tests/test_fullsize_gpu.py on the small fixtures too: forward quantities within
+    1e-5 of the float64 oracle, gradients by the same three criteria (norm-wise 1e-5 or the fp32 oracle's own distance,
+    element-wise 1e-4 of scale outside the slice-attention group, median 2e-5)."""
+    from test_fullsize_gpu import check_gradients, compare_to_fp64
+    graphs = cases.make_graphs(case)
+    P = O.init_parameters(cases.WEIGHT_SEED)
+    report, _ = compare_to_fp64(graphs, P, case)
+    for key in ("loss_cont", "loss_mom_x", "loss_mom_y", "loss_press", "uvp_node", "uvp_cell", "loss"):
+        if report[key][0] == 0.0 and report[key][1] == 0.0:
+            continue
+        assert report[key][0] < TOL, (key, report[key])
+    check_gradients(report, case)

@@ -108,6 +108,26 @@ def test_oracle_on_more_reference_example_meshes(golden_dir, name):
     assert abs(float(O.training_loss(out)) - float(fx["loss"])) < TOL * abs(float(fx["loss"]))
 
 
+def _check_prep_against_reference(mesh, fp, name):
+    """k-hop stencil (integers: exact) and WLSQ moment arrays (floats: fingerprints to 1e-6) of a finished mesh against what the
+    REFERENCE's pipeline produced on the same example mesh (tests/golden/make_prep_golden.py)."""
+    fx = np.asarray(mesh["face_node_x"], dtype=np.int64)
+    assert np.array_equal(cases.int_fingerprint(fx), fp[name + ".stencil"]), name
+    assert np.array_equal(fx[:, :64], fp[name + ".stencil_head"].astype(np.int64)), name
+    for k in ("A_node_to_node", "single_B_node_to_node", "extra_B_node_to_node"):
+        mine, want = cases.fingerprint(np.asarray(mesh[k], dtype=np.float64)), fp[name + "." + k]
+        assert np.all(np.abs(mine - want) <= 1e-6 * np.abs(want[1]) + 1e-12), (name, k, mine, want)
+
+
+@pytest.mark.parametrize("name", sorted(cases.REAL_MESHES))
+def test_host_preprocessing_matches_reference_generated_fingerprints(golden_dir, name):
+    """Row f2 on the host: gfv.meshgen's k-hop stencil and moment matrices against the reference's own (these were
+    pinned only transitively)."""
+    fp = np.load(os.path.join(golden_dir, "real_prep_fp.npz"))
+    _g, _fx, mesh = cases.real_mesh(name, golden_dir)
+    _check_prep_against_reference(mesh, fp, name)
+
+
 def test_oracle_transfvgn_v1_matches_reference(golden_dir):
     """net='TransFVGN_v1' (one processor).  Fixture = the reference itself run with that net
     (tests/golden/make_golden_v1.py); the oracle's forward agrees bit for bit there (make_golden_v1.log)."""
