@@ -20,6 +20,9 @@ static int cc_cus() {
     hipDeviceProp_t pr;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) n = pr.multiProcessorCount;
     if (n <= 0) n = 256;
+    // (experiment: fewer persistent workgroups than CUs leaves CUs to the weight-gradient queue while a launch runs)
+    const int want = cc_env("GFV_COLCHAIN_WGS", 0);
+    if (want > 0 && want <= n) n = want;
   }
   return n;
 }
