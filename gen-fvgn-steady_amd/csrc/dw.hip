@@ -507,14 +507,17 @@ __global__ __launch_bounds__(256, 2) void dw_multi_h_kernel(const DwLaunch A) {
 extern "C" int gfv_reduce_partials(const float*, int32_t, int32_t, float*, int32_t, void*);
 
 extern "C" int gfv_dw_slabs(int32_t M, int32_t ntiles, int32_t* rows_per_slab) {
-  // aim at ~512 workgroups per launch (one full round at 2 per CU; measured best of 384/512/768/1024: fewer slabs =
-  // less partial-sum traffic), slabs of a multiple of 32 rows, at least 64 rows
+  // aim at ~256 workgroups per launch, slabs of a multiple of 32 rows, at least 64 rows.  (Rounds 1 - 2: 512, one full round
+  // at 2 per CU, best of 384 / 512 / 768 / 1024.  Since the dX chains accumulate two of every MLP's three weight gradients
+  // themselves the edge-level launches of this kernel are one tile wide and run beside a persistent backward launch: fewer,
+  // longer slabs = half the partial-sum traffic; step time with 512 / 384 / 320 / 256: 3.823 / 3.821 / 3.806 / 3.797 ms,
+  // profiles/r03_ab_dw_wgs.txt)
   if (ntiles < 1) ntiles = 1;
   static int wgs = 0, wgs_small = 0;
   if (wgs == 0) {
     const char* e = getenv("GFV_DW_WGS");
-    wgs = e ? atoi(e) : 512;
-    if (wgs < 1) wgs = 512;
+    wgs = e ? atoi(e) : 0;
+    if (wgs < 1) wgs = 0;   // 0: by size (below)
     // launches of < 40 000 rows (node-level MLPs): half as many, longer slabs - half the partial-sum traffic and one
     // workgroup per CU beside the dX chain of the next block (A/B on one box, profiles/tools/ab_env.sh, step time with
     // 128 / 192 / 256 / 320 / 512: 4.61 / 4.38 / 4.37 / 4.42 / 4.46 ms)
@@ -522,7 +525,9 @@ extern "C" int gfv_dw_slabs(int32_t M, int32_t ntiles, int32_t* rows_per_slab) {
     wgs_small = e ? atoi(e) : 256;
     if (wgs_small < 1) wgs_small = 256;
   }
-  long target = (M < 40000 ? wgs_small : wgs) / ntiles;
+  // one 50 k-cell mesh (75 k edge rows): 256; batches (8 meshes: 604 k rows) keep 512 - there 256 costs 1.8 % (23.13 against 22.73 ms)
+  const int wgs_big = wgs ? wgs : (M < 200000 ? 256 : 512);
+  long target = (M < 40000 ? wgs_small : wgs_big) / ntiles;
   if (target < 1) target = 1;
   long rows = (M + target - 1) / target;
   rows = ((rows + 31) / 32) * 32;
