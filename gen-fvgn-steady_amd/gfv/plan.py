@@ -284,12 +284,22 @@ def _live_tensors(graphs):
     return (gn.y, gn.node_type, ge.face_type, gi.theta_PDE, gi.sigma, gi.uvp_dim, gi.dt_graph)
 
 
+def _is_pooled(graphs):
+    """Batches assembled by gfv.pool.DevicePool carry their plan; its tensors (y, node / face types, PDE coefficients) ARE the
+    state - `reset_env` edits them in place - and the stub graph objects hold no copies of them to follow."""
+    return getattr(graphs[0], "_gfv_pool_plan", None) is not None
+
+
 def _live_key(graphs):
+    if _is_pooled(graphs):
+        return ()
     return tuple((t.data_ptr(), t._version) for t in _live_tensors(graphs))
 
 
 def _refresh_live(p, graphs):
     """Re-read the live data into the plan's own tensors IN PLACE (pointers held by captured hipGraphs stay valid)."""
+    if _is_pooled(graphs):
+        return
     y, node_type, face_type, theta, sigma, uvp_dim, dt = _live_tensors(graphs)
     for dst, src in ((p.y, y[:, 0:2]), (p.node_type, node_type.reshape(-1)), (p.ftype, face_type.reshape(-1)),
                      (p.theta, theta), (p.sigma, sigma), (p.uvp_dim, uvp_dim), (p.dt, dt.reshape(-1))):

@@ -167,3 +167,48 @@ def test_reset_env_on_the_device_equals_host_transform_mesh():
         assert float((mine - want).abs().max()) <= 2e-7 * float(want.abs().max())
     n0 = ms[0]["node|pos"].shape[0]
     assert float(graphs[0].x[:n0, 0].abs().max()) > 0 and float(plan.y[:n0, 0].max()) > 1.0   # a parabolic inlet profile
+
+
+def test_trainstep_on_pooled_batches_set_batch_and_step():
+    """`TrainStep` over batches of a `DevicePool` (`set_batch` + `step`, the path gfv/pool.py advertises and
+    profiles/pool_timing.py times).  Pooled batches carry their plan; the stub graph objects have no `y` / `node_type` /
+    `face_type` for the live-data check to read.  The steps must equal those of a TrainStep over the rebuilt batches, and a
+    `reset_env` edit of the pooled plan must reach the next step (its tensors are the state)."""
+    from FVMmodel.importer import NNmodel
+    from gfv.graph import build_batch
+    from gfv.params import default_params
+    from gfv.pool import DevicePool
+    from gfv.trainer import TrainStep
+    ms, fs = _meshes()
+    P = O.init_parameters(cases.WEIGHT_SEED)
+
+    def model():
+        m = NNmodel(default_params(dataset_size=1))
+        sd = m.state_dict()
+        for k, v in P.items():
+            sd[k].copy_(v)
+        m.load_state_dict(sd)
+        return m.cuda()
+
+    batches = ([2, 0], [1, 3], [2, 0])
+    results = []
+    for pooled in (True, False):
+        pool = DevicePool(ms, fs)
+        mk = (lambda idx: pool.batch(idx)[0]) if pooled else (
+            lambda idx: build_batch([ms[i] for i in idx], [fs[i] for i in idx], device="cuda"))
+        g0 = mk(batches[0])
+        if not pooled:
+            g0[0].norm_uvp, g0[0].norm_global = True, True
+        ts = TrainStep(model(), g0, lr=1e-3, use_graph="list" if pooled else False)
+        losses = []
+        for k, idx in enumerate(batches):
+            if k:
+                g = mk(idx)
+                if not pooled:
+                    g[0].norm_uvp, g[0].norm_global = True, True
+                ts.set_batch(g)
+            for _ in range(4):     # (command list: two warm-up steps, the recording, one replay)
+                losses.append(float(ts.step()))
+        results.append((losses, ts.flat_p.clone()))
+    assert results[0][0] == results[1][0]
+    assert torch.equal(results[0][1], results[1][1])
