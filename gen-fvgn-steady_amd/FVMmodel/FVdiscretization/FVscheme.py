@@ -14,7 +14,9 @@ class _IntegratorPhiFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, engine, plan, phi8):
         GF.require_gpu(phi8)
-        losses, uvp_node, uvp_cell, sv = engine.fvm_core_fwd(phi8.detach().contiguous(), plan)
+        # raw_outputs: the smoothed node field BEFORE the Dirichlet overwrite and both fields un-scaled, as the reference's
+        # Intergrator returns them (FVscheme.py:253-262,718-724; importer.py:223-231 applies both afterwards)
+        losses, uvp_node, uvp_cell, sv = engine.fvm_core_fwd(phi8.detach().contiguous(), plan, raw_outputs=True)
         ctx.engine, ctx.plan, ctx.sv = engine, plan, sv
         ctx.mark_non_differentiable(uvp_node, uvp_cell)
         return losses, uvp_node, uvp_cell
@@ -39,11 +41,4 @@ class Intergrator(nn.Module):
                         conserved_form=bool(getattr(params, "conserved_form", True)),   # FVscheme.py:671-715
                         order=getattr(params, "order", "2nd"))                          # FVscheme.py:653
         losses, uvp_node, uvp_cell = _IntegratorPhiFn.apply(eng, plan, phi8)
-        # the reference returns the smoothed node field BEFORE the Dirichlet overwrite / re-dimensionalisation of
-        # importer.py:223-231; the fused kernel applies both, so undo the scaling here for the stand-alone operator
-        nb, cb = graph_node.batch, graph_cell.batch
-        scale_n = graph_Index.uvp_dim[nb] * graph_Index.sigma[nb]
-        scale_c = graph_Index.uvp_dim[cb] * graph_Index.sigma[cb]
-        safe = lambda t: torch.where(t == 0, torch.ones_like(t), t)
-        return (losses[:, 0:1], losses[:, 1:2], losses[:, 2:3], losses[:, 3:4], uvp_node / safe(scale_n),
-                uvp_cell / safe(scale_c))
+        return (losses[:, 0:1], losses[:, 1:2], losses[:, 2:3], losses[:, 3:4], uvp_node, uvp_cell)

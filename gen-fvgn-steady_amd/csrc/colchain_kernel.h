@@ -1,32 +1,27 @@
-// Column-owner persistent GEMM chain (gfx950): the second kernel family behind gfv_rowtile_chain (contract: include/gfv.h)
-// for the big 3-layer MLP launches of the GnBlocks (EPD.py:10-33 build_mlp inside blocks.py EdgeBlock / NodeBlock) in
-// the split-fp16 product form.
+// Column-owner persistent backward chain (gfx950): the kernel family behind gfv_rowtile_chain (contract: include/gfv.h) for
+// the backward of the big 3-layer MLP launches (EPD.py:10-33 build_mlp inside blocks.py EdgeBlock / NodeBlock, the encoders)
+// in the split-fp16 product form, with the weight gradients fused (gfv_rowtile_args_t.dw_partial).
 //
-// tchain_kernel.h gives every wave 16 ROWS and streams all three layers' weight images (192 KB) through LDS for every
-// 64-row tile: 12 slice barriers per tile, each behind an L2 round trip, and the tile's life is latency, not work
-// (profiles/r02_sq_counters.txt).  Here the roles are swapped:
+// tchain_kernel.h gives every wave 16 ROWS and streams the layers' weight images through LDS; the 128 x 128 output of a
+// weight gradient G^T A is then spread over rows no wave owns.  Here the roles are swapped:
 //
 //   * ONE workgroup of 8 waves per CU, persistent over a contiguous range of 16-row groups.  Wave w owns output COLUMNS
-//     16 w .. 16 w + 15 of every 128-wide layer and keeps ITS slice of all three weight images - the A operands
-//     W[16 w + i][k] of v_mfma_f32_16x16x32_f16, hi and lo parts, 32 VGPRs per 128-deep layer - in registers for the whole
-//     launch.  Weights are read once per workgroup (256 x 192 KB per launch instead of one 192 KB stream per 64 rows).
+//     16 w .. 16 w + 15 of every 128-wide layer; its slice of a layer's weight image - the A operands W[16 w + i][k] of
+//     v_mfma_f32_16x16x32_f16, hi and lo parts, 32 VGPRs per 128-deep layer - is fetched per tile one phase ahead of its use
+//     (4 KB per wave, L2 hits), and ITS n-tile of every fused weight gradient lives in registers for the whole launch.
 //   * LDS holds only activations, already in MFMA B-fragment form ([group][k-group T][part][lane] x 16 B: what
-//     to_halves() of the row-owner kernel builds in registers).  A tile is up to TG groups of 16 rows; per layer every
+//     to_halves() of the row-owner kernel builds in registers).  A tile is TG groups of 16 rows; per layer every
 //     wave reads all of the tile's fragments (one conflict-free ds_read_b128 per fragment), runs 12 MFMAs per group
-//     against its resident weights, applies the element ops to its 16 columns and writes its 8-byte share of the next
+//     against its weight slice, applies the element ops to its 16 columns and writes its 8-byte share of the next
 //     layer's fragments (the columns a wave produces are exactly half a k-group of the next layer: T' = w >> 1,
-//     slots 4 (w & 1) .. + 3).  One barrier per layer, four per tile of 128 rows.
-//   * Rows enter through "loader" roles: wave w < (groups in the tile) loads the 16 full rows of group w one tile ahead
-//     (global -> registers, no wait until the tile is consumed), takes the row's power-of-two scale (exact), splits
-//     and parks the fragments.  Hidden activations (GELU outputs) are split after a FIXED power-of-two scale CC_SH: a row scale would
+//     slots 4 (w & 1) .. + 3).  One barrier per phase.
+//   * Hidden activations (GELU outputs) are split after a FIXED power-of-two scale CC_SH: a row scale would
 //     need the row maximum over all eight waves (a second barrier per layer), and the split has 2^16 of slack - a hidden
 //     row with max |a| in [2^-4, 2^11] keeps every product at fp32 accuracy; beyond 2^11 the status flag
 //     GFV_FLAG_CHAIN_RANGE is raised (the values still convert up to 4095).
-//   * LayerNorm statistics of a row are spread over the eight waves: each leaves (mean, M2) of its 16 columns in LDS, after
-//     the barrier every lane combines the eight pairs (Chan's parallel form of the two-pass variance).
 //
-// Element-op semantics, argument struct and saved tensors are those of tchain_kernel.h (same launches, same results to
-// rounding: the summation order inside a dot product differs, and hidden activations carry the fixed scale).
+// (Round 3 also had two generations of a column-owner FORWARD here; parity-green and never faster than the row-owner chain -
+// DESIGN.md 5 - they were removed in round 4.)
 #pragma once
 #include "tchain_kernel.h"
 
@@ -36,24 +31,6 @@ constexpr int CC_W = 8;                  // waves per workgroup
 constexpr float CC_SH = 16.0f;           // fixed scale of hidden activations ahead of the fp16 split
 constexpr float CC_SH_INV = 1.0f / 16.0f;
 constexpr float CC_SH_LIMIT = 2048.0f;   // |a| beyond this raises GFV_FLAG_CHAIN_RANGE
-#ifndef GFV_CC_SPLIT
-#define GFV_CC_SPLIT 0
-#endif
-constexpr bool SPLIT = GFV_CC_SPLIT != 0;   // fragment reads | epilogue of the previous pair | MFMAs (else reads + MFMAs | epilogue)
-
-// LDS carve (bytes).  XIN: the tile's input fragments (KT0 k-groups), later the second hidden layer's (4 k-groups);
-// XMID: the first hidden layer's fragments, later each wave's stash of its last-layer values (TG x 1 KB per wave).
-template <int KT0, int TG>
-struct CcLds {
-  static constexpr int XIN = 0;
-  static constexpr int XMID = XIN + TG * KT0 * 2048;
-  static constexpr int SINV = XMID + TG * 8192;          // float [TG][16]: 1 / row scale of the input rows
-  static constexpr int IDXS = SINV + TG * 64;            // int   [TG][16]: gather rows of the first-layer addend (sender)
-  static constexpr int IDXR = IDXS + TG * 64;            //                                            (receiver)
-  static constexpr int LNP = IDXR + TG * 64;             // float2 [TG][16][8]: (mean, M2) of a row's 16 columns per wave
-  static constexpr int TOTAL = LNP + TG * 16 * 8 * 8;
-};
-
 // -DGFV_CC_TIMING: per wave, cycles spent in each phase and at each barrier, written through fin_presave's ... no:
 // through `status` + 64 (a debug build takes a bigger status buffer; scratch experiments only)
 #ifdef GFV_CC_TIMING
@@ -103,44 +80,6 @@ __device__ __forceinline__ void cc_mma_pair(const char* xbuf, int pair, const gf
   }
 }
 
-// the same in two steps, so that the epilogue arithmetic of the previous pair sits between the fragment reads and the MFMAs
-// that consume them (the LDS latency of 16 reads is ~ 1 k cycles for a wave that has nothing else to issue)
-template <int KT, bool LOWP>
-struct CcFrags {
-  gfv_f16x8 h0[KT], h1[KT], l0[LOWP ? 1 : KT], l1[LOWP ? 1 : KT];
-};
-template <int KT, bool LOWP>
-__device__ __forceinline__ void cc_frag_load(const char* xbuf, int pair, int lane, CcFrags<KT, LOWP>& f) {
-  const gfv_f16x8* f0 = reinterpret_cast<const gfv_f16x8*>(xbuf + (size_t)(2 * pair) * KT * 2048) + lane;
-  const gfv_f16x8* f1 = f0 + KT * 128;
-#pragma unroll
-  for (int T = 0; T < KT; ++T) {
-    f.h0[T] = f0[(2 * T) * 64];
-    f.h1[T] = f1[(2 * T) * 64];
-    if (!LOWP) {
-      f.l0[T] = f0[(2 * T + 1) * 64];
-      f.l1[T] = f1[(2 * T + 1) * 64];
-    }
-  }
-}
-template <int KT, bool LOWP>
-__device__ __forceinline__ void cc_mma_frags(const CcFrags<KT, LOWP>& f, const gfv_f16x8 (&wh)[KT], const gfv_f16x8 (&wl)[KT],
-                                             floatx4& a0, floatx4& a1) {
-  a0 = floatx4{0.f, 0.f, 0.f, 0.f};
-  a1 = floatx4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int T = 0; T < KT; ++T) {
-    if (!LOWP) {
-      a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[T], f.h0[T], a0, 0, 0, 0);
-      a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[T], f.h1[T], a1, 0, 0, 0);
-      a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[T], f.l0[T], a0, 0, 0, 0);
-      a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[T], f.l1[T], a1, 0, 0, 0);
-    }
-    a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[T], f.h0[T], a0, 0, 0, 0);
-    a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[T], f.h1[T], a1, 0, 0, 0);
-  }
-}
-
 // this lane's 4 values of one row -> its 8-byte share of the next layer's fragments (k-group w >> 1, half w & 1)
 __device__ __forceinline__ void cc_put_frag(char* xbuf, int q, const CcCtx& c, const float (&a)[4], float scale) {
   unsigned h0, h1, l0, l1;
@@ -150,339 +89,6 @@ __device__ __forceinline__ void cc_put_frag(char* xbuf, int q, const CcCtx& c, c
   *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
   *reinterpret_cast<uint2*>(dst + 1024) = make_uint2(l0, l1);
 }
-
-struct CcAdd {   // prefetched first-layer addend rows of one pair of groups (factored EdgeBlock: (W1a nb)[s] + (W1b nb)[r])
-  float4 s0, r0, s1, r1;
-};
-__device__ __forceinline__ CcAdd cc_padd_load(const gfv_rowtile_args_t& A, const CcCtx& c, const int* idxs, const int* idxr,
-                                              int pair) {
-  CcAdd p;
-  const int q0 = 2 * pair, q1 = 2 * pair + 1;
-  const float* base = A.padd + c.col0;
-  p.s0 = ld4(base + (size_t)idxs[q0 * 16 + c.j] * A.padd_ld);
-  p.r0 = ld4(base + (size_t)idxr[q0 * 16 + c.j] * A.padd_ld + 128);
-  p.s1 = ld4(base + (size_t)idxs[q1 * 16 + c.j] * A.padd_ld);
-  p.r1 = ld4(base + (size_t)idxr[q1 * 16 + c.j] * A.padd_ld + 128);
-  return p;
-}
-
-// hidden-layer epilogue of one group (forward form, GFV_OP_BIAS_GELU): v = acc / scales + bias (+ addend) - handed back for the
-// save, which the caller issues after the math of both groups of a pair (a predicated store ends a basic block: the MFMAs
-// of the next pair and this arithmetic are to stay in one); a = gelu(v) -> fragments of the next layer
-template <int L, bool PADD>
-__device__ __forceinline__ void cc_hidden_fwd(CcCtx& c, int q, const floatx4& acc, const float4& bias, const float* sinv,
-                                              const float4& ps, const float4& pr, char* xout, float (&v)[4]) {
-  if (L == 0) {
-    const float si = sinv[q * 16 + c.j];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] = (acc[r] * si) * c.invw;
-  } else {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] = (acc[r] * CC_SH_INV) * c.invw;
-  }
-  v[0] += bias.x; v[1] += bias.y; v[2] += bias.z; v[3] += bias.w;
-  if (L == 0 && PADD) {
-    v[0] += ps.x + pr.x; v[1] += ps.y + pr.y; v[2] += ps.z + pr.z; v[3] += ps.w + pr.w;
-  }
-  float a[4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) a[r] = gfv_gelu(v[r]);
-  const float mq = max3_abs(max3_abs(0.f, a[0], a[1]), a[2], a[3]);
-  c.mabs = fmaxf(c.mabs, q < c.ngt ? mq : 0.f);   // (the dead groups of a partial tile hold whatever LDS held)
-  cc_put_frag(xout, q, c, a, CC_SH);
-}
-__device__ __forceinline__ void cc_save_pair(float* save, const CcCtx& c, int p, const float (&v0)[4], const float (&v1)[4]) {
-  const int r0 = c.row0 + 32 * p + c.j, r1 = r0 + 16;
-  if (save && 2 * p < c.ngt && r0 < c.M) st4(save + (size_t)r0 * 128 + c.col0, v0);
-  if (save && 2 * p + 1 < c.ngt && r1 < c.M) st4(save + (size_t)r1 * 128 + c.col0, v1);
-}
-
-// the tile-ahead input rows of a loader wave: 2 KT0 pieces of 16 columns (float4 per lane), concatenated segments
-template <int KT0>
-struct CcPre {
-  float4 v[2 * KT0];
-  int is, ir;   // gather rows of the first-layer addend for this lane's row
-};
-
-// N0: 16-column pieces of segment 0 (the rest of the 2 KT0 pieces come from segment 1) - compile-time, so that the loads
-// are one straight run (a run-time segment lookup per piece compiled into a branch per load)
-template <int KT0, int N0>
-__device__ __forceinline__ void cc_prefetch(const gfv_rowtile_args_t& A, const CcCtx& c, int row0, CcPre<KT0>& pre) {
-  // (unconditional loads from a clamped row: a register array filled under a branch is parked in scratch by the compiler)
-  const int row = min(row0 + 16 * c.w + c.j, A.M - 1);
-  const int* i0 = A.seg[0].idx;
-  const float* p0 = A.seg[0].ptr + (size_t)(i0 ? i0[row] : row) * A.seg[0].ld + 4 * c.g;
-  const float* p1 = p0;
-  if (N0 < 2 * KT0) {
-    const int* i1 = A.seg[1].idx;
-    p1 = A.seg[1].ptr + (size_t)(i1 ? i1[row] : row) * A.seg[1].ld + 4 * c.g;
-  }
-#pragma unroll
-  for (int u = 0; u < 2 * KT0; ++u) pre.v[u] = ld4(u < N0 ? p0 + 16 * u : p1 + 16 * (u - N0));
-  pre.is = A.padd ? A.padd_s[row] : 0;
-  pre.ir = A.padd ? A.padd_r[row] : 0;
-}
-
-// loader: the prefetched 16 rows -> row scale, fragments, gather rows in LDS (dead groups: zero gather rows)
-template <int KT0>
-__device__ __forceinline__ void cc_park_input(const CcCtx& c, const CcPre<KT0>& pre, char* xin, float* sinv, int* idxs, int* idxr) {
-  float m0 = 0.f, m1 = 0.f;
-#pragma unroll
-  for (int u = 0; u < 2 * KT0; ++u) {
-    m0 = max3_abs(m0, pre.v[u].x, pre.v[u].y);
-    m1 = max3_abs(m1, pre.v[u].z, pre.v[u].w);
-  }
-  const float s = gfv_pow2_scale(row_max4(max3_abs(0.f, m0, m1)));
-  const bool livegrp = c.w < c.ngt;
-  if (c.g == 0) {
-    sinv[c.w * 16 + c.j] = 1.0f / s;
-    idxs[c.w * 16 + c.j] = livegrp ? pre.is : 0;
-    idxr[c.w * 16 + c.j] = livegrp ? pre.ir : 0;
-  }
-  if (livegrp) {
-    gfv_uint4* dst = reinterpret_cast<gfv_uint4*>(xin + (size_t)c.w * KT0 * 2048) + c.lane;
-#pragma unroll
-    for (int T = 0; T < KT0; ++T) {
-      const float e[8] = {pre.v[2 * T].x * s,     pre.v[2 * T].y * s,     pre.v[2 * T].z * s,     pre.v[2 * T].w * s,
-                          pre.v[2 * T + 1].x * s, pre.v[2 * T + 1].y * s, pre.v[2 * T + 1].z * s, pre.v[2 * T + 1].w * s};
-      gfv_uint4 hi, lo;
-      gfv_split8(e, hi, lo);
-      dst[(2 * T) * 64] = hi;
-      dst[(2 * T + 1) * 64] = lo;
-    }
-  }
-}
-
-// Forward form: 3 layers (bias + GELU, bias + GELU, bias), LayerNorm, optional residual; segments of 32-multiples wide
-// (plain or row-gathered), optional gathered first-layer addend.  KT0 = k-groups of the first layer (K / 32), N0 = 16-column
-// pieces of the first segment,
-// TG = groups of 16 rows per tile (<= 8: one loader wave per group).
-// LITE: the high-occupancy form.  The kernels of this family are bound by instruction issue per wave, not by memory or the
-// matrix pipe (profiles/tools/colchain_ablate.py: with every output stream but one removed a launch still takes 58 % of its
-// time), so waves per SIMD are what buys throughput: a wave keeps only the CURRENT layer's weight slice in registers (reloaded
-// from L2 per phase, 4 KB per wave, issued ahead of the barrier that starts the phase), rows are loaded where they are consumed
-// (the second workgroup of the CU covers the latency), the register budget is 128 and two workgroups of 8 waves share a CU.
-template <int KT0, int N0, int TG, bool PADD, bool LOWP, bool LITE>
-__global__ __launch_bounds__(64 * CC_W, LITE ? 4 : 2) void colchain_fwd_kernel(const gfv_rowtile_args_t A, int* status) {
-  static_assert(TG <= CC_W && (TG & 1) == 0, "one loader wave per group, groups in pairs");
-  using LY = CcLds<KT0, TG>;
-  __shared__ __attribute__((aligned(16))) char lds[LY::TOTAL];
-  char* xin = lds + LY::XIN;
-  char* xmid = lds + LY::XMID;
-  float* sinv = reinterpret_cast<float*>(lds + LY::SINV);
-  int* idxs = reinterpret_cast<int*>(lds + LY::IDXS);
-  int* idxr = reinterpret_cast<int*>(lds + LY::IDXR);
-  float* lnp = reinterpret_cast<float*>(lds + LY::LNP);
-
-  CcCtx c;
-  c.w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  c.lane = threadIdx.x & 63;
-  c.j = c.lane & 15;
-  c.g = c.lane >> 4;
-  c.col0 = 16 * c.w + 4 * c.g;
-  c.M = A.M;
-  c.mabs = 0.f;
-  c.invw = 1.0f / gfv_pow2_scale(*A.wmax);
-
-  // this workgroup's groups: a contiguous range, XCD-aware (neighbouring ranges gather the same rows: one L2)
-  const int nwg = gridDim.x;
-  const int wg = (nwg & 7) == 0 ? (int)(blockIdx.x & 7) * (nwg >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
-  const int NG = (A.M + 15) >> 4;
-  const int g_beg = (int)((long)NG * wg / nwg), g_end = (int)((long)NG * (wg + 1) / nwg);
-  if (g_beg >= g_end) return;
-
-  // tile-ahead loads of the first tile go out before anything else
-  CcPre<KT0> pre;
-  if (!LITE) cc_prefetch<KT0, N0>(A, c, 16 * g_beg, pre);
-
-  // this wave's n-tile of every layer's image ([pass][T][nt][part][lane] x 16 B, include/gfv.h): resident for the whole launch,
-  // or (LITE) one layer at a time in (wh0, wl0) / (wh1, wl1)
-  gfv_f16x8 wh0[KT0], wl0[KT0], wh1[4], wl1[4], wh2[4], wl2[4];
-  const gfv_f16x8* i0 = reinterpret_cast<const gfv_f16x8*>(A.layer[0].Wh) + (size_t)c.w * 128 + c.lane;
-  const gfv_f16x8* i1 = reinterpret_cast<const gfv_f16x8*>(A.layer[1].Wh) + (size_t)c.w * 128 + c.lane;
-  const gfv_f16x8* i2 = reinterpret_cast<const gfv_f16x8*>(A.layer[2].Wh) + (size_t)c.w * 128 + c.lane;
-  if (!LITE) {
-#pragma unroll
-    for (int T = 0; T < KT0; ++T) { wh0[T] = i0[T * 1024]; wl0[T] = i0[T * 1024 + 64]; }
-#pragma unroll
-    for (int T = 0; T < 4; ++T) {
-      wh1[T] = i1[T * 1024]; wl1[T] = i1[T * 1024 + 64];
-      wh2[T] = i2[T * 1024]; wl2[T] = i2[T * 1024 + 64];
-    }
-  }
-  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  const float4 b0 = A.layer[0].bias ? ld4(A.layer[0].bias + c.col0) : zero4;
-  const float4 b1 = A.layer[1].bias ? ld4(A.layer[1].bias + c.col0) : zero4;
-  const float4 b2 = A.layer[2].bias ? ld4(A.layer[2].bias + c.col0) : zero4;
-  const float4 gam = ld4(A.fin_gamma + c.col0);
-  const float4 bet = ld4(A.fin_beta + c.col0);
-  const float hsc = CC_SH_INV;
-
-  CT_DECL
-  for (int t0 = g_beg; t0 < g_end; t0 += TG) {
-    c.row0 = 16 * t0;
-    c.ngt = min(TG, g_end - t0);
-    const int np = (c.ngt + 1) >> 1;
-    // ---- P0: the prefetched rows become the tile's input fragments ----
-    if (LITE) {
-#pragma unroll
-      for (int T = 0; T < KT0; ++T) { wh0[T] = i0[T * 1024]; wl0[T] = i0[T * 1024 + 64]; }   // layer 0's slice: lands behind the barrier
-      if (c.w < TG) {
-        cc_prefetch<KT0, N0>(A, c, c.row0, pre);
-        cc_park_input<KT0>(c, pre, xin, sinv, idxs, idxr);
-      }
-    } else if (c.w < TG) {
-      cc_park_input<KT0>(c, pre, xin, sinv, idxs, idxr);
-    }
-    CT(0);
-    cc_barrier();
-    CT(1);
-    // next tile's rows: in flight through the whole tile (after the last tile: every lane re-reads row M - 1, a few cached
-    // lines - the loads stay unconditional, a register array filled under a branch is parked in scratch by the compiler)
-    if (!LITE) cc_prefetch<KT0, N0>(A, c, t0 + TG < g_end ? 16 * (t0 + TG) : A.M, pre);
-
-    // ---- P1: layer 0, xin -> xmid ----
-    {
-      floatx4 a0, a1;
-      cc_mma_pair<KT0, LOWP, LITE>(xin, 0, wh0, wl0, c.lane, a0, a1);
-      CcAdd pn;
-      pn.s0 = pn.r0 = pn.s1 = pn.r1 = zero4;
-      if (PADD && !LITE) pn = cc_padd_load(A, c, idxs, idxr, 0);
-      for (int p = 0; p < np; ++p) {
-        const int pnext = min(p + 1, TG / 2 - 1);
-        // (LITE: the addend rows of THIS pair, loaded ahead of the next pair's MFMAs; else one pair ahead)
-        const CcAdd pc = (LITE && PADD) ? cc_padd_load(A, c, idxs, idxr, p) : pn;
-        if (PADD && !LITE) pn = cc_padd_load(A, c, idxs, idxr, pnext);
-        floatx4 n0, n1;
-        cc_mma_pair<KT0, LOWP, LITE>(xin, pnext, wh0, wl0, c.lane, n0, n1);
-
-        float v0[4], v1[4];
-        cc_hidden_fwd<0, PADD>(c, 2 * p, a0, b0, sinv, pc.s0, pc.r0, xmid, v0);
-        cc_hidden_fwd<0, PADD>(c, 2 * p + 1, a1, b0, sinv, pc.s1, pc.r1, xmid, v1);
-        cc_save_pair(A.layer[0].save, c, p, v0, v1);
-        a0 = n0; a1 = n1;
-      }
-    }
-    if (LITE) {   // layer 1's slice goes out ahead of the barrier
-#pragma unroll
-      for (int T = 0; T < 4; ++T) { wh1[T] = i1[T * 1024]; wl1[T] = i1[T * 1024 + 64]; }
-    }
-    CT(2);
-    cc_barrier();
-    CT(3);
-    // ---- P2: layer 1, xmid -> xin ----
-    {
-      floatx4 a0, a1;
-      cc_mma_pair<4, LOWP, LITE>(xmid, 0, wh1, wl1, c.lane, a0, a1);
-      for (int p = 0; p < np; ++p) {
-        const int pnext = min(p + 1, TG / 2 - 1);
-        floatx4 n0, n1;
-        float v0[4], v1[4];
-        if (SPLIT && !LITE) {
-          CcFrags<4, LOWP> fr;
-          cc_frag_load<4, LOWP>(xmid, pnext, c.lane, fr);
-          __builtin_amdgcn_sched_barrier(0);
-          cc_hidden_fwd<1, false>(c, 2 * p, a0, b1, sinv, zero4, zero4, xin, v0);
-          cc_hidden_fwd<1, false>(c, 2 * p + 1, a1, b1, sinv, zero4, zero4, xin, v1);
-          __builtin_amdgcn_sched_barrier(0);
-          cc_mma_frags<4, LOWP>(fr, wh1, wl1, n0, n1);
-        } else {
-          cc_mma_pair<4, LOWP, LITE>(xmid, pnext, wh1, wl1, c.lane, n0, n1);
-          cc_hidden_fwd<1, false>(c, 2 * p, a0, b1, sinv, zero4, zero4, xin, v0);
-          cc_hidden_fwd<1, false>(c, 2 * p + 1, a1, b1, sinv, zero4, zero4, xin, v1);
-        }
-        cc_save_pair(A.layer[1].save, c, p, v0, v1);
-        a0 = n0; a1 = n1;
-      }
-    }
-    if (LITE) {
-#pragma unroll
-      for (int T = 0; T < 4; ++T) { wh2[T] = i2[T * 1024]; wl2[T] = i2[T * 1024 + 64]; }
-    }
-    CT(4);
-    cc_barrier();
-    CT(5);
-    // ---- P3: layer 2, xin -> values; LayerNorm partials; the values wait in this wave's stash (xmid is free) ----
-    float4* stash = reinterpret_cast<float4*>(xmid + (size_t)c.w * TG * 1024) + c.lane;
-    {
-      floatx4 a0, a1;
-      cc_mma_pair<4, LOWP, LITE>(xin, 0, wh2, wl2, c.lane, a0, a1);
-      for (int p = 0; p < np; ++p) {
-        const int pnext = min(p + 1, TG / 2 - 1);
-        floatx4 n0, n1;
-        cc_mma_pair<4, LOWP, LITE>(xin, pnext, wh2, wl2, c.lane, n0, n1);
-        float y0[4], y1[4];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const int q = 2 * p + h;
-          const floatx4& acc = h ? a1 : a0;
-          float (&y)[4] = h ? y1 : y0;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) y[r] = (acc[r] * hsc) * c.invw;
-          y[0] += b2.x; y[1] += b2.y; y[2] += b2.z; y[3] += b2.w;
-          const float mw = row_sum((y[0] + y[1]) + (y[2] + y[3])) * 0.0625f;
-          const float d0 = y[0] - mw, d1 = y[1] - mw, d2 = y[2] - mw, d3 = y[3] - mw;
-          const float m2 = row_sum((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3));
-          if (c.g == 0) *reinterpret_cast<float2*>(lnp + ((q * 16 + c.j) * 8 + c.w) * 2) = make_float2(mw, m2);
-          stash[q * 64] = make_float4(y[0], y[1], y[2], y[3]);
-        }
-        cc_save_pair(A.fin_presave, c, p, y0, y1);
-        a0 = n0; a1 = n1;
-      }
-    }
-    // the residual rows of the whole tile go out ahead of the barrier and ahead of P4's stores (the memory counter is in order:
-    // a load waited for behind stores waits for their acknowledgement too)
-    float4 rres[LITE ? 1 : TG];
-    if (!LITE && A.res[0]) {
-#pragma unroll
-      for (int q = 0; q < TG; ++q)
-        rres[q] = ld4(A.res[0] + (size_t)min(c.row0 + 16 * q + c.j, c.M - 1) * A.res_ld[0] + c.col0);
-    }
-    CT(6);
-    cc_barrier();   // (also the write-after-read guard of xin for the next tile's P0)
-    CT(7);
-    {
-      // ---- P4: LayerNorm over the eight waves' partials, affine, residual, stores ----
-#pragma unroll
-      for (int q = 0; q < TG; ++q) {
-        if (q >= c.ngt) break;
-        const int row = c.row0 + 16 * q + c.j;
-        const bool live = row < c.M;
-        const int rc = live ? row : c.M - 1;
-        float4 rv = zero4;
-        if (A.res[0]) rv = LITE ? ld4(A.res[0] + (size_t)rc * A.res_ld[0] + c.col0) : rres[LITE ? 0 : q];
-        const float4* pp = reinterpret_cast<const float4*>(lnp + (q * 16 + c.j) * 16);
-        const float4 p0 = pp[0], p1 = pp[1], p2 = pp[2], p3 = pp[3];   // (mean, M2) x 8 waves
-        const float mean = (((p0.x + p0.z) + (p1.x + p1.z)) + ((p2.x + p2.z) + (p3.x + p3.z))) * 0.125f;
-        const float e0 = p0.x - mean, e1 = p0.z - mean, e2 = p1.x - mean, e3 = p1.z - mean, e4 = p2.x - mean,
-                    e5 = p2.z - mean, e6 = p3.x - mean, e7 = p3.z - mean;
-        const float m2 = (((p0.y + p0.w) + (p1.y + p1.w)) + ((p2.y + p2.w) + (p3.y + p3.w))) +
-                         16.0f * (((e0 * e0 + e1 * e1) + (e2 * e2 + e3 * e3)) + ((e4 * e4 + e5 * e5) + (e6 * e6 + e7 * e7)));
-        const float rstd = rsqrtf(m2 * 0.0078125f + 1e-5f);   // nn.LayerNorm eps (EPD.py:32)
-        if (A.fin_stats && live && c.w == 0 && c.g == 0) *reinterpret_cast<float2*>(A.fin_stats + 2 * (size_t)row) = make_float2(mean, rstd);
-        const float4 yv = stash[q * 64];
-        float o[4] = {(yv.x - mean) * rstd * gam.x + bet.x, (yv.y - mean) * rstd * gam.y + bet.y,
-                      (yv.z - mean) * rstd * gam.z + bet.z, (yv.w - mean) * rstd * gam.w + bet.w};
-        if (live) {
-          if (A.out_nores) st4(A.out_nores + (size_t)row * 128 + c.col0, o);
-          o[0] += rv.x; o[1] += rv.y; o[2] += rv.z; o[3] += rv.w;
-          st4(A.out[0] + (size_t)row * A.out_ld[0] + c.col0, o);
-        }
-      }
-    }
-    // (no barrier here: the next tile's P0 writes xin / sinv / idx, last read before the P3 / P1 barriers; xmid's stash is
-    // rewritten as fragments only after the next tile's first barrier)
-  }
-#ifdef GFV_CC_TIMING
-  CT(8);
-  if (c.lane == 0 && A.in_aux) {
-    long long* dbg = reinterpret_cast<long long*>(const_cast<float*>(A.in_aux)) + ((size_t)blockIdx.x * CC_W + c.w) * 12;
-    for (int k = 0; k < 12; ++k) dbg[k] = ct_[k];
-  }
-#endif
-  if (c.mabs > CC_SH_LIMIT) atomicOr(status, 2);
-}
-
 
 // =====================================================================================================================
 // Backward form: LayerNorm backward -> [W3^T, x gelu'(z2)] -> [W2^T, x gelu'(z1)] -> [W1^T] (+ residual), with the weight
@@ -505,6 +111,18 @@ __global__ __launch_bounds__(64 * CC_W, LITE ? 4 : 2) void colchain_fwd_kernel(c
 //   P2   (barrier) chain layer 1; epilogue: z1 -> gz1 (stored: the node-level scatter reads it), a1 -> fragments
 //   P1   (barrier) chain layer 2 -> input gradient (+ residual) stored;  dW2 from (gz2, a1)
 // Three fragment buffers (g3 | gz1, gz2, a2 | a1); tiles of TG = 4 groups (64 rows): 96 KB + 4 KB of partials.
+//
+// RC (gfv_rowtile_args_t.rc_Wh: recompute instead of re-read).  The forward then saves only z1 (and the row statistics); this
+// kernel rebuilds what the LayerNorm backward and the GELU' factors need, on a matrix pipe that sat at 13 %:
+//   R1   a1 = gelu(z1) (rows loaded a tile ahead) -> fragments (a FOURTH buffer: a1 lives until the weight-gradient phase)
+//   R2   (barrier) z2 = W2 a1 + b2 against the FORWARD image of W2; a2 = gelu(z2) -> fragments, gelu'(z2) parked in LDS (in the
+//        bytes of the gz2 buffer this lane will overwrite in P3)
+//   R3   (barrier) y3 = W3 a2 + b3 -> registers; then P0 .. P3 as above (P3's epilogue multiplies by the parked gelu'(z2))
+//   dW   (barrier) dW3 += g3^T a2 AND dW2 += gz2^T a1 in one phase (both operand pairs exist by then), which frees the a1
+//        buffer two barriers ahead of the next tile's R1 - no barrier between tiles
+//   P2   (barrier) chain layer 1 with gelu'(z1) from z1 re-read (an L2 hit: this tile's rows were read in R1);  P1 chain layer 2
+// Per row the launch reads dy, z1 (+ residual) and writes gz1 and the input gradient: y3 and z2 are neither written by the
+// forward nor read here (2 x 512 B per row less in each direction); 7 barriers and 7 matrix phases per tile instead of 6 and 5.
 // Scales: g3 fragments carry s3 = 2^k with s3 max|g3| <= 2^15 over the tile (from a bound taken before the barrier; an
 // order of magnitude of slack costs nothing: the split keeps 2^13 of headroom below the maximum); gz2 / gz1 step down from it by
 // the layers' guaranteed growth bounds (row 1-norms of the weight images, taken at kernel start); a2 / a1 carry the fixed CC_SH.  The weight-gradient
@@ -588,6 +206,32 @@ __device__ __forceinline__ void cb_hidden_bwd(CcCtx& c, int q, const floatx4& ac
   cc_put_frag(aout, q, c, a, CC_SH);
 }
 
+// (RC) this lane's 16 bytes of a fragment buffer - the two 8-byte slots cc_put_frag(xbuf, q, ...) will write - as a parking place
+// for four floats of its own: the lane reads them back right before it writes the fragments there, no other lane touches them
+__device__ __forceinline__ char* cb_own_slot(char* xbuf, int q, const CcCtx& c) {
+  return xbuf + (size_t)((q * 4 + (c.w >> 1)) * 2) * 1024 + c.lane * 16 + (c.w & 1) * 8;
+}
+__device__ __forceinline__ void cb_park4(char* xbuf, int q, const CcCtx& c, const float (&v)[4]) {
+  char* d = cb_own_slot(xbuf, q, c);
+  *reinterpret_cast<float2*>(d) = make_float2(v[0], v[1]);
+  *reinterpret_cast<float2*>(d + 1024) = make_float2(v[2], v[3]);
+}
+__device__ __forceinline__ void cb_unpark4(char* xbuf, int q, const CcCtx& c, float (&v)[4]) {
+  const char* d = cb_own_slot(xbuf, q, c);
+  const float2 a = *reinterpret_cast<const float2*>(d), b = *reinterpret_cast<const float2*>(d + 1024);
+  v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y;
+}
+
+// the same with the GELU' factor given (RC: kept from the recompute phase, or taken from z alone) and no activation output
+__device__ __forceinline__ void cb_hidden_bwd_dg(CcCtx& c, int q, const floatx4& acc, float inv_in, const float (&dg)[4], float sg,
+                                                 char* gout, float (&v)[4]) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) v[r] = ((acc[r] * inv_in) * c.invw) * dg[r];
+  const float mq = max3_abs(max3_abs(0.f, v[0], v[1]), v[2], v[3]) * sg;
+  c.mabs = fmaxf(c.mabs, q < c.ngt ? mq : 0.f);
+  cc_put_frag(gout, q, c, v, sg);
+}
+
 // ---- buffer addressing ---------------------------------------------------------------------------------------------
 // Every [M, 128] array of a launch is addressed through a buffer descriptor (4 SGPRs, built from the kernel arguments) and
 // ONE 32-bit byte offset per row group that all of them share (row x 512 + first column x 4): no 64-bit address per access
@@ -647,6 +291,18 @@ __device__ __forceinline__ void cb_load_inputs(const CbBufs& B, const CcCtx& c, 
     in.st[q] = cb_ld2(B.stats, min(row0 + 16 * q + c.j, c.M - 1) * 8);
   }
 }
+// (RC) the incoming gradient rows and the forward's row statistics only: y3 is recomputed
+__device__ __forceinline__ void cb_load_dy_stats(const CbBufs& B, const CcCtx& c, int row0, CbIn& in) {
+#pragma unroll
+  for (int q = 0; q < CB_TG; ++q) {
+    in.dy[q] = cb_ld4(B.dy, cb_off(c, row0, q));
+    in.st[q] = cb_ld2(B.stats, min(row0 + 16 * q + c.j, c.M - 1) * 8);
+  }
+}
+__device__ __forceinline__ void cb_load_rows(cb_rsrc r, const CcCtx& c, int row0, float4 (&v)[CB_TG]) {
+#pragma unroll
+  for (int q = 0; q < CB_TG; ++q) v[q] = cb_ld4(r, cb_off(c, row0, q));
+}
 template <bool GADD>
 __device__ __forceinline__ void cb_load_gathers(const CbBufs& B, const CcCtx& c, const int (&gidx)[CB_TG], CbIn& in) {
   if (GADD) {   // [gadd[s] (64) | gadd[r] (64)]: this wave's 16 columns lie in one half
@@ -661,14 +317,16 @@ __device__ __forceinline__ void cb_load_gathers(const CbBufs& B, const CcCtx& c,
 // blocks.py:54): waves 0..3 own a second n-tile and write out[1] ([M, 64], no residual)
 // NOOUT: the MLP's input needs no gradient (the encoders, EPD.py:92-119): a two-layer launch whose out[0] receives gz1 (what the
 // first Linear's weight-gradient launch reads); the third chain phase is only the weight gradient of the second Linear
-template <bool LOWP, bool GADD, bool DW1, bool OUT2 = false, bool NOOUT = false>
+// RC: z2 and y3 are recomputed from z1 (rc_Wh / rc_bias: the forward's second and third Linear) instead of read
+template <bool LOWP, bool GADD, bool DW1, bool OUT2 = false, bool NOOUT = false, bool RC = false>
 __global__ __launch_bounds__(64 * CC_W, 2) void colchain_bwd_kernel(const gfv_rowtile_args_t A, int* status) {
+  static_assert(!(RC && DW1), "the fourth fragment buffer is either the first Linear's input rows or the recomputed a1");
   constexpr int TG = CB_TG;
-  __shared__ __attribute__((aligned(16))) char lds[CbLds::TOTAL + (DW1 ? CbLds::BUF : 0)];
+  __shared__ __attribute__((aligned(16))) char lds[CbLds::TOTAL + ((DW1 || RC) ? CbLds::BUF : 0)];
   char* b0 = lds + CbLds::B0;
   char* b1 = lds + CbLds::B1;
   char* b2 = lds + CbLds::B2;
-  char* b3 = lds + CbLds::TOTAL;   // (DW1) fragments of the first Linear's input rows
+  char* b3 = lds + CbLds::TOTAL;   // (DW1) fragments of the first Linear's input rows; (RC) a1 = gelu(z1)
   float* part = reinterpret_cast<float*>(lds + CbLds::PART);
   float* smax = reinterpret_cast<float*>(lds + CbLds::SMAX);
 
@@ -690,9 +348,9 @@ __global__ __launch_bounds__(64 * CC_W, 2) void colchain_bwd_kernel(const gfv_ro
   const size_t rows128 = (size_t)A.M * 512;
   CbBufs B;
   B.dy = cb_buf(A.seg[0].ptr, rows128);
-  B.y3 = cb_buf(A.in_aux, rows128);
+  B.y3 = cb_buf(RC ? nullptr : A.in_aux, rows128);
   B.stats = cb_buf(A.in_stats, (size_t)A.M * 8);
-  B.z2 = cb_buf(A.layer[0].aux, rows128);
+  B.z2 = cb_buf(RC ? nullptr : A.layer[0].aux, rows128);
   B.z1 = cb_buf(A.layer[1].aux, rows128);
   B.gadd = cb_buf(A.gadd, 0x7fffffe0ull);   // (its row count is not an argument; the gather rows come from the index arrays)
   B.gidx = cb_buf(c.w < 4 ? A.gadd_s : A.gadd_r, (size_t)A.M * 4);
@@ -707,6 +365,8 @@ __global__ __launch_bounds__(64 * CC_W, 2) void colchain_bwd_kernel(const gfv_ro
   // LayerNorm-backward phase, where the register pressure peaks, holds none of them.
   const cb_rsrc w0 = cb_buf(A.layer[0].Wh, 65536), w1 = cb_buf(A.layer[1].Wh, 65536),
                 w2 = cb_buf(NOOUT ? nullptr : A.layer[2].Wh, OUT2 ? 131072 : 65536);
+  // (RC) the FORWARD images of the second and third Linear, for the recompute phases
+  const cb_rsrc rw2 = cb_buf(RC ? A.rc_Wh[0] : nullptr, 65536), rw3 = cb_buf(RC ? A.rc_Wh[1] : nullptr, 65536);
   const int woff = (c.w * 128 + c.lane) * 16;   // + T * 16384 (+ 1024: the lo part)
   // fused weight gradients: D[n = 16 w + 4 g + r][k = 16 kt + j] in lane (j, g) of acc[kt][r]
   floatx4 dw3[8], dw2[8], dw1[DW1 ? 8 : 1], db3 = floatx4{0.f, 0.f, 0.f, 0.f}, db2 = db3, db1 = db3;
@@ -755,9 +415,14 @@ __global__ __launch_bounds__(64 * CC_W, 2) void colchain_bwd_kernel(const gfv_ro
   constexpr bool PRE = !DW1;
   int gidx[TG] = {0, 0, 0, 0};
   CbIn in;
+  float4 zn[RC ? TG : 1];   // (RC) the next tile's z1 rows
   if (g_beg < g_end) {
     cb_load_gidx<GADD>(B, c, 16 * g_beg, gidx);
-    if (PRE) {
+    if constexpr (RC) {
+      cb_load_rows(B.z1, c, 16 * g_beg, zn);
+      cb_load_dy_stats(B, c, 16 * g_beg, in);
+      cb_load_gathers<GADD>(B, c, gidx, in);
+    } else if (PRE) {
       cb_load_inputs(B, c, 16 * g_beg, in);
       cb_load_gathers<GADD>(B, c, gidx, in);
     }
@@ -775,6 +440,93 @@ __global__ __launch_bounds__(64 * CC_W, 2) void colchain_bwd_kernel(const gfv_ro
       offL[q] = cb_off(c, c.row0, q);
       offS[q] = (q < c.ngt && row < c.M) ? row * 512 + c.col0 * 4 : CB_OFF_DEAD;
     }
+    if constexpr (RC) {
+      gfv_f16x8 rh[4], rl[4];   // the forward slice of the phase that follows
+#pragma unroll
+      for (int T = 0; T < 4; ++T) {
+        rh[T] = __builtin_bit_cast(gfv_f16x8, __builtin_amdgcn_raw_buffer_load_b128(rw2, woff + T * 16384, 0, 0));
+        rl[T] = __builtin_bit_cast(gfv_f16x8, __builtin_amdgcn_raw_buffer_load_b128(rw2, woff + T * 16384 + 1024, 0, 0));
+      }
+      const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      // ---- R1: a1 = gelu(z1) -> b3 (free since the previous tile's weight-gradient phase, two barriers back) ----
+#pragma unroll
+      for (int q = 0; q < TG; ++q) {
+        const float z4[4] = {zn[q].x, zn[q].y, zn[q].z, zn[q].w};
+        float a[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a[r] = gfv_gelu(z4[r]);
+        const float ma = max3_abs(max3_abs(0.f, a[0], a[1]), a[2], a[3]) * (CC_SH * (1.0f / 32.0f));
+        c.mabs = fmaxf(c.mabs, q < c.ngt ? ma : 0.f);
+        cc_put_frag(b3, q, c, a, CC_SH);
+      }
+      cc_barrier();
+      // ---- R2: z2 = W2 a1 + b2;  a2 = gelu(z2) -> b2, gelu'(z2) kept ----
+#pragma unroll
+      for (int q = 0; q < TG; ++q) in.yv[q] = zero4;   // (pairs past the tile's end: zeros, not whatever LDS held)
+      {
+        // (the bias rows are fetched where they are used - an L1 hit per tile - through a descriptor and a 32-bit offset: as a
+        // plain load the compiler hoists them out of the tile loop, eight registers alive through every phase, or keeps their
+        // 64-bit addresses in registers and spills those; `tvar` makes the offset look loop-variant)
+        int tvar = 0;
+        asm volatile("" : "+v"(tvar));
+        const float4 bi2 = cb_ld4(cb_buf(A.rc_bias[0], 512), c.col0 * 4 + tvar);   // (NULL: zero records, reads as zeros)
+        floatx4 a0, a1;
+        cc_mma_pair<4, LOWP, true>(b3, 0, rh, rl, c.lane, a0, a1);
+#pragma unroll
+        for (int p = 0; p < TG / 2; ++p) {
+          if (p >= np) break;
+          floatx4 n0 = a0, n1 = a1;
+          if (p + 1 < TG / 2) cc_mma_pair<4, LOWP, true>(b3, p + 1, rh, rl, c.lane, n0, n1);
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int q = 2 * p + h;
+            const floatx4& acc = h ? a1 : a0;
+            const float bb[4] = {bi2.x, bi2.y, bi2.z, bi2.w};
+            float a[4], dg[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float z = (acc[r] * CC_SH_INV) * c.invw + bb[r];
+              const gfv_erfc_t e = gfv_erfc_half(z);   // gelu and gelu' share the erfc evaluation (gfv_common.h)
+              const float cdf = z >= 0.0f ? 1.0f - e.y : e.y;
+              dg[r] = fmaf(z * 0.39894228040143267794f, e.e, cdf);
+              a[r] = fmaf(-fabsf(z), e.y, fmaxf(z, 0.0f));
+            }
+            // gelu'(z2) waits for P3 in b1 (free since the previous tile's second chain layer): in the very bytes this lane
+            // will write its share of the gz2 fragments to - 16 registers less from here to P3, where the kernel peaks
+            cb_park4(b1, q, c, dg);
+            const float ma = max3_abs(max3_abs(0.f, a[0], a[1]), a[2], a[3]) * (CC_SH * (1.0f / 32.0f));
+            c.mabs = fmaxf(c.mabs, q < c.ngt ? ma : 0.f);
+            cc_put_frag(b2, q, c, a, CC_SH);
+          }
+          a0 = n0; a1 = n1;
+        }
+      }
+#pragma unroll
+      for (int T = 0; T < 4; ++T) {
+        rh[T] = __builtin_bit_cast(gfv_f16x8, __builtin_amdgcn_raw_buffer_load_b128(rw3, woff + T * 16384, 0, 0));
+        rl[T] = __builtin_bit_cast(gfv_f16x8, __builtin_amdgcn_raw_buffer_load_b128(rw3, woff + T * 16384 + 1024, 0, 0));
+      }
+      cc_barrier();
+      // ---- R3: y3 = W3 a2 + b3 -> registers (what the launch would otherwise read from in_aux) ----
+      {
+        int tvar = 0;
+        asm volatile("" : "+v"(tvar));
+        const float4 bi3 = cb_ld4(cb_buf(A.rc_bias[1], 512), c.col0 * 4 + tvar);
+        floatx4 a0, a1;
+        cc_mma_pair<4, LOWP, true>(b2, 0, rh, rl, c.lane, a0, a1);
+#pragma unroll
+        for (int p = 0; p < TG / 2; ++p) {
+          if (p >= np) break;
+          floatx4 n0 = a0, n1 = a1;
+          if (p + 1 < TG / 2) cc_mma_pair<4, LOWP, true>(b2, p + 1, rh, rl, c.lane, n0, n1);
+          in.yv[2 * p] = make_float4((a0[0] * CC_SH_INV) * c.invw + bi3.x, (a0[1] * CC_SH_INV) * c.invw + bi3.y,
+                                     (a0[2] * CC_SH_INV) * c.invw + bi3.z, (a0[3] * CC_SH_INV) * c.invw + bi3.w);
+          in.yv[2 * p + 1] = make_float4((a1[0] * CC_SH_INV) * c.invw + bi3.x, (a1[1] * CC_SH_INV) * c.invw + bi3.y,
+                                         (a1[2] * CC_SH_INV) * c.invw + bi3.z, (a1[3] * CC_SH_INV) * c.invw + bi3.w);
+          a0 = n0; a1 = n1;
+        }
+      }
+    }
     // ---- P0: LayerNorm backward, first half (the rows were loaded one tile ahead) ----
     float gg[TG][4], xh[TG][4], rs[TG];
     {
@@ -791,7 +543,8 @@ __global__ __launch_bounds__(64 * CC_W, 2) void colchain_bwd_kernel(const gfv_ro
           in.dy[q].x += t.x; in.dy[q].y += t.y; in.dy[q].z += t.z; in.dy[q].w += t.w;
         }
       }
-      const float4 gam = ld4(A.in_gamma + c.col0);
+      float* part_j = part + (c.j * 8 + c.w) * 2;   // (one address + immediate offsets: four separate addresses were spilled)
+      const float4 gam = RC ? cb_ld4(cb_buf(A.in_gamma, 512), c.col0 * 4) : ld4(A.in_gamma + c.col0);
 #pragma unroll
       for (int q = 0; q < TG; ++q) {
         const float lf = offS[q] != CB_OFF_DEAD ? 1.0f : 0.0f;   // rows past M / dead groups must not reach any sum over rows
@@ -815,7 +568,7 @@ __global__ __launch_bounds__(64 * CC_W, 2) void colchain_bwd_kernel(const gfv_ro
         }
         s1 = row_sum(s1);
         s2 = row_sum(s2);
-        if (c.g == 0) *reinterpret_cast<float2*>(part + ((q * 16 + c.j) * 8 + c.w) * 2) = make_float2(s1, s2);
+        if (c.g == 0) *reinterpret_cast<float2*>(part_j + q * 256) = make_float2(s1, s2);   // part[((q * 16 + j) * 8 + w) * 2]
         bmax = fmaxf(bmax, am * fabsf(rstd) * lf);
       }
       bmax = gfv_wave_max(bmax);
@@ -829,8 +582,10 @@ __global__ __launch_bounds__(64 * CC_W, 2) void colchain_bwd_kernel(const gfv_ro
     }
     // the saved pre-activations the first chain layer's epilogue needs: in flight through P0b
     float4 zq[TG];
+    if constexpr (!RC) {
 #pragma unroll
-    for (int q = 0; q < TG; ++q) zq[q] = cb_ld4(B.z2, offL[q]);
+      for (int q = 0; q < TG; ++q) zq[q] = cb_ld4(B.z2, offL[q]);
+    }
     CT(0);
     cc_barrier();
     CT(1);
@@ -892,8 +647,16 @@ __global__ __launch_bounds__(64 * CC_W, 2) void colchain_bwd_kernel(const gfv_ro
         floatx4 n0 = a0, n1 = a1;
         if (p + 1 < TG / 2) cc_mma_pair<4, LOWP, true>(b0, p + 1, wh, wl, c.lane, n0, n1);
         float v0[4], v1[4];
-        cb_hidden_bwd(c, 2 * p, a0, inv_in, zq[2 * p], s2s, b1, b2, v0);
-        cb_hidden_bwd(c, 2 * p + 1, a1, inv_in, zq[2 * p + 1], s2s, b1, b2, v1);
+        if constexpr (RC) {   // gelu'(z2) was parked in b1 by R2, a2 is in b2 already
+          float d0[4], d1[4];
+          cb_unpark4(b1, 2 * p, c, d0);
+          cb_unpark4(b1, 2 * p + 1, c, d1);
+          cb_hidden_bwd_dg(c, 2 * p, a0, inv_in, d0, s2s, b1, v0);
+          cb_hidden_bwd_dg(c, 2 * p + 1, a1, inv_in, d1, s2s, b1, v1);
+        } else {
+          cb_hidden_bwd(c, 2 * p, a0, inv_in, zq[2 * p], s2s, b1, b2, v0);
+          cb_hidden_bwd(c, 2 * p + 1, a1, inv_in, zq[2 * p + 1], s2s, b1, b2, v1);
+        }
         if (A.layer[0].save) {
           const cb_rsrc s0 = cb_buf(A.layer[0].save, rows128);
           cb_st4(s0, offS[2 * p], v0);
@@ -919,7 +682,10 @@ __global__ __launch_bounds__(64 * CC_W, 2) void colchain_bwd_kernel(const gfv_ro
 #pragma unroll
       for (int q = 0; q < TG; ++q) ev[q] = cb_ld4(cb_buf(A.dw_in, rows128), offL[q]);
     }
+    // (RC) the next tile's z1 rows: in flight through the weight gradients and the last two chain layers
+    if constexpr (RC) cb_load_rows(B.z1, c, next_row0, zn);
     cb_dw_tile<LOWP>(b0, b2, np, c.w, c.lane, dw3, db3);
+    if constexpr (RC) cb_dw_tile<LOWP>(b1, b3, np, c.w, c.lane, dw2, db2);   // gz2 and a1 both exist: frees b3 for the next tile's R1
     if (DW1) {
 #pragma unroll
       for (int q = 0; q < TG; ++q) {
@@ -943,8 +709,16 @@ __global__ __launch_bounds__(64 * CC_W, 2) void colchain_bwd_kernel(const gfv_ro
         floatx4 n0 = a0, n1 = a1;
         if (p + 1 < TG / 2) cc_mma_pair<4, LOWP, true>(b1, p + 1, wh, wl, c.lane, n0, n1);
         float v0[4], v1[4];
-        cb_hidden_bwd(c, 2 * p, a0, inv_in, zq[2 * p], s1s, b0, b2, v0);
-        cb_hidden_bwd(c, 2 * p + 1, a1, inv_in, zq[2 * p + 1], s1s, b0, b2, v1);
+        if constexpr (RC) {   // a1 is in b3 since R1; only gelu'(z1) is needed here
+          const float d0[4] = {gfv_dgelu(zq[2 * p].x), gfv_dgelu(zq[2 * p].y), gfv_dgelu(zq[2 * p].z), gfv_dgelu(zq[2 * p].w)};
+          const float d1[4] = {gfv_dgelu(zq[2 * p + 1].x), gfv_dgelu(zq[2 * p + 1].y), gfv_dgelu(zq[2 * p + 1].z),
+                               gfv_dgelu(zq[2 * p + 1].w)};
+          cb_hidden_bwd_dg(c, 2 * p, a0, inv_in, d0, s1s, b0, v0);
+          cb_hidden_bwd_dg(c, 2 * p + 1, a1, inv_in, d1, s1s, b0, v1);
+        } else {
+          cb_hidden_bwd(c, 2 * p, a0, inv_in, zq[2 * p], s1s, b0, b2, v0);
+          cb_hidden_bwd(c, 2 * p + 1, a1, inv_in, zq[2 * p + 1], s1s, b0, b2, v1);
+        }
         cb_st4(B.save1, offS[2 * p], v0);
         cb_st4(B.save1, offS[2 * p + 1], v1);
         a0 = n0; a1 = n1;
@@ -1017,11 +791,18 @@ __global__ __launch_bounds__(64 * CC_W, 2) void colchain_bwd_kernel(const gfv_ro
     CT(10);
     // the next tile's rows (and its gathered addend rows): in flight through the last weight gradients.  (Issued any earlier
     // they sit in 56 registers beside a chain phase, and the kernel spills: a scratch reload waits for every load in flight.)
-    if (PRE) {
-      cb_load_inputs(B, c, next_row0, in);
+    if constexpr (RC) {
+      // the next tile's gradient rows, statistics and gathered addend: in flight through R1 .. R3.  (Issued at the start of P1
+      // they sit beside the last chain layer's weight slice, residual rows and accumulators: 254 registers, the kernel spills.)
+      cb_load_dy_stats(B, c, next_row0, in);
       cb_load_gathers<GADD>(B, c, gidx, in);
+    } else {
+      if (PRE) {
+        cb_load_inputs(B, c, next_row0, in);
+        cb_load_gathers<GADD>(B, c, gidx, in);
+      }
+      cb_dw_tile<LOWP>(b1, b2, np, c.w, c.lane, dw2, db2);
     }
-    cb_dw_tile<LOWP>(b1, b2, np, c.w, c.lane, dw2, db2);
     if constexpr (DW1) cb_dw_tile<LOWP>(b0, b3, np, c.w, c.lane, dw1, db1);
     CT(11);
     // (the next tile's P0 writes only `part` / `smax`, last read in P0b; its P0b writes b0 behind the barrier that follows P0)
@@ -1069,263 +850,5 @@ __global__ __launch_bounds__(64 * CC_W, 2) void colchain_bwd_kernel(const gfv_ro
   if (c.mabs > 60000.0f) atomicOr(status, 2);
 }
 
-
-// =====================================================================================================================
-// Forward form, second generation: the structure that made the backward kernel fast, applied to the forward chain.
-// Against colchain_fwd_kernel above: no loader roles (every wave loads ITS 16 columns of the tile's input rows, the row
-// maxima for the row scales are combined through LDS behind the barrier the phase needs anyway), buffer addressing (one
-// 32-bit offset per row group for every [M, 128] array, bounds-checked stores instead of exec-masked ones), the layers'
-// weight slices fetched one phase ahead instead of resident, the gathered first-layer addend and the next tile's rows in
-// flight a phase / a tile ahead, the last layer's values kept in registers through the LayerNorm barrier.  Tiles of
-// TG = 4 groups (64 rows), five barriers per tile; WPS = waves per SIMD the register allocation aims at (2: one workgroup
-// per CU; 4: two, 128 registers).
-//   P0   (rows loaded a tile ahead) per-wave row maxima -> LDS;  the addend gathers and layer 0's slice go out
-//   P0b  row scale from the eight partial maxima; input fragments
-//   P1   layer 0 -> z1 (+ bias + addend) saved, gelu -> fragments;  P2  layer 1 likewise;  P3  layer 2 -> y3 saved,
-//        (mean, M2) partials of the LayerNorm -> LDS, values stay in registers
-//   P4   LayerNorm from the eight partials, statistics / pre-residual / output rows stored; next tile's rows requested
-struct CfLds {
-  static constexpr int XIN = 0;
-  static constexpr int XMID = CB_TG * 8192;
-  static constexpr int RMAX = 2 * CB_TG * 8192;                 // float [TG][16][8]: per-wave max |x| of a row's 16 columns
-  static constexpr int LNP = RMAX + CB_TG * 16 * 8 * 4;        // float2 [TG][16][8]
-  static constexpr int TOTAL = LNP + CB_TG * 16 * 8 * 8;
-};
-
-template <bool PADD, bool LOWP, int WPS>
-__global__ __launch_bounds__(64 * CC_W, WPS) void colchain_fwd2_kernel(const gfv_rowtile_args_t A, int* status) {
-  constexpr int TG = CB_TG;
-  __shared__ __attribute__((aligned(16))) char lds[CfLds::TOTAL];
-  char* xin = lds + CfLds::XIN;
-  char* xmid = lds + CfLds::XMID;
-  float* rmax = reinterpret_cast<float*>(lds + CfLds::RMAX);
-  float* lnp = reinterpret_cast<float*>(lds + CfLds::LNP);
-
-  CcCtx c;
-  c.w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  c.lane = threadIdx.x & 63;
-  c.j = c.lane & 15;
-  c.g = c.lane >> 4;
-  c.col0 = 16 * c.w + 4 * c.g;
-  c.M = A.M;
-  c.mabs = 0.f;
-  c.invw = 1.0f / gfv_pow2_scale(*A.wmax);
-
-  const int nwg = gridDim.x;
-  const int wg = (nwg & 7) == 0 ? (int)(blockIdx.x & 7) * (nwg >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
-  const int NG = (A.M + 15) >> 4;
-  const int g_beg = (int)((long)NG * wg / nwg), g_end = (int)((long)NG * (wg + 1) / nwg);
-
-  const size_t rows128 = (size_t)A.M * 512;
-  const cb_rsrc bx = cb_buf(A.seg[0].ptr, rows128), bz1 = cb_buf(A.layer[0].save, rows128), bz2 = cb_buf(A.layer[1].save, rows128),
-                by3 = cb_buf(A.fin_presave, rows128), bnr = cb_buf(A.out_nores, rows128), bres = cb_buf(A.res[0], rows128),
-                bout = cb_buf(A.out[0], rows128), bst = cb_buf(A.fin_stats, (size_t)A.M * 8),
-                bpad = cb_buf(A.padd, 0x7fffffe0ull), bis = cb_buf(A.padd_s, (size_t)A.M * 4), bir = cb_buf(A.padd_r, (size_t)A.M * 4);
-  const cb_rsrc w0 = cb_buf(A.layer[0].Wh, 65536), w1 = cb_buf(A.layer[1].Wh, 65536), w2 = cb_buf(A.layer[2].Wh, 65536);
-  const int woff = (c.w * 128 + c.lane) * 16;
-  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  const float4 bi0 = A.layer[0].bias ? ld4(A.layer[0].bias + c.col0) : zero4;
-  const float4 bi1 = A.layer[1].bias ? ld4(A.layer[1].bias + c.col0) : zero4;
-  const float4 bi2 = A.layer[2].bias ? ld4(A.layer[2].bias + c.col0) : zero4;
-  const int padld4 = A.padd_ld * 4;
-
-  // the first tile's rows and gather rows
-  float4 xv[TG];
-  int is[TG], ir[TG];
-#pragma unroll
-  for (int q = 0; q < TG; ++q) {
-    xv[q] = cb_ld4(bx, cb_off(c, 16 * g_beg, q));
-    if (PADD) {
-      const int ro = min(16 * g_beg + 16 * q + c.j, c.M - 1) * 4;
-      is[q] = __builtin_amdgcn_raw_buffer_load_b32(bis, ro, 0, 0);
-      ir[q] = __builtin_amdgcn_raw_buffer_load_b32(bir, ro, 0, 0);
-    }
-  }
-
-  for (int t0 = g_beg; t0 < g_end; t0 += TG) {
-    c.row0 = 16 * t0;
-    c.ngt = min(TG, g_end - t0);
-    const int np = (c.ngt + 1) >> 1;
-    const int next_row0 = t0 + TG < g_end ? 16 * (t0 + TG) : c.M;
-    int offL[TG], offS[TG];
-#pragma unroll
-    for (int q = 0; q < TG; ++q) {
-      const int row = c.row0 + 16 * q + c.j;
-      offL[q] = cb_off(c, c.row0, q);
-      offS[q] = (q < c.ngt && row < c.M) ? row * 512 + c.col0 * 4 : CB_OFF_DEAD;
-    }
-    // ---- P0: this wave's share of the row maxima; the addend rows and layer 0's slice go out ----
-#pragma unroll
-    for (int q = 0; q < TG; ++q) {
-      const float m = row_max4(max3_abs(max3_abs(0.f, xv[q].x, xv[q].y), xv[q].z, xv[q].w));
-      if (c.g == 0) rmax[(q * 16 + c.j) * 8 + c.w] = m;
-    }
-    float4 ps[PADD ? TG : 1], pr[PADD ? TG : 1];
-    if (PADD) {
-#pragma unroll
-      for (int q = 0; q < TG; ++q) {
-        ps[q] = cb_ld4(bpad, is[q] * padld4 + c.col0 * 4);
-        pr[q] = cb_ld4(bpad, ir[q] * padld4 + 512 + c.col0 * 4);
-      }
-    }
-    gfv_f16x8 wh[4], wl[4];
-#pragma unroll
-    for (int T = 0; T < 4; ++T) {
-      wh[T] = __builtin_bit_cast(gfv_f16x8, __builtin_amdgcn_raw_buffer_load_b128(w0, woff + T * 16384, 0, 0));
-      wl[T] = __builtin_bit_cast(gfv_f16x8, __builtin_amdgcn_raw_buffer_load_b128(w0, woff + T * 16384 + 1024, 0, 0));
-    }
-    cc_barrier();
-    // ---- P0b: row scales, input fragments ----
-    float sinv[TG];
-#pragma unroll
-    for (int q = 0; q < TG; ++q) {
-      const float4* pp = reinterpret_cast<const float4*>(rmax + (q * 16 + c.j) * 8);
-      const float4 a = pp[0], b = pp[1];
-      const float sc = gfv_pow2_scale(fmaxf(fmaxf(fmaxf(a.x, a.y), fmaxf(a.z, a.w)), fmaxf(fmaxf(b.x, b.y), fmaxf(b.z, b.w))));
-      sinv[q] = 1.0f / sc;
-      const float x4[4] = {xv[q].x, xv[q].y, xv[q].z, xv[q].w};
-      cc_put_frag(xin, q, c, x4, sc);
-    }
-    cc_barrier();
-    // ---- P1: layer 0, xin -> xmid ----
-    {
-      floatx4 a0, a1;
-      cc_mma_pair<4, LOWP, true>(xin, 0, wh, wl, c.lane, a0, a1);
-#pragma unroll
-      for (int p = 0; p < TG / 2; ++p) {
-        if (p >= np) break;
-        floatx4 n0 = a0, n1 = a1;
-        if (p + 1 < TG / 2) cc_mma_pair<4, LOWP, true>(xin, p + 1, wh, wl, c.lane, n0, n1);
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const int q = 2 * p + h;
-          const floatx4& acc = h ? a1 : a0;
-          float v[4];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = (acc[r] * sinv[q]) * c.invw;
-          v[0] += bi0.x; v[1] += bi0.y; v[2] += bi0.z; v[3] += bi0.w;
-          if (PADD) {
-            v[0] += ps[q].x + pr[q].x; v[1] += ps[q].y + pr[q].y; v[2] += ps[q].z + pr[q].z; v[3] += ps[q].w + pr[q].w;
-          }
-          cb_st4(bz1, offS[q], v);
-          float a[4];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) a[r] = gfv_gelu(v[r]);
-          const float mq = max3_abs(max3_abs(0.f, a[0], a[1]), a[2], a[3]);
-          c.mabs = fmaxf(c.mabs, q < c.ngt ? mq : 0.f);
-          cc_put_frag(xmid, q, c, a, CC_SH);
-        }
-        a0 = n0; a1 = n1;
-      }
-    }
-#pragma unroll
-    for (int T = 0; T < 4; ++T) {
-      wh[T] = __builtin_bit_cast(gfv_f16x8, __builtin_amdgcn_raw_buffer_load_b128(w1, woff + T * 16384, 0, 0));
-      wl[T] = __builtin_bit_cast(gfv_f16x8, __builtin_amdgcn_raw_buffer_load_b128(w1, woff + T * 16384 + 1024, 0, 0));
-    }
-    cc_barrier();
-    // ---- P2: layer 1, xmid -> xin ----
-    {
-      floatx4 a0, a1;
-      cc_mma_pair<4, LOWP, true>(xmid, 0, wh, wl, c.lane, a0, a1);
-#pragma unroll
-      for (int p = 0; p < TG / 2; ++p) {
-        if (p >= np) break;
-        floatx4 n0 = a0, n1 = a1;
-        if (p + 1 < TG / 2) cc_mma_pair<4, LOWP, true>(xmid, p + 1, wh, wl, c.lane, n0, n1);
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const int q = 2 * p + h;
-          const floatx4& acc = h ? a1 : a0;
-          float v[4];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = (acc[r] * CC_SH_INV) * c.invw;
-          v[0] += bi1.x; v[1] += bi1.y; v[2] += bi1.z; v[3] += bi1.w;
-          cb_st4(bz2, offS[q], v);
-          float a[4];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) a[r] = gfv_gelu(v[r]);
-          const float mq = max3_abs(max3_abs(0.f, a[0], a[1]), a[2], a[3]);
-          c.mabs = fmaxf(c.mabs, q < c.ngt ? mq : 0.f);
-          cc_put_frag(xin, q, c, a, CC_SH);
-        }
-        a0 = n0; a1 = n1;
-      }
-    }
-#pragma unroll
-    for (int T = 0; T < 4; ++T) {
-      wh[T] = __builtin_bit_cast(gfv_f16x8, __builtin_amdgcn_raw_buffer_load_b128(w2, woff + T * 16384, 0, 0));
-      wl[T] = __builtin_bit_cast(gfv_f16x8, __builtin_amdgcn_raw_buffer_load_b128(w2, woff + T * 16384 + 1024, 0, 0));
-    }
-    // the residual rows: in flight through P3
-    float4 rr[TG];
-#pragma unroll
-    for (int q = 0; q < TG; ++q) rr[q] = cb_ld4(bres, offL[q]);
-    cc_barrier();
-    // ---- P3: layer 2, xin -> y3 (saved), LayerNorm partials; the values stay in registers ----
-    float y[TG][4];
-    {
-      floatx4 a0, a1;
-      cc_mma_pair<4, LOWP, true>(xin, 0, wh, wl, c.lane, a0, a1);
-#pragma unroll
-      for (int p = 0; p < TG / 2; ++p) {
-        floatx4 n0 = a0, n1 = a1;
-        if (p + 1 < TG / 2) cc_mma_pair<4, LOWP, true>(xin, p + 1, wh, wl, c.lane, n0, n1);
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const int q = 2 * p + h;
-          const floatx4& acc = h ? a1 : a0;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) y[q][r] = (acc[r] * CC_SH_INV) * c.invw;
-          y[q][0] += bi2.x; y[q][1] += bi2.y; y[q][2] += bi2.z; y[q][3] += bi2.w;
-          cb_st4(by3, offS[q], y[q]);
-          const float mw = row_sum((y[q][0] + y[q][1]) + (y[q][2] + y[q][3])) * 0.0625f;
-          const float d0 = y[q][0] - mw, d1 = y[q][1] - mw, d2 = y[q][2] - mw, d3 = y[q][3] - mw;
-          const float m2 = row_sum((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3));
-          if (c.g == 0) *reinterpret_cast<float2*>(lnp + ((q * 16 + c.j) * 8 + c.w) * 2) = make_float2(mw, m2);
-        }
-        a0 = n0; a1 = n1;
-      }
-    }
-    // the next tile's rows and gather rows: requested here, in flight through P4 and the next tile's P0
-#pragma unroll
-    for (int q = 0; q < TG; ++q) {
-      xv[q] = cb_ld4(bx, cb_off(c, next_row0, q));
-      if (PADD) {
-        const int ro = min(next_row0 + 16 * q + c.j, c.M - 1) * 4;
-        is[q] = __builtin_amdgcn_raw_buffer_load_b32(bis, ro, 0, 0);
-        ir[q] = __builtin_amdgcn_raw_buffer_load_b32(bir, ro, 0, 0);
-      }
-    }
-    cc_barrier();
-    // ---- P4: LayerNorm over the eight waves' partials, affine, residual, stores ----
-    {
-      const float4 gam = ld4(A.fin_gamma + c.col0), bet = ld4(A.fin_beta + c.col0);
-#pragma unroll
-      for (int q = 0; q < TG; ++q) {
-        const float4* pp = reinterpret_cast<const float4*>(lnp + (q * 16 + c.j) * 16);
-        const float4 p0 = pp[0], p1 = pp[1], p2 = pp[2], p3 = pp[3];   // (mean, M2) x 8 waves
-        const float mean = (((p0.x + p0.z) + (p1.x + p1.z)) + ((p2.x + p2.z) + (p3.x + p3.z))) * 0.125f;
-        const float e0 = p0.x - mean, e1 = p0.z - mean, e2 = p1.x - mean, e3 = p1.z - mean, e4 = p2.x - mean,
-                    e5 = p2.z - mean, e6 = p3.x - mean, e7 = p3.z - mean;
-        const float m2 = (((p0.y + p0.w) + (p1.y + p1.w)) + ((p2.y + p2.w) + (p3.y + p3.w))) +
-                         16.0f * (((e0 * e0 + e1 * e1) + (e2 * e2 + e3 * e3)) + ((e4 * e4 + e5 * e5) + (e6 * e6 + e7 * e7)));
-        const float rstd = rsqrtf(m2 * 0.0078125f + 1e-5f);   // nn.LayerNorm eps (EPD.py:32)
-        if (c.w == 0 && c.g == 0) {
-          const int row = c.row0 + 16 * q + c.j;
-          const cb_f32x2 st = {mean, rstd};
-          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(cb_i32x2, st), bst, (q < c.ngt && row < c.M) ? row * 8 : CB_OFF_DEAD, 0, 0);
-        }
-        float o[4] = {(y[q][0] - mean) * rstd * gam.x + bet.x, (y[q][1] - mean) * rstd * gam.y + bet.y,
-                      (y[q][2] - mean) * rstd * gam.z + bet.z, (y[q][3] - mean) * rstd * gam.w + bet.w};
-        cb_st4(bnr, offS[q], o);
-        o[0] += rr[q].x; o[1] += rr[q].y; o[2] += rr[q].z; o[3] += rr[q].w;
-        cb_st4(bout, offS[q], o);
-      }
-    }
-    // (the next tile's P0 writes only rmax, last read in P0b; xin / xmid / lnp are rewritten behind its barriers)
-  }
-  if (c.mabs > CC_SH_LIMIT) atomicOr(status, 2);
-}
 
 }  // namespace

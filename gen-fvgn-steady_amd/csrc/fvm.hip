@@ -481,7 +481,9 @@ __global__ __launch_bounds__(256) void cell_to_node_kernel(const float* __restri
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= N) return;
   float u, v, p;
-  if (smooth) {
+  // smooth: bit 0 = inverse-distance smoothing (else the node field itself), bit 1 = RAW: the value the reference's stand-alone
+  // Intergrator returns (FVscheme.py:253-262,718-724) - before the Dirichlet overwrite, not re-dimensionalised
+  if (smooth & 1) {
     const float px = pos[2 * i], py = pos[2 * i + 1];
     float su = 0.f, sv = 0.f, sp = 0.f, sw = 0.f;
     for (int k = nrow[i]; k < nrow[i + 1]; ++k) {
@@ -493,6 +495,10 @@ __global__ __launch_bounds__(256) void cell_to_node_kernel(const float* __restri
     u = su / sw; v = sv / sw; p = sp / sw;
   } else {
     u = phi[(size_t)i * 8]; v = phi[(size_t)i * 8 + 1]; p = phi[(size_t)i * 8 + 2];
+  }
+  if (smooth & 2) {
+    out[3 * i] = u; out[3 * i + 1] = v; out[3 * i + 2] = p;
+    return;
   }
   const int nt = node_type[i];
   if (nt == NT_WALL || nt == NT_INFLOW || nt == NT_PRESS || nt == NT_INWALL) { u = y[2 * i]; v = y[2 * i + 1]; }

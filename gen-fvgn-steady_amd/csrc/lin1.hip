@@ -15,6 +15,7 @@
 // per-16-row scales of those rows for the weight-gradient launch: gscale slot 0), bias / bias2, the GELU' epilogue with its
 // saved pre-activations, residual addends, 128 or 256 outputs (256 inputs with 128 outputs).  Anything else stays with the
 // chain kernel.
+#include <atomic>
 #include <cstdlib>
 
 #include "../../include/gfv.h"
@@ -514,6 +515,17 @@ int l1_env(const char* n, int dflt) {
   return e ? atoi(e) : dflt;
 }
 
+// The kernels' dynamic LDS beyond 64 KB is a per-DEVICE function attribute: set it once per (kernel, device) - a process that
+// launches on a second GPU (torch.cuda.set_device(1) after device 0 was used) needs it there too.
+static inline bool l1_dyn_lds(const void* fn, int bytes, std::atomic<unsigned long long>& done) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return false;
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (done.load(std::memory_order_relaxed) & bit) return true;
+  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return false;
+  done.fetch_or(bit);
+  return true;
+}
 }  // namespace
 
 // 1: launched; 0: not a launch of this family.  lowp: the reduced-precision product form (one product per term).
@@ -547,12 +559,12 @@ int gfv_internal_lin1_try(const gfv_rowtile_args_t* a, int lowp, hipStream_t str
     int* st = gfv_internal_status_ptr();
     const dim3 grid((a->M + 127) / 128), blk(512);
     if (lowp) {
-      static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(&lin1_csr_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-      if (once != hipSuccess) return 0;
+      static std::atomic<unsigned long long> done{0};
+      if (!l1_dyn_lds(reinterpret_cast<const void*>(&lin1_csr_kernel<true>), 131072, done)) return 0;
       hipLaunchKernelGGL((lin1_csr_kernel<true>), grid, blk, 131072, stream, B, st);
     } else {
-      static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(&lin1_csr_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-      if (once != hipSuccess) return 0;
+      static std::atomic<unsigned long long> done{0};
+      if (!l1_dyn_lds(reinterpret_cast<const void*>(&lin1_csr_kernel<false>), 131072, done)) return 0;
       hipLaunchKernelGGL((lin1_csr_kernel<false>), grid, blk, 131072, stream, B, st);
     }
     return 1;
@@ -592,12 +604,12 @@ int gfv_internal_lin1_try(const gfv_rowtile_args_t* a, int lowp, hipStream_t str
     int* st = gfv_internal_status_ptr();
     const dim3 grid((a->M + 127) / 128), blk(512);
     if (lowp) {
-      static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(&lin1_lnbwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-      if (once != hipSuccess) return 0;
+      static std::atomic<unsigned long long> done{0};
+      if (!l1_dyn_lds(reinterpret_cast<const void*>(&lin1_lnbwd_kernel<true>), 131072, done)) return 0;
       hipLaunchKernelGGL((lin1_lnbwd_kernel<true>), grid, blk, 131072, stream, B, st);
     } else {
-      static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(&lin1_lnbwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-      if (once != hipSuccess) return 0;
+      static std::atomic<unsigned long long> done{0};
+      if (!l1_dyn_lds(reinterpret_cast<const void*>(&lin1_lnbwd_kernel<false>), 131072, done)) return 0;
       hipLaunchKernelGGL((lin1_lnbwd_kernel<false>), grid, blk, 131072, stream, B, st);
     }
     return 1;
@@ -659,9 +671,8 @@ int gfv_internal_lin1_try(const gfv_rowtile_args_t* a, int lowp, hipStream_t str
   const int iop = a->in_op == GFV_IN_GELU ? 1 : (a->in_op == GFV_IN_LN ? 2 : 0);
 #define L1_ONE(KS, NP, IOP, DG, LP)                                                                                             \
   do {                                                                                                                          \
-    static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(&lin1_kernel<KS, NP, IOP, DG, LP>),       \
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (NP) * (KS) * 16384);       \
-    if (once != hipSuccess) return 0;                                                                                           \
+    static std::atomic<unsigned long long> done{0};                                                                             \
+    if (!l1_dyn_lds(reinterpret_cast<const void*>(&lin1_kernel<KS, NP, IOP, DG, LP>), (NP) * (KS) * 16384, done)) return 0;     \
     hipLaunchKernelGGL((lin1_kernel<KS, NP, IOP, DG, LP>), grid, blk, (size_t)(NP) * (KS) * 16384, stream, A, st);              \
   } while (0)
 #define L1_FORM(KS, NP, LP)                                                                                                     \

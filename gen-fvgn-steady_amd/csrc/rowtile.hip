@@ -10,6 +10,7 @@
 // Operand trick: the k index inside a 16-wide k step is permuted consistently for A and B (lane group q takes
 // k = 4q..4q+3), so every lane fetches its four A (and four B) values of four consecutive MFMAs with ONE
 // ds_read_b128 from row-major [row][k] / [n][k] images - nn.Linear's [out,in] weight layout is read as stored.
+#include <atomic>
 #include <stdio.h>
 #include <stdlib.h>
 #include "gfv_common.h"
@@ -481,18 +482,31 @@ static int tchain_mode() {
 // GFV_F16SPLIT (or gfv_set_f16split): 0 = every GEMM product on the fp32 MFMA, even when a launch carries split-fp16
 // weight images; 1 (default) = split-fp16 products; 2 = the reduced-precision form, ONE fp16 x fp16 product with fp32
 // accumulation (the high parts only); shared with dw.hip
-// (thread-local: a launch context of the calling thread, like the HIP runtime's current device - two host threads driving two
-// models do not see each other's settings; a launch may also carry its own, gfv_rowtile_args_t.product_form / .hidden)
-static thread_local int g_f16split = -1;
-extern "C" int gfv_f16split_enabled(void) {
-  if (g_f16split < 0) {
+// State: a PROCESS-WIDE default (atomic; gfv_set_f16split) - PyTorch runs the backward of an autograd node on its device
+// worker thread, and a form chosen on the user's thread must reach the launches issued there - and a per-thread OVERRIDE
+// (gfv_set_f16split_thread; -1 = none) for two host threads driving two models in different forms; a launch may also carry its
+// own, gfv_rowtile_args_t.product_form / .hidden
+static std::atomic<int> g_f16_default{-1};
+static thread_local int g_f16split = -1;   // this thread's override
+static int f16_default() {
+  int d = g_f16_default.load(std::memory_order_relaxed);
+  if (d < 0) {
     const char* e = getenv("GFV_F16SPLIT");
-    g_f16split = e ? (atoi(e) == 2 ? 2 : (atoi(e) != 0)) : 1;
+    d = e ? (atoi(e) == 2 ? 2 : (atoi(e) != 0)) : 1;
+    int expect = -1;
+    if (!g_f16_default.compare_exchange_strong(expect, d)) d = expect;
   }
-  return g_f16split;
+  return d;
 }
+extern "C" int gfv_f16split_enabled(void) { return g_f16split >= 0 ? g_f16split : f16_default(); }
 extern "C" int gfv_set_f16split(int32_t on) {
-  g_f16split = on == 2 ? 2 : (on ? 1 : 0);
+  g_f16_default.store(on == 2 ? 2 : (on ? 1 : 0));
+  g_f16split = -1;   // (the caller asked for the process-wide form: its own override, if any, would hide it)
+  return GFV_OK;
+}
+extern "C" int gfv_set_f16split_thread(int32_t on) {
+  if (on < -1 || on > 2) return GFV_ERR_ARG;
+  g_f16split = on;
   return GFV_OK;
 }
 static int f16_mode() { return gfv_f16split_enabled(); }
@@ -522,7 +536,7 @@ extern "C" int gfv_rowtile_chain(const gfv_rowtile_args_t* args, void* stream) {
   if (args->product_form < 0 || args->product_form > 3 || (args->hidden != 0 && (args->hidden < 16 || args->hidden > 128 || (args->hidden & 15))))
     return GFV_ERR_ARG;
   if (args->product_form == 0 && args->hidden == 0) return rowtile_chain_impl(args, stream);
-  const int f0 = g_f16split, h0 = g_hidden;
+  const int f0 = g_f16split, h0 = g_hidden;   // (f0: this thread's override or -1; restored below)
   if (args->product_form) g_f16split = args->product_form - 1;   // 1 fp32 MFMA, 2 split-fp16, 3 reduced precision
   if (args->hidden) g_hidden = args->hidden;
   const int rc = rowtile_chain_impl(args, stream);
@@ -543,6 +557,7 @@ static int rowtile_chain_impl(const gfv_rowtile_args_t* args, void* stream) {
   if (k0 != args->layer[0].K) return GFV_ERR_ARG;
   const gfv_layer_t& last = args->layer[args->nlayers - 1];
   if (last.N > 384 || last.N < 1) return GFV_ERR_ARG;
+  if ((args->rc_Wh[0] || args->rc_Wh[1]) && !args->dw_partial) return GFV_ERR_ARG;   // (recompute: the fused column-owner backward only)
   if (args->padd && (args->nlayers < 2 || args->padd_ld < 256 || (args->padd_ld & 3) || !args->padd_s || !args->padd_r)) return GFV_ERR_ARG;
   for (int l = 0; l < args->nlayers; ++l)
     if (args->layer[l].ldw != 0 && args->layer[l].ldw < args->layer[l].K) return GFV_ERR_ARG;
@@ -632,7 +647,7 @@ static int rowtile_chain_impl(const gfv_rowtile_args_t* args, void* stream) {
       // dX chain with fused weight gradients (column-owner backward family): + the two (three) weight-gradient GEMMs, the
       // forward's row statistics read, the first Linear's input rows read, the per-workgroup blocks written
       kind = GFV_K_COLCHAIN_BWD;
-      const int nfused = args->dw_in ? 3 : 2;
+      const int nfused = (args->dw_in ? 3 : 2) + (args->rc_Wh[0] ? 2 : 0);   // (+ the two recomputed forward layers)
       fl += nfused * 2.0 * args->M * 128.0 * 128.0;
       by += 8.0 * args->M + (args->dw_in ? 4.0 * args->M * 128.0 : 0.0) + 4.0 * (double)gfv_rowtile_dw_partials() * (double)args->dw_partial_stride;
     }

@@ -25,13 +25,6 @@ def file_flags(src):
     return first[len(tag):].split() if first.startswith(tag) else []
 
 
-def _stale(target, deps):
-    if not os.path.exists(target):
-        return True
-    t = os.path.getmtime(target)
-    return any(os.path.getmtime(d) > t for d in deps)
-
-
 def source_hash():
     """sha256 over every source the library is built from (a fresh checkout has arbitrary mtimes: the hash decides)."""
     import hashlib
@@ -45,17 +38,37 @@ def source_hash():
     return h.hexdigest()
 
 
+def _deps(src, seen=None):
+    """The local headers a source includes (transitively): `#include "x.h"` relative to the including file."""
+    import re
+    seen = set() if seen is None else seen
+    for m in re.finditer(r'^\s*#\s*include\s+"([^"]+)"', open(src).read(), re.M):
+        h = os.path.normpath(os.path.join(os.path.dirname(src), m.group(1)))
+        if h not in seen and os.path.exists(h):
+            seen.add(h)
+            _deps(h, seen)
+    return sorted(seen)
+
+
+def _unit_hash(src):
+    import hashlib
+    h = hashlib.sha256()
+    for f in [src] + _deps(src):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    h.update(" ".join(FLAGS + file_flags(src)).encode())
+    return h.hexdigest()
+
+
 def build(force=False, verbose=False):
     """Compile csrc/*.hip -> gfv/libgfv.so.  Up to date = the library exists AND was built from exactly these sources
-    (content hash kept next to it); otherwise everything is recompiled."""
+    (content hash kept next to it); otherwise the objects whose source or headers changed (a content hash per object, kept
+    next to it) are recompiled and the library is linked again."""
     stamp = LIB + ".srchash"
     want = source_hash()
     if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read().strip() == want:
         return LIB
-    force = True
     srcs = sources()
-    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
-    hdrs.append(os.path.join(os.path.dirname(os.path.dirname(HERE)), "include", "gfv.h"))
     objdir = os.path.join(CSRC, "build")
     os.makedirs(objdir, exist_ok=True)
     jobs = []
@@ -63,8 +76,10 @@ def build(force=False, verbose=False):
     for s in srcs:
         o = os.path.join(objdir, os.path.basename(s)[:-4] + ".o")
         objs.append(o)
-        if force or _stale(o, [s] + hdrs):
-            jobs.append([HIPCC, *FLAGS, *file_flags(s), "-c", s, "-o", o])
+        uh = _unit_hash(s)
+        hs = o + ".hash"
+        if force or not os.path.exists(o) or not os.path.exists(hs) or open(hs).read().strip() != uh:
+            jobs.append(([HIPCC, *FLAGS, *file_flags(s), "-c", s, "-o", o], hs, uh))
 
     def run(cmd):
         if verbose:
@@ -74,10 +89,17 @@ def build(force=False, verbose=False):
             raise RuntimeError(f"hipcc failed: {' '.join(cmd)}\n{r.stdout}\n{r.stderr}")
         return r
 
+    def compile_one(job):
+        cmd, hs, uh = job
+        if os.path.exists(hs):
+            os.remove(hs)
+        run(cmd)
+        with open(hs, "w") as f:
+            f.write(uh + "\n")
+
     with ThreadPoolExecutor(max_workers=4) as ex:
-        list(ex.map(run, jobs))
-    if force or jobs or _stale(LIB, objs):
-        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB])
+        list(ex.map(compile_one, jobs))
+    run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB])
     with open(stamp, "w") as f:
         f.write(want + "\n")
     return LIB

@@ -138,6 +138,9 @@ class Engine:
         # gfv_rowtile_args_t.dw_partial): the chain launch accumulates dW3, dW2 (and dW1 of a 128-deep first layer), the bias
         # gradients and the LayerNorm's per workgroup; one reduction launch per MLP sums the blocks
         self.fuse_dw = os.environ.get("GFV_FUSE_DW", "1") != "0"
+        # ... and recompute z2 and the LayerNorm input from z1 in that launch instead of saving them in the forward and reading
+        # them back (gfv_rowtile_args_t.rc_Wh): the forward of such an MLP writes z1, the row statistics and its outputs only
+        self.recompute = os.environ.get("GFV_RECOMPUTE", "1") != "0"
         self._slice_fuse = os.environ.get("GFV_SLICE_FUSE", "1") != "0"   # Transolver adjoint: one pass behind the attention
         self._tail_main = int(os.environ.get("GFV_TAIL_MAIN", "2"))
         self._split_all = int(os.environ.get("GFV_SPLIT_ALL", "0"))     # (experiment) the same split for every GnBlock's flush
@@ -288,6 +291,8 @@ class Engine:
                                                L.stream_ptr()), "gfv_weight_absmax")
         elif not wi.static and self._wt:
             wi.add_static(self._wt.values())
+            if self.recompute:
+                wi.add_static(P.values())   # the recompute form also takes FORWARD images of the second / third Linear here
         wi.build()
         return ops.set_weight_images(wi)
 
@@ -386,15 +391,17 @@ class Engine:
             W1 = w1
         dev = W1.device
         nout = W3.shape[0]
+        # (mean, 1 / std) of the LayerNorm rows for a backward launch that fuses the weight gradients (it does not recompute them)
+        fused_bwd = (keep and ln and self.fuse_dw and self.f16split and self.hidden == 128 and nout == 128
+                     and M >= self._fuse_dw_min and (self._fuse_noout or all(sg.width % 32 == 0 for sg in segs)))
+        stats = _empty(dev, M, 2) if fused_bwd else None
+        # that launch rebuilds z2 and the LayerNorm input from z1 (recompute form): they are not written here at all
+        lean = fused_bwd and self.recompute
         z1 = _empty(dev, M, 128) if keep else None
-        z2 = _empty(dev, M, 128) if keep else None
-        y3 = _empty(dev, M, 128) if (keep and ln) else None
+        z2 = _empty(dev, M, 128) if (keep and not lean) else None
+        y3 = _empty(dev, M, 128) if (keep and ln and not lean) else None
         out = _empty(dev, M, nout)
         nores = _empty(dev, M, 128) if want_nores else None
-        # (mean, 1 / std) of the LayerNorm rows for a backward launch that fuses the weight gradients (it does not recompute them)
-        stats = _empty(dev, M, 2) if (keep and ln and self.fuse_dw and self.f16split and self.hidden == 128 and nout == 128
-                                      and M >= self._fuse_dw_min
-                                      and (self._fuse_noout or all(sg.width % 32 == 0 for sg in segs))) else None
         ops.rowtile_chain(
             M, segs,
             [LayerSpec(W1, b1, L.OP_BIAS_GELU, save=z1), LayerSpec(W2, b2, L.OP_BIAS_GELU, save=z2), LayerSpec(W3, b3)],
@@ -404,8 +411,20 @@ class Engine:
             **(dict(padd=padd[0], padd_s=padd[1], padd_r=padd[2]) if padd is not None else {}))
         # (a segmented-sum input segment is kept for the backward in its assembled form, written by the launch itself)
         saved = dict(z1=z1, z2=z2, y3=y3, segs=segs if saved_segs is None else saved_segs, in_add=in_add, M=M, ln=ln,
-                     prefix=prefix, stats=stats)
+                     prefix=prefix, stats=stats, lean=lean)
         return out, nores, saved
+
+    def _rematerialize(self, P, sv):
+        """z2 and the LayerNorm input of an MLP whose forward kept z1 only (recompute form), for a backward that turns out not
+        to run fused after all (a gradient with a foreign row stride, a stand-alone operator called with other arguments): one
+        two-layer launch from z1."""
+        if not sv.get("lean") or sv["z2"] is not None:
+            return
+        names = self._mlp_names(sv["prefix"], sv["ln"])
+        M, dev = sv["M"], sv["z1"].device
+        sv["z2"], sv["y3"] = _empty(dev, M, 128), _empty(dev, M, 128)
+        ops.rowtile_chain(M, [Seg(sv["z1"])], [LayerSpec(P[names[2]], P[names[3]], L.OP_BIAS_GELU, save=sv["z2"]),
+                                              LayerSpec(P[names[4]], P[names[5]])], [sv["y3"]], in_op=L.IN_GELU)
 
     def mlp3_bwd(self, P, sv, G, grads, *, outs=None, res=None, gadd=None, W1t=None, g_ld=None, g_add=None):
         """G: grad wrt the MLP output (after LayerNorm, before the residual) [M, nout].  outs: per 128-chunk of the
@@ -421,6 +440,7 @@ class Engine:
                 and self._mlp3_bwd_fused(P, sv, G, grads, names, W3t, W2t,
                                          None if outs is None else (W1t if W1t is not None else self._T(W1)), outs, res, g_add)):
             return
+        self._rematerialize(P, sv)
         gz2, gz1 = _empty(dev, M, 128), _empty(dev, M, 128)
         tiles_n = ops.rowtile_tiles(M)
         part = _empty(dev, tiles_n, 2, 128) if ln else None
@@ -489,7 +509,7 @@ class Engine:
             layers = [LayerSpec(W3t, None, L.OP_MUL_DGELU, aux=sv["z2"]),
                       LayerSpec(W2t, None, L.OP_MUL_DGELU, save=gz1, aux=sv["z1"]), LayerSpec(W1t)]
         kw = dict(res=res, in_op=L.IN_LNBWD, in_gamma=P[names[6]], in_aux=sv["y3"], in_stats=sv["stats"], dw_partial=dwp, gscale=gs,
-                  in_add=g_add)
+                  in_add=g_add, rc=(P[names[2]], P[names[3]], P[names[4]], P[names[5]]) if sv["z2"] is None else None)
         if not ops.rowtile_chain(M, [Seg(G)], layers, outs, query_fused=True, **kw):
             return False
         ops.rowtile_chain(M, [Seg(G)], layers, outs, **kw)
@@ -632,6 +652,7 @@ class Engine:
             fused = self._edge_bwd_fused(P, sv, G, grads, pl, gadd, names, (W3t, W2t, W1ct, Wabt))
             if fused is not None:
                 return fused
+        self._rematerialize(P, sv)
         gz2, gz1, g3, g_e_in = (_empty(dev, M, 128) for _ in range(4))
         tiles_n = ops.rowtile_tiles(M)
         part = _empty(dev, tiles_n, 2, 128)
@@ -693,7 +714,8 @@ class Engine:
         e = sv["segs"][0].t
         lib = L.load()
         nwg = lib.gfv_rowtile_dw_partials()
-        fuse1 = os.environ.get("GFV_FUSE_DW1", "0") == "1"   # the first layer's gradient in the chain launch too (it spills: off)
+        lean = sv["z2"] is None   # recompute form: the forward kept z1 only
+        fuse1 = os.environ.get("GFV_FUSE_DW1", "0") == "1" and not lean   # the first layer's gradient in the chain launch too (it spills: off)
         FL = L.DW_FUSED_FLOATS_IN if fuse1 else L.DW_FUSED_FLOATS
         dwp = _empty(dev, nwg, FL)
         gz1, g_e_in = _empty(dev, M, 128), _empty(dev, M, 128)
@@ -701,7 +723,8 @@ class Engine:
                   LayerSpec(W1ct)]
         gs = _empty(dev, 3, ops.gscale_ld(M))   # slot 2: the scales of gz1's rows for the first layer's weight-gradient launch
         kw = dict(res=[G], in_op=L.IN_LNBWD, in_gamma=P[names[6]], in_aux=sv["y3"], in_stats=sv["stats"], gadd=gadd[0], gadd_s=gadd[1],
-                  gadd_r=gadd[2], dw_partial=dwp, dw_in=e if fuse1 else None, gscale=gs)
+                  gadd_r=gadd[2], dw_partial=dwp, dw_in=e if fuse1 else None, gscale=gs,
+                  rc=(P[names[2]], P[names[3]], P[names[4]], P[names[5]]) if lean else None)
         if not ops.rowtile_chain(M, [Seg(G)], layers, [g_e_in], query_fused=True, **kw):
             return None
         ops.rowtile_chain(M, [Seg(G)], layers, [g_e_in], **kw)
@@ -961,8 +984,11 @@ class Engine:
         sv["dec"] = dec
         return losses, uvp_node, uvp_cell, sv
 
-    def fvm_core_fwd(self, phi, pl, want_outputs=True):
-        """phi [N,8] = (uvp_new, uv_hat, uv_old, 0) -> residual losses [B,4], smoothed node field, cell field."""
+    def fvm_core_fwd(self, phi, pl, want_outputs=True, raw_outputs=False):
+        """phi [N,8] = (uvp_new, uv_hat, uv_old, 0) -> residual losses [B,4], smoothed node field, cell field.
+        raw_outputs: the two fields as the reference's stand-alone Intergrator returns them (FVscheme.py:253-262,718-724) - the
+        smoothed node field before the Dirichlet overwrite and neither field re-dimensionalised (importer.py:223-231 does both
+        afterwards)."""
         lib = L.load()
         st = L.stream_ptr()
         N, E, C, B = pl.N, pl.E, pl.C, pl.B
@@ -995,7 +1021,9 @@ class Engine:
             L.check(lib.gfv_cell_to_node(phic.data_ptr(), pl.nrow.data_ptr(), pl.ncell.data_ptr(), pl.pos.data_ptr(),
                                          pl.centroid.data_ptr(), pl.node_type.data_ptr(), pl.y.data_ptr(),
                                          pl.batch.data_ptr(), pl.uvp_dim.data_ptr(), pl.sigma.data_ptr(), phi.data_ptr(),
-                                         self.smooth, uvp_node.data_ptr(), N, st), "cell_to_node")
+                                         self.smooth | (2 if raw_outputs else 0), uvp_node.data_ptr(), N, st), "cell_to_node")
+            if raw_outputs:
+                uvp_cell = phic[:, 0:3].clone()
         sv = dict(Ff=Ff, cres=cres, sums=sums, phi=phi, grad=grad, phic=phic, gradc=gradc)
         return losses, uvp_node, uvp_cell, sv
 

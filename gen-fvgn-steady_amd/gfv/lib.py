@@ -47,8 +47,11 @@ class RowtileArgs(C.Structure):
         ("gscale", C.c_void_p), ("gscale_ld", C.c_int32), ("product_form", C.c_int32),
         ("fin_stats", C.c_void_p), ("in_stats", C.c_void_p), ("dw_partial", C.c_void_p), ("dw_partial_stride", C.c_int64),
         ("dw_in", C.c_void_p), ("dw_in_ld", C.c_int32), ("reserved2_", C.c_int32),
+        ("rc_Wh", C.c_void_p * 2), ("rc_bias", C.c_void_p * 2),
     ]
 
+
+ABI_VERSION = 2   # GFV_ABI_VERSION of include/gfv.h this binding is written against
 
 DW_FUSED_FLOATS = 2 * 128 * 128 + 4 * 128   # floats per workgroup block of a fused weight-gradient launch (include/gfv.h)
 DW_FUSED_FLOATS_IN = 3 * 128 * 128 + 5 * 128   # ... with the first Linear's weight gradient fused as well (dw_in)
@@ -113,6 +116,7 @@ _SIGNATURES = {
     "gfv_concat_offsets": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "gfv_f16split_enabled": (C.c_int, []),
     "gfv_set_f16split": (C.c_int, [C.c_int32]),
+    "gfv_set_f16split_thread": (C.c_int, [C.c_int32]),
     "gfv_hidden_size": (C.c_int, []),
     "gfv_set_hidden_size": (C.c_int, [C.c_int32]),
     "gfv_weight_image_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
@@ -211,6 +215,14 @@ def load(raw=False):
     for name, (restype, argtypes) in _SIGNATURES.items():
         fn = getattr(lib, name)  # raises AttributeError if the symbol is missing
         fn.restype, fn.argtypes = restype, argtypes
+    # the binding and the library must agree on the ABI: version and the layout of every argument struct
+    if lib.gfv_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"libgfv.so has ABI {lib.gfv_abi_version()}, this binding is written for {ABI_VERSION}: rebuild it "
+                           "(python gen-fvgn-steady_amd/gfv/build.py)")
+    for which, st in enumerate((Seg, Layer, RowtileArgs, WimgDesc, DwTile, ReducePiece, PlanDesc)):
+        if lib.gfv_struct_size(which) != C.sizeof(st):
+            raise RuntimeError(f"libgfv.so: struct {st.__name__} is {lib.gfv_struct_size(which)} bytes in the library, "
+                               f"{C.sizeof(st)} in the binding")
     _lib = lib
     return lib if (_recording is None or raw) else _recording
 

@@ -229,7 +229,7 @@ def rowtile_chain(M, segs, layers, outs, *, in_add=None, in_op=L.IN_NONE, in_gam
                   gadd=None, gadd_s=None, gadd_r=None, in_save=None, ln_partial=None, fin_op=L.FIN_PLAIN,
                   fin_gamma=None, fin_beta=None, fin_aux=None, fin_presave=None, res=None, out_nores=None,
                   padd=None, padd_s=None, padd_r=None, wimg=None, gscale=None, family=0, fin_stats=None, in_stats=None,
-                  dw_partial=None, dw_in=None, query_fused=False):
+                  dw_partial=None, dw_in=None, query_fused=False, rc=None):
     """Launch the fused row-tile GEMM chain.  outs / res: list (per 128-wide chunk of the last layer) of
     (tensor, ld) or tensors; see include/gfv.h for the semantics of every field.  gscale: [3, ld] buffer for the
     per-16-row scales of the gradient rows the launch leaves behind; returns True when the launch wrote it (split-fp16
@@ -237,7 +237,9 @@ def rowtile_chain(M, segs, layers, outs, *, in_add=None, in_op=L.IN_NONE, in_gam
     the kernel family, lib.CHAIN_ROW_OWNER / lib.CHAIN_COLUMN_OWNER pin it (include/gfv.h, gfv_rowtile_args_t.flags).
     fin_stats / in_stats: [M, 2] LayerNorm row statistics out of a forward / into a backward launch; dw_partial:
     [gfv_rowtile_dw_partials(), DW_FUSED_FLOATS] workspace of a backward chain with fused weight gradients; query_fused:
-    do not launch, return whether the library would run this launch with fused weight gradients (gfv_rowtile_fuses_dw)."""
+    do not launch, return whether the library would run this launch with fused weight gradients (gfv_rowtile_fuses_dw).
+    rc = (W2, b2, W3, b3): the FORWARD's second and third Linear of the MLP whose backward this launch is - it then recomputes
+    z2 and the LayerNorm input from z1 instead of reading them (include/gfv.h, rc_Wh; needs dw_partial and weight images)."""
     lib = L.load()
     wi = wimg if wimg is not None else _WI
     if layers[-1].stack is not None:
@@ -298,6 +300,15 @@ def rowtile_chain(M, segs, layers, outs, *, in_add=None, in_op=L.IN_NONE, in_gam
         a.dw_partial, a.dw_partial_stride = dw_partial.data_ptr(), dw_partial.stride(0)
         if dw_in is not None:
             a.dw_in, a.dw_in_ld = dw_in.data_ptr(), dw_in.stride(0)
+    if rc is not None:
+        W2, b2, W3, b3 = rc
+        h2, h3 = (wi.lookup(W2), wi.lookup(W3)) if wi is not None else (0, 0)
+        if not (h2 and h3):
+            if query_fused:
+                return False
+            raise RuntimeError("recompute form: no split-fp16 image of the forward's second / third Linear")
+        a.rc_Wh[0], a.rc_Wh[1] = h2, h3
+        a.rc_bias[0], a.rc_bias[1] = _p(b2), _p(b3)
     if padd is not None:
         a.padd, a.padd_s, a.padd_r, a.padd_ld = _p(padd), _p(padd_s), _p(padd_r), padd.stride(0)
     if gscale is not None:

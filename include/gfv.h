@@ -2,8 +2,9 @@
  *
  * Every entry point is `extern "C"`, takes plain device pointers + sizes + a hipStream_t (as void*), allocates
  * nothing, is asynchronous on the given stream and returns 0 (GFV_OK) or a negative error code.  State the library keeps:
- * two THREAD-LOCAL launch-context values (the product form, gfv_set_f16split, and the model's hidden size,
- * gfv_set_hidden_size - like the HIP runtime's current device; a chain launch may carry its own in its argument struct),
+ * the product form (a process-wide default, gfv_set_f16split, with an optional per-thread override,
+ * gfv_set_f16split_thread) and the model's hidden size (thread-local, gfv_set_hidden_size - like the HIP runtime's current
+ * device); a chain launch may carry its own of both in its argument struct,
  * the device status word (gfv_status_flags), the optional profiling records (gfv_profile_*) and the mesh plans a caller
  * creates and destroys (gfv_plan_create / gfv_plan_destroy).  All floating point data is fp32, all index data int32 (plans are narrowed from the reference's
  * int64 once per mesh batch).
@@ -21,7 +22,10 @@
 extern "C" {
 #endif
 
-#define GFV_ABI_VERSION 1
+/* 2 (round 4): gfv_rowtile_args_t grew (rc_Wh, rc_bias; round 3 had already turned its former pad fields hidden / flags /
+ * product_form into live inputs and appended fin_stats .. dw_in_ld without a bump), gfv_set_f16split became a process-wide
+ * default with gfv_set_f16split_thread beside it.  A binding checks gfv_abi_version() AND gfv_struct_size() at load. */
+#define GFV_ABI_VERSION 2
 int gfv_abi_version(void);
 /* sizeof of the argument structs as the library was compiled (which: 0 gfv_seg_t, 1 gfv_layer_t, 2 gfv_rowtile_args_t,
  * 3 gfv_wimg_desc_t, 4 gfv_dw_tile_t, 5 gfv_reduce_piece_t, 6 gfv_plan_desc_t): lets a binding check its own layout */
@@ -152,7 +156,7 @@ typedef struct {
    * gfv_dw_tile_t.gscale takes a slot: the slab scale of the gradient rows then needs no extra pass over them. */
   float* gscale;
   int32_t gscale_ld;
-  int32_t product_form;   /* 0 = the calling thread's setting (gfv_set_f16split); 1 fp32 MFMA, 2 split-fp16, 3 reduced precision */
+  int32_t product_form;   /* 0 = gfv_f16split_enabled() of the calling thread; 1 fp32 MFMA, 2 split-fp16, 3 reduced precision */
   /* LayerNorm statistics of the rows, [M, 2] = (mean, 1 / sqrt(var + eps)): written by a GFV_FIN_LN launch when fin_stats is
    * given, read by a GFV_IN_LNBWD launch when in_stats is given (the column-owner backward needs them: its LayerNorm backward
    * is spread over eight waves and takes the row statistics as they were in the forward instead of recomputing them) */
@@ -175,6 +179,14 @@ typedef struct {
   const float* dw_in;
   int32_t dw_in_ld;
   int32_t reserved2_;
+  /* optional with dw_partial (ABI 2): RECOMPUTE instead of re-read.  rc_Wh[0] / rc_Wh[1] = split-fp16 images (built with the
+   * same wmax) of the FORWARD's second and third Linear ([128, 128] each, un-transposed), rc_bias[0] / rc_bias[1] their biases
+   * (or NULL).  The launch then rebuilds z2 = W2 gelu(z1) + b2 and the LayerNorm input y = W3 gelu(z2) + b3 tile by tile from
+   * z1 (layer[1].aux) on the matrix cores; layer[0].aux (z2) and in_aux (y) are NOT read and may be NULL - the forward launch
+   * need not save them (gfv_layer_t.save of its second layer, fin_presave).  in_stats is still read (the rows' forward
+   * statistics).  Not together with dw_in. */
+  const void* rc_Wh[2];
+  const float* rc_bias[2];
 } gfv_rowtile_args_t;
 enum { GFV_DW_FUSED_FLOATS = 2 * 128 * 128 + 4 * 128, GFV_DW_FUSED_FLOATS_IN = 3 * 128 * 128 + 5 * 128 };
 int gfv_rowtile_dw_partials(void);                              /* workgroups (= partial blocks) of a fused launch */
@@ -204,7 +216,11 @@ typedef struct {
 } gfv_wimg_desc_t;
 size_t gfv_weight_image_bytes(int32_t N, int32_t K);
 /* wmax[0] = max |W| over all described blocks (device scalar, overwritten) */
-/* the calling thread's product form (thread-local; initial value: environment GFV_F16SPLIT, default 1);
+/* the product form of the launches that do not name their own: a PROCESS-WIDE default (initial value: environment
+ * GFV_F16SPLIT, default 1; gfv_set_f16split) - it must reach launches issued from other threads than the one that chose it:
+ * PyTorch runs the backward of an autograd node on its device worker thread - and an optional override of the CALLING THREAD
+ * (gfv_set_f16split_thread(0 / 1 / 2); -1 removes it) for hosts that drive two models in different forms from two threads.
+ * gfv_set_f16split also removes the calling thread's override.  gfv_f16split_enabled() = what a launch from this thread gets.
  * 0 = fp32 MFMA everywhere (chain launches ignore their images, weight gradients take the fp32 kernel);
  * 1 = split-fp16 products (fp32 accuracy);
  * 2 = reduced precision: one fp16 x fp16 product per term with fp32 accumulation - the high parts of the same operands
@@ -212,6 +228,7 @@ size_t gfv_weight_image_bytes(int32_t N, int32_t K);
  *     BASELINE configs 3 / 5 - never the form the parity claims or bench.py's `value` are made on) */
 int gfv_f16split_enabled(void);
 int gfv_set_f16split(int32_t on);
+int gfv_set_f16split_thread(int32_t on);
 /* hidden_size of the model the following launches belong to (the reference's --hidden_size, utils/get_param.py:69; default
  * 128; multiples of 16 in [16, 128]).  Every kernel works on 128-column latent rows; a narrower model runs zero-padded to
  * 128 columns (the host side pads its parameters: FVMmodel/padding.py) and differs in two places only - LayerNorm takes its

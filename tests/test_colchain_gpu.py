@@ -1,6 +1,7 @@
-"""GPU: the column-owner persistent chain family (csrc/colchain_kernel.h) against a float64 torch restatement of the
-fused MLP (EPD.py:10-33 build_mlp inside blocks.py EdgeBlock / NodeBlock) and against the row-owner family on the same
-launch; tolerance 1e-5 relative (fp32), as for every other kernel (tests/test_kernels_gpu.py)."""
+"""GPU: the column-owner persistent backward family (csrc/colchain_kernel.h) against float64 autograd of the fused MLP
+(EPD.py:10-33 build_mlp inside blocks.py EdgeBlock / NodeBlock, the encoders); tolerance 1e-5 relative (fp32), as for every
+other kernel (tests/test_kernels_gpu.py).  Every test runs in the read form (z2 and the LayerNorm input saved by the forward)
+and in the RECOMPUTE form (rebuilt from z1 inside the launch: include/gfv.h, rc_Wh)."""
 import pytest
 import torch
 import torch.nn.functional as F
@@ -48,95 +49,9 @@ def _images(dev, Ws):
     return wi
 
 
-@pytest.mark.parametrize("M", [5000, 2049, 16, 129])
-@pytest.mark.parametrize("padd", [True, False])
-def test_column_owner_edge_mlp_forward(dev, M, padd):
-    """EdgeBlock forward in its factored form: one 128-wide segment + the gathered first-layer addend, every saved tensor."""
-    from gfv import lib as L, ops
-    g = torch.Generator().manual_seed(M + padd)
-    n_nodes = 700
-    e = torch.randn(M, 128, generator=g) * (1 + 3 * torch.rand(M, 1, generator=g))
-    e[3] *= 1e-4          # a tiny row and a big row: the input rows carry their own power-of-two scale
-    e[min(5, M - 1)] *= 30.0
-    pab = torch.randn(n_nodes, 256, generator=g)
-    s = torch.randint(0, n_nodes, (M,), generator=g)
-    r = torch.randint(0, n_nodes, (M,), generator=g)
-    P = _params(g, 128)
-    add = (pab[s, :128] + pab[r, 128:]).double() if padd else None
-    z1, z2, y3, ln = _ref(P, e.double(), add)
-    d = lambda t: t.to(dev).contiguous()
-    Pd = {k: d(v) for k, v in P.items()}
-    ed, pabd, sd, rd = d(e), d(pab), d(s.int()), d(r.int())
-    wi = _images(dev, [P["W1"], P["W2"], P["W3"]])
-    res = {}
-    for fam in (L.CHAIN_COLUMN_OWNER, L.CHAIN_ROW_OWNER):
-        z1d, z2d, y3d, outd, enew = (torch.full((M, 128), float("nan"), device=dev) for _ in range(5))
-        ops.rowtile_chain(
-            M, [ops.Seg(ed)],
-            [ops.LayerSpec(Pd["W1"], Pd["b1"], L.OP_BIAS_GELU, save=z1d),
-             ops.LayerSpec(Pd["W2"], Pd["b2"], L.OP_BIAS_GELU, save=z2d), ops.LayerSpec(Pd["W3"], Pd["b3"])],
-            [outd], fin_op=L.FIN_LN, fin_gamma=Pd["gamma"], fin_beta=Pd["beta"], fin_presave=y3d, res=[ed], out_nores=enew,
-            wimg=wi, family=fam, **(dict(padd=pabd, padd_s=sd, padd_r=rd) if padd else {}))
-        path = L.load().gfv_rowtile_last_path()
-        assert path == (13 if fam == L.CHAIN_COLUMN_OWNER else 5), path
-        for mine, want, name in ((z1d, z1, "z1"), (z2d, z2, "z2"), (y3d, y3, "y3"), (enew, ln, "ln"), (outd, ln + e.double(), "out")):
-            assert rel(mine, want) < TOL, (fam, name, rel(mine, want))
-        res[fam] = outd
-    assert rel(res[L.CHAIN_COLUMN_OWNER], res[L.CHAIN_ROW_OWNER]) < 2e-6
-    flags = L.C.c_int32(0)
-    L.check(L.load().gfv_status_flags(L.C.byref(flags)), "gfv_status_flags")
-    assert flags.value == 0
-
-
-@pytest.mark.parametrize("M", [3000, 97])
-def test_column_owner_node_mlp_forward(dev, M):
-    """NodeBlock forward: input [nbm (64) | x (128)], K = 192, row-gathered first segment."""
-    from gfv import lib as L, ops
-    g = torch.Generator().manual_seed(M)
-    nbm, x = torch.randn(M + 50, 64, generator=g), torch.randn(M, 128, generator=g)
-    idx = torch.randperm(M + 50, generator=g)[:M]
-    P = _params(g, 192)
-    z1, z2, y3, ln = _ref(P, torch.cat((nbm[idx], x), 1).double())
-    d = lambda t: t.to(dev).contiguous()
-    Pd = {k: d(v) for k, v in P.items()}
-    xd, nbmd = d(x), d(nbm)
-    wi = _images(dev, [P["W1"], P["W2"], P["W3"]])
-    z1d, z2d, y3d, outd = (torch.full((M, 128), float("nan"), device=dev) for _ in range(4))
-    ops.rowtile_chain(M, [ops.Seg(nbmd, d(idx.int())), ops.Seg(xd)],
-                      [ops.LayerSpec(Pd["W1"], Pd["b1"], L.OP_BIAS_GELU, save=z1d),
-                       ops.LayerSpec(Pd["W2"], Pd["b2"], L.OP_BIAS_GELU, save=z2d), ops.LayerSpec(Pd["W3"], Pd["b3"])],
-                      [outd], fin_op=L.FIN_LN, fin_gamma=Pd["gamma"], fin_beta=Pd["beta"], fin_presave=y3d, res=[xd],
-                      wimg=wi, family=L.CHAIN_COLUMN_OWNER)
-    assert L.load().gfv_rowtile_last_path() == 13
-    for mine, want, name in ((z1d, z1, "z1"), (z2d, z2, "z2"), (y3d, y3, "y3"), (outd, ln + x.double(), "out")):
-        assert rel(mine, want) < TOL, (name, rel(mine, want))
-
-
-def test_column_owner_hidden_range_flag(dev):
-    """Hidden activations are split after a fixed scale: beyond 2^11 the status word says so (include/gfv.h)."""
-    from gfv import lib as L, ops
-    g = torch.Generator().manual_seed(0)
-    M = 64
-    P = _params(g, 128)
-    P["b1"] = P["b1"] + 5000.0
-    d = lambda t: t.to(dev).contiguous()
-    Pd = {k: d(v) for k, v in P.items()}
-    ed = d(torch.randn(M, 128, generator=g))
-    out = torch.empty(M, 128, device=dev)
-    wi = _images(dev, [P["W1"], P["W2"], P["W3"]])
-    flags = L.C.c_int32(0)
-    L.check(L.load().gfv_status_flags(L.C.byref(flags)), "gfv_status_flags")
-    ops.rowtile_chain(M, [ops.Seg(ed)],
-                      [ops.LayerSpec(Pd["W1"], Pd["b1"], L.OP_BIAS_GELU), ops.LayerSpec(Pd["W2"], Pd["b2"], L.OP_BIAS_GELU),
-                       ops.LayerSpec(Pd["W3"], Pd["b3"])], [out], fin_op=L.FIN_LN, fin_gamma=Pd["gamma"],
-                      fin_beta=Pd["beta"], wimg=wi, family=L.CHAIN_COLUMN_OWNER)
-    L.check(L.load().gfv_status_flags(L.C.byref(flags)), "gfv_status_flags")
-    assert flags.value & 2
-
-
 @pytest.mark.parametrize("M", [4000, 97, 1024])
 @pytest.mark.parametrize("extras", [True, False])
-@pytest.mark.parametrize("dw1", [True, False])
+@pytest.mark.parametrize("dw1", [True, False, "rc"])
 def test_column_owner_backward_with_fused_weight_gradients(dev, M, extras, dw1):
     """EdgeBlock backward in its factored form: LayerNorm backward, the three transposed layers, residual; with the weight
     gradients of the third and second Linear, their bias gradients and (dgamma, dbeta) accumulated by the same launch
@@ -172,8 +87,13 @@ def test_column_owner_backward_with_fused_weight_gradients(dev, M, extras, dw1):
     nwg = L.load().gfv_rowtile_dw_partials()
     part = torch.full((nwg, L.DW_FUSED_FLOATS_IN if dw1 else L.DW_FUSED_FLOATS), float("nan"), device=dev)
     kw = dict(gadd=d(gagg), gadd_s=d(s.int()), gadd_r=d(r.int()), in_add=d(gadd2)) if extras else {}
+    rc = dw1 == "rc"     # recompute form: neither z2 nor the LayerNorm input is handed over
+    dw1 = dw1 is True
     if dw1:
         kw["dw_in"] = d(e)
+    if rc:
+        kw["rc"] = (Pd["W2"], Pd["b2"], Pd["W3"], Pd["b3"])
+        z2d = y3d = None
     args = dict(in_op=L.IN_LNBWD, in_gamma=Pd["gamma"], in_aux=y3d, in_stats=stats, res=[god], dw_partial=part, wimg=wi,
                 family=L.CHAIN_COLUMN_OWNER, **kw)
     layers = [ops.LayerSpec(W3t, None, L.OP_MUL_DGELU, aux=z2d), ops.LayerSpec(W2t, None, L.OP_MUL_DGELU, save=gz1, aux=z1d),
@@ -203,7 +123,8 @@ def test_column_owner_backward_with_fused_weight_gradients(dev, M, extras, dw1):
 
 
 @pytest.mark.parametrize("M", [3000, 333])
-def test_column_owner_backward_node_mlp_192_wide(dev, M):
+@pytest.mark.parametrize("rc", [False, True])
+def test_column_owner_backward_node_mlp_192_wide(dev, M, rc):
     """NodeBlock dX chain: last layer 192 wide, written as [x part 128 (+ residual) | neighbour-mean part 64] (blocks.py:54
     adjoint); weight gradients of the third and second Linear fused, the first one's by the weight-gradient kernel with the
     row scales the chain launch leaves behind."""
@@ -229,10 +150,14 @@ def test_column_owner_backward_node_mlp_192_wide(dev, M):
     part = torch.full((L.load().gfv_rowtile_dw_partials(), L.DW_FUSED_FLOATS), float("nan"), device=dev)
     gs = torch.zeros(3, ops.gscale_ld(M), device=dev)
     god = d(go)
+    rckw = {}
+    if rc:
+        rckw["rc"] = (Pd["W2"], Pd["b2"], Pd["W3"], Pd["b3"])
+        z2d = y3d = None
     layers = [ops.LayerSpec(ops.transpose(Pd["W3"]), None, L.OP_MUL_DGELU, aux=z2d),
               ops.LayerSpec(ops.transpose(Pd["W2"]), None, L.OP_MUL_DGELU, save=gz1, aux=z1d), ops.LayerSpec(W1t)]
     kw = dict(res=[god, None], in_op=L.IN_LNBWD, in_gamma=Pd["gamma"], in_aux=y3d, in_stats=stats, dw_partial=part, gscale=gs,
-              wimg=wi, family=L.CHAIN_COLUMN_OWNER)
+              wimg=wi, family=L.CHAIN_COLUMN_OWNER, **rckw)
     assert ops.rowtile_chain(M, [ops.Seg(god)], layers, [gx, (gnbm, 64)], query_fused=True, **kw)
     ops.rowtile_chain(M, [ops.Seg(god)], layers, [gx, (gnbm, 64)], **kw)
     assert L.load().gfv_rowtile_last_path() == 5 + 16
@@ -247,7 +172,8 @@ def test_column_owner_backward_node_mlp_192_wide(dev, M):
 
 
 @pytest.mark.parametrize("M", [3000, 333, 16])
-def test_column_owner_backward_without_input_gradient(dev, M):
+@pytest.mark.parametrize("rc", [False, True])
+def test_column_owner_backward_without_input_gradient(dev, M, rc):
     """Encoder backward (EPD.py:92-119: the raw inputs need no gradient): a TWO-layer launch whose output is gz1; weight
     gradients of the third and second Linear, bias and LayerNorm gradients fused; the narrow first Linear's (16 input
     columns) by the weight-gradient kernel with the row scales the chain launch leaves behind."""
@@ -268,10 +194,14 @@ def test_column_owner_backward_without_input_gradient(dev, M):
     part = torch.full((L.load().gfv_rowtile_dw_partials(), L.DW_FUSED_FLOATS), float("nan"), device=dev)
     gs = torch.zeros(3, ops.gscale_ld(M), device=dev)
     god = d(go)
+    rckw = {}
+    if rc:
+        rckw["rc"] = (Pd["W2"], Pd["b2"], Pd["W3"], Pd["b3"])
+        z2d = y3d = None
     layers = [ops.LayerSpec(ops.transpose(Pd["W3"]), None, L.OP_MUL_DGELU, aux=z2d),
               ops.LayerSpec(ops.transpose(Pd["W2"]), None, L.OP_MUL_DGELU, aux=z1d)]
     kw = dict(in_op=L.IN_LNBWD, in_gamma=Pd["gamma"], in_aux=y3d, in_stats=stats, dw_partial=part, gscale=gs, wimg=wi,
-              family=L.CHAIN_COLUMN_OWNER)
+              family=L.CHAIN_COLUMN_OWNER, **rckw)
     assert ops.rowtile_chain(M, [ops.Seg(god)], layers, [gz1], query_fused=True, **kw)
     ops.rowtile_chain(M, [ops.Seg(god)], layers, [gz1], **kw)
     assert L.load().gfv_rowtile_last_path() == 5 + 16

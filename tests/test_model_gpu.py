@@ -498,3 +498,42 @@ def test_small_fixtures_against_the_float64_oracle(case):
             continue
         assert report[key][0] < TOL, (key, report[key])
     check_gradients(report, case)
+
+
+def test_product_form_reaches_the_autograd_worker_thread():
+    """PyTorch runs the backward of a CUDA autograd node on its device worker thread.  The product form
+    chosen with `gfv_set_f16split` on the user's thread is a process-wide default, so the launches issued from that thread take
+    it too (a thread-local-only setting left the backward in the environment's form while the forward ran in the requested one);
+    `gfv_set_f16split_thread` is the per-thread override on top of it."""
+    import threading
+    from gfv import lib as L
+    lib = L.load()
+    seen = {}
+
+    class Probe(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x):
+            return x.clone()
+
+        @staticmethod
+        def backward(ctx, g):
+            seen["form"], seen["thread"] = lib.gfv_f16split_enabled(), threading.get_ident()
+            return g
+
+    try:
+        for form in (2, 0, 1):
+            lib.gfv_set_f16split(form)
+            x = torch.ones(4, device="cuda", requires_grad=True)
+            Probe.apply(x).sum().backward()
+            assert seen["form"] == form and lib.gfv_f16split_enabled() == form
+        assert seen["thread"] != threading.get_ident(), "the probe's backward ran on the calling thread: nothing was tested"
+        # the per-thread override: visible on this thread only, removed by -1 and by gfv_set_f16split
+        assert lib.gfv_set_f16split_thread(2) == 0 and lib.gfv_f16split_enabled() == 2
+        other = {}
+        t = threading.Thread(target=lambda: other.setdefault("form", lib.gfv_f16split_enabled()))
+        t.start(); t.join()
+        assert other["form"] == 1
+        assert lib.gfv_set_f16split_thread(-1) == 0 and lib.gfv_f16split_enabled() == 1
+        assert lib.gfv_set_f16split_thread(3) != 0
+    finally:
+        lib.gfv_set_f16split(1)

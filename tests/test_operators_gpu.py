@@ -132,9 +132,25 @@ def test_integrator_and_wlsq_operators(setup):
                         params=default_params())
     for i in range(4):
         assert rel(out[i], ref[i]) < TOL, i
+    # outputs 4 / 5 as the reference's Intergrator returns them (FVscheme.py:253-262,718-724): the smoothed node field BEFORE the
+    # Dirichlet overwrite and neither field re-dimensionalised (importer.py:223-231 does both afterwards)
+    assert rel(out[4], ref[4]) < TOL
     assert rel(out[5], ref[5]) < TOL
     (torch.cat(out[0:4], 1) * w.cuda()).sum().backward()
     assert rel(ud.grad, uvp_g.grad) < 1e-4
+    # ... and on the Poisson fixture (sigma = [1, 0, 0]: the re-dimensionalisation of importer.py:228 would zero v and p)
+    pgraphs = cases.make_graphs("poisson_b1")
+    PG = O.graph_tensors(*pgraphs)
+    Np = pgraphs[0].x.shape[0]
+    pu, po = torch.randn(Np, 3, generator=gen) * 0.3, torch.randn(Np, 2, generator=gen) * 0.3
+    pref = O.integrator_conserved(pu, (po + pu[:, 0:2]) / 2, po, PG, O.DEFAULT_HYPER)
+    pc = tuple(g.clone().to("cuda") for g in pgraphs)
+    pout = Intergrator()(uvp_new_node=pu.cuda(), uv_hat_node=(po.cuda() + pu.cuda()[:, 0:2]) / 2, uv_old_node=po.cuda(),
+                         graph_node=pc[0], graph_node_x=pc[1], graph_edge=pc[2], graph_cell=pc[3], graph_Index=pc[4],
+                         params=default_params())
+    for i in (0, 1, 2, 3, 4, 5):
+        assert pout[i].shape == pref[i].shape and rel(pout[i], pref[i]) < TOL, i
+    assert float(pref[4][:, 1:3].abs().max()) > 0   # (the un-scaled field keeps v and p)
     # node_based_WLSQ stand-alone: all five 2nd-order entries and its adjoint
     phi = torch.randn(N, 7, generator=gen)
     pg = phi.clone().requires_grad_(True)
