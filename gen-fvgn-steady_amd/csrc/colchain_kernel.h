@@ -34,7 +34,7 @@ constexpr float CC_SH_LIMIT = 2048.0f;   // |a| beyond this raises GFV_FLAG_CHAI
 // -DGFV_CC_TIMING: per wave, cycles spent in each phase and at each barrier, written through fin_presave's ... no:
 // through `status` + 64 (a debug build takes a bigger status buffer; scratch experiments only)
 #ifdef GFV_CC_TIMING
-#define CT_DECL long long ct_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; long long ct_prev_ = clock64();
+#define CT_DECL long long ct_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; long long ct_prev_ = clock64();
 #define CT(k) do { __builtin_amdgcn_s_waitcnt(0xc07f); const long long now_ = clock64(); ct_[k] += now_ - ct_prev_; ct_prev_ = now_; } while (0)
 #else
 #define CT_DECL
@@ -459,7 +459,9 @@ __global__ __launch_bounds__(64 * CC_W, 2) void colchain_bwd_kernel(const gfv_ro
         c.mabs = fmaxf(c.mabs, q < c.ngt ? ma : 0.f);
         cc_put_frag(b3, q, c, a, CC_SH);
       }
+      CT(12);
       cc_barrier();
+      CT(13);
       // ---- R2: z2 = W2 a1 + b2;  a2 = gelu(z2) -> b2, gelu'(z2) kept ----
 #pragma unroll
       for (int q = 0; q < TG; ++q) in.yv[q] = zero4;   // (pairs past the tile's end: zeros, not whatever LDS held)
@@ -506,7 +508,9 @@ __global__ __launch_bounds__(64 * CC_W, 2) void colchain_bwd_kernel(const gfv_ro
         rh[T] = __builtin_bit_cast(gfv_f16x8, __builtin_amdgcn_raw_buffer_load_b128(rw3, woff + T * 16384, 0, 0));
         rl[T] = __builtin_bit_cast(gfv_f16x8, __builtin_amdgcn_raw_buffer_load_b128(rw3, woff + T * 16384 + 1024, 0, 0));
       }
+      CT(14);
       cc_barrier();
+      CT(15);
       // ---- R3: y3 = W3 a2 + b3 -> registers (what the launch would otherwise read from in_aux) ----
       {
         int tvar = 0;
@@ -810,8 +814,8 @@ __global__ __launch_bounds__(64 * CC_W, 2) void colchain_bwd_kernel(const gfv_ro
 
 #ifdef GFV_CC_TIMING
   if (c.lane == 0 && A.fin_aux) {
-    long long* dbg = reinterpret_cast<long long*>(const_cast<float*>(A.fin_aux)) + ((size_t)blockIdx.x * CC_W + c.w) * 12;
-    for (int kk = 0; kk < 12; ++kk) dbg[kk] = ct_[kk];
+    long long* dbg = reinterpret_cast<long long*>(const_cast<float*>(A.fin_aux)) + ((size_t)blockIdx.x * CC_W + c.w) * 16;
+    for (int kk = 0; kk < 16; ++kk) dbg[kk] = ct_[kk];
   }
 #endif
   // ---- the workgroup's partial block: [dW3 | db3 | dW2 | db2 | dgamma | dbeta | dW1 | db1] (include/gfv.h) ----

@@ -139,8 +139,12 @@ class Engine:
         # gradients and the LayerNorm's per workgroup; one reduction launch per MLP sums the blocks
         self.fuse_dw = os.environ.get("GFV_FUSE_DW", "1") != "0"
         # ... and recompute z2 and the LayerNorm input from z1 in that launch instead of saving them in the forward and reading
-        # them back (gfv_rowtile_args_t.rc_Wh): the forward of such an MLP writes z1, the row statistics and its outputs only
-        self.recompute = os.environ.get("GFV_RECOMPUTE", "1") != "0"
+        # them back (gfv_rowtile_args_t.rc_Wh): the forward of such an MLP writes z1, the row statistics and its outputs only.
+        # Parity-green, 1.45 GB per step less HBM traffic - and SLOWER: 3.92 against 3.82 ms at B = 1, 23.44 against 23.09 ms at 8
+        # meshes per GPU (profiles/r04_ab_recompute.txt).  The forward chains gain 8 us per launch, the backward loses 25 (edge
+        # level): that kernel is bound by instruction issue inside the CU (vector + LDS + matrix time add up,
+        # profiles/r04_colchain_phases.txt: a fifth of the read traffic changes its time by 7 %), not by bytes.  Opt-in.
+        self.recompute = os.environ.get("GFV_RECOMPUTE", "0") != "0"
         self._slice_fuse = os.environ.get("GFV_SLICE_FUSE", "1") != "0"   # Transolver adjoint: one pass behind the attention
         self._tail_main = int(os.environ.get("GFV_TAIL_MAIN", "2"))
         self._split_all = int(os.environ.get("GFV_SPLIT_ALL", "0"))     # (experiment) the same split for every GnBlock's flush
