@@ -42,7 +42,7 @@ class TrainStep:
         self.engine.dist_world, self.engine.dist_group = world_size, process_group
         self.engine.dist_force = self.dist_on
         self.use_graph = use_graph
-        self._split, self._comm, self._work = None, None, None
+        self._split, self._comm, self._early = None, None, False
         self.want_outputs = want_outputs
         dev = graphs[0].x.device
         self.dev = dev
@@ -270,7 +270,10 @@ class TrainStep:
 
     # data-parallel exchange: the flat gradient is reduced in two buckets.  The upper one (last processor + decoder:
     # their backward runs first) goes out on a communication stream as soon as its last gradient kernel is launched and
-    # overlaps the backward of the first processor and the encoders; the lower one follows the backward.
+    # overlaps the backward of the first processor and the encoders; the lower one follows the backward.  The fork to the
+    # communication stream and the early all-reduce go through cmdlist.call: a RECORDED step replays them at the same
+    # point of the backward (round 4: the command list is the default launch mode - the exchange of its first bucket used
+    # to be exposed behind the replay).  A hipGraph capture keeps the exchange outside the graph, in one piece.
     def _bucket_split(self):
         if self._split is None:
             names = [n for n in self.G.off if ".processpr_list." in n]
@@ -279,36 +282,49 @@ class TrainStep:
             self._split = min(offs) if (last > 0 and offs) else 0
         return self._split
 
-    def _bucket_ready(self):
+    def _allreduce_upper(self):
         import torch.distributed as dist
+        # (the blocking form: under `torch.cuda.stream(comm)` it is the communication STREAM that waits for the collective - the
+        # host does not under RCCL - and nothing has to be kept alive for a replay)
+        dist.all_reduce(self.flat_g[self._split:], op=dist.ReduceOp.SUM, group=self.pg)
+
+    def _bucket_ready(self):
         split = self._bucket_split()
         if split <= 0 or torch.cuda.is_current_stream_capturing():
             return
         if self._comm is None:
             self._comm = torch.cuda.Stream()
-        self._comm.wait_stream(torch.cuda.current_stream())
+        cmdlist.call(self._comm.wait_stream, torch.cuda.current_stream())
         for sd in self.engine._sides:
-            self._comm.wait_stream(sd)                      # the weight-gradient kernels run there
+            cmdlist.call(self._comm.wait_stream, sd)        # the weight-gradient kernels run there
         with torch.cuda.stream(self._comm):
-            self._work = dist.all_reduce(self.flat_g[split:], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+            cmdlist.call(self._allreduce_upper)
+        self._early = True
 
-    def _allreduce(self):
+    def _allreduce(self, early=None):
+        """The rest of the exchange, behind the backward: the lower bucket + the join with the communication stream when the
+        upper one went out early (`early`: default = what the step that just ran did), else the whole buffer."""
         import torch.distributed as dist
-        if self._work is not None:
+        early = self._early if early is None else early
+        self._early = False
+        if early:
             dist.all_reduce(self.flat_g[:self._split], op=dist.ReduceOp.SUM, group=self.pg)
-            self._work.wait()                              # the current stream waits for the early bucket
             torch.cuda.current_stream().wait_stream(self._comm)
-            self._work = None
         else:
             dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM, group=self.pg)
 
-    def _eager(self, acc, dist_on):
+    def _hooked_body(self, acc, dist_on):
         # (a padded model's true-shape gradient exists only after the gather at the end of the backward: one all-reduce)
+        self._early = False
         self.engine.bucket_hook = self._bucket_ready if (dist_on and not self.padded) else None
         try:
             self._body(acc, with_adam=not dist_on)
         finally:
             self.engine.bucket_hook = None
+        return self._early
+
+    def _eager(self, acc, dist_on):
+        self._hooked_body(acc, dist_on)
         if dist_on:
             self._allreduce()
             self._adam()
@@ -360,15 +376,15 @@ class TrainStep:
                     self._eager(acc, dist_on)
                 else:
                     with cmdlist.record() as cl:
-                        self._body(acc, with_adam=not dist_on)
-                    self._graphs[key] = (cl, self.engine.capture_signature())
+                        early = self._hooked_body(acc, dist_on)   # (the early bucket's fork + all-reduce are part of the list)
+                    self._graphs[key] = (cl, self.engine.capture_signature(), early)
                     if dist_on:
-                        self._allreduce()
+                        self._allreduce(early)
                         self._adam()
             else:
                 entry[0].replay()
                 if dist_on:
-                    self._allreduce()
+                    self._allreduce(entry[2])
                     self._adam()
         else:
             key = (acc, dist_on)

@@ -4,7 +4,8 @@ backend it was written for - the early gradient bucket on the communication stre
 (`_bucket_ready`), the late bucket + join (`_allreduce`), the Normalizer statistics exchange inside the forward
 (`allreduce_normalizer`, accumulating Normalizer) - and, a one-rank all-reduce being the identity, the parameters,
 Adam moments and Normalizer buffers must be BIT-IDENTICAL to the non-distributed TrainStep on the same batch.
-Both eager and hipGraph replay (the replay keeps the exchange outside the graph) are checked."""
+Eager, hipGraph replay (the exchange stays outside the graph) and command-list replay (the early bucket is part of the list) are
+checked."""
 import os
 import sys
 
@@ -14,6 +15,9 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "gen-fvgn-steady_amd"), os.path.join(ROOT, "tests", "golden")):
     sys.path.insert(0, p)
+
+
+NSTEPS = 7   # two accumulating steps (always eager), two warm-up steps, the recording, two replays of the command list
 
 
 def main():
@@ -49,13 +53,14 @@ def main():
                 calls["bucket"] += 1
                 return b0()
 
-            def allred():
+            def allred(early=None):
                 calls["allreduce"] += 1
-                # the early bucket must be in flight on the communication stream when the backward returns (eager steps)
-                calls["early_pending"] = calls.get("early_pending", 0) + (1 if ts._work is not None else 0)
-                return a0()
+                # the early bucket must have gone out on the communication stream when the backward returns - in eager steps
+                # (issued by the hook) and in command-list steps (recorded with the list, re-issued by every replay)
+                calls["early_pending"] = calls.get("early_pending", 0) + (1 if (ts._early if early is None else early) else 0)
+                return a0(early)
             ts._bucket_ready, ts._allreduce = bucket, allred
-        for _ in range(5):
+        for _ in range(NSTEPS):
             ts.step()
         torch.cuda.synchronize()
         nn_ = model.node_norm
@@ -74,10 +79,17 @@ def main():
         same = not diff
         if diff:
             print("RCCLDIFF", use_graph, diff)
-        ok = ok and same and calls["allreduce"] == 5
+        ok = ok and same and calls["allreduce"] == NSTEPS
         if use_graph is False:
             # eager: every step started the upper bucket from inside the backward, on the communication stream
-            ok = ok and calls["bucket"] == 5 and calls.get("early_pending", 0) == 5 and ts._comm is not None
+            ok = ok and calls["bucket"] == NSTEPS and calls.get("early_pending", 0) == NSTEPS and ts._comm is not None
+        if use_graph == "list":
+            # command list: the two accumulating steps run eager (2 hook calls), two warm-up steps (2), the recording (1): the
+            # replays carry the early bucket INSIDE the list (no hook call), and every step's late exchange joins an early one
+            ok = ok and calls.get("early_pending", 0) == NSTEPS and calls["bucket"] == 5 and ts._comm is not None
+            n_comm = sum(1 for _, _, st in next(iter(ts._graphs.values()))[0].cmds if st is not None and st == ts._comm)
+            ok = ok and n_comm == 1
+            print("RCCLLIST recorded_on_comm_stream", n_comm)
         print(f"RCCLRESULT graph={ {False: 0, True: 1, 'list': 2}[use_graph] } same={int(same)} bucket={calls['bucket']} allreduce={calls['allreduce']} "
               f"early_pending={calls.get('early_pending', 0)} backend={dist.get_backend()} world={dist.get_world_size()}")
     print(f"RCCLOK {int(ok)}")

@@ -215,3 +215,57 @@ def test_column_owner_backward_without_input_gradient(dev, M, rc):
     flags = L.C.c_int32(0)
     L.check(L.load().gfv_status_flags(L.C.byref(flags)), "gfv_status_flags")
     assert flags.value == 0
+
+
+@pytest.mark.parametrize("mode", ["recompute", "rematerialize"])
+def test_engine_recompute_form_and_its_fallback(dev, mode):
+    """The engine's use of the recompute form (GFV_RECOMPUTE=1 / Engine.recompute): the forward of an MLP whose backward runs
+    fused keeps z1 only, the backward launch rebuilds z2 and the LayerNorm input.  `rematerialize`: the backward turns out not to
+    run fused after all (here: fusing switched off between forward and backward) and gets them from one extra two-layer launch.
+    Input gradient and every parameter gradient against the read form of the same engine (1e-5) and against float64 autograd."""
+    from gfv import lib as L, ops
+    from gfv.engine import Engine, GradStore
+    from gfv.ops import Seg
+    g = torch.Generator().manual_seed(11)
+    M = 20000                                            # (>= GFV_COLCHAIN_BWD_MIN_M: the fused backward takes it)
+    x = torch.randn(M, 128, generator=g)
+    P = _params(g, 128)
+    names = ["mlp.0.0.weight", "mlp.0.0.bias", "mlp.0.2.weight", "mlp.0.2.bias", "mlp.0.4.weight", "mlp.0.4.bias", "mlp.1.weight", "mlp.1.bias"]
+    vals = [P["W1"], P["b1"], P["W2"], P["b2"], P["W3"], P["b3"], P["gamma"], P["beta"]]
+    Pd = {n: v.to(dev).contiguous() for n, v in zip(names, vals)}
+    # persistent parameter storage: the weight images are built for static address ranges only
+    go = torch.randn(M, 128, generator=g) * torch.logspace(-3, 0, M)[:, None]
+    Pg = {k: v.double().requires_grad_(True) for k, v in P.items()}
+    X = x.double().requires_grad_(True)
+    (_ref(Pg, X)[3] * go.double()).sum().backward()
+    want = dict(zip(names, (Pg[k].grad for k in ("W1", "b1", "W2", "b2", "W3", "b3", "gamma", "beta"))))
+    res = {}
+    for form in ("read", mode):
+        eng = Engine()
+        eng.recompute = form != "read"
+        xd, god = x.to(dev), go.to(dev)
+        grads = GradStore(names, [Pd[n].shape for n in names], dev)
+        wi_prev = eng._wi_enter("fwd", Pd)
+        try:
+            out, _, sv = eng.mlp3_fwd(Pd, "mlp", M, [Seg(xd)])
+        finally:
+            eng._wi_exit("fwd", wi_prev)
+        assert (sv["z2"] is None) == (form != "read") and sv["stats"] is not None
+        if form == "rematerialize":
+            eng.fuse_dw = False
+        gx = torch.empty(M, 128, device=dev)
+        eng.prepare_transposes(Pd)
+        wi_prev = eng._wi_enter("bwd", Pd)
+        try:
+            eng.mlp3_bwd(Pd, sv, god, grads, outs=[gx])
+            eng.join()
+        finally:
+            eng._wt_live = False
+            eng._wi_exit("bwd", wi_prev)
+        torch.cuda.synchronize()
+        res[form] = (out.clone(), gx.clone(), {n: grads.view(n).clone() for n in names})
+        assert rel(gx, X.grad) < TOL, (form, rel(gx, X.grad))
+        for n in names:
+            assert rel(grads.view(n), want[n]) < TOL, (form, n, rel(grads.view(n), want[n]))
+    assert torch.equal(res["read"][0], res[mode][0])           # the forward's outputs do not depend on what it saves
+    assert rel(res[mode][1], res["read"][1]) < TOL

@@ -464,10 +464,13 @@ def test_lbfgs_loop_tracks_the_oracle_under_the_same_optimizer():
     assert min(hh) < hh[0] - 1e-3
 
 
-def test_data_parallel_trainstep_two_ranks():
-    """SURVEY.md 8e on the device path: two ranks (one mesh each, sharing this GPU, gloo) run the sharded TrainStep with an
-    accumulating Normalizer; both ranks must end bit-identical, and equal (to rounding) to a single process stepping on
-    the two-mesh batch.  Child processes via torch.distributed.run (tests/dp_gpu_worker.py)."""
+@pytest.mark.parametrize("mode", ["eager", "list"])
+def test_data_parallel_trainstep_two_ranks(mode):
+    """SURVEY.md 8e on the device path: two ranks (one mesh each, sharing this GPU, gloo) run the sharded TrainStep; both ranks
+    must end bit-identical, and equal (to rounding) to a single process stepping on the two-mesh batch.  `eager`: an
+    accumulating Normalizer, every step exchanges its statistics; `list`: command-list replay, the early gradient bucket (fork to
+    the communication stream + all-reduce) is part of the recorded list.  Child processes via
+    torch.distributed.run (tests/dp_gpu_worker.py)."""
     import os
     import re
     import subprocess
@@ -476,7 +479,7 @@ def test_data_parallel_trainstep_two_ranks():
     port = 29600 + (os.getpid() % 300)
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                         "--master-addr", "127.0.0.1", "--master-port", str(port), worker],
-                       capture_output=True, text=True, timeout=600, env=dict(os.environ, MASTER_ADDR="127.0.0.1"))
+                       capture_output=True, text=True, timeout=600, env=dict(os.environ, MASTER_ADDR="127.0.0.1", GFV_TEST_MODE=mode))
     m = re.search(r"DPRESULT same=(\d) param_err=(\S+) norm_err=(\S+)", r.stdout)
     assert r.returncode == 0 and m, r.stdout[-1500:] + r.stderr[-1500:]
     assert m.group(1) == "1", "ranks diverged"
