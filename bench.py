@@ -110,6 +110,25 @@ def compulsory_step_bytes(sz):
     return {"gnn": gnn, "slice": slc, "fvm": fvm, "misc": misc}
 
 
+def measured_copy_rate_gbs(device, nbytes=1 << 30, reps=6):
+    """HBM copy rate of THIS device in THIS run: a 1 GiB device-to-device copy (read + write = 2 GiB of traffic, ~0.35 ms ...
+    repeated until ~20 ms have been timed), HIP events on the current stream, best of `reps`."""
+    src = torch.empty(nbytes // 4, dtype=torch.float32, device=device).fill_(1.0)
+    dst = torch.empty_like(src)
+    dst.copy_(src)
+    best = 0.0
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(8):
+            dst.copy_(src)
+        e1.record()
+        torch.cuda.synchronize()
+        best = max(best, 8 * 2.0 * nbytes / (e0.elapsed_time(e1) * 1e-3) / 1e9)
+    del src, dst
+    return best
+
+
 def cpu_model():
     try:
         for ln in open("/proc/cpuinfo"):
@@ -285,23 +304,27 @@ def main():
     # above runs the weight-gradient kernels on a side stream, concurrently with the dX chains; here every kernel is
     # launched on ONE stream so that its duration is its own (concurrent kernels share the CUs and stretch each other).
     roof, roof_all = None, []
-    ts_use_graph, eng_overlap = ts.use_graph, ts.engine.overlap
-    ts.use_graph, ts.engine.overlap = False, False
-    for _ in range(2):
-        ts.step()
-    single_stream_ms = 1e3 * timed(5) / 5          # the un-instrumented single-stream eager step the classes must add up to
-    lib.gfv_profile_reset()
-    lib.gfv_profile_set_sizes(float(2 * sz["Ex"] + 2 * sz["B"]), float(sz["Sigma"]))
-    lib.gfv_profile_enable(1)
-    args.profile_steps = max(1, args.profile_steps)
-    for _ in range(args.profile_steps):
-        ts.step()
-    torch.cuda.synchronize()
-    lib.gfv_profile_enable(0)
-    ts.use_graph, ts.engine.overlap = ts_use_graph, eng_overlap
+    copy_rate = measured_copy_rate_gbs(device) if rank == 0 else 0.0
+    do_roofline = args.profile_steps > 0   # (--profile-steps 0: a profiling run that executes the timed form of the step only)
+    single_stream_ms = float("nan")
+    if do_roofline:
+        ts_use_graph, eng_overlap = ts.use_graph, ts.engine.overlap
+        ts.use_graph, ts.engine.overlap = False, False
+        for _ in range(2):
+            ts.step()
+        single_stream_ms = 1e3 * timed(5) / 5          # the un-instrumented single-stream eager step the classes must add up to
+        lib.gfv_profile_reset()
+        lib.gfv_profile_set_sizes(float(2 * sz["Ex"] + 2 * sz["B"]), float(sz["Sigma"]))
+        lib.gfv_profile_enable(1)
+        for _ in range(args.profile_steps):
+            ts.step()
+        torch.cuda.synchronize()
+        lib.gfv_profile_enable(0)
+        ts.use_graph, ts.engine.overlap = ts_use_graph, eng_overlap
     executed_flops = 0.0
     step_roof = None
-    if rank == 0:
+    traffic_source = None
+    if rank == 0 and do_roofline:
         out = (ctypes.c_double * 4)()
         # names as rocprofv3 prints them (profiles/*_kernel_stats.csv).  The chain kernels run their fp32 products as 3 f16
         # MFMAs per product group (include/gfv.h): their matrix roofline is the f16 MFMA peak / 3 in fp32-equivalent
@@ -314,7 +337,7 @@ def main():
         spec = {7: (tc(0, "false"), chain_peak, "gnn"), 8: (tc(1, "false"), chain_peak, "gnn"),
                 9: (tc(2, "false"), chain_peak, "gnn"), 10: (tc(0, "true"), chain_peak, "gnn"),
                 13: (tc(0, "false", "true"), chain_peak, "gnn"),
-                14: ("colchain_bwd_kernel", chain_peak, "gnn"), 15: ("colchain_fwd_kernel", chain_peak, "gnn"),
+                14: ("colchain_bwd_kernel", chain_peak, "gnn"),
                 16: ("lin1_kernel / lin1_lnbwd_kernel / lin1_csr_kernel (single-layer launches)", chain_peak, "gnn"),
                 1: ("rowtile_chain_kernel", PEAK_F32_MFMA_TFLOPS, "gnn"),
                 2: ("dw_multi_h_kernel" if ts.engine.f16split else "dw_multi_kernel", chain_peak, "gnn"),
@@ -363,13 +386,35 @@ def main():
         # average durations of a rocprofv3 --kernel-trace --stats run of this command (profiles/collect.sh -> the committed
         # profiles/kernel_stats_in_step.json), against the same algorithmic bytes / flops per launch
         instep_path = os.path.join(ROOT, "profiles", "kernel_stats_in_step.json")
+        instep_note, dominant = None, None
         if os.path.exists(instep_path) and args.meshes_per_gpu == 1 and args.cells == 50000 and args.workload == "cylinder":
             instep = json.load(open(instep_path))
-            for r in roof_all:
-                us = instep.get(r["kernel"])
-                if us:
-                    r["avg_launch_us_in_step"] = round(us, 2)
-                    r["frac_in_step"] = round(r["frac_isolated"] * r["avg_launch_us"] / us, 4)
+            built_from = instep.get("__lib_srchash__")
+            here = None
+            try:
+                here = open(L.LIB_PATH + ".srchash").read().strip()
+            except OSError:
+                pass
+            if built_from is not None and built_from != here:
+                # the committed averages were taken from another build of the kernels: not this run's, not quoted
+                instep_note = "profiles/kernel_stats_in_step.json belongs to another build of libgfv.so (source hash differs): ignored"
+            else:
+                instep_note = ("profiles/kernel_stats_in_step.json: rocprofv3 --kernel-trace --stats of `bench.py --graph list "
+                               "--skip-fp32-form --profile-steps 0 --cpu-budget 0` (profiles/collect.sh), same library build; "
+                               "NOT measured in this run")
+                for r in roof_all:
+                    us = instep.get(r["kernel"])
+                    if us:
+                        r["avg_launch_us_in_step"] = round(us, 2)
+                        r["frac_in_step"] = round(r["frac_isolated"] * r["avg_launch_us"] / us, 4)
+                        r["ms_per_step_in_step"] = round(us * r["launches_per_step"] / 1e3, 4)
+                timed_in = [r for r in roof_all if r.get("ms_per_step_in_step")]
+                if timed_in:
+                    d = max(timed_in, key=lambda r: r["ms_per_step_in_step"])
+                    dominant = {"kernel": d["kernel"], "ms_per_step_in_step": d["ms_per_step_in_step"],
+                                "avg_launch_us_in_step": d["avg_launch_us_in_step"], "frac_in_step": d["frac_in_step"],
+                                "bound": d["bound"], "note": "the class with the largest summed duration inside the timed two-stream "
+                                "step (its queue may differ from the main one: weight gradients run on the side queue)"}
         if roof_all:
             roof = max(roof_all, key=lambda r: r["ms_per_step"])
         comp = compulsory_step_bytes(sz)
@@ -446,10 +491,12 @@ def main():
         if half != ncores and "GFV_CPU_THREADS" not in os.environ:
             torch.set_num_threads(half)
             sec2, nst2 = cpu_baseline(graphs_cpu, 0.4 * args.cpu_budget, max_steps=5, min_steps=1)
-            cpu["at_half_the_cpus"] = {"value": round(args.meshes_per_gpu / sec2, 5), "cores": half, "timed_steps": nst2,
-                                       "median_s_per_step": round(sec2, 3),
-                                       "note": "torch.set_num_threads(os.cpu_count() // 2) as the reference sets it; as many timed "
-                                               "steps as the budget allows (>= 1)"}
+            cpu["at_half_the_cpus_indicative"] = {
+                "value": round(args.meshes_per_gpu / sec2, 5), "cores": half, "timed_steps": nst2, "median_s_per_step": round(sec2, 3),
+                "note": "torch.set_num_threads(os.cpu_count() // 2) as the reference sets it (pre_train_Adam.py:38).  INDICATIVE "
+                        "only: at ~10 s per step the budget of the default run allows as few as ONE timed step here, fewer than the "
+                        "five SURVEY.md 8(d) asks for - no ratio is quoted on it; `value` above (>= 5 timed steps at the fastest "
+                        "thread count) is the baseline"}
             torch.set_num_threads(ncores)
 
     if rank == 0:
@@ -472,6 +519,11 @@ def main():
             "dtype_note": ("fp32 values end to end; the products of the fused GEMM chains run as 3 f16 MFMAs on exact (hi, lo) "
                            "fp16 splits of the fp32 operands with fp32 accumulation (error <= the f32 MFMA's, parity tests at 1e-5)"
                            if ts.engine.f16split else "fp32 MFMA"),
+            "parity_note": ("fields, residual losses and the scalar loss are within 1e-5 of the float64 value of the reference's "
+                            "algorithm and of exactly pooled fp32 residuals; against the REFERENCE'S OWN fp32 outputs the pooled "
+                            "residual losses are held to 1e-4, not 1e-5: its sequential fp32 index_add_ pooling is itself 3e-5 ... 1e-4 "
+                            "from the exact sum of its own terms (DESIGN.md 2).  The reduced-precision form reported beside the "
+                            "headline (f16_products_form) is single fp16 x fp16 products, NOT the bf16 BASELINE config 3 names"),
             "config": {"workload": wl, "cells": sz["C"], "nodes": sz["N"], "faces": sz["E"],
                        "meshes_per_gpu": args.meshes_per_gpu, "global_batch": total_meshes, "parallelism": f"dp{world}",
                        "hip_graph": ts.use_graph is True, "launch_mode": used, "final_loss": round(final_loss, 6)},
@@ -483,9 +535,14 @@ def main():
                             "frac_note": "frac = frac_isolated: HIP events around the launches of a single-stream eager step in this "
                                          "run; frac_in_step: the same bytes over the kernel's average duration inside the two-stream "
                                          "step (rocprofv3 run of this command, profiles/kernel_stats_in_step.json)",
-                            "hbm_rates_measured_gbs": {"spec": PEAK_HBM_GBS, "copy": 6290.0, "2 reads + 5 writes, runs >= 128 B": 5800.0,
-                                                       "2 reads + 5 writes, 64-B runs": 4200.0,
-                                                       "source": "MI355X_MICROARCH.md (copy); profiles/r03_stream_run.txt (mixes)"}})
+                            "kernel_in_step_dominant": dominant, "in_step_source": instep_note,
+                            "hbm_copy_rate_measured_gbs": round(copy_rate, 1),
+                            "hbm_copy_rate_note": "1 GiB device-to-device copy (read + write bytes / time), HIP events, THIS run",
+                            "hbm_rates_committed_gbs": {"spec": PEAK_HBM_GBS, "copy (guide)": 6290.0,
+                                                        "2 reads + 5 writes, runs >= 128 B": 5800.0,
+                                                        "2 reads + 5 writes, 64-B runs": 4200.0,
+                                                        "source": "constants, NOT measured in this run: MI355X_MICROARCH.md (copy); "
+                                                                  "profiles/r03_stream_run.txt (mixes, profiles/tools/stream)"}})
                         if roof else None,
             "roofline_step": step_roof,
             "roofline_kernels": roof_all,

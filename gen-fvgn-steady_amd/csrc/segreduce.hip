@@ -402,6 +402,10 @@ extern "C" int gfv_seg_gather_sum_ex(const float* src, const int32_t* rowptr, co
     const double by = 4.0 * rsrc * F + 4.0 * (double)nnz_hint + 4.0 * (double)n_rows * F * (accumulate ? 2 : 1) + 4.0 * (double)n_rows;
     tok = gfv_prof_begin(GFV_K_SEG, 4.0 * (double)nnz_hint * F, by, st);
   }
+  // (Round 4 measured two more forms - all eight entries of a row requested at once, one or two rows per sub-wave - against this
+  // one on the bench mesh's tables: 8 - 23 % SLOWER at 8 meshes per GPU, profiles/r04_seg_forms.txt; the unconditional requests
+  // past a row's end and the lower occupancy cost more than the saved round trip.  This kernel moves 5.0 - 5.3 TB/s of counter
+  // bytes = 0.63 - 0.66 of 8 TB/s at 8 meshes per GPU on three of its four launch shapes: profiles/r04_seg_pmc_b8.txt.)
 #define LAUNCH_VEC(LPR)                                                                                       \
   hipLaunchKernelGGL((seg_gather_sum_vec<LPR>), dim3(gfv_xcd_grid(grid_for(n_rows, 256 / LPR))), dim3(256), 0, st, src, \
                      rowptr, col, scale, src_scale, out, n_rows, accumulate)

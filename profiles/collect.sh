@@ -19,10 +19,11 @@ timeout 900 python3 $R/bench.py > $O/bench.json 2> $O/bench.err
 timeout 900 python3 $R/bench.py --meshes-per-gpu 8 --cpu-budget 0 --steps 10 --warmup 4 > $O/bench_b8.json 2> $O/bench_b8.err
 timeout 900 python3 $R/bench.py --workload cavity --cells 5041 --cpu-budget 8 > $O/bench_cavity.json 2> $O/bench_cavity.err
 timeout 900 python3 $R/bench.py --workload poly --cpu-budget 8 > $O/bench_poly.json 2> $O/bench_poly.err
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 $R/bench.py --cpu-budget 0 > $O/prof.log 2>&1
+# one form of the step only (command-list replay, split-fp16 products): what the in-step averages are taken from
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 $R/bench.py --cpu-budget 0 --graph list --skip-fp32-form --profile-steps 0 > $O/prof.log 2>&1
 find $O/prof -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats.csv \;
 rm -rf $O/prof
-python3 $R/profiles/instep_aggregate.py $O/kernel_stats.csv $O/kernel_stats_in_step.json > $O/kernel_stats_in_step.txt
+python3 $R/profiles/instep_aggregate.py $O/kernel_stats.csv $O/kernel_stats_in_step.json $R/gen-fvgn-steady_amd/gfv/libgfv.so.srchash > $O/kernel_stats_in_step.txt
 # PMC passes: eager launches only, split-fp16 form only; the JSON line says how many steps ran (steps_executed)
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 900 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_$c -- python3 $R/bench.py --steps 5 --warmup 1 --graph off --min-time 0 --cpu-budget 0 --profile-steps 1 --skip-fp32-form > $O/pmc_$c.log 2>&1
