@@ -83,8 +83,9 @@ __device__ __forceinline__ void cc_mma_pair(const char* xbuf, int pair, const gf
 // this lane's 4 values of one row -> its 8-byte share of the next layer's fragments (k-group w >> 1, half w & 1)
 __device__ __forceinline__ void cc_put_frag(char* xbuf, int q, const CcCtx& c, const float (&a)[4], float scale) {
   unsigned h0, h1, l0, l1;
-  gfv_split_pair(a[0] * scale, a[1] * scale, h0, l0);
-  gfv_split_pair(a[2] * scale, a[3] * scale, h1, l1);
+  const gfv_f2 s01 = gfv_f2{a[0], a[1]} * gfv_splat2(scale), s23 = gfv_f2{a[2], a[3]} * gfv_splat2(scale);
+  gfv_split_pair(s01.x, s01.y, h0, l0);
+  gfv_split_pair(s23.x, s23.y, h1, l1);
   char* dst = xbuf + (size_t)((q * 4 + (c.w >> 1)) * 2) * 1024 + c.lane * 16 + (c.w & 1) * 8;
   *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
   *reinterpret_cast<uint2*>(dst + 1024) = make_uint2(l0, l1);
@@ -188,17 +189,15 @@ __device__ __forceinline__ void cb_dw_tile(const char* gbuf, const char* abuf, i
 // the scale `sg`; a = gelu(z) -> fragments with CC_SH (the weight gradient's other operand); v is handed back for the save
 __device__ __forceinline__ void cb_hidden_bwd(CcCtx& c, int q, const floatx4& acc, float inv_in, const float4& z, float sg,
                                               char* gout, char* aout, float (&v)[4]) {
-  const float zz[4] = {z.x, z.y, z.z, z.w};
-  float a[4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    // gelu and gelu' share the erfc evaluation (gfv_common.h)
-    const gfv_erfc_t e = gfv_erfc_half(zz[r]);
-    const float cdf = zz[r] >= 0.0f ? 1.0f - e.y : e.y;
-    const float dg = fmaf(zz[r] * 0.39894228040143267794f, e.e, cdf);
-    a[r] = fmaf(-fabsf(zz[r]), e.y, fmaxf(zz[r], 0.0f));
-    v[r] = ((acc[r] * inv_in) * c.invw) * dg;
-  }
+  // two values per instruction (packed fp32, gfv_common.h): the same operations in the same order as the scalar form
+  const gfv_f2 z01 = {z.x, z.y}, z23 = {z.z, z.w};
+  gfv_f2 a01, a23, d01, d23;
+  gfv_gelu_dgelu2(z01, a01, d01);   // gelu and gelu' share the erfc evaluation
+  gfv_gelu_dgelu2(z23, a23, d23);
+  const gfv_f2 ki = gfv_splat2(inv_in), kw = gfv_splat2(c.invw);
+  const gfv_f2 v01 = ((gfv_f2{acc[0], acc[1]} * ki) * kw) * d01, v23 = ((gfv_f2{acc[2], acc[3]} * ki) * kw) * d23;
+  v[0] = v01.x; v[1] = v01.y; v[2] = v23.x; v[3] = v23.y;
+  const float a[4] = {a01.x, a01.y, a23.x, a23.y};
   const float mq = max3_abs(max3_abs(0.f, v[0], v[1]), v[2], v[3]) * sg;
   const float ma = max3_abs(max3_abs(0.f, a[0], a[1]), a[2], a[3]) * (CC_SH * (1.0f / 32.0f));   // (a against CC_SH_LIMIT x 32 = 65536)
   c.mabs = fmaxf(c.mabs, q < c.ngt ? fmaxf(mq, ma) : 0.f);
@@ -257,6 +256,9 @@ __device__ __forceinline__ float4 cb_ld4(cb_rsrc r, int off) {
 __device__ __forceinline__ float2 cb_ld2(cb_rsrc r, int off) {
   const cb_f32x2 f = __builtin_bit_cast(cb_f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0));
   return make_float2(f[0], f[1]);
+}
+__device__ __forceinline__ void cb_st4v(cb_rsrc r, int off, const floatx4& f) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(cb_i32x4, f), r, off, 0, 0);
 }
 __device__ __forceinline__ void cb_st4(cb_rsrc r, int off, const float (&v)[4]) {
   const floatx4 f = {v[0], v[1], v[2], v[3]};
@@ -559,16 +561,23 @@ __global__ __launch_bounds__(64 * CC_W, 2) void colchain_bwd_kernel(const gfv_ro
         const float mean = in.st[q].x, rstd = in.st[q].y;
         rs[q] = rstd;
         float s1 = 0.f, s2 = 0.f, am = 0.f;
+        // (value pairs on the packed-fp32 instructions, gfv_common.h; every value sees the operations of the scalar form)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          d[r] *= lf;
-          xh[q][r] = (y[r] - mean) * rstd;
-          dgam[r] += d[r] * xh[q][r];
-          dbet[r] += d[r];
-          gg[q][r] = d[r] * gm[r];
-          s1 += gg[q][r];
-          s2 += gg[q][r] * xh[q][r];
-          am = fmaxf(am, fabsf(gg[q][r]));
+        for (int h = 0; h < 2; ++h) {
+          const int r = 2 * h;
+          const gfv_f2 dd = gfv_f2{d[r], d[r + 1]} * gfv_splat2(lf);
+          const gfv_f2 xx = (gfv_f2{y[r], y[r + 1]} - gfv_splat2(mean)) * gfv_splat2(rstd);
+          const gfv_f2 dx = dd * xx;
+          const gfv_f2 g2 = dd * gfv_f2{gm[r], gm[r + 1]};
+          const gfv_f2 gx = g2 * xx;
+          const gfv_f2 ng = gfv_f2{dgam[r], dgam[r + 1]} + dx, nb = gfv_f2{dbet[r], dbet[r + 1]} + dd;
+          dgam[r] = ng.x; dgam[r + 1] = ng.y;
+          dbet[r] = nb.x; dbet[r + 1] = nb.y;
+          xh[q][r] = xx.x; xh[q][r + 1] = xx.y;
+          gg[q][r] = g2.x; gg[q][r + 1] = g2.y;
+          s1 += g2.x; s1 += g2.y;
+          s2 += gx.x; s2 += gx.y;
+          am = max3_abs(am, g2.x, g2.y);
         }
         s1 = row_sum(s1);
         s2 = row_sum(s2);
@@ -610,7 +619,11 @@ __global__ __launch_bounds__(64 * CC_W, 2) void colchain_bwd_kernel(const gfv_ro
         const float m2 = (((p0.y + p0.w) + (p1.y + p1.w)) + ((p2.y + p2.w) + (p3.y + p3.w))) * 0.0078125f;
         float g3[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) g3[r] = rs[q] * (gg[q][r] - m1 - xh[q][r] * m2);
+        for (int h = 0; h < 2; ++h) {
+          const int r = 2 * h;
+          const gfv_f2 t = gfv_splat2(rs[q]) * ((gfv_f2{gg[q][r], gg[q][r + 1]} - gfv_splat2(m1)) - gfv_f2{xh[q][r], xh[q][r + 1]} * gfv_splat2(m2));
+          g3[r] = t.x; g3[r + 1] = t.y;
+        }
         if (A.in_save) cb_st4(cb_buf(A.in_save, rows128), offS[q], g3);
         cc_put_frag(b0, q, c, g3, s3);
       }
@@ -754,16 +767,11 @@ __global__ __launch_bounds__(64 * CC_W, 2) void colchain_bwd_kernel(const gfv_ro
         if (p >= np) break;
         floatx4 n0 = a0, n1 = a1;
         if (p + 1 < TG / 2) cc_mma_pair<4, LOWP, true>(b0, p + 1, wh, wl, c.lane, n0, n1);
-        float o0[4], o1[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          o0[r] = (a0[r] * inv_in) * c.invw;
-          o1[r] = (a1[r] * inv_in) * c.invw;
-        }
-        o0[0] += rr[2 * p].x; o0[1] += rr[2 * p].y; o0[2] += rr[2 * p].z; o0[3] += rr[2 * p].w;
-        o1[0] += rr[2 * p + 1].x; o1[1] += rr[2 * p + 1].y; o1[2] += rr[2 * p + 1].z; o1[3] += rr[2 * p + 1].w;
-        cb_st4(B.out, offS[2 * p], o0);
-        cb_st4(B.out, offS[2 * p + 1], o1);
+        // (whole accumulator vectors: hipcc turns these into packed-fp32 instructions, two values each)
+        const floatx4 o0 = (a0 * inv_in) * c.invw + floatx4{rr[2 * p].x, rr[2 * p].y, rr[2 * p].z, rr[2 * p].w};
+        const floatx4 o1 = (a1 * inv_in) * c.invw + floatx4{rr[2 * p + 1].x, rr[2 * p + 1].y, rr[2 * p + 1].z, rr[2 * p + 1].w};
+        cb_st4v(B.out, offS[2 * p], o0);
+        cb_st4v(B.out, offS[2 * p + 1], o1);
         a0 = n0; a1 = n1;
       }
       if constexpr (OUT2) {
@@ -779,15 +787,10 @@ __global__ __launch_bounds__(64 * CC_W, 2) void colchain_bwd_kernel(const gfv_ro
             if (p >= np) break;
             floatx4 e0, e1;
             cc_mma_pair<4, LOWP, true>(b0, p, xh2, xl2, c.lane, e0, e1);
-            float o0[4], o1[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              o0[r] = (e0[r] * inv_in) * c.invw;
-              o1[r] = (e1[r] * inv_in) * c.invw;
-            }
+            const floatx4 o0 = (e0 * inv_in) * c.invw, o1 = (e1 * inv_in) * c.invw;
             const int ra = c.row0 + 32 * p + c.j, rb = ra + 16;
-            cb_st4(out2, (2 * p < c.ngt && ra < c.M) ? ra * 256 + c.col0 * 4 : CB_OFF_DEAD, o0);
-            cb_st4(out2, (2 * p + 1 < c.ngt && rb < c.M) ? rb * 256 + c.col0 * 4 : CB_OFF_DEAD, o1);
+            cb_st4v(out2, (2 * p < c.ngt && ra < c.M) ? ra * 256 + c.col0 * 4 : CB_OFF_DEAD, o0);
+            cb_st4v(out2, (2 * p + 1 < c.ngt && rb < c.M) ? rb * 256 + c.col0 * 4 : CB_OFF_DEAD, o1);
           }
         }
       }

@@ -41,6 +41,48 @@ static __device__ __forceinline__ gfv_erfc_t gfv_erfc_half(float x) {
   r.y = (p * t) * r.e;
   return r;
 }
+// Two values at a time on the packed-fp32 instructions of gfx90a+ (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32: two fp32
+// operations per lane and issue slot).  The chain kernels are bound by vector ISSUE (round 4: a fifth of the read traffic moves
+// the persistent backward by 7 %, profiles/r04_colchain_phases.txt); the same operations in the same order as the scalar form
+// above - bit-identical results - in 14 instead of 26 instructions per pair.  hipcc selects the packed forms for arithmetic on
+// float2 ext-vectors (the SLP vectoriser, which would find them by itself, is off for these files: it shuffles registers).
+typedef float gfv_f2 __attribute__((ext_vector_type(2)));
+struct gfv_erfc2_t {
+  gfv_f2 y, e;
+};
+static __device__ __forceinline__ gfv_f2 gfv_splat2(float v) { return gfv_f2{v, v}; }
+static __device__ __forceinline__ gfv_erfc2_t gfv_erfc_half2(gfv_f2 x) {
+  const gfv_f2 a = {fabsf(x.x) * 0.84932180028801904272f, fabsf(x.y) * 0.84932180028801904272f};
+  const gfv_f2 d = __builtin_elementwise_fma(gfv_splat2(0.2727374808792225f), a, gfv_splat2(1.0f));
+  const gfv_f2 t = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+  const gfv_f2 aa = a * a;
+  gfv_erfc2_t r;
+  r.e = gfv_f2{__builtin_amdgcn_exp2f(-aa.x), __builtin_amdgcn_exp2f(-aa.y)};
+  gfv_f2 p = __builtin_elementwise_fma(gfv_splat2(0.5307027145f), t, gfv_splat2(-0.7265760135f));
+  p = __builtin_elementwise_fma(p, t, gfv_splat2(0.7107068705f));
+  p = __builtin_elementwise_fma(p, t, gfv_splat2(-0.142248368f));
+  p = __builtin_elementwise_fma(p, t, gfv_splat2(0.127414796f));
+  r.y = (p * t) * r.e;
+  return r;
+}
+// gelu(x) and gelu'(x) of a pair from ONE erfc evaluation (what the scalar gfv_gelu / gfv_dgelu compute, value for value)
+static __device__ __forceinline__ void gfv_gelu_dgelu2(gfv_f2 x, gfv_f2& g, gfv_f2& dg) {
+  const gfv_erfc2_t r = gfv_erfc_half2(x);
+  const gfv_f2 m = gfv_splat2(1.0f) - r.y;
+  const gfv_f2 cdf = {x.x >= 0.0f ? m.x : r.y.x, x.y >= 0.0f ? m.y : r.y.y};
+  dg = __builtin_elementwise_fma(x * gfv_splat2(0.39894228040143267794f), r.e, cdf);
+  g = gfv_f2{fmaf(-fabsf(x.x), r.y.x, fmaxf(x.x, 0.0f)), fmaf(-fabsf(x.y), r.y.y, fmaxf(x.y, 0.0f))};
+}
+static __device__ __forceinline__ gfv_f2 gfv_gelu2(gfv_f2 x) {
+  const gfv_erfc2_t r = gfv_erfc_half2(x);
+  return gfv_f2{fmaf(-fabsf(x.x), r.y.x, fmaxf(x.x, 0.0f)), fmaf(-fabsf(x.y), r.y.y, fmaxf(x.y, 0.0f))};
+}
+static __device__ __forceinline__ gfv_f2 gfv_dgelu2(gfv_f2 x) {
+  const gfv_erfc2_t r = gfv_erfc_half2(x);
+  const gfv_f2 m = gfv_splat2(1.0f) - r.y;
+  const gfv_f2 cdf = {x.x >= 0.0f ? m.x : r.y.x, x.y >= 0.0f ? m.y : r.y.y};
+  return __builtin_elementwise_fma(x * gfv_splat2(0.39894228040143267794f), r.e, cdf);
+}
 #ifndef GFV_LIBM_ERF
 static __device__ __forceinline__ float gfv_gelu(float x) {
   const gfv_erfc_t r = gfv_erfc_half(x);
