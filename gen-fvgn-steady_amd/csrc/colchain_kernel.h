@@ -27,6 +27,11 @@
 
 namespace {
 
+// -DGFV_ABL=<bits>: ablations for timing experiments (profiles/tools/colchain_bwd_phases.py; the results are garbage):
+// 1 = no MFMA issued, 2 = fragment / transposed-operand LDS reads replaced by register constants, 4 = no erfc in the epilogues
+#ifndef GFV_ABL
+#define GFV_ABL 0
+#endif
 constexpr int CC_W = 8;                  // waves per workgroup
 constexpr float CC_SH = 16.0f;           // fixed scale of hidden activations ahead of the fp16 split
 constexpr float CC_SH_INV = 1.0f / 16.0f;
@@ -64,9 +69,18 @@ __device__ __forceinline__ void cc_mma_pair(const char* xbuf, int pair, const gf
   a1 = floatx4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int T = 0; T < KT; ++T) {
+#if GFV_ABL & 2
+    const gfv_f16x8 xh0 = wh[T], xh1 = wl[T], xl0 = wl[T], xl1 = wh[T];
+#else
     const gfv_f16x8 xh0 = f0[(2 * T) * 64], xh1 = f1[(2 * T) * 64];
+#endif
+#if GFV_ABL & 1
+    a0 += __builtin_bit_cast(floatx4, xh0); a1 += __builtin_bit_cast(floatx4, xh1);
+#else
     if (!LOWP) {
+#if !(GFV_ABL & 2)
       const gfv_f16x8 xl0 = f0[(2 * T + 1) * 64], xl1 = f1[(2 * T + 1) * 64];
+#endif
       a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[T], xh0, a0, 0, 0, 0);
       a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[T], xh1, a1, 0, 0, 0);
       a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[T], xl0, a0, 0, 0, 0);
@@ -74,6 +88,7 @@ __device__ __forceinline__ void cc_mma_pair(const char* xbuf, int pair, const gf
     }
     a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[T], xh0, a0, 0, 0, 0);
     a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[T], xh1, a1, 0, 0, 0);
+#endif
     // (FENCE: the scheduler may not hoist the next k-group's four fragment reads above this one's MFMAs - at a budget of 128
     // registers sixteen fragments in flight are 64 of them)
     if (FENCE) __builtin_amdgcn_sched_barrier(0);
@@ -168,18 +183,32 @@ __device__ __forceinline__ void cb_dw_tile(const char* gbuf, const char* abuf, i
   const gfv_f16x8 ones = {one, one, one, one, one, one, one, one};
   for (int pr = 0; pr < npairs; ++pr) {
     gfv_f16x8 gh, gl;
+#if GFV_ABL & 2
+    gh = ones; gl = ones; gh[0] = (_Float16)(float)pr;
+#else
     cb_tr_operand(gbuf, 2 * pr, w, lane, gh, gl);
+#endif
+#if !(GFV_ABL & 1)
     if (!LOWP) accb = __builtin_amdgcn_mfma_f32_16x16x32_f16(gl, ones, accb, 0, 0, 0);
     accb = __builtin_amdgcn_mfma_f32_16x16x32_f16(gh, ones, accb, 0, 0, 0);
+#endif
 #pragma unroll
     for (int kt = 0; kt < 8; ++kt) {
       gfv_f16x8 ah, al;
+#if GFV_ABL & 2
+      ah = gh; al = gl; ah[1] = (_Float16)(float)kt;
+#else
       cb_tr_operand(abuf, 2 * pr, kt, lane, ah, al);
+#endif
+#if GFV_ABL & 1
+      acc[kt] += __builtin_bit_cast(floatx4, ah) + __builtin_bit_cast(floatx4, al);
+#else
       if (!LOWP) {
         acc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(gl, ah, acc[kt], 0, 0, 0);
         acc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(gh, al, acc[kt], 0, 0, 0);
       }
       acc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(gh, ah, acc[kt], 0, 0, 0);
+#endif
       if ((kt & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // (four k-tiles' operands in flight, not eight: the register budget)
     }
   }
@@ -192,8 +221,12 @@ __device__ __forceinline__ void cb_hidden_bwd(CcCtx& c, int q, const floatx4& ac
   // two values per instruction (packed fp32, gfv_common.h): the same operations in the same order as the scalar form
   const gfv_f2 z01 = {z.x, z.y}, z23 = {z.z, z.w};
   gfv_f2 a01, a23, d01, d23;
+#if GFV_ABL & 4
+  a01 = z01; a23 = z23; d01 = z01 * z01; d23 = z23 * z23;
+#else
   gfv_gelu_dgelu2(z01, a01, d01);   // gelu and gelu' share the erfc evaluation
   gfv_gelu_dgelu2(z23, a23, d23);
+#endif
   const gfv_f2 ki = gfv_splat2(inv_in), kw = gfv_splat2(c.invw);
   const gfv_f2 v01 = ((gfv_f2{acc[0], acc[1]} * ki) * kw) * d01, v23 = ((gfv_f2{acc[2], acc[3]} * ki) * kw) * d23;
   v[0] = v01.x; v[1] = v01.y; v[2] = v23.x; v[3] = v23.y;

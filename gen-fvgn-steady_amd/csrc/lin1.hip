@@ -178,13 +178,32 @@ __global__ __launch_bounds__(512, 2) void lin1_kernel(const Lin1Args A, int* sta
   const float inv = (1.0f / sx), invw = 1.0f / gfv_pow2_scale(*A.wmax);
   __syncthreads();   // the image is in LDS
   // ---- products: D[n = 16 nt + 4 g + r][row li] ----
+  // The rows of the epilogue's operands (the saved pre-activations of a GELU' epilogue, the residual) are requested a GROUP of
+  // four n-tiles ahead of their use: loaded where they are used - the first form of this loop - every n-tile ended in a
+  // dependent global round trip (two waves per SIMD do not cover it), and the GELU' launches of the Transolver's linear_post
+  // adjoint took 3.5 x the time of their plain siblings (351 against 101 us at 8 meshes per GPU, profiles/r04_ab_lin1_prefetch.txt).
+  constexpr int NGRP = 2 * NP;   // groups of four n-tiles over all passes
+  float4 zq[2][4], rq[2][4];
+  auto fetch = [&](int grp, int buf) {
+    const int p = grp >> 1, nt0 = 4 * (grp & 1);
 #pragma unroll
-  for (int p = 0; p < NP; ++p) {
+    for (int k = 0; k < 4; ++k) {
+      const int col = 16 * (nt0 + k) + 4 * g;
+      if (DGELU) zq[buf][k] = *reinterpret_cast<const float4*>(A.aux + mr * (128 * NP) + 128 * p + col);
+      if (A.res[p]) rq[buf][k] = *reinterpret_cast<const float4*>(A.res[p] + mr * A.res_ld[p] + col);
+    }
+  };
+  fetch(0, 0);
+#pragma unroll
+  for (int grp = 0; grp < NGRP; ++grp) {
+    const int p = grp >> 1, nt0 = 4 * (grp & 1), buf = grp & 1;
     float* outp = A.out[p];
     const float* resp = A.res[p];
     const float* bp = A.bias[p];
-#pragma unroll 2
-    for (int nt = 0; nt < 8; ++nt) {
+    if (grp + 1 < NGRP) fetch(grp + 1, buf ^ 1);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int nt = nt0 + k;
       floatx4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int T = 0; T < KS; ++T) {
@@ -204,11 +223,11 @@ __global__ __launch_bounds__(512, 2) void lin1_kernel(const Lin1Args A, int* sta
         o.x += b.x; o.y += b.y; o.z += b.z; o.w += b.w;
       }
       if (DGELU) {
-        const float4 z = *reinterpret_cast<const float4*>(A.aux + mr * (128 * NP) + 128 * p + col);
+        const float4 z = zq[buf][k];
         o.x *= gfv_dgelu(z.x); o.y *= gfv_dgelu(z.y); o.z *= gfv_dgelu(z.z); o.w *= gfv_dgelu(z.w);
       }
       if (resp) {
-        const float4 r = *reinterpret_cast<const float4*>(resp + mr * A.res_ld[p] + col);
+        const float4 r = rq[buf][k];
         o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
       }
       if (live) *reinterpret_cast<float4*>(outp + mr * A.out_ld[p] + col) = o;
