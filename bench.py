@@ -339,7 +339,6 @@ def main():
                 13: (tc(0, "false", "true"), chain_peak, "gnn"),
                 14: ("colchain_bwd_kernel", chain_peak, "gnn"),
                 16: ("lin1_kernel / lin1_lnbwd_kernel / lin1_csr_kernel (single-layer launches)", chain_peak, "gnn"),
-                1: ("rowtile_chain_kernel", PEAK_F32_MFMA_TFLOPS, "gnn"),
                 2: ("dw_multi_h_kernel" if ts.engine.f16split else "dw_multi_kernel", chain_peak, "gnn"),
                 3: ("seg_gather_sum_vec", None, "gnn"),
                 11: ("reduce_multi_kernel / reduce_partials_*", None, "gnn"),

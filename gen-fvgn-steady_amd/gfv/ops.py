@@ -76,9 +76,9 @@ def reduce_multi(pieces):
 
 
 def csr_prologue_enabled():
-    """Segmented-sum segments need the register-resident chain (GFV_TCHAIN != 0); GFV_CSR_FUSE=0 keeps the separate launches."""
+    """GFV_CSR_FUSE=0 keeps the neighbour sums as launches of their own."""
     import os
-    return os.environ.get("GFV_TCHAIN", "1") != "0" and os.environ.get("GFV_CSR_FUSE", "1") != "0"
+    return os.environ.get("GFV_CSR_FUSE", "1") != "0"
 
 
 def rowtile_tiles(M):

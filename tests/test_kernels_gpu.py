@@ -32,8 +32,6 @@ def chain_mode(request, dev, monkeypatch):
     if request.param == "f32":
         yield "f32"
         return
-    if os.environ.get("GFV_TCHAIN") == "0" or "fallback" in request.node.name:
-        pytest.skip("the split-fp16 form lives in the register-resident chain kernel")
     from gfv import lib as L, ops
     orig = ops.rowtile_chain
     wmax = torch.zeros(1, device=dev)
@@ -556,18 +554,3 @@ def test_chain_group_scales_feed_the_weight_gradient(dev, chain_mode):
         a, _ = ops.linear_dw(t, 128, [ops.Seg(A)], M, a_op=1)
         b, _ = ops.linear_dw(t, 128, [ops.Seg(A)], M, a_op=1, gscale=gs[slot])
         assert torch.equal(a, b), slot
-
-
-def test_lds_rowtile_fallback_kernel_still_passes():
-    """`GFV_TCHAIN=0` routes every fused-MLP launch to the first implementation (rowtile.hip, 64-row tile in LDS), which
-    stays in the library as the fallback.  The switch is read once per process, so the row-tile tests of this file are
-    re-run in a child process with it set (a child, never an exec of this GPU process)."""
-    import os
-    import subprocess
-    import sys
-    env = dict(os.environ, GFV_TCHAIN="0")
-    here = os.path.abspath(__file__)
-    r = subprocess.run([sys.executable, "-m", "pytest", here, "-q", "-x", "-m", "gpu", "-k", "rowtile and not fallback"],
-                       env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert " passed" in r.stdout
