@@ -444,38 +444,54 @@ __global__ __launch_bounds__(512, 2) void lin1_csr_kernel(const Lin1CsrArgs A, i
   const int mc = live ? m : A.M - 1;
   float v[KS][8];
 #pragma unroll
+  for (int T = 0; T < KS; ++T)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[T][e] = 0.f;
+  // The two segments are walked TOGETHER, two neighbour rows of each in flight (four rows = 32 loads of 16 B per lane): walked
+  // one after the other - the first form of this loop - a workgroup (alone on its CU: the image takes 128 KB of LDS) went through
+  // four dependent memory round trips where this takes two.  Entries are added in CSR order per segment, as before.
+  int kk[2], ee[2], cn0[2], cn1[2];
+#pragma unroll
   for (int s = 0; s < 2; ++s) {
-    const int beg = A.rowptr[s][mc], end = live ? A.rowptr[s][mc + 1] : beg;
+    kk[s] = A.rowptr[s][mc];
+    ee[s] = live ? A.rowptr[s][mc + 1] : kk[s];
+    cn0[s] = kk[s] < ee[s] ? A.col[s][kk[s]] : 0;
+    cn1[s] = kk[s] + 1 < ee[s] ? A.col[s][kk[s] + 1] : cn0[s];
+  }
+  while (kk[0] < ee[0] || kk[1] < ee[1]) {
+    float4 a0[2][8], a1[2][8];
+    bool one[2], two[2];
 #pragma unroll
-    for (int T = 0; T < 4; ++T)
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[4 * s + T][e] = 0.f;
-    const int* cidx = A.col[s];
-    int cn0 = beg < end ? cidx[beg] : 0, cn1 = beg + 1 < end ? cidx[beg + 1] : cn0;
-    for (int k = beg; k < end; k += 2) {
-      const bool two = (k + 1 < end);
-      const int c0 = cn0, c1 = cn1;
+    for (int s = 0; s < 2; ++s) {
+      const int k = kk[s], end = ee[s];
+      one[s] = k < end;
+      two[s] = k + 1 < end;
+      const int c0 = cn0[s], c1 = cn1[s];
       if (k + 2 < end) {
-        cn0 = cidx[k + 2];
-        cn1 = cidx[k + 3 < end ? k + 3 : k + 2];
+        cn0[s] = A.col[s][k + 2];
+        cn1[s] = A.col[s][k + 3 < end ? k + 3 : k + 2];
       }
       const float* p0 = A.src[s] + (size_t)c0 * (size_t)A.src_ld[s] + 4 * g;
       const float* p1 = A.src[s] + (size_t)c1 * (size_t)A.src_ld[s] + 4 * g;
-      float4 a0[8], a1[8];
 #pragma unroll
       for (int t = 0; t < 8; ++t) {
-        a0[t] = *reinterpret_cast<const float4*>(p0 + 16 * t);
-        a1[t] = *reinterpret_cast<const float4*>(p1 + 16 * t);
+        a0[s][t] = *reinterpret_cast<const float4*>(p0 + 16 * t);   // (a finished segment re-reads its last rows: L1 hits, not added)
+        a1[s][t] = *reinterpret_cast<const float4*>(p1 + 16 * t);
       }
-      const float w1 = two ? 1.0f : 0.0f;   // (the second row of an odd tail is the first one again: added with weight 0)
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
 #pragma unroll
       for (int t = 0; t < 8; ++t) {
         float* d = &v[4 * s + (t >> 1)][4 * (t & 1)];
-        d[0] += a0[t].x; d[1] += a0[t].y; d[2] += a0[t].z; d[3] += a0[t].w;
-        if (two) { d[0] += a1[t].x; d[1] += a1[t].y; d[2] += a1[t].z; d[3] += a1[t].w; }
+        if (one[s]) { d[0] += a0[s][t].x; d[1] += a0[s][t].y; d[2] += a0[s][t].z; d[3] += a0[s][t].w; }
+        if (two[s]) { d[0] += a1[s][t].x; d[1] += a1[s][t].y; d[2] += a1[s][t].z; d[3] += a1[s][t].w; }
       }
-      (void)w1;
+      kk[s] = min(kk[s] + 2, ee[s]);
     }
+  }
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
     if (A.save[s] && live) {
 #pragma unroll
       for (int T = 0; T < 4; ++T) {

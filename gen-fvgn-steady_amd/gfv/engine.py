@@ -140,7 +140,7 @@ class Engine:
         self.fuse_dw = os.environ.get("GFV_FUSE_DW", "1") != "0"
         # ... and recompute z2 and the LayerNorm input from z1 in that launch instead of saving them in the forward and reading
         # them back (gfv_rowtile_args_t.rc_Wh): the forward of such an MLP writes z1, the row statistics and its outputs only.
-        # Parity-green, 1.45 GB per step less HBM traffic - and SLOWER: 3.92 against 3.82 ms at B = 1, 23.44 against 23.09 ms at 8
+        # Parity-green, 1.17 GB per step less HBM traffic (12.49 -> 11.32 GB on the counters) - and SLOWER: 3.92 against 3.82 ms at B = 1, 23.44 against 23.09 ms at 8
         # meshes per GPU (profiles/r04_ab_recompute.txt).  The forward chains gain 8 us per launch, the backward loses 25 (edge
         # level): that kernel is bound by instruction issue inside the CU (vector + LDS + matrix time add up,
         # profiles/r04_colchain_phases.txt: a fifth of the read traffic changes its time by 7 %), not by bytes.  Opt-in.
