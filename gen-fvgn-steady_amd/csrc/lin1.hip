@@ -78,8 +78,15 @@ __global__ __launch_bounds__(512, 2) void lin1_kernel(const Lin1Args A, int* sta
 #pragma unroll
     for (int u = 0; u < PER; ++u) img[u * 512 + tid] = t[u];
   }
+  // Row blocks of 128: a workgroup walks blocks blockIdx.x, + gridDim.x, ... (the launcher caps the grid at a few workgroups
+  // per CU: round 4).  The image is staged ONCE and never written again, so nothing below needs a barrier but the first block's:
+  // the eight waves drift apart and one wave's row loads overlap another's products and stores, where one workgroup per block
+  // paid the image (64 - 128 KB from L2) and a serial load -> split -> products -> store life per 128 rows.
+  const int nblk = (A.M + 127) >> 7;
+  bool first = true;
+  for (int blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
   // ---- this wave's 16 rows: lane (row li, column group g) holds columns 32 T + 4 g + (0..3) and 32 T + 16 + 4 g + (0..3) ----
-  const int m = blockIdx.x * 128 + 16 * wave + li;
+  const int m = blk * 128 + 16 * wave + li;
   const bool live = m < A.M;
   const size_t mr = (size_t)(live ? m : A.M - 1);
   float v[KS][8];
@@ -162,7 +169,7 @@ __global__ __launch_bounds__(512, 2) void lin1_kernel(const Lin1Args A, int* sta
   const float sx = gfv_pow2_scale(l1_row_max4(fmaxf(m0, m1)));
   if (A.gscale) {   // the group's scale = the smallest of its 16 rows' (tchain_kernel.h group_scale_out)
     const float sg = gfv_row16_min(sx);
-    if (lane == 0) A.gscale[blockIdx.x * 8 + wave] = sg;
+    if (lane == 0) A.gscale[blk * 8 + wave] = sg;
   }
   gfv_f16x8 xh[KS], xl[KS];
 #pragma unroll
@@ -176,7 +183,8 @@ __global__ __launch_bounds__(512, 2) void lin1_kernel(const Lin1Args A, int* sta
     xl[T] = __builtin_bit_cast(gfv_f16x8, lo);
   }
   const float inv = (1.0f / sx), invw = 1.0f / gfv_pow2_scale(*A.wmax);
-  __syncthreads();   // the image is in LDS
+  if (first) __syncthreads();   // the image is in LDS
+  first = false;
   // ---- products: D[n = 16 nt + 4 g + r][row li] ----
   // The rows of the epilogue's operands (the saved pre-activations of a GELU' epilogue, the residual) are requested a GROUP of
   // four n-tiles ahead of their use: loaded where they are used - the first form of this loop - every n-tile ended in a
@@ -233,6 +241,7 @@ __global__ __launch_bounds__(512, 2) void lin1_kernel(const Lin1Args A, int* sta
       if (live) *reinterpret_cast<float4*>(outp + mr * A.out_ld[p] + col) = o;
     }
   }
+  }   // row blocks
   (void)status;
 }
 
@@ -436,7 +445,9 @@ __global__ __launch_bounds__(512, 2) void lin1_csr_kernel(const Lin1CsrArgs A, i
 #pragma unroll
     for (int u = 0; u < 16; ++u) img[u * 512 + tid] = t[u];
   }
-  // XCD-aware order of the 128-row workgroups (consecutive row blocks share neighbour rows in the same L2)
+  // XCD-aware order of the 128-row workgroups (consecutive row blocks share neighbour rows in the same L2).  (A persistent form -
+  // one workgroup per CU walking a range of blocks with the image staged once, as lin1_kernel does - was measured in round 4:
+  // 22.74 against 22.67 ms per step of 8 meshes, no gain: the gathers, not the image, are this kernel's time.)
   const int nwg = gridDim.x;
   const int wg = (nwg & 7) == 0 ? (int)(blockIdx.x & 7) * (nwg >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
   const int m = wg * 128 + 16 * wave + li;
@@ -550,6 +561,16 @@ int l1_env(const char* n, int dflt) {
   return e ? atoi(e) : dflt;
 }
 
+static int l1_cus() {
+  static int n = 0;
+  if (!n) {
+    int dev = 0;
+    hipDeviceProp_t pr;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) n = pr.multiProcessorCount;
+    if (n <= 0) n = 256;
+  }
+  return n;
+}
 // The kernels' dynamic LDS beyond 64 KB is a per-DEVICE function attribute: set it once per (kernel, device) - a process that
 // launches on a second GPU (torch.cuda.set_device(1) after device 0 was used) needs it there too.
 static inline bool l1_dyn_lds(const void* fn, int bytes, std::atomic<unsigned long long>& done) {
@@ -701,7 +722,11 @@ int gfv_internal_lin1_try(const gfv_rowtile_args_t* a, int lowp, hipStream_t str
   A.gscale = a->gscale;
   if (dry) return 1;
   int* st = gfv_internal_status_ptr();
-  const dim3 grid((a->M + 127) / 128), blk(512);
+  // at most GFV_LIN1_WGS_PER_CU workgroups per CU (default 2: the 64 KB forms fit two per CU, the 128 KB ones run them in turn)
+  static const int per_cu = getenv("GFV_LIN1_WGS_PER_CU") ? atoi(getenv("GFV_LIN1_WGS_PER_CU")) : 2;
+  const int nblk_all = (a->M + 127) / 128;
+  const int cap = per_cu > 0 ? per_cu * l1_cus() : nblk_all;
+  const dim3 grid(nblk_all < cap ? nblk_all : cap), blk(512);
   // instantiated: (in_op none | GELU | LayerNorm) without the GELU' epilogue, in_op none with it
   const int iop = a->in_op == GFV_IN_GELU ? 1 : (a->in_op == GFV_IN_LN ? 2 : 0);
 #define L1_ONE(KS, NP, IOP, DG, LP)                                                                                             \
