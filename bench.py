@@ -396,9 +396,9 @@ def main():
                 here = open(L.LIB_PATH + ".srchash").read().strip()
             except OSError:
                 pass
-            if built_from is not None and built_from != here:
+            if built_from is None or built_from != here:
                 # the committed averages were taken from another build of the kernels: not this run's, not quoted
-                instep_note = "profiles/kernel_stats_in_step.json belongs to another build of libgfv.so (source hash differs): ignored"
+                instep_note = "profiles/kernel_stats_in_step.json belongs to another build of libgfv.so (source hash differs or absent): ignored"
             else:
                 instep_note = ("profiles/kernel_stats_in_step.json: rocprofv3 --kernel-trace --stats of `bench.py --graph list "
                                "--skip-fp32-form --profile-steps 0 --cpu-budget 0` (profiles/collect.sh), same library build; "
