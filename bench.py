@@ -474,6 +474,28 @@ def main():
                                          "(profiles/r03_parity_fp64.txt)",
                     "tolerance_vs_fp32_oracle": {"field": 2e-4, "losses": 2e-3, "logloss": 1e-5, "grad_norm": 2e-3}}
 
+    # ---- and on bf16 operands (gfv_set_f16split(3): v_mfma_f32_16x16x32_bf16 - BASELINE config 3's "bf16 MLP GEMMs on MFMA"
+    # to the letter; same kernels, bf16-rounded operands, fp32 accumulation and fp32 everywhere else) ----
+    bf16_form = None
+    if ts.engine.f16split and not args.skip_fp32_form:
+        ts_use_graph = ts.use_graph
+        ts.use_graph = False
+        lib.gfv_set_f16split(3)
+        for _ in range(3):
+            ts.step()
+        nf = max(5, min(20, args.steps))
+        el = timed(nf)
+        lib.gfv_set_f16split(1)
+        ts.use_graph = ts_use_graph
+        for _ in range(2):
+            ts.step()   # (back in the default form: the images are rebuilt by the step)
+        bf16_form = {"value": round(world * args.meshes_per_gpu * nf / el, 3), "ms_per_step": round(1e3 * el / nf, 4),
+                     "steps": nf, "note": "eager launches, single bf16 x bf16 products with fp32 accumulation (GFV_F16SPLIT=3, "
+                                          "v_mfma_f32_16x16x32_bf16): NOT the form `value` is measured on.  Stated tolerances against "
+                                          "the fp32 oracle (tests/golden/cases.py BF16_TOL; asserted by tests/test_model_gpu.py; what "
+                                          "the form computes is pinned per kernel family by tests/test_bf16_form_gpu.py)",
+                     "tolerance_vs_fp32_oracle": {"field": 2e-3, "losses": 2e-2, "logloss": 1e-4, "grad_norm": 2e-2}}
+
     cpu = None
     if rank == 0 and world == 1 and args.cpu_budget > 0:
         # 16 threads is the fastest setting for this launch-bound eager workload on the GPU box's host
@@ -524,7 +546,8 @@ def main():
                             "algorithm and of exactly pooled fp32 residuals; against the REFERENCE'S OWN fp32 outputs the pooled "
                             "residual losses are held to 1e-4, not 1e-5: its sequential fp32 index_add_ pooling is itself 3e-5 ... 1e-4 "
                             "from the exact sum of its own terms (DESIGN.md 2).  The reduced-precision form reported beside the "
-                            "headline (f16_products_form) is single fp16 x fp16 products, NOT the bf16 BASELINE config 3 names"),
+                            "headline are f16_products_form (single fp16 x fp16 products) and bf16_products_form (single bf16 x bf16 "
+                            "products on v_mfma_f32_16x16x32_bf16: what BASELINE config 3 names); neither is the form of `value`"),
             "config": {"workload": wl, "cells": sz["C"], "nodes": sz["N"], "faces": sz["E"],
                        "meshes_per_gpu": args.meshes_per_gpu, "global_batch": total_meshes, "parallelism": f"dp{world}",
                        "hip_graph": ts.use_graph is True, "launch_mode": used, "final_loss": round(final_loss, 6)},
@@ -549,6 +572,7 @@ def main():
             "roofline_kernels": roof_all,
             "fp32_mfma_form": fp32_form,
             "f16_products_form": f16_form,
+            "bf16_products_form": bf16_form,
             # reference algorithm vs what the launches execute (EdgeBlock first layer factored through
             # the nodes, gfv/engine.py): the fraction of the fp32 MFMA peak is quoted on the EXECUTED flops
             "algorithmic_step_tflops": round(algorithmic_step_flops(sz) / 1e12, 4),

@@ -95,8 +95,10 @@ int gfv_internal_colchain_try(const gfv_rowtile_args_t* a, hipStream_t stream) {
     else CB_K(LOWP, false, false, false, false, RC);                                                                             \
   } while (0)
     const bool rc = a->rc_Wh[0] != nullptr;   // (cc_bwd_ok: never together with dw_in)
-    if (a->product_form != 0) { if (rc) CB_LAUNCH(true, true); else CB_LAUNCH(true, false); }
-    else { if (rc) CB_LAUNCH(false, true); else CB_LAUNCH(false, false); }
+    // (product_form as gfv_internal_tchain_launch left it: 0 three products, 1 / 2 the single-product forms in fp16 / bf16)
+    if (a->product_form == 2) { if (rc) CB_LAUNCH(2, true); else CB_LAUNCH(2, false); }
+    else if (a->product_form != 0) { if (rc) CB_LAUNCH(1, true); else CB_LAUNCH(1, false); }
+    else { if (rc) CB_LAUNCH(0, true); else CB_LAUNCH(0, false); }
 #undef CB_K
 #undef CB_LAUNCH
     return 2;

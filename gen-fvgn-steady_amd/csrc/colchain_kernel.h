@@ -60,7 +60,7 @@ struct CcCtx {
 };
 
 // one pair of groups against this wave's resident weights: acc_q += W[16 w + i][k] x_q[row][k] over KT k-groups
-template <int KT, bool LOWP, bool FENCE = false>
+template <int KT, int LOWP, bool FENCE = false>   // LOWP: 0 three products, 1 / 2 the single-product forms (fp16 / bf16)
 __device__ __forceinline__ void cc_mma_pair(const char* xbuf, int pair, const gfv_f16x8 (&wh)[KT], const gfv_f16x8 (&wl)[KT],
                                             int lane, floatx4& a0, floatx4& a1) {
   const gfv_f16x8* f0 = reinterpret_cast<const gfv_f16x8*>(xbuf + (size_t)(2 * pair) * KT * 2048) + lane;
@@ -86,8 +86,8 @@ __device__ __forceinline__ void cc_mma_pair(const char* xbuf, int pair, const gf
       a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[T], xl0, a0, 0, 0, 0);
       a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[T], xl1, a1, 0, 0, 0);
     }
-    a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[T], xh0, a0, 0, 0, 0);
-    a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[T], xh1, a1, 0, 0, 0);
+    a0 = gfv_mma_hh<LOWP == 2>(wh[T], xh0, a0);
+    a1 = gfv_mma_hh<LOWP == 2>(wh[T], xh1, a1);
 #endif
     // (FENCE: the scheduler may not hoist the next k-group's four fragment reads above this one's MFMAs - at a budget of 128
     // registers sixteen fragments in flight are 64 of them)
@@ -96,11 +96,12 @@ __device__ __forceinline__ void cc_mma_pair(const char* xbuf, int pair, const gf
 }
 
 // this lane's 4 values of one row -> its 8-byte share of the next layer's fragments (k-group w >> 1, half w & 1)
+template <bool BF>   // BF: the bf16 single-product form (the high parts in bf16; the low slots are written but never read)
 __device__ __forceinline__ void cc_put_frag(char* xbuf, int q, const CcCtx& c, const float (&a)[4], float scale) {
   unsigned h0, h1, l0, l1;
   const gfv_f2 s01 = gfv_f2{a[0], a[1]} * gfv_splat2(scale), s23 = gfv_f2{a[2], a[3]} * gfv_splat2(scale);
-  gfv_split_pair(s01.x, s01.y, h0, l0);
-  gfv_split_pair(s23.x, s23.y, h1, l1);
+  gfv_split_pair_t<BF>(s01.x, s01.y, h0, l0);
+  gfv_split_pair_t<BF>(s23.x, s23.y, h1, l1);
   char* dst = xbuf + (size_t)((q * 4 + (c.w >> 1)) * 2) * 1024 + c.lane * 16 + (c.w & 1) * 8;
   *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
   *reinterpret_cast<uint2*>(dst + 1024) = make_uint2(l0, l1);
@@ -176,11 +177,10 @@ __device__ __forceinline__ void cb_tr_operand(const char* xbuf, int q0, int ct, 
 
 // one tile's contribution to a fused weight gradient: acc[kt] += G^T (n-tile w) x A (k-tile kt) over the tile's row pairs;
 // accb += G^T x ones (the bias gradient: every column of the result is the column sum of G)
-template <bool LOWP>
+template <int LOWP>
 __device__ __forceinline__ void cb_dw_tile(const char* gbuf, const char* abuf, int npairs, int w, int lane, floatx4 (&acc)[8],
                                            floatx4& accb) {
-  const _Float16 one = (_Float16)1.0f;
-  const gfv_f16x8 ones = {one, one, one, one, one, one, one, one};
+  const gfv_f16x8 ones = gfv_frag_ones<LOWP == 2>();
   for (int pr = 0; pr < npairs; ++pr) {
     gfv_f16x8 gh, gl;
 #if GFV_ABL & 2
@@ -190,7 +190,7 @@ __device__ __forceinline__ void cb_dw_tile(const char* gbuf, const char* abuf, i
 #endif
 #if !(GFV_ABL & 1)
     if (!LOWP) accb = __builtin_amdgcn_mfma_f32_16x16x32_f16(gl, ones, accb, 0, 0, 0);
-    accb = __builtin_amdgcn_mfma_f32_16x16x32_f16(gh, ones, accb, 0, 0, 0);
+    accb = gfv_mma_hh<LOWP == 2>(gh, ones, accb);
 #endif
 #pragma unroll
     for (int kt = 0; kt < 8; ++kt) {
@@ -207,7 +207,7 @@ __device__ __forceinline__ void cb_dw_tile(const char* gbuf, const char* abuf, i
         acc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(gl, ah, acc[kt], 0, 0, 0);
         acc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(gh, al, acc[kt], 0, 0, 0);
       }
-      acc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(gh, ah, acc[kt], 0, 0, 0);
+      acc[kt] = gfv_mma_hh<LOWP == 2>(gh, ah, acc[kt]);
 #endif
       if ((kt & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // (four k-tiles' operands in flight, not eight: the register budget)
     }
@@ -216,6 +216,7 @@ __device__ __forceinline__ void cb_dw_tile(const char* gbuf, const char* abuf, i
 
 // chain-layer epilogue of one group in the backward form (GFV_OP_MUL_DGELU): v = acc / scales x gelu'(z) -> fragments with
 // the scale `sg`; a = gelu(z) -> fragments with CC_SH (the weight gradient's other operand); v is handed back for the save
+template <bool BF>
 __device__ __forceinline__ void cb_hidden_bwd(CcCtx& c, int q, const floatx4& acc, float inv_in, const float4& z, float sg,
                                               char* gout, char* aout, float (&v)[4]) {
   // two values per instruction (packed fp32, gfv_common.h): the same operations in the same order as the scalar form
@@ -234,8 +235,8 @@ __device__ __forceinline__ void cb_hidden_bwd(CcCtx& c, int q, const floatx4& ac
   const float mq = max3_abs(max3_abs(0.f, v[0], v[1]), v[2], v[3]) * sg;
   const float ma = max3_abs(max3_abs(0.f, a[0], a[1]), a[2], a[3]) * (CC_SH * (1.0f / 32.0f));   // (a against CC_SH_LIMIT x 32 = 65536)
   c.mabs = fmaxf(c.mabs, q < c.ngt ? fmaxf(mq, ma) : 0.f);
-  cc_put_frag(gout, q, c, v, sg);
-  cc_put_frag(aout, q, c, a, CC_SH);
+  cc_put_frag<BF>(gout, q, c, v, sg);
+  cc_put_frag<BF>(aout, q, c, a, CC_SH);
 }
 
 // (RC) this lane's 16 bytes of a fragment buffer - the two 8-byte slots cc_put_frag(xbuf, q, ...) will write - as a parking place
@@ -255,13 +256,14 @@ __device__ __forceinline__ void cb_unpark4(char* xbuf, int q, const CcCtx& c, fl
 }
 
 // the same with the GELU' factor given (RC: kept from the recompute phase, or taken from z alone) and no activation output
+template <bool BF>
 __device__ __forceinline__ void cb_hidden_bwd_dg(CcCtx& c, int q, const floatx4& acc, float inv_in, const float (&dg)[4], float sg,
                                                  char* gout, float (&v)[4]) {
 #pragma unroll
   for (int r = 0; r < 4; ++r) v[r] = ((acc[r] * inv_in) * c.invw) * dg[r];
   const float mq = max3_abs(max3_abs(0.f, v[0], v[1]), v[2], v[3]) * sg;
   c.mabs = fmaxf(c.mabs, q < c.ngt ? mq : 0.f);
-  cc_put_frag(gout, q, c, v, sg);
+  cc_put_frag<BF>(gout, q, c, v, sg);
 }
 
 // ---- buffer addressing ---------------------------------------------------------------------------------------------
@@ -353,7 +355,7 @@ __device__ __forceinline__ void cb_load_gathers(const CbBufs& B, const CcCtx& c,
 // NOOUT: the MLP's input needs no gradient (the encoders, EPD.py:92-119): a two-layer launch whose out[0] receives gz1 (what the
 // first Linear's weight-gradient launch reads); the third chain phase is only the weight gradient of the second Linear
 // RC: z2 and y3 are recomputed from z1 (rc_Wh / rc_bias: the forward's second and third Linear) instead of read
-template <bool LOWP, bool GADD, bool DW1, bool OUT2 = false, bool NOOUT = false, bool RC = false>
+template <int LOWP, bool GADD, bool DW1, bool OUT2 = false, bool NOOUT = false, bool RC = false>
 __global__ __launch_bounds__(64 * CC_W, 2) void colchain_bwd_kernel(const gfv_rowtile_args_t A, int* status) {
   static_assert(!(RC && DW1), "the fourth fragment buffer is either the first Linear's input rows or the recomputed a1");
   constexpr int TG = CB_TG;
@@ -429,8 +431,14 @@ __global__ __launch_bounds__(64 * CC_W, 2) void colchain_bwd_kernel(const gfv_ro
       for (int T = 0; T < 4; ++T) {
         const gfv_f16x8 h = __builtin_bit_cast(gfv_f16x8, __builtin_amdgcn_raw_buffer_load_b128(wb, woff + T * 16384, 0, 0));
         const gfv_f16x8 lo = __builtin_bit_cast(gfv_f16x8, __builtin_amdgcn_raw_buffer_load_b128(wb, woff + T * 16384 + 1024, 0, 0));
+        if (LOWP == 2) {   // (the bf16 form's image: bf16 high parts, zero low parts)
+          const gfv_bf16x8 hb = __builtin_bit_cast(gfv_bf16x8, h);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc += fabsf((float)h[e] + (float)lo[e]);
+          for (int e = 0; e < 8; ++e) acc += fabsf((float)hb[e]);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc += fabsf((float)h[e] + (float)lo[e]);
+        }
       }
       l1[l] = gfv_wave_max(row_sum(acc));   // row_sum: the 4 lane groups that share a weight row; then the 16 rows
     }
@@ -492,7 +500,7 @@ __global__ __launch_bounds__(64 * CC_W, 2) void colchain_bwd_kernel(const gfv_ro
         for (int r = 0; r < 4; ++r) a[r] = gfv_gelu(z4[r]);
         const float ma = max3_abs(max3_abs(0.f, a[0], a[1]), a[2], a[3]) * (CC_SH * (1.0f / 32.0f));
         c.mabs = fmaxf(c.mabs, q < c.ngt ? ma : 0.f);
-        cc_put_frag(b3, q, c, a, CC_SH);
+        cc_put_frag<LOWP == 2>(b3, q, c, a, CC_SH);
       }
       CT(12);
       cc_barrier();
@@ -533,7 +541,7 @@ __global__ __launch_bounds__(64 * CC_W, 2) void colchain_bwd_kernel(const gfv_ro
             cb_park4(b1, q, c, dg);
             const float ma = max3_abs(max3_abs(0.f, a[0], a[1]), a[2], a[3]) * (CC_SH * (1.0f / 32.0f));
             c.mabs = fmaxf(c.mabs, q < c.ngt ? ma : 0.f);
-            cc_put_frag(b2, q, c, a, CC_SH);
+            cc_put_frag<LOWP == 2>(b2, q, c, a, CC_SH);
           }
           a0 = n0; a1 = n1;
         }
@@ -658,7 +666,7 @@ __global__ __launch_bounds__(64 * CC_W, 2) void colchain_bwd_kernel(const gfv_ro
           g3[r] = t.x; g3[r + 1] = t.y;
         }
         if (A.in_save) cb_st4(cb_buf(A.in_save, rows128), offS[q], g3);
-        cc_put_frag(b0, q, c, g3, s3);
+        cc_put_frag<LOWP == 2>(b0, q, c, g3, s3);
       }
     }
     // the accumulators move to this tile's units
@@ -701,11 +709,11 @@ __global__ __launch_bounds__(64 * CC_W, 2) void colchain_bwd_kernel(const gfv_ro
           float d0[4], d1[4];
           cb_unpark4(b1, 2 * p, c, d0);
           cb_unpark4(b1, 2 * p + 1, c, d1);
-          cb_hidden_bwd_dg(c, 2 * p, a0, inv_in, d0, s2s, b1, v0);
-          cb_hidden_bwd_dg(c, 2 * p + 1, a1, inv_in, d1, s2s, b1, v1);
+          cb_hidden_bwd_dg<LOWP == 2>(c, 2 * p, a0, inv_in, d0, s2s, b1, v0);
+          cb_hidden_bwd_dg<LOWP == 2>(c, 2 * p + 1, a1, inv_in, d1, s2s, b1, v1);
         } else {
-          cb_hidden_bwd(c, 2 * p, a0, inv_in, zq[2 * p], s2s, b1, b2, v0);
-          cb_hidden_bwd(c, 2 * p + 1, a1, inv_in, zq[2 * p + 1], s2s, b1, b2, v1);
+          cb_hidden_bwd<LOWP == 2>(c, 2 * p, a0, inv_in, zq[2 * p], s2s, b1, b2, v0);
+          cb_hidden_bwd<LOWP == 2>(c, 2 * p + 1, a1, inv_in, zq[2 * p + 1], s2s, b1, b2, v1);
         }
         if (A.layer[0].save) {
           const cb_rsrc s0 = cb_buf(A.layer[0].save, rows128);
@@ -742,7 +750,7 @@ __global__ __launch_bounds__(64 * CC_W, 2) void colchain_bwd_kernel(const gfv_ro
         const float e4[4] = {ev[q].x, ev[q].y, ev[q].z, ev[q].w};
         const float me = max3_abs(max3_abs(0.f, e4[0], e4[1]), e4[2], e4[3]) * (CC_SH * (1.0f / 32.0f));
         c.mabs = fmaxf(c.mabs, q < c.ngt ? me : 0.f);
-        cc_put_frag(b3, q, c, e4, CC_SH);
+        cc_put_frag<LOWP == 2>(b3, q, c, e4, CC_SH);
       }
     }
     CT(6);
@@ -763,11 +771,11 @@ __global__ __launch_bounds__(64 * CC_W, 2) void colchain_bwd_kernel(const gfv_ro
           const float d0[4] = {gfv_dgelu(zq[2 * p].x), gfv_dgelu(zq[2 * p].y), gfv_dgelu(zq[2 * p].z), gfv_dgelu(zq[2 * p].w)};
           const float d1[4] = {gfv_dgelu(zq[2 * p + 1].x), gfv_dgelu(zq[2 * p + 1].y), gfv_dgelu(zq[2 * p + 1].z),
                                gfv_dgelu(zq[2 * p + 1].w)};
-          cb_hidden_bwd_dg(c, 2 * p, a0, inv_in, d0, s1s, b0, v0);
-          cb_hidden_bwd_dg(c, 2 * p + 1, a1, inv_in, d1, s1s, b0, v1);
+          cb_hidden_bwd_dg<LOWP == 2>(c, 2 * p, a0, inv_in, d0, s1s, b0, v0);
+          cb_hidden_bwd_dg<LOWP == 2>(c, 2 * p + 1, a1, inv_in, d1, s1s, b0, v1);
         } else {
-          cb_hidden_bwd(c, 2 * p, a0, inv_in, zq[2 * p], s1s, b0, b2, v0);
-          cb_hidden_bwd(c, 2 * p + 1, a1, inv_in, zq[2 * p + 1], s1s, b0, b2, v1);
+          cb_hidden_bwd<LOWP == 2>(c, 2 * p, a0, inv_in, zq[2 * p], s1s, b0, b2, v0);
+          cb_hidden_bwd<LOWP == 2>(c, 2 * p + 1, a1, inv_in, zq[2 * p + 1], s1s, b0, b2, v1);
         }
         cb_st4(B.save1, offS[2 * p], v0);
         cb_st4(B.save1, offS[2 * p + 1], v1);

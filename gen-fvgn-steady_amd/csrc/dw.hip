@@ -50,7 +50,7 @@ struct DwLaunch {
   int rows_per_slab;  // multiple of 32
   long ws_stride;     // floats per slab in the workspace
   float* ws;
-  int lowp;           // split form: 1 = reduced precision (gfv_set_f16split(2)): the hi x hi products only
+  int lowp;           // split form: 1 / 2 = reduced precision (gfv_set_f16split(2) / (3)): the hi x hi products only, fp16 / bf16 operands
   float ln_inv_n, ln_npad;   // LayerNorm width of a_op = 2 (gfv_set_hidden_size): 1 / h, 128 - h
 };
 
@@ -246,7 +246,7 @@ constexpr int HSTAGE = HBUF;               // experiment build: one staging buff
 constexpr int HSTAGE = 2 * HBUF;           // two staging buffers
 #endif
 
-template <bool FULL>
+template <bool FULL, bool BF>   // BF: the bf16 single-product form (its own instantiation: the default form's registers stay as they are)
 __device__ __forceinline__ void dw_body_h(const DwLaunch& A, const gfv_dw_tile_t& Tin, unsigned char* lds) {
   gfv_dw_tile_t T = Tin;
   const bool colscale = (T.a_op & GFV_DW_COLSCALE) != 0;
@@ -367,8 +367,8 @@ __device__ __forceinline__ void dw_body_h(const DwLaunch& A, const gfv_dw_tile_t
   const int slot = ((r4 >> 1) * 16) * 16 + 8 * (r4 & 1);
   auto put4 = [&](unsigned char* op, int c, float v0, float v1, float v2, float v3) {
     unsigned h0, h1, l0, l1;
-    gfv_split_pair(v0, v1, h0, l0);
-    gfv_split_pair(v2, v3, h1, l1);
+    gfv_split_pair_t<BF>(v0, v1, h0, l0);   // (BF: high parts in bf16, no low parts)
+    gfv_split_pair_t<BF>(v2, v3, h1, l1);
     unsigned char* b = op + ((c >> 4) * 2) * HBLK + ((c & 15) ^ ((c >> 4) & 3)) * 16 + slot;
     *reinterpret_cast<uint2*>(b) = make_uint2(h0, h1);
     *reinterpret_cast<uint2*>(b + HBLK) = make_uint2(l0, l1);
@@ -433,16 +433,24 @@ __device__ __forceinline__ void dw_body_h(const DwLaunch& A, const gfv_dw_tile_t
       ah[i] = *reinterpret_cast<const gfv_f16x8*>(As + ((4 * wk + i) * 2 + 0) * HBLK + (lane ^ i) * 16);
       al[i] = *reinterpret_cast<const gfv_f16x8*>(As + ((4 * wk + i) * 2 + 1) * HBLK + (lane ^ i) * 16);
     }
+    if constexpr (BF) {   // bf16 operands: v_mfma_f32_16x16x32_bf16
 #pragma unroll
-    for (int term = 0; term < 3; ++term)
-      if (term == 2 || !A.lowp)   // (uniform)
+      for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j)
+          if (FULL || (64 * wn + 16 * i < npad && 64 * wk + 16 * j < kpad)) acc[i][j] = gfv_mma_hh<true>(gh[i], ah[j], acc[i][j]);
+    } else {
 #pragma unroll
-          for (int j = 0; j < 4; ++j)
-            if (FULL || (64 * wn + 16 * i < npad && 64 * wk + 16 * j < kpad))
-              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(term == 0 ? gl[i] : gh[i], term == 1 ? al[j] : ah[j],
-                                                                 acc[i][j], 0, 0, 0);
+      for (int term = 0; term < 3; ++term)
+        if (term == 2 || !A.lowp)   // (uniform)
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              if (FULL || (64 * wn + 16 * i < npad && 64 * wk + 16 * j < kpad))
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(term == 0 ? gl[i] : gh[i], term == 1 ? al[j] : ah[j],
+                                                                   acc[i][j], 0, 0, 0);
+    }
 #ifdef GFV_DW_SINGLEBUF
     // experiment (profiles/tools/ab.sh): ONE 32 KB staging buffer - every wave holds its fragments after the reads above,
     // so the buffer may be refilled after a barrier; a second barrier publishes it
@@ -493,13 +501,14 @@ __global__ __launch_bounds__(256, 2) void dw_multi_kernel(const DwLaunch A) {
   else dw_body<false>(A, T, lds);
 }
 
+template <bool BF>
 __global__ __launch_bounds__(256, 2) void dw_multi_h_kernel(const DwLaunch A) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[HSTAGE + 512];   // + the inverse column scales
   static_assert(HSTAGE >= 8 * LDT * 4, "the bias-gradient fold reuses the staging buffers");
   const gfv_dw_tile_t& T = A.tile[blockIdx.y];
   const bool full = (T.n_out == 128) && (T.width == 128) && ((T.ldg & 3) == 0) && ((T.ld & 3) == 0);
-  if (full) dw_body_h<true>(A, T, lds);
-  else dw_body_h<false>(A, T, lds);
+  if (full) dw_body_h<true, BF>(A, T, lds);
+  else dw_body_h<false, BF>(A, T, lds);
 }
 
 }  // namespace
@@ -553,7 +562,7 @@ extern "C" int gfv_dw_multi(const gfv_dw_tile_t* tiles, int32_t ntiles, int32_t 
     by += 4.0 * M * ((double)t.n_out + t.width);
   }
   a.ntiles = ntiles;
-  a.lowp = gfv_f16split_enabled() == 2 ? 1 : 0;
+  a.lowp = gfv_f16split_enabled() == 2 ? 1 : (gfv_f16split_enabled() == 3 ? 2 : 0);
   a.ln_inv_n = 1.0f / (float)gfv_hidden_size();
   a.ln_npad = (float)(128 - gfv_hidden_size());
   a.M = M;
@@ -565,7 +574,8 @@ extern "C" int gfv_dw_multi(const gfv_dw_tile_t* tiles, int32_t ntiles, int32_t 
   // slots of the block that no tile writes (alignment padding) keep whatever the workspace held: callers hand in a
   // zero-initialised workspace, so padding entries of the gradient block stay finite and are never read.
   void* tok = gfv_prof_begin(GFV_K_DW, fl, by + 8.0 * (double)slabs * block_floats, (hipStream_t)stream);
-  if (gfv_f16split_enabled()) hipLaunchKernelGGL(dw_multi_h_kernel, dim3(slabs, ntiles), dim3(256), 0, (hipStream_t)stream, a);
+  if (a.lowp == 2) hipLaunchKernelGGL(dw_multi_h_kernel<true>, dim3(slabs, ntiles), dim3(256), 0, (hipStream_t)stream, a);
+  else if (gfv_f16split_enabled()) hipLaunchKernelGGL(dw_multi_h_kernel<false>, dim3(slabs, ntiles), dim3(256), 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL(dw_multi_kernel, dim3(slabs, ntiles), dim3(256), 0, (hipStream_t)stream, a);
   gfv_prof_end(tok, (hipStream_t)stream);
   GFV_CHECK_LAUNCH();

@@ -62,7 +62,7 @@ struct Lin1Args {
 
 // KS: 32-wide k-steps (4: one 128-wide segment, 8: two); NP: 128-row passes of the image = 128-wide output chunks
 // IN_OP: 0 none, 1 GELU, 2 LayerNorm (one segment); DGELU: out = (acc) * gelu'(aux)
-template <int KS, int NP, int IN_OP, bool DGELU, bool LOWP>
+template <int KS, int NP, int IN_OP, bool DGELU, int LOWP>   // LOWP: 0 three products, 1 / 2 the single-product forms (fp16 / bf16)
 __global__ __launch_bounds__(512, 2) void lin1_kernel(const Lin1Args A, int* status) {
   extern __shared__ __attribute__((aligned(16))) char lds_raw[];
   gfv_uint4* img = reinterpret_cast<gfv_uint4*>(lds_raw);
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(512, 2) void lin1_kernel(const Lin1Args A, int* sta
 #pragma unroll
     for (int i = 0; i < 8; ++i) e[i] = v[T][i] * sx;
     gfv_uint4 hi, lo;
-    gfv_split8(e, hi, lo);
+    gfv_split8_t<LOWP == 2>(e, hi, lo);
     xh[T] = __builtin_bit_cast(gfv_f16x8, hi);
     xl[T] = __builtin_bit_cast(gfv_f16x8, lo);
   }
@@ -222,7 +222,7 @@ __global__ __launch_bounds__(512, 2) void lin1_kernel(const Lin1Args A, int* sta
           acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh[T], acc, 0, 0, 0);
           acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl[T], acc, 0, 0, 0);
         }
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh[T], acc, 0, 0, 0);
+        acc = gfv_mma_hh<LOWP == 2>(wh, xh[T], acc);
       }
       const int col = 16 * nt + 4 * g;
       float4 o = make_float4((acc[0] * inv) * invw, (acc[1] * inv) * invw, (acc[2] * inv) * invw, (acc[3] * inv) * invw);
@@ -254,7 +254,7 @@ struct Lin1LnbArgs {
   float* ln_partial;     // [n_tiles, 2, 128]
   int n_tiles;
 };
-template <bool LOWP>
+template <int LOWP>
 __global__ __launch_bounds__(512, 2) void lin1_lnbwd_kernel(const Lin1LnbArgs B, int* status) {
   constexpr int KS = 8;
   const Lin1Args& A = B.a;
@@ -300,7 +300,7 @@ __global__ __launch_bounds__(512, 2) void lin1_lnbwd_kernel(const Lin1LnbArgs B,
 #pragma unroll
       for (int i = 0; i < 8; ++i) e[i] = v[T][i] * sx;
       gfv_uint4 hi, lo;
-      gfv_split8(e, hi, lo);
+      gfv_split8_t<LOWP == 2>(e, hi, lo);
       xh[T] = __builtin_bit_cast(gfv_f16x8, hi);
       xl[T] = __builtin_bit_cast(gfv_f16x8, lo);
     }
@@ -327,7 +327,7 @@ __global__ __launch_bounds__(512, 2) void lin1_lnbwd_kernel(const Lin1LnbArgs B,
         acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh[T], acc[nt], 0, 0, 0);
         acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl[T], acc[nt], 0, 0, 0);
       }
-      acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh[T], acc[nt], 0, 0, 0);
+      acc[nt] = gfv_mma_hh<LOWP == 2>(wh, xh[T], acc[nt]);
     }
   }
   // ---- LayerNorm backward of the row (tchain_kernel.h ln_stats / ln_bwd) ----
@@ -431,7 +431,7 @@ struct Lin1CsrArgs {
   int out_ld;
   int M;
 };
-template <bool LOWP>
+template <int LOWP>
 __global__ __launch_bounds__(512, 2) void lin1_csr_kernel(const Lin1CsrArgs A, int* status) {
   constexpr int KS = 8;
   extern __shared__ __attribute__((aligned(16))) char lds_raw[];
@@ -528,7 +528,7 @@ __global__ __launch_bounds__(512, 2) void lin1_csr_kernel(const Lin1CsrArgs A, i
 #pragma unroll
     for (int i = 0; i < 8; ++i) e[i] = v[T][i] * sx;
     gfv_uint4 hi, lo;
-    gfv_split8(e, hi, lo);
+    gfv_split8_t<LOWP == 2>(e, hi, lo);
     xh[T] = __builtin_bit_cast(gfv_f16x8, hi);
     xl[T] = __builtin_bit_cast(gfv_f16x8, lo);
   }
@@ -546,7 +546,7 @@ __global__ __launch_bounds__(512, 2) void lin1_csr_kernel(const Lin1CsrArgs A, i
         acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh[T], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl[T], acc, 0, 0, 0);
       }
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh[T], acc, 0, 0, 0);
+      acc = gfv_mma_hh<LOWP == 2>(wh, xh[T], acc);
     }
     if (live)
       *reinterpret_cast<float4*>(A.out + (size_t)m * A.out_ld + 16 * nt + 4 * g) =
@@ -584,7 +584,7 @@ static inline bool l1_dyn_lds(const void* fn, int bytes, std::atomic<unsigned lo
 }
 }  // namespace
 
-// 1: launched; 0: not a launch of this family.  lowp: the reduced-precision product form (one product per term).
+// 1: launched; 0: not a launch of this family.  lowp: the reduced-precision product forms (one product per term; 1 fp16, 2 bf16).
 // dry != 0: only tell whether the launch would be taken (the profiler prices it as this family's before it is issued)
 int gfv_internal_lin1_try(const gfv_rowtile_args_t* a, int lowp, hipStream_t stream, int dry) {
   static const int on = l1_env("GFV_LIN1", 1);
@@ -614,15 +614,16 @@ int gfv_internal_lin1_try(const gfv_rowtile_args_t* a, int lowp, hipStream_t str
     if (dry) return 1;
     int* st = gfv_internal_status_ptr();
     const dim3 grid((a->M + 127) / 128), blk(512);
-    if (lowp) {
-      static std::atomic<unsigned long long> done{0};
-      if (!l1_dyn_lds(reinterpret_cast<const void*>(&lin1_csr_kernel<true>), 131072, done)) return 0;
-      hipLaunchKernelGGL((lin1_csr_kernel<true>), grid, blk, 131072, stream, B, st);
-    } else {
-      static std::atomic<unsigned long long> done{0};
-      if (!l1_dyn_lds(reinterpret_cast<const void*>(&lin1_csr_kernel<false>), 131072, done)) return 0;
-      hipLaunchKernelGGL((lin1_csr_kernel<false>), grid, blk, 131072, stream, B, st);
-    }
+#define L1_CSR(LP)                                                                                               \
+  do {                                                                                                           \
+    static std::atomic<unsigned long long> done{0};                                                              \
+    if (!l1_dyn_lds(reinterpret_cast<const void*>(&lin1_csr_kernel<LP>), 131072, done)) return 0;                \
+    hipLaunchKernelGGL((lin1_csr_kernel<LP>), grid, blk, 131072, stream, B, st);                                 \
+  } while (0)
+    if (lowp == 2) L1_CSR(2);
+    else if (lowp) L1_CSR(1);
+    else L1_CSR(0);
+#undef L1_CSR
     return 1;
   }
   if (a->fin_op == GFV_FIN_LNBWD) {
@@ -659,15 +660,16 @@ int gfv_internal_lin1_try(const gfv_rowtile_args_t* a, int lowp, hipStream_t str
     if (dry) return 1;
     int* st = gfv_internal_status_ptr();
     const dim3 grid((a->M + 127) / 128), blk(512);
-    if (lowp) {
-      static std::atomic<unsigned long long> done{0};
-      if (!l1_dyn_lds(reinterpret_cast<const void*>(&lin1_lnbwd_kernel<true>), 131072, done)) return 0;
-      hipLaunchKernelGGL((lin1_lnbwd_kernel<true>), grid, blk, 131072, stream, B, st);
-    } else {
-      static std::atomic<unsigned long long> done{0};
-      if (!l1_dyn_lds(reinterpret_cast<const void*>(&lin1_lnbwd_kernel<false>), 131072, done)) return 0;
-      hipLaunchKernelGGL((lin1_lnbwd_kernel<false>), grid, blk, 131072, stream, B, st);
-    }
+#define L1_LNB(LP)                                                                                               \
+  do {                                                                                                           \
+    static std::atomic<unsigned long long> done{0};                                                              \
+    if (!l1_dyn_lds(reinterpret_cast<const void*>(&lin1_lnbwd_kernel<LP>), 131072, done)) return 0;              \
+    hipLaunchKernelGGL((lin1_lnbwd_kernel<LP>), grid, blk, 131072, stream, B, st);                               \
+  } while (0)
+    if (lowp == 2) L1_LNB(2);
+    else if (lowp) L1_LNB(1);
+    else L1_LNB(0);
+#undef L1_LNB
     return 1;
   }
   const bool dgelu = L.op == GFV_OP_MUL_DGELU;
@@ -744,8 +746,9 @@ int gfv_internal_lin1_try(const gfv_rowtile_args_t* a, int lowp, hipStream_t str
   } while (0)
 #define L1_LAUNCH(KS, NP)                                                                                                       \
   do {                                                                                                                          \
-    if (lowp) L1_FORM(KS, NP, true);                                                                                            \
-    else L1_FORM(KS, NP, false);                                                                                                \
+    if (lowp == 2) L1_FORM(KS, NP, 2);                                                                                          \
+    else if (lowp) L1_FORM(KS, NP, 1);                                                                                          \
+    else L1_FORM(KS, NP, 0);                                                                                                    \
   } while (0)
   if (a->nseg == 2) L1_LAUNCH(8, 1);
   else if (np == 2) L1_LAUNCH(4, 2);

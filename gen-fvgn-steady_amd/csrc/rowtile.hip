@@ -21,7 +21,8 @@ int gfv_internal_tchain_launch(const gfv_rowtile_args_t* args, int ragged, int f
 
 // GFV_F16SPLIT (or gfv_set_f16split): 0 = every GEMM product on the fp32 MFMA, even when a launch carries split-fp16
 // weight images; 1 (default) = split-fp16 products; 2 = the reduced-precision form, ONE fp16 x fp16 product with fp32
-// accumulation (the high parts only); shared with dw.hip
+// accumulation (the high parts only); 3 = the same with bf16 operands (v_mfma_f32_16x16x32_bf16: BASELINE config 3's wording;
+// weight images must be built in the form they are used in - gfv_weight_images reads it); shared with dw.hip
 // State: a PROCESS-WIDE default (atomic; gfv_set_f16split) - PyTorch runs the backward of an autograd node on its device
 // worker thread, and a form chosen on the user's thread must reach the launches issued there - and a per-thread OVERRIDE
 // (gfv_set_f16split_thread; -1 = none) for two host threads driving two models in different forms; a launch may also carry its
@@ -32,7 +33,7 @@ static int f16_default() {
   int d = g_f16_default.load(std::memory_order_relaxed);
   if (d < 0) {
     const char* e = getenv("GFV_F16SPLIT");
-    d = e ? (atoi(e) == 2 ? 2 : (atoi(e) != 0)) : 1;
+    d = e ? ((atoi(e) == 2 || atoi(e) == 3) ? atoi(e) : (atoi(e) != 0)) : 1;
     int expect = -1;
     if (!g_f16_default.compare_exchange_strong(expect, d)) d = expect;
   }
@@ -40,12 +41,12 @@ static int f16_default() {
 }
 extern "C" int gfv_f16split_enabled(void) { return g_f16split >= 0 ? g_f16split : f16_default(); }
 extern "C" int gfv_set_f16split(int32_t on) {
-  g_f16_default.store(on == 2 ? 2 : (on ? 1 : 0));
+  g_f16_default.store((on == 2 || on == 3) ? on : (on ? 1 : 0));
   g_f16split = -1;   // (the caller asked for the process-wide form: its own override, if any, would hide it)
   return GFV_OK;
 }
 extern "C" int gfv_set_f16split_thread(int32_t on) {
-  if (on < -1 || on > 2) return GFV_ERR_ARG;
+  if (on < -1 || on > 3) return GFV_ERR_ARG;
   g_f16split = on;
   return GFV_OK;
 }
@@ -73,11 +74,11 @@ static int rowtile_chain_impl(const gfv_rowtile_args_t* args, void* stream);
 extern "C" int gfv_rowtile_chain(const gfv_rowtile_args_t* args, void* stream) {
   if (!args) return GFV_ERR_ARG;
   // the launch's own product form / hidden size (0: the calling thread's context)
-  if (args->product_form < 0 || args->product_form > 3 || (args->hidden != 0 && (args->hidden < 16 || args->hidden > 128 || (args->hidden & 15))))
+  if (args->product_form < 0 || args->product_form > 4 || (args->hidden != 0 && (args->hidden < 16 || args->hidden > 128 || (args->hidden & 15))))
     return GFV_ERR_ARG;
   if (args->product_form == 0 && args->hidden == 0) return rowtile_chain_impl(args, stream);
   const int f0 = g_f16split, h0 = g_hidden;   // (f0: this thread's override or -1; restored below)
-  if (args->product_form) g_f16split = args->product_form - 1;   // 1 fp32 MFMA, 2 split-fp16, 3 reduced precision
+  if (args->product_form) g_f16split = args->product_form - 1;   // 1 fp32 MFMA, 2 split-fp16, 3 / 4 reduced precision (fp16 / bf16)
   if (args->hidden) g_hidden = args->hidden;
   const int rc = rowtile_chain_impl(args, stream);
   g_f16split = f0;
@@ -179,7 +180,7 @@ static int rowtile_chain_impl(const gfv_rowtile_args_t* args, void* stream) {
     int kind = fast_t ? GFV_K_TCHAIN0 + lnm : GFV_K_TCHAIN_RAG;
     for (int i = 0; i < args->nseg; ++i)
       if (args->seg[i].csr_rowptr || args->seg[i].save) kind = GFV_K_TCHAIN_CSR;
-    if (fast_t && f16 && args->nlayers == 1 && gfv_internal_lin1_try(args, f16_mode() == 2 ? 1 : 0, (hipStream_t)stream, 1))
+    if (fast_t && f16 && args->nlayers == 1 && gfv_internal_lin1_try(args, f16_mode() >= 2 ? f16_mode() - 1 : 0, (hipStream_t)stream, 1))
       kind = GFV_K_LIN1;   // the lean single-layer kernel (same algorithmic work as the chain launch it stands in for)
     if (args->dw_partial) {
       // dX chain with fused weight gradients (column-owner backward family): + the two (three) weight-gradient GEMMs, the
@@ -193,7 +194,7 @@ static int rowtile_chain_impl(const gfv_rowtile_args_t* args, void* stream) {
   }
   g_last_path = (fast_t ? 1 : 2) + (f16 ? 4 : 0);
   if (args->dw_partial && !(fast_t && f16)) return GFV_ERR_ARG;   // (fused weight gradients: ask gfv_rowtile_fuses_dw first)
-  if (fast_t && f16 && args->nlayers == 1 && gfv_internal_lin1_try(args, f16_mode() == 2 ? 1 : 0, (hipStream_t)stream, 0)) {
+  if (fast_t && f16 && args->nlayers == 1 && gfv_internal_lin1_try(args, f16_mode() >= 2 ? f16_mode() - 1 : 0, (hipStream_t)stream, 0)) {
     g_last_path += 32;   // the lean single-layer kernel (lin1.hip)
   } else if (fast_t) {
     const int took = gfv_internal_tchain_launch(args, 0, f16 ? 1 : 0, (hipStream_t)stream);   // 1: the column-owner family, 2: with fused dW

@@ -4,6 +4,7 @@
 
 void gfv_internal_tchain_fwd_plain(const gfv_rowtile_args_t* args, int f16, int iop, hipStream_t stream);   // tchain_fwd.hip
 int gfv_internal_colchain_try(const gfv_rowtile_args_t* args, hipStream_t stream);                              // colchain.hip
+void gfv_internal_tchain_launch_bf16(const gfv_rowtile_args_t* args, int ragged, int lnm, hipStream_t stream);  // tchain_bf16.hip
 
 // 1 / 2: every layer before the last has GFV_OP_BIAS_GELU / GFV_OP_MUL_DGELU and the prologue op is none or the LayerNorm
 // backward (the IOP instantiations, tchain_kernel.h); 0: anything else - the instantiation that reads the ops at run time
@@ -43,12 +44,12 @@ static void launch_h(const gfv_rowtile_args_t* args, int ragged, int lnm, hipStr
 
 // fast-path launcher used by gfv_rowtile_chain (rowtile.hip); ragged: the instantiation that also takes ragged shapes
 // (only without LayerNorm backward); f16: the split-fp16 form (every layer has a weight image)
-extern "C" int gfv_f16split_enabled(void);   // rowtile.hip: 0 fp32 MFMA, 1 split-fp16, 2 reduced precision
+extern "C" int gfv_f16split_enabled(void);   // rowtile.hip: 0 fp32 MFMA, 1 split-fp16, 2 / 3 reduced precision (fp16 / bf16)
 extern "C" int gfv_hidden_size(void);         // rowtile.hip
 
 int gfv_internal_tchain_launch(const gfv_rowtile_args_t* args_in, int ragged, int f16, hipStream_t stream) {
   gfv_rowtile_args_t local = *args_in;
-  local.product_form = (f16 && gfv_f16split_enabled() == 2) ? 1 : 0;
+  local.product_form = f16 ? (gfv_f16split_enabled() == 2 ? 1 : (gfv_f16split_enabled() == 3 ? 2 : 0)) : 0;   // 1 / 2: the single-product forms (fp16 / bf16)
   local.hidden = gfv_hidden_size();   // LayerNorm width (gfv_set_hidden_size)
   const gfv_rowtile_args_t* args = &local;
   const int lnm = args->in_op == GFV_IN_LNBWD ? 1 : (args->fin_op == GFV_FIN_LNBWD ? 2 : 0);
@@ -56,6 +57,10 @@ int gfv_internal_tchain_launch(const gfv_rowtile_args_t* args_in, int ragged, in
   if (f16 && !ragged) {   // the column-owner persistent family
     const int took = gfv_internal_colchain_try(args, stream);
     if (took) return took;
+  }
+  if (f16 && local.product_form == 2) {   // the bf16 form: the run-time-op instantiations of its own translation unit
+    gfv_internal_tchain_launch_bf16(args, ragged, lnm, stream);
+    return 0;
   }
   if (f16) {
     // (an 8-wave workgroup sharing one weight stream over 128 rows - launch_h<8> - was measured in round 2: 5.28 ms / step

@@ -408,7 +408,9 @@ __device__ __forceinline__ void w_store_n(float* Wb, int tid, const WRegs& r) {
 
 // H: one 32-wide k group on the f16 pipe; LDS slice image [nt 8][part 2][lane 64] x 16 B; n-tiles >= 4 are skipped for
 // the 64-wide tail chunk of a 192-wide last layer (nth = number of 4-tile halves with valid rows)
-// lowp (gfv_set_f16split(2)): the hi x hi term only
+// lowp (gfv_set_f16split(2)): the hi x hi term only.  BF (gfv_set_f16split(3); its own instantiations, tchain_bf16.hip): the
+// hi x hi term on bf16 operands (v_mfma_f32_16x16x32_bf16)
+template <bool BF>
 __device__ __forceinline__ void mma_slice_h(floatx4 (&acc)[8], const gfv_f16x8& xh, const gfv_f16x8& xl, const float* Wb,
                                             int lane, int nth, bool lowp) {
   const gfv_f16x8* wp = reinterpret_cast<const gfv_f16x8*>(Wb) + lane;
@@ -418,6 +420,11 @@ __device__ __forceinline__ void mma_slice_h(floatx4 (&acc)[8], const gfv_f16x8& 
       gfv_f16x8 w0[4], w1[4];
 #pragma unroll
       for (int n = 0; n < 4; ++n) w0[n] = wp[((4 * h + n) * 2 + 0) * 64];
+      if constexpr (BF) {
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[4 * h + n] = gfv_mma_hh<true>(w0[n], xh, acc[4 * h + n]);
+        continue;
+      }
       if (!lowp) {   // (uniform branch)
 #pragma unroll
         for (int n = 0; n < 4; ++n) w1[n] = wp[((4 * h + n) * 2 + 1) * 64];
@@ -456,13 +463,14 @@ __device__ __forceinline__ void group_scale_out(float* dst, float s, int lane) {
   if (lane == 0) *dst = s;
 }
 // H: fp32 activations -> B-operand fragments of the four 32-groups: slots e = 0..3 <- act[2T][.], 4..7 <- act[2T+1][.]
+template <bool BF>   // BF: high parts in bf16, no low parts
 __device__ __forceinline__ void to_halves(const float (&v)[8][4], float sc, gfv_f16x8 (&xh)[4], gfv_f16x8 (&xl)[4]) {
 #pragma unroll
   for (int T32 = 0; T32 < 4; ++T32) {
     const float e[8] = {v[2 * T32][0] * sc,     v[2 * T32][1] * sc,     v[2 * T32][2] * sc,     v[2 * T32][3] * sc,
                         v[2 * T32 + 1][0] * sc, v[2 * T32 + 1][1] * sc, v[2 * T32 + 1][2] * sc, v[2 * T32 + 1][3] * sc};
     gfv_uint4 hi, lo;
-    gfv_split8(e, hi, lo);
+    gfv_split8_t<BF>(e, hi, lo);
     xh[T32] = __builtin_bit_cast(gfv_f16x8, hi);
     xl[T32] = __builtin_bit_cast(gfv_f16x8, lo);
   }
@@ -685,7 +693,7 @@ __device__ __forceinline__ void load_segment(const gfv_rowtile_args_t& A, int si
 // handful of the model's launches are.  With the ops known at compile time the epilogues have no branches to merge:
 // hipcc joins the arms of a run-time `switch (op)` over a 32-register activation array with 100 - 150 register moves per
 // layer (a tenth of the kernel's VALU instructions).
-template <int T, int LNM, bool RAG, bool H, int NW = 4, bool CSR = false, int IOP = 0>
+template <int T, int LNM, bool RAG, bool H, int NW = 4, bool CSR = false, int IOP = 0, bool BF = false>
 #ifndef GFV_CHAIN_WAVES   // waves per SIMD the register allocation aims at (a translation unit may set its own)
 #define GFV_CHAIN_WAVES(H, LNM, RAG) 2
 #endif
@@ -823,7 +831,7 @@ __global__ __launch_bounds__(64 * NW, GFV_CHAIN_WAVES(H, LNM, RAG)) void tchain_
               for (int nt = 0; nt < 8; ++nt) acc[0][nt] *= ratio;
             }
             sx = sn;
-            to_halves(act[0], sx, xh, xl);
+            to_halves<BF>(act[0], sx, xh, xl);
           }
           TS_WAIT();
           TS(1);
@@ -850,7 +858,7 @@ __global__ __launch_bounds__(64 * NW, GFV_CHAIN_WAVES(H, LNM, RAG)) void tchain_
             __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ABOVE the MFMAs (the scheduler sinks it otherwise)
 #endif
             TS(2);
-            if (H) mma_slice_h(acc[0], xh[sl], xl[sl], lds + wbuf * WS_FLOATS, lane, (cur.nrows + 63) >> 6, lowp);
+            if (H) mma_slice_h<BF>(acc[0], xh[sl], xl[sl], lds + wbuf * WS_FLOATS, lane, (cur.nrows + 63) >> 6, lowp);
             else mma_slice<T>(acc, act, 2 * sl, lds + wbuf * WS_FLOATS, off0);
             TS(3);
 #ifndef NO_SCHEDB
@@ -961,7 +969,7 @@ __global__ __launch_bounds__(64 * NW, GFV_CHAIN_WAVES(H, LNM, RAG)) void tchain_
         if (H) {
           sx = row_scale(act[0]);
           if (A.gscale && lop == GFV_OP_MUL_DGELU) group_scale_out(A.gscale + (size_t)(layer + 1) * A.gscale_ld + rowgroup, sx, lane);
-          to_halves(act[0], sx, xh, xl);
+          to_halves<BF>(act[0], sx, xh, xl);
         }
         TS_WAIT();
         TS(6);

@@ -26,8 +26,8 @@ __global__ __launch_bounds__(256) void wabsmax_kernel(const gfv_wimg_desc_t* __r
   if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(reinterpret_cast<unsigned*>(wmax), __float_as_uint(m));
 }
 
-// one thread = one (pass, T, nt, lane) fragment, both parts
-__global__ __launch_bounds__(256) void wimg_kernel(const gfv_wimg_desc_t* __restrict__ descs, const float* __restrict__ wmax) {
+// one thread = one (pass, T, nt, lane) fragment, both parts (bf: the bf16 single-product form - the high part in bf16, no low part)
+__global__ __launch_bounds__(256) void wimg_kernel(const gfv_wimg_desc_t* __restrict__ descs, const float* __restrict__ wmax, int bf) {
   const gfv_wimg_desc_t d = descs[blockIdx.y];
   const int nT = (d.K + 31) >> 5, npass = (d.N + 127) >> 7;
   const long f = (long)blockIdx.x * 256 + threadIdx.x;
@@ -44,7 +44,8 @@ __global__ __launch_bounds__(256) void wimg_kernel(const gfv_wimg_desc_t* __rest
     v[e] = (n < d.N && k < d.K) ? d.W[(size_t)n * d.ldw + k] * ws : 0.f;
   }
   gfv_uint4 hi, lo;
-  gfv_split8(v, hi, lo);
+  if (bf) gfv_split8_t<true>(v, hi, lo);   // (uniform)
+  else gfv_split8(v, hi, lo);
   gfv_uint4* img = reinterpret_cast<gfv_uint4*>(d.img) + ((size_t)(pass * nT + T) * 8 + nt) * 128 + lane;
   img[0] = hi;
   img[64] = lo;
@@ -66,13 +67,14 @@ extern "C" int gfv_weight_absmax(const gfv_wimg_desc_t* descs_dev, int32_t n_des
   return GFV_OK;
 }
 
+extern "C" int gfv_f16split_enabled(void);   // rowtile.hip
 extern "C" int gfv_weight_images(const gfv_wimg_desc_t* descs_dev, int32_t n_desc, int64_t max_frags, const float* wmax,
                                  void* stream) {
   GfvProfScope ps_(GFV_K_WIMG, 0, 32.0 * (double)max_frags * n_desc, stream);
   if (!descs_dev || !wmax || n_desc < 0 || max_frags < 0) return GFV_ERR_ARG;
   if (n_desc == 0 || max_frags == 0) return GFV_OK;
   hipLaunchKernelGGL(wimg_kernel, dim3((unsigned)((max_frags + 255) / 256), n_desc), dim3(256), 0, (hipStream_t)stream,
-                     descs_dev, wmax);
+                     descs_dev, wmax, gfv_f16split_enabled() == 3 ? 1 : 0);
   GFV_CHECK_LAUNCH();
   return GFV_OK;
 }

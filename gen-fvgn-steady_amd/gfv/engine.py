@@ -304,8 +304,8 @@ class Engine:
         """Identity of everything a captured step points at inside the engine (weight images, descriptor tables,
         transposed copies); TrainStep drops its hipGraphs when it changes."""
         wi = self._wi or {}
-        return (self._wi_key, self._wt_key, tuple((ph, len(w.images), None if w._desc is None else w._desc.data_ptr())
-                                                  for ph, w in sorted(wi.items())))
+        return (self._wi_key, self._wt_key, L.load().gfv_f16split_enabled(),   # (the product form: launches and images depend on it)
+                tuple((ph, len(w.images), None if w._desc is None else w._desc.data_ptr()) for ph, w in sorted(wi.items())))
 
     def _wi_exit(self, phase, prev):
         if not self.f16split:

@@ -140,6 +140,7 @@ class WeightImages:
         self.static = []                            # sorted [(start, end)]
         self._desc, self._desc_keys, self._max_frags = None, (), 0
         self._retired = []
+        self._bf = None                             # the valid images hold bf16 high parts (built under gfv_set_f16split(3))
 
     def add_static(self, tensors):
         for t in tensors:
@@ -175,6 +176,14 @@ class WeightImages:
         if stack is not None:
             assert W.shape == stack.shape and W.shape[0] == 128
             key = ("stack", key, (stack.data_ptr(), stack.stride(0), stack.shape[0], stack.shape[1]))
+        bf = L.load().gfv_f16split_enabled() == 3
+        if bf != self._bf:
+            # images are built in the product form they are used in (bf16 high parts / fp16 hi + lo, include/gfv.h): the form
+            # changed since these were made - rebuild them all now (outside a capture; inside one they simply are not valid)
+            self._bf = bf
+            self.invalidate()
+            if self.images and not torch.cuda.is_current_stream_capturing():
+                self.build()
         img = self.images.get(key)
         if img is not None:
             return img.data_ptr() if key in self.valid else 0
@@ -204,6 +213,7 @@ class WeightImages:
             return
         L.check(L.load().gfv_weight_images(self._desc.data_ptr(), self._ndesc, self._max_frags,
                                            self.wmax.data_ptr(), L.stream_ptr()), "gfv_weight_images")
+        self._bf = L.load().gfv_f16split_enabled() == 3
         self.valid = set(self._desc_keys)
 
     def invalidate(self):

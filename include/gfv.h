@@ -156,7 +156,7 @@ typedef struct {
    * gfv_dw_tile_t.gscale takes a slot: the slab scale of the gradient rows then needs no extra pass over them. */
   float* gscale;
   int32_t gscale_ld;
-  int32_t product_form;   /* 0 = gfv_f16split_enabled() of the calling thread; 1 fp32 MFMA, 2 split-fp16, 3 reduced precision */
+  int32_t product_form;   /* 0 = gfv_f16split_enabled() of the calling thread; 1 fp32 MFMA, 2 split-fp16, 3 / 4 reduced precision (fp16 / bf16) */
   /* LayerNorm statistics of the rows, [M, 2] = (mean, 1 / sqrt(var + eps)): written by a GFV_FIN_LN launch when fin_stats is
    * given, read by a GFV_IN_LNBWD launch when in_stats is given (the column-owner backward needs them: its LayerNorm backward
    * is spread over eight waves and takes the row statistics as they were in the forward instead of recomputing them) */
@@ -219,13 +219,17 @@ size_t gfv_weight_image_bytes(int32_t N, int32_t K);
 /* the product form of the launches that do not name their own: a PROCESS-WIDE default (initial value: environment
  * GFV_F16SPLIT, default 1; gfv_set_f16split) - it must reach launches issued from other threads than the one that chose it:
  * PyTorch runs the backward of an autograd node on its device worker thread - and an optional override of the CALLING THREAD
- * (gfv_set_f16split_thread(0 / 1 / 2); -1 removes it) for hosts that drive two models in different forms from two threads.
+ * (gfv_set_f16split_thread(0 / 1 / 2 / 3); -1 removes it) for hosts that drive two models in different forms from two threads.
  * gfv_set_f16split also removes the calling thread's override.  gfv_f16split_enabled() = what a launch from this thread gets.
  * 0 = fp32 MFMA everywhere (chain launches ignore their images, weight gradients take the fp32 kernel);
  * 1 = split-fp16 products (fp32 accuracy);
  * 2 = reduced precision: one fp16 x fp16 product per term with fp32 accumulation - the high parts of the same operands
  *     (11 significand bits: results agree with the fp32 forms to ~1e-3; the counterpart of the reference's autocast runs,
- *     BASELINE configs 3 / 5 - never the form the parity claims or bench.py's `value` are made on) */
+ *     BASELINE configs 3 / 5 - never the form the parity claims or bench.py's `value` are made on);
+ * 3 = the same single product with bf16 operands (v_mfma_f32_16x16x32_bf16, fp32 accumulation; 8 significand bits: ~1e-2 of
+ *     the fp32 forms) - BASELINE config 3's "bf16 MLP GEMMs on MFMA" to the letter.  Same fragment layouts and scales; the
+ *     weight images hold bf16 high parts and no low parts, so they must be BUILT in this form: gfv_weight_images reads the
+ *     calling thread's form, and images built in forms 0 - 2 are not valid for form 3 (nor the other way round). */
 int gfv_f16split_enabled(void);
 int gfv_set_f16split(int32_t on);
 int gfv_set_f16split_thread(int32_t on);

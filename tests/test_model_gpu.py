@@ -442,9 +442,13 @@ def test_fp32_mfma_form_still_matches_oracle():
 LOWP_TOL = cases.LOWP_TOL
 
 
+# `gfv_set_f16split(3)`: the same single product on bf16 operands (v_mfma_f32_16x16x32_bf16; 8 significand bits) - stated
+# tolerances cases.BF16_TOL, ten times the fp16 form's.
+@pytest.mark.parametrize("form", [2, 3])
 @pytest.mark.parametrize("name", ["cavity_mixed_b1", "cyl_cavity_b2", "cyl_b3"])
-def test_reduced_precision_form_against_the_fp32_oracle(name):
+def test_reduced_precision_form_against_the_fp32_oracle(name, form):
     from gfv import lib as L
+    LOWP_TOL = cases.LOWP_TOL if form == 2 else cases.BF16_TOL
     graphs = cases.make_graphs(name)
     P = O.init_parameters(cases.WEIGHT_SEED)
     buffers = O.new_normalizer_buffers()
@@ -456,7 +460,7 @@ def test_reduced_precision_form_against_the_fp32_oracle(name):
     ograds = dict(zip(names, torch.autograd.grad(oloss, [Pg[k] for k in names], allow_unused=True)))
     lib = L.load()
     try:
-        lib.gfv_set_f16split(2)
+        lib.gfv_set_f16split(form)
         model = _hip_model(P)
         hg = tuple(g.clone().to("cuda") for g in graphs)
         hg[0].norm_uvp, hg[0].norm_global = True, True
@@ -481,7 +485,7 @@ def test_reduced_precision_form_against_the_fp32_oracle(name):
     meas["grad_norm"] = (num / den) ** 0.5
     assert meas["grad_norm"] < LOWP_TOL["grad_norm"], meas
     assert max(meas.values()) > 1e-6, "the reduced-precision switch did not reach the kernels"
-    print("reduced-precision form vs fp32 oracle,", name, {k: f"{v:.2e}" for k, v in meas.items()})
+    print("reduced-precision form", form, "vs fp32 oracle,", name, {k: f"{v:.2e}" for k, v in meas.items()})
 
 
 @pytest.mark.parametrize("case", ["cavity_mixed_b1", "cyl_cavity_b2", "poisson_b1", "cyl_b3"])
@@ -534,6 +538,6 @@ def test_product_form_reaches_the_autograd_worker_thread():
         t.start(); t.join()
         assert other["form"] == 1
         assert lib.gfv_set_f16split_thread(-1) == 0 and lib.gfv_f16split_enabled() == 1
-        assert lib.gfv_set_f16split_thread(3) != 0
+        assert lib.gfv_set_f16split_thread(4) != 0
     finally:
         lib.gfv_set_f16split(1)

@@ -249,7 +249,8 @@ def test_reduced_precision_form_tracks_the_fp32_forms():
     chain and weight-gradient kernels as ONE fp16 x fp16 product with fp32 accumulation (the high parts of the same
     operands, fp32 everywhere else).  It is not the form any parity claim is made on; this test pins what it is: after the
     same 4 training steps the loss agrees with the split-fp16 (fp32-accurate) form to 1e-2 relative and the parameters
-    to 2e-2 of the step they took - and it is NOT identical (the switch reaches the kernels)."""
+    to 2e-2 of the step they took - and it is NOT identical (the switch reaches the kernels).  `gfv_set_f16split(3)` is the
+    same single product on bf16 operands (v_mfma_f32_16x16x32_bf16)."""
     from FVMmodel.importer import NNmodel
     from gfv import lib as L
     from gfv.params import default_params
@@ -259,7 +260,7 @@ def test_reduced_precision_form_tracks_the_fp32_forms():
     lib = L.load()
     out = {}
     try:
-        for mode in (1, 2):
+        for mode in (1, 2, 3):
             lib.gfv_set_f16split(mode)
             model = NNmodel(default_params(dataset_size=1))
             sd = model.state_dict()
@@ -275,11 +276,15 @@ def test_reduced_precision_form_tracks_the_fp32_forms():
     finally:
         lib.gfv_set_f16split(1)
     p0 = torch.cat([P[k].reshape(-1) for k in ts.named_state().keys()]).cuda() if set(ts.named_state().keys()) <= set(P.keys()) else None
-    (l1, w1), (l2, w2) = out[1], out[2]
+    (l1, w1), (l2, w2), (l3, w3) = out[1], out[2], out[3]
     assert l1 != l2 or not torch.equal(w1, w2), "the reduced-precision switch did not reach the kernels"
     assert abs(l1 - l2) <= 1e-2 * abs(l1), (l1, l2)
     moved = (w1 - p0).norm() if p0 is not None else w1.norm() * 1e-3
     assert float((w1 - w2).norm()) <= 2e-2 * float(moved) + 1e-6 * float(w1.norm()), (float((w1 - w2).norm()), float(moved))
+    # the bf16 form (gfv_set_f16split(3), 8 significand bits): neither of the other two, and within 5e-2 / 1e-1 of them
+    assert not torch.equal(w3, w2) and not torch.equal(w3, w1)
+    assert abs(l1 - l3) <= 5e-2 * abs(l1), (l1, l3)
+    assert float((w1 - w3).norm()) <= 1e-1 * float(moved) + 1e-6 * float(w1.norm()), (float((w1 - w3).norm()), float(moved))
 
 
 def test_trainstep_state_dict_resume_equals_uninterrupted(tmp_path):
