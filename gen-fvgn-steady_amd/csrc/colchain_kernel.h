@@ -91,7 +91,11 @@ __device__ __forceinline__ void cc_mma_pair(const char* xbuf, int pair, const gf
 #endif
     // (FENCE: the scheduler may not hoist the next k-group's four fragment reads above this one's MFMAs - at a budget of 128
     // registers sixteen fragments in flight are 64 of them)
+#ifdef GFV_FENCE_MASK
+    if (FENCE) __builtin_amdgcn_sched_barrier(GFV_FENCE_MASK);
+#else
     if (FENCE) __builtin_amdgcn_sched_barrier(0);
+#endif
   }
 }
 
@@ -175,12 +179,64 @@ __device__ __forceinline__ void cb_tr_operand(const char* xbuf, int q0, int ct, 
   lo = __builtin_bit_cast(gfv_f16x8, l);
 }
 
-// one tile's contribution to a fused weight gradient: acc[kt] += G^T (n-tile w) x A (k-tile kt) over the tile's row pairs;
-// accb += G^T x ones (the bias gradient: every column of the result is the column sum of G)
+// one tile's contribution to a fused weight gradient: D += G^T x A over the tile's row pairs; accb += G^T x ones (the bias
+// gradient: every column of the result is the column sum of G).
+// A wave owns a 2 x 4 block of the 8 x 8 output tiles - n-tiles 2 (w >> 1) + {0, 1}, k-tiles 4 (w & 1) + {0 .. 3}; acc[4 nn + kk] -
+// and the bias gradient of n-tile 2 (w >> 1) + (w & 1).  (The first form gave a wave one n-tile and all eight k-tiles: 36
+// transposed LDS reads per row pair where this takes 24 - every wave read ALL of A - and the weight-gradient phases are
+// LDS-read time: DESIGN.md 5.)
+#ifndef GFV_DW24
+#define GFV_DW24 1
+#endif
+__device__ __forceinline__ int cb_dw_ntile(int w, int i) { return GFV_DW24 ? 2 * (w >> 1) + (i >> 2) : w; }
+__device__ __forceinline__ int cb_dw_ktile(int w, int i) { return GFV_DW24 ? 4 * (w & 1) + (i & 3) : i; }
+__device__ __forceinline__ int cb_dw_btile(int w) { return GFV_DW24 ? 2 * (w >> 1) + (w & 1) : w; }
 template <int LOWP>
 __device__ __forceinline__ void cb_dw_tile(const char* gbuf, const char* abuf, int npairs, int w, int lane, floatx4 (&acc)[8],
                                            floatx4& accb) {
   const gfv_f16x8 ones = gfv_frag_ones<LOWP == 2>();
+#if GFV_DW24
+  const int nt0 = 2 * (w >> 1), kt0 = 4 * (w & 1);
+  for (int pr = 0; pr < npairs; ++pr) {
+    gfv_f16x8 gh[2], gl[2];
+#if GFV_ABL & 2
+    gh[0] = gh[1] = gl[0] = gl[1] = ones; gh[0][0] = (_Float16)(float)pr;
+#else
+    cb_tr_operand(gbuf, 2 * pr, nt0, lane, gh[0], gl[0]);
+    cb_tr_operand(gbuf, 2 * pr, nt0 + 1, lane, gh[1], gl[1]);
+#endif
+#if !(GFV_ABL & 1)
+    {
+      const bool odd = (w & 1) != 0;   // (wave-uniform)
+      const gfv_f16x8 bh = odd ? gh[1] : gh[0], bl = odd ? gl[1] : gl[0];
+      if (!LOWP) accb = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl, ones, accb, 0, 0, 0);
+      accb = gfv_mma_hh<LOWP == 2>(bh, ones, accb);
+    }
+#endif
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      gfv_f16x8 ah, al;
+#if GFV_ABL & 2
+      ah = gh[0]; al = gl[0]; ah[1] = (_Float16)(float)kk;
+#else
+      cb_tr_operand(abuf, 2 * pr, kt0 + kk, lane, ah, al);
+#endif
+#pragma unroll
+      for (int nn = 0; nn < 2; ++nn) {
+#if GFV_ABL & 1
+        acc[4 * nn + kk] += __builtin_bit_cast(floatx4, ah) + __builtin_bit_cast(floatx4, al);
+#else
+        if (!LOWP) {
+          acc[4 * nn + kk] = __builtin_amdgcn_mfma_f32_16x16x32_f16(gl[nn], ah, acc[4 * nn + kk], 0, 0, 0);
+          acc[4 * nn + kk] = __builtin_amdgcn_mfma_f32_16x16x32_f16(gh[nn], al, acc[4 * nn + kk], 0, 0, 0);
+        }
+        acc[4 * nn + kk] = gfv_mma_hh<LOWP == 2>(gh[nn], ah, acc[4 * nn + kk]);
+#endif
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);   // (one row pair's operands in flight: the register budget)
+  }
+#else
   for (int pr = 0; pr < npairs; ++pr) {
     gfv_f16x8 gh, gl;
 #if GFV_ABL & 2
@@ -212,6 +268,7 @@ __device__ __forceinline__ void cb_dw_tile(const char* gbuf, const char* abuf, i
       if ((kt & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // (four k-tiles' operands in flight, not eight: the register budget)
     }
   }
+#endif
 }
 
 // chain-layer epilogue of one group in the backward form (GFV_OP_MUL_DGELU): v = acc / scales x gelu'(z) -> fragments with
@@ -470,6 +527,15 @@ __global__ __launch_bounds__(64 * CC_W, 2) void colchain_bwd_kernel(const gfv_ro
       cb_load_gathers<GADD>(B, c, gidx, in);
     }
   }
+  // The second wave of each SIMD (waves 4 .. 7) runs a chain phase as MMA(0) EPI(0) MMA(1) EPI(1) where the first runs
+  // MMA(0) MMA(1) EPI(0) EPI(1): its epilogue (vector arithmetic, stores) then falls beside the other wave's matrix instructions
+  // instead of both queueing for the matrix pipe and then for the vector unit.  Same operations per wave, bit-identical results;
+  // 42.1 k -> 40.3 k cycles per tile (most of it in P1, whose epilogue is stores).  -DGFV_SKEW_WAVES=0 builds the lockstep form.
+#if defined(GFV_SKEW_WAVES) && GFV_SKEW_WAVES == 0
+  constexpr bool CB_LATE = false;
+#else
+  const bool CB_LATE = c.w >= 4;
+#endif
   CT_DECL
   for (int t0 = g_beg; t0 < g_end; t0 += TG) {
     c.row0 = 16 * t0;
@@ -703,8 +769,8 @@ __global__ __launch_bounds__(64 * CC_W, 2) void colchain_bwd_kernel(const gfv_ro
       for (int p = 0; p < TG / 2; ++p) {
         if (p >= np) break;
         floatx4 n0 = a0, n1 = a1;
-        if (p + 1 < TG / 2) cc_mma_pair<4, LOWP, true>(b0, p + 1, wh, wl, c.lane, n0, n1);
         float v0[4], v1[4];
+        if (!CB_LATE && p + 1 < TG / 2) cc_mma_pair<4, LOWP, true>(b0, p + 1, wh, wl, c.lane, n0, n1);
         if constexpr (RC) {   // gelu'(z2) was parked in b1 by R2, a2 is in b2 already
           float d0[4], d1[4];
           cb_unpark4(b1, 2 * p, c, d0);
@@ -720,6 +786,7 @@ __global__ __launch_bounds__(64 * CC_W, 2) void colchain_bwd_kernel(const gfv_ro
           cb_st4(s0, offS[2 * p], v0);
           cb_st4(s0, offS[2 * p + 1], v1);
         }
+        if (CB_LATE && p + 1 < TG / 2) cc_mma_pair<4, LOWP, true>(b0, p + 1, wh, wl, c.lane, n0, n1);
         a0 = n0; a1 = n1;
       }
     }
@@ -765,8 +832,8 @@ __global__ __launch_bounds__(64 * CC_W, 2) void colchain_bwd_kernel(const gfv_ro
       for (int p = 0; p < TG / 2; ++p) {
         if (p >= np) break;
         floatx4 n0 = a0, n1 = a1;
-        if (p + 1 < TG / 2) cc_mma_pair<4, LOWP, true>(b1, p + 1, wh, wl, c.lane, n0, n1);
         float v0[4], v1[4];
+        if (!CB_LATE && p + 1 < TG / 2) cc_mma_pair<4, LOWP, true>(b1, p + 1, wh, wl, c.lane, n0, n1);
         if constexpr (RC) {   // a1 is in b3 since R1; only gelu'(z1) is needed here
           const float d0[4] = {gfv_dgelu(zq[2 * p].x), gfv_dgelu(zq[2 * p].y), gfv_dgelu(zq[2 * p].z), gfv_dgelu(zq[2 * p].w)};
           const float d1[4] = {gfv_dgelu(zq[2 * p + 1].x), gfv_dgelu(zq[2 * p + 1].y), gfv_dgelu(zq[2 * p + 1].z),
@@ -779,6 +846,7 @@ __global__ __launch_bounds__(64 * CC_W, 2) void colchain_bwd_kernel(const gfv_ro
         }
         cb_st4(B.save1, offS[2 * p], v0);
         cb_st4(B.save1, offS[2 * p + 1], v1);
+        if (CB_LATE && p + 1 < TG / 2) cc_mma_pair<4, LOWP, true>(b1, p + 1, wh, wl, c.lane, n0, n1);
         a0 = n0; a1 = n1;
       }
     }
@@ -807,12 +875,13 @@ __global__ __launch_bounds__(64 * CC_W, 2) void colchain_bwd_kernel(const gfv_ro
       for (int p = 0; p < TG / 2; ++p) {
         if (p >= np) break;
         floatx4 n0 = a0, n1 = a1;
-        if (p + 1 < TG / 2) cc_mma_pair<4, LOWP, true>(b0, p + 1, wh, wl, c.lane, n0, n1);
+        if (!CB_LATE && p + 1 < TG / 2) cc_mma_pair<4, LOWP, true>(b0, p + 1, wh, wl, c.lane, n0, n1);
         // (whole accumulator vectors: hipcc turns these into packed-fp32 instructions, two values each)
         const floatx4 o0 = (a0 * inv_in) * c.invw + floatx4{rr[2 * p].x, rr[2 * p].y, rr[2 * p].z, rr[2 * p].w};
         const floatx4 o1 = (a1 * inv_in) * c.invw + floatx4{rr[2 * p + 1].x, rr[2 * p + 1].y, rr[2 * p + 1].z, rr[2 * p + 1].w};
         cb_st4v(B.out, offS[2 * p], o0);
         cb_st4v(B.out, offS[2 * p + 1], o1);
+        if (CB_LATE && p + 1 < TG / 2) cc_mma_pair<4, LOWP, true>(b0, p + 1, wh, wl, c.lane, n0, n1);
         a0 = n0; a1 = n1;
       }
       if constexpr (OUT2) {
@@ -872,7 +941,7 @@ __global__ __launch_bounds__(64 * CC_W, 2) void colchain_bwd_kernel(const gfv_ro
     for (int kt = 0; kt < 8; ++kt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int n = 16 * c.w + 4 * c.g + r, k = 16 * kt + c.j;
+        const int n = 16 * cb_dw_ntile(c.w, kt) + 4 * c.g + r, k = 16 * cb_dw_ktile(c.w, kt) + c.j;
         blk[n * 128 + k] = dw3[kt][r] * u3;
         blk[16384 + 128 + n * 128 + k] = dw2[kt][r] * u2;
         if (DW1) blk[2 * 16384 + 512 + n * 128 + k] = dw1[kt][r] * u1;
@@ -880,9 +949,10 @@ __global__ __launch_bounds__(64 * CC_W, 2) void colchain_bwd_kernel(const gfv_ro
     if (c.j == 0) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        blk[16384 + 16 * c.w + 4 * c.g + r] = db3[r] * is;
-        blk[2 * 16384 + 128 + 16 * c.w + 4 * c.g + r] = db2[r] * (is * r2);
-        if (DW1) blk[3 * 16384 + 512 + 16 * c.w + 4 * c.g + r] = db1[r] * (is * r1);
+        const int nb = 16 * cb_dw_btile(c.w) + 4 * c.g + r;
+        blk[16384 + nb] = db3[r] * is;
+        blk[2 * 16384 + 128 + nb] = db2[r] * (is * r2);
+        if (DW1) blk[3 * 16384 + 512 + nb] = db1[r] * (is * r1);
       }
     }
     // (dgamma, dbeta): lane-private sums over the rows j and the groups this lane saw -> sum over the 16 lanes of a DPP row
