@@ -511,6 +511,87 @@ __global__ __launch_bounds__(256, 2) void dw_multi_h_kernel(const DwLaunch A) {
   else dw_body_h<false, BF>(A, T, lds);
 }
 
+// Weight gradient against a NARROW raw input (the encoders' first Linear: edge_attr [E,15], node inputs [N,12]; EPD.py:92-119) -
+// dW[n][k] = sum_m G[m][n] x[m][k], k < width <= 16, and db[n] = sum_m G[m][n] - as plain fp32 FMAs: the 128 x 128 MFMA tiles of
+// dw_multi_h_kernel spend a 128-wide tile's time (and a pass for the column scales) on 15 columns, 60 us for 75 k rows where the
+// rows are 38 MB; and these two launches END the backward on the main queue, with nothing beside them.
+// One slab of rows per workgroup (the slab partition of gfv_dw_slabs), 1024 threads: thread (n = column of G, part = 0 .. 7) walks
+// rows part, part + 8, ... of 256-row chunks whose input rows sit in LDS (broadcast reads) - its G values coalesced over n, eight
+// in flight -, the 8 parts are added pairwise through LDS (fixed order), one partial block per slab as dw_multi_h_kernel leaves it.
+__global__ __launch_bounds__(1024) void dw_narrow_kernel(const gfv_dw_tile_t T, int M, int rows_per_slab, float* __restrict__ ws,
+                                                         long ws_stride) {
+  __shared__ float red[4][128][17];
+  __shared__ __attribute__((aligned(16))) float xs[256][16];   // a chunk of the slab's input rows (zero beyond `width`)
+  const int tid = threadIdx.x, n = tid & 127, part = tid >> 7;
+  const int r0 = blockIdx.x * rows_per_slab, r1 = min(M, r0 + rows_per_slab);
+  const int width = T.width;
+  float acc[16], accb = 0.f;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) acc[k] = 0.f;
+  for (int c0 = r0; c0 < r1; c0 += 256) {
+    const int cn = min(256, r1 - c0);
+    {
+      const int rr = tid >> 2, k4 = (tid & 3) * 4;
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = (rr < cn && k4 + e < width) ? T.A[(size_t)(c0 + rr) * T.ld + k4 + e] : 0.f;
+      *reinterpret_cast<float4*>(&xs[rr][k4]) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+    __syncthreads();
+    // rows part, part + 8, ...: eight of this thread's G values in flight
+    for (int i0 = part; i0 < cn; i0 += 64) {
+      float g[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + 8 * u;
+        g[u] = i < cn ? T.G[(size_t)(c0 + i) * T.ldg + n] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = min(i0 + 8 * u, 255);     // (rows beyond cn carry g = 0)
+        const float4* xr = reinterpret_cast<const float4*>(&xs[i][0]);   // the same address in every lane: a broadcast read
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 x4 = xr[q];
+          acc[4 * q + 0] = __builtin_fmaf(g[u], x4.x, acc[4 * q + 0]);
+          acc[4 * q + 1] = __builtin_fmaf(g[u], x4.y, acc[4 * q + 1]);
+          acc[4 * q + 2] = __builtin_fmaf(g[u], x4.z, acc[4 * q + 2]);
+          acc[4 * q + 3] = __builtin_fmaf(g[u], x4.w, acc[4 * q + 3]);
+        }
+        accb += g[u];
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int s = 4; s >= 1; s >>= 1) {
+    if (part >= s && part < 2 * s) {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) red[part - s][n][k] = acc[k];
+      red[part - s][n][16] = accb;
+    }
+    __syncthreads();
+    if (part < s) {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) acc[k] += red[part][n][k];
+      accb += red[part][n][16];
+    }
+    __syncthreads();
+  }
+  if (part == 0) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) red[0][n][k] = acc[k];
+    red[0][n][16] = accb;
+  }
+  __syncthreads();
+  float* blk = ws + (size_t)blockIdx.x * ws_stride;
+  for (int i = tid; i < 128 * width; i += 1024) {
+    const int nn = i / width, k = i - nn * width;
+    blk[T.out_off + (long)nn * T.ld_out + k] = red[0][nn][k];
+  }
+  if (T.db_off >= 0 && tid < 128) blk[T.db_off + tid] = red[0][tid][16];
+}
+
 }  // namespace
 
 extern "C" int gfv_reduce_partials(const float*, int32_t, int32_t, float*, int32_t, void*);
@@ -574,6 +655,12 @@ extern "C" int gfv_dw_multi(const gfv_dw_tile_t* tiles, int32_t ntiles, int32_t 
   // slots of the block that no tile writes (alignment padding) keep whatever the workspace held: callers hand in a
   // zero-initialised workspace, so padding entries of the gradient block stay finite and are never read.
   void* tok = gfv_prof_begin(GFV_K_DW, fl, by + 8.0 * (double)slabs * block_floats, (hipStream_t)stream);
+  static const int narrow_on = getenv("GFV_DW_NARROW") ? atoi(getenv("GFV_DW_NARROW")) : 1;
+  const gfv_dw_tile_t& t0 = tiles[0];
+  if (narrow_on && ntiles == 1 && t0.width <= 16 && t0.n_out == 128 && !t0.idx && !t0.in_add && (t0.a_op & 7) == 0 && t0.ld >= t0.width) {
+    // a narrow raw input (the encoders' first Linear): plain fp32 FMAs whatever the product form (dw_narrow_kernel)
+    hipLaunchKernelGGL(dw_narrow_kernel, dim3(slabs), dim3(1024), 0, (hipStream_t)stream, t0, M, rows, workspace, (long)block_floats);
+  } else
   if (a.lowp == 2) hipLaunchKernelGGL(dw_multi_h_kernel<true>, dim3(slabs, ntiles), dim3(256), 0, (hipStream_t)stream, a);
   else if (gfv_f16split_enabled()) hipLaunchKernelGGL(dw_multi_h_kernel<false>, dim3(slabs, ntiles), dim3(256), 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL(dw_multi_kernel, dim3(slabs, ntiles), dim3(256), 0, (hipStream_t)stream, a);

@@ -146,6 +146,14 @@ class Engine:
         # profiles/r04_colchain_phases.txt: a fifth of the read traffic changes its time by 7 %), not by bytes.  Opt-in.
         self.recompute = os.environ.get("GFV_RECOMPUTE", "0") != "0"
         self._slice_fuse = os.environ.get("GFV_SLICE_FUSE", "1") != "0"   # Transolver adjoint: one pass behind the attention
+        # the end of the backward: how many of the trailing weight-gradient flushes run on the MAIN stream (GFV_TAIL_MAIN: 1 = the last
+        # encoder's, 2 = both encoders', 3 = the first GnBlock's too) and how the first GnBlock's flush is split between the streams
+        # (GFV_TAIL_SPLIT: 0 = not at all, 1 / 2 = its first / its other pieces on main).  Unset: by launch size - (3, 0) between
+        # 30 k and 300 k edge rows, (2, 1) outside.  Measured with the round-4 kernels (the encoders' narrow weight gradients now
+        # take 12 - 36 us instead of 27 - 66, which left the side queue as the tail): one 50 k-cell mesh 3.704 against 3.731 ms,
+        # the reference's 15 k-cell polygon mesh 3.239 against 3.280; 8 meshes 21.92 against 21.84 and the 5 k-cell cavity 2.022
+        # against 2.005 the other way round (latency-bound and bandwidth-bound ends) - interleaved on one box
+        self._tail_env = ("GFV_TAIL_MAIN" in os.environ) or ("GFV_TAIL_SPLIT" in os.environ)
         self._tail_main = int(os.environ.get("GFV_TAIL_MAIN", "2"))
         self._split_all = int(os.environ.get("GFV_SPLIT_ALL", "0"))     # (experiment) the same split for every GnBlock's flush
         self._tail_split = int(os.environ.get("GFV_TAIL_SPLIT", "1"))   # last GnBlock's flush: 1 / 2 = its first / its other pieces on main
@@ -211,6 +219,12 @@ class Engine:
             yield
         finally:
             L.check(lib.gfv_set_hidden_size(128), "gfv_set_hidden_size")
+
+    def _tail_cfg(self, pl):
+        """(GFV_TAIL_MAIN, GFV_TAIL_SPLIT) of this batch: the environment's, or by the number of edge rows (see __init__)."""
+        if self._tail_env:
+            return self._tail_main, self._tail_split
+        return (3, 0) if 30000 <= pl.E < 300000 else (2, 1)
 
     def defer(self, fn, *keep):
         """Parameter-gradient work (nothing downstream of the backward chain reads it): queued and launched on the side
@@ -794,7 +808,8 @@ class Engine:
         ops.seg_gather_sum(g_nb, pl.n_rowptr, pl.n_col_node, N, out=g_x_in, accumulate=True)
         # the block's weight gradients: one fork (the last block's may go to the main stream: GFV_TAIL_MAIN >= 3)
         last = self._defer_mode and getattr(self, "_last_gn", False)
-        self.flush(on_main=last and self._tail_main >= 3, split=self._tail_split if last else (self._split_all if self._defer_mode else 0))
+        tail_main, tail_split = self._tail_cfg(pl)
+        self.flush(on_main=last and tail_main >= 3, split=tail_split if last else (self._split_all if self._defer_mode else 0))
         return g_x_in, g_e_in
 
     # ------------------------------------------------------------------------------------------------------------
@@ -1165,7 +1180,7 @@ class Engine:
                 self.bucket_hook()
         # (the two encoders end the backward; running the big one - edge encoder, 75 k rows - first so that its weight
         # gradient overlaps the node encoder's chain was measured: 4.892 against 4.877 ms / step in this order)
-        tail = self._tail_main if self._defer_mode else 0   # how many of the trailing flushes run on the main stream
+        tail = self._tail_cfg(pl)[0] if self._defer_mode else 0   # how many of the trailing flushes run on the main stream
         if self._enc_order == 0:
             self.mlp3_bwd(P, sv["sv_nenc"], g_x, grads, g_add=pending)
             self.flush(on_main=tail >= 2)
