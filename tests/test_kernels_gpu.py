@@ -554,26 +554,3 @@ def test_chain_group_scales_feed_the_weight_gradient(dev, chain_mode):
         a, _ = ops.linear_dw(t, 128, [ops.Seg(A)], M, a_op=1)
         b, _ = ops.linear_dw(t, 128, [ops.Seg(A)], M, a_op=1, gscale=gs[slot])
         assert torch.equal(a, b), slot
-
-
-@pytest.mark.parametrize("M", [75499, 2300, 257, 5])
-def test_narrow_input_weight_gradient_kernel(dev, chain_mode, M):
-    """The encoders' first Linear (EPD.py:92-119: edge_attr [E,15] / node inputs [N,12]): the weight gradient against an input of
-    <= 16 columns runs as plain fp32 FMAs (csrc/dw.hip dw_narrow_kernel, round 4) whatever the product form - widths 15 / 12 / 16
-    / 1, row strides 16 / 12 / 16 / 4, row counts that leave slabs ragged or empty; every element against its own sum |g x| at
-    fp32 accumulation accuracy, the bias gradient too."""
-    if chain_mode != "f32":
-        pytest.skip("one pass is enough")
-    from gfv import ops
-    g = torch.Generator().manual_seed(M)
-    d = lambda t: t.to(dev).contiguous()
-    G = torch.randn(M, 128, generator=g) * torch.logspace(-4, 0, M)[:, None]
-    for width, ld in ((15, 16), (12, 12), (16, 16), (1, 4)):
-        x = torch.randn(M, ld, generator=g) * torch.tensor([1.0] * max(width - 3, 1) + [1e-4] * (ld - max(width - 3, 1)))[:ld]
-        dW, db = ops.linear_dw(d(G), 128, [ops.Seg(d(x), width=width, ld=ld)], M, col_scale=True)
-        assert dW.shape == (128, width)
-        ref = G.double().T @ x[:, :width].double()
-        mag = G.double().abs().T @ x[:, :width].double().abs()
-        e = float(((dW.double().cpu() - ref).abs() / (mag + 1e-300)).max())
-        assert e < 2e-6, (width, ld, e)
-        assert rel(db, G.double().sum(0)) < 2e-6, (width, ld)
