@@ -12,6 +12,15 @@ for p in (ROOT, PKG, os.path.join(ROOT, "tests", "golden")):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the CPU oracle inside the tests is launch-bound eager PyTorch: on the GPU box's 256-thread host it is fastest at 16
+    # intra-op threads (bench.py cpu_baseline: 4.3 / 3.5 / 3.6 / 5.2 / 188 s per 50 k-cell step at 8 / 16 / 32 / 64 / 256) and
+    # 2 - 3 x slower at torch's default there; GFV_TEST_THREADS overrides
+    try:
+        import torch
+        n = int(os.environ.get("GFV_TEST_THREADS", "0")) or min(16, os.cpu_count() or 1)
+        torch.set_num_threads(n)
+    except Exception:
+        pass
 
 
 @pytest.fixture(scope="session")
