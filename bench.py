@@ -160,6 +160,26 @@ def cpu_baseline(graphs_cpu, budget_s, max_steps=6, min_steps=1):
     return float(np.median(times)), len(times)
 
 
+def self_launch_command(gpus, argv, port=None):
+    """The command `python bench.py --gpus N ...` runs when it is started WITHOUT a launcher: the driver's own multi-GPU line
+    (one rank per GPU over RCCL, rendezvous on 127.0.0.1), with this invocation's arguments passed through unchanged."""
+    if port is None:
+        port = int(os.environ.get("MASTER_PORT", "0")) or (29500 + os.getpid() % 2000)
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={int(gpus)}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *argv]
+
+
+def self_launch(gpus, argv):
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs on this driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    env.pop("GFV_BENCH_SELF_LAUNCH", None)
+    cmd = self_launch_command(gpus, argv)
+    print("bench.py: no launcher in the environment, starting " + " ".join(cmd[1:7]) + " ...", file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)   # stdout is inherited: rank 0's JSON line is this process's line
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -189,11 +209,15 @@ def main():
                     help="self-test only: let several ranks share one GPU (the JSON then says so in distinct_gpus)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or os.environ.get("GFV_BENCH_SELF_LAUNCH") == "1"):
+        # `python bench.py --gpus N` by itself: start the N ranks as a CHILD process group (nothing in this process has touched
+        # the GPU yet - importing torch does not - and it never will: no exec, the child's exit code is ours)
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("launch with torch.distributed.run for --gpus > 1 (one process per GPU)")
+    if args.gpus > 1 and args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} under WORLD_SIZE={world}: the launcher's rank count and --gpus must agree")
     ndev = torch.cuda.device_count()   # (counting devices does not initialise the GPU)
     if ndev < 1:
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
@@ -244,6 +268,7 @@ def main():
 
     inner = args.inner_steps if args.inner_steps > 0 else (20 if args.workload == "poly" else 0)
     since_advance = [0]
+    own_times = []   # this rank's own wall time of every timed() loop
 
     def timed(n):
         barrier()
@@ -257,6 +282,7 @@ def main():
                     since_advance[0] = 0
         barrier()
         el = time.perf_counter() - tc
+        own_times.append(el)
         if dist_on:
             t = torch.tensor([el], dtype=torch.float64, device=device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -291,6 +317,7 @@ def main():
         ts.step()
 
     reps, elapsed = [], 0.0
+    own_times.clear()
     while True:
         el = timed(args.steps)           # EXACTLY K steps between barrier + synchronize on both sides
         reps.append(el)
@@ -300,6 +327,29 @@ def main():
     timed_steps = args.steps * len(reps)
     ms_per_step = 1e3 * elapsed / timed_steps
     final_loss = float(ts.loss.item())
+    # every rank's own clock over the same timed loops (the line's ms_per_step is the MAX over ranks, loop by loop)
+    rank_ms = [1e3 * sum(own_times) / timed_steps]
+    if dist_on:
+        t = torch.zeros(world, dtype=torch.float64, device=device)
+        t[rank] = rank_ms[0]
+        dist.all_reduce(t)
+        rank_ms = [float(v) for v in t.tolist()]
+    # what the gradient exchange costs the step: the same step, same launch mode, with the collectives taken out (every rank
+    # then steps on its own gradient: a timing leg, so the replicas' state is put back afterwards)
+    exposed_us = None
+    if dist_on:
+        snap = [b.clone() for b in (ts.flat_p, ts.flat_m, ts.flat_v, ts.adam_state)]
+        ts.dist_on = ts.engine.dist_force = False
+        for _ in range(6):
+            ts.step()
+        local_ms = 1e3 * timed(cal_steps) / cal_steps
+        ts.dist_on = ts.engine.dist_force = True
+        for dst, src in zip((ts.flat_p, ts.flat_m, ts.flat_v, ts.adam_state), snap):
+            dst.copy_(src)
+        for _ in range(4):
+            ts.step()
+        with_ms = 1e3 * timed(cal_steps) / cal_steps
+        exposed_us = round(1e3 * (with_ms - local_ms), 1)
 
     # ---- roofline leg: same step, eager, HIP events around every launch --------------------------------------------
     # every rank runs the instrumented steps (they contain the gradient all-reduce); rank 0 reports.  The timed region
@@ -553,6 +603,9 @@ def main():
                        "hip_graph": ts.use_graph is True, "launch_mode": used, "final_loss": round(final_loss, 6)},
             "rccl_ranks": (dist.get_world_size() if dist_on else 0), "dist_backend": (dist.get_backend() if dist_on else None),
             "distinct_gpus": min(world, ndev),
+            "rank_ms_per_step": {"min": round(min(rank_ms), 4), "max": round(max(rank_ms), 4),
+                                 "note": "each rank's own clock over the timed loops; ms_per_step is the max over ranks per loop"},
+            "allreduce_exposed_us": exposed_us,   # step with the gradient exchange minus the same step without it (same run, same mode)
             "roofline": ({k: roof[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")}
                          | {"kernel": roof["kernel"], "traffic_source": traffic_source,
                             "frac_isolated": roof["frac_isolated"], "frac_in_step": roof.get("frac_in_step"),

@@ -484,10 +484,14 @@ __global__ __launch_bounds__(512, 2) void lin1_csr_kernel(const Lin1CsrArgs A, i
       }
       const float* p0 = A.src[s] + (size_t)c0 * (size_t)A.src_ld[s] + 4 * g;
       const float* p1 = A.src[s] + (size_t)c1 * (size_t)A.src_ld[s] + 4 * g;
+      // (a finished or empty segment issues no loads: its source table may have no rows at all)
+      if (one[s]) {
 #pragma unroll
-      for (int t = 0; t < 8; ++t) {
-        a0[s][t] = *reinterpret_cast<const float4*>(p0 + 16 * t);   // (a finished segment re-reads its last rows: L1 hits, not added)
-        a1[s][t] = *reinterpret_cast<const float4*>(p1 + 16 * t);
+        for (int t = 0; t < 8; ++t) a0[s][t] = *reinterpret_cast<const float4*>(p0 + 16 * t);
+      }
+      if (two[s]) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) a1[s][t] = *reinterpret_cast<const float4*>(p1 + 16 * t);
       }
     }
 #pragma unroll

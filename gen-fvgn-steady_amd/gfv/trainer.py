@@ -284,8 +284,10 @@ class TrainStep:
 
     def _allreduce_upper(self):
         import torch.distributed as dist
-        # (the blocking form: under `torch.cuda.stream(comm)` it is the communication STREAM that waits for the collective - the
-        # host does not under RCCL - and nothing has to be kept alive for a replay)
+        # (the blocking form: under `torch.cuda.stream(comm)` it is the communication STREAM that waits for the collective and
+        # nothing has to be kept alive for a replay.  The overlap with the rest of the backward is an RCCL property: under gloo,
+        # or with TORCH_NCCL_BLOCKING_WAIT set, the HOST waits here and the early bucket is merely correct, not overlapped -
+        # the gloo tests assert numerics only)
         dist.all_reduce(self.flat_g[self._split:], op=dist.ReduceOp.SUM, group=self.pg)
 
     def _bucket_ready(self):

@@ -62,8 +62,17 @@ int gfv_gather_pair(const float* a, const int32_t* s, const int32_t* r, const fl
  * prologues and bias / GELU / LayerNorm / residual epilogues; forward and the dX chain of the backward are the same entry
  * with different element ops.  One entry point, several kernel families behind it (gfv_rowtile_last_path tells which):
  * the register-resident row-owner chain (a wave owns 16 rows; split-fp16 products from per-step weight images, or fp32
- * MFMA), the column-owner persistent backward with fused weight gradients (dw_partial), the lean kernel for single-layer
- * launches, and - for shapes none of them takes - a generic kernel whose 64-row tile stays in LDS (fp32 MFMA).
+ * MFMA), the column-owner persistent backward with fused weight gradients (dw_partial) and the lean kernel for single-layer
+ * launches.  ACCEPTED SHAPES (anything else returns GFV_ERR_ARG and launches nothing - the generic LDS kernel that used to take
+ * the rest was retired with ABI 2; tests/test_kernels_gpu.py holds the negative test):
+ *   plain:   every segment width a multiple of 32 and every row stride (seg ld, out_ld, res_ld) a multiple of 4; K and ldw of
+ *            every layer multiples of 4; inner layers 128 wide, the last layer a multiple of 64 (exactly 128 with a LayerNorm
+ *            epilogue).  Only this class takes LayerNorm backward (GFV_IN_LNBWD / GFV_FIN_LNBWD), segmented-sum segments
+ *            (csr_rowptr) and per-segment saves.
+ *   ragged:  any segment width / row stride, any first-layer K, a last layer of any width <= 128 (or a multiple of 64 above);
+ *            inner layers 128 wide with K = 128; NO LayerNorm backward; a last layer that is not a multiple of 16 wide takes
+ *            neither GFV_OP_MUL_DGELU nor a LayerNorm epilogue nor out_nores; GFV_IN_LN and gadd need a 128-wide seg[0] with a
+ *            row stride that is a multiple of 4.
  * Replaces nn.Linear/GELU/LayerNorm inside build_mlp (FVMmodel/Models/FVGN/EPD.py:10-63), the concat + MLP of
  * EdgeBlock/NodeBlock (blocks.py:54,101-111) and the Linear layers of the Transolver block
  * (FVMmodel/Models/GraphTransolver/GraphTransolver.py:54-59,95,98-128,163-169).
@@ -194,8 +203,8 @@ int gfv_rowtile_fuses_dw(const gfv_rowtile_args_t* args);       /* 1: gfv_rowtil
 
 int gfv_rowtile_tiles(int32_t M); /* number of 64-row tiles = rows of ln_partial */
 int gfv_rowtile_chain(const gfv_rowtile_args_t* args, void* stream);
-/* which kernel the calling thread's last gfv_rowtile_chain launch took: 0 generic LDS row-tile, 1 register-resident
- * chain, 2 its ragged-shape instantiation; + 4 when the products ran as split-fp16; + 8 when the column-owner persistent
+/* which kernel the calling thread's last gfv_rowtile_chain launch took: 1 register-resident chain, 2 its ragged-shape
+ * instantiation (0 was the generic LDS row-tile kernel, retired with ABI 2); + 4 when the products ran as split-fp16; + 8 when the column-owner persistent
  * family took the launch, + 16 when it ran with fused weight gradients, + 32 when a single-layer launch ran on the lean
  * one-Linear kernel (csrc/lin1.hip: the layer's image staged in LDS once per 128-row workgroup; same products, same
  * results to rounding) (tests assert the path they mean) */

@@ -1,11 +1,11 @@
 #!/bin/bash
 # One step's device timeline from rocprofv3 --kernel-trace (command-list replay): per hardware queue busy time, gaps, and the
-# longest kernels;  gpurun -- 'bash profiles/tools/timeline.sh'
+# longest kernels;  gpurun -- '[ABFLAGS="--workload cavity --cells 5041"] [TL_TAG=timeline_cavity] bash profiles/tools/timeline.sh'
 R=${GRAFT_REPO_ROOT:-/root/repo}
-O=$R/gpurun_out/timeline
+O=$R/gpurun_out/${TL_TAG:-timeline}
 rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --output-format csv -d $O/prof -- python3 $R/bench.py --cpu-budget 0 --min-time 0.3 --graph list --skip-fp32-form --profile-steps 1 > $O/bench.json 2> $O/err.txt
+timeout 600 rocprofv3 --kernel-trace --output-format csv -d $O/prof -- python3 $R/bench.py --cpu-budget 0 --min-time 0.3 --graph list --skip-fp32-form --profile-steps 0 --skip-copy-rate $ABFLAGS > $O/bench.json 2> $O/err.txt
 f=$(find $O/prof -name "*kernel_trace.csv" | head -1)
 python3 - "$f" <<'PY'
 import csv,sys,collections

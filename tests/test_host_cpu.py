@@ -223,3 +223,40 @@ def test_bench_polygon_workload_builds_on_the_host():
     graphs, sz = bench.build_workload("poly", 0, 1, 0, "cpu")
     assert (sz["C"], sz["N"], sz["E"]) == (17436, 27778, 45214) and sz["B"] == 1
     assert graphs[0].x.shape == (27778, 12)
+
+
+def test_bench_starts_its_own_ranks_when_called_without_a_launcher(monkeypatch):
+    """`python bench.py --gpus N` with no WORLD_SIZE in the environment (how the 1-GPU driver line reads with N > 1): the parent
+    touches no GPU, starts `torch.distributed.run --nproc-per-node N bench.py <same arguments>` as a child process and exits with
+    the child's code.  Checked here: the command it builds, that the arguments pass through, that the child is a child (no
+    exec), and that a rank started by a launcher does not start ranks again."""
+    import importlib
+    import subprocess
+    import sys
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    cmd = bench.self_launch_command(4, ["--gpus", "4", "--steps", "7", "--warmup", "2"], port=29611)
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29611"
+    k = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[k + 1:] == ["--gpus", "4", "--steps", "7", "--warmup", "2"]
+    seen = {}
+
+    def fake_call(c, env=None):
+        seen["cmd"], seen["env"] = c, env
+        return 7
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2", "--steps", "3"])
+    with pytest.raises(SystemExit) as ex:
+        bench.main()
+    assert ex.value.code == 7                                      # the child's exit code is the parent's
+    assert "--nproc-per-node=2" in seen["cmd"] and seen["cmd"][-4:] == ["--gpus", "2", "--steps", "3"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    # under a launcher (WORLD_SIZE set) the same invocation goes on as a rank: here it stops at the GPU check, not at a spawn
+    seen.clear()
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    with pytest.raises(SystemExit) as ex:
+        bench.main()
+    assert not seen and "MI355X" in str(ex.value.code)

@@ -554,3 +554,30 @@ def test_chain_group_scales_feed_the_weight_gradient(dev, chain_mode):
         a, _ = ops.linear_dw(t, 128, [ops.Seg(A)], M, a_op=1)
         b, _ = ops.linear_dw(t, 128, [ops.Seg(A)], M, a_op=1, gscale=gs[slot])
         assert torch.equal(a, b), slot
+
+
+def test_rowtile_unsupported_shape_is_an_error_and_launches_nothing(dev, chain_mode):
+    """A shape no kernel family takes (include/gfv.h, "ACCEPTED SHAPES": the generic LDS kernel that used to take the rest was
+    retired with ABI 2) returns GFV_ERR_ARG and leaves the output untouched: a LayerNorm-backward epilogue with an output row
+    stride that is not a multiple of 4, and a GELU' epilogue on a ragged last layer."""
+    from gfv import lib as L, ops
+    from gfv.ops import LayerSpec, Seg
+    if chain_mode != "f32":
+        pytest.skip("one pass is enough")
+    M = 256
+    g = torch.Generator(device="cpu").manual_seed(3)
+    x = torch.randn(M, 128, generator=g).to(dev)
+    W = (0.05 * torch.randn(128, 128, generator=g)).to(dev)
+    y = torch.randn(M, 128, generator=g).to(dev)
+    gamma = torch.ones(128, device=dev)
+    out = torch.full((M, 130), 7.0, device=dev)
+    part = torch.zeros(ops.rowtile_tiles(M), 2, 128, device=dev)
+    with pytest.raises(RuntimeError, match="gfv_rowtile_chain"):
+        ops.rowtile_chain(M, [Seg(x)], [LayerSpec(W)], [(out, 130)], fin_op=L.FIN_LNBWD, fin_gamma=gamma, fin_aux=y, ln_partial=part)
+    W2 = (0.05 * torch.randn(40, 128, generator=g)).to(dev)
+    z = torch.randn(M, 40, generator=g).to(dev)
+    out2 = torch.full((M, 40), 7.0, device=dev)
+    with pytest.raises(RuntimeError, match="gfv_rowtile_chain"):
+        ops.rowtile_chain(M, [Seg(x)], [LayerSpec(W2, None, L.OP_MUL_DGELU, aux=z)], [out2])
+    torch.cuda.synchronize()
+    assert bool((out == 7.0).all()) and bool((out2 == 7.0).all()) and bool((part == 0).all())
