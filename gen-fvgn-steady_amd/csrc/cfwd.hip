@@ -1,0 +1,385 @@
+// gfv-build-flags: -fno-slp-vectorize
+// Column-owner SMALL-TILE forward of the 3-layer MLPs (round 5): the kernel family behind gfv_rowtile_chain (contract:
+// include/gfv.h) for the forward of build_mlp (EPD.py:10-33: Linear GELU Linear GELU Linear LayerNorm) inside the NodeBlock /
+// EdgeBlock (blocks.py:54,101-111) and the two encoders (EPD.py:92-119) when the launch is SHORT - a node-level launch of any
+// mesh, every launch of a small mesh - in the split-fp16 product forms.
+//
+// Why: profiles/r05_latency_floor_before.txt.  The row-owner chain (tchain_kernel.h: a wave owns 16 rows and ALL 128 columns,
+// the three layers' weights stream through LDS in twelve barrier-separated slices) takes 20 - 27 us for ONE 64-row tile however
+// few tiles the launch has: a node-level launch of the 50 k-cell mesh (400 tiles on 256 CUs) takes 35 us, the same launch on a
+// 5 k-cell mesh 25 us, on a 1 k-cell mesh 23 us.  One wave walks 288 MFMAs and ~2 400 vector instructions per tile behind
+// twelve barriers; the launch's time is that serial walk, not bandwidth.  Here the walk is cut four ways instead:
+//   * a workgroup = 4 waves = ONE tile of TG groups of 16 rows (TG = 2: 32 rows; 4: 64 rows); wave w owns output COLUMNS
+//     32 w .. 32 w + 31 (two n-tiles) of every layer: a quarter of the MFMAs and of the epilogue arithmetic per wave and tile row;
+//   * its slice of a layer's weight image - the A operands W[32 w + i][k], (hi, lo) parts, 16 registers per k-group - comes
+//     straight from L2 into registers, one layer ahead of its use: no weight staging, no slice barriers;
+//   * activations cross waves between layers as MFMA B fragments in LDS ([group][k-group][part][lane] x 16 B; the 32 columns a
+//     wave produces are exactly ONE k-group of the next layer: a 16-byte write per lane and part), one barrier per layer;
+//   * LayerNorm over the four waves' partial (mean, M2) pairs (Chan's combination: two-pass accuracy, one exchange).
+// 4 barriers per tile instead of 13; per wave 48 TG / 2 MFMAs per 128-deep layer.  Hidden activations are split behind the fixed
+// scale CF_SH (colchain_kernel.h CC_SH: GELU outputs in [2^-4, 2^11] keep fp32 accuracy; beyond 2^11 GFV_FLAG_CHAIN_RANGE is
+// raised), the layer INPUT rows behind their own power-of-two row scale as everywhere else.
+// Price: every tile pulls the three images (160 - 224 KB) from L2 - 32-row tiles only where the launch is small (TG = 2 up to
+// GFV_CFWD_TG2_MAX_M rows), 64-row tiles above, and nothing above GFV_CFWD_MAX_M rows (the 75 k-row edge launches of the
+// headline mesh stay with the row-owner chain: there the tiles' latencies overlap and the weight stream is shared by 64 rows).
+#include <cstdlib>
+
+#include "tchain_kernel.h"
+
+int* gfv_internal_status_ptr();
+
+namespace {
+
+constexpr float CF_SH = 16.0f;
+constexpr float CF_SH_INV = 1.0f / 16.0f;
+constexpr float CF_SH_LIMIT = 2048.0f;
+
+__device__ __forceinline__ void cf_barrier() {
+  // LDS only: global loads (next layer's weights, the residual rows) and stores stay in flight across it
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+template <int KT0, int TG>
+struct CfLds {
+  static constexpr int KTB = KT0 > 4 ? KT0 : 4;
+  static constexpr int B0 = 0;                          // the input fragments; later the third layer's input
+  static constexpr int B1 = TG * KTB * 2048;            // the second layer's input
+  static constexpr int SINV = B1 + TG * 8192;           // float [TG * 16]: 1 / row scale of the input rows
+  static constexpr int LNP = SINV + TG * 64;            // float2 [TG * 16][4]: per-wave (mean, M2) of a row
+  static constexpr int TOTAL = LNP + TG * 16 * 4 * 8;
+};
+
+// KT0: k-groups of the first layer (K / 32, zero padded); N0: 16-column pieces of segment 0 (the rest from segment 1);
+// PADD: gathered first-layer addend (factored EdgeBlock); LOWP: 0 three products, 1 / 2 the single-product forms (fp16 / bf16);
+// RAGIN: ONE narrow segment (width <= 32, any row stride: the encoders' raw inputs), loaded element by element
+template <int KT0, int N0, int TG, bool PADD, int LOWP, bool RAGIN>
+__global__ __launch_bounds__(256, 2) void cfwd_kernel(const gfv_rowtile_args_t A, int* status) {
+  static_assert(TG == 2 || TG == 4, "one loader wave per group");
+  using LY = CfLds<KT0, TG>;
+  constexpr bool BF = LOWP == 2;
+  __shared__ __attribute__((aligned(16))) char lds[LY::TOTAL];
+  char* b0 = lds + LY::B0;
+  char* b1 = lds + LY::B1;
+  float* sinv = reinterpret_cast<float*>(lds + LY::SINV);
+  float* lnp = reinterpret_cast<float*>(lds + LY::LNP);
+
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
+  const int tile = PADD ? gfv_xcd_tile(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+  const int row0 = tile * (16 * TG);
+  if (row0 >= A.M) return;
+  const int ngt = min(TG, (A.M - row0 + 15) >> 4);   // live groups of this tile
+  const int c0 = 32 * w + 4 * g;                     // this lane's columns: c0 .. c0 + 3 (n-tile 2 w) and c0 + 16 .. + 19
+  const float invw = 1.0f / gfv_pow2_scale(*A.wmax);
+
+  // ---- first layer's weight slice: in flight beside the row loads ----
+  gfv_f16x8 wh[2][KT0 > 4 ? KT0 : 4], wl[2][KT0 > 4 ? KT0 : 4];
+  {
+    const gfv_f16x8* im = reinterpret_cast<const gfv_f16x8*>(A.layer[0].Wh) + (size_t)(2 * w) * 128 + lane;
+#pragma unroll
+    for (int T = 0; T < KT0; ++T)
+#pragma unroll
+      for (int n = 0; n < 2; ++n) {
+        wh[n][T] = im[T * 1024 + n * 128];
+        if (!LOWP) wl[n][T] = im[T * 1024 + n * 128 + 64];
+      }
+  }
+  // gathered addend rows of the first pre-activation: index, then row - two round trips, started now
+  float4 ps[PADD ? TG : 1][2], pr[PADD ? TG : 1][2];
+  if (PADD) {
+#pragma unroll
+    for (int q = 0; q < TG; ++q) {
+      const int row = min(row0 + 16 * q + j, A.M - 1);
+      const float* s = A.padd + (size_t)A.padd_s[row] * A.padd_ld + c0;
+      const float* r = A.padd + (size_t)A.padd_r[row] * A.padd_ld + 128 + c0;
+      ps[q][0] = ld4(s); ps[q][1] = ld4(s + 16);
+      pr[q][0] = ld4(r); pr[q][1] = ld4(r + 16);
+    }
+  }
+  // ---- input rows -> row scale -> fragments (wave q loads group q) ----
+  if (w < TG) {
+    const int row = min(row0 + 16 * w + j, A.M - 1);
+    float v[2 * KT0][4];
+    if (RAGIN) {
+      const int width = A.seg[0].width;
+      const float* rp = A.seg[0].ptr + (size_t)row * A.seg[0].ld;
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int col = 16 * u + 4 * g + e;
+          v[u][e] = col < width ? rp[col] : 0.f;
+        }
+    } else {
+      const float* p0 = A.seg[0].ptr + (size_t)row * A.seg[0].ld + 4 * g;
+      const float* p1 = p0;
+      if (N0 < 2 * KT0) p1 = A.seg[1].ptr + (size_t)row * A.seg[1].ld + 4 * g;
+#pragma unroll
+      for (int u = 0; u < 2 * KT0; ++u) {
+        const float4 t = ld4(u < N0 ? p0 + 16 * u : p1 + 16 * (u - N0));
+        v[u][0] = t.x; v[u][1] = t.y; v[u][2] = t.z; v[u][3] = t.w;
+      }
+    }
+    float m0 = 0.f, m1 = 0.f;
+#pragma unroll
+    for (int u = 0; u < 2 * KT0; ++u) {
+      m0 = max3_abs(m0, v[u][0], v[u][1]);
+      m1 = max3_abs(m1, v[u][2], v[u][3]);
+    }
+    const float s = gfv_pow2_scale(row_max4(max3_abs(0.f, m0, m1)));
+    if (g == 0) sinv[w * 16 + j] = 1.0f / s;
+    gfv_uint4* dst = reinterpret_cast<gfv_uint4*>(b0 + (size_t)w * KT0 * 2048) + lane;
+#pragma unroll
+    for (int T = 0; T < KT0; ++T) {
+      float e[8];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { e[r] = v[2 * T][r] * s; e[4 + r] = v[2 * T + 1][r] * s; }
+      gfv_uint4 hi, lo;
+      gfv_split8_t<BF>(e, hi, lo);
+      dst[(2 * T) * 64] = hi;
+      if (!LOWP) dst[(2 * T + 1) * 64] = lo;
+    }
+  }
+  // this wave's bias columns of the three layers, LayerNorm affine
+  float4 bias[3][2];
+#pragma unroll
+  for (int l = 0; l < 3; ++l) {
+    const float* bp = A.layer[l].bias;
+#pragma unroll
+    for (int n = 0; n < 2; ++n) bias[l][n] = bp ? ld4(bp + c0 + 16 * n) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  float mabs = 0.f;
+  cf_barrier();
+
+  floatx4 acc[TG][2];
+  // one layer's products: acc[q][n] = sum_T W[n-tile 2 w + n][T] x frag[q][T]
+  auto mma = [&](const char* xbuf, auto ktc) {
+    constexpr int KT = decltype(ktc)::value;
+#pragma unroll
+    for (int q = 0; q < TG; ++q)
+#pragma unroll
+      for (int n = 0; n < 2; ++n) acc[q][n] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int T = 0; T < KT; ++T) {
+#pragma unroll
+      for (int q = 0; q < TG; ++q) {
+        const gfv_f16x8* f = reinterpret_cast<const gfv_f16x8*>(xbuf + (size_t)(q * KT + T) * 2048) + lane;
+        const gfv_f16x8 xh = f[0];
+        if (!LOWP) {
+          const gfv_f16x8 xl = f[64];
+#pragma unroll
+          for (int n = 0; n < 2; ++n) {
+            acc[q][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[n][T], xh, acc[q][n], 0, 0, 0);
+            acc[q][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[n][T], xl, acc[q][n], 0, 0, 0);
+          }
+        }
+#pragma unroll
+        for (int n = 0; n < 2; ++n) acc[q][n] = gfv_mma_hh<BF>(wh[n][T], xh, acc[q][n]);
+      }
+    }
+  };
+  auto load_w = [&](const void* image) {   // a 128-deep layer's slice
+    const gfv_f16x8* im = reinterpret_cast<const gfv_f16x8*>(image) + (size_t)(2 * w) * 128 + lane;
+#pragma unroll
+    for (int T = 0; T < 4; ++T)
+#pragma unroll
+      for (int n = 0; n < 2; ++n) {
+        wh[n][T] = im[T * 1024 + n * 128];
+        if (!LOWP) wl[n][T] = im[T * 1024 + n * 128 + 64];
+      }
+  };
+  // hidden-layer epilogue: v = acc / scales + bias (+ addend) -> saved; gelu(v) -> the next layer's fragments (k-group w)
+  auto hidden = [&](int layer, char* xout, float* save) {
+#pragma unroll
+    for (int q = 0; q < TG; ++q) {
+      const int row = row0 + 16 * q + j;
+      const bool live = q < ngt && row < A.M;
+      const float si = layer == 0 ? sinv[q * 16 + j] : CF_SH_INV;
+      float a[8];
+#pragma unroll
+      for (int n = 0; n < 2; ++n) {
+        const float4 b = bias[layer][n];
+        float v[4] = {(acc[q][n][0] * si) * invw + b.x, (acc[q][n][1] * si) * invw + b.y, (acc[q][n][2] * si) * invw + b.z,
+                      (acc[q][n][3] * si) * invw + b.w};
+        if (PADD && layer == 0) {
+          v[0] += ps[PADD ? q : 0][n].x + pr[PADD ? q : 0][n].x; v[1] += ps[PADD ? q : 0][n].y + pr[PADD ? q : 0][n].y;
+          v[2] += ps[PADD ? q : 0][n].z + pr[PADD ? q : 0][n].z; v[3] += ps[PADD ? q : 0][n].w + pr[PADD ? q : 0][n].w;
+        }
+        if (save && live) st4(save + (size_t)row * 128 + c0 + 16 * n, v);
+        const gfv_f2 g01 = gfv_gelu2(gfv_f2{v[0], v[1]}), g23 = gfv_gelu2(gfv_f2{v[2], v[3]});
+        a[4 * n + 0] = g01.x; a[4 * n + 1] = g01.y; a[4 * n + 2] = g23.x; a[4 * n + 3] = g23.y;
+      }
+      float m = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; e += 2) m = max3_abs(m, a[e], a[e + 1]);
+      mabs = fmaxf(mabs, live ? m : 0.f);
+      float e8[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) e8[e] = a[e] * CF_SH;
+      gfv_uint4 hi, lo;
+      gfv_split8_t<BF>(e8, hi, lo);
+      gfv_uint4* dst = reinterpret_cast<gfv_uint4*>(xout + (size_t)(q * 4 + w) * 2048) + lane;
+      dst[0] = hi;
+      if (!LOWP) dst[64] = lo;
+    }
+  };
+
+  // ---- layer 0: b0 -> b1 ----
+  mma(b0, std::integral_constant<int, KT0>{});
+  load_w(A.layer[1].Wh);
+  hidden(0, b1, A.layer[0].save);
+  cf_barrier();
+  // ---- layer 1: b1 -> b0 ----
+  mma(b1, std::integral_constant<int, 4>{});
+  load_w(A.layer[2].Wh);
+  hidden(1, b0, A.layer[1].save);
+  // LayerNorm affine and the residual rows: requested ahead of the last layer
+  const float4 gam0 = ld4(A.fin_gamma + c0), gam1 = ld4(A.fin_gamma + c0 + 16);
+  const float4 bet0 = ld4(A.fin_beta + c0), bet1 = ld4(A.fin_beta + c0 + 16);
+  float4 rres[TG][2];
+  if (A.res[0]) {
+#pragma unroll
+    for (int q = 0; q < TG; ++q) {
+      const float* rp = A.res[0] + (size_t)min(row0 + 16 * q + j, A.M - 1) * A.res_ld[0] + c0;
+      rres[q][0] = ld4(rp);
+      rres[q][1] = ld4(rp + 16);
+    }
+  }
+  cf_barrier();
+  // ---- layer 2: b0 -> y; LayerNorm ----
+  mma(b0, std::integral_constant<int, 4>{});
+  const int hcols = (A.hidden > 0 && A.hidden < 128) ? A.hidden : 128;   // LayerNorm width (a narrower model runs zero padded)
+  const int cw = min(max(hcols - 32 * w, 0), 32);                        // real columns among this wave's 32
+  float y[TG][8];
+#pragma unroll
+  for (int q = 0; q < TG; ++q) {
+    const int row = row0 + 16 * q + j;
+    const bool live = q < ngt && row < A.M;
+    float s = 0.f;
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+      const float4 b = bias[2][n];
+      float v[4] = {(acc[q][n][0] * CF_SH_INV) * invw + b.x, (acc[q][n][1] * CF_SH_INV) * invw + b.y,
+                    (acc[q][n][2] * CF_SH_INV) * invw + b.z, (acc[q][n][3] * CF_SH_INV) * invw + b.w};
+      if (A.fin_presave && live) st4(A.fin_presave + (size_t)row * 128 + c0 + 16 * n, v);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        y[q][4 * n + r] = v[r];
+        s += (c0 + 16 * n + r < hcols) ? v[r] : 0.f;
+      }
+    }
+    const float mw = row_sum(s) * (1.0f / (float)max(cw, 1));
+    float m2 = 0.f;
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float d = (c0 + 16 * n + r < hcols) ? y[q][4 * n + r] - mw : 0.f;
+        m2 += d * d;
+      }
+    m2 = row_sum(m2);
+    if (g == 0) *reinterpret_cast<float2*>(lnp + ((q * 16 + j) * 4 + w) * 2) = make_float2(mw, m2);
+  }
+  cf_barrier();
+  {
+    const float inv_h = 1.0f / (float)hcols;
+    const float cws[4] = {(float)min(max(hcols, 0), 32), (float)min(max(hcols - 32, 0), 32), (float)min(max(hcols - 64, 0), 32),
+                          (float)min(max(hcols - 96, 0), 32)};
+#pragma unroll
+    for (int q = 0; q < TG; ++q) {
+      const int row = row0 + 16 * q + j;
+      const bool live = q < ngt && row < A.M;
+      const float4* pp = reinterpret_cast<const float4*>(lnp + (q * 16 + j) * 8);
+      const float4 p0 = pp[0], p1 = pp[1];   // (mean, M2) of waves 0, 1 | 2, 3
+      const float mean = ((cws[0] * p0.x + cws[1] * p0.z) + (cws[2] * p1.x + cws[3] * p1.z)) * inv_h;
+      const float e0 = p0.x - mean, e1 = p0.z - mean, e2 = p1.x - mean, e3 = p1.z - mean;
+      const float m2 = ((p0.y + p0.w) + (p1.y + p1.w)) + ((cws[0] * e0 * e0 + cws[1] * e1 * e1) + (cws[2] * e2 * e2 + cws[3] * e3 * e3));
+      const float rstd = rsqrtf(m2 * inv_h + 1e-5f);   // nn.LayerNorm eps (EPD.py:32)
+      if (A.fin_stats && live && w == 0 && g == 0) *reinterpret_cast<float2*>(A.fin_stats + 2 * (size_t)row) = make_float2(mean, rstd);
+#pragma unroll
+      for (int n = 0; n < 2; ++n) {
+        const float4 ga = n ? gam1 : gam0, be = n ? bet1 : bet0;
+        float o[4] = {(y[q][4 * n + 0] - mean) * rstd * ga.x + be.x, (y[q][4 * n + 1] - mean) * rstd * ga.y + be.y,
+                      (y[q][4 * n + 2] - mean) * rstd * ga.z + be.z, (y[q][4 * n + 3] - mean) * rstd * ga.w + be.w};
+        if (live) {
+          if (A.out_nores) st4(A.out_nores + (size_t)row * 128 + c0 + 16 * n, o);
+          if (A.res[0]) { o[0] += rres[q][n].x; o[1] += rres[q][n].y; o[2] += rres[q][n].z; o[3] += rres[q][n].w; }
+          st4(A.out[0] + (size_t)row * A.out_ld[0] + c0 + 16 * n, o);
+        }
+      }
+    }
+  }
+  if (mabs > CF_SH_LIMIT) atomicOr(status, 2);   // GFV_FLAG_CHAIN_RANGE
+}
+
+inline bool cf_al16(const void* p) { return (reinterpret_cast<size_t>(p) & 15) == 0; }
+int cf_env(const char* n, int dflt) {
+  const char* e = getenv(n);
+  return e ? atoi(e) : dflt;
+}
+
+template <int KT0, int N0, bool PADD, bool RAGIN>
+void cf_launch(const gfv_rowtile_args_t& a, int tg, int lowp, hipStream_t stream) {
+  int* st = gfv_internal_status_ptr();
+  const int tiles = (a.M + 16 * tg - 1) / (16 * tg);
+  const dim3 grid(PADD ? gfv_xcd_grid(tiles) : tiles), blk(256);
+#define CF_ONE(TG, LP) hipLaunchKernelGGL((cfwd_kernel<KT0, N0, TG, PADD, LP, RAGIN>), grid, blk, 0, stream, a, st)
+#define CF_TG(LP) do { if (tg == 2) CF_ONE(2, LP); else CF_ONE(4, LP); } while (0)
+  if (lowp == 2) CF_TG(2);
+  else if (lowp) CF_TG(1);
+  else CF_TG(0);
+#undef CF_TG
+#undef CF_ONE
+}
+
+}  // namespace
+
+// 1: launched; 0: not a launch of this family.  lowp: 0 three products, 1 / 2 the single-product forms.  dry != 0: only tell
+// whether the launch would be taken.  `args` carries `hidden` (the launcher of rowtile.hip fills it in).
+int gfv_internal_cfwd_try(const gfv_rowtile_args_t* a, int lowp, hipStream_t stream, int dry) {
+  static const int on = cf_env("GFV_CFWD", 1);
+  static const int max_m = cf_env("GFV_CFWD_MAX_M", 40000);
+  static const int tg2_max = cf_env("GFV_CFWD_TG2_MAX_M", 16384);
+  if (!on || a->nlayers != 3 || a->M > max_m || a->M < 1 || (a->flags & (GFV_CHAIN_ROW_OWNER | GFV_CHAIN_COLUMN_OWNER))) return 0;
+  if (a->fin_op != GFV_FIN_LN || a->in_op != GFV_IN_NONE || !a->wmax || !a->fin_gamma || !a->fin_beta) return 0;
+  if (a->in_add || a->gadd || a->in_save || a->in_aux || a->ln_partial || a->gscale || a->dw_partial || a->in_stats || a->fin_aux) return 0;
+  for (int l = 0; l < 3; ++l) {
+    const gfv_layer_t& L = a->layer[l];
+    if (!L.Wh || L.N != 128 || L.aux || L.bias2 || (L.bias && !cf_al16(L.bias))) return 0;
+    if (L.op != (l < 2 ? GFV_OP_BIAS_GELU : GFV_OP_NONE)) return 0;
+    if (l > 0 && L.K != 128) return 0;
+    if (L.save && !cf_al16(L.save)) return 0;
+  }
+  if (a->layer[2].save) return 0;
+  if (!a->out[0] || a->out[1] || a->out[2] || (a->out_ld[0] & 3) || !cf_al16(a->out[0]) || a->res[1] || a->res[2]) return 0;
+  if (a->res[0] && ((a->res_ld[0] & 3) || !cf_al16(a->res[0]))) return 0;
+  if ((a->out_nores && !cf_al16(a->out_nores)) || (a->fin_presave && !cf_al16(a->fin_presave)) || !cf_al16(a->fin_gamma) || !cf_al16(a->fin_beta))
+    return 0;
+  if (a->fin_stats && (reinterpret_cast<size_t>(a->fin_stats) & 7)) return 0;
+  for (int i = 0; i < a->nseg; ++i)
+    if (a->seg[i].idx || a->seg[i].csr_rowptr || a->seg[i].csr_scale || a->seg[i].save) return 0;
+  const int K0 = a->layer[0].K;
+  const int tg = a->M <= tg2_max ? 2 : 4;
+  int shape = -1;   // 0: [64 | 128] (NodeBlock), 1: [128] + gathered addend (factored EdgeBlock), 2: [128] plain, 3: one narrow ragged segment
+  auto plain = [&](int i, int width) {
+    const gfv_seg_t& s = a->seg[i];
+    return s.width == width && (s.ld & 3) == 0 && cf_al16(s.ptr);
+  };
+  if (a->padd) {
+    if (a->nseg == 1 && K0 == 128 && plain(0, 128) && a->padd_s && a->padd_r && a->padd_ld >= 256 && (a->padd_ld & 3) == 0 && cf_al16(a->padd))
+      shape = 1;
+  } else if (a->nseg == 2 && K0 == 192 && plain(0, 64) && plain(1, 128)) {
+    shape = 0;
+  } else if (a->nseg == 1 && K0 == 128 && plain(0, 128)) {
+    shape = 2;
+  } else if (a->nseg == 1 && K0 <= 32 && a->seg[0].width == K0) {
+    shape = 3;
+  }
+  if (shape < 0) return 0;
+  if (dry) return 1;
+  if (shape == 0) cf_launch<6, 4, false, false>(*a, tg, lowp, stream);
+  else if (shape == 1) cf_launch<4, 8, true, false>(*a, tg, lowp, stream);
+  else if (shape == 2) cf_launch<4, 8, false, false>(*a, tg, lowp, stream);
+  else cf_launch<1, 2, false, true>(*a, tg, lowp, stream);
+  return 1;
+}

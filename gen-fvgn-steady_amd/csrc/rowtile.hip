@@ -86,6 +86,14 @@ extern "C" int gfv_rowtile_chain(const gfv_rowtile_args_t* args, void* stream) {
   return rc;
 }
 int gfv_internal_lin1_try(const gfv_rowtile_args_t* a, int lowp, hipStream_t stream, int dry);   // lin1.hip
+int gfv_internal_cfwd_try(const gfv_rowtile_args_t* a, int lowp, hipStream_t stream, int dry);   // cfwd.hip
+// the column-owner small-tile forward (cfwd.hip) reads the LayerNorm width from its arguments
+static int cfwd_try(const gfv_rowtile_args_t* args, int lowp, hipStream_t stream, int dry) {
+  if (args->nlayers != 3 || args->fin_op != GFV_FIN_LN) return 0;
+  gfv_rowtile_args_t local = *args;
+  local.hidden = g_hidden;
+  return gfv_internal_cfwd_try(&local, lowp, stream, dry);
+}
 static int rowtile_chain_impl(const gfv_rowtile_args_t* args, void* stream) {
   if (!args || args->M < 0 || args->nlayers < 1 || args->nlayers > 3 || args->nseg < 1 || args->nseg > 3) return GFV_ERR_ARG;
   if (args->M == 0) return GFV_OK;
@@ -182,6 +190,8 @@ static int rowtile_chain_impl(const gfv_rowtile_args_t* args, void* stream) {
       if (args->seg[i].csr_rowptr || args->seg[i].save) kind = GFV_K_TCHAIN_CSR;
     if (fast_t && f16 && args->nlayers == 1 && gfv_internal_lin1_try(args, f16_mode() >= 2 ? f16_mode() - 1 : 0, (hipStream_t)stream, 1))
       kind = GFV_K_LIN1;   // the lean single-layer kernel (same algorithmic work as the chain launch it stands in for)
+    if (f16 && cfwd_try(args, f16_mode() >= 2 ? f16_mode() - 1 : 0, (hipStream_t)stream, 1))
+      kind = GFV_K_COLCHAIN_FWD;   // the column-owner small-tile forward (same algorithmic work)
     if (args->dw_partial) {
       // dX chain with fused weight gradients (column-owner backward family): + the two (three) weight-gradient GEMMs, the
       // forward's row statistics read, the first Linear's input rows read, the per-workgroup blocks written
@@ -196,6 +206,8 @@ static int rowtile_chain_impl(const gfv_rowtile_args_t* args, void* stream) {
   if (args->dw_partial && !(fast_t && f16)) return GFV_ERR_ARG;   // (fused weight gradients: ask gfv_rowtile_fuses_dw first)
   if (fast_t && f16 && args->nlayers == 1 && gfv_internal_lin1_try(args, f16_mode() >= 2 ? f16_mode() - 1 : 0, (hipStream_t)stream, 0)) {
     g_last_path += 32;   // the lean single-layer kernel (lin1.hip)
+  } else if (f16 && !args->dw_partial && cfwd_try(args, f16_mode() >= 2 ? f16_mode() - 1 : 0, (hipStream_t)stream, 0)) {
+    g_last_path += 64;   // the column-owner small-tile forward (cfwd.hip)
   } else if (fast_t) {
     const int took = gfv_internal_tchain_launch(args, 0, f16 ? 1 : 0, (hipStream_t)stream);   // 1: the column-owner family, 2: with fused dW
     if (args->dw_partial && took != 2) return GFV_ERR_ARG;

@@ -207,7 +207,9 @@ int gfv_rowtile_chain(const gfv_rowtile_args_t* args, void* stream);
  * instantiation (0 was the generic LDS row-tile kernel, retired with ABI 2); + 4 when the products ran as split-fp16; + 8 when the column-owner persistent
  * family took the launch, + 16 when it ran with fused weight gradients, + 32 when a single-layer launch ran on the lean
  * one-Linear kernel (csrc/lin1.hip: the layer's image staged in LDS once per 128-row workgroup; same products, same
- * results to rounding) (tests assert the path they mean) */
+ * results to rounding), + 64 when a short 3-layer LayerNorm forward ran on the column-owner small-tile kernel (csrc/cfwd.hip:
+ * a wave owns 32 output columns of a 32- / 64-row tile; hidden activations split behind a fixed scale as in the column-owner
+ * backward) (tests assert the path they mean) */
 int gfv_rowtile_last_path(void);
 
 /* fp32 products on the f16 MFMA pipe (v_mfma_f32_16x16x32_f16, 16x the f32 MFMA rate): every fp32 operand is split

@@ -13,7 +13,7 @@ import bench
 from gfv.params import default_params
 from gfv.trainer import TrainStep
 from FVMmodel.importer import NNmodel
-graphs_cpu, sz = bench.build_workload("cylinder", 50000, 1, 0, "cuda")
+graphs_cpu, sz = bench.build_workload(os.environ.get("LC_WORKLOAD", "cylinder"), int(os.environ.get("LC_CELLS", "50000")), 1, 0, "cuda")
 graphs = tuple(g.clone().to("cuda") for g in graphs_cpu)
 torch.manual_seed(0)
 model = NNmodel(default_params(dataset_size=1)).cuda()
