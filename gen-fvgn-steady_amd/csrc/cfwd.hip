@@ -19,9 +19,14 @@
 // 4 barriers per tile instead of 13; per wave 48 TG / 2 MFMAs per 128-deep layer.  Hidden activations are split behind the fixed
 // scale CF_SH (colchain_kernel.h CC_SH: GELU outputs in [2^-4, 2^11] keep fp32 accuracy; beyond 2^11 GFV_FLAG_CHAIN_RANGE is
 // raised), the layer INPUT rows behind their own power-of-two row scale as everywhere else.
-// Price: every tile pulls the three images (160 - 224 KB) from L2 - 32-row tiles only where the launch is small (TG = 2 up to
-// GFV_CFWD_TG2_MAX_M rows), 64-row tiles above, and nothing above GFV_CFWD_MAX_M rows (the 75 k-row edge launches of the
-// headline mesh stay with the row-owner chain: there the tiles' latencies overlap and the weight stream is shared by 64 rows).
+// Price: every tile pulls the three images (160 - 224 KB) from L2 into registers, and a CU fetches 25 - 35 B / clock from L2
+// (profiles/r05_launch_floor.txt): where a CU runs several tiles the weight stream is what the launch waits for.  Measured
+// (profiles/r05_cfwd.txt, in-step averages): 5 k-row launches 11.9 us against 25 (NodeBlock), 17.5 against 27 (EdgeBlock, 10 k
+// rows), 12.0 against 22 (encoder); 25 k-row NodeBlock launches 30.9 us with 32-row tiles, 35.6 with 64-row tiles (84 KB of LDS:
+// one workgroup per CU) against 35 for the row-owner chain; 75 k-row EdgeBlock launches 78 - 83 us against 80.  So: 32-row tiles
+// up to GFV_CFWD_TG2_MAX_M rows (default = every launch the family takes), nothing above GFV_CFWD_MAX_M = 40 000 rows (the
+// 75 k-row edge launches of the headline mesh stay with the row-owner chain, whose 64 rows share one weight stream through
+// LDS), the encoders' narrow inputs up to GFV_CFWD_RAG_MAX_M = 16 384 rows (33 us against 30 at 25 k rows).
 #include <cstdlib>
 
 #include "tchain_kernel.h"
@@ -248,8 +253,11 @@ __global__ __launch_bounds__(256, 2) void cfwd_kernel(const gfv_rowtile_args_t A
   cf_barrier();
   // ---- layer 2: b0 -> y; LayerNorm ----
   mma(b0, std::integral_constant<int, 4>{});
-  const int hcols = (A.hidden > 0 && A.hidden < 128) ? A.hidden : 128;   // LayerNorm width (a narrower model runs zero padded)
-  const int cw = min(max(hcols - 32 * w, 0), 32);                        // real columns among this wave's 32
+  // LayerNorm width: a narrower model runs zero padded to 128 columns, and WHERE its h real columns sit depends on the tensor
+  // (node latents 0 .. h - 1, the two halves of an edge latent at 0 and 64: FVMmodel/padding.py) - so the statistics are taken
+  // over all 128 columns, whose padded ones are exactly zero, and corrected: mean_h = sum / h,
+  // sum_real (y - mean_h)^2 = M2_128 + 128 (mean_128 - mean_h)^2 - (128 - h) mean_h^2   (tchain_kernel.h ln_stats: the same sums)
+  const int hcols = (A.hidden > 0 && A.hidden < 128) ? A.hidden : 128;
   float y[TG][8];
 #pragma unroll
   for (int q = 0; q < TG; ++q) {
@@ -265,35 +273,34 @@ __global__ __launch_bounds__(256, 2) void cfwd_kernel(const gfv_rowtile_args_t A
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         y[q][4 * n + r] = v[r];
-        s += (c0 + 16 * n + r < hcols) ? v[r] : 0.f;
+        s += v[r];
       }
     }
-    const float mw = row_sum(s) * (1.0f / (float)max(cw, 1));
+    const float mw = row_sum(s) * 0.03125f;   // this wave's 32 columns
     float m2 = 0.f;
 #pragma unroll
-    for (int n = 0; n < 2; ++n)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float d = (c0 + 16 * n + r < hcols) ? y[q][4 * n + r] - mw : 0.f;
-        m2 += d * d;
-      }
+    for (int e = 0; e < 8; ++e) {
+      const float d = y[q][e] - mw;
+      m2 += d * d;
+    }
     m2 = row_sum(m2);
     if (g == 0) *reinterpret_cast<float2*>(lnp + ((q * 16 + j) * 4 + w) * 2) = make_float2(mw, m2);
   }
   cf_barrier();
   {
-    const float inv_h = 1.0f / (float)hcols;
-    const float cws[4] = {(float)min(max(hcols, 0), 32), (float)min(max(hcols - 32, 0), 32), (float)min(max(hcols - 64, 0), 32),
-                          (float)min(max(hcols - 96, 0), 32)};
+    const float inv_h = 1.0f / (float)hcols, npad = (float)(128 - hcols);
 #pragma unroll
     for (int q = 0; q < TG; ++q) {
       const int row = row0 + 16 * q + j;
       const bool live = q < ngt && row < A.M;
       const float4* pp = reinterpret_cast<const float4*>(lnp + (q * 16 + j) * 8);
       const float4 p0 = pp[0], p1 = pp[1];   // (mean, M2) of waves 0, 1 | 2, 3
-      const float mean = ((cws[0] * p0.x + cws[1] * p0.z) + (cws[2] * p1.x + cws[3] * p1.z)) * inv_h;
-      const float e0 = p0.x - mean, e1 = p0.z - mean, e2 = p1.x - mean, e3 = p1.z - mean;
-      const float m2 = ((p0.y + p0.w) + (p1.y + p1.w)) + ((cws[0] * e0 * e0 + cws[1] * e1 * e1) + (cws[2] * e2 * e2 + cws[3] * e3 * e3));
+      const float m128 = ((p0.x + p0.z) + (p1.x + p1.z)) * 0.25f;
+      const float e0 = p0.x - m128, e1 = p0.z - m128, e2 = p1.x - m128, e3 = p1.z - m128;
+      const float m2a = ((p0.y + p0.w) + (p1.y + p1.w)) + 32.0f * ((e0 * e0 + e1 * e1) + (e2 * e2 + e3 * e3));   // about m128, all columns
+      const float mean = hcols == 128 ? m128 : (m128 * 128.0f) * inv_h;
+      const float dm = m128 - mean;
+      const float m2 = hcols == 128 ? m2a : (m2a + 128.0f * dm * dm) - npad * (mean * mean);
       const float rstd = rsqrtf(m2 * inv_h + 1e-5f);   // nn.LayerNorm eps (EPD.py:32)
       if (A.fin_stats && live && w == 0 && g == 0) *reinterpret_cast<float2*>(A.fin_stats + 2 * (size_t)row) = make_float2(mean, rstd);
 #pragma unroll
@@ -339,7 +346,8 @@ void cf_launch(const gfv_rowtile_args_t& a, int tg, int lowp, hipStream_t stream
 int gfv_internal_cfwd_try(const gfv_rowtile_args_t* a, int lowp, hipStream_t stream, int dry) {
   static const int on = cf_env("GFV_CFWD", 1);
   static const int max_m = cf_env("GFV_CFWD_MAX_M", 40000);
-  static const int tg2_max = cf_env("GFV_CFWD_TG2_MAX_M", 16384);
+  static const int tg2_max = cf_env("GFV_CFWD_TG2_MAX_M", 40000);
+  static const int rag_max = cf_env("GFV_CFWD_RAG_MAX_M", 16384);
   if (!on || a->nlayers != 3 || a->M > max_m || a->M < 1 || (a->flags & (GFV_CHAIN_ROW_OWNER | GFV_CHAIN_COLUMN_OWNER))) return 0;
   if (a->fin_op != GFV_FIN_LN || a->in_op != GFV_IN_NONE || !a->wmax || !a->fin_gamma || !a->fin_beta) return 0;
   if (a->in_add || a->gadd || a->in_save || a->in_aux || a->ln_partial || a->gscale || a->dw_partial || a->in_stats || a->fin_aux) return 0;
@@ -372,7 +380,7 @@ int gfv_internal_cfwd_try(const gfv_rowtile_args_t* a, int lowp, hipStream_t str
     shape = 0;
   } else if (a->nseg == 1 && K0 == 128 && plain(0, 128)) {
     shape = 2;
-  } else if (a->nseg == 1 && K0 <= 32 && a->seg[0].width == K0) {
+  } else if (a->nseg == 1 && K0 <= 32 && a->seg[0].width == K0 && a->M <= rag_max) {
     shape = 3;
   }
   if (shape < 0) return 0;

@@ -30,11 +30,14 @@ static int cc_cus() {
 // the backward form with fused weight gradients (colchain_bwd_kernel): does the launch qualify?
 static bool cc_bwd_ok(const gfv_rowtile_args_t* a) {
   static const int on = cc_env("GFV_COLCHAIN_BWD", 1);
-  static const int min_m = cc_env("GFV_COLCHAIN_BWD_MIN_M", 16384);
+  static const int min_m = cc_env("GFV_COLCHAIN_BWD_MIN_M", 2048);
   if (a->flags & GFV_CHAIN_ROW_OWNER) return false;
   if (!(a->flags & GFV_CHAIN_COLUMN_OWNER) && (!on || a->M < min_m)) return false;
   if (!a->dw_partial || a->dw_partial_stride < (a->dw_in ? GFV_DW_FUSED_FLOATS_IN : GFV_DW_FUSED_FLOATS) || !a->in_stats || !a->wmax) return false;
   if (a->dw_in && (!al16(a->dw_in) || (a->dw_in_ld & 3) || a->dw_in_ld < 128)) return false;
+  // (the trailing first-layer weight gradient keeps one scale per tile of a workgroup in LDS: 256 tiles of 64 rows each)
+  if (a->dw_in && ((a->M + 63) / 64 + cc_cus() - 1) / cc_cus() + 1 > 256) return false;
+  if (a->dw_in && !a->layer[1].save) return false;   // (it reads the gz1 rows the tile loop stored)
   // (two layers: the input needs no gradient - the encoders; out[0] then receives gz1, the last layer's op is the second DGELU)
   const bool noout = a->nlayers == 2;
   // recompute form: the forward images of the second and third Linear are given, z2 (layer[0].aux) and y (in_aux) are not read

@@ -290,7 +290,7 @@ __device__ __forceinline__ void cb_hidden_bwd(CcCtx& c, int q, const floatx4& ac
   v[0] = v01.x; v[1] = v01.y; v[2] = v23.x; v[3] = v23.y;
   const float a[4] = {a01.x, a01.y, a23.x, a23.y};
   const float mq = max3_abs(max3_abs(0.f, v[0], v[1]), v[2], v[3]) * sg;
-  const float ma = max3_abs(max3_abs(0.f, a[0], a[1]), a[2], a[3]) * (CC_SH * (1.0f / 32.0f));   // (a against CC_SH_LIMIT x 32 = 65536)
+  const float ma = max3_abs(max3_abs(0.f, a[0], a[1]), a[2], a[3]) * (60000.0f / CC_SH_LIMIT);   // (|a| beyond CC_SH_LIMIT raises the flag: mabs is compared with 60000)
   c.mabs = fmaxf(c.mabs, q < c.ngt ? fmaxf(mq, ma) : 0.f);
   cc_put_frag<BF>(gout, q, c, v, sg);
   cc_put_frag<BF>(aout, q, c, a, CC_SH);
@@ -406,7 +406,14 @@ __device__ __forceinline__ void cb_load_gathers(const CbBufs& B, const CcCtx& c,
 }
 
 // GADD: the gathered addend [gadd[s] | gadd[r]] of the incoming gradient exists; DW1: the forward's first Linear is 128 deep
-// and its input rows are given (dw_in): its weight gradient is fused as well (a fourth fragment buffer, 36 more registers)
+// and its input rows are given (dw_in): its weight gradient dW1 = gz1^T x is formed by this launch as well - in a TRAILING pass
+// of every workgroup over its own rows, behind the tile loop (round 5).  (Rounds 3 - 4 accumulated it tile by tile beside dW3 /
+// dW2: 36 more live registers in a kernel that sits at 253 of 256 - 18 to 43 spilled registers in every variant, 4.06 against
+// 3.82 ms per step.)  The trailing pass re-reads the gz1 rows this workgroup wrote (L2 / Infinity Cache) and the input rows,
+// splits both into fragments (two buffer pairs, alternating: one barrier per tile), and runs the weight-gradient phase on them
+// with the registers of the dW3 accumulators, which have left for the partial block by then: no live value is added to the
+// tile loop.  It replaces the one-tile weight-gradient launch over the E rows on the side queue (27 us alone, ~115 us beside a
+// persistent launch) at ~3 k cycles per tile here.
 // OUT2: the last chain layer is 192 wide (NodeBlock: W1^T with the rows for x first, then the 64 for the neighbour mean,
 // blocks.py:54): waves 0..3 own a second n-tile and write out[1] ([M, 64], no residual)
 // NOOUT: the MLP's input needs no gradient (the encoders, EPD.py:92-119): a two-layer launch whose out[0] receives gz1 (what the
@@ -416,11 +423,13 @@ template <int LOWP, bool GADD, bool DW1, bool OUT2 = false, bool NOOUT = false, 
 __global__ __launch_bounds__(64 * CC_W, 2) void colchain_bwd_kernel(const gfv_rowtile_args_t A, int* status) {
   static_assert(!(RC && DW1), "the fourth fragment buffer is either the first Linear's input rows or the recomputed a1");
   constexpr int TG = CB_TG;
-  __shared__ __attribute__((aligned(16))) char lds[CbLds::TOTAL + ((DW1 || RC) ? CbLds::BUF : 0)];
+  constexpr int CB_TSC_MAX = 256;   // (DW1) tiles per workgroup whose gz1 scale is kept for the trailing pass (the launcher checks)
+  __shared__ __attribute__((aligned(16))) char lds[CbLds::TOTAL + ((DW1 || RC) ? CbLds::BUF : 0) + (DW1 ? 4 * CB_TSC_MAX : 0)];
   char* b0 = lds + CbLds::B0;
   char* b1 = lds + CbLds::B1;
   char* b2 = lds + CbLds::B2;
-  char* b3 = lds + CbLds::TOTAL;   // (DW1) fragments of the first Linear's input rows; (RC) a1 = gelu(z1)
+  char* b3 = lds + CbLds::TOTAL;   // (DW1) the trailing pass's second fragment pair; (RC) a1 = gelu(z1)
+  float* tsc = reinterpret_cast<float*>(lds + CbLds::TOTAL + CbLds::BUF);   // (DW1) gz1 fragment scale of every tile of this workgroup
   float* part = reinterpret_cast<float*>(lds + CbLds::PART);
   float* smax = reinterpret_cast<float*>(lds + CbLds::SMAX);
 
@@ -463,11 +472,9 @@ __global__ __launch_bounds__(64 * CC_W, 2) void colchain_bwd_kernel(const gfv_ro
   const cb_rsrc rw2 = cb_buf(RC ? A.rc_Wh[0] : nullptr, 65536), rw3 = cb_buf(RC ? A.rc_Wh[1] : nullptr, 65536);
   const int woff = (c.w * 128 + c.lane) * 16;   // + T * 16384 (+ 1024: the lo part)
   // fused weight gradients: D[n = 16 w + 4 g + r][k = 16 kt + j] in lane (j, g) of acc[kt][r]
-  floatx4 dw3[8], dw2[8], dw1[DW1 ? 8 : 1], db3 = floatx4{0.f, 0.f, 0.f, 0.f}, db2 = db3, db1 = db3;
+  floatx4 dw3[8], dw2[8], db3 = floatx4{0.f, 0.f, 0.f, 0.f}, db2 = db3;
 #pragma unroll
   for (int kt = 0; kt < 8; ++kt) dw3[kt] = dw2[kt] = floatx4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int kt = 0; kt < (DW1 ? 8 : 1); ++kt) dw1[kt] = floatx4{0.f, 0.f, 0.f, 0.f};
   float dgam[4] = {0.f, 0.f, 0.f, 0.f}, dbet[4] = {0.f, 0.f, 0.f, 0.f};
   float sacc = 0.f;          // scale the g3-side accumulators are in (0: nothing accumulated yet); gz2 side: / 32, gz1 side: / 1024
   float scap = 3.0e38f;      // 2^20 x the smallest tile scale so far
@@ -511,8 +518,7 @@ __global__ __launch_bounds__(64 * CC_W, 2) void colchain_bwd_kernel(const gfv_ro
     step2 = 1.0f / gfv_pow2_ceil(g1);
   }
 
-  // (DW1: the 36 registers of the third accumulator set leave no room for rows in flight a tile ahead - they are loaded in P0)
-  constexpr bool PRE = !DW1;
+  constexpr bool PRE = true;
   int gidx[TG] = {0, 0, 0, 0};
   CbIn in;
   float4 zn[RC ? TG : 1];   // (RC) the next tile's z1 rows
@@ -537,7 +543,8 @@ __global__ __launch_bounds__(64 * CC_W, 2) void colchain_bwd_kernel(const gfv_ro
   const bool CB_LATE = c.w >= 4;
 #endif
   CT_DECL
-  for (int t0 = g_beg; t0 < g_end; t0 += TG) {
+  int tloc = 0;   // (DW1) this workgroup's tile counter
+  for (int t0 = g_beg; t0 < g_end; t0 += TG, ++tloc) {
     c.row0 = 16 * t0;
     c.ngt = min(TG, g_end - t0);
     const int np = (c.ngt + 1) >> 1;
@@ -564,7 +571,7 @@ __global__ __launch_bounds__(64 * CC_W, 2) void colchain_bwd_kernel(const gfv_ro
         float a[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) a[r] = gfv_gelu(z4[r]);
-        const float ma = max3_abs(max3_abs(0.f, a[0], a[1]), a[2], a[3]) * (CC_SH * (1.0f / 32.0f));
+        const float ma = max3_abs(max3_abs(0.f, a[0], a[1]), a[2], a[3]) * (60000.0f / CC_SH_LIMIT);
         c.mabs = fmaxf(c.mabs, q < c.ngt ? ma : 0.f);
         cc_put_frag<LOWP == 2>(b3, q, c, a, CC_SH);
       }
@@ -605,7 +612,7 @@ __global__ __launch_bounds__(64 * CC_W, 2) void colchain_bwd_kernel(const gfv_ro
             // gelu'(z2) waits for P3 in b1 (free since the previous tile's second chain layer): in the very bytes this lane
             // will write its share of the gz2 fragments to - 16 registers less from here to P3, where the kernel peaks
             cb_park4(b1, q, c, dg);
-            const float ma = max3_abs(max3_abs(0.f, a[0], a[1]), a[2], a[3]) * (CC_SH * (1.0f / 32.0f));
+            const float ma = max3_abs(max3_abs(0.f, a[0], a[1]), a[2], a[3]) * (60000.0f / CC_SH_LIMIT);
             c.mabs = fmaxf(c.mabs, q < c.ngt ? ma : 0.f);
             cc_put_frag<LOWP == 2>(b2, q, c, a, CC_SH);
           }
@@ -740,14 +747,12 @@ __global__ __launch_bounds__(64 * CC_W, 2) void colchain_bwd_kernel(const gfv_ro
       const float ratio = s3 / sacc;
 #pragma unroll
       for (int kt = 0; kt < 8; ++kt) { dw3[kt] *= ratio; dw2[kt] *= ratio; }
-#pragma unroll
-      for (int kt = 0; kt < (DW1 ? 8 : 1); ++kt) dw1[kt] *= ratio;
       db3 *= ratio;
       db2 *= ratio;
-      db1 *= ratio;
     }
     sacc = s3;
     const float s2s = s3 * step1, s1s = s2s * step2;
+    if (DW1 && c.w == 0 && c.lane == 0) tsc[tloc] = s1s;   // the scale the trailing pass gives this tile's gz1 fragments
     // per-16-row scales of the rows this launch leaves for a weight-gradient launch of its own (gfv_rowtile_args_t.gscale):
     // the tile's fragment scales, a quarter of them (a slab scale s wants s max|v| <= 2^14, the fragments allow 2^16)
     if (A.gscale && c.w == 0 && c.lane < c.ngt) {
@@ -802,24 +807,10 @@ __global__ __launch_bounds__(64 * CC_W, 2) void colchain_bwd_kernel(const gfv_ro
     cc_barrier();
     CT(5);
     // ---- dW3 += g3^T a2 ----
-    float4 ev[DW1 ? TG : 1];   // (DW1) the first Linear's input rows: in flight through this phase, fragments at its end
-    if (DW1) {
-#pragma unroll
-      for (int q = 0; q < TG; ++q) ev[q] = cb_ld4(cb_buf(A.dw_in, rows128), offL[q]);
-    }
     // (RC) the next tile's z1 rows: in flight through the weight gradients and the last two chain layers
     if constexpr (RC) cb_load_rows(B.z1, c, next_row0, zn);
     cb_dw_tile<LOWP>(b0, b2, np, c.w, c.lane, dw3, db3);
     if constexpr (RC) cb_dw_tile<LOWP>(b1, b3, np, c.w, c.lane, dw2, db2);   // gz2 and a1 both exist: frees b3 for the next tile's R1
-    if (DW1) {
-#pragma unroll
-      for (int q = 0; q < TG; ++q) {
-        const float e4[4] = {ev[q].x, ev[q].y, ev[q].z, ev[q].w};
-        const float me = max3_abs(max3_abs(0.f, e4[0], e4[1]), e4[2], e4[3]) * (CC_SH * (1.0f / 32.0f));
-        c.mabs = fmaxf(c.mabs, q < c.ngt ? me : 0.f);
-        cc_put_frag<LOWP == 2>(b3, q, c, e4, CC_SH);
-      }
-    }
     CT(6);
     cc_barrier();
     CT(7);
@@ -920,7 +911,6 @@ __global__ __launch_bounds__(64 * CC_W, 2) void colchain_bwd_kernel(const gfv_ro
       }
       cb_dw_tile<LOWP>(b1, b2, np, c.w, c.lane, dw2, db2);
     }
-    if constexpr (DW1) cb_dw_tile<LOWP>(b0, b3, np, c.w, c.lane, dw1, db1);
     CT(11);
     // (the next tile's P0 writes only `part` / `smax`, last read in P0b; its P0b writes b0 behind the barrier that follows P0)
   }
@@ -936,7 +926,7 @@ __global__ __launch_bounds__(64 * CC_W, 2) void colchain_bwd_kernel(const gfv_ro
     float* blk = A.dw_partial + (size_t)blockIdx.x * A.dw_partial_stride;
     const float is = sacc != 0.f ? 1.0f / sacc : 0.f;
     const float r2 = 1.0f / step1, r1 = r2 / step2;   // the gz2 / gz1 sides are in units of sacc * step1 (* step2)
-    const float u3 = is * CC_SH_INV, u2 = (is * r2) * CC_SH_INV, u1 = (is * r1) * CC_SH_INV;
+    const float u3 = is * CC_SH_INV, u2 = (is * r2) * CC_SH_INV;
 #pragma unroll
     for (int kt = 0; kt < 8; ++kt)
 #pragma unroll
@@ -944,7 +934,6 @@ __global__ __launch_bounds__(64 * CC_W, 2) void colchain_bwd_kernel(const gfv_ro
         const int n = 16 * cb_dw_ntile(c.w, kt) + 4 * c.g + r, k = 16 * cb_dw_ktile(c.w, kt) + c.j;
         blk[n * 128 + k] = dw3[kt][r] * u3;
         blk[16384 + 128 + n * 128 + k] = dw2[kt][r] * u2;
-        if (DW1) blk[2 * 16384 + 512 + n * 128 + k] = dw1[kt][r] * u1;
       }
     if (c.j == 0) {
 #pragma unroll
@@ -952,7 +941,6 @@ __global__ __launch_bounds__(64 * CC_W, 2) void colchain_bwd_kernel(const gfv_ro
         const int nb = 16 * cb_dw_btile(c.w) + 4 * c.g + r;
         blk[16384 + nb] = db3[r] * is;
         blk[2 * 16384 + 128 + nb] = db2[r] * (is * r2);
-        if (DW1) blk[3 * 16384 + 512 + nb] = db1[r] * (is * r1);
       }
     }
     // (dgamma, dbeta): lane-private sums over the rows j and the groups this lane saw -> sum over the 16 lanes of a DPP row
@@ -962,6 +950,79 @@ __global__ __launch_bounds__(64 * CC_W, 2) void colchain_bwd_kernel(const gfv_ro
       if (c.j == 0) {
         blk[2 * 16384 + 256 + c.col0 + r] = dg;
         blk[2 * 16384 + 384 + c.col0 + r] = db;
+      }
+    }
+  }
+  // ---- (DW1) trailing pass: dW1 = gz1^T x and db1 over this workgroup's rows ----
+  if constexpr (DW1) {
+    floatx4 (&d1)[8] = dw3;   // (the dW3 accumulators have left for the partial block)
+    floatx4 b1acc = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kt = 0; kt < 8; ++kt) d1[kt] = floatx4{0.f, 0.f, 0.f, 0.f};
+    const cb_rsrc xin = cb_buf(A.dw_in, rows128);
+    float4 gq[TG], xq[TG];
+    float sacc1 = 0.f;
+    if (g_beg < g_end) {
+#pragma unroll
+      for (int q = 0; q < TG; ++q) {
+        const int off = cb_off(c, 16 * g_beg, q);
+        gq[q] = cb_ld4(B.save1, off);   // (this lane's own stores of the tile loop)
+        xq[q] = cb_ld4(xin, off);
+      }
+    }
+    cc_barrier();   // every wave is through the tile loop's last weight-gradient phase: the fragment buffers are free
+    int tl = 0;
+    for (int t0 = g_beg; t0 < g_end; t0 += TG, ++tl) {
+      const int row0 = 16 * t0, ngt = min(TG, g_end - t0), np = (ngt + 1) >> 1;
+      const float s1 = tsc[tl];
+      if (sacc1 != 0.f && sacc1 != s1) {
+        const float ratio = s1 / sacc1;
+#pragma unroll
+        for (int kt = 0; kt < 8; ++kt) d1[kt] *= ratio;
+        b1acc *= ratio;
+      }
+      sacc1 = s1;
+      char* gb = (tl & 1) ? b1 : b0;
+      char* ab = (tl & 1) ? b3 : b2;
+#pragma unroll
+      for (int q = 0; q < TG; ++q) {
+        const int row = row0 + 16 * q + c.j;
+        // rows past M / dead groups must not reach the sums over rows.  A SELECT, not a multiplication by 0: a dead lane's clamped
+        // load may land on a gz1 row another workgroup has not written yet (whatever the buffer held, NaN included)
+        const bool lv = q < ngt && row < c.M;
+        const float lf = lv ? 1.0f : 0.0f;
+        const float g4[4] = {lv ? gq[q].x : 0.f, lv ? gq[q].y : 0.f, lv ? gq[q].z : 0.f, lv ? gq[q].w : 0.f};
+        const float x4[4] = {xq[q].x, xq[q].y, xq[q].z, xq[q].w};
+        const float mx = max3_abs(max3_abs(0.f, x4[0], x4[1]), x4[2], x4[3]) * (60000.0f / CC_SH_LIMIT);
+        c.mabs = fmaxf(c.mabs, lf != 0.f ? mx : 0.f);
+        cc_put_frag<LOWP == 2>(gb, q, c, g4, s1);
+        cc_put_frag<LOWP == 2>(ab, q, c, x4, CC_SH);
+      }
+      // the next tile's rows: in flight through the barrier and this tile's products
+      const int nrow0 = t0 + TG < g_end ? 16 * (t0 + TG) : c.M;
+#pragma unroll
+      for (int q = 0; q < TG; ++q) {
+        const int off = cb_off(c, nrow0, q);
+        gq[q] = cb_ld4(B.save1, off);
+        xq[q] = cb_ld4(xin, off);
+      }
+      cc_barrier();
+      cb_dw_tile<LOWP>(gb, ab, np, c.w, c.lane, d1, b1acc);
+    }
+    if (A.dw_partial) {
+      float* blk = A.dw_partial + (size_t)blockIdx.x * A.dw_partial_stride;
+      const float is1 = sacc1 != 0.f ? 1.0f / sacc1 : 0.f;
+      const float u1 = is1 * CC_SH_INV;
+#pragma unroll
+      for (int kt = 0; kt < 8; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int n = 16 * cb_dw_ntile(c.w, kt) + 4 * c.g + r, k = 16 * cb_dw_ktile(c.w, kt) + c.j;
+          blk[2 * 16384 + 512 + n * 128 + k] = d1[kt][r] * u1;
+        }
+      if (c.j == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) blk[3 * 16384 + 512 + 16 * cb_dw_btile(c.w) + 4 * c.g + r] = b1acc[r] * is1;
       }
     }
   }

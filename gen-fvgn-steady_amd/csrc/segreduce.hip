@@ -301,7 +301,7 @@ __global__ __launch_bounds__(1024) void reduce_partials_small_kernel(const float
 // (a thousand chunks x 1 KB) and the small attention / slice-projection partials alike, so the parameter gradients of one
 // MLP need one reduction launch instead of two to five.
 struct ReduceMulti {
-  gfv_reduce_piece_t piece[8];
+  gfv_reduce_piece_t piece[12];
 };
 __global__ __launch_bounds__(256) void reduce_multi_kernel(const ReduceMulti A) {
   __shared__ float4 red[16][17];
@@ -480,7 +480,7 @@ extern "C" int gfv_reduce_partials_2d(const float* partial, int32_t n_chunks, in
 }
 
 extern "C" int gfv_reduce_multi(const gfv_reduce_piece_t* pieces, int32_t n_pieces, void* stream) {
-  if (n_pieces < 1 || n_pieces > 8) return GFV_ERR_ARG;
+  if (n_pieces < 1 || n_pieces > 12) return GFV_ERR_ARG;
   ReduceMulti a;
   long maxn4 = 0;
   double by = 0;

@@ -159,7 +159,10 @@ class Engine:
         self._tail_split = int(os.environ.get("GFV_TAIL_SPLIT", "1"))   # last GnBlock's flush: 1 / 2 = its first / its other pieces on main
         self._enc_order = int(os.environ.get("GFV_ENC_ORDER", "1"))
         self._fuse_noout = os.environ.get("GFV_FUSE_NOOUT", "1") != "0"   # ... also where the input needs no gradient (encoders)
-        self._fuse_dw_min = int(os.environ.get("GFV_COLCHAIN_BWD_MIN_M", "16384"))
+        # (round 5: 2 048 instead of 16 384 rows - on a 5 k-cell mesh the persistent backward with one tile per workgroup takes
+        # 26 - 31 us per launch where the row-owner dX chain took 33 - 41 and left three weight-gradient tiles to the side queue:
+        # 1.836 -> 1.77 ms per step, profiles/r05_cfwd.txt)
+        self._fuse_dw_min = int(os.environ.get("GFV_COLCHAIN_BWD_MIN_M", "2048"))
         self._wi, self._wi_key, self._wmax, self._wi_abs = None, None, None, None
         self._pkey_cache = None
         self._zero_e = None
@@ -533,20 +536,22 @@ class Engine:
         ops.rowtile_chain(M, [Seg(G)], layers, outs, **kw)
         segs = sv["segs"]
 
+        base = dwp.data_ptr()
+        piece = lambda off, out, cols: dict(partial=base + 4 * off, out=out, n_chunks=nwg, chunk_stride=FL, rows=1, cols=cols)
+        fused_pieces = [piece(16384 + 128, self._gview2(grads, names[2], names[3]), 16384 + 128),   # dW2 | db2
+                        piece(0, self._gview2(grads, names[4], names[5]), 16384 + 128),             # dW3 | db3
+                        piece(2 * 16384 + 256, self._gview2(grads, names[6], names[7]), 256)]       # dgamma | dbeta
+        keep = (dwp, gz1, gs, sv["in_add"], *[sg.t for sg in segs], *[sg.idx for sg in segs])
+
         def side():
             lay = [(names[0], names[1], len(segs))]
             tiles = [self._tile(gz1, 128, sg, in_add=sv["in_add"] if i == 0 else None, gscale=gs[2],
                                 a_op=L.DW_COLSCALE if sg.width <= 16 else 0) for i, sg in enumerate(segs)]
             w1, slabs1, blen1, _ = self._dw_block(grads, lay, tiles, M, reduce=False)
             off0, _ = grads.block(names[0], names[1])
-            base = dwp.data_ptr()
-            piece = lambda off, out, cols: dict(partial=base + 4 * off, out=out, n_chunks=nwg, chunk_stride=FL, rows=1, cols=cols)
-            ops.reduce_multi([
-                dict(partial=w1, out=grads.flat.data_ptr() + 4 * off0, n_chunks=slabs1, chunk_stride=blen1, rows=1, cols=blen1),
-                piece(16384 + 128, self._gview2(grads, names[2], names[3]), 16384 + 128),   # dW2 | db2
-                piece(0, self._gview2(grads, names[4], names[5]), 16384 + 128),             # dW3 | db3
-                piece(2 * 16384 + 256, self._gview2(grads, names[6], names[7]), 256)])      # dgamma | dbeta
-        self.defer(side, dwp, gz1, gs, sv["in_add"], *[sg.t for sg in segs], *[sg.idx for sg in segs])
+            ops.reduce_multi([dict(partial=w1, out=grads.flat.data_ptr() + 4 * off0, n_chunks=slabs1, chunk_stride=blen1, rows=1,
+                                   cols=blen1)] + fused_pieces)
+        self.defer(side, *keep)
         return True
 
     @staticmethod
@@ -733,7 +738,12 @@ class Engine:
         lib = L.load()
         nwg = lib.gfv_rowtile_dw_partials()
         lean = sv["z2"] is None   # recompute form: the forward kept z1 only
-        fuse1 = os.environ.get("GFV_FUSE_DW1", "0") == "1" and not lean   # the first layer's gradient in the chain launch too (it spills: off)
+        # the first layer's gradient (the W1c block over the E rows) by the chain launch too: a trailing pass of every persistent
+        # workgroup over its own rows (round 5, csrc/colchain_kernel.h) instead of a one-tile weight-gradient launch on the side queue
+        # Measured (profiles/r05_ab_dw1_trailing.txt): 3 spilled registers instead of 18 - 43, parity-green - and time-neutral on the
+        # 50 k-cell mesh (3.71 - 3.76 against 3.72 - 3.74 ms), neutral at 8 meshes per GPU, 2.5 % slower on the 5 k-cell cavity (one
+        # tile per workgroup: the trailing pass is pure latency there): opt-in
+        fuse1 = os.environ.get("GFV_FUSE_DW1", "0") == "1" and not lean
         FL = L.DW_FUSED_FLOATS_IN if fuse1 else L.DW_FUSED_FLOATS
         dwp = _empty(dev, nwg, FL)
         gz1, g_e_in = _empty(dev, M, 128), _empty(dev, M, 128)

@@ -326,7 +326,7 @@ int gfv_reduce_partials_2d(const float* partial, int32_t n_chunks, int64_t chunk
 /* Several such reductions in ONE launch (the parameter gradients of one MLP: slab partials of gfv_dw_multi with
  * grad_block == NULL, per-tile LayerNorm partials, small per-block partials), each straight into its place:
  *   out[r * ld_out + c] = sum_{chunk < n_chunks} partial[chunk * chunk_stride + r * ld_in + c]   (r < rows, c < cols)
- * cols, ld_in, ld_out, chunk_stride multiples of 4 floats, pointers 16-byte aligned; n_pieces <= 8.  Fixed summation
+ * cols, ld_in, ld_out, chunk_stride multiples of 4 floats, pointers 16-byte aligned; n_pieces <= 12.  Fixed summation
  * order (16 interleaved chunk lanes, then an ordered fold): deterministic, no atomics. */
 typedef struct {
   const float* partial;

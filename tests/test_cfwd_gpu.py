@@ -25,27 +25,41 @@ def _wi(ws):
     return wi
 
 
-def _params(g, k_in, h=128):
+def _real_cols(h, layout="node"):
+    """The real columns of a latent of a model of hidden size h inside the kernels' 128 columns (FVMmodel/padding.py): node
+    latents at the front, the two halves of an edge latent at columns 0 and 64."""
+    m = torch.zeros(128, dtype=torch.bool)
+    if layout == "node":
+        m[:h] = True
+    else:
+        m[:h // 2] = True
+        m[64:64 + h // 2] = True
+    return m
+
+
+def _params(g, k_in, h=128, layout="node"):
     s = lambda *sh: torch.randn(*sh, generator=g)
     P = {"W1": s(128, k_in) * (1.0 / k_in ** 0.5), "b1": s(128) * 0.1, "W2": s(128, 128) * 0.09, "b2": s(128) * 0.1,
          "W3": s(128, 128) * 0.09, "b3": s(128) * 0.1, "gamma": 1.0 + 0.1 * s(128), "beta": 0.1 * s(128)}
     if h < 128:   # a narrower model, zero padded to the kernels' 128 columns (FVMmodel/padding.py)
+        dead = ~_real_cols(h, layout)
         for k in ("W1", "W2", "W3"):
-            P[k][h:, :] = 0
+            P[k][dead, :] = 0
         for k in ("W2", "W3"):
-            P[k][:, h:] = 0
+            P[k][:, dead] = 0
         for k in ("b1", "b2", "b3", "gamma", "beta"):
-            P[k][h:] = 0
+            P[k][dead] = 0
     return P
 
 
-def _ref(P, X, add=None, h=128):
+def _ref(P, X, add=None, h=128, layout="node"):
     P = {k: v.double() for k, v in P.items()}
     z1 = X @ P["W1"].T + P["b1"] + (0 if add is None else add)
     z2 = F.gelu(z1) @ P["W2"].T + P["b2"]
     y3 = F.gelu(z2) @ P["W3"].T + P["b3"]
-    mean = y3[:, :h].mean(1, keepdim=True)
-    var = ((y3[:, :h] - mean) ** 2).mean(1, keepdim=True)
+    real = _real_cols(h, layout)
+    mean = y3[:, real].mean(1, keepdim=True)
+    var = ((y3[:, real] - mean) ** 2).mean(1, keepdim=True)
     rstd = 1.0 / torch.sqrt(var + 1e-5)
     ln = (y3 - mean) * rstd * P["gamma"] + P["beta"]
     return z1, z2, y3, ln, torch.cat((mean, rstd), 1)
@@ -164,20 +178,23 @@ def test_small_tile_forward_single_product_forms(form):
     assert rel(a["out"], ln) < tol and rel(a["out"], b["out"]) < tol, (rel(a["out"], ln), rel(a["out"], b["out"]))
 
 
-def test_small_tile_forward_narrow_model_layernorm_width():
-    """hidden_size 64 zero padded to 128 columns: LayerNorm statistics over the 64 real columns, padded columns stay exactly 0."""
+@pytest.mark.parametrize("h,layout", [(64, "node"), (32, "edge"), (112, "edge")])
+def test_small_tile_forward_narrow_model_layernorm_width(h, layout):
+    """hidden_size h < 128 zero padded to 128 columns: LayerNorm statistics over the h real columns WHEREVER they sit (node
+    latents at the front, the halves of an edge latent at columns 0 and 64), padded columns stay exactly 0."""
     from gfv import lib as L, ops
     lib = L.load()
-    M, h = 640, 64
-    g = torch.Generator().manual_seed(5)
+    M = 640
+    g = torch.Generator().manual_seed(h)
     d = lambda t: t.cuda().contiguous()
+    real = _real_cols(h, layout)
     x = torch.randn(M, 128, generator=g)
-    x[:, h:] = 0
-    P = _params(g, 128, h=h)
-    P["W1"][:, h:] = 0
+    x[:, ~real] = 0
+    P = _params(g, 128, h=h, layout=layout)
+    P["W1"][:, ~real] = 0
     Pd = {k: d(v) for k, v in P.items()}
     wi = _wi([P["W1"], P["W2"], P["W3"]])
-    z1, z2, y3, ln, st = _ref(P, x.double(), h=h)
+    z1, z2, y3, ln, st = _ref(P, x.double(), h=h, layout=layout)
     assert lib.gfv_set_hidden_size(h) == 0
     try:
         xd = d(x)
@@ -189,4 +206,4 @@ def test_small_tile_forward_narrow_model_layernorm_width():
     for k, ref in (("y3", y3), ("out", ln + x.double()), ("stats", st)):
         assert rel(a[k], ref) < TOL, (k, rel(a[k], ref))
         assert rel(a[k], b[k]) < 4e-6, (k, rel(a[k], b[k]))
-    assert bool((a["out"][:, h:] == 0).all())
+    assert bool((a["out"][:, ~real.cuda()] == 0).all())
