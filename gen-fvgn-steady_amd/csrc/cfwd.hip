@@ -330,7 +330,7 @@ void cf_launch(const gfv_rowtile_args_t& a, int tg, int lowp, hipStream_t stream
   int* st = gfv_internal_status_ptr();
   const int tiles = (a.M + 16 * tg - 1) / (16 * tg);
   const dim3 grid(PADD ? gfv_xcd_grid(tiles) : tiles), blk(256);
-#define CF_ONE(TG, LP) hipLaunchKernelGGL((cfwd_kernel<KT0, N0, TG, PADD, LP, RAGIN>), grid, blk, 0, stream, a, st)
+#define CF_ONE(TG, LP) GFV_LAUNCH((cfwd_kernel<KT0, N0, TG, PADD, LP, RAGIN>), grid, blk, 0, stream, a, st)
 #define CF_TG(LP) do { if (tg == 2) CF_ONE(2, LP); else CF_ONE(4, LP); } while (0)
   if (lowp == 2) CF_TG(2);
   else if (lowp) CF_TG(1);

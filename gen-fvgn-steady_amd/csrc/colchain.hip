@@ -86,7 +86,7 @@ int gfv_internal_colchain_try(const gfv_rowtile_args_t* a, hipStream_t stream) {
     int* st = gfv_internal_status_ptr();
     if (!st) return 0;
     const dim3 grid(cc_cus()), blk(64 * CC_W);
-#define CB_K(...) hipLaunchKernelGGL((colchain_bwd_kernel<__VA_ARGS__>), grid, blk, 0, stream, *a, st)
+#define CB_K(...) GFV_LAUNCH((colchain_bwd_kernel<__VA_ARGS__>), grid, blk, 0, stream, *a, st)
 #define CB_LAUNCH(LOWP, RC)                                                                                                      \
   do {                                                                                                                           \
     if (a->nlayers == 2) CB_K(LOWP, false, false, false, true, RC);                                                              \

@@ -659,11 +659,11 @@ extern "C" int gfv_dw_multi(const gfv_dw_tile_t* tiles, int32_t ntiles, int32_t 
   const gfv_dw_tile_t& t0 = tiles[0];
   if (narrow_on && ntiles == 1 && t0.width <= 16 && t0.n_out == 128 && !t0.idx && !t0.in_add && (t0.a_op & 7) == 0 && t0.ld >= t0.width) {
     // a narrow raw input (the encoders' first Linear): plain fp32 FMAs whatever the product form (dw_narrow_kernel)
-    hipLaunchKernelGGL(dw_narrow_kernel, dim3(slabs), dim3(1024), 0, (hipStream_t)stream, t0, M, rows, workspace, (long)block_floats);
+    GFV_LAUNCH(dw_narrow_kernel, dim3(slabs), dim3(1024), 0, (hipStream_t)stream, t0, M, rows, workspace, (long)block_floats);
   } else
-  if (a.lowp == 2) hipLaunchKernelGGL(dw_multi_h_kernel<true>, dim3(slabs, ntiles), dim3(256), 0, (hipStream_t)stream, a);
-  else if (gfv_f16split_enabled()) hipLaunchKernelGGL(dw_multi_h_kernel<false>, dim3(slabs, ntiles), dim3(256), 0, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL(dw_multi_kernel, dim3(slabs, ntiles), dim3(256), 0, (hipStream_t)stream, a);
+  if (a.lowp == 2) GFV_LAUNCH(dw_multi_h_kernel<true>, dim3(slabs, ntiles), dim3(256), 0, (hipStream_t)stream, a);
+  else if (gfv_f16split_enabled()) GFV_LAUNCH(dw_multi_h_kernel<false>, dim3(slabs, ntiles), dim3(256), 0, (hipStream_t)stream, a);
+  else GFV_LAUNCH(dw_multi_kernel, dim3(slabs, ntiles), dim3(256), 0, (hipStream_t)stream, a);
   gfv_prof_end(tok, (hipStream_t)stream);
   GFV_CHECK_LAUNCH();
   if (!grad_block) return GFV_OK;  // the caller reduces the slab workspace itself (gfv_reduce_partials_2d)

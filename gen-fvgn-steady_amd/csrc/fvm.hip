@@ -783,7 +783,7 @@ __global__ __launch_bounds__(256) void interp2_bwd_kernel(const float* __restric
 #define LAUNCH1D(kernel, n, stream, ...)                                                                    \
   do {                                                                                                      \
     if ((n) > 0) {                                                                                          \
-      hipLaunchKernelGGL(kernel, dim3(gfv_div_up((n), 256)), dim3(256), 0, (hipStream_t)(stream), __VA_ARGS__); \
+      GFV_LAUNCH(kernel, dim3(gfv_div_up((n), 256)), dim3(256), 0, (hipStream_t)(stream), __VA_ARGS__); \
       GFV_CHECK_LAUNCH();                                                                                   \
     }                                                                                                       \
   } while (0)
@@ -887,7 +887,7 @@ extern "C" int gfv_graph_loss(const float* cres, const int32_t* gcell_ptr, const
                               float* sums, float* losses, int32_t B, void* stream) {
   GfvProfScope ps_(GFV_K_FVM, 0, 16.0 * gfv_prof_size_Sigma() / 3.0, stream);
   if (B <= 0) return GFV_OK;
-  hipLaunchKernelGGL(graph_loss_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, cres, gcell_ptr, theta, sigma, sums,
+  GFV_LAUNCH(graph_loss_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, cres, gcell_ptr, theta, sigma, sums,
                      losses);
   GFV_CHECK_LAUNCH();
   return GFV_OK;
@@ -955,10 +955,10 @@ extern "C" int gfv_wlsq_moments(const double* pos, const int32_t* rowptr, const 
   if (N < 0) return GFV_ERR_ARG;
   if (N == 0) return GFV_OK;
   switch (terms) {
-    case 2: hipLaunchKernelGGL(wlsq_moments_kernel<2>, dim3(gfv_div_up(N, 128)), dim3(128), 0, (hipStream_t)stream, pos, rowptr, outn, entry, A, B, N); break;
-    case 5: hipLaunchKernelGGL(wlsq_moments_kernel<5>, dim3(gfv_div_up(N, 128)), dim3(128), 0, (hipStream_t)stream, pos, rowptr, outn, entry, A, B, N); break;
-    case 9: hipLaunchKernelGGL(wlsq_moments_kernel<9>, dim3(gfv_div_up(N, 128)), dim3(128), 0, (hipStream_t)stream, pos, rowptr, outn, entry, A, B, N); break;
-    case 14: hipLaunchKernelGGL(wlsq_moments_kernel<14>, dim3(gfv_div_up(N, 128)), dim3(128), 0, (hipStream_t)stream, pos, rowptr, outn, entry, A, B, N); break;
+    case 2: GFV_LAUNCH(wlsq_moments_kernel<2>, dim3(gfv_div_up(N, 128)), dim3(128), 0, (hipStream_t)stream, pos, rowptr, outn, entry, A, B, N); break;
+    case 5: GFV_LAUNCH(wlsq_moments_kernel<5>, dim3(gfv_div_up(N, 128)), dim3(128), 0, (hipStream_t)stream, pos, rowptr, outn, entry, A, B, N); break;
+    case 9: GFV_LAUNCH(wlsq_moments_kernel<9>, dim3(gfv_div_up(N, 128)), dim3(128), 0, (hipStream_t)stream, pos, rowptr, outn, entry, A, B, N); break;
+    case 14: GFV_LAUNCH(wlsq_moments_kernel<14>, dim3(gfv_div_up(N, 128)), dim3(128), 0, (hipStream_t)stream, pos, rowptr, outn, entry, A, B, N); break;
     default: return GFV_ERR_ARG;
   }
   GFV_CHECK_LAUNCH();

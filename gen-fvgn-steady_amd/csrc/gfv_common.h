@@ -186,3 +186,5 @@ static __device__ __forceinline__ int gfv_xcd_tile(int wg, int grid) {
   return (wg & 7) * per + (wg >> 3);
 #endif
 }
+
+#include "gfv_launch.h"   // GFV_LAUNCH: every kernel launch, recordable (record.hip)

@@ -590,8 +590,10 @@ static inline bool l1_dyn_lds(const void* fn, int bytes, std::atomic<unsigned lo
 
 // 1: launched; 0: not a launch of this family.  lowp: the reduced-precision product forms (one product per term; 1 fp16, 2 bf16).
 // dry != 0: only tell whether the launch would be taken (the profiler prices it as this family's before it is issued)
+int gfv_internal_lin1s_try(const gfv_rowtile_args_t* a, int lowp, hipStream_t stream, int dry);   // lin1s.hip: the small-tile form
 int gfv_internal_lin1_try(const gfv_rowtile_args_t* a, int lowp, hipStream_t stream, int dry) {
   static const int on = l1_env("GFV_LIN1", 1);
+  if (on && gfv_internal_lin1s_try(a, lowp, stream, dry)) return 1;   // short launches: column-owner small tiles (round 5)
   static const int min_m = l1_env("GFV_LIN1_MIN_M", 1024);
   if (!on || a->nlayers != 1 || a->M < min_m || (a->flags & (GFV_CHAIN_ROW_OWNER | GFV_CHAIN_COLUMN_OWNER))) return 0;
   const gfv_layer_t& L = a->layer[0];
@@ -622,7 +624,7 @@ int gfv_internal_lin1_try(const gfv_rowtile_args_t* a, int lowp, hipStream_t str
   do {                                                                                                           \
     static std::atomic<unsigned long long> done{0};                                                              \
     if (!l1_dyn_lds(reinterpret_cast<const void*>(&lin1_csr_kernel<LP>), 131072, done)) return 0;                \
-    hipLaunchKernelGGL((lin1_csr_kernel<LP>), grid, blk, 131072, stream, B, st);                                 \
+    GFV_LAUNCH((lin1_csr_kernel<LP>), grid, blk, 131072, stream, B, st);                                 \
   } while (0)
     if (lowp == 2) L1_CSR(2);
     else if (lowp) L1_CSR(1);
@@ -668,7 +670,7 @@ int gfv_internal_lin1_try(const gfv_rowtile_args_t* a, int lowp, hipStream_t str
   do {                                                                                                           \
     static std::atomic<unsigned long long> done{0};                                                              \
     if (!l1_dyn_lds(reinterpret_cast<const void*>(&lin1_lnbwd_kernel<LP>), 131072, done)) return 0;              \
-    hipLaunchKernelGGL((lin1_lnbwd_kernel<LP>), grid, blk, 131072, stream, B, st);                               \
+    GFV_LAUNCH((lin1_lnbwd_kernel<LP>), grid, blk, 131072, stream, B, st);                               \
   } while (0)
     if (lowp == 2) L1_LNB(2);
     else if (lowp) L1_LNB(1);
@@ -739,7 +741,7 @@ int gfv_internal_lin1_try(const gfv_rowtile_args_t* a, int lowp, hipStream_t str
   do {                                                                                                                          \
     static std::atomic<unsigned long long> done{0};                                                                             \
     if (!l1_dyn_lds(reinterpret_cast<const void*>(&lin1_kernel<KS, NP, IOP, DG, LP>), (NP) * (KS) * 16384, done)) return 0;     \
-    hipLaunchKernelGGL((lin1_kernel<KS, NP, IOP, DG, LP>), grid, blk, (size_t)(NP) * (KS) * 16384, stream, A, st);              \
+    GFV_LAUNCH((lin1_kernel<KS, NP, IOP, DG, LP>), grid, blk, (size_t)(NP) * (KS) * 16384, stream, A, st);              \
   } while (0)
 #define L1_FORM(KS, NP, LP)                                                                                                     \
   do {                                                                                                                          \

@@ -278,7 +278,7 @@ extern "C" int gfv_graph_norm_stats(const float* x, int32_t ldx, const int32_t* 
                                     void* stream) {
   GfvProfScope ps_(GFV_K_MISC, 0, 12.0 * 0.0, stream);
   if (B <= 0) return GFV_OK;
-  hipLaunchKernelGGL(graph_norm_stats_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, x, ldx, gnode_ptr, stats);
+  GFV_LAUNCH(graph_norm_stats_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, x, ldx, gnode_ptr, stats);
   GFV_CHECK_LAUNCH();
   return GFV_OK;
 }
@@ -289,9 +289,9 @@ extern "C" int gfv_graph_norm_stats_ws(const float* x, int32_t ldx, const int32_
   GfvProfScope ps_(GFV_K_MISC, 0, 12.0 * 0.0, stream);
   if (B <= 0) return GFV_OK;
   if (!workspace || (reinterpret_cast<size_t>(workspace) & 7)) return GFV_ERR_ARG;
-  hipLaunchKernelGGL(graph_norm_partial_kernel, dim3(NORM_NB, B), dim3(256), 0, (hipStream_t)stream, x, ldx, gnode_ptr,
+  GFV_LAUNCH(graph_norm_partial_kernel, dim3(NORM_NB, B), dim3(256), 0, (hipStream_t)stream, x, ldx, gnode_ptr,
                      reinterpret_cast<double*>(workspace));
-  hipLaunchKernelGGL(graph_norm_final_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, reinterpret_cast<const double*>(workspace),
+  GFV_LAUNCH(graph_norm_final_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, reinterpret_cast<const double*>(workspace),
                      gnode_ptr, stats);
   GFV_CHECK_LAUNCH();
   return GFV_OK;
@@ -305,10 +305,10 @@ extern "C" int gfv_normalizer_update(const float* x, int32_t ldx, int32_t N, int
   GfvProfScope ps_(GFV_K_MISC, 0, accumulate ? 36.0 * N : 0.0, stream);
   const int nb = gfv_normalizer_blocks(N);
   if (accumulate && N > 0) {
-    hipLaunchKernelGGL(normalizer_partial_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, x, ldx, N, partial_ws);
+    GFV_LAUNCH(normalizer_partial_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, x, ldx, N, partial_ws);
     GFV_CHECK_LAUNCH();
   }
-  hipLaunchKernelGGL(normalizer_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, partial_ws, nb, (float)N,
+  GFV_LAUNCH(normalizer_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, partial_ws, nb, (float)N,
                      accumulate, acc_count, num_acc, acc_sum, acc_sq, mean_std);
   GFV_CHECK_LAUNCH();
   return GFV_OK;
@@ -318,7 +318,7 @@ extern "C" int gfv_node_prep(float* x, int32_t ldx, const int32_t* batch, const 
                              const float* mean_std, int32_t norm_global, float* uv_old, int32_t N, void* stream) {
   GfvProfScope ps_(GFV_K_MISC, 0, (96.0 + 4.0 + 8.0) * N, stream);
   if (N <= 0) return GFV_OK;
-  hipLaunchKernelGGL(node_prep_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, ldx, batch, stats,
+  GFV_LAUNCH(node_prep_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, ldx, batch, stats,
                      uvp_dim, mean_std, norm_global, uv_old, N);
   GFV_CHECK_LAUNCH();
   return GFV_OK;
@@ -328,7 +328,7 @@ extern "C" int gfv_edge_attr(const float* x, int32_t ldx, const float* pos, cons
                              float* out16, float* out15, int32_t E, void* stream) {
   GfvProfScope ps_(GFV_K_MISC, 0, (8.0 + 64.0 + (out15 ? 60.0 : 0.0)) * E, stream);
   if (E <= 0) return GFV_OK;
-  hipLaunchKernelGGL(edge_attr_kernel, dim3((E + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, ldx, pos, es, er,
+  GFV_LAUNCH(edge_attr_kernel, dim3((E + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, ldx, pos, es, er,
                      out16, out15, E);
   GFV_CHECK_LAUNCH();
   return GFV_OK;
@@ -339,8 +339,8 @@ extern "C" int gfv_adam_step_dev(float* p, const float* g, float* m, float* v, i
   GfvProfScope ps_(GFV_K_MISC, 0, 28.0 * (double)n, stream);   // p, g, m, v in; p, m, v out
   if (n <= 0) return GFV_OK;
   if (!state || !hyper) return GFV_ERR_ARG;
-  hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, state, hyper);
-  hipLaunchKernelGGL(adam_kernel, dim3(cap_grid(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long)n, state, hyper);
+  GFV_LAUNCH(adam_tick_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, state, hyper);
+  GFV_LAUNCH(adam_kernel, dim3(cap_grid(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long)n, state, hyper);
   GFV_CHECK_LAUNCH();
   return GFV_OK;
 }
@@ -348,7 +348,7 @@ extern "C" int gfv_adam_step_dev(float* p, const float* g, float* m, float* v, i
 extern "C" int gfv_train_loss(const float* losses, int32_t B, float w_cont, float w_mom, float w_press, float* loss,
                               float* gloss, void* stream) {
   if (B <= 0) return GFV_ERR_ARG;
-  hipLaunchKernelGGL(train_loss_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, losses, B, w_cont, w_mom, w_press,
+  GFV_LAUNCH(train_loss_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, losses, B, w_cont, w_mom, w_press,
                      (const float*)nullptr, loss, gloss);
   GFV_CHECK_LAUNCH();
   return GFV_OK;
@@ -357,7 +357,7 @@ extern "C" int gfv_train_loss(const float* losses, int32_t B, float w_cont, floa
 extern "C" int gfv_train_loss_dev(const float* losses, int32_t B, const float* hyper, float* loss, float* gloss, void* stream) {
   GfvProfScope ps_(GFV_K_MISC, 0, 32.0 * B, stream);
   if (B <= 0 || !hyper) return GFV_ERR_ARG;
-  hipLaunchKernelGGL(train_loss_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, losses, B, 0.f, 0.f, 0.f, hyper, loss, gloss);
+  GFV_LAUNCH(train_loss_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, losses, B, 0.f, 0.f, 0.f, hyper, loss, gloss);
   GFV_CHECK_LAUNCH();
   return GFV_OK;
 }
@@ -387,7 +387,7 @@ __global__ __launch_bounds__(256) void concat_offsets_kernel(const gfv_concat_de
 extern "C" int gfv_concat_offsets(const gfv_concat_desc_t* descs, int32_t n_desc, int32_t blocks_per_desc, void* stream) {
   if (n_desc <= 0) return GFV_OK;
   if (blocks_per_desc < 1) blocks_per_desc = 1;
-  hipLaunchKernelGGL(concat_offsets_kernel, dim3(blocks_per_desc, n_desc), dim3(256), 0, (hipStream_t)stream, descs);
+  GFV_LAUNCH(concat_offsets_kernel, dim3(blocks_per_desc, n_desc), dim3(256), 0, (hipStream_t)stream, descs);
   GFV_CHECK_LAUNCH();
   return GFV_OK;
 }

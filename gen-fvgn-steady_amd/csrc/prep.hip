@@ -133,13 +133,13 @@ extern "C" int gfv_khop_count(const int64_t* face0, const int64_t* face1, int32_
   int* nbr = flag + 8;                 // [2 F]
   if (hipMemsetAsync(deg, 0, sizeof(int) * (size_t)(N + 1), stream) != hipSuccess) return GFV_ERR_LAUNCH;
   if (hipMemsetAsync(flag, 0, sizeof(int) * 8, stream) != hipSuccess) return GFV_ERR_LAUNCH;
-  if (F > 0) hipLaunchKernelGGL(degree_kernel, dim3(gfv_div_up(F, 256)), dim3(256), 0, stream, face0, face1, F, deg);
-  hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, stream, deg, rowptr, N);
+  if (F > 0) GFV_LAUNCH(degree_kernel, dim3(gfv_div_up(F, 256)), dim3(256), 0, stream, face0, face1, F, deg);
+  GFV_LAUNCH(scan_kernel, dim3(1), dim3(1024), 0, stream, deg, rowptr, N);
   if (hipMemsetAsync(deg, 0, sizeof(int) * (size_t)(N + 1), stream) != hipSuccess) return GFV_ERR_LAUNCH;
-  if (F > 0) hipLaunchKernelGGL(csr_fill_kernel, dim3(gfv_div_up(F, 256)), dim3(256), 0, stream, face0, face1, F, rowptr, deg, nbr);
-  hipLaunchKernelGGL(khop_kernel<false>, dim3(gfv_div_up(N, 128)), dim3(128), 0, stream, rowptr, nbr, N, k, counts, offs,
+  if (F > 0) GFV_LAUNCH(csr_fill_kernel, dim3(gfv_div_up(F, 256)), dim3(256), 0, stream, face0, face1, F, rowptr, deg, nbr);
+  GFV_LAUNCH(khop_kernel<false>, dim3(gfv_div_up(N, 128)), dim3(128), 0, stream, rowptr, nbr, N, k, counts, offs,
                      (int64_t*)nullptr, (int64_t*)nullptr, flag);
-  hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, stream, counts, offs, N);
+  GFV_LAUNCH(scan_kernel, dim3(1), dim3(1024), 0, stream, counts, offs, N);
   GFV_CHECK_LAUNCH();
   return GFV_OK;
 }
@@ -151,7 +151,7 @@ extern "C" int gfv_khop_fill(int32_t N, int32_t k, const int32_t* ws, int64_t* o
   const int* offs = ws + 3 * (size_t)(N + 1);
   int* flag = const_cast<int*>(ws) + 4 * (size_t)(N + 1);
   const int* nbr = flag + 8;
-  hipLaunchKernelGGL(khop_kernel<true>, dim3(gfv_div_up(N, 128)), dim3(128), 0, stream, rowptr, nbr, N, k, (int*)nullptr, offs,
+  GFV_LAUNCH(khop_kernel<true>, dim3(gfv_div_up(N, 128)), dim3(128), 0, stream, rowptr, nbr, N, k, (int*)nullptr, offs,
                      out0, out1, flag);
   GFV_CHECK_LAUNCH();
   return GFV_OK;

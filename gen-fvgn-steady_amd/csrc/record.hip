@@ -1,0 +1,135 @@
+// Native command list (include/gfv.h gfv_record_*): the launches of one recorded step, replayed from C.  See gfv_launch.h.
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/gfv.h"
+#include "gfv_common.h"
+#include "gfv_launch.h"
+
+struct GfvRecorder {
+  struct Cmd {
+    void (*run)(const void*, hipStream_t);
+    hipStream_t st;
+    size_t off;
+  };
+  std::vector<Cmd> cmds;
+  std::vector<char> arena;   // argument blobs, 16-byte aligned
+};
+
+namespace {
+thread_local GfvRecorder* t_active = nullptr;
+std::mutex g_mu;
+std::unordered_map<int64_t, GfvRecorder*> g_lists;
+int64_t g_next = 1;
+
+// events for stream-to-stream edges: a wait refers to the event's record at the time of the call, so a small ring is enough
+constexpr int N_EVENTS = 64;
+hipEvent_t g_events[N_EVENTS];
+bool g_events_ready = false;
+int g_event_next = 0;
+hipEvent_t next_event() {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (!g_events_ready) {
+    for (int i = 0; i < N_EVENTS; ++i)
+      if (hipEventCreateWithFlags(&g_events[i], hipEventDisableTiming) != hipSuccess) return nullptr;
+    g_events_ready = true;
+  }
+  hipEvent_t e = g_events[g_event_next];
+  g_event_next = (g_event_next + 1) % N_EVENTS;
+  return e;
+}
+struct WaitBlob {
+  hipStream_t waited;
+};
+void run_wait(const void* p, hipStream_t waiter) {
+  const WaitBlob& B = *static_cast<const WaitBlob*>(p);
+  hipEvent_t e = next_event();
+  if (!e) return;
+  hipEventRecord(e, B.waited);
+  hipStreamWaitEvent(waiter, e, 0);
+}
+struct MemsetBlob {
+  void* dst;
+  int value;
+  size_t bytes;
+};
+void run_memset(const void* p, hipStream_t st) {
+  const MemsetBlob& B = *static_cast<const MemsetBlob*>(p);
+  hipMemsetAsync(B.dst, B.value, B.bytes, st);
+}
+}  // namespace
+
+GfvRecorder* gfv_rec_active() { return t_active; }
+void gfv_rec_push(GfvRecorder* r, void (*run)(const void*, hipStream_t), const void* blob, size_t bytes, hipStream_t st) {
+  const size_t off = (r->arena.size() + 15) & ~(size_t)15;
+  r->arena.resize(off + bytes);
+  memcpy(r->arena.data() + off, blob, bytes);
+  r->cmds.push_back({run, st, off});
+}
+void gfv_memset_rec(void* dst, int value, size_t bytes, hipStream_t st) {
+  const MemsetBlob b{dst, value, bytes};
+  run_memset(&b, st);
+  if (GfvRecorder* r = gfv_rec_active()) gfv_rec_push(r, run_memset, &b, sizeof(b), st);
+}
+
+extern "C" int gfv_record_begin(void) {
+  if (t_active) return GFV_ERR_ARG;
+  t_active = new GfvRecorder();
+  return GFV_OK;
+}
+extern "C" int gfv_record_count(void) { return t_active ? (int)t_active->cmds.size() : -1; }
+extern "C" int64_t gfv_record_end(void) {
+  if (!t_active) return 0;
+  GfvRecorder* r = t_active;
+  t_active = nullptr;
+  std::lock_guard<std::mutex> lk(g_mu);
+  const int64_t h = g_next++;
+  g_lists[h] = r;
+  return h;
+}
+extern "C" int gfv_record_length(int64_t handle) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  auto it = g_lists.find(handle);
+  return it == g_lists.end() ? -1 : (int)it->second->cmds.size();
+}
+extern "C" int gfv_record_replay(int64_t handle, int32_t first, int32_t last) {
+  GfvRecorder* r = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_lists.find(handle);
+    if (it == g_lists.end()) return GFV_ERR_ARG;
+    r = it->second;
+  }
+  const int n = (int)r->cmds.size();
+  if (first < 0 || last > n || first > last) return GFV_ERR_ARG;
+  if (t_active) return GFV_ERR_ARG;   // (a replay inside a recording would be recorded again)
+  const char* base = r->arena.data();
+  for (int i = first; i < last; ++i) r->cmds[i].run(base + r->cmds[i].off, r->cmds[i].st);
+  GFV_CHECK_LAUNCH();
+  return GFV_OK;
+}
+extern "C" int gfv_record_free(int64_t handle) {
+  GfvRecorder* r = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_lists.find(handle);
+    if (it == g_lists.end()) return GFV_ERR_ARG;
+    r = it->second;
+    g_lists.erase(it);
+  }
+  delete r;
+  return GFV_OK;
+}
+// `waiter` waits for everything submitted to `waited` so far (event record + stream wait); recorded like a launch
+extern "C" int gfv_stream_wait(void* waiter, void* waited) {
+  const WaitBlob b{(hipStream_t)waited};
+  hipEvent_t e = next_event();
+  if (!e) return GFV_ERR_LAUNCH;
+  if (hipEventRecord(e, (hipStream_t)waited) != hipSuccess || hipStreamWaitEvent((hipStream_t)waiter, e, 0) != hipSuccess)
+    return GFV_ERR_LAUNCH;
+  if (GfvRecorder* r = gfv_rec_active()) gfv_rec_push(r, run_wait, &b, sizeof(b), (hipStream_t)waiter);
+  return GFV_OK;
+}

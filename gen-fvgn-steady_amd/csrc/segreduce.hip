@@ -407,7 +407,7 @@ extern "C" int gfv_seg_gather_sum_ex(const float* src, const int32_t* rowptr, co
   // past a row's end and the lower occupancy cost more than the saved round trip.  This kernel moves 5.0 - 5.3 TB/s of counter
   // bytes = 0.63 - 0.66 of 8 TB/s at 8 meshes per GPU on three of its four launch shapes: profiles/r04_seg_pmc_b8.txt.)
 #define LAUNCH_VEC(LPR)                                                                                       \
-  hipLaunchKernelGGL((seg_gather_sum_vec<LPR>), dim3(gfv_xcd_grid(grid_for(n_rows, 256 / LPR))), dim3(256), 0, st, src, \
+  GFV_LAUNCH((seg_gather_sum_vec<LPR>), dim3(gfv_xcd_grid(grid_for(n_rows, 256 / LPR))), dim3(256), 0, st, src, \
                      rowptr, col, scale, src_scale, out, n_rows, accumulate)
   switch (F) {
     case 4: LAUNCH_VEC(1); break;
@@ -418,7 +418,7 @@ extern "C" int gfv_seg_gather_sum_ex(const float* src, const int32_t* rowptr, co
     case 128: LAUNCH_VEC(32); break;
     case 256: LAUNCH_VEC(64); break;
     default:
-      hipLaunchKernelGGL(seg_gather_sum_scalar, dim3(grid_for((long)n_rows * F, 256)), dim3(256), 0, st, src, rowptr,
+      GFV_LAUNCH(seg_gather_sum_scalar, dim3(grid_for((long)n_rows * F, 256)), dim3(256), 0, st, src, rowptr,
                          col, scale, src_scale, out, n_rows, F, accumulate);
   }
 #undef LAUNCH_VEC
@@ -433,9 +433,9 @@ extern "C" int gfv_gather_pair(const float* a, const int32_t* s, const int32_t* 
   if (n_edges == 0) return GFV_OK;
   hipStream_t st = (hipStream_t)stream;
   if (F == 64) {
-    hipLaunchKernelGGL((gather_pair_kernel<16>), dim3(grid_for(n_edges, 8)), dim3(256), 0, st, a, s, r, base, out, n_edges);
+    GFV_LAUNCH((gather_pair_kernel<16>), dim3(grid_for(n_edges, 8)), dim3(256), 0, st, a, s, r, base, out, n_edges);
   } else if (F == 128) {
-    hipLaunchKernelGGL((gather_pair_kernel<32>), dim3(grid_for(n_edges, 4)), dim3(256), 0, st, a, s, r, base, out, n_edges);
+    GFV_LAUNCH((gather_pair_kernel<32>), dim3(grid_for(n_edges, 4)), dim3(256), 0, st, a, s, r, base, out, n_edges);
   } else {
     return GFV_ERR_ARG;
   }
@@ -448,18 +448,18 @@ extern "C" int gfv_reduce_partials(const float* partial, int32_t n_chunks, int32
   GfvProfScope ps_(GFV_K_REDUCE, 0, 4.0 * ((double)n_chunks + 1.0) * n, stream);
   if (n <= 0) return GFV_OK;
   if (n <= 4096 && n_chunks >= 32) {
-    hipLaunchKernelGGL(reduce_partials_small_kernel, dim3((n + 31) / 32), dim3(1024), 0, (hipStream_t)stream, partial,
+    GFV_LAUNCH(reduce_partials_small_kernel, dim3((n + 31) / 32), dim3(1024), 0, (hipStream_t)stream, partial,
                        n_chunks, n, out, accumulate);
     GFV_CHECK_LAUNCH();
     return GFV_OK;
   }
   if ((n & 3) == 0 && n_chunks >= 16 && ((reinterpret_cast<size_t>(partial) | reinterpret_cast<size_t>(out)) & 15) == 0) {
-    hipLaunchKernelGGL(reduce_partials_vec_kernel, dim3((n / 4 + 63) / 64), dim3(256), 0, (hipStream_t)stream, partial,
+    GFV_LAUNCH(reduce_partials_vec_kernel, dim3((n / 4 + 63) / 64), dim3(256), 0, (hipStream_t)stream, partial,
                        n_chunks, n / 4, out, accumulate);
     GFV_CHECK_LAUNCH();
     return GFV_OK;
   }
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, partial,
+  GFV_LAUNCH(reduce_partials_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, partial,
                      n_chunks, n, out, accumulate);
   GFV_CHECK_LAUNCH();
   return GFV_OK;
@@ -473,7 +473,7 @@ extern "C" int gfv_reduce_partials_2d(const float* partial, int32_t n_chunks, in
       ((reinterpret_cast<size_t>(partial) | reinterpret_cast<size_t>(out)) & 15))
     return GFV_ERR_ARG;
   const int n4 = rows * (cols / 4);
-  hipLaunchKernelGGL(reduce_partials_2d_kernel, dim3((n4 + 63) / 64), dim3(256), 0, (hipStream_t)stream, partial, n_chunks,
+  GFV_LAUNCH(reduce_partials_2d_kernel, dim3((n4 + 63) / 64), dim3(256), 0, (hipStream_t)stream, partial, n_chunks,
                      (long)(chunk_stride / 4), n4, cols / 4, ld_out / 4, out);
   GFV_CHECK_LAUNCH();
   return GFV_OK;
@@ -495,7 +495,7 @@ extern "C" int gfv_reduce_multi(const gfv_reduce_piece_t* pieces, int32_t n_piec
     by += 4.0 * ((double)p.n_chunks + 1.0) * p.rows * p.cols;
   }
   GfvProfScope ps_(GFV_K_REDUCE, 0, by, stream);
-  hipLaunchKernelGGL(reduce_multi_kernel, dim3((unsigned)((maxn4 + 15) / 16), n_pieces), dim3(256), 0, (hipStream_t)stream, a);
+  GFV_LAUNCH(reduce_multi_kernel, dim3((unsigned)((maxn4 + 15) / 16), n_pieces), dim3(256), 0, (hipStream_t)stream, a);
   GFV_CHECK_LAUNCH();
   return GFV_OK;
 }
@@ -505,7 +505,7 @@ extern "C" int gfv_reduce_partials_seg(const float* partial, const int32_t* seg_
   GfvProfScope ps_(GFV_K_REDUCE, 0, 4.0 * 64.0 * n_seg * n, stream);
   if (n_seg <= 0 || n <= 0) return GFV_OK;
   if ((n & 3) || ((reinterpret_cast<size_t>(partial) | reinterpret_cast<size_t>(out)) & 15)) return GFV_ERR_ARG;
-  hipLaunchKernelGGL(reduce_partials_seg_kernel, dim3((n / 4 + 63) / 64, n_seg), dim3(1024), 0, (hipStream_t)stream,
+  GFV_LAUNCH(reduce_partials_seg_kernel, dim3((n / 4 + 63) / 64, n_seg), dim3(1024), 0, (hipStream_t)stream,
                      partial, seg_ptr, n / 4, out);
   GFV_CHECK_LAUNCH();
   return GFV_OK;
@@ -513,7 +513,7 @@ extern "C" int gfv_reduce_partials_seg(const float* partial, const int32_t* seg_
 
 extern "C" int gfv_transpose(const float* in, int32_t ld_in, float* out, int32_t rows, int32_t cols, void* stream) {
   if (rows <= 0 || cols <= 0) return GFV_ERR_ARG;
-  hipLaunchKernelGGL(transpose_kernel, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(256), 0, (hipStream_t)stream, in,
+  GFV_LAUNCH(transpose_kernel, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(256), 0, (hipStream_t)stream, in,
                      ld_in, out, rows, cols);
   GFV_CHECK_LAUNCH();
   return GFV_OK;
@@ -543,7 +543,7 @@ extern "C" int gfv_transpose_batch(const gfv_transpose_desc_t* descs, int32_t n,
                                    void* stream) {
   GfvProfScope ps_(GFV_K_WIMG, 0, 8.0 * (double)n * max_rows * max_cols, stream);
   if (n <= 0) return GFV_OK;
-  hipLaunchKernelGGL(transpose_batch_kernel, dim3((max_cols + 31) / 32, (max_rows + 31) / 32, n), dim3(256), 0,
+  GFV_LAUNCH(transpose_batch_kernel, dim3((max_cols + 31) / 32, (max_rows + 31) / 32, n), dim3(256), 0,
                      (hipStream_t)stream, descs);
   GFV_CHECK_LAUNCH();
   return GFV_OK;

@@ -1037,7 +1037,7 @@ extern "C" int gfv_slice_softmax_fwd(const float* xmid, const float* Ws, const f
                                      int32_t N, void* stream) {
   GfvProfScope ps_(GFV_K_SLICE, 0, 1536.0 * N, stream);   // x_mid [N,128] in, w [N,8,32] out
   if (N <= 0) return N == 0 ? GFV_OK : GFV_ERR_ARG;
-  hipLaunchKernelGGL(slice_softmax_fwd_kernel, dim3(gfv_div_up((long)N * H, 256)), dim3(256), 0, (hipStream_t)stream,
+  GFV_LAUNCH(slice_softmax_fwd_kernel, dim3(gfv_div_up((long)N * H, 256)), dim3(256), 0, (hipStream_t)stream,
                      xmid, Ws, bs, temp, w, N);
   GFV_CHECK_LAUNCH();
   return GFV_OK;
@@ -1050,7 +1050,7 @@ extern "C" int gfv_slice_softmax_bwd(const float* xmid, const float* Ws, const f
                                      void* stream) {
   GfvProfScope ps_(GFV_K_SLICE, 0, 3072.0 * N, stream);   // x_mid, w, gw in, g_x_mid out
   if (N <= 0) return N == 0 ? GFV_OK : GFV_ERR_ARG;
-  hipLaunchKernelGGL(slice_softmax_bwd_kernel, dim3(gfv_div_up((long)N * H, 256)), dim3(256), 0, (hipStream_t)stream,
+  GFV_LAUNCH(slice_softmax_bwd_kernel, dim3(gfv_div_up((long)N * H, 256)), dim3(256), 0, (hipStream_t)stream,
                      xmid, Ws, bs, temp, w, gw, gxmid, partial, N);
   GFV_CHECK_LAUNCH();
   return GFV_OK;
@@ -1066,10 +1066,10 @@ extern "C" int gfv_slice_token_partial(const float* w, const float* a, const int
   GfvProfScope ps_(GFV_K_SLICE, 0, 64.0 * 1536.0 * n_chunks, stream);   // 64-node chunks: w + a rows in
   if (n_chunks <= 0) return n_chunks == 0 ? GFV_OK : GFV_ERR_ARG;
   if (slice_mfma_on())
-    hipLaunchKernelGGL((slice_token_mfma_kernel<false>), dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, nullptr, nullptr, nullptr,
+    GFV_LAUNCH((slice_token_mfma_kernel<false>), dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, nullptr, nullptr, nullptr,
                        nullptr, const_cast<float*>(w), a, chunk_beg, chunk_end, partial);
   else
-    hipLaunchKernelGGL(slice_token_partial_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, w, a, chunk_beg,
+    GFV_LAUNCH(slice_token_partial_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, w, a, chunk_beg,
                        chunk_end, partial);
   GFV_CHECK_LAUNCH();
   return GFV_OK;
@@ -1080,7 +1080,7 @@ extern "C" int gfv_slice_softmax_token(const float* xmid, const float* Ws, const
                                        float* partial, void* stream) {
   GfvProfScope ps_(GFV_K_SLICE, 0, 64.0 * 2048.0 * n_chunks, stream);   // x_mid + a rows in, w out
   if (n_chunks <= 0) return n_chunks == 0 ? GFV_OK : GFV_ERR_ARG;
-  hipLaunchKernelGGL((slice_token_mfma_kernel<true>), dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, xmid, Ws, bs, temp, w, a,
+  GFV_LAUNCH((slice_token_mfma_kernel<true>), dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, xmid, Ws, bs, temp, w, a,
                      chunk_beg, chunk_end, partial);
   GFV_CHECK_LAUNCH();
   return GFV_OK;
@@ -1095,7 +1095,7 @@ extern "C" int gfv_slice_attention_fwd(const float* partial, const int32_t* gchu
   GfvProfScope ps_(GFV_K_SLICE, 0, 60000.0 * B, stream);
   if (B <= 0) return B == 0 ? GFV_OK : GFV_ERR_ARG;
   AttnFwdArgs a{partial, gchunk_ptr, Wq, Wk, Wv, token, norm, attn, out_token, attn_scale()};
-  hipLaunchKernelGGL(slice_attention_fwd_kernel, dim3(B, H), dim3(256), 0, (hipStream_t)stream, a);
+  GFV_LAUNCH(slice_attention_fwd_kernel, dim3(B, H), dim3(256), 0, (hipStream_t)stream, a);
   GFV_CHECK_LAUNCH();
   return GFV_OK;
 }
@@ -1106,7 +1106,7 @@ extern "C" int gfv_slice_attention_bwd(const float* gpartial, const int32_t* gch
   GfvProfScope ps_(GFV_K_SLICE, 0, 100000.0 * B, stream);
   if (B <= 0) return B == 0 ? GFV_OK : GFV_ERR_ARG;
   AttnBwdArgs a{gpartial, gchunk_ptr, Wq, Wk, Wv, token, norm, attn, g_raw, g_norm, dW_partial, attn_scale()};
-  hipLaunchKernelGGL(slice_attention_bwd_kernel, dim3(B, H), dim3(256), 0, (hipStream_t)stream, a);
+  GFV_LAUNCH(slice_attention_bwd_kernel, dim3(B, H), dim3(256), 0, (hipStream_t)stream, a);
   GFV_CHECK_LAUNCH();
   return GFV_OK;
 }
@@ -1119,12 +1119,12 @@ extern "C" int gfv_deslice(const float* w, const float* T, const int32_t* batch,
   if (dmfma && slice_mfma_on() && !(accumulate & 1)) {
     // workgroups of one graph on the matrix cores, then (unless the caller says the batch is ONE graph: accumulate bit 2) the
     // ones that straddle two graphs
-    hipLaunchKernelGGL(deslice_mfma_kernel, dim3(gfv_div_up((long)N * H, 256)), dim3(256), 0, (hipStream_t)stream, w, T, batch, out, N);
+    GFV_LAUNCH(deslice_mfma_kernel, dim3(gfv_div_up((long)N * H, 256)), dim3(256), 0, (hipStream_t)stream, w, T, batch, out, N);
     if (!(accumulate & 4))
-      hipLaunchKernelGGL(deslice_kernel, dim3(gfv_div_up((long)N * H, 256)), dim3(256), 0, (hipStream_t)stream, w, T, batch, out, N, 2);
+      GFV_LAUNCH(deslice_kernel, dim3(gfv_div_up((long)N * H, 256)), dim3(256), 0, (hipStream_t)stream, w, T, batch, out, N, 2);
   } else {
     accumulate &= 1;
-    hipLaunchKernelGGL(deslice_kernel, dim3(gfv_div_up((long)N * H, 256)), dim3(256), 0, (hipStream_t)stream, w, T, batch,
+    GFV_LAUNCH(deslice_kernel, dim3(gfv_div_up((long)N * H, 256)), dim3(256), 0, (hipStream_t)stream, w, T, batch,
                        out, N, accumulate);
   }
   GFV_CHECK_LAUNCH();
@@ -1135,7 +1135,7 @@ extern "C" int gfv_slice_gw(const float* a, const float* T, const float* add, co
                             int32_t accumulate, void* stream) {
   GfvProfScope ps_(GFV_K_SLICE, 0, (accumulate ? 3072.0 : 1536.0) * N, stream);   // a in, gw out (+ gw in, fx_mid)
   if (N <= 0) return N == 0 ? GFV_OK : GFV_ERR_ARG;
-  hipLaunchKernelGGL(slice_gw_kernel, dim3(gfv_div_up((long)N * H, 256)), dim3(256), 0, (hipStream_t)stream, a, T, add,
+  GFV_LAUNCH(slice_gw_kernel, dim3(gfv_div_up((long)N * H, 256)), dim3(256), 0, (hipStream_t)stream, a, T, add,
                      batch, gw, N, accumulate);
   GFV_CHECK_LAUNCH();
   return GFV_OK;
@@ -1153,13 +1153,13 @@ extern "C" int gfv_slice_post_bwd(const float* xmid, const float* Ws, const floa
   const dim3 grid(gfv_div_up((long)N * H, 256));
   if (mfma) {
     // workgroups of one graph on the matrix cores; the ones that straddle two graphs (none in a one-graph batch) by the scalar form
-    hipLaunchKernelGGL(slice_post_bwd_mfma_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+    GFV_LAUNCH(slice_post_bwd_mfma_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
     if (n_graphs != 1) {
       a.only_straddling = 1;
-      hipLaunchKernelGGL(slice_post_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+      GFV_LAUNCH(slice_post_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
     }
   } else {
-    hipLaunchKernelGGL(slice_post_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+    GFV_LAUNCH(slice_post_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
   }
   GFV_CHECK_LAUNCH();
   return GFV_OK;

@@ -29,17 +29,17 @@ static void launch_h(const gfv_rowtile_args_t* args, int ragged, int lnm, hipStr
   for (int i = 0; i < args->nseg; ++i) csr = csr || args->seg[i].csr_rowptr != nullptr || args->seg[i].save != nullptr;
   if (csr) {   // (the caller checked: plain instantiation only)
     if (iop == GFV_OP_BIAS_GELU)
-      hipLaunchKernelGGL((tchain_kernel<1, 0, false, true, NW, true, 1>), dim3(gfv_xcd_grid(tiles)), blk, 0, stream, *args);
+      GFV_LAUNCH((tchain_kernel<1, 0, false, true, NW, true, 1>), dim3(gfv_xcd_grid(tiles)), blk, 0, stream, *args);
     else
-      hipLaunchKernelGGL((tchain_kernel<1, 0, false, true, NW, true>), dim3(gfv_xcd_grid(tiles)), blk, 0, stream, *args);
+      GFV_LAUNCH((tchain_kernel<1, 0, false, true, NW, true>), dim3(gfv_xcd_grid(tiles)), blk, 0, stream, *args);
     return;
   }
-  if (ragged) hipLaunchKernelGGL((tchain_kernel<1, 0, true, true, NW>), wgs, blk, 0, stream, *args);
+  if (ragged) GFV_LAUNCH((tchain_kernel<1, 0, true, true, NW>), wgs, blk, 0, stream, *args);
   else if (lnm == 0 && iop != 0) gfv_internal_tchain_fwd_plain(args, 1, iop, stream);
-  else if (lnm == 0) hipLaunchKernelGGL((tchain_kernel<1, 0, false, true, NW>), wgs, blk, 0, stream, *args);
-  else if (lnm == 1 && iop == GFV_OP_MUL_DGELU) hipLaunchKernelGGL((tchain_kernel<1, 1, false, true, NW, false, 2>), wgs, blk, 0, stream, *args);
-  else if (lnm == 1) hipLaunchKernelGGL((tchain_kernel<1, 1, false, true, NW>), wgs, blk, 0, stream, *args);
-  else hipLaunchKernelGGL((tchain_kernel<1, 2, false, true, NW>), wgs, blk, 0, stream, *args);
+  else if (lnm == 0) GFV_LAUNCH((tchain_kernel<1, 0, false, true, NW>), wgs, blk, 0, stream, *args);
+  else if (lnm == 1 && iop == GFV_OP_MUL_DGELU) GFV_LAUNCH((tchain_kernel<1, 1, false, true, NW, false, 2>), wgs, blk, 0, stream, *args);
+  else if (lnm == 1) GFV_LAUNCH((tchain_kernel<1, 1, false, true, NW>), wgs, blk, 0, stream, *args);
+  else GFV_LAUNCH((tchain_kernel<1, 2, false, true, NW>), wgs, blk, 0, stream, *args);
 }
 
 // fast-path launcher used by gfv_rowtile_chain (rowtile.hip); ragged: the instantiation that also takes ragged shapes
@@ -71,10 +71,10 @@ int gfv_internal_tchain_launch(const gfv_rowtile_args_t* args_in, int ragged, in
   // fp32-MFMA form: the run-time-op instantiations only (it is the reference form of the tests, not the product path)
   bool csr = false;
   for (int i = 0; i < args->nseg; ++i) csr = csr || args->seg[i].csr_rowptr != nullptr || args->seg[i].save != nullptr;
-  if (csr) hipLaunchKernelGGL((tchain_kernel<1, 0, false, false, 4, true>), dim3(gfv_xcd_grid((args->M + 63) / 64)), blk, 0, stream, *args);
-  else if (ragged) hipLaunchKernelGGL((tchain_kernel<1, 0, true, false>), wgs, blk, 0, stream, *args);
+  if (csr) GFV_LAUNCH((tchain_kernel<1, 0, false, false, 4, true>), dim3(gfv_xcd_grid((args->M + 63) / 64)), blk, 0, stream, *args);
+  else if (ragged) GFV_LAUNCH((tchain_kernel<1, 0, true, false>), wgs, blk, 0, stream, *args);
   else if (lnm == 0) gfv_internal_tchain_fwd_plain(args, 0, 0, stream);
-  else if (lnm == 1) hipLaunchKernelGGL((tchain_kernel<1, 1, false, false>), wgs, blk, 0, stream, *args);
-  else hipLaunchKernelGGL((tchain_kernel<1, 2, false, false>), wgs, blk, 0, stream, *args);
+  else if (lnm == 1) GFV_LAUNCH((tchain_kernel<1, 1, false, false>), wgs, blk, 0, stream, *args);
+  else GFV_LAUNCH((tchain_kernel<1, 2, false, false>), wgs, blk, 0, stream, *args);
   return 0;
 }

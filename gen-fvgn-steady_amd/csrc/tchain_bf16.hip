@@ -8,9 +8,9 @@ void gfv_internal_tchain_launch_bf16(const gfv_rowtile_args_t* args, int ragged,
   const dim3 wgs(tiles), blk(256);
   bool csr = false;
   for (int i = 0; i < args->nseg; ++i) csr = csr || args->seg[i].csr_rowptr != nullptr || args->seg[i].save != nullptr;
-  if (csr) hipLaunchKernelGGL((tchain_kernel<1, 0, false, true, 4, true, 0, true>), dim3(gfv_xcd_grid(tiles)), blk, 0, stream, *args);
-  else if (ragged) hipLaunchKernelGGL((tchain_kernel<1, 0, true, true, 4, false, 0, true>), wgs, blk, 0, stream, *args);
-  else if (lnm == 0) hipLaunchKernelGGL((tchain_kernel<1, 0, false, true, 4, false, 0, true>), wgs, blk, 0, stream, *args);
-  else if (lnm == 1) hipLaunchKernelGGL((tchain_kernel<1, 1, false, true, 4, false, 0, true>), wgs, blk, 0, stream, *args);
-  else hipLaunchKernelGGL((tchain_kernel<1, 2, false, true, 4, false, 0, true>), wgs, blk, 0, stream, *args);
+  if (csr) GFV_LAUNCH((tchain_kernel<1, 0, false, true, 4, true, 0, true>), dim3(gfv_xcd_grid(tiles)), blk, 0, stream, *args);
+  else if (ragged) GFV_LAUNCH((tchain_kernel<1, 0, true, true, 4, false, 0, true>), wgs, blk, 0, stream, *args);
+  else if (lnm == 0) GFV_LAUNCH((tchain_kernel<1, 0, false, true, 4, false, 0, true>), wgs, blk, 0, stream, *args);
+  else if (lnm == 1) GFV_LAUNCH((tchain_kernel<1, 1, false, true, 4, false, 0, true>), wgs, blk, 0, stream, *args);
+  else GFV_LAUNCH((tchain_kernel<1, 2, false, true, 4, false, 0, true>), wgs, blk, 0, stream, *args);
 }

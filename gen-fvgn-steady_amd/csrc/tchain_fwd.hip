@@ -11,7 +11,7 @@
 
 void gfv_internal_tchain_fwd_plain(const gfv_rowtile_args_t* args, int f16, int iop, hipStream_t stream) {
   const dim3 wgs((args->M + 63) / 64), blk(256);
-  if (!f16) hipLaunchKernelGGL((tchain_kernel<1, 0, false, false>), wgs, blk, 0, stream, *args);
-  else if (iop == GFV_OP_BIAS_GELU) hipLaunchKernelGGL((tchain_kernel<1, 0, false, true, 4, false, 1>), wgs, blk, 0, stream, *args);
-  else hipLaunchKernelGGL((tchain_kernel<1, 0, false, true, 4, false, 2>), wgs, blk, 0, stream, *args);
+  if (!f16) GFV_LAUNCH((tchain_kernel<1, 0, false, false>), wgs, blk, 0, stream, *args);
+  else if (iop == GFV_OP_BIAS_GELU) GFV_LAUNCH((tchain_kernel<1, 0, false, true, 4, false, 1>), wgs, blk, 0, stream, *args);
+  else GFV_LAUNCH((tchain_kernel<1, 0, false, true, 4, false, 2>), wgs, blk, 0, stream, *args);
 }

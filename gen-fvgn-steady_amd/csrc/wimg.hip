@@ -60,9 +60,9 @@ extern "C" size_t gfv_weight_image_bytes(int32_t N, int32_t K) {
 extern "C" int gfv_weight_absmax(const gfv_wimg_desc_t* descs_dev, int32_t n_desc, float* wmax, void* stream) {
   GfvProfScope ps_(GFV_K_WIMG, 0, 4.0 * 1181539.0, stream);
   if (!descs_dev || !wmax || n_desc < 0) return GFV_ERR_ARG;
-  if (hipMemsetAsync(wmax, 0, sizeof(float), (hipStream_t)stream) != hipSuccess) return GFV_ERR_LAUNCH;
+  gfv_memset_rec(wmax, 0, sizeof(float), (hipStream_t)stream);   // (recordable: gfv_launch.h)
   if (n_desc == 0) return GFV_OK;
-  hipLaunchKernelGGL(wabsmax_kernel, dim3(4, n_desc), dim3(256), 0, (hipStream_t)stream, descs_dev, wmax);
+  GFV_LAUNCH(wabsmax_kernel, dim3(4, n_desc), dim3(256), 0, (hipStream_t)stream, descs_dev, wmax);
   GFV_CHECK_LAUNCH();
   return GFV_OK;
 }
@@ -73,7 +73,7 @@ extern "C" int gfv_weight_images(const gfv_wimg_desc_t* descs_dev, int32_t n_des
   GfvProfScope ps_(GFV_K_WIMG, 0, 32.0 * (double)max_frags * n_desc, stream);
   if (!descs_dev || !wmax || n_desc < 0 || max_frags < 0) return GFV_ERR_ARG;
   if (n_desc == 0 || max_frags == 0) return GFV_OK;
-  hipLaunchKernelGGL(wimg_kernel, dim3((unsigned)((max_frags + 255) / 256), n_desc), dim3(256), 0, (hipStream_t)stream,
+  GFV_LAUNCH(wimg_kernel, dim3((unsigned)((max_frags + 255) / 256), n_desc), dim3(256), 0, (hipStream_t)stream,
                      descs_dev, wmax, gfv_f16split_enabled() == 3 ? 1 : 0);
   GFV_CHECK_LAUNCH();
   return GFV_OK;

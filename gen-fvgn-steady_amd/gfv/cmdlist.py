@@ -22,28 +22,64 @@ from __future__ import annotations
 import torch
 
 # entry points that return a value to the host and launch nothing: never recorded
+import os
+
+# GFV_CMDLIST_NATIVE=0: the round-2 form - every library call of the recorded step kept as (ctypes function, arguments) and
+# re-issued from a Python loop.  Default (round 5): the library notes its own kernel launches while the step is recorded
+# (include/gfv.h gfv_record_*, csrc/gfv_launch.h) and replays them from C - one hipLaunchKernelGGL per launch, no ctypes call,
+# no argument checks, no kernel-family choice; only the few host-side commands (tensor copies, collectives) stay in the Python
+# list, each with the number of native launches that precede it.  Host time to issue the 5 k-cell cavity step: 1.22 -> see
+# profiles/r05_launch_cost.txt.
+NATIVE = os.environ.get("GFV_CMDLIST_NATIVE", "1") != "0"
+
 _QUERIES = frozenset((
     "gfv_abi_version", "gfv_struct_size", "gfv_rowtile_tiles", "gfv_rowtile_last_path", "gfv_dw_chunks", "gfv_dw_slabs",
     "gfv_linear_dw_workspace_floats", "gfv_dw_multi_workspace_floats", "gfv_f16split_enabled", "gfv_set_f16split", "gfv_set_f16split_thread", "gfv_hidden_size",
     "gfv_weight_image_bytes", "gfv_normalizer_blocks", "gfv_slice_softmax_bwd_blocks", "gfv_profile_enable",
     "gfv_profile_collect", "gfv_profile_reset", "gfv_profile_set_sizes", "gfv_status_flags", "gfv_rowtile_dw_partials",
-    "gfv_rowtile_fuses_dw", "gfv_graph_norm_workspace_bytes", "gfv_plan_create", "gfv_plan_destroy", "gfv_plan_table", "gfv_plan_sizes"))
+    "gfv_rowtile_fuses_dw", "gfv_graph_norm_workspace_bytes", "gfv_plan_create", "gfv_plan_destroy", "gfv_plan_table", "gfv_plan_sizes",
+    "gfv_record_begin", "gfv_record_count", "gfv_record_end", "gfv_record_length", "gfv_record_replay", "gfv_record_free"))
 
 
 class CommandList:
     def __init__(self):
-        self.cmds = []          # (callable, args, stream or None)
+        self.cmds = []          # (callable, args, stream or None[, native launches issued before it])
         self.pool = None
         self.main = None        # the stream the step was recorded on
         self.keep = []          # results of recorded calls that returned tensors (kept alive with the list)
+        self.native = 0         # handle of the library's own list of this step's launches (0: Python-level list)
+        self.n_native = 0
 
     def __len__(self):
-        return len(self.cmds)
+        return len(self.cmds) + self.n_native
+
+    def __del__(self):
+        if self.native:
+            try:
+                from . import lib as L
+                L.load(raw=True).gfv_record_free(self.native)
+            except Exception:
+                pass
 
     def replay(self):
         cur = torch.cuda.current_stream()
         if cur != self.main:
             raise RuntimeError("a command list replays on the stream it was recorded on")
+        if self.native:
+            from . import lib as L
+            lib, h, pos = L.load(raw=True), self.native, 0
+            for fn, args, st, idx in self.cmds:
+                if idx > pos:
+                    L.check(lib.gfv_record_replay(h, pos, idx), "gfv_record_replay")
+                    pos = idx
+                if st is None or st == cur:
+                    fn(*args)
+                else:
+                    with torch.cuda.stream(st):
+                        fn(*args)
+            if self.n_native > pos:
+                L.check(lib.gfv_record_replay(h, pos, self.n_native), "gfv_record_replay")
+            return
         for fn, args, st in self.cmds:
             if st is None or st == cur:
                 fn(*args)
@@ -72,7 +108,11 @@ def call(fn, *args):
     finally:
         _IN_CALL -= 1
     if _ACTIVE is not None:
-        _ACTIVE.cmds.append((fn, args, torch.cuda.current_stream()))
+        if _ACTIVE.native:
+            from . import lib as L
+            _ACTIVE.cmds.append((fn, args, torch.cuda.current_stream(), L.load(raw=True).gfv_record_count()))
+        else:
+            _ACTIVE.cmds.append((fn, args, torch.cuda.current_stream()))
     return r
 
 
@@ -122,6 +162,10 @@ class _RecordingLib:
             self._cache[name] = f
             return f
         cmds = self._target.cmds
+        if self._target.native:
+            # the library notes its own launches (gfv_record_begin is open on this thread): nothing to keep here
+            self._cache[name] = f
+            return f
 
         def launch(*args):
             rc = f(*args)
@@ -148,6 +192,9 @@ class record:
         self._ctx = torch.cuda.use_mem_pool(self.cl.pool)
         self._ctx.__enter__()
         _ACTIVE = self.cl
+        if NATIVE:
+            L.check(L.load(raw=True).gfv_record_begin(), "gfv_record_begin")
+            self.cl.native = -1   # (open; the handle arrives at the end)
         L._recording = _RecordingLib(L.load(raw=True), self.cl)
         self._guard = None
         if __import__("os").environ.get("GFV_CMDLIST_GUARD", "1") != "0":
@@ -162,5 +209,12 @@ class record:
             self._guard.__exit__(*exc)
         L._recording = None
         _ACTIVE = None
+        if self.cl.native:
+            lib = L.load(raw=True)
+            self.cl.n_native = max(lib.gfv_record_count(), 0)
+            self.cl.native = int(lib.gfv_record_end())
+            if exc and exc[0] is not None and self.cl.native:
+                lib.gfv_record_free(self.cl.native)
+                self.cl.native = 0
         self._ctx.__exit__(*exc)
         return False

@@ -193,7 +193,7 @@ class Engine:
                 # ONE side queue: the weight-gradient launches share one slab workspace and the stand-in gradient blocks, so
                 # two side queues would race on them (the several-queues experiment of round 2 is gone with its knob)
                 e._sides = [e._side]
-            cmdlist.call(e._side.wait_stream, torch.cuda.current_stream())
+            L.stream_wait(e._side, torch.cuda.current_stream())
             # tensors the side stream reads must outlive this call: the caching allocator would hand their blocks to
             # the next allocation on the main stream while the side stream is still reading them
             e._keep.extend(t for t in self.keep if t is not None)
@@ -277,7 +277,7 @@ class Engine:
         self.flush()
         if self.overlap and self._side is not None:
             for sd in self._sides:
-                cmdlist.call(torch.cuda.current_stream().wait_stream, sd)
+                L.stream_wait(torch.cuda.current_stream(), sd)
         self._keep.clear()
 
     # ------------------------------------------------------------------------------------------------------------

@@ -171,6 +171,13 @@ _SIGNATURES = {
     "gfv_plan_destroy": (C.c_int, [C.c_void_p]),
     "gfv_plan_table": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
     "gfv_plan_sizes": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
+    "gfv_record_begin": (C.c_int, []),
+    "gfv_record_count": (C.c_int, []),
+    "gfv_record_end": (C.c_int64, []),
+    "gfv_record_length": (C.c_int, [C.c_int64]),
+    "gfv_record_replay": (C.c_int, [C.c_int64, C.c_int32, C.c_int32]),
+    "gfv_record_free": (C.c_int, [C.c_int64]),
+    "gfv_stream_wait": (C.c_int, [C.c_void_p, C.c_void_p]),
 }
 
 
@@ -229,6 +236,12 @@ def load(raw=False):
 
 def stream_ptr():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def stream_wait(waiter, waited):
+    """`waiter.wait_stream(waited)` through the library (include/gfv.h gfv_stream_wait): the same event record + stream wait,
+    and part of a natively recorded step (gfv/cmdlist.py)."""
+    check(load().gfv_stream_wait(C.c_void_p(waiter.cuda_stream), C.c_void_p(waited.cuda_stream)), "gfv_stream_wait")
 
 
 def ptr(t):

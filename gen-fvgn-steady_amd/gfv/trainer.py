@@ -296,9 +296,9 @@ class TrainStep:
             return
         if self._comm is None:
             self._comm = torch.cuda.Stream()
-        cmdlist.call(self._comm.wait_stream, torch.cuda.current_stream())
+        L.stream_wait(self._comm, torch.cuda.current_stream())
         for sd in self.engine._sides:
-            cmdlist.call(self._comm.wait_stream, sd)        # the weight-gradient kernels run there
+            L.stream_wait(self._comm, sd)        # the weight-gradient kernels run there
         with torch.cuda.stream(self._comm):
             cmdlist.call(self._allreduce_upper)
         self._early = True

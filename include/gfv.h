@@ -600,6 +600,26 @@ int gfv_plan_table(const gfv_plan_t* plan, int32_t which, const void** ptr, int6
 /* sizes5 = {N, E, C, Sigma, S = 2 n_stencil_pairs + n_support_pairs} */
 int gfv_plan_sizes(const gfv_plan_t* plan, int64_t* sizes5);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Native command list (round 5).  Between gfv_record_begin and gfv_record_end every kernel launch the CALLING THREAD issues
+ * through this library is executed as usual AND noted - kernel, grid, block, dynamic LDS, stream, arguments by value.
+ * gfv_record_replay(handle, first, last) issues the noted launches [first, last) again, on the streams they were recorded on,
+ * with no host work but the launches themselves.  What makes a replay valid is the caller's business: the device buffers the
+ * recorded arguments point to must still be the step's buffers (gfv/cmdlist.py records inside a private torch memory pool), and
+ * host-side decisions (shapes, kernel families, product form) are frozen at record time.  gfv_stream_wait(waiter, waited) is
+ * the stream-to-stream edge of such a list: `waiter` waits for everything submitted to `waited` so far (recorded like a launch).
+ * gfv_record_count: launches noted so far by the calling thread's open recording (-1: none open).  Replaces, for the replayed
+ * step, the per-launch Python / ctypes / argument-check path (the reference pays the same per-op host cost in PyTorch eager:
+ * pre_train_Adam.py:158-191).
+ * ---------------------------------------------------------------------------------------------------------- */
+int gfv_record_begin(void);
+int gfv_record_count(void);
+int64_t gfv_record_end(void);                 /* -> handle (> 0), 0 if no recording was open */
+int gfv_record_length(int64_t handle);
+int gfv_record_replay(int64_t handle, int32_t first, int32_t last);
+int gfv_record_free(int64_t handle);
+int gfv_stream_wait(void* waiter_stream, void* waited_stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -71,7 +71,7 @@ def main():
     assert 0 < split < ts.flat_g.numel() and ts._comm is not None and not ts._early, (split, ts._comm, ts._early)
     if mode == "list":
         (cl, _, early), = ts._graphs.values()
-        assert early and sum(1 for _, _, st in cl.cmds if st is not None and st == ts._comm) == 1, "the early bucket is not part of the command list"
+        assert early and sum(1 for c in cl.cmds if c[2] is not None and c[2] == ts._comm) == 1, "the early bucket is not part of the command list"
     mine = torch.cat([ts.P[k].reshape(-1) for k in ts.P] + [model.node_norm.acc_sum.reshape(-1),
                                                           model.node_norm.acc_sum_squared.reshape(-1),
                                                           model.node_norm.acc_count.reshape(-1)]).cpu()

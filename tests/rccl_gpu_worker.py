@@ -87,7 +87,7 @@ def main():
             # command list: the two accumulating steps run eager (2 hook calls), two warm-up steps (2), the recording (1): the
             # replays carry the early bucket INSIDE the list (no hook call), and every step's late exchange joins an early one
             ok = ok and calls.get("early_pending", 0) == NSTEPS and calls["bucket"] == 5 and ts._comm is not None
-            n_comm = sum(1 for _, _, st in next(iter(ts._graphs.values()))[0].cmds if st is not None and st == ts._comm)
+            n_comm = sum(1 for c in next(iter(ts._graphs.values()))[0].cmds if c[2] is not None and c[2] == ts._comm)
             ok = ok and n_comm == 1
             print("RCCLLIST recorded_on_comm_stream", n_comm)
         print(f"RCCLRESULT graph={ {False: 0, True: 1, 'list': 2}[use_graph] } same={int(same)} bucket={calls['bucket']} allreduce={calls['allreduce']} "

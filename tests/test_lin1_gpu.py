@@ -36,7 +36,7 @@ def _both(M, segs, layer, outs, wi, per_run=None, **kw):
     return paths
 
 
-@pytest.mark.parametrize("M", [5000, 1025, 2048])
+@pytest.mark.parametrize("M", [5000, 1025, 2048, 17000, 33])   # (<= 16 384 rows: the small-tile form, csrc/lin1s.hip; above: csrc/lin1.hip)
 def test_lean_single_layer_kernel_against_the_chain_kernel_and_float64(M):
     from gfv import ops
     g = torch.Generator().manual_seed(M)
@@ -88,8 +88,7 @@ def test_lean_single_layer_kernel_against_the_chain_kernel_and_float64(M):
 
 
 def test_lean_kernel_leaves_what_it_does_not_cover_to_the_chain():
-    """A one-pass GELU' launch that asks for the scales of its output rows, a gathered segment or fewer rows than
-    GFV_LIN1_MIN_M stays on the chain kernel."""
+    """A one-pass GELU' launch that asks for the scales of its output rows or a gathered segment stays on the chain kernel."""
     from gfv import lib as L, ops
     g = torch.Generator().manual_seed(3)
     M = 3000
@@ -105,13 +104,13 @@ def test_lean_kernel_leaves_what_it_does_not_cover_to_the_chain():
     idx = torch.randint(0, M, (M,), generator=g).int().cuda()
     ops.rowtile_chain(M, [ops.Seg(x, idx)], [ops.LayerSpec(W)], [o], wimg=wi)
     assert L.load().gfv_rowtile_last_path() == 5
-    ops.rowtile_chain(512, [ops.Seg(x)], [ops.LayerSpec(W)], [o], wimg=wi)
-    assert L.load().gfv_rowtile_last_path() == 5
+    ops.rowtile_chain(512, [ops.Seg(x)], [ops.LayerSpec(W)], [o], wimg=wi)   # (round 5: short launches take the small-tile form)
+    assert L.load().gfv_rowtile_last_path() == 5 + 32
     ops.rowtile_chain(M, [ops.Seg(x)], [ops.LayerSpec(W)], [o], wimg=wi)
     assert L.load().gfv_rowtile_last_path() == 5 + 32
 
 
-@pytest.mark.parametrize("M", [3000, 1100])
+@pytest.mark.parametrize("M", [3000, 1100, 16500])
 def test_lean_kernel_layernorm_prologue_and_gelu_prime_epilogue(M):
     """The two remaining Transolver launches the lean kernel takes: linear_pre behind LayerNorm ln_2 (128 -> 256) and the
     adjoint of linear_post (gradient (+ addend, kept) x W_post -> 256 wide, x gelu'(z)), with the per-16-row scales of the
@@ -153,7 +152,7 @@ def test_lean_kernel_layernorm_prologue_and_gelu_prime_epilogue(M):
     assert torch.equal(gsum[0], gsum[1]) and torch.equal(gs[0][0, :(M + 15) // 16], gs[1][0, :(M + 15) // 16])
 
 
-@pytest.mark.parametrize("M", [3000, 1100, 1089])
+@pytest.mark.parametrize("M", [3000, 1100, 1089, 16500])
 def test_lean_kernel_layernorm_backward_epilogue(M):
     """The adjoint of linear_pre behind LayerNorm ln_2: g_fx1 = LNbwd(g_z [M,256] W; fx1, gamma) + residual, and the per-tile
     (dgamma, dbeta) partials for the reduction launch - against the chain kernel and float64 autograd."""
@@ -186,7 +185,7 @@ def test_lean_kernel_layernorm_backward_epilogue(M):
     assert rel(part[0].sum(0), part[1].sum(0)) < 2e-6
 
 
-@pytest.mark.parametrize("M,E", [(3000, 9000), (1100, 2500)])
+@pytest.mark.parametrize("M,E", [(3000, 9000), (1100, 2500), (16500, 50000)])
 def test_lean_kernel_segmented_sum_prologue(M, E):
     """The per-side scatter of the factored EdgeBlock's adjoint in front of its node-level Linear: rows = sums of gz1 rows by
     sender / by receiver (CSR, some rows empty), the assembled rows written out - against the chain kernel and float64."""
