@@ -492,32 +492,31 @@ def main():
     fp32_form = None
     if ts.engine.f16split and not args.skip_fp32_form:
         ts_use_graph = ts.use_graph
-        ts.use_graph, ts.engine.f16split = False, False
+        ts.engine.f16split = False      # (same launch mode as `value`: a form change re-records the list, Engine.capture_signature)
         lib.gfv_set_f16split(0)
-        for _ in range(3):
+        for _ in range(5):
             ts.step()
         nf = max(5, min(20, args.steps))
         el = timed(nf)
         lib.gfv_set_f16split(1)
         ts.use_graph, ts.engine.f16split = ts_use_graph, True
         fp32_form = {"value": round(world * args.meshes_per_gpu * nf / el, 3), "ms_per_step": round(1e3 * el / nf, 4),
-                     "steps": nf, "note": "eager launches, all products on v_mfma_f32_16x16x4_f32 (GFV_F16SPLIT=0)"}
+                     "steps": nf, "note": f"launch mode {used}, all products on v_mfma_f32_16x16x4_f32 (GFV_F16SPLIT=0)"}
 
     # ---- and with ONE fp16 x fp16 product per term (the reduced-precision form, include/gfv.h gfv_set_f16split(2)): the
     # counterpart of the reference's autocast runs (BASELINE configs 3 / 5), reported beside the headline, never as it ----
     f16_form = None
     if ts.engine.f16split and not args.skip_fp32_form:
         ts_use_graph = ts.use_graph
-        ts.use_graph = False
         lib.gfv_set_f16split(2)
-        for _ in range(3):
+        for _ in range(5):
             ts.step()
         nf = max(5, min(20, args.steps))
         el = timed(nf)
         lib.gfv_set_f16split(1)
         ts.use_graph = ts_use_graph
         f16_form = {"value": round(world * args.meshes_per_gpu * nf / el, 3), "ms_per_step": round(1e3 * el / nf, 4),
-                    "steps": nf, "note": "eager launches, single fp16 x fp16 products with fp32 accumulation (GFV_F16SPLIT=2): "
+                    "steps": nf, "note": f"launch mode {used}, single fp16 x fp16 products with fp32 accumulation (GFV_F16SPLIT=2): "
                                          "NOT the form `value` is measured on.  Stated tolerances against the fp32 oracle "
                                          "(tests/golden/cases.py LOWP_TOL; asserted by tests/test_model_gpu.py and, on this "
                                          "mesh, tests/test_fullsize_gpu.py): fields 2e-4, residual losses 2e-3, log-loss 1e-5, "
@@ -530,18 +529,17 @@ def main():
     bf16_form = None
     if ts.engine.f16split and not args.skip_fp32_form:
         ts_use_graph = ts.use_graph
-        ts.use_graph = False
         lib.gfv_set_f16split(3)
-        for _ in range(3):
+        for _ in range(5):
             ts.step()
         nf = max(5, min(20, args.steps))
         el = timed(nf)
         lib.gfv_set_f16split(1)
         ts.use_graph = ts_use_graph
-        for _ in range(2):
-            ts.step()   # (back in the default form: the images are rebuilt by the step)
+        for _ in range(5):
+            ts.step()   # (back in the default form: the images are rebuilt, the list re-recorded)
         bf16_form = {"value": round(world * args.meshes_per_gpu * nf / el, 3), "ms_per_step": round(1e3 * el / nf, 4),
-                     "steps": nf, "note": "eager launches, single bf16 x bf16 products with fp32 accumulation (GFV_F16SPLIT=3, "
+                     "steps": nf, "note": f"launch mode {used}, single bf16 x bf16 products with fp32 accumulation (GFV_F16SPLIT=3, "
                                           "v_mfma_f32_16x16x32_bf16): NOT the form `value` is measured on.  Stated tolerances against "
                                           "the fp32 oracle (tests/golden/cases.py BF16_TOL; asserted by tests/test_model_gpu.py; what "
                                           "the form computes is pinned per kernel family by tests/test_bf16_form_gpu.py)",

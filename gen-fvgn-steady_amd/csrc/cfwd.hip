@@ -24,9 +24,10 @@
 // (profiles/r05_cfwd.txt, in-step averages): 5 k-row launches 11.9 us against 25 (NodeBlock), 17.5 against 27 (EdgeBlock, 10 k
 // rows), 12.0 against 22 (encoder); 25 k-row NodeBlock launches 30.9 us with 32-row tiles, 35.6 with 64-row tiles (84 KB of LDS:
 // one workgroup per CU) against 35 for the row-owner chain; 75 k-row EdgeBlock launches 78 - 83 us against 80.  So: 32-row tiles
-// up to GFV_CFWD_TG2_MAX_M rows (default = every launch the family takes), nothing above GFV_CFWD_MAX_M = 40 000 rows (the
-// 75 k-row edge launches of the headline mesh stay with the row-owner chain, whose 64 rows share one weight stream through
-// LDS), the encoders' narrow inputs up to GFV_CFWD_RAG_MAX_M = 16 384 rows (33 us against 30 at 25 k rows).
+// up to GFV_CFWD_TG2_MAX_M = 40 000 rows, 64-row tiles up to GFV_CFWD_MAX_M = 100 000 rows (edge-level launches of 50 k rows:
+// 3.26 against 3.35 ms per step on a 25 k-cell mesh, of 75 k rows: 3.67 against 3.70 on the headline mesh; beyond that - 8
+// meshes per GPU - the row-owner chain, whose 64 rows share one weight stream through LDS), the encoders' narrow inputs up to
+// GFV_CFWD_RAG_MAX_M = 16 384 rows (33 us against 30 at 25 k rows).
 #include <cstdlib>
 
 #include "tchain_kernel.h"
@@ -345,7 +346,7 @@ void cf_launch(const gfv_rowtile_args_t& a, int tg, int lowp, hipStream_t stream
 // whether the launch would be taken.  `args` carries `hidden` (the launcher of rowtile.hip fills it in).
 int gfv_internal_cfwd_try(const gfv_rowtile_args_t* a, int lowp, hipStream_t stream, int dry) {
   static const int on = cf_env("GFV_CFWD", 1);
-  static const int max_m = cf_env("GFV_CFWD_MAX_M", 40000);
+  static const int max_m = cf_env("GFV_CFWD_MAX_M", 100000);
   static const int tg2_max = cf_env("GFV_CFWD_TG2_MAX_M", 40000);
   static const int rag_max = cf_env("GFV_CFWD_RAG_MAX_M", 16384);
   if (!on || a->nlayers != 3 || a->M > max_m || a->M < 1 || (a->flags & (GFV_CHAIN_ROW_OWNER | GFV_CHAIN_COLUMN_OWNER))) return 0;

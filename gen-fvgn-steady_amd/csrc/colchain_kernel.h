@@ -27,11 +27,8 @@
 
 namespace {
 
-// -DGFV_ABL=<bits>: ablations for timing experiments (profiles/tools/colchain_bwd_phases.py; the results are garbage):
-// 1 = no MFMA issued, 2 = fragment / transposed-operand LDS reads replaced by register constants, 4 = no erfc in the epilogues
-#ifndef GFV_ABL
-#define GFV_ABL 0
-#endif
+// (Round 4's ablation switches - GFV_ABL: no MFMA / no fragment reads / no erfc; GFV_DW24, GFV_SKEW_WAVES, GFV_FENCE_MASK - are
+// gone with round 5: their results are recorded in profiles/r04_colchain_phases.txt, the kept forms are the code below.)
 constexpr int CC_W = 8;                  // waves per workgroup
 constexpr float CC_SH = 16.0f;           // fixed scale of hidden activations ahead of the fp16 split
 constexpr float CC_SH_INV = 1.0f / 16.0f;
@@ -69,18 +66,9 @@ __device__ __forceinline__ void cc_mma_pair(const char* xbuf, int pair, const gf
   a1 = floatx4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int T = 0; T < KT; ++T) {
-#if GFV_ABL & 2
-    const gfv_f16x8 xh0 = wh[T], xh1 = wl[T], xl0 = wl[T], xl1 = wh[T];
-#else
     const gfv_f16x8 xh0 = f0[(2 * T) * 64], xh1 = f1[(2 * T) * 64];
-#endif
-#if GFV_ABL & 1
-    a0 += __builtin_bit_cast(floatx4, xh0); a1 += __builtin_bit_cast(floatx4, xh1);
-#else
     if (!LOWP) {
-#if !(GFV_ABL & 2)
       const gfv_f16x8 xl0 = f0[(2 * T + 1) * 64], xl1 = f1[(2 * T + 1) * 64];
-#endif
       a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[T], xh0, a0, 0, 0, 0);
       a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[T], xh1, a1, 0, 0, 0);
       a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[T], xl0, a0, 0, 0, 0);
@@ -88,14 +76,9 @@ __device__ __forceinline__ void cc_mma_pair(const char* xbuf, int pair, const gf
     }
     a0 = gfv_mma_hh<LOWP == 2>(wh[T], xh0, a0);
     a1 = gfv_mma_hh<LOWP == 2>(wh[T], xh1, a1);
-#endif
     // (FENCE: the scheduler may not hoist the next k-group's four fragment reads above this one's MFMAs - at a budget of 128
     // registers sixteen fragments in flight are 64 of them)
-#ifdef GFV_FENCE_MASK
-    if (FENCE) __builtin_amdgcn_sched_barrier(GFV_FENCE_MASK);
-#else
     if (FENCE) __builtin_amdgcn_sched_barrier(0);
-#endif
   }
 }
 
@@ -185,90 +168,39 @@ __device__ __forceinline__ void cb_tr_operand(const char* xbuf, int q0, int ct, 
 // and the bias gradient of n-tile 2 (w >> 1) + (w & 1).  (The first form gave a wave one n-tile and all eight k-tiles: 36
 // transposed LDS reads per row pair where this takes 24 - every wave read ALL of A - and the weight-gradient phases are
 // LDS-read time: DESIGN.md 5.)
-#ifndef GFV_DW24
-#define GFV_DW24 1
-#endif
-__device__ __forceinline__ int cb_dw_ntile(int w, int i) { return GFV_DW24 ? 2 * (w >> 1) + (i >> 2) : w; }
-__device__ __forceinline__ int cb_dw_ktile(int w, int i) { return GFV_DW24 ? 4 * (w & 1) + (i & 3) : i; }
-__device__ __forceinline__ int cb_dw_btile(int w) { return GFV_DW24 ? 2 * (w >> 1) + (w & 1) : w; }
+__device__ __forceinline__ int cb_dw_ntile(int w, int i) { return 2 * (w >> 1) + (i >> 2); }
+__device__ __forceinline__ int cb_dw_ktile(int w, int i) { return 4 * (w & 1) + (i & 3); }
+__device__ __forceinline__ int cb_dw_btile(int w) { return 2 * (w >> 1) + (w & 1); }
 template <int LOWP>
 __device__ __forceinline__ void cb_dw_tile(const char* gbuf, const char* abuf, int npairs, int w, int lane, floatx4 (&acc)[8],
                                            floatx4& accb) {
   const gfv_f16x8 ones = gfv_frag_ones<LOWP == 2>();
-#if GFV_DW24
   const int nt0 = 2 * (w >> 1), kt0 = 4 * (w & 1);
   for (int pr = 0; pr < npairs; ++pr) {
     gfv_f16x8 gh[2], gl[2];
-#if GFV_ABL & 2
-    gh[0] = gh[1] = gl[0] = gl[1] = ones; gh[0][0] = (_Float16)(float)pr;
-#else
     cb_tr_operand(gbuf, 2 * pr, nt0, lane, gh[0], gl[0]);
     cb_tr_operand(gbuf, 2 * pr, nt0 + 1, lane, gh[1], gl[1]);
-#endif
-#if !(GFV_ABL & 1)
     {
       const bool odd = (w & 1) != 0;   // (wave-uniform)
       const gfv_f16x8 bh = odd ? gh[1] : gh[0], bl = odd ? gl[1] : gl[0];
       if (!LOWP) accb = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl, ones, accb, 0, 0, 0);
       accb = gfv_mma_hh<LOWP == 2>(bh, ones, accb);
     }
-#endif
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       gfv_f16x8 ah, al;
-#if GFV_ABL & 2
-      ah = gh[0]; al = gl[0]; ah[1] = (_Float16)(float)kk;
-#else
       cb_tr_operand(abuf, 2 * pr, kt0 + kk, lane, ah, al);
-#endif
 #pragma unroll
       for (int nn = 0; nn < 2; ++nn) {
-#if GFV_ABL & 1
-        acc[4 * nn + kk] += __builtin_bit_cast(floatx4, ah) + __builtin_bit_cast(floatx4, al);
-#else
         if (!LOWP) {
           acc[4 * nn + kk] = __builtin_amdgcn_mfma_f32_16x16x32_f16(gl[nn], ah, acc[4 * nn + kk], 0, 0, 0);
           acc[4 * nn + kk] = __builtin_amdgcn_mfma_f32_16x16x32_f16(gh[nn], al, acc[4 * nn + kk], 0, 0, 0);
         }
         acc[4 * nn + kk] = gfv_mma_hh<LOWP == 2>(gh[nn], ah, acc[4 * nn + kk]);
-#endif
       }
     }
     __builtin_amdgcn_sched_barrier(0);   // (one row pair's operands in flight: the register budget)
   }
-#else
-  for (int pr = 0; pr < npairs; ++pr) {
-    gfv_f16x8 gh, gl;
-#if GFV_ABL & 2
-    gh = ones; gl = ones; gh[0] = (_Float16)(float)pr;
-#else
-    cb_tr_operand(gbuf, 2 * pr, w, lane, gh, gl);
-#endif
-#if !(GFV_ABL & 1)
-    if (!LOWP) accb = __builtin_amdgcn_mfma_f32_16x16x32_f16(gl, ones, accb, 0, 0, 0);
-    accb = gfv_mma_hh<LOWP == 2>(gh, ones, accb);
-#endif
-#pragma unroll
-    for (int kt = 0; kt < 8; ++kt) {
-      gfv_f16x8 ah, al;
-#if GFV_ABL & 2
-      ah = gh; al = gl; ah[1] = (_Float16)(float)kt;
-#else
-      cb_tr_operand(abuf, 2 * pr, kt, lane, ah, al);
-#endif
-#if GFV_ABL & 1
-      acc[kt] += __builtin_bit_cast(floatx4, ah) + __builtin_bit_cast(floatx4, al);
-#else
-      if (!LOWP) {
-        acc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(gl, ah, acc[kt], 0, 0, 0);
-        acc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(gh, al, acc[kt], 0, 0, 0);
-      }
-      acc[kt] = gfv_mma_hh<LOWP == 2>(gh, ah, acc[kt]);
-#endif
-      if ((kt & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // (four k-tiles' operands in flight, not eight: the register budget)
-    }
-  }
-#endif
 }
 
 // chain-layer epilogue of one group in the backward form (GFV_OP_MUL_DGELU): v = acc / scales x gelu'(z) -> fragments with
@@ -279,12 +211,8 @@ __device__ __forceinline__ void cb_hidden_bwd(CcCtx& c, int q, const floatx4& ac
   // two values per instruction (packed fp32, gfv_common.h): the same operations in the same order as the scalar form
   const gfv_f2 z01 = {z.x, z.y}, z23 = {z.z, z.w};
   gfv_f2 a01, a23, d01, d23;
-#if GFV_ABL & 4
-  a01 = z01; a23 = z23; d01 = z01 * z01; d23 = z23 * z23;
-#else
   gfv_gelu_dgelu2(z01, a01, d01);   // gelu and gelu' share the erfc evaluation
   gfv_gelu_dgelu2(z23, a23, d23);
-#endif
   const gfv_f2 ki = gfv_splat2(inv_in), kw = gfv_splat2(c.invw);
   const gfv_f2 v01 = ((gfv_f2{acc[0], acc[1]} * ki) * kw) * d01, v23 = ((gfv_f2{acc[2], acc[3]} * ki) * kw) * d23;
   v[0] = v01.x; v[1] = v01.y; v[2] = v23.x; v[3] = v23.y;
@@ -536,12 +464,8 @@ __global__ __launch_bounds__(64 * CC_W, 2) void colchain_bwd_kernel(const gfv_ro
   // The second wave of each SIMD (waves 4 .. 7) runs a chain phase as MMA(0) EPI(0) MMA(1) EPI(1) where the first runs
   // MMA(0) MMA(1) EPI(0) EPI(1): its epilogue (vector arithmetic, stores) then falls beside the other wave's matrix instructions
   // instead of both queueing for the matrix pipe and then for the vector unit.  Same operations per wave, bit-identical results;
-  // 42.1 k -> 40.3 k cycles per tile (most of it in P1, whose epilogue is stores).  -DGFV_SKEW_WAVES=0 builds the lockstep form.
-#if defined(GFV_SKEW_WAVES) && GFV_SKEW_WAVES == 0
-  constexpr bool CB_LATE = false;
-#else
+  // 42.1 k -> 40.3 k cycles per tile (most of it in P1, whose epilogue is stores).
   const bool CB_LATE = c.w >= 4;
-#endif
   CT_DECL
   int tloc = 0;   // (DW1) this workgroup's tile counter
   for (int t0 = g_beg; t0 < g_end; t0 += TG, ++tloc) {

@@ -146,74 +146,14 @@ __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast
 __device__ __forceinline__ void st4(float* p, const float (&v)[4]) {
   *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
 }
-// rows saved for the backward (pre-activations, the pre-LayerNorm values): written once, read a millisecond later.
-// -DGFV_NT_SAVE=1 stores them non-temporally (experiment: profiles/tools/build_variant.sh)
-#ifndef GFV_NT_SAVE
-#define GFV_NT_SAVE 0
-#endif
+// rows saved for the backward (pre-activations, the pre-LayerNorm values): written once, read a millisecond later
+// (non-temporal stores were measured in round 3: 4.07 - 4.11 against 4.06 ms, no gain)
 __device__ __forceinline__ void st4_save(float* p, const float (&v)[4]) {
-#if GFV_NT_SAVE
-  typedef float nt_f4 __attribute__((ext_vector_type(4)));
-  __builtin_nontemporal_store(nt_f4{v[0], v[1], v[2], v[3]}, reinterpret_cast<nt_f4*>(p));
-#else
   st4(p, v);
-#endif
 }
 
-// ---- 128-byte runs ------------------------------------------------------------------------------------------------
-// The accumulator layout puts the 4 lanes g = 0..3 of a row on 64 contiguous bytes, so a plain float4 access of a wave touches
-// 16 rows x 64 B - and the memory side moves such read / write mixes at 4.2 TB/s where runs of 128 B and more reach 5.8
-// (profiles/tools/stream/stream_run.py, profiles/r03_stream_run.txt).  Two neighbouring 16-column tiles (2u, 2u + 1) of a row
-// are 128 contiguous bytes: one instruction takes rows 0..7 of the wave's 16 (lanes j < 8: their own first half, lanes j >= 8:
-// the second half of row j - 8), a second one rows 8..15; the halves change lanes by a DPP row rotation by 8 with a bank mask
-// (4 VALU instructions per float4 moved).  Same values in the same registers as the plain accesses: results are unchanged.
-#ifndef GFV_RUN128
-#define GFV_RUN128 0
-#endif
-struct RowPair {
-  int rlo, rhi;     // the two rows this lane touches (clamped to M - 1)
-  bool llo, lhi;    // ... exist
-  int hoff;         // column offset inside a 32-column pair: 16 (j >> 3) + 4 g
-};
-__device__ __forceinline__ RowPair row_pair(int row16, int li, int g, int M) {   // row16: first of the wave's 16 rows
-  RowPair p;
-  const int r0 = row16 + (li & 7), r1 = r0 + 8;
-  p.llo = r0 < M;
-  p.lhi = r1 < M;
-  p.rlo = p.llo ? r0 : M - 1;
-  p.rhi = p.lhi ? r1 : M - 1;
-  p.hoff = 16 * (li >> 3) + 4 * g;
-  return p;
-}
-// lanes 8..15 of every 16-lane row take `src` from the lane 8 below, the others keep `old`
-__device__ __forceinline__ float ror8_hi(float old, float src) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src), 0x128, 0xf, 0xc, false));
-}
-// lanes 0..7 take `src` from the lane 8 above, the others keep `old`
-__device__ __forceinline__ float ror8_lo(float old, float src) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src), 0x128, 0xf, 0x3, false));
-}
-// tiles (2u, 2u + 1) of this lane's row <- the two 128-byte-run loads (rows rlo / rhi at columns 32 u + hoff)
-__device__ __forceinline__ void runs_to_pair(const float4& x, const float4& y, float (&a)[4], float (&b)[4]) {
-  a[0] = ror8_hi(x.x, y.x); a[1] = ror8_hi(x.y, y.y); a[2] = ror8_hi(x.z, y.z); a[3] = ror8_hi(x.w, y.w);
-  b[0] = ror8_lo(y.x, x.x); b[1] = ror8_lo(y.y, x.y); b[2] = ror8_lo(y.z, x.z); b[3] = ror8_lo(y.w, x.w);
-}
-__device__ __forceinline__ void ld_pair(const float* base, size_t ld, const RowPair& rp, int u, float (&a)[4], float (&b)[4]) {
-  const float4 x = ld4(base + (size_t)rp.rlo * ld + 32 * u + rp.hoff);
-  const float4 y = ld4(base + (size_t)rp.rhi * ld + 32 * u + rp.hoff);
-  runs_to_pair(x, y, a, b);
-}
-// the same with the two row pointers given (gathered rows)
-__device__ __forceinline__ void ld_pair_p(const float* plo, const float* phi, int u, float (&a)[4], float (&b)[4]) {
-  const float4 x = ld4(plo + 32 * u), y = ld4(phi + 32 * u);
-  runs_to_pair(x, y, a, b);
-}
-__device__ __forceinline__ void st_pair(float* base, size_t ld, const RowPair& rp, int u, const float (&a)[4], const float (&b)[4]) {
-  const float x[4] = {ror8_hi(a[0], b[0]), ror8_hi(a[1], b[1]), ror8_hi(a[2], b[2]), ror8_hi(a[3], b[3])};
-  const float y[4] = {ror8_lo(b[0], a[0]), ror8_lo(b[1], a[1]), ror8_lo(b[2], a[2]), ror8_lo(b[3], a[3])};
-  if (rp.llo) st4(base + (size_t)rp.rlo * ld + 32 * u + rp.hoff, x);
-  if (rp.lhi) st4(base + (size_t)rp.rhi * ld + 32 * u + rp.hoff, y);
-}
+// (Round 3 also had a 128-byte-run form of every row access here - lane pairs exchanging half rows by DPP, `GFV_RUN128`:
+// 3.99 against 3.89 ms per step, the extra moves cost what the wider runs gave, profiles/r03_ab_run128.txt - removed in round 5.)
 
 // LayerNorm statistics of one row spread over 4 lanes x 8 x 4 registers
 // LnW: the LayerNorm width.  A model of hidden_size h < 128 runs zero-padded to 128 columns (gfv_set_hidden_size): the
@@ -492,9 +432,6 @@ __device__ __forceinline__ void load_segment(const gfv_rowtile_args_t& A, int si
     const bool csr = CSR && s.csr_rowptr != nullptr;
     const size_t srow = (s.idx && !csr) ? (size_t)s.idx[mc] : (size_t)mc;
     const float* rp = s.ptr + srow * (size_t)s.ld + 4 * g;
-    const RowPair pr = row_pair(m - li, li, g, A.M);
-    // (source rows of the two runs: the segment's gather index, if any, of rows rlo / rhi)
-    const size_t slo = (s.idx && !csr) ? (size_t)s.idx[pr.rlo] : (size_t)pr.rlo, shi = (s.idx && !csr) ? (size_t)s.idx[pr.rhi] : (size_t)pr.rhi;
     if (csr) {
       // the segment row is a segmented sum: scale[m] * sum_{k in [rowptr[m], rowptr[m+1])} src[idx[k], :] - the neighbour
       // aggregation of the GnBlock (blocks.py:25-51,84-99) and the per-side scatter of the factored EdgeBlock's adjoint,
@@ -553,43 +490,15 @@ __device__ __forceinline__ void load_segment(const gfv_rowtile_args_t& A, int si
           }
           act[tt][t][r] = v;
         }
-    } else if (GFV_RUN128 && !(nt_valid & 1)) {
-      const float* plo = s.ptr + slo * (size_t)s.ld + pr.hoff;
-      const float* phi = s.ptr + shi * (size_t)s.ld + pr.hoff;
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        if (2 * u < nt_valid) {
-          ld_pair_p(plo, phi, u, act[tt][2 * u], act[tt][2 * u + 1]);
-        } else {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) act[tt][2 * u][r] = act[tt][2 * u + 1][r] = 0.f;
-        }
-      }
     } else {
 #pragma unroll
-    for (int t = 0; t < 8; ++t) {
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-#ifndef ABL_NOSEG
-      if (t < nt_valid) v = ld4(rp + 16 * t);
-#else
-      v = make_float4(0.001f * t, 0.002f, 0.003f * g, 0.004f);
-#endif
-      act[tt][t][0] = v.x; act[tt][t][1] = v.y; act[tt][t][2] = v.z; act[tt][t][3] = v.w;
-    }
+      for (int t = 0; t < 8; ++t) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (t < nt_valid) v = ld4(rp + 16 * t);
+        act[tt][t][0] = v.x; act[tt][t][1] = v.y; act[tt][t][2] = v.z; act[tt][t][3] = v.w;
+      }
     }
     if (first && A.in_add && !(RAG && ((s.width & 31) || (s.ld & 3)))) {
-      if (GFV_RUN128 && !(nt_valid & 1)) {
-        const float* plo = A.in_add + slo * (size_t)s.ld + pr.hoff;
-        const float* phi = A.in_add + shi * (size_t)s.ld + pr.hoff;
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-          if (2 * u < nt_valid) {
-            float a[4], b[4];
-            ld_pair_p(plo, phi, u, a, b);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { act[tt][2 * u][r] += a[r]; act[tt][2 * u + 1][r] += b[r]; }
-          }
-      } else {
       const float* ap = A.in_add + srow * (size_t)s.ld + 4 * g;
 #pragma unroll
       for (int t = 0; t < 8; ++t)
@@ -597,23 +506,8 @@ __device__ __forceinline__ void load_segment(const gfv_rowtile_args_t& A, int si
           const float4 v = ld4(ap + 16 * t);
           act[tt][t][0] += v.x; act[tt][t][1] += v.y; act[tt][t][2] += v.z; act[tt][t][3] += v.w;
         }
-      }
     }
     if (first && A.gadd) {
-#if GFV_RUN128
-      // [gadd[s] (64) | gadd[r] (64)]: pairs 0, 1 from the sender rows, 2, 3 from the receiver rows
-      const float* gslo = A.gadd + (size_t)A.gadd_s[pr.rlo] * 64 + pr.hoff;
-      const float* gshi = A.gadd + (size_t)A.gadd_s[pr.rhi] * 64 + pr.hoff;
-      const float* grlo = A.gadd + (size_t)A.gadd_r[pr.rlo] * 64 + pr.hoff;
-      const float* grhi = A.gadd + (size_t)A.gadd_r[pr.rhi] * 64 + pr.hoff;
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        float a[4], b[4];
-        ld_pair_p(u < 2 ? gslo : grlo, u < 2 ? gshi : grhi, u & 1, a, b);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { act[tt][2 * u][r] += a[r]; act[tt][2 * u + 1][r] += b[r]; }
-      }
-#else
       const float* gs = A.gadd + (size_t)A.gadd_s[mc] * 64 + 4 * g;
       const float* gr = A.gadd + (size_t)A.gadd_r[mc] * 64 + 4 * g;
 #pragma unroll
@@ -621,7 +515,6 @@ __device__ __forceinline__ void load_segment(const gfv_rowtile_args_t& A, int si
         const float4 v = ld4((t < 4 ? gs : gr) + 16 * (t & 3));
         act[tt][t][0] += v.x; act[tt][t][1] += v.y; act[tt][t][2] += v.z; act[tt][t][3] += v.w;
       }
-#endif
     }
     if (in_op == GFV_IN_GELU) {
 #pragma unroll
@@ -632,17 +525,12 @@ __device__ __forceinline__ void load_segment(const gfv_rowtile_args_t& A, int si
       ln_apply(act[tt], gam, bet, g, lnw);
     } else if (LNM == 1 && in_op == GFV_IN_LNBWD) {
       float y[8][4];
-#if GFV_RUN128
-#pragma unroll
-      for (int u = 0; u < 4; ++u) ld_pair(A.in_aux, 128, pr, u, y[2 * u], y[2 * u + 1]);
-#else
       const float* yp = A.in_aux + (size_t)mc * 128 + 4 * g;
 #pragma unroll
       for (int t = 0; t < 8; ++t) {
         const float4 v = ld4(yp + 16 * t);
         y[t][0] = v.x; y[t][1] = v.y; y[t][2] = v.z; y[t][3] = v.w;
       }
-#endif
       // rows past M (clamped re-reads of row M - 1) must not reach the (dgamma, dbeta) sums: their incoming gradient is
       // multiplied by 0 - everything ln_bwd derives from it is then 0 as well.  (A multiplication, not `if (!live) act = 0`:
       // hipcc turns the conditional assignment of a register array into a copy of all 32 registers plus 32 more moves
@@ -658,18 +546,11 @@ __device__ __forceinline__ void load_segment(const gfv_rowtile_args_t& A, int si
       else ln_bwd<false>(act[tt], y, gam, g, dgam, dbet, lnw);
     }
     // (rows past M keep the values of row M - 1 from here on: nothing of theirs is stored, and no other sum runs over rows)
-#if GFV_RUN128
-    if (first && A.in_save) {
-#pragma unroll
-      for (int u = 0; u < 4; ++u) st_pair(A.in_save, 128, pr, u, act[tt][2 * u], act[tt][2 * u + 1]);
-    }
-#else
     if (first && A.in_save && live) {
       float* sp = A.in_save + (size_t)m * 128 + 4 * g;
 #pragma unroll
       for (int t = 0; t < 8; ++t) st4(sp + 16 * t, act[tt][t]);
     }
-#endif
     if (CSR && s.save && live) {   // the assembled rows of THIS segment (the weight-gradient launch reads them)
       float* sp = s.save + (size_t)m * 128 + 4 * g;
 #pragma unroll
@@ -731,22 +612,12 @@ __global__ __launch_bounds__(64 * NW, GFV_CHAIN_WAVES(H, LNM, RAG)) void tchain_
   // gather rows of the factored first-layer addend: index round trip issued first thing, used in the first epilogue
   const float* pad_s[T];
   const float* pad_r[T];
-  const float* pad_s2[T];   // GFV_RUN128: (pad_s, pad_r) belong to row rlo of the wave's row pair, (pad_s2, pad_r2) to row rhi
-  const float* pad_r2[T];
   if (A.padd) {
 #pragma unroll
     for (int tt = 0; tt < T; ++tt) {
-#if GFV_RUN128
-      const RowPair pr = row_pair(rowbase - li + 16 * tt, li, g, A.M);
-      pad_s[tt] = A.padd + (size_t)A.padd_s[pr.rlo] * A.padd_ld + pr.hoff;
-      pad_r[tt] = A.padd + (size_t)A.padd_r[pr.rlo] * A.padd_ld + 128 + pr.hoff;
-      pad_s2[tt] = A.padd + (size_t)A.padd_s[pr.rhi] * A.padd_ld + pr.hoff;
-      pad_r2[tt] = A.padd + (size_t)A.padd_r[pr.rhi] * A.padd_ld + 128 + pr.hoff;
-#else
       const int mc = min(rowbase + 16 * tt, A.M - 1);
       pad_s[tt] = A.padd + (size_t)A.padd_s[mc] * A.padd_ld + 4 * g;
       pad_r[tt] = A.padd + (size_t)A.padd_r[mc] * A.padd_ld + 128 + 4 * g;
-#endif
     }
   }
   // small parameter vectors -> LDS: one round trip at kernel start (overlapping the first weight slice) instead of a
@@ -844,7 +715,6 @@ __global__ __launch_bounds__(64 * NW, GFV_CHAIN_WAVES(H, LNM, RAG)) void tchain_
             const float* wsrc = more ? cur.w + WK * (sl + 1) : nxt.w;
             const int wld = more ? cur.ldw : nxt.ldw;
             const int wnr = more ? cur.nrows : nxt.nrows;
-#ifndef ABL_NOW
             if (H) {
               wr0 = w_load_h<NW>(more ? cur.w + 4096 * (sl + 1) : nxt.w, tid);
             } else if (RAG && (more ? cur.rag : nxt.rag)) {
@@ -853,22 +723,15 @@ __global__ __launch_bounds__(64 * NW, GFV_CHAIN_WAVES(H, LNM, RAG)) void tchain_
             } else {
               wr0 = w_load(wsrc, wld, wnr, wrow, wc);
             }
-#endif
-#ifndef NO_SCHEDB
             __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ABOVE the MFMAs (the scheduler sinks it otherwise)
-#endif
             TS(2);
             if (H) mma_slice_h<BF>(acc[0], xh[sl], xl[sl], lds + wbuf * WS_FLOATS, lane, (cur.nrows + 63) >> 6, lowp);
             else mma_slice<T>(acc, act, 2 * sl, lds + wbuf * WS_FLOATS, off0);
             TS(3);
-#ifndef NO_SCHEDB
             __builtin_amdgcn_sched_barrier(0);
-#endif
-#ifndef ABL_NOW
             w_store_n<NW>(lds + (wbuf ^ 1) * WS_FLOATS, tid, wr0);
             TS(4);
             __syncthreads();
-#endif
             TS(5);
             wbuf ^= 1;
           }
@@ -885,51 +748,6 @@ __global__ __launch_bounds__(64 * NW, GFV_CHAIN_WAVES(H, LNM, RAG)) void tchain_
           const int m = rowbase + 16 * tt;
           const bool live = m < A.M;
           const size_t mrow = (size_t)(live ? m : A.M - 1) * 128 + 4 * g;
-#if GFV_RUN128
-          const RowPair pr = row_pair(m - li, li, g, A.M);
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            float v0[4], v1[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              v0[r] = acc[tt][2 * u][r];
-              v1[r] = acc[tt][2 * u + 1][r];
-              if (H) { v0[r] = (v0[r] * invx) * invw; v1[r] = (v1[r] * invx) * invw; }
-            }
-            if (lop == GFV_OP_MUL_DGELU) {
-              float z0[4], z1[4];
-              ld_pair(L.aux, 128, pr, u, z0, z1);
-#pragma unroll
-              for (int r = 0; r < 4; ++r) { v0[r] *= gfv_dgelu(z0[r]); v1[r] *= gfv_dgelu(z1[r]); }
-              if (L.save) st_pair(L.save, 128, pr, u, v0, v1);
-            } else {
-              {
-                const float4 b0 = ld4(par + 128 * layer + 32 * u + 4 * g), b1 = ld4(par + 128 * layer + 32 * u + 16 + 4 * g);
-                v0[0] += b0.x; v0[1] += b0.y; v0[2] += b0.z; v0[3] += b0.w;
-                v1[0] += b1.x; v1[1] += b1.y; v1[2] += b1.z; v1[3] += b1.w;
-              }
-              if (layer == 0 && A.padd) {
-                // first layer factored through the nodes: + (W1a x)[s] + (W1b x)[r]
-                float a0[4], a1[4], c0[4], c1[4];
-                ld_pair_p(pad_s[tt], pad_s2[tt], u, a0, a1);
-                ld_pair_p(pad_r[tt], pad_r2[tt], u, c0, c1);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { v0[r] += a0[r] + c0[r]; v1[r] += a1[r] + c1[r]; }
-              }
-              if (lop == GFV_OP_BIAS_GELU) {
-#ifndef ABL_NOSTORE
-                if (L.save) st_pair(L.save, 128, pr, u, v0, v1);
-#endif
-#ifndef ABL_NOGELU
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { v0[r] = gfv_gelu(v0[r]); v1[r] = gfv_gelu(v1[r]); }
-#endif
-              }
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { act[tt][2 * u][r] = v0[r]; act[tt][2 * u + 1][r] = v1[r]; }
-          }
-#else
 #pragma unroll
           for (int nt = 0; nt < 8; ++nt) {
             float v[4] = {acc[tt][nt][0], acc[tt][nt][1], acc[tt][nt][2], acc[tt][nt][3]};
@@ -952,19 +770,14 @@ __global__ __launch_bounds__(64 * NW, GFV_CHAIN_WAVES(H, LNM, RAG)) void tchain_
                 v[0] += pa.x + pb.x; v[1] += pa.y + pb.y; v[2] += pa.z + pb.z; v[3] += pa.w + pb.w;
               }
               if (lop == GFV_OP_BIAS_GELU) {
-#ifndef ABL_NOSTORE
                 if (L.save && live) st4_save(L.save + mrow + 16 * nt, v);
-#endif
-#ifndef ABL_NOGELU
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = gfv_gelu(v[r]);
-#endif
               }
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) act[tt][nt][r] = v[r];
           }
-#endif
         }
         if (H) {
           sx = row_scale(act[0]);
@@ -995,8 +808,6 @@ __global__ __launch_bounds__(64 * NW, GFV_CHAIN_WAVES(H, LNM, RAG)) void tchain_
           const bool live = m < A.M;
           const size_t mc = (size_t)(live ? m : A.M - 1);
           float v[8][4];
-          constexpr bool PAIRS = GFV_RUN128 && !RAG;   // (non-ragged instantiations: ntv is 8 or 4)
-          const RowPair pr = row_pair(m - li, li, g, A.M);
 #pragma unroll
           for (int nt = 0; nt < 8; ++nt) {
 #pragma unroll
@@ -1005,46 +816,23 @@ __global__ __launch_bounds__(64 * NW, GFV_CHAIN_WAVES(H, LNM, RAG)) void tchain_
               const float4 b = ld4(par + 128 * layer + 128 * pass + 16 * nt + 4 * g);
               v[nt][0] += b.x; v[nt][1] += b.y; v[nt][2] += b.z; v[nt][3] += b.w;
             }
-            if (!PAIRS && L.op == GFV_OP_MUL_DGELU && nt < ntv) {
+            if (L.op == GFV_OP_MUL_DGELU && nt < ntv) {
               const float4 z = ld4(L.aux + mc * (size_t)L.N + 128 * pass + 16 * nt + 4 * g);
               v[nt][0] *= gfv_dgelu(z.x); v[nt][1] *= gfv_dgelu(z.y); v[nt][2] *= gfv_dgelu(z.z); v[nt][3] *= gfv_dgelu(z.w);
             }
           }
-          if (PAIRS && L.op == GFV_OP_MUL_DGELU) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-              if (2 * u < ntv) {
-                float z0[4], z1[4];
-                ld_pair(L.aux + 128 * pass, (size_t)L.N, pr, u, z0, z1);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { v[2 * u][r] *= gfv_dgelu(z0[r]); v[2 * u + 1][r] *= gfv_dgelu(z1[r]); }
-              }
-          }
           if (A.fin_op == GFV_FIN_LN) {
-#ifndef ABL_NOSTORE
-            if (PAIRS) {
-              if (A.fin_presave) {
-#pragma unroll
-                for (int u = 0; u < 4; ++u) st_pair(A.fin_presave, 128, pr, u, v[2 * u], v[2 * u + 1]);
-              }
-            } else if (A.fin_presave && live) {
+            if (A.fin_presave && live) {
 #pragma unroll
               for (int nt = 0; nt < 8; ++nt) st4_save(A.fin_presave + mc * 128 + 16 * nt + 4 * g, v[nt]);
             }
-#endif
             ln_apply(v, par + PAR_GAMMA, par + PAR_BETA, g, lnw, (A.fin_stats && live) ? A.fin_stats + 2 * mc : nullptr);
           } else if (lnb_fin) {
             float y[8][4];
-            if (PAIRS) {
-#pragma unroll
-              for (int u = 0; u < 4; ++u) ld_pair(A.fin_aux, 128, pr, u, y[2 * u], y[2 * u + 1]);
-            }
 #pragma unroll
             for (int nt = 0; nt < 8; ++nt) {
-              if (!PAIRS) {
-                const float4 yy = ld4(A.fin_aux + mc * 128 + 16 * nt + 4 * g);
-                y[nt][0] = yy.x; y[nt][1] = yy.y; y[nt][2] = yy.z; y[nt][3] = yy.w;
-              }
+              const float4 yy = ld4(A.fin_aux + mc * 128 + 16 * nt + 4 * g);
+              y[nt][0] = yy.x; y[nt][1] = yy.y; y[nt][2] = yy.z; y[nt][3] = yy.w;
               const float livef = live ? 1.0f : 0.0f;   // (rows past M: see the prologue form)
               v[nt][0] *= livef; v[nt][1] *= livef; v[nt][2] *= livef; v[nt][3] *= livef;
             }
@@ -1056,31 +844,11 @@ __global__ __launch_bounds__(64 * NW, GFV_CHAIN_WAVES(H, LNM, RAG)) void tchain_
             if (!live) rs = 8.5070592e37f;       // 2^126: a dead row never lowers the group's scale
             group_scale_out(A.gscale + (size_t)A.nlayers * A.gscale_ld + rowgroup, rs, lane);
           }
-          if (PAIRS) {
-#ifndef ABL_NOSTORE
-            if (pass == 0 && A.out_nores) {
-#pragma unroll
-              for (int u = 0; u < 4; ++u) st_pair(A.out_nores, 128, pr, u, v[2 * u], v[2 * u + 1]);
-            }
-#endif
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-              if (2 * u < ntv) {
-                if (res) {
-                  float r0[4], r1[4];
-                  ld_pair(res, (size_t)rld, pr, u, r0, r1);
-#pragma unroll
-                  for (int r = 0; r < 4; ++r) { v[2 * u][r] += r0[r]; v[2 * u + 1][r] += r1[r]; }
-                }
-                st_pair(out, (size_t)old, pr, u, v[2 * u], v[2 * u + 1]);
-              }
-          } else if (live) {
-#ifndef ABL_NOSTORE
+          if (live) {
             if (pass == 0 && A.out_nores) {
 #pragma unroll
               for (int nt = 0; nt < 8; ++nt) st4(A.out_nores + mc * 128 + 16 * nt + 4 * g, v[nt]);
             }
-#endif
 #pragma unroll
             for (int nt = 0; nt < 8; ++nt) {
               if (nt < ntv) {
