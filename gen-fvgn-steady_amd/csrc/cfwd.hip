@@ -9,8 +9,9 @@
 // few tiles the launch has: a node-level launch of the 50 k-cell mesh (400 tiles on 256 CUs) takes 35 us, the same launch on a
 // 5 k-cell mesh 25 us, on a 1 k-cell mesh 23 us.  One wave walks 288 MFMAs and ~2 400 vector instructions per tile behind
 // twelve barriers; the launch's time is that serial walk, not bandwidth.  Here the walk is cut four ways instead:
-//   * a workgroup = 4 waves = ONE tile of TG groups of 16 rows (TG = 2: 32 rows; 4: 64 rows); wave w owns output COLUMNS
-//     32 w .. 32 w + 31 (two n-tiles) of every layer: a quarter of the MFMAs and of the epilogue arithmetic per wave and tile row;
+//   * a workgroup = ONE tile of TG groups of 16 rows: 32 rows on 8 waves (wave w owns output COLUMNS 16 w .. 16 w + 15 of every
+//     layer) or 64 rows on 4 waves (columns 32 w .. 32 w + 31): an eighth / a quarter of the MFMAs and of the epilogue arithmetic
+//     per wave and tile row;
 //   * its slice of a layer's weight image - the A operands W[32 w + i][k], (hi, lo) parts, 16 registers per k-group - comes
 //     straight from L2 into registers, one layer ahead of its use: no weight staging, no slice barriers;
 //   * activations cross waves between layers as MFMA B fragments in LDS ([group][k-group][part][lane] x 16 B; the 32 columns a
@@ -45,23 +46,27 @@ __device__ __forceinline__ void cf_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-template <int KT0, int TG>
+template <int KT0, int TG, int NW>
 struct CfLds {
   static constexpr int KTB = KT0 > 4 ? KT0 : 4;
   static constexpr int B0 = 0;                          // the input fragments; later the third layer's input
   static constexpr int B1 = TG * KTB * 2048;            // the second layer's input
   static constexpr int SINV = B1 + TG * 8192;           // float [TG * 16]: 1 / row scale of the input rows
-  static constexpr int LNP = SINV + TG * 64;            // float2 [TG * 16][4]: per-wave (mean, M2) of a row
-  static constexpr int TOTAL = LNP + TG * 16 * 4 * 8;
+  static constexpr int LNP = SINV + TG * 64;            // float2 [TG * 16][NW]: per-wave (mean, M2) of a row
+  static constexpr int TOTAL = LNP + TG * 16 * NW * 8;
 };
 
 // KT0: k-groups of the first layer (K / 32, zero padded); N0: 16-column pieces of segment 0 (the rest from segment 1);
 // PADD: gathered first-layer addend (factored EdgeBlock); LOWP: 0 three products, 1 / 2 the single-product forms (fp16 / bf16);
 // RAGIN: ONE narrow segment (width <= 32, any row stride: the encoders' raw inputs), loaded element by element
-template <int KT0, int N0, int TG, bool PADD, int LOWP, bool RAGIN>
-__global__ __launch_bounds__(256, 2) void cfwd_kernel(const gfv_rowtile_args_t A, int* status) {
+// NW: waves per workgroup - 4 (a wave owns NT = 2 n-tiles = 32 columns) or 8 (one n-tile = 16 columns: twice the waves in
+// flight per tile, half the instruction stream per wave; the columns a wave produces are then HALF a k-group of the next layer)
+template <int KT0, int N0, int TG, bool PADD, int LOWP, bool RAGIN, int NW = 4>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void cfwd_kernel(const gfv_rowtile_args_t A, int* status) {
   static_assert(TG == 2 || TG == 4, "one loader wave per group");
-  using LY = CfLds<KT0, TG>;
+  static_assert(NW == 4 || NW == 8, "32 or 16 columns per wave");
+  constexpr int NT = 8 / NW;   // n-tiles per wave
+  using LY = CfLds<KT0, TG, NW>;
   constexpr bool BF = LOWP == 2;
   __shared__ __attribute__((aligned(16))) char lds[LY::TOTAL];
   char* b0 = lds + LY::B0;
@@ -75,31 +80,31 @@ __global__ __launch_bounds__(256, 2) void cfwd_kernel(const gfv_rowtile_args_t A
   const int row0 = tile * (16 * TG);
   if (row0 >= A.M) return;
   const int ngt = min(TG, (A.M - row0 + 15) >> 4);   // live groups of this tile
-  const int c0 = 32 * w + 4 * g;                     // this lane's columns: c0 .. c0 + 3 (n-tile 2 w) and c0 + 16 .. + 19
+  const int c0 = 16 * NT * w + 4 * g;                // this lane's columns: c0 .. c0 + 3 (and, NT = 2, c0 + 16 .. + 19)
   const float invw = 1.0f / gfv_pow2_scale(*A.wmax);
 
   // ---- first layer's weight slice: in flight beside the row loads ----
-  gfv_f16x8 wh[2][KT0 > 4 ? KT0 : 4], wl[2][KT0 > 4 ? KT0 : 4];
+  gfv_f16x8 wh[NT][KT0 > 4 ? KT0 : 4], wl[NT][KT0 > 4 ? KT0 : 4];
   {
-    const gfv_f16x8* im = reinterpret_cast<const gfv_f16x8*>(A.layer[0].Wh) + (size_t)(2 * w) * 128 + lane;
+    const gfv_f16x8* im = reinterpret_cast<const gfv_f16x8*>(A.layer[0].Wh) + (size_t)(NT * w) * 128 + lane;
 #pragma unroll
     for (int T = 0; T < KT0; ++T)
 #pragma unroll
-      for (int n = 0; n < 2; ++n) {
+      for (int n = 0; n < NT; ++n) {
         wh[n][T] = im[T * 1024 + n * 128];
         if (!LOWP) wl[n][T] = im[T * 1024 + n * 128 + 64];
       }
   }
   // gathered addend rows of the first pre-activation: index, then row - two round trips, started now
-  float4 ps[PADD ? TG : 1][2], pr[PADD ? TG : 1][2];
+  float4 ps[PADD ? TG : 1][NT], pr[PADD ? TG : 1][NT];
   if (PADD) {
 #pragma unroll
     for (int q = 0; q < TG; ++q) {
       const int row = min(row0 + 16 * q + j, A.M - 1);
       const float* s = A.padd + (size_t)A.padd_s[row] * A.padd_ld + c0;
       const float* r = A.padd + (size_t)A.padd_r[row] * A.padd_ld + 128 + c0;
-      ps[q][0] = ld4(s); ps[q][1] = ld4(s + 16);
-      pr[q][0] = ld4(r); pr[q][1] = ld4(r + 16);
+#pragma unroll
+      for (int n = 0; n < NT; ++n) { ps[q][n] = ld4(s + 16 * n); pr[q][n] = ld4(r + 16 * n); }
     }
   }
   // ---- input rows -> row scale -> fragments (wave q loads group q) ----
@@ -147,24 +152,24 @@ __global__ __launch_bounds__(256, 2) void cfwd_kernel(const gfv_rowtile_args_t A
     }
   }
   // this wave's bias columns of the three layers, LayerNorm affine
-  float4 bias[3][2];
+  float4 bias[3][NT];
 #pragma unroll
   for (int l = 0; l < 3; ++l) {
     const float* bp = A.layer[l].bias;
 #pragma unroll
-    for (int n = 0; n < 2; ++n) bias[l][n] = bp ? ld4(bp + c0 + 16 * n) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int n = 0; n < NT; ++n) bias[l][n] = bp ? ld4(bp + c0 + 16 * n) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
   float mabs = 0.f;
   cf_barrier();
 
-  floatx4 acc[TG][2];
+  floatx4 acc[TG][NT];
   // one layer's products: acc[q][n] = sum_T W[n-tile 2 w + n][T] x frag[q][T]
   auto mma = [&](const char* xbuf, auto ktc) {
     constexpr int KT = decltype(ktc)::value;
 #pragma unroll
     for (int q = 0; q < TG; ++q)
 #pragma unroll
-      for (int n = 0; n < 2; ++n) acc[q][n] = floatx4{0.f, 0.f, 0.f, 0.f};
+      for (int n = 0; n < NT; ++n) acc[q][n] = floatx4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int T = 0; T < KT; ++T) {
 #pragma unroll
@@ -174,22 +179,22 @@ __global__ __launch_bounds__(256, 2) void cfwd_kernel(const gfv_rowtile_args_t A
         if (!LOWP) {
           const gfv_f16x8 xl = f[64];
 #pragma unroll
-          for (int n = 0; n < 2; ++n) {
+          for (int n = 0; n < NT; ++n) {
             acc[q][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[n][T], xh, acc[q][n], 0, 0, 0);
             acc[q][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[n][T], xl, acc[q][n], 0, 0, 0);
           }
         }
 #pragma unroll
-        for (int n = 0; n < 2; ++n) acc[q][n] = gfv_mma_hh<BF>(wh[n][T], xh, acc[q][n]);
+        for (int n = 0; n < NT; ++n) acc[q][n] = gfv_mma_hh<BF>(wh[n][T], xh, acc[q][n]);
       }
     }
   };
   auto load_w = [&](const void* image) {   // a 128-deep layer's slice
-    const gfv_f16x8* im = reinterpret_cast<const gfv_f16x8*>(image) + (size_t)(2 * w) * 128 + lane;
+    const gfv_f16x8* im = reinterpret_cast<const gfv_f16x8*>(image) + (size_t)(NT * w) * 128 + lane;
 #pragma unroll
     for (int T = 0; T < 4; ++T)
 #pragma unroll
-      for (int n = 0; n < 2; ++n) {
+      for (int n = 0; n < NT; ++n) {
         wh[n][T] = im[T * 1024 + n * 128];
         if (!LOWP) wl[n][T] = im[T * 1024 + n * 128 + 64];
       }
@@ -201,9 +206,9 @@ __global__ __launch_bounds__(256, 2) void cfwd_kernel(const gfv_rowtile_args_t A
       const int row = row0 + 16 * q + j;
       const bool live = q < ngt && row < A.M;
       const float si = layer == 0 ? sinv[q * 16 + j] : CF_SH_INV;
-      float a[8];
+      float a[4 * NT];
 #pragma unroll
-      for (int n = 0; n < 2; ++n) {
+      for (int n = 0; n < NT; ++n) {
         const float4 b = bias[layer][n];
         float v[4] = {(acc[q][n][0] * si) * invw + b.x, (acc[q][n][1] * si) * invw + b.y, (acc[q][n][2] * si) * invw + b.z,
                       (acc[q][n][3] * si) * invw + b.w};
@@ -217,16 +222,27 @@ __global__ __launch_bounds__(256, 2) void cfwd_kernel(const gfv_rowtile_args_t A
       }
       float m = 0.f;
 #pragma unroll
-      for (int e = 0; e < 8; e += 2) m = max3_abs(m, a[e], a[e + 1]);
+      for (int e = 0; e < 4 * NT; e += 2) m = max3_abs(m, a[e], a[e + 1]);
       mabs = fmaxf(mabs, live ? m : 0.f);
-      float e8[8];
+      if constexpr (NT == 2) {
+        // the wave's 32 columns are ONE k-group of the next layer: 16 bytes per lane and part
+        float e8[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) e8[e] = a[e] * CF_SH;
-      gfv_uint4 hi, lo;
-      gfv_split8_t<BF>(e8, hi, lo);
-      gfv_uint4* dst = reinterpret_cast<gfv_uint4*>(xout + (size_t)(q * 4 + w) * 2048) + lane;
-      dst[0] = hi;
-      if (!LOWP) dst[64] = lo;
+        for (int e = 0; e < 8; ++e) e8[e] = a[e] * CF_SH;
+        gfv_uint4 hi, lo;
+        gfv_split8_t<BF>(e8, hi, lo);
+        gfv_uint4* dst = reinterpret_cast<gfv_uint4*>(xout + (size_t)(q * 4 + w) * 2048) + lane;
+        dst[0] = hi;
+        if (!LOWP) dst[64] = lo;
+      } else {
+        // 16 columns: half a k-group (k-group w >> 1, slots 4 (w & 1) .. + 3): 8 bytes per lane and part
+        unsigned h0, h1, l0, l1;
+        gfv_split_pair_t<BF>(a[0] * CF_SH, a[1] * CF_SH, h0, l0);
+        gfv_split_pair_t<BF>(a[2] * CF_SH, a[3] * CF_SH, h1, l1);
+        char* dst = xout + (size_t)(q * 4 + (w >> 1)) * 2048 + lane * 16 + (w & 1) * 8;
+        *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
+        if (!LOWP) *reinterpret_cast<uint2*>(dst + 1024) = make_uint2(l0, l1);
+      }
     }
   };
 
@@ -240,15 +256,16 @@ __global__ __launch_bounds__(256, 2) void cfwd_kernel(const gfv_rowtile_args_t A
   load_w(A.layer[2].Wh);
   hidden(1, b0, A.layer[1].save);
   // LayerNorm affine and the residual rows: requested ahead of the last layer
-  const float4 gam0 = ld4(A.fin_gamma + c0), gam1 = ld4(A.fin_gamma + c0 + 16);
-  const float4 bet0 = ld4(A.fin_beta + c0), bet1 = ld4(A.fin_beta + c0 + 16);
-  float4 rres[TG][2];
+  float4 gam[NT], bet[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) { gam[n] = ld4(A.fin_gamma + c0 + 16 * n); bet[n] = ld4(A.fin_beta + c0 + 16 * n); }
+  float4 rres[TG][NT];
   if (A.res[0]) {
 #pragma unroll
     for (int q = 0; q < TG; ++q) {
       const float* rp = A.res[0] + (size_t)min(row0 + 16 * q + j, A.M - 1) * A.res_ld[0] + c0;
-      rres[q][0] = ld4(rp);
-      rres[q][1] = ld4(rp + 16);
+#pragma unroll
+      for (int n = 0; n < NT; ++n) rres[q][n] = ld4(rp + 16 * n);
     }
   }
   cf_barrier();
@@ -259,14 +276,14 @@ __global__ __launch_bounds__(256, 2) void cfwd_kernel(const gfv_rowtile_args_t A
   // over all 128 columns, whose padded ones are exactly zero, and corrected: mean_h = sum / h,
   // sum_real (y - mean_h)^2 = M2_128 + 128 (mean_128 - mean_h)^2 - (128 - h) mean_h^2   (tchain_kernel.h ln_stats: the same sums)
   const int hcols = (A.hidden > 0 && A.hidden < 128) ? A.hidden : 128;
-  float y[TG][8];
+  float y[TG][4 * NT];
 #pragma unroll
   for (int q = 0; q < TG; ++q) {
     const int row = row0 + 16 * q + j;
     const bool live = q < ngt && row < A.M;
     float s = 0.f;
 #pragma unroll
-    for (int n = 0; n < 2; ++n) {
+    for (int n = 0; n < NT; ++n) {
       const float4 b = bias[2][n];
       float v[4] = {(acc[q][n][0] * CF_SH_INV) * invw + b.x, (acc[q][n][1] * CF_SH_INV) * invw + b.y,
                     (acc[q][n][2] * CF_SH_INV) * invw + b.z, (acc[q][n][3] * CF_SH_INV) * invw + b.w};
@@ -277,15 +294,15 @@ __global__ __launch_bounds__(256, 2) void cfwd_kernel(const gfv_rowtile_args_t A
         s += v[r];
       }
     }
-    const float mw = row_sum(s) * 0.03125f;   // this wave's 32 columns
+    const float mw = row_sum(s) * (1.0f / (16.0f * NT));   // this wave's 16 NT columns
     float m2 = 0.f;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
+    for (int e = 0; e < 4 * NT; ++e) {
       const float d = y[q][e] - mw;
       m2 += d * d;
     }
     m2 = row_sum(m2);
-    if (g == 0) *reinterpret_cast<float2*>(lnp + ((q * 16 + j) * 4 + w) * 2) = make_float2(mw, m2);
+    if (g == 0) *reinterpret_cast<float2*>(lnp + ((q * 16 + j) * NW + w) * 2) = make_float2(mw, m2);
   }
   cf_barrier();
   {
@@ -294,19 +311,29 @@ __global__ __launch_bounds__(256, 2) void cfwd_kernel(const gfv_rowtile_args_t A
     for (int q = 0; q < TG; ++q) {
       const int row = row0 + 16 * q + j;
       const bool live = q < ngt && row < A.M;
-      const float4* pp = reinterpret_cast<const float4*>(lnp + (q * 16 + j) * 8);
-      const float4 p0 = pp[0], p1 = pp[1];   // (mean, M2) of waves 0, 1 | 2, 3
-      const float m128 = ((p0.x + p0.z) + (p1.x + p1.z)) * 0.25f;
-      const float e0 = p0.x - m128, e1 = p0.z - m128, e2 = p1.x - m128, e3 = p1.z - m128;
-      const float m2a = ((p0.y + p0.w) + (p1.y + p1.w)) + 32.0f * ((e0 * e0 + e1 * e1) + (e2 * e2 + e3 * e3));   // about m128, all columns
+      const float4* pp = reinterpret_cast<const float4*>(lnp + (q * 16 + j) * 2 * NW);
+      float m128, m2a;   // mean and sum of squared deviations over all 128 columns (Chan's combination of the waves' pairs)
+      if constexpr (NW == 4) {
+        const float4 p0 = pp[0], p1 = pp[1];   // (mean, M2) of waves 0, 1 | 2, 3
+        m128 = ((p0.x + p0.z) + (p1.x + p1.z)) * 0.25f;
+        const float e0 = p0.x - m128, e1 = p0.z - m128, e2 = p1.x - m128, e3 = p1.z - m128;
+        m2a = ((p0.y + p0.w) + (p1.y + p1.w)) + 32.0f * ((e0 * e0 + e1 * e1) + (e2 * e2 + e3 * e3));
+      } else {
+        const float4 p0 = pp[0], p1 = pp[1], p2 = pp[2], p3 = pp[3];
+        m128 = (((p0.x + p0.z) + (p1.x + p1.z)) + ((p2.x + p2.z) + (p3.x + p3.z))) * 0.125f;
+        const float e0 = p0.x - m128, e1 = p0.z - m128, e2 = p1.x - m128, e3 = p1.z - m128, e4 = p2.x - m128, e5 = p2.z - m128,
+                    e6 = p3.x - m128, e7 = p3.z - m128;
+        m2a = (((p0.y + p0.w) + (p1.y + p1.w)) + ((p2.y + p2.w) + (p3.y + p3.w))) +
+              16.0f * (((e0 * e0 + e1 * e1) + (e2 * e2 + e3 * e3)) + ((e4 * e4 + e5 * e5) + (e6 * e6 + e7 * e7)));
+      }
       const float mean = hcols == 128 ? m128 : (m128 * 128.0f) * inv_h;
       const float dm = m128 - mean;
       const float m2 = hcols == 128 ? m2a : (m2a + 128.0f * dm * dm) - npad * (mean * mean);
       const float rstd = rsqrtf(m2 * inv_h + 1e-5f);   // nn.LayerNorm eps (EPD.py:32)
       if (A.fin_stats && live && w == 0 && g == 0) *reinterpret_cast<float2*>(A.fin_stats + 2 * (size_t)row) = make_float2(mean, rstd);
 #pragma unroll
-      for (int n = 0; n < 2; ++n) {
-        const float4 ga = n ? gam1 : gam0, be = n ? bet1 : bet0;
+      for (int n = 0; n < NT; ++n) {
+        const float4 ga = gam[n], be = bet[n];
         float o[4] = {(y[q][4 * n + 0] - mean) * rstd * ga.x + be.x, (y[q][4 * n + 1] - mean) * rstd * ga.y + be.y,
                       (y[q][4 * n + 2] - mean) * rstd * ga.z + be.z, (y[q][4 * n + 3] - mean) * rstd * ga.w + be.w};
         if (live) {
@@ -330,14 +357,19 @@ template <int KT0, int N0, bool PADD, bool RAGIN>
 void cf_launch(const gfv_rowtile_args_t& a, int tg, int lowp, hipStream_t stream) {
   int* st = gfv_internal_status_ptr();
   const int tiles = (a.M + 16 * tg - 1) / (16 * tg);
-  const dim3 grid(PADD ? gfv_xcd_grid(tiles) : tiles), blk(256);
-#define CF_ONE(TG, LP) GFV_LAUNCH((cfwd_kernel<KT0, N0, TG, PADD, LP, RAGIN>), grid, blk, 0, stream, a, st)
-#define CF_TG(LP) do { if (tg == 2) CF_ONE(2, LP); else CF_ONE(4, LP); } while (0)
+  // 32-row tiles on 8 waves of 16 columns, 64-row tiles on 4 waves of 32 columns (measured, profiles/r05_cfwd.txt: 8 waves on the
+  // small tiles 1.644 against 1.659 ms on the 5 k-cell mesh and 3.62 against 3.64 on the 50 k-cell one; 8 waves on the 64-row
+  // tiles of 50 k-row edge launches 3.30 against 3.26)
+  const dim3 grid(PADD ? gfv_xcd_grid(tiles) : tiles), blk(tg == 2 ? 512 : 256);
+#define CF_TG(LP)                                                                                              \
+  do {                                                                                                         \
+    if (tg == 2) GFV_LAUNCH((cfwd_kernel<KT0, N0, 2, PADD, LP, RAGIN, 8>), grid, blk, 0, stream, a, st);       \
+    else GFV_LAUNCH((cfwd_kernel<KT0, N0, 4, PADD, LP, RAGIN, 4>), grid, blk, 0, stream, a, st);              \
+  } while (0)
   if (lowp == 2) CF_TG(2);
   else if (lowp) CF_TG(1);
   else CF_TG(0);
 #undef CF_TG
-#undef CF_ONE
 }
 
 }  // namespace

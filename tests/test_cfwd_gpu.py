@@ -82,7 +82,7 @@ def _run(M, segs, Pd, wi, fam, *, res=None, padd=None, nores=False, stats=True, 
     return dict(z1=z1, z2=z2, y3=y3, out=out, stats=st, nores=onr), path
 
 
-@pytest.mark.parametrize("M", [777, 32, 20001])     # 32-row tiles (partial last tile; exactly one tile), 64-row tiles
+@pytest.mark.parametrize("M", [777, 32, 20001, 41003])   # 32-row tiles on 4 waves (partial last tile; one tile; many), 64-row tiles on 8 waves
 def test_small_tile_forward_node_and_edge_shapes(M):
     from gfv import lib as L, ops
     g = torch.Generator().manual_seed(M)
