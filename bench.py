@@ -390,7 +390,7 @@ def main():
                 9: (tc(2, "false"), chain_peak, "gnn"), 10: (tc(0, "true"), chain_peak, "gnn"),
                 13: (tc(0, "false", "true"), chain_peak, "gnn"),
                 14: ("colchain_bwd_kernel", chain_peak, "gnn"),
-                15: ("cfwd_kernel (column-owner small-tile forward of the short 3-layer launches)", chain_peak, "gnn"),
+                15: ("cfwd_kernel", chain_peak, "gnn"),   # column-owner small-tile forward of the 3-layer launches up to 100 k rows (csrc/cfwd.hip)
                 16: ("lin1_kernel / lin1_lnbwd_kernel / lin1_csr_kernel (single-layer launches)", chain_peak, "gnn"),
                 2: ("dw_multi_h_kernel" if ts.engine.f16split else "dw_multi_kernel", chain_peak, "gnn"),
                 3: ("seg_gather_sum_vec", None, "gnn"),

@@ -39,6 +39,12 @@ done
 NSTEPS8=$(python3 -c "import json,sys; print([json.loads(l) for l in open('$O/b8/pmc_FETCH_SIZE.log') if l.startswith('{')][-1]['steps_executed'])")
 python3 $R/profiles/pmc_aggregate.py $O/b8 $NSTEPS8 > $O/hbm_pmc_b8.txt
 rm -rf $O/b8/pmc_FETCH_SIZE $O/b8/pmc_WRITE_SIZE
+# round 5: floor + slope of every kernel of the step over four mesh sizes (single stream), and one step's two-queue timeline on
+# the headline mesh and on the 5 k-cell cavity
+bash $R/profiles/tools/latency_floor.sh ${tag}_lf > /dev/null 2>&1
+cp $R/gpurun_out/${tag}_lf/latency_floor.txt $O/latency_floor.txt
+TL_TAG=${tag}_tl bash $R/profiles/tools/timeline.sh > $O/timeline.txt 2>&1
+ABFLAGS="--workload cavity --cells 5041" TL_TAG=${tag}_tlc bash $R/profiles/tools/timeline.sh > $O/timeline_cavity.txt 2>&1
 tail -3 $O/pytest.log
 head -c 400 $O/bench.json; echo
 tail -4 $O/hbm_pmc.txt
