@@ -73,6 +73,12 @@ static bool cc_bwd_ok(const gfv_rowtile_args_t* a) {
 extern "C" int gfv_hidden_size(void);
 extern "C" int gfv_f16split_enabled(void);
 extern "C" int gfv_rowtile_dw_partials(void) { return cc_cus(); }
+// a launch over M rows runs min(CUs, 64-row tiles) workgroups: on a short launch the blocks of idle workgroups were 34 MB written
+// and read again for nothing (round 5: 21 - 26 us per launch at 1 - 5 k rows, profiles/r05_latency_floor.txt)
+extern "C" int gfv_rowtile_dw_partials_m(int32_t M) {
+  const int tiles = (M + 63) / 64;
+  return tiles < cc_cus() ? (tiles > 0 ? tiles : 1) : cc_cus();
+}
 extern "C" int gfv_rowtile_fuses_dw(const gfv_rowtile_args_t* a) {
   if (!a || gfv_hidden_size() != 128 || gfv_f16split_enabled() == 0) return 0;
   gfv_rowtile_args_t t = *a;
@@ -85,7 +91,7 @@ int gfv_internal_colchain_try(const gfv_rowtile_args_t* a, hipStream_t stream) {
   if (a->hidden == 128 && cc_bwd_ok(a)) {
     int* st = gfv_internal_status_ptr();
     if (!st) return 0;
-    const dim3 grid(cc_cus()), blk(64 * CC_W);
+    const dim3 grid(gfv_rowtile_dw_partials_m(a->M)), blk(64 * CC_W);
 #define CB_K(...) GFV_LAUNCH((colchain_bwd_kernel<__VA_ARGS__>), grid, blk, 0, stream, *a, st)
 #define CB_LAUNCH(LOWP, RC)                                                                                                      \
   do {                                                                                                                           \

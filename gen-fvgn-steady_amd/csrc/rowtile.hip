@@ -198,7 +198,7 @@ static int rowtile_chain_impl(const gfv_rowtile_args_t* args, void* stream) {
       kind = GFV_K_COLCHAIN_BWD;
       const int nfused = (args->dw_in ? 3 : 2) + (args->rc_Wh[0] ? 2 : 0);   // (+ the two recomputed forward layers)
       fl += nfused * 2.0 * args->M * 128.0 * 128.0;
-      by += 8.0 * args->M + (args->dw_in ? 4.0 * args->M * 128.0 : 0.0) + 4.0 * (double)gfv_rowtile_dw_partials() * (double)args->dw_partial_stride;
+      by += 8.0 * args->M + (args->dw_in ? 4.0 * args->M * 128.0 : 0.0) + 4.0 * (double)gfv_rowtile_dw_partials_m(args->M) * (double)args->dw_partial_stride;
     }
     tok = gfv_prof_begin(kind, fl, by, (hipStream_t)stream);
   }

@@ -559,6 +559,8 @@ extern "C" int gfv_struct_size(int32_t which) {
     case 4: return (int)sizeof(gfv_dw_tile_t);
     case 5: return (int)sizeof(gfv_reduce_piece_t);
     case 6: return (int)sizeof(gfv_plan_desc_t);
+    case 7: return (int)sizeof(gfv_trans_mlp_t);
+    case 8: return (int)sizeof(gfv_trans_mlp_bwd_t);
     default: return -1;
   }
 }

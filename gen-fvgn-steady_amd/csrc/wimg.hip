@@ -22,8 +22,15 @@ __global__ __launch_bounds__(256) void wabsmax_kernel(const gfv_wimg_desc_t* __r
       for (int k = threadIdx.x & 63; k < d.K; k += 64) m = fmaxf(m, fabsf(d.W[(size_t)n * d.ldw + k]));
   }
   m = gfv_wave_max(m);
+  // ONE atomic per workgroup (four per workgroup - 800 on one address - were most of this launch's 12.6 us: round 5)
+  __shared__ float wm[4];
+  if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+  __syncthreads();
   // non-negative floats order like their bit patterns
-  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(reinterpret_cast<unsigned*>(wmax), __float_as_uint(m));
+  if (threadIdx.x == 0) {
+    m = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
+    if (m > 0.f) atomicMax(reinterpret_cast<unsigned*>(wmax), __float_as_uint(m));
+  }
 }
 
 // one thread = one (pass, T, nt, lane) fragment, both parts (bf: the bf16 single-product form - the high part in bf16, no low part)

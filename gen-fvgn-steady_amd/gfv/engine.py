@@ -146,6 +146,11 @@ class Engine:
         # profiles/r04_colchain_phases.txt: a fifth of the read traffic changes its time by 7 %), not by bytes.  Opt-in.
         self.recompute = os.environ.get("GFV_RECOMPUTE", "0") != "0"
         self._slice_fuse = os.environ.get("GFV_SLICE_FUSE", "1") != "0"   # Transolver adjoint: one pass behind the attention
+        # the row-local Linear chains of a Transolver block (to_out .. linear_post and their adjoints) as one launch each (round 5)
+        self._trans_fuse = os.environ.get("GFV_TRANS_FUSE", "1") != "0"
+        # (above the small-tile single-layer family's range: 3.60 - 3.62 against 3.64 ms on the 50 k-cell mesh, 22.06 against 22.17 at
+        # 8 meshes per GPU; on the 5 k-cell cavity the three small-tile launches are as fast: profiles/r05_ab_transmlp.txt)
+        self._trans_fuse_min = int(os.environ.get("GFV_TRANS_FUSE_MIN_M", "16385"))
         # the end of the backward: how many of the trailing weight-gradient flushes run on the MAIN stream (GFV_TAIL_MAIN: 1 = the last
         # encoder's, 2 = both encoders', 3 = the first GnBlock's too) and how the first GnBlock's flush is split between the streams
         # (GFV_TAIL_SPLIT: 0 = not at all, 1 / 2 = its first / its other pieces on main).  Unset: by launch size - (3, 0) between
@@ -517,7 +522,7 @@ class Engine:
         M = sv["M"]
         dev = G.device
         lib = L.load()
-        nwg = lib.gfv_rowtile_dw_partials()
+        nwg = lib.gfv_rowtile_dw_partials_m(M)
         FL = L.DW_FUSED_FLOATS
         dwp = _empty(dev, nwg, FL)
         gz1 = _empty(dev, M, 128)
@@ -736,7 +741,7 @@ class Engine:
         dev = G.device
         e = sv["segs"][0].t
         lib = L.load()
-        nwg = lib.gfv_rowtile_dw_partials()
+        nwg = lib.gfv_rowtile_dw_partials_m(M)
         lean = sv["z2"] is None   # recompute form: the forward kept z1 only
         # the first layer's gradient (the W1c block over the E rows) by the chain launch too: a trailing pass of every persistent
         # workgroup over its own rows (round 5, csrc/colchain_kernel.h) instead of a one-tile weight-gradient launch on the side queue
@@ -862,18 +867,21 @@ class Engine:
         out_x = _empty(dev, N, 128)
         L.check(lib.gfv_deslice(w.data_ptr(), out_token.data_ptr(), pl.batch.data_ptr(), out_x.data_ptr(), N,
                                 4 if B == 1 else 0, st), "deslice")
-        fx1 = _empty(dev, N, 128)
-        ops.rowtile_chain(N, [Seg(out_x)], [LayerSpec(P[f"{a}.to_out.0.weight"], P[f"{a}.to_out.0.bias"])], [fx1],
-                          res=[fx_in])
-        z = _empty(dev, N, 256)
-        ops.rowtile_chain(N, [Seg(fx1)],
-                          [LayerSpec(P[f"{prefix}.mlp.linear_pre.0.weight"], P[f"{prefix}.mlp.linear_pre.0.bias"])],
-                          [(z, 256), (z.data_ptr() + 512, 256)], in_op=L.IN_LN, in_gamma=P[f"{prefix}.ln_2.weight"],
-                          in_beta=P[f"{prefix}.ln_2.bias"])
-        out = _empty(dev, N, 128)
-        ops.rowtile_chain(N, [Seg(z, width=128, ld=256), Seg(z, width=128, ld=256, offset=128)],
-                          [LayerSpec(P[f"{prefix}.mlp.linear_post.weight"], P[f"{prefix}.mlp.linear_post.bias"])], [out],
-                          in_op=L.IN_GELU, res=[fx1])
+        fx1, z, out = _empty(dev, N, 128), _empty(dev, N, 256), _empty(dev, N, 128)
+        # to_out + residual, ln_2, linear_pre, GELU, linear_post + residual: nothing crosses rows - ONE launch (csrc/transmlp.hip)
+        if not (self._trans_fuse and N >= self._trans_fuse_min and ops.trans_mlp_fwd(
+                out_x, fx_in, P[f"{a}.to_out.0.weight"], P[f"{a}.to_out.0.bias"], P[f"{prefix}.ln_2.weight"], P[f"{prefix}.ln_2.bias"],
+                P[f"{prefix}.mlp.linear_pre.0.weight"], P[f"{prefix}.mlp.linear_pre.0.bias"], P[f"{prefix}.mlp.linear_post.weight"],
+                P[f"{prefix}.mlp.linear_post.bias"], fx1, z, out)):
+            ops.rowtile_chain(N, [Seg(out_x)], [LayerSpec(P[f"{a}.to_out.0.weight"], P[f"{a}.to_out.0.bias"])], [fx1],
+                              res=[fx_in])
+            ops.rowtile_chain(N, [Seg(fx1)],
+                              [LayerSpec(P[f"{prefix}.mlp.linear_pre.0.weight"], P[f"{prefix}.mlp.linear_pre.0.bias"])],
+                              [(z, 256), (z.data_ptr() + 512, 256)], in_op=L.IN_LN, in_gamma=P[f"{prefix}.ln_2.weight"],
+                              in_beta=P[f"{prefix}.ln_2.bias"])
+            ops.rowtile_chain(N, [Seg(z, width=128, ld=256), Seg(z, width=128, ld=256, offset=128)],
+                              [LayerSpec(P[f"{prefix}.mlp.linear_post.weight"], P[f"{prefix}.mlp.linear_post.bias"])], [out],
+                              in_op=L.IN_GELU, res=[fx1])
         sv = dict(prefix=prefix, fx_in=fx_in, fx_mid=fx_mid, x_mid=x_mid, w=w, token=token, norm=norm, attn=attn,
                   out_token=out_token, out_x=out_x, fx1=fx1, z=z)
         return out, sv
@@ -903,8 +911,19 @@ class Engine:
         g_z = _empty(dev, N, 256)
         g_sum = _empty(dev, N, 128) if g_add is not None else None
         gs = _empty(dev, 3, ops.gscale_ld(N))
-        have = ops.rowtile_chain(N, [Seg(g_out)], [LayerSpec(self._T(Wpost), None, L.OP_MUL_DGELU, aux=z)],
-                                 [(g_z, 256), (g_z.data_ptr() + 512, 256)], in_add=g_add, in_save=g_sum, gscale=gs)
+        tiles = ops.rowtile_tiles(N)
+        part = _empty(dev, tiles, 2, 128)
+        g_fx1, g_out_x = _empty(dev, N, 128), _empty(dev, N, 128)
+        gam2, bet2 = P[f"{prefix}.ln_2.weight"], P[f"{prefix}.ln_2.bias"]
+        # the three adjoint launches (GELU' epilogue, LayerNorm-backward epilogue, plain) as ONE (csrc/transmlp.hip)
+        fused = (self._trans_fuse and N >= self._trans_fuse_min and
+                 ops.trans_mlp_bwd(g_out, g_add, g_sum, z, fx1, self._T(Wpost), self._T(Wpre), self._T(P[f"{a}.to_out.0.weight"]),
+                                   gam2, g_z, g_fx1, g_out_x, part, gs[0]))
+        if fused:
+            have = True
+        else:
+            have = ops.rowtile_chain(N, [Seg(g_out)], [LayerSpec(self._T(Wpost), None, L.OP_MUL_DGELU, aux=z)],
+                                     [(g_z, 256), (g_z.data_ptr() + 512, 256)], in_add=g_add, in_save=g_sum, gscale=gs)
         s_post = gs[0] if have else None   # scale of the prologue result g_out (+ g_add) = the rows linear_post's dW reads
         if g_add is not None:
             g_out = g_sum
@@ -912,13 +931,10 @@ class Engine:
         self.defer(lambda: self._dw_block(grads, [(f"{prefix}.mlp.linear_post.weight", f"{prefix}.mlp.linear_post.bias", 2)],
                                           [self._tile(g_post, 128, zs, a_op=1, gscale=s_post) for zs in zsegs], N), g_post, z, gs)
         # linear_pre behind LayerNorm ln_2
-        tiles = ops.rowtile_tiles(N)
-        part = _empty(dev, tiles, 2, 128)
-        g_fx1 = _empty(dev, N, 128)
-        gam2, bet2 = P[f"{prefix}.ln_2.weight"], P[f"{prefix}.ln_2.bias"]
-        ops.rowtile_chain(N, [Seg(g_z, width=128, ld=256), Seg(g_z, width=128, ld=256, offset=128)],
-                          [LayerSpec(self._T(Wpre))], [g_fx1], fin_op=L.FIN_LNBWD, fin_gamma=gam2, fin_aux=fx1,
-                          ln_partial=part, res=[g_out])
+        if not fused:
+            ops.rowtile_chain(N, [Seg(g_z, width=128, ld=256), Seg(g_z, width=128, ld=256, offset=128)],
+                              [LayerSpec(self._T(Wpre))], [g_fx1], fin_op=L.FIN_LNBWD, fin_gamma=gam2, fin_aux=fx1,
+                              ln_partial=part, res=[g_out])
         def side_pre():
             wn, bn = f"{prefix}.mlp.linear_pre.0.weight", f"{prefix}.mlp.linear_pre.0.bias"
             wptr, slabs, blen, _ = self._dw_block(
@@ -932,8 +948,8 @@ class Engine:
                      chunk_stride=256, rows=1, cols=256)])
         self.defer(side_pre, g_z, fx1, part)
         # to_out
-        g_out_x = _empty(dev, N, 128)
-        ops.rowtile_chain(N, [Seg(g_fx1)], [LayerSpec(self._T(P[f"{a}.to_out.0.weight"]))], [g_out_x])
+        if not fused:
+            ops.rowtile_chain(N, [Seg(g_fx1)], [LayerSpec(self._T(P[f"{a}.to_out.0.weight"]))], [g_out_x])
         self.defer(lambda: self._dw_block(grads, [(f"{a}.to_out.0.weight", f"{a}.to_out.0.bias", 1)],
                                           [self._tile(g_fx1, 128, Seg(sv["out_x"]))], N), g_fx1, sv["out_x"])
         # de-slice / attention / slice

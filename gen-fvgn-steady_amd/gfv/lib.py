@@ -74,6 +74,20 @@ class ReducePiece(C.Structure):
                 ("rows", C.c_int32), ("cols", C.c_int32), ("ld_in", C.c_int32), ("ld_out", C.c_int32), ("reserved", C.c_int32)]
 
 
+class TransMlp(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("res", C.c_void_p), ("img_out", C.c_void_p), ("img_pre", C.c_void_p), ("img_post", C.c_void_p),
+                ("b_out", C.c_void_p), ("b_pre", C.c_void_p), ("b_post", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p),
+                ("wmax", C.c_void_p), ("fx1", C.c_void_p), ("z", C.c_void_p), ("out", C.c_void_p), ("M", C.c_int32),
+                ("reserved", C.c_int32)]
+
+
+class TransMlpBwd(C.Structure):
+    _fields_ = [("g", C.c_void_p), ("g_add", C.c_void_p), ("g_sum", C.c_void_p), ("z", C.c_void_p), ("fx1", C.c_void_p),
+                ("img_post_t", C.c_void_p), ("img_pre_t", C.c_void_p), ("img_out_t", C.c_void_p), ("gamma", C.c_void_p),
+                ("wmax", C.c_void_p), ("g_z", C.c_void_p), ("g_fx1", C.c_void_p), ("g_out_x", C.c_void_p),
+                ("ln_partial", C.c_void_p), ("gscale", C.c_void_p), ("M", C.c_int32), ("reserved", C.c_int32)]
+
+
 _lib = None
 
 _SIGNATURES = {
@@ -97,6 +111,7 @@ _SIGNATURES = {
     "gfv_rowtile_chain": (C.c_int, [C.POINTER(RowtileArgs), C.c_void_p]),
     "gfv_rowtile_last_path": (C.c_int, []),
     "gfv_rowtile_dw_partials": (C.c_int, []),
+    "gfv_rowtile_dw_partials_m": (C.c_int, [C.c_int32]),
     "gfv_rowtile_fuses_dw": (C.c_int, [C.POINTER(RowtileArgs)]),
     "gfv_dw_chunks": (C.c_int, [C.c_int32]),
     "gfv_linear_dw_workspace_floats": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
@@ -171,6 +186,8 @@ _SIGNATURES = {
     "gfv_plan_destroy": (C.c_int, [C.c_void_p]),
     "gfv_plan_table": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
     "gfv_plan_sizes": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
+    "gfv_trans_mlp_fwd": (C.c_int, [C.POINTER(TransMlp), C.c_void_p]),
+    "gfv_trans_mlp_bwd": (C.c_int, [C.POINTER(TransMlpBwd), C.c_void_p]),
     "gfv_record_begin": (C.c_int, []),
     "gfv_record_count": (C.c_int, []),
     "gfv_record_end": (C.c_int64, []),
@@ -226,7 +243,7 @@ def load(raw=False):
     if lib.gfv_abi_version() != ABI_VERSION:
         raise RuntimeError(f"libgfv.so has ABI {lib.gfv_abi_version()}, this binding is written for {ABI_VERSION}: rebuild it "
                            "(python gen-fvgn-steady_amd/gfv/build.py)")
-    for which, st in enumerate((Seg, Layer, RowtileArgs, WimgDesc, DwTile, ReducePiece, PlanDesc)):
+    for which, st in enumerate((Seg, Layer, RowtileArgs, WimgDesc, DwTile, ReducePiece, PlanDesc, TransMlp, TransMlpBwd)):
         if lib.gfv_struct_size(which) != C.sizeof(st):
             raise RuntimeError(f"libgfv.so: struct {st.__name__} is {lib.gfv_struct_size(which)} bytes in the library, "
                                f"{C.sizeof(st)} in the binding")

@@ -331,6 +331,42 @@ def rowtile_chain(M, segs, layers, outs, *, in_add=None, in_op=L.IN_NONE, in_gam
     return gscale is not None and lib.gfv_rowtile_last_path() >= 5
 
 
+def trans_mlp_fwd(x, res, Wout, bout, gamma, beta, Wpre, bpre, Wpost, bpost, fx1, z, out):
+    """The row-local chain of a Transolver block's forward in one launch (include/gfv.h gfv_trans_mlp_fwd).  False: not available
+    (fp32-MFMA form, or no split-fp16 image of one of the three weights) - the caller issues the three single-layer launches."""
+    lib = L.load()
+    if _WI is None or not lib.gfv_f16split_enabled():
+        return False
+    hs = (_WI.lookup(Wout), _WI.lookup(Wpre), _WI.lookup(Wpost))
+    if not all(hs):
+        return False
+    a = L.TransMlp()
+    a.x, a.res, a.img_out, a.img_pre, a.img_post = x.data_ptr(), res.data_ptr(), hs[0], hs[1], hs[2]
+    a.b_out, a.b_pre, a.b_post = _p(bout), _p(bpre), _p(bpost)
+    a.gamma, a.beta, a.wmax = gamma.data_ptr(), beta.data_ptr(), _WI.wmax.data_ptr()
+    a.fx1, a.z, a.out, a.M = fx1.data_ptr(), z.data_ptr(), out.data_ptr(), x.shape[0]
+    L.check(lib.gfv_trans_mlp_fwd(C.byref(a), L.stream_ptr()), "gfv_trans_mlp_fwd")
+    return True
+
+
+def trans_mlp_bwd(g, g_add, g_sum, z, fx1, Wpost_t, Wpre_t, Wout_t, gamma, g_z, g_fx1, g_out_x, ln_partial, gscale):
+    """... and of its backward (gfv_trans_mlp_bwd); the W*_t are the TRANSPOSED weights ([256,128], [128,256], [128,128])."""
+    lib = L.load()
+    if _WI is None or not lib.gfv_f16split_enabled():
+        return False
+    hs = (_WI.lookup(Wpost_t), _WI.lookup(Wpre_t), _WI.lookup(Wout_t))
+    if not all(hs):
+        return False
+    a = L.TransMlpBwd()
+    a.g, a.g_add, a.g_sum, a.z, a.fx1 = g.data_ptr(), _p(g_add), _p(g_sum), z.data_ptr(), fx1.data_ptr()
+    a.img_post_t, a.img_pre_t, a.img_out_t = hs
+    a.gamma, a.wmax = gamma.data_ptr(), _WI.wmax.data_ptr()
+    a.g_z, a.g_fx1, a.g_out_x = g_z.data_ptr(), g_fx1.data_ptr(), g_out_x.data_ptr()
+    a.ln_partial, a.gscale, a.M = _p(ln_partial), _p(gscale), g.shape[0]
+    L.check(lib.gfv_trans_mlp_bwd(C.byref(a), L.stream_ptr()), "gfv_trans_mlp_bwd")
+    return True
+
+
 def linear_dw(G, n_out, segs, M, *, ldg=None, in_add=None, a_op=0, a_gamma=None, a_beta=None, dW=None, db=None,
               want_db=True, accumulate=False, workspace=None, g_offset=0, gscale=None, col_scale=False):
     """dW[n,k] = sum_m G[m,n] A[m,k]; db[n] = sum_m G[m,n].  Returns (dW [n_out,K], db [n_out] or None).

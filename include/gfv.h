@@ -28,7 +28,8 @@ extern "C" {
 #define GFV_ABI_VERSION 2
 int gfv_abi_version(void);
 /* sizeof of the argument structs as the library was compiled (which: 0 gfv_seg_t, 1 gfv_layer_t, 2 gfv_rowtile_args_t,
- * 3 gfv_wimg_desc_t, 4 gfv_dw_tile_t, 5 gfv_reduce_piece_t, 6 gfv_plan_desc_t): lets a binding check its own layout */
+ * 3 gfv_wimg_desc_t, 4 gfv_dw_tile_t, 5 gfv_reduce_piece_t, 6 gfv_plan_desc_t, 7 gfv_trans_mlp_t, 8 gfv_trans_mlp_bwd_t): lets a
+ * binding check its own layout */
 int gfv_struct_size(int32_t which);
 
 /* ------------------------------------------------------------------------------------------------------------
@@ -177,7 +178,7 @@ typedef struct {
    * prologue result, gz2 = layer 0's product, z2 / z1 = layer[0].aux / layer[1].aux), their bias gradients (column sums of
    * g3 / gz2) and the LayerNorm's (dgamma, dbeta).  With dw_partial set the launch accumulates them per workgroup - no float
    * atomics - and leaves  dw_partial[wg * dw_partial_stride + ...] = [dW3 (128 x 128, row n, column k) | db3 (128) | dW2 |
-   * db2 | dgamma | dbeta]  (GFV_DW_FUSED_FLOATS floats) for wg < gfv_rowtile_dw_partials(); sum them with gfv_reduce_multi.
+   * db2 | dgamma | dbeta]  (GFV_DW_FUSED_FLOATS floats) for wg < gfv_rowtile_dw_partials_m(M); sum them with gfv_reduce_multi.
    * layer[0].save / in_save / ln_partial may then be NULL (nothing else reads g3 / gz2). */
   float* dw_partial;
   int64_t dw_partial_stride;
@@ -198,7 +199,8 @@ typedef struct {
   const float* rc_bias[2];
 } gfv_rowtile_args_t;
 enum { GFV_DW_FUSED_FLOATS = 2 * 128 * 128 + 4 * 128, GFV_DW_FUSED_FLOATS_IN = 3 * 128 * 128 + 5 * 128 };
-int gfv_rowtile_dw_partials(void);                              /* workgroups (= partial blocks) of a fused launch */
+int gfv_rowtile_dw_partials(void);                              /* the most workgroups (= partial blocks) a fused launch runs */
+int gfv_rowtile_dw_partials_m(int32_t M);                       /* ... a fused launch over M rows runs: blocks 0 .. this - 1 are written */
 int gfv_rowtile_fuses_dw(const gfv_rowtile_args_t* args);       /* 1: gfv_rowtile_chain would run this launch with fused weight gradients */
 
 int gfv_rowtile_tiles(int32_t M); /* number of 64-row tiles = rows of ln_partial */
@@ -599,6 +601,56 @@ int gfv_plan_destroy(gfv_plan_t* plan);                 /* NULL is accepted */
 int gfv_plan_table(const gfv_plan_t* plan, int32_t which, const void** ptr, int64_t* count);
 /* sizes5 = {N, E, C, Sigma, S = 2 n_stencil_pairs + n_support_pairs} */
 int gfv_plan_sizes(const gfv_plan_t* plan, int64_t* sizes5);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * The row-local Linear chains of a Transolver block, one launch each (round 5; split-fp16 product forms only: GFV_ERR_ARG under
+ * gfv_set_f16split(0), where the caller issues the three gfv_rowtile_chain launches instead).  All arrays row-major fp32 with
+ * row stride = width, 16-byte aligned; img_* = split-fp16 images (gfv_weight_images, built with `wmax`) of the named weights.
+ *   forward:   fx1 = out_x W_out^T + b_out + fx_in;   z = LayerNorm(fx1; gamma, beta) W_pre^T + b_pre   [M,256];
+ *              out = gelu(z) W_post^T + b_post + fx1          (GraphTransolver.py:93-95,163-169)
+ *   backward:  g = g_out (+ g_add) (-> g_sum);  g_z = (g W_post) * gelu'(z);  g_fx1 = LayerNorm-backward(g_z W_pre; fx1, gamma) + g;
+ *              g_out_x = g_fx1 W_out;  ln_partial[tile, 0:128 | 128:256] = per-64-row-tile (dgamma, dbeta) sums (gfv_rowtile_tiles(M)
+ *              rows; sum them with gfv_reduce_multi);  gscale[row / 16] = the 16-row-group scales of g (gfv_dw_tile_t.gscale).
+ *   The backward takes the images of the TRANSPOSED weights: img_post_t of W_post^T [256,128], img_pre_t of W_pre^T [128,256],
+ *   img_out_t of W_out^T [128,128].  The weight gradients stay with gfv_dw_multi (they read g / z, g_z / fx1, g_fx1 / out_x).
+ * ---------------------------------------------------------------------------------------------------------- */
+typedef struct {
+  const float* x;        /* out_x [M,128] */
+  const float* res;      /* fx_in [M,128] */
+  const void* img_out;   /* to_out.0.weight [128,128] */
+  const void* img_pre;   /* mlp.linear_pre.0.weight [256,128] */
+  const void* img_post;  /* mlp.linear_post.weight [128,256] */
+  const float* b_out;    /* [128] or NULL */
+  const float* b_pre;    /* [256] or NULL */
+  const float* b_post;   /* [128] or NULL */
+  const float* gamma;    /* ln_2 [128] */
+  const float* beta;
+  const float* wmax;
+  float* fx1;            /* [M,128] out (saved for the backward) */
+  float* z;              /* [M,256] out (saved) */
+  float* out;            /* [M,128] */
+  int32_t M, reserved;
+} gfv_trans_mlp_t;
+typedef struct {
+  const float* g;        /* [M,128] */
+  const float* g_add;    /* optional [M,128] */
+  float* g_sum;          /* optional [M,128] */
+  const float* z;        /* [M,256] */
+  const float* fx1;      /* [M,128] */
+  const void* img_post_t;
+  const void* img_pre_t;
+  const void* img_out_t;
+  const float* gamma;
+  const float* wmax;
+  float* g_z;            /* [M,256] out */
+  float* g_fx1;          /* [M,128] out */
+  float* g_out_x;        /* [M,128] out */
+  float* ln_partial;     /* optional [gfv_rowtile_tiles(M), 256] */
+  float* gscale;         /* optional [ceil(M / 128) * 8] */
+  int32_t M, reserved;
+} gfv_trans_mlp_bwd_t;
+int gfv_trans_mlp_fwd(const gfv_trans_mlp_t* args, void* stream);
+int gfv_trans_mlp_bwd(const gfv_trans_mlp_bwd_t* args, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Native command list (round 5).  Between gfv_record_begin and gfv_record_end every kernel launch the CALLING THREAD issues

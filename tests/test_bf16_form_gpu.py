@@ -170,7 +170,7 @@ def test_column_owner_backward_in_the_bf16_form(dev, bf16_form, M, rc):
     wi = _images(dev, [P["W1"], P["W2"], P["W3"]])
     god = d(go)
     gz1d, ged = (torch.full((M, 128), float("nan"), device=dev) for _ in range(2))
-    part = torch.full((L.load().gfv_rowtile_dw_partials(), L.DW_FUSED_FLOATS), float("nan"), device=dev)
+    part = torch.full((L.load().gfv_rowtile_dw_partials_m(M), L.DW_FUSED_FLOATS), float("nan"), device=dev)
     kw = dict(rc=(Pd["W2"], Pd["b2"], Pd["W3"], Pd["b3"])) if rc else {}
     layers = [ops.LayerSpec(ops.transpose(Pd["W3"]), None, L.OP_MUL_DGELU, aux=None if rc else d(z2.float())),
               ops.LayerSpec(ops.transpose(Pd["W2"]), None, L.OP_MUL_DGELU, save=gz1d, aux=d(z1.float())),

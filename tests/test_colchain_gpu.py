@@ -84,7 +84,7 @@ def test_column_owner_backward_with_fused_weight_gradients(dev, M, extras, dw1):
     god = d(go)
     gz1 = torch.full((M, 128), float("nan"), device=dev)
     ge = torch.full((M, 128), float("nan"), device=dev)
-    nwg = L.load().gfv_rowtile_dw_partials()
+    nwg = L.load().gfv_rowtile_dw_partials_m(M)
     part = torch.full((nwg, L.DW_FUSED_FLOATS_IN if dw1 else L.DW_FUSED_FLOATS), float("nan"), device=dev)
     kw = dict(gadd=d(gagg), gadd_s=d(s.int()), gadd_r=d(r.int()), in_add=d(gadd2)) if extras else {}
     rc = dw1 == "rc"     # recompute form: neither z2 nor the LayerNorm input is handed over
@@ -147,7 +147,7 @@ def test_column_owner_backward_node_mlp_192_wide(dev, M, rc):
     wi = _images(dev, [P["W1"], P["W2"], P["W3"]])
     gx, gnbm = torch.full((M, 128), float("nan"), device=dev), torch.full((M, 64), float("nan"), device=dev)
     gz1 = torch.full((M, 128), float("nan"), device=dev)
-    part = torch.full((L.load().gfv_rowtile_dw_partials(), L.DW_FUSED_FLOATS), float("nan"), device=dev)
+    part = torch.full((L.load().gfv_rowtile_dw_partials_m(M), L.DW_FUSED_FLOATS), float("nan"), device=dev)
     gs = torch.zeros(3, ops.gscale_ld(M), device=dev)
     god = d(go)
     rckw = {}
@@ -191,7 +191,7 @@ def test_column_owner_backward_without_input_gradient(dev, M, rc):
     stats = d(torch.stack((y3.detach().mean(1), (y3.detach().var(1, unbiased=False) + 1e-5).rsqrt()), 1).float())
     wi = _images(dev, [P["W2"], P["W3"]])
     gz1 = torch.full((M, 128), float("nan"), device=dev)
-    part = torch.full((L.load().gfv_rowtile_dw_partials(), L.DW_FUSED_FLOATS), float("nan"), device=dev)
+    part = torch.full((L.load().gfv_rowtile_dw_partials_m(M), L.DW_FUSED_FLOATS), float("nan"), device=dev)
     gs = torch.zeros(3, ops.gscale_ld(M), device=dev)
     god = d(go)
     rckw = {}

@@ -35,7 +35,8 @@ def test_ctypes_structs_match_header_layout():
     assert C.sizeof(lib.DwTile) == 6 * 8 + 6 * 4 + 2 * 8 + 8   # (+ gscale)
     assert C.sizeof(lib.RowtileArgs) % 8 == 0
     handle = lib.load()   # the library reports the sizes it was compiled with
-    for which, st in enumerate((lib.Seg, lib.Layer, lib.RowtileArgs, lib.WimgDesc, lib.DwTile, lib.ReducePiece, lib.PlanDesc)):
+    for which, st in enumerate((lib.Seg, lib.Layer, lib.RowtileArgs, lib.WimgDesc, lib.DwTile, lib.ReducePiece, lib.PlanDesc, lib.TransMlp,
+                                lib.TransMlpBwd)):
         assert handle.gfv_struct_size(which) == C.sizeof(st), (which, st)
 
 
