@@ -61,7 +61,9 @@ struct CfLds {
 // RAGIN: ONE narrow segment (width <= 32, any row stride: the encoders' raw inputs), loaded element by element
 // NW: waves per workgroup - 4 (a wave owns NT = 2 n-tiles = 32 columns) or 8 (one n-tile = 16 columns: twice the waves in
 // flight per tile, half the instruction stream per wave; the columns a wave produces are then HALF a k-group of the next layer)
-template <int KT0, int N0, int TG, bool PADD, int LOWP, bool RAGIN, int NW = 4>
+// FINLN = false: no LayerNorm and a NARROW last layer (the decoder, EPD.py:199-219: 128 -> 128 -> 128 -> 3): the wave that owns
+// columns 0 .. 15 runs the last layer alone and stores the N <= 16 valid columns (any output row stride)
+template <int KT0, int N0, int TG, bool PADD, int LOWP, bool RAGIN, int NW = 4, bool FINLN = true>
 __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void cfwd_kernel(const gfv_rowtile_args_t A, int* status) {
   static_assert(TG == 2 || TG == 4, "one loader wave per group");
   static_assert(NW == 4 || NW == 8, "32 or 16 columns per wave");
@@ -155,7 +157,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void cfwd_kernel(const gf
   float4 bias[3][NT];
 #pragma unroll
   for (int l = 0; l < 3; ++l) {
-    const float* bp = A.layer[l].bias;
+    const float* bp = (FINLN || l < 2) ? A.layer[l].bias : nullptr;
 #pragma unroll
     for (int n = 0; n < NT; ++n) bias[l][n] = bp ? ld4(bp + c0 + 16 * n) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
@@ -257,8 +259,10 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void cfwd_kernel(const gf
   hidden(1, b0, A.layer[1].save);
   // LayerNorm affine and the residual rows: requested ahead of the last layer
   float4 gam[NT], bet[NT];
+  if constexpr (FINLN) {
 #pragma unroll
-  for (int n = 0; n < NT; ++n) { gam[n] = ld4(A.fin_gamma + c0 + 16 * n); bet[n] = ld4(A.fin_beta + c0 + 16 * n); }
+    for (int n = 0; n < NT; ++n) { gam[n] = ld4(A.fin_gamma + c0 + 16 * n); bet[n] = ld4(A.fin_beta + c0 + 16 * n); }
+  }
   float4 rres[TG][NT];
   if (A.res[0]) {
 #pragma unroll
@@ -269,6 +273,27 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void cfwd_kernel(const gf
     }
   }
   cf_barrier();
+  if constexpr (!FINLN) {
+    // ---- narrow last layer (N <= 16 columns): wave 0's first n-tile; bias read element-wise (its array has N entries) ----
+    if (w == 0) {
+      mma(b0, std::integral_constant<int, 4>{});
+      const int ncol = A.layer[2].N;
+      const float* bp = A.layer[2].bias;
+#pragma unroll
+      for (int q = 0; q < TG; ++q) {
+        const int row = row0 + 16 * q + j;
+        if (q < ngt && row < A.M) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int col = 4 * g + r;
+            if (col < ncol) A.out[0][(size_t)row * A.out_ld[0] + col] = (acc[q][0][r] * CF_SH_INV) * invw + (bp ? bp[col] : 0.f);
+          }
+        }
+      }
+    }
+    if (mabs > CF_SH_LIMIT) atomicOr(status, 2);
+    return;
+  }
   // ---- layer 2: b0 -> y; LayerNorm ----
   mma(b0, std::integral_constant<int, 4>{});
   // LayerNorm width: a narrower model runs zero padded to 128 columns, and WHERE its h real columns sit depends on the tensor
@@ -353,7 +378,7 @@ int cf_env(const char* n, int dflt) {
   return e ? atoi(e) : dflt;
 }
 
-template <int KT0, int N0, bool PADD, bool RAGIN>
+template <int KT0, int N0, bool PADD, bool RAGIN, bool FINLN = true>
 void cf_launch(const gfv_rowtile_args_t& a, int tg, int lowp, hipStream_t stream) {
   int* st = gfv_internal_status_ptr();
   const int tiles = (a.M + 16 * tg - 1) / (16 * tg);
@@ -363,8 +388,8 @@ void cf_launch(const gfv_rowtile_args_t& a, int tg, int lowp, hipStream_t stream
   const dim3 grid(PADD ? gfv_xcd_grid(tiles) : tiles), blk(tg == 2 ? 512 : 256);
 #define CF_TG(LP)                                                                                              \
   do {                                                                                                         \
-    if (tg == 2) GFV_LAUNCH((cfwd_kernel<KT0, N0, 2, PADD, LP, RAGIN, 8>), grid, blk, 0, stream, a, st);       \
-    else GFV_LAUNCH((cfwd_kernel<KT0, N0, 4, PADD, LP, RAGIN, 4>), grid, blk, 0, stream, a, st);              \
+    if (tg == 2) GFV_LAUNCH((cfwd_kernel<KT0, N0, 2, PADD, LP, RAGIN, 8, FINLN>), grid, blk, 0, stream, a, st); \
+    else GFV_LAUNCH((cfwd_kernel<KT0, N0, 4, PADD, LP, RAGIN, 4, FINLN>), grid, blk, 0, stream, a, st);        \
   } while (0)
   if (lowp == 2) CF_TG(2);
   else if (lowp) CF_TG(1);
@@ -382,19 +407,24 @@ int gfv_internal_cfwd_try(const gfv_rowtile_args_t* a, int lowp, hipStream_t str
   static const int tg2_max = cf_env("GFV_CFWD_TG2_MAX_M", 40000);
   static const int rag_max = cf_env("GFV_CFWD_RAG_MAX_M", 16384);
   if (!on || a->nlayers != 3 || a->M > max_m || a->M < 1 || (a->flags & (GFV_CHAIN_ROW_OWNER | GFV_CHAIN_COLUMN_OWNER))) return 0;
-  if (a->fin_op != GFV_FIN_LN || a->in_op != GFV_IN_NONE || !a->wmax || !a->fin_gamma || !a->fin_beta) return 0;
+  // the decoder's shape: no LayerNorm, a last layer of <= 16 columns, nothing else around it
+  const bool dec = a->fin_op == GFV_FIN_PLAIN && a->layer[2].N >= 1 && a->layer[2].N <= 16 && !a->res[0] && !a->out_nores && !a->fin_presave &&
+                   !a->fin_stats && !a->padd && a->nseg == 1 && a->layer[0].K == 128;
+  if (a->in_op != GFV_IN_NONE || !a->wmax) return 0;
+  if (!dec && (a->fin_op != GFV_FIN_LN || !a->fin_gamma || !a->fin_beta)) return 0;
   if (a->in_add || a->gadd || a->in_save || a->in_aux || a->ln_partial || a->gscale || a->dw_partial || a->in_stats || a->fin_aux) return 0;
   for (int l = 0; l < 3; ++l) {
     const gfv_layer_t& L = a->layer[l];
-    if (!L.Wh || L.N != 128 || L.aux || L.bias2 || (L.bias && !cf_al16(L.bias))) return 0;
+    if (!L.Wh || (L.N != 128 && !(dec && l == 2)) || L.aux || L.bias2 || (L.bias && !cf_al16(L.bias) && !(dec && l == 2))) return 0;
     if (L.op != (l < 2 ? GFV_OP_BIAS_GELU : GFV_OP_NONE)) return 0;
     if (l > 0 && L.K != 128) return 0;
     if (L.save && !cf_al16(L.save)) return 0;
   }
   if (a->layer[2].save) return 0;
-  if (!a->out[0] || a->out[1] || a->out[2] || (a->out_ld[0] & 3) || !cf_al16(a->out[0]) || a->res[1] || a->res[2]) return 0;
+  if (!a->out[0] || a->out[1] || a->out[2] || (!dec && ((a->out_ld[0] & 3) || !cf_al16(a->out[0]))) || a->res[1] || a->res[2]) return 0;
   if (a->res[0] && ((a->res_ld[0] & 3) || !cf_al16(a->res[0]))) return 0;
-  if ((a->out_nores && !cf_al16(a->out_nores)) || (a->fin_presave && !cf_al16(a->fin_presave)) || !cf_al16(a->fin_gamma) || !cf_al16(a->fin_beta))
+  if ((a->out_nores && !cf_al16(a->out_nores)) || (a->fin_presave && !cf_al16(a->fin_presave)) ||
+      (!dec && (!cf_al16(a->fin_gamma) || !cf_al16(a->fin_beta))))
     return 0;
   if (a->fin_stats && (reinterpret_cast<size_t>(a->fin_stats) & 7)) return 0;
   for (int i = 0; i < a->nseg; ++i)
@@ -411,6 +441,8 @@ int gfv_internal_cfwd_try(const gfv_rowtile_args_t* a, int lowp, hipStream_t str
       shape = 1;
   } else if (a->nseg == 2 && K0 == 192 && plain(0, 64) && plain(1, 128)) {
     shape = 0;
+  } else if (dec) {
+    if (plain(0, 128) && a->M <= rag_max) shape = 4;
   } else if (a->nseg == 1 && K0 == 128 && plain(0, 128)) {
     shape = 2;
   } else if (a->nseg == 1 && K0 <= 32 && a->seg[0].width == K0 && a->M <= rag_max) {
@@ -421,6 +453,7 @@ int gfv_internal_cfwd_try(const gfv_rowtile_args_t* a, int lowp, hipStream_t str
   if (shape == 0) cf_launch<6, 4, false, false>(*a, tg, lowp, stream);
   else if (shape == 1) cf_launch<4, 8, true, false>(*a, tg, lowp, stream);
   else if (shape == 2) cf_launch<4, 8, false, false>(*a, tg, lowp, stream);
+  else if (shape == 4) cf_launch<4, 8, false, false, false>(*a, tg, lowp, stream);
   else cf_launch<1, 2, false, true>(*a, tg, lowp, stream);
   return 1;
 }

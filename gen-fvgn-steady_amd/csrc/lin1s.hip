@@ -59,8 +59,10 @@ struct L1sLds {
 
 // KS: 32-wide k-groups (4 / 8); NP: 128-column output passes; IN_OP: 0 none, 1 GELU, 2 LayerNorm; EPI: 0 bias / residual,
 // 1 x GELU'(aux), 2 LayerNorm backward (+ residual, per-tile partials); CSR: two segmented-sum segments; LOWP: product form
+// (CSR with KS = 4: ONE segmented-sum segment - the GnBlock's neighbour sum in front of the EdgeBlock's node projection)
 template <int KS, int NP, int IN_OP, int EPI, bool CSR, int LOWP, int TG>
 __global__ __launch_bounds__(256, 2) void lin1s_kernel(const Lin1sArgs A, int* status) {
+  constexpr int NSEG = KS / 4;   // 128-wide segments of the input
   using LY = L1sLds<KS, TG>;
   constexpr bool BF = LOWP == 2;
   __shared__ __attribute__((aligned(16))) char lds[LY::TOTAL];
@@ -105,18 +107,19 @@ __global__ __launch_bounds__(256, 2) void lin1s_kernel(const Lin1sArgs A, int* s
         for (int e = 0; e < 8; ++e) v[T][e] = 0.f;
       const int mc = (int)mr;
       int kk[2], ee[2], cn0[2], cn1[2];
+      kk[1] = ee[1] = 0;
 #pragma unroll
-      for (int s = 0; s < 2; ++s) {
+      for (int s = 0; s < NSEG; ++s) {
         kk[s] = A.rowptr[s][mc];
         ee[s] = live ? A.rowptr[s][mc + 1] : kk[s];
         cn0[s] = kk[s] < ee[s] ? A.col[s][kk[s]] : 0;
         cn1[s] = kk[s] + 1 < ee[s] ? A.col[s][kk[s] + 1] : cn0[s];
       }
       while (kk[0] < ee[0] || kk[1] < ee[1]) {
-        float4 a0[2][8], a1[2][8];
-        bool one[2], two[2];
+        float4 a0[NSEG][8], a1[NSEG][8];
+        bool one[NSEG], two[NSEG];
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
+        for (int s = 0; s < NSEG; ++s) {
           const int k = kk[s], end = ee[s];
           one[s] = k < end;
           two[s] = k + 1 < end;
@@ -137,7 +140,7 @@ __global__ __launch_bounds__(256, 2) void lin1s_kernel(const Lin1sArgs A, int* s
           }
         }
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
+        for (int s = 0; s < NSEG; ++s) {
 #pragma unroll
           for (int t = 0; t < 8; ++t) {
             float* d = &v[(4 * s + (t >> 1)) % KS][4 * (t & 1)];
@@ -148,7 +151,7 @@ __global__ __launch_bounds__(256, 2) void lin1s_kernel(const Lin1sArgs A, int* s
         }
       }
 #pragma unroll
-      for (int s = 0; s < 2; ++s) {
+      for (int s = 0; s < NSEG; ++s) {
         if (A.save[s] && live) {
 #pragma unroll
           for (int T = 0; T < 4; ++T) {
@@ -436,19 +439,26 @@ int gfv_internal_lin1s_try(const gfv_rowtile_args_t* a, int lowp, hipStream_t st
     B.ln_npad = (float)(128 - h);
   }
   int* st = gfv_internal_status_ptr();
-  const bool csr = a->nseg == 2 && a->seg[0].csr_rowptr && a->seg[1].csr_rowptr;
+  const bool csr = (a->nseg == 2 && a->seg[0].csr_rowptr && a->seg[1].csr_rowptr) || (a->nseg == 1 && a->seg[0].csr_rowptr);
   int epi = 0, iop = 0, ks = 0, np = 0, tg = 2;
   if (csr) {
-    if (L.op != GFV_OP_NONE || L.aux || L.bias || a->in_op != GFV_IN_NONE || a->fin_op != GFV_FIN_PLAIN || L.K != 256 || L.N != 128) return 0;
+    // two segments in front of [256 -> 128] (the per-side scatter of the factored EdgeBlock's adjoint), or one in front of
+    // [128 -> 256] (the neighbour sum in front of its node projection, two row-stacked blocks)
+    const bool one = a->nseg == 1;
+    if (L.op != GFV_OP_NONE || L.aux || L.bias || a->in_op != GFV_IN_NONE || a->fin_op != GFV_FIN_PLAIN ||
+        L.K != (one ? 128 : 256) || L.N != (one ? 256 : 128))
+      return 0;
     if (a->in_add || a->in_save || a->gscale || a->ln_partial || a->res[0] || a->res[1] || a->res[2]) return 0;
-    if (!a->out[0] || a->out[1] || a->out[2] || (a->out_ld[0] & 3) || !l1s_al16(a->out[0])) return 0;
-    for (int i = 0; i < 2; ++i) {
+    if (!a->out[0] || (one ? !a->out[1] : a->out[1] != nullptr) || a->out[2] || (a->out_ld[0] & 3) || !l1s_al16(a->out[0])) return 0;
+    if (one && ((a->out_ld[1] & 3) || !l1s_al16(a->out[1]))) return 0;
+    for (int i = 0; i < a->nseg; ++i) {
       const gfv_seg_t& sg = a->seg[i];
       if (sg.width != 128 || !sg.idx || sg.csr_scale || (sg.ld & 3) || !l1s_al16(sg.ptr) || (sg.save && !l1s_al16(sg.save))) return 0;
       B.seg[i] = sg.ptr; B.seg_ld[i] = sg.ld; B.rowptr[i] = sg.csr_rowptr; B.col[i] = sg.idx; B.save[i] = sg.save;
     }
     B.out[0] = a->out[0]; B.out_ld[0] = a->out_ld[0];
-    ks = 8; np = 1;
+    if (one) { B.out[1] = a->out[1]; B.out_ld[1] = a->out_ld[1]; }
+    ks = one ? 4 : 8; np = one ? 2 : 1;
   } else {
     if (a->nseg < 1 || a->nseg > 2 || L.K != 128 * a->nseg || (L.N != 128 && L.N != 256) || (a->nseg == 2 && L.N != 128)) return 0;
     for (int i = 0; i < a->nseg; ++i) {
@@ -499,7 +509,8 @@ int gfv_internal_lin1s_try(const gfv_rowtile_args_t* a, int lowp, hipStream_t st
 #define L1S_ONE(KS, NP, IOP, EPI, CSR, LP, TG) GFV_LAUNCH((lin1s_kernel<KS, NP, IOP, EPI, CSR, LP, TG>), grid, blk, 0, stream, B, st)
 #define L1S_FORM(LP)                                                                 \
   do {                                                                               \
-    if (csr) L1S_ONE(8, 1, 0, 0, true, LP, 2);                                       \
+    if (csr && ks == 4) L1S_ONE(4, 2, 0, 0, true, LP, 2);                            \
+    else if (csr) L1S_ONE(8, 1, 0, 0, true, LP, 2);                                  \
     else if (epi == 2) L1S_ONE(8, 1, 0, 2, false, LP, 4);                            \
     else if (epi == 1 && ks == 4 && np == 2) L1S_ONE(4, 2, 0, 1, false, LP, 2);      \
     else if (epi == 1 && ks == 4 && np == 1) L1S_ONE(4, 1, 0, 1, false, LP, 2);      \

@@ -89,7 +89,7 @@ int gfv_internal_lin1_try(const gfv_rowtile_args_t* a, int lowp, hipStream_t str
 int gfv_internal_cfwd_try(const gfv_rowtile_args_t* a, int lowp, hipStream_t stream, int dry);   // cfwd.hip
 // the column-owner small-tile forward (cfwd.hip) reads the LayerNorm width from its arguments
 static int cfwd_try(const gfv_rowtile_args_t* args, int lowp, hipStream_t stream, int dry) {
-  if (args->nlayers != 3 || args->fin_op != GFV_FIN_LN) return 0;
+  if (args->nlayers != 3 || (args->fin_op != GFV_FIN_LN && args->fin_op != GFV_FIN_PLAIN)) return 0;
   gfv_rowtile_args_t local = *args;
   local.hidden = g_hidden;
   return gfv_internal_cfwd_try(&local, lowp, stream, dry);

@@ -134,6 +134,7 @@ class Engine:
         # SIMD (tchain_fwd.hip) the two forward uses lose to a seg_gather_sum launch + a plain chain; step time, one-box
         # A/B, masks 7 / 3 / 1 / 2 / 0 / 6 / 5 / 4: 4.313 / 4.345 / 4.310 / 4.308 / 4.273 / 4.282 / 4.275 / 4.252 ms
         self._fuse_mask = int(os.environ.get("GFV_CSR_FUSE_MASK", "4"))
+        self._csr1_max = int(os.environ.get("GFV_CSR1_MAX_M", "16384"))   # bit 1 regardless of the mask up to this many node rows
         # weight gradients fused into the dX chain of the big MLP launches (column-owner backward family, include/gfv.h
         # gfv_rowtile_args_t.dw_partial): the chain launch accumulates dW3, dW2 (and dW1 of a 128-deep first layer), the bias
         # gradients and the LayerNorm's per workgroup; one reduction launch per MLP sums the blocks
@@ -632,7 +633,9 @@ class Engine:
         if self.factor:
             W1 = P[f"{prefix}.eb_module.net.0.0.weight"]                   # [128, 384] = [W1a | W1b | W1c]
             pab = _empty(x.device, N, 256)                                  # [W1a nb | W1b nb] per node
-            if fuse and (self._fuse_mask & 1) and ops.stack_ready(W1[:, 0:128], W1[:, 128:256], rows=True):
+            # (on short launches - the small-tile single-layer family's range, csrc/lin1s.hip - the prologue form always: one launch
+            # of ~6 us instead of two of 5 + 8)
+            if fuse and ((self._fuse_mask & 1) or N <= self._csr1_max) and ops.stack_ready(W1[:, 0:128], W1[:, 128:256], rows=True):
                 # nb = sum over the neighbours (blocks.py:84-99) formed in the prologue of the launch that multiplies it
                 nb = _empty(x.device, N, 128)
                 ops.rowtile_chain(N, [Seg(x, csr=(pl.n_rowptr, pl.n_col_node), save=nb)],

@@ -207,3 +207,35 @@ def test_small_tile_forward_narrow_model_layernorm_width(h, layout):
         assert rel(a[k], ref) < TOL, (k, rel(a[k], ref))
         assert rel(a[k], b[k]) < 4e-6, (k, rel(a[k], b[k]))
     assert bool((a["out"][:, ~real.cuda()] == 0).all())
+
+
+@pytest.mark.parametrize("M", [900, 33])
+def test_small_tile_forward_decoder_shape(M):
+    """The decoder (EPD.py:199-219): 128 -> 128 -> 128 -> 3, GELUs, no LayerNorm; the output has row stride 3."""
+    from gfv import lib as L, ops
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(M)
+    d = lambda t: t.cuda().contiguous()
+    x = torch.randn(M, 128, generator=g)
+    P = _params(g, 128)
+    P["W3"], P["b3"] = torch.randn(3, 128, generator=g) * 0.09, torch.randn(3, generator=g) * 0.1
+    Pd = {k: d(v) for k, v in P.items()}
+    wi = _wi([P["W1"], P["W2"], P["W3"]])
+    Pq = {k: v.double() for k, v in P.items()}
+    z1 = x.double() @ Pq["W1"].T + Pq["b1"]
+    z2 = F.gelu(z1) @ Pq["W2"].T + Pq["b2"]
+    y = F.gelu(z2) @ Pq["W3"].T + Pq["b3"]
+    res = {}
+    for fam in (0, L.CHAIN_ROW_OWNER):
+        s1, s2 = torch.full((M, 128), float("nan"), device=dev), torch.full((M, 128), float("nan"), device=dev)
+        out = torch.full((M, 3), float("nan"), device=dev)
+        ops.rowtile_chain(M, [ops.Seg(d(x))], [ops.LayerSpec(Pd["W1"], Pd["b1"], L.OP_BIAS_GELU, save=s1),
+                                               ops.LayerSpec(Pd["W2"], Pd["b2"], L.OP_BIAS_GELU, save=s2), ops.LayerSpec(Pd["W3"], Pd["b3"])],
+                          [out], wimg=wi, family=fam)
+        res[fam] = (s1, s2, out, L.load().gfv_rowtile_last_path())
+    torch.cuda.synchronize()
+    a, b = res[0], res[L.CHAIN_ROW_OWNER]
+    assert a[3] & 64 and not (b[3] & 64), (a[3], b[3])
+    for mine, other, ref, name in ((a[0], b[0], z1, "z1"), (a[1], b[1], z2, "z2"), (a[2], b[2], y, "out")):
+        assert rel(mine, ref) < TOL, (name, rel(mine, ref))
+        assert rel(mine, other) < 4e-6, (name, rel(mine, other))
