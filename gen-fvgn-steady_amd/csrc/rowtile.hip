@@ -67,6 +67,8 @@ extern "C" int gfv_set_hidden_size(int32_t h) {
 
 static thread_local int g_last_path = -1;
 extern "C" int gfv_rowtile_last_path(void) { return g_last_path; }
+static thread_local int g_last_ln_rows = 0;
+extern "C" int gfv_rowtile_last_ln_rows(void) { return g_last_ln_rows; }
 
 extern "C" int gfv_rowtile_tiles(int32_t M) { return (M + BM - 1) / BM; }
 
@@ -87,12 +89,20 @@ extern "C" int gfv_rowtile_chain(const gfv_rowtile_args_t* args, void* stream) {
 }
 int gfv_internal_lin1_try(const gfv_rowtile_args_t* a, int lowp, hipStream_t stream, int dry);   // lin1.hip
 int gfv_internal_cfwd_try(const gfv_rowtile_args_t* a, int lowp, hipStream_t stream, int dry);   // cfwd.hip
+int gfv_internal_cbwd_try(const gfv_rowtile_args_t* a, int lowp, hipStream_t stream, int dry);   // cbwd.hip
 // the column-owner small-tile forward (cfwd.hip) reads the LayerNorm width from its arguments
 static int cfwd_try(const gfv_rowtile_args_t* args, int lowp, hipStream_t stream, int dry) {
   if (args->nlayers != 3 || (args->fin_op != GFV_FIN_LN && args->fin_op != GFV_FIN_PLAIN)) return 0;
   gfv_rowtile_args_t local = *args;
   local.hidden = g_hidden;
   return gfv_internal_cfwd_try(&local, lowp, stream, dry);
+}
+// the column-owner small-tile backward (cbwd.hip): the dX chain behind a LayerNorm backward, no fused weight gradients
+static int cbwd_try(const gfv_rowtile_args_t* args, int lowp, hipStream_t stream, int dry) {
+  if (args->in_op != GFV_IN_LNBWD || args->dw_partial || !args->in_stats) return 0;
+  gfv_rowtile_args_t local = *args;
+  local.hidden = g_hidden;
+  return gfv_internal_cbwd_try(&local, lowp, stream, dry);
 }
 static int rowtile_chain_impl(const gfv_rowtile_args_t* args, void* stream) {
   if (!args || args->M < 0 || args->nlayers < 1 || args->nlayers > 3 || args->nseg < 1 || args->nseg > 3) return GFV_ERR_ARG;
@@ -203,11 +213,15 @@ static int rowtile_chain_impl(const gfv_rowtile_args_t* args, void* stream) {
     tok = gfv_prof_begin(kind, fl, by, (hipStream_t)stream);
   }
   g_last_path = (fast_t ? 1 : 2) + (f16 ? 4 : 0);
+  g_last_ln_rows = (args->M + BM - 1) / BM;
   if (args->dw_partial && !(fast_t && f16)) return GFV_ERR_ARG;   // (fused weight gradients: ask gfv_rowtile_fuses_dw first)
   if (fast_t && f16 && args->nlayers == 1 && gfv_internal_lin1_try(args, f16_mode() >= 2 ? f16_mode() - 1 : 0, (hipStream_t)stream, 0)) {
     g_last_path += 32;   // the lean single-layer kernel (lin1.hip)
   } else if (f16 && !args->dw_partial && cfwd_try(args, f16_mode() >= 2 ? f16_mode() - 1 : 0, (hipStream_t)stream, 0)) {
     g_last_path += 64;   // the column-owner small-tile forward (cfwd.hip)
+  } else if (fast_t && f16 && cbwd_try(args, f16_mode() >= 2 ? f16_mode() - 1 : 0, (hipStream_t)stream, 0)) {
+    g_last_path += 128;   // the column-owner small-tile backward (cbwd.hip): ln_partial holds one row per 32 rows
+    g_last_ln_rows = (args->M + 31) / 32;
   } else if (fast_t) {
     const int took = gfv_internal_tchain_launch(args, 0, f16 ? 1 : 0, (hipStream_t)stream);   // 1: the column-owner family, 2: with fused dW
     if (args->dw_partial && took != 2) return GFV_ERR_ARG;

@@ -169,6 +169,9 @@ class Engine:
         # 26 - 31 us per launch where the row-owner dX chain took 33 - 41 and left three weight-gradient tiles to the side queue:
         # 1.836 -> 1.77 ms per step, profiles/r05_cfwd.txt)
         self._fuse_dw_min = int(os.environ.get("GFV_COLCHAIN_BWD_MIN_M", "2048"))
+        # up to this many rows the dX chain of an MLP runs on the column-owner small-tile backward (csrc/cbwd.hip) and its weight
+        # gradients as one launch of the side queue; above it the persistent backward with fused weight gradients
+        self._cbwd_max = int(os.environ.get("GFV_CBWD_MAX_M", "16384")) if os.environ.get("GFV_CBWD", "1") != "0" else 0
         self._wi, self._wi_key, self._wmax, self._wi_abs = None, None, None, None
         self._pkey_cache = None
         self._zero_e = None
@@ -420,8 +423,10 @@ class Engine:
         nout = W3.shape[0]
         # (mean, 1 / std) of the LayerNorm rows for a backward launch that fuses the weight gradients (it does not recompute them)
         fused_bwd = (keep and ln and self.fuse_dw and self.f16split and self.hidden == 128 and nout == 128
-                     and M >= self._fuse_dw_min and (self._fuse_noout or all(sg.width % 32 == 0 for sg in segs)))
-        stats = _empty(dev, M, 2) if fused_bwd else None
+                     and M >= self._fuse_dw_min and M > self._cbwd_max
+                     and (self._fuse_noout or all(sg.width % 32 == 0 for sg in segs)))
+        # (the small-tile backward reads them as well)
+        stats = _empty(dev, M, 2) if (fused_bwd or (keep and ln and self.f16split and nout == 128 and M <= self._cbwd_max)) else None
         # that launch rebuilds z2 and the LayerNorm input from z1 (recompute form): they are not written here at all
         lean = fused_bwd and self.recompute
         z1 = _empty(dev, M, 128) if keep else None
@@ -438,7 +443,7 @@ class Engine:
             **(dict(padd=padd[0], padd_s=padd[1], padd_r=padd[2]) if padd is not None else {}))
         # (a segmented-sum input segment is kept for the backward in its assembled form, written by the launch itself)
         saved = dict(z1=z1, z2=z2, y3=y3, segs=segs if saved_segs is None else saved_segs, in_add=in_add, M=M, ln=ln,
-                     prefix=prefix, stats=stats, lean=lean)
+                     prefix=prefix, stats=stats, lean=lean, fused=fused_bwd)
         return out, nores, saved
 
     def _rematerialize(self, P, sv):
@@ -462,18 +467,18 @@ class Engine:
         dev = W1.device
         nout = W3.shape[0]
         W3t, W2t = self._T(W3), self._T(W2)
-        if (self.fuse_dw and ln and sv.get("stats") is not None and G.stride(0) == 128 and g_ld is None and gadd is None
+        if (self.fuse_dw and ln and sv.get("fused", sv.get("stats") is not None) and G.stride(0) == 128 and g_ld is None and gadd is None
                 and (outs is not None or (res is None and self._fuse_noout))
                 and self._mlp3_bwd_fused(P, sv, G, grads, names, W3t, W2t,
                                          None if outs is None else (W1t if W1t is not None else self._T(W1)), outs, res, g_add)):
             return
         self._rematerialize(P, sv)
         gz2, gz1 = _empty(dev, M, 128), _empty(dev, M, 128)
-        tiles_n = ops.rowtile_tiles(M)
-        part = _empty(dev, tiles_n, 2, 128) if ln else None
+        part = _empty(dev, ops.ln_rows(M), 2, 128) if ln else None
         g3 = _empty(dev, M, 128) if ln else G
         gseg = Seg(G, width=nout, ld=G.stride(0) if g_ld is None else g_ld)
-        kw = dict(in_op=L.IN_LNBWD, in_gamma=P[names[6]], in_aux=sv["y3"], in_save=g3, ln_partial=part) if ln else {}
+        kw = dict(in_op=L.IN_LNBWD, in_gamma=P[names[6]], in_aux=sv["y3"], in_save=g3, ln_partial=part,
+                  in_stats=sv.get("stats")) if ln else {}
         if gadd is not None:
             kw.update(gadd=gadd[0], gadd_s=gadd[1], gadd_r=gadd[2])
         if g_add is not None:   # G + g_add is the gradient (added in the prologue, before the LayerNorm backward)
@@ -491,6 +496,7 @@ class Engine:
             have = ops.rowtile_chain(M, [gseg],
                                      [LayerSpec(W3t, None, L.OP_MUL_DGELU, save=gz2, aux=sv["z2"]),
                                       LayerSpec(W2t, None, L.OP_MUL_DGELU, aux=sv["z1"])], [gz1], gscale=gs, **kw)
+        tiles_n = ops.last_ln_rows()   # (one row per 64 rows, per 32 when the small-tile backward took the launch)
         s0, s1, s2 = (gs[0], gs[1], gs[2]) if have else (None, None, None)
         if not ln and (gadd is not None or g_add is not None):
             s0 = None   # slot 0 describes the prologue RESULT (= g3 with LayerNorm); without it the weight gradient reads G
@@ -679,20 +685,20 @@ class Engine:
         dev = W1.device
         W3t, W2t, W1ct, Wabt = self._T(W3), self._T(W2), self._T(W1, perm="c"), self._T(W1, perm="ab")
         e = sv["segs"][0].t
-        if self.fuse_dw and sv.get("stats") is not None and e.stride(0) == 128 and G.stride(0) == 128:
+        if self.fuse_dw and sv.get("fused", sv.get("stats") is not None) and e.stride(0) == 128 and G.stride(0) == 128:
             fused = self._edge_bwd_fused(P, sv, G, grads, pl, gadd, names, (W3t, W2t, W1ct, Wabt))
             if fused is not None:
                 return fused
         self._rematerialize(P, sv)
         gz2, gz1, g3, g_e_in = (_empty(dev, M, 128) for _ in range(4))
-        tiles_n = ops.rowtile_tiles(M)
-        part = _empty(dev, tiles_n, 2, 128)
+        part = _empty(dev, ops.ln_rows(M), 2, 128)
         gs = _empty(dev, 3, ops.gscale_ld(M))
         have = ops.rowtile_chain(M, [Seg(G)],
                                  [LayerSpec(W3t, None, L.OP_MUL_DGELU, save=gz2, aux=sv["z2"]),
                                   LayerSpec(W2t, None, L.OP_MUL_DGELU, save=gz1, aux=sv["z1"]), LayerSpec(W1ct)],
                                  [g_e_in], res=[G], in_op=L.IN_LNBWD, in_gamma=P[names[6]], in_aux=sv["y3"], in_save=g3,
-                                 ln_partial=part, gadd=gadd[0], gadd_s=gadd[1], gadd_r=gadd[2], gscale=gs)
+                                 ln_partial=part, gadd=gadd[0], gadd_s=gadd[1], gadd_r=gadd[2], gscale=gs, in_stats=sv.get("stats"))
+        tiles_n = ops.last_ln_rows()
         s0, s1, s2 = (gs[0], gs[1], gs[2]) if have else (None, None, None)
         # adjoint of the gathers (W1a nb)[s], (W1b nb)[r]: per-side scatter of dz1 to the nodes, then ONE node-level GEMM
         g_nb = _empty(dev, N, 128)

@@ -110,6 +110,8 @@ _SIGNATURES = {
     "gfv_rowtile_tiles": (C.c_int, [C.c_int32]),
     "gfv_rowtile_chain": (C.c_int, [C.POINTER(RowtileArgs), C.c_void_p]),
     "gfv_rowtile_last_path": (C.c_int, []),
+    "gfv_rowtile_ln_rows": (C.c_int, [C.c_int32]),
+    "gfv_rowtile_last_ln_rows": (C.c_int, []),
     "gfv_rowtile_dw_partials": (C.c_int, []),
     "gfv_rowtile_dw_partials_m": (C.c_int, [C.c_int32]),
     "gfv_rowtile_fuses_dw": (C.c_int, [C.POINTER(RowtileArgs)]),

@@ -85,6 +85,16 @@ def rowtile_tiles(M):
     return (M + 63) // 64
 
 
+def ln_rows(M):
+    """Rows of an `ln_partial` buffer to provide for a chain launch over M rows (one per 32 rows; csrc/cbwd.hip)."""
+    return (M + 31) // 32
+
+
+def last_ln_rows():
+    """How many `ln_partial` rows the last chain launch filled (include/gfv.h: gfv_rowtile_last_ln_rows)."""
+    return L.load().gfv_rowtile_last_ln_rows()
+
+
 def gscale_ld(M):
     """Row length of a `gscale` buffer for M rows: one float per group of 16 rows, whole 128-row workgroups."""
     return (M + 127) // 128 * 8

@@ -135,7 +135,8 @@ typedef struct {
   const int32_t* gadd_s;
   const int32_t* gadd_r;
   float* in_save;         /* optional [M,128]: result of the prologue */
-  float* ln_partial;      /* GFV_IN_LNBWD / GFV_FIN_LNBWD: [n_tiles, 2, 128] per-tile (dgamma, dbeta) partial sums */
+  float* ln_partial;      /* GFV_IN_LNBWD / GFV_FIN_LNBWD: [n_tiles, 2, 128] per-tile (dgamma, dbeta) partial sums; provide
+                           * gfv_rowtile_ln_rows(M) rows, sum the first gfv_rowtile_last_ln_rows() of them (below) */
   gfv_layer_t layer[3];
   int32_t fin_op;
   int32_t hidden;         /* hidden_size of the model this launch belongs to (LayerNorm width; gfv_set_hidden_size); 0 = the calling
@@ -203,7 +204,12 @@ int gfv_rowtile_dw_partials(void);                              /* the most work
 int gfv_rowtile_dw_partials_m(int32_t M);                       /* ... a fused launch over M rows runs: blocks 0 .. this - 1 are written */
 int gfv_rowtile_fuses_dw(const gfv_rowtile_args_t* args);       /* 1: gfv_rowtile_chain would run this launch with fused weight gradients */
 
-int gfv_rowtile_tiles(int32_t M); /* number of 64-row tiles = rows of ln_partial */
+int gfv_rowtile_tiles(int32_t M); /* number of 64-row tiles = rows of ln_partial every family but the small-tile backward fills */
+/* rows of ln_partial to PROVIDE for a launch over M rows (one per 32 rows), and how many of them the calling thread's last
+ * gfv_rowtile_chain launch filled: ceil(M / 32) when the column-owner small-tile backward took it (csrc/cbwd.hip; last_path & 128),
+ * gfv_rowtile_tiles(M) otherwise.  The rows beyond that count are not written. */
+int gfv_rowtile_ln_rows(int32_t M);
+int gfv_rowtile_last_ln_rows(void);
 int gfv_rowtile_chain(const gfv_rowtile_args_t* args, void* stream);
 /* which kernel the calling thread's last gfv_rowtile_chain launch took: 1 register-resident chain, 2 its ragged-shape
  * instantiation (0 was the generic LDS row-tile kernel, retired with ABI 2); + 4 when the products ran as split-fp16; + 8 when the column-owner persistent
@@ -211,7 +217,9 @@ int gfv_rowtile_chain(const gfv_rowtile_args_t* args, void* stream);
  * one-Linear kernel (csrc/lin1.hip: the layer's image staged in LDS once per 128-row workgroup; same products, same
  * results to rounding), + 64 when a short 3-layer LayerNorm forward ran on the column-owner small-tile kernel (csrc/cfwd.hip:
  * a wave owns 32 output columns of a 32- / 64-row tile; hidden activations split behind a fixed scale as in the column-owner
- * backward) (tests assert the path they mean) */
+ * backward), + 128 when a short dX chain behind a LayerNorm backward (in_stats given, no fused weight gradients) ran on the
+ * column-owner small-tile backward (csrc/cbwd.hip: 32- / 64-row tiles on 8 waves, the scales of the persistent backward)
+ * (tests assert the path they mean) */
 int gfv_rowtile_last_path(void);
 
 /* fp32 products on the f16 MFMA pipe (v_mfma_f32_16x16x32_f16, 16x the f32 MFMA rate): every fp32 operand is split
