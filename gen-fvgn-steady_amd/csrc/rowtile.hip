@@ -89,6 +89,7 @@ extern "C" int gfv_rowtile_chain(const gfv_rowtile_args_t* args, void* stream) {
 }
 int gfv_internal_lin1_try(const gfv_rowtile_args_t* a, int lowp, hipStream_t stream, int dry);   // lin1.hip
 int gfv_internal_cfwd_try(const gfv_rowtile_args_t* a, int lowp, hipStream_t stream, int dry);   // cfwd.hip
+bool gfv_internal_wimg_form_ok(const float* wmax);                                               // wimg.hip
 int gfv_internal_cbwd_try(const gfv_rowtile_args_t* a, int lowp, hipStream_t stream, int dry);   // cbwd.hip
 // the column-owner small-tile forward (cfwd.hip) reads the LayerNorm width from its arguments
 static int cfwd_try(const gfv_rowtile_args_t* args, int lowp, hipStream_t stream, int dry) {
@@ -163,6 +164,8 @@ static int rowtile_chain_impl(const gfv_rowtile_args_t* args, void* stream) {
   bool f16 = (fast_t || rag_t) && f16_mode() != 0 && args->wmax != nullptr;
   for (int l = 0; l < args->nlayers; ++l) f16 = f16 && args->layer[l].Wh != nullptr;
   for (int i = 0; i + 1 < args->nseg; ++i) f16 = f16 && (args->seg[i].width % 32 == 0);
+  // images built in the other class of product form (fp16 parts against bf16 high parts: include/gfv.h) are refused, not multiplied
+  if (f16 && !gfv_internal_wimg_form_ok(args->wmax)) return GFV_ERR_ARG;
   // a layer may come without fp32 weights (a row-stacked virtual layer that exists as an image only): split form or nothing
   for (int l = 0; l < args->nlayers; ++l)
     if ((!args->layer[l].W || args->layer[l].bias2) && !f16) return GFV_ERR_ARG;

@@ -412,6 +412,8 @@ void tm_ln(float& inv_n, float& npad) {
 }
 }  // namespace
 
+bool gfv_internal_wimg_form_ok(const float* wmax);   // wimg.hip
+
 extern "C" int gfv_trans_mlp_fwd(const gfv_trans_mlp_t* a, void* stream) {
   if (!a || a->M < 0) return GFV_ERR_ARG;
   if (a->M == 0) return GFV_OK;
@@ -420,6 +422,7 @@ extern "C" int gfv_trans_mlp_fwd(const gfv_trans_mlp_t* a, void* stream) {
   const void* ptrs[] = {a->x, a->res, a->img_out, a->img_pre, a->img_post, a->gamma, a->beta, a->wmax, a->fx1, a->z, a->out};
   for (const void* p : ptrs)
     if (!p || !tm_al16(p)) return GFV_ERR_ARG;
+  if (!gfv_internal_wimg_form_ok(a->wmax)) return GFV_ERR_ARG;   // (images of the other class of product form: wimg.hip)
   if ((a->b_out && !tm_al16(a->b_out)) || (a->b_pre && !tm_al16(a->b_pre)) || (a->b_post && !tm_al16(a->b_post))) return GFV_ERR_ARG;
   TmFwdArgs B{};
   B.x = a->x; B.res = a->res; B.imgA = a->img_out; B.imgB = a->img_pre; B.imgC = a->img_post;
@@ -453,6 +456,7 @@ extern "C" int gfv_trans_mlp_bwd(const gfv_trans_mlp_bwd_t* a, void* stream) {
   const void* ptrs[] = {a->g, a->z, a->fx1, a->img_post_t, a->img_pre_t, a->img_out_t, a->gamma, a->wmax, a->g_z, a->g_fx1, a->g_out_x};
   for (const void* p : ptrs)
     if (!p || !tm_al16(p)) return GFV_ERR_ARG;
+  if (!gfv_internal_wimg_form_ok(a->wmax)) return GFV_ERR_ARG;
   if ((a->g_add && !tm_al16(a->g_add)) || (a->g_sum && !tm_al16(a->g_sum)) || (a->ln_partial && !tm_al16(a->ln_partial))) return GFV_ERR_ARG;
   TmBwdArgs B{};
   B.g = a->g; B.g_add = a->g_add; B.g_sum = a->g_sum; B.z = a->z; B.fx1 = a->fx1;

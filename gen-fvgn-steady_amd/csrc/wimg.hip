@@ -3,8 +3,20 @@
 #include "gfv_prof.h"
 #include "gfv_split.h"
 #include "../../include/gfv.h"
+#include <mutex>
+#include <unordered_map>
 
 namespace {
+
+// The form tag of a set of images (round 5).  An image holds fp16 (hi, lo) parts - forms 0 / 1 / 2 - or bf16 high parts and no low
+// parts - form 3 -, and nothing in its bytes says which; a launch in the other class of form would multiply garbage without any
+// error.  The images of one build share the device scalar they were scaled with (`wmax`), and every launch that uses them names
+// that scalar again: so the library remembers, per wmax address, the class its images were last built in (host state, updated
+// by gfv_weight_images - also while a command list is being recorded), and the entry points that take images refuse a launch whose
+// product form is of the other class (GFV_ERR_ARG).  An address the library has not seen (images a caller laid out itself) is
+// not checked.
+std::mutex g_tag_mu;
+std::unordered_map<const void*, int> g_tag;   // wmax address -> 0 fp16 parts, 1 bf16 high parts
 
 __global__ __launch_bounds__(256) void wabsmax_kernel(const gfv_wimg_desc_t* __restrict__ descs, float* __restrict__ wmax) {
   const gfv_wimg_desc_t d = descs[blockIdx.y];
@@ -80,8 +92,25 @@ extern "C" int gfv_weight_images(const gfv_wimg_desc_t* descs_dev, int32_t n_des
   GfvProfScope ps_(GFV_K_WIMG, 0, 32.0 * (double)max_frags * n_desc, stream);
   if (!descs_dev || !wmax || n_desc < 0 || max_frags < 0) return GFV_ERR_ARG;
   if (n_desc == 0 || max_frags == 0) return GFV_OK;
+  const int bf = gfv_f16split_enabled() == 3 ? 1 : 0;
+  {
+    std::lock_guard<std::mutex> lk(g_tag_mu);
+    g_tag[wmax] = bf;
+  }
   GFV_LAUNCH(wimg_kernel, dim3((unsigned)((max_frags + 255) / 256), n_desc), dim3(256), 0, (hipStream_t)stream,
-                     descs_dev, wmax, gfv_f16split_enabled() == 3 ? 1 : 0);
+                     descs_dev, wmax, bf);
   GFV_CHECK_LAUNCH();
   return GFV_OK;
+}
+
+// -1: images the library did not build; 0: fp16 parts (forms 0 - 2); 1: bf16 high parts (form 3)
+extern "C" int gfv_weight_images_form(const float* wmax) {
+  std::lock_guard<std::mutex> lk(g_tag_mu);
+  const auto it = g_tag.find(wmax);
+  return it == g_tag.end() ? -1 : it->second;
+}
+// may a launch of the calling thread's product form use the images that were scaled with `wmax`?
+bool gfv_internal_wimg_form_ok(const float* wmax) {
+  const int tag = gfv_weight_images_form(wmax);
+  return tag < 0 || tag == (gfv_f16split_enabled() == 3 ? 1 : 0);
 }

@@ -266,6 +266,11 @@ int gfv_weight_absmax(const gfv_wimg_desc_t* descs_dev, int32_t n_desc, float* w
 /* build every image; max_frags = max over descs of gfv_weight_image_bytes / 32 */
 int gfv_weight_images(const gfv_wimg_desc_t* descs_dev, int32_t n_desc, int64_t max_frags, const float* wmax,
                       void* stream);
+/* The form tag of a set of images: -1 = `wmax` is not the scale of images this library built, 0 = fp16 (hi, lo) parts (built in
+ * forms 0 / 1 / 2), 1 = bf16 high parts (built in form 3).  Kept per `wmax` address (host state, set by gfv_weight_images);
+ * gfv_rowtile_chain and gfv_trans_mlp_fwd / _bwd return GFV_ERR_ARG for a launch whose product form is of the other class than
+ * the images it names through args.wmax - images carry nothing in their bytes that would tell. */
+int gfv_weight_images_form(const float* wmax);
 
 /* Weight gradient of a Linear layer: dW[n,k] = sum_m G[m,n] * A[m,k], db[n] = sum_m G[m,n] (two-stage,
  * deterministic).  A is assembled like the forward input (segments, gather, optional GELU of a saved

@@ -95,6 +95,36 @@ def test_images_follow_the_form_they_are_used_in(dev):
         lib.gfv_set_f16split(1)
 
 
+def test_library_refuses_images_of_the_other_form_class(dev):
+    """The C-ABI side of the same rule (include/gfv.h, gfv_weight_images_form): the library remembers per `wmax` scalar which class
+    of parts its images were built with, and a launch in the other class of product form is GFV_ERR_ARG, not a product of
+    garbage - here the Python-side bookkeeping is told the stale fp16 images were bf16 ones."""
+    from gfv import lib as L, ops
+    lib = L.load()
+    g = torch.Generator().manual_seed(9)
+    M = 600
+    x, W = torch.randn(M, 128, generator=g).to(dev), (torch.randn(128, 128, generator=g) * 0.1).to(dev)
+    wi = _images(dev, [W.cpu()])
+    o = torch.full((M, 128), 7.0, device=dev)
+    try:
+        ops.rowtile_chain(M, [ops.Seg(x)], [ops.LayerSpec(W)], [o], wimg=wi)          # builds the fp16 (hi, lo) images
+        assert lib.gfv_weight_images_form(wi.wmax.data_ptr()) == 0
+        o.fill_(7.0)
+        lib.gfv_set_f16split(3)
+        wi._bf = True                                                                   # (suppresses the rebuild)
+        with pytest.raises(RuntimeError, match="gfv_rowtile_chain"):
+            ops.rowtile_chain(M, [ops.Seg(x)], [ops.LayerSpec(W)], [o], wimg=wi)
+        torch.cuda.synchronize()
+        assert bool((o == 7.0).all())
+        wi._bf = None                                                                   # the honest path: rebuilt as bf16 images
+        ops.rowtile_chain(M, [ops.Seg(x)], [ops.LayerSpec(W)], [o], wimg=wi)
+        assert lib.gfv_weight_images_form(wi.wmax.data_ptr()) == 1
+        assert rel(o, bfr(x.cpu()) @ bfr(W.cpu()).T) < TIGHT
+    finally:
+        lib.gfv_set_f16split(1)
+    assert lib.gfv_weight_images_form(wi.wmax.data_ptr() + 4) == -1      # (an address no set of images was scaled with)
+
+
 @pytest.mark.parametrize("M", [5000, 700])
 def test_weight_gradient_is_the_product_of_the_bf16_rounded_operands(dev, bf16_form, M):
     from gfv import ops
