@@ -17,6 +17,8 @@
 //       MFMA per ~10 vector instructions) - the instruction-level overlap round 4 could not afford in 256 registers
 //   C   16 waves, four per SIMD: 8 column owners x 2 row pairs, <= 128 registers; a wave owns a 2 x 2 block of the weight gradient (16
 //       accumulator registers per fused gradient) - more waves to hide each other's latencies instead of fewer
+//   D   16 waves of TWO KINDS on 32-row tiles: 8 chain waves on tile t beside 8 weight-gradient waves on tile t - 1 (fragments handed over
+//       in LDS, two generations), one barrier per 32-row tile: every SIMD holds two waves of each kind (cycles are per 64 ROWS = two of its tiles)
 // Each with the tiles' rows streaming from / to HBM (1 KB per row and chain phase: what a phase of the real kernel moves) and with every
 // tile of a workgroup on the same 64 rows (cache hits: the compute side alone).
 // Output: cycles per tile and phase kind (wall time x clock / tiles per workgroup), and the registers each form took.
@@ -388,6 +390,89 @@ __global__ __launch_bounds__(1024, 4) void phase_c(const Args A, int* status) {
   if (c.mabs > 3.0e38f) atomicOr(status, 2);
 }
 
+// ---- form D: 16 waves of TWO KINDS on 32-row tiles: waves 0 .. 7 run the chain phase of tile t (8 x 16 columns, one pair of groups)
+// while waves 8 .. 15 run the weight-gradient phase of tile t - 1 out of the fragments the chain waves left in LDS (two generations of
+// buffers); one barrier per tile.  Every SIMD then holds two chain waves and two weight-gradient waves: different phase kinds side by
+// side, which is what the lockstep forms cannot have.  <= 128 registers (chain waves carry no accumulators, weight-gradient waves no
+// chain state) ----
+__global__ __launch_bounds__(1024, 4) void phase_d(const Args A, int* status) {
+  __shared__ __attribute__((aligned(16))) char lds[5 * 2 * 8192];   // input pair | g generation 0, 1 | a generation 0, 1
+  char* bin = lds;
+  const int w16 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const bool dwk = w16 >= 8;   // (wave-uniform) kind
+  CcCtx c;
+  c.w = w16 & 7;
+  c.lane = threadIdx.x & 63;
+  c.j = c.lane & 15;
+  c.g = c.lane >> 4;
+  c.col0 = 16 * c.w + 4 * c.g;
+  c.M = A.M;
+  c.mabs = 0.f;
+  c.invw = 1.0f;
+  c.ngt = 2;
+  if (!dwk) {
+    for (int q = 0; q < 2; ++q) {
+      const float a[4] = {0.01f * c.lane, 0.02f * c.w, 0.5f, -0.25f + q};
+      cc_put_frag<false>(bin, q, c, a, 64.0f);
+      for (int gen = 0; gen < 2; ++gen) {
+        cc_put_frag<false>(lds + (1 + gen) * 16384, q, c, a, 64.0f);
+        cc_put_frag<false>(lds + (3 + gen) * 16384, q, c, a, 16.0f);
+      }
+    }
+  }
+  const size_t rows128 = (size_t)A.M * 512;
+  const cb_rsrc bz = cb_buf(A.z, rows128), bv = cb_buf(A.v, rows128), w0 = cb_buf(A.wimg, 65536);
+  const int woff = (c.w * 128 + c.lane) * 16;
+  floatx4 dw3[8], db3 = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < 8; ++k) dw3[k] = floatx4{0.f, 0.f, 0.f, 0.f};
+  const int ntile = 2 * A.tiles_per_wg;   // 32-row tiles
+  const int tile0 = blockIdx.x * ntile;
+  float4 zq[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) zq[h] = cb_ld4(bz, (tile0 * 32 + 16 * h + c.j) * 512 + c.col0 * 4);
+  cc_barrier();
+  for (int t = 0; t <= ntile; ++t) {
+    char* gcur = lds + (1 + (t & 1)) * 16384;
+    char* acur = lds + (3 + (t & 1)) * 16384;
+    const char* gprev = lds + (1 + ((t & 1) ^ 1)) * 16384;
+    const char* aprev = lds + (3 + ((t & 1) ^ 1)) * 16384;
+    if (!dwk) {
+      if (A.do_chain && t < ntile) {
+        c.row0 = (tile0 + (A.alias ? 0 : t)) * 32;
+        gfv_f16x8 wh[4], wl[4];
+#pragma unroll
+        for (int T = 0; T < 4; ++T) {
+          wh[T] = __builtin_bit_cast(gfv_f16x8, __builtin_amdgcn_raw_buffer_load_b128(w0, woff + T * 16384, 0, 0));
+          wl[T] = __builtin_bit_cast(gfv_f16x8, __builtin_amdgcn_raw_buffer_load_b128(w0, woff + T * 16384 + 1024, 0, 0));
+        }
+        floatx4 a0, a1;
+        cc_mma_pair<4, 0, true>(bin, 0, wh, wl, c.lane, a0, a1);
+        float v0[4], v1[4];
+        cb_hidden_bwd<false>(c, 0, a0, 1.0f / 64.0f, zq[0], 2.0f, gcur, acur, v0);
+        cb_hidden_bwd<false>(c, 1, a1, 1.0f / 64.0f, zq[1], 2.0f, gcur, acur, v1);
+        cb_st4(bv, (c.row0 + c.j) * 512 + c.col0 * 4, v0);
+        cb_st4(bv, (c.row0 + 16 + c.j) * 512 + c.col0 * 4, v1);
+        const int nr = (t + 1 < ntile && !A.alias) ? c.row0 + 32 : c.row0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) zq[h] = cb_ld4(bz, (nr + 16 * h + c.j) * 512 + c.col0 * 4);
+      }
+    } else if (A.do_dw && t > 0) {
+      cb_dw_tile<0>(gprev, aprev, 1, c.w, c.lane, dw3, db3);
+    }
+    cc_barrier();
+  }
+  if (dwk) {
+    float* blk = A.sink + (size_t)blockIdx.x * 16384;
+#pragma unroll
+    for (int kt = 0; kt < 8; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        blk[(16 * cb_dw_ntile(c.w, kt) + 4 * c.g + r) * 128 + 16 * cb_dw_ktile(c.w, kt) + c.j] = dw3[kt][r] + db3[r];
+  }
+  if (c.mabs > 3.0e38f) atomicOr(status, 2);
+}
+
 }  // namespace
 
 int main() {
@@ -426,19 +511,21 @@ int main() {
   attrs((const void*)phase_b<false>, "B");
   attrs((const void*)phase_b<true>, "Bw");
   attrs((const void*)phase_c, "C");
+  attrs((const void*)phase_d, "D");
   const char* kinds[3] = {"CHAIN", "DW", "CHAIN+DW"};
   for (int alias = 0; alias < 2; ++alias)
   for (int kind = 0; kind < 3; ++kind) {
     if (alias && kind == 1) continue;
     Args a{z, v, wimg, sink, M, tiles, kind != 1, kind != 0, alias};
-    for (int form = 0; form < 4; ++form) {
+    for (int form = 0; form < 5; ++form) {
       float best = 1e30f;
       for (int rep = 0; rep < 5; ++rep) {
         CK(hipEventRecord(e0, 0));
         if (form == 0) hipLaunchKernelGGL(phase_a, dim3(nwg), dim3(512), 0, 0, a, status);
         else if (form == 1) hipLaunchKernelGGL(phase_b<false>, dim3(nwg), dim3(256), 0, 0, a, status);
         else if (form == 2) hipLaunchKernelGGL(phase_b<true>, dim3(nwg), dim3(256), 0, 0, a, status);
-        else hipLaunchKernelGGL(phase_c, dim3(nwg), dim3(1024), 0, 0, a, status);
+        else if (form == 3) hipLaunchKernelGGL(phase_c, dim3(nwg), dim3(1024), 0, 0, a, status);
+        else hipLaunchKernelGGL(phase_d, dim3(nwg), dim3(1024), 0, 0, a, status);
         CK(hipEventRecord(e1, 0));
         CK(hipEventSynchronize(e1));
         float ms;
@@ -446,7 +533,7 @@ int main() {
         best = ms < best ? ms : best;
       }
       const double cyc = (double)best * 1e-3 * (double)pr.clockRate * 1e3 / tiles;
-      printf("%-9s %s form %-2s : %8.1f us per launch, %7.0f cycles per tile\n", kinds[kind], alias ? "(rows in cache)" : "(rows from HBM)", form == 0 ? "A" : (form == 1 ? "B" : (form == 2 ? "Bw" : "C")), best * 1e3, cyc);
+      printf("%-9s %s form %-2s : %8.1f us per launch, %7.0f cycles per tile\n", kinds[kind], alias ? "(rows in cache)" : "(rows from HBM)", form == 0 ? "A" : (form == 1 ? "B" : (form == 2 ? "Bw" : (form == 3 ? "C" : "D"))), best * 1e3, cyc);
     }
   }
   return 0;
