@@ -10,7 +10,7 @@
 // (colchain_kernel.h: 64-row tiles, 8 waves at 253 registers, the fused weight gradients' 72 accumulator registers, a 136 KB
 // partial block per workgroup) takes 25 - 30 us for ONE tile per workgroup, and that kernel needs a whole CU to itself - it waits
 // for the side queue's workgroups to leave.  The row-owner chain (tchain_kernel.h) takes 22 - 41 us for the same launch.  This is
-// the backward counterpart of cfwd.hip: a workgroup = ONE tile of 32 rows (TG = 2 groups of 16) or 64 rows (TG = 4) on 8 waves,
+// the backward counterpart of cfwd.hip: a workgroup = ONE tile of 32 rows (TG = 2 groups of 16) on 8 waves,
 // wave w owns output COLUMNS 16 w .. 16 w + 15 of every layer; the layers' weight slices come straight from L2 into registers a
 // phase ahead; activations cross waves as MFMA B fragments in LDS; 4 barriers per tile; at most 128 registers, 34 KB of LDS: two
 // tiles (or a tile and the side queue's workgroups) share a CU.  No fused weight gradients - a 32-row tile would leave a 136 KB
@@ -21,7 +21,7 @@
 // carry ONE power-of-two scale per tile taken from a bound before the barrier, gz2 / gz1 step down from it by the layers'
 // guaranteed growth bounds (row 1-norms of the weight images).  The LayerNorm width is the launch's (gfv_rowtile_args_t.hidden):
 // a narrower model's padded columns carry gamma = 0 and add nothing to the row sums.
-// ln_partial: one row [dgamma 128 | dbeta 128] per 32 ROWS of the launch (TG = 4: the odd rows are zeros) - gfv_rowtile_ln_rows(M)
+// ln_partial: one row [dgamma 128 | dbeta 128] per 32 ROWS of the launch - gfv_rowtile_ln_rows(M)
 // rows; every other kernel family writes one per 64 rows (include/gfv.h; gfv_rowtile_last_path() & 128 tells).
 #include <cstdlib>
 
@@ -76,7 +76,8 @@ __device__ __forceinline__ float cw_slice_norm(const gfv_f16x8 (&wh)[4], const g
 // GADD: the gathered addend [gadd[s] | gadd[r]] of the incoming gradient; OUT2: a 192-wide last layer (NodeBlock: out[1] [M, 64]
 // from the image's second pass, waves 0 .. 3); NOOUT: two layers, out[0] receives gz1 (the encoders)
 template <int TG, int LOWP, bool GADD, bool OUT2, bool NOOUT>
-__global__ __launch_bounds__(512, TG == 2 ? 4 : 2) void cbwd_kernel(const gfv_rowtile_args_t A, int* status) {
+__global__ __launch_bounds__(512, 4) void cbwd_kernel(const gfv_rowtile_args_t A, int* status) {
+  static_assert(TG == 2, "32-row tiles: the only form that is built and tested");
   using LY = CwLds<TG>;
   constexpr bool BF = LOWP == 2;
   constexpr int NP = TG / 2;
@@ -194,7 +195,7 @@ __global__ __launch_bounds__(512, TG == 2 ? 4 : 2) void cbwd_kernel(const gfv_ro
     if (c.lane == 0) { smax[c.w] = bmax; nrm[c.w] = n0; }
     // (dgamma, dbeta) of the tile: this wave owns its columns - a sum over the 16 lanes of a DPP row, no cross-wave step
     if (A.ln_partial) {
-      float* lp = A.ln_partial + (size_t)(TG == 4 ? 2 * blockIdx.x : blockIdx.x) * 256 + c.col0;
+      float* lp = A.ln_partial + (size_t)blockIdx.x * 256 + c.col0;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         dgam[r] = gfv_row16_sum(dgam[r]);
@@ -203,11 +204,6 @@ __global__ __launch_bounds__(512, TG == 2 ? 4 : 2) void cbwd_kernel(const gfv_ro
       if (c.j == 0) {
         st4(lp, dgam);
         st4(lp + 128, dbet);
-        if (TG == 4 && 64 * (int)blockIdx.x + 32 < c.M) {
-          const float z4[4] = {0.f, 0.f, 0.f, 0.f};
-          st4(lp + 256, z4);
-          st4(lp + 384, z4);
-        }
       }
     }
   }
@@ -353,18 +349,17 @@ int cw_env(const char* n, int dflt) {
   return e ? atoi(e) : dflt;
 }
 
-template <int TG, bool GADD, bool OUT2, bool NOOUT>
-void cw_launch_tg(const gfv_rowtile_args_t& a, int lowp, hipStream_t stream) {
+// 32-row tiles only.  (A 64-row instantiation was timed - slower at every size, profiles/r05_cfwd.txt run 20 / 21 - and then failed a
+// model-level check that reached it through the environment, 1.4e-3 on the gradients of a 50 k-cell mesh: it had no kernel test of
+// its own.  It is gone; the 32-row form is tested up to 41 003 rows and through the whole model at every size.)
+template <bool GADD, bool OUT2, bool NOOUT>
+void cw_launch(const gfv_rowtile_args_t& a, int lowp, hipStream_t stream) {
+  constexpr int TG = 2;
   int* st = gfv_internal_status_ptr();
   const dim3 grid((a.M + 16 * TG - 1) / (16 * TG)), blk(512);
   if (lowp == 2) GFV_LAUNCH((cbwd_kernel<TG, 2, GADD, OUT2, NOOUT>), grid, blk, 0, stream, a, st);
   else if (lowp) GFV_LAUNCH((cbwd_kernel<TG, 1, GADD, OUT2, NOOUT>), grid, blk, 0, stream, a, st);
   else GFV_LAUNCH((cbwd_kernel<TG, 0, GADD, OUT2, NOOUT>), grid, blk, 0, stream, a, st);
-}
-template <bool GADD, bool OUT2, bool NOOUT>
-void cw_launch(const gfv_rowtile_args_t& a, int tg, int lowp, hipStream_t stream) {
-  if (tg == 2) cw_launch_tg<2, GADD, OUT2, NOOUT>(a, lowp, stream);
-  else cw_launch_tg<4, GADD, OUT2, NOOUT>(a, lowp, stream);
 }
 
 }  // namespace
@@ -376,9 +371,10 @@ extern "C" int gfv_rowtile_ln_rows(int32_t M) { return (M + 31) / 32; }
 // 1: launched; 0: not a launch of this family.  lowp: 0 three products, 1 / 2 the single-product forms.  dry != 0: only tell
 // whether the launch would be taken.  `a` carries `hidden` (the launcher of rowtile.hip fills it in).
 int gfv_internal_cbwd_try(const gfv_rowtile_args_t* a, int lowp, hipStream_t stream, int dry) {
-  static const int on = cw_env("GFV_CBWD", 1);
-  static const int max_m = cw_env("GFV_CBWD_MAX_M", 16384);
-  static const int tg2_max = cw_env("GFV_CBWD_TG2_MAX_M", 16384);
+  // (read per launch - at record time under a command list -, not once: the tests move the row limit to reach the kernel at sizes
+  // the default leaves to the persistent backward)
+  const int on = cw_env("GFV_CBWD", 1);
+  const int max_m = cw_env("GFV_CBWD_MAX_M", 16384);
   if (!on || a->M > max_m || a->M < 1 || (a->flags & (GFV_CHAIN_ROW_OWNER | GFV_CHAIN_COLUMN_OWNER))) return 0;
   const bool noout = a->nlayers == 2;
   if ((a->nlayers != 3 && !noout) || a->in_op != GFV_IN_LNBWD || a->fin_op != GFV_FIN_PLAIN || a->nseg != 1) return 0;
@@ -404,10 +400,9 @@ int gfv_internal_cbwd_try(const gfv_rowtile_args_t* a, int lowp, hipStream_t str
   if (a->gadd && (!cw_al16(a->gadd) || !a->gadd_s || !a->gadd_r || out2 || noout)) return 0;
   if (a->ln_partial && !cw_al16(a->ln_partial)) return 0;
   if (dry) return 1;
-  const int tg = a->M <= tg2_max ? 2 : 4;
-  if (noout) cw_launch<false, false, true>(*a, tg, lowp, stream);
-  else if (out2) cw_launch<false, true, false>(*a, tg, lowp, stream);
-  else if (a->gadd) cw_launch<true, false, false>(*a, tg, lowp, stream);
-  else cw_launch<false, false, false>(*a, tg, lowp, stream);
+  if (noout) cw_launch<false, false, true>(*a, lowp, stream);
+  else if (out2) cw_launch<false, true, false>(*a, lowp, stream);
+  else if (a->gadd) cw_launch<true, false, false>(*a, lowp, stream);
+  else cw_launch<false, false, false>(*a, lowp, stream);
   return 1;
 }

@@ -67,12 +67,15 @@ def _ln_sums(part, M):
     return tot[0], tot[1]
 
 
-@pytest.mark.parametrize("M", [4000, 97, 1024, 33, 16384])
+@pytest.mark.parametrize("M", [4000, 97, 1024, 33, 16384, 41003])
 @pytest.mark.parametrize("extras", [True, False])
-def test_small_tile_backward_edge_mlp(dev, M, extras):
+def test_small_tile_backward_edge_mlp(dev, M, extras, monkeypatch):
     """EdgeBlock backward in its factored form: LayerNorm backward (+ the gathered and the plain addend of the incoming
-    gradient), the three transposed layers, residual."""
+    gradient), the three transposed layers, residual.  (41 003 rows: beyond the default row limit of the family, which the
+    library reads per launch.)"""
     from gfv import lib as L, ops
+    if M > 16384:
+        monkeypatch.setenv("GFV_CBWD_MAX_M", "100000")
     g = torch.Generator().manual_seed(M + 7 * extras)
     n_nodes = 300
     e = torch.randn(M, 128, generator=g)
