@@ -227,3 +227,95 @@ def test_small_tile_backward_matches_the_row_owner_chain(dev):
         res[fam] = (ge, g3, gz2, gz1, part[:n].sum(0))
     for a, b in zip(res[0], res[L.CHAIN_ROW_OWNER]):
         assert rel(a, b) < TOL
+
+
+@pytest.mark.parametrize("form", [2, 3])
+def test_small_tile_backward_single_product_forms(dev, form):
+    """The reduced-precision forms (one fp16 x fp16 / bf16 x bf16 product per term): the small-tile kernel against the row-owner
+    chain in the same form (both round the same operands; their gradient-row scales differ) and, loosely, float64."""
+    from gfv import lib as L, ops
+    lib = L.load()
+    M = 1500
+    g = torch.Generator().manual_seed(form)
+    e = torch.randn(M, 128, generator=g)
+    P = _params(g, 128)
+    Pg = {k: v.double().requires_grad_(True) for k, v in P.items()}
+    X = e.double().requires_grad_(True)
+    z1, z2, y3, ln = _ref(Pg, X)
+    go = torch.randn(M, 128, generator=g) * torch.logspace(-3, 0, M)[:, None]
+    (ln * go.double()).sum().backward()
+    d = lambda t: t.to(dev).contiguous()
+    Pd = {k: d(v) for k, v in P.items()}
+    z1d, z2d, y3d = d(z1.detach().float()), d(z2.detach().float()), d(y3.detach().float())
+    W3t, W2t, W1t = ops.transpose(Pd["W3"]), ops.transpose(Pd["W2"]), ops.transpose(Pd["W1"])
+    god = d(go)
+    res = {}
+    lib.gfv_set_f16split(form)
+    try:
+        wi = _images(dev, [P["W1"], P["W2"], P["W3"]])
+        for fam in (0, L.CHAIN_ROW_OWNER):
+            ge, gz1 = torch.full((M, 128), float("nan"), device=dev), torch.full((M, 128), float("nan"), device=dev)
+            part = torch.full((ops.ln_rows(M), 2, 128), float("nan"), device=dev)
+            layers = [ops.LayerSpec(W3t, None, L.OP_MUL_DGELU, aux=z2d), ops.LayerSpec(W2t, None, L.OP_MUL_DGELU, save=gz1, aux=z1d),
+                      ops.LayerSpec(W1t)]
+            ops.rowtile_chain(M, [ops.Seg(god)], layers, [ge], in_op=L.IN_LNBWD, in_gamma=Pd["gamma"], in_aux=y3d, in_stats=_stats(y3, d),
+                              ln_partial=part, res=[god], wimg=wi, family=fam)
+            assert bool(lib.gfv_rowtile_last_path() & 128) == (fam == 0)
+            res[fam] = (ge, gz1, part[:ops.last_ln_rows()].sum(0))
+    finally:
+        lib.gfv_set_f16split(1)
+    tol = 4e-3 if form == 2 else 3e-2
+    assert rel(res[0][0], X.grad + go.double()) < tol
+    for a, b in zip(res[0], res[L.CHAIN_ROW_OWNER]):
+        assert rel(a, b) < tol, rel(a, b)
+    # (dgamma, dbeta) do not pass through a product: fp32 sums in both kernels
+    assert rel(res[0][2][0], Pg["gamma"].grad) < TOL and rel(res[0][2][1], Pg["beta"].grad) < TOL
+
+
+@pytest.mark.parametrize("h", [64, 32])
+def test_small_tile_backward_narrow_model_layernorm_width(dev, h):
+    """A model of hidden_size h < 128 runs zero padded to 128 columns (FVMmodel/padding.py): LayerNorm statistics over the h real
+    columns, gamma = beta = 0 and zero weight rows / columns in the padding - input gradient and (dgamma, dbeta) of the real
+    columns against float64 autograd of the h-wide MLP, the padded columns of the input gradient exactly zero."""
+    from gfv import lib as L, ops
+    lib = L.load()
+    M = 2100
+    g = torch.Generator().manual_seed(h)
+    pad = lambda w, r, c: F.pad(w, (0, c - w.shape[-1], 0, r - w.shape[0])) if w.dim() == 2 else F.pad(w, (0, r - w.shape[0]))
+    Ph = dict(W1=torch.randn(h, h, generator=g) * 0.3, b1=torch.randn(h, generator=g) * 0.1,
+              W2=torch.randn(h, h, generator=g) * 0.3, b2=torch.randn(h, generator=g) * 0.1,
+              W3=torch.randn(h, h, generator=g) * 0.3, b3=torch.randn(h, generator=g) * 0.1,
+              gamma=1 + 0.1 * torch.randn(h, generator=g), beta=0.1 * torch.randn(h, generator=g))
+    x = torch.randn(M, h, generator=g)
+    Pg = {k: v.double().requires_grad_(True) for k, v in Ph.items()}
+    X = x.double().requires_grad_(True)
+    z1 = F.linear(X, Pg["W1"], Pg["b1"])
+    z2 = F.linear(F.gelu(z1), Pg["W2"], Pg["b2"])
+    y3 = F.linear(F.gelu(z2), Pg["W3"], Pg["b3"])
+    ln = F.layer_norm(y3, (h,), Pg["gamma"], Pg["beta"], 1e-5)
+    go = torch.randn(M, h, generator=g) * torch.logspace(-3, 0, M)[:, None]
+    (ln * go.double()).sum().backward()
+    d = lambda t: t.to(dev).contiguous()
+    P = {k: pad(v, 128, 128) for k, v in Ph.items()}
+    Pd = {k: d(v) for k, v in P.items()}
+    wide = lambda t: d(F.pad(t.detach().float(), (0, 128 - h)))
+    stats = d(torch.stack((y3.detach().mean(1), (y3.detach().var(1, unbiased=False) + 1e-5).rsqrt()), 1).float())
+    W3t, W2t, W1t = ops.transpose(Pd["W3"]), ops.transpose(Pd["W2"]), ops.transpose(Pd["W1"])
+    wi = _images(dev, [P["W1"], P["W2"], P["W3"]])
+    god = wide(go)
+    ge, gz1 = torch.full((M, 128), float("nan"), device=dev), torch.full((M, 128), float("nan"), device=dev)
+    part = torch.full((ops.ln_rows(M), 2, 128), float("nan"), device=dev)
+    layers = [ops.LayerSpec(W3t, None, L.OP_MUL_DGELU, aux=wide(z2)), ops.LayerSpec(W2t, None, L.OP_MUL_DGELU, save=gz1, aux=wide(z1)),
+              ops.LayerSpec(W1t)]
+    assert lib.gfv_set_hidden_size(h) == 0
+    try:
+        ops.rowtile_chain(M, [ops.Seg(god)], layers, [ge], in_op=L.IN_LNBWD, in_gamma=Pd["gamma"], in_aux=wide(y3), in_stats=stats,
+                          ln_partial=part, res=[god], wimg=wi)
+        assert lib.gfv_rowtile_last_path() == PATH
+    finally:
+        lib.gfv_set_hidden_size(128)
+    assert rel(ge[:, :h], X.grad + go.double()) < TOL
+    assert bool((ge[:, h:] == 0).all())
+    dgam, dbet = _ln_sums(part, M)
+    assert rel(dgam[:h], Pg["gamma"].grad) < TOL and rel(dbet[:h], Pg["beta"].grad) < TOL
+    _no_flags()
