@@ -307,18 +307,24 @@ class Engine:
         key = self._pkey(P, fresh=(phase == "fwd"))
         if self._wi_key != key:
             dev = next(iter(P.values())).device
-            self._retired.append((self._wi, self._wmax, self._wi_abs))
+            self._retired.append((self._wi, self._wmax, self._wi_abs, getattr(self, "_wi_abs_ws", None)))
             self._wmax = torch.zeros((1,), dtype=torch.float32, device=dev)
             self._wi = {ph: ops.WeightImages(dev, self._wmax) for ph in ("fwd", "bwd")}
             self._wi["fwd"].add_static(P.values())
             mats = [t for t in P.values() if t.dim() == 2 and t.stride(1) == 1]
             self._wi_abs = ops.WeightImages._upload([((t.data_ptr(), t.stride(0), t.shape[0], t.shape[1]), t) for t in mats], dev)
+            self._wi_abs_ws = torch.zeros((L.load().gfv_weight_absmax_ws_floats(self._wi_abs[1]),), dtype=torch.float32, device=dev)
             self._wi_key = key
         wi = self._wi[phase]
         if phase == "fwd":
             # one power-of-two scale for all weight images of this step, from max|W| over every weight matrix
-            L.check(L.load().gfv_weight_absmax(self._wi_abs[0].data_ptr(), self._wi_abs[1], self._wmax.data_ptr(),
-                                               L.stream_ptr()), "gfv_weight_absmax")
+            # (GFV_ABSMAX_WS=1: one launch - the maximum is written by the workgroup that arrives last, no fill in front)
+            if os.environ.get("GFV_ABSMAX_WS", "0") == "1":   # (measured neutral, profiles/r05_ab_step_start.txt: opt-in)
+                L.check(L.load().gfv_weight_absmax_ws(self._wi_abs[0].data_ptr(), self._wi_abs[1], self._wmax.data_ptr(),
+                                                      self._wi_abs_ws.data_ptr(), L.stream_ptr()), "gfv_weight_absmax_ws")
+            else:
+                L.check(L.load().gfv_weight_absmax(self._wi_abs[0].data_ptr(), self._wi_abs[1], self._wmax.data_ptr(),
+                                                   L.stream_ptr()), "gfv_weight_absmax")
         elif not wi.static and self._wt:
             wi.add_static(self._wt.values())
             if self.recompute:
@@ -1229,11 +1235,17 @@ class Engine:
     # ------------------------------------------------------------------------------------------------------------
     # whole model (importer.py:156-240)
     # ------------------------------------------------------------------------------------------------------------
-    def forward(self, P, buffers, x, pl, *, norm_global=True, accumulate=True, want_outputs=True, want_edge_attr15=True):
+    def forward(self, P, buffers, x, pl, *, norm_global=True, accumulate=True, want_outputs=True, want_edge_attr15=True,
+                before_prep=None):
+        """before_prep: main-stream work of the caller that only the input preparation waits for (TrainStep's restore of the
+        un-normalised node state): issued BEHIND the fork, so that the side stream's image build - which the first encoder launch
+        waits for, ~16 us in round 5's timelines - starts a copy and a cross-queue signal earlier."""
         # the per-step weight images are built on the side stream while the input preparation runs on the main one
         with self.fork():
             prev = self._wi_enter("fwd", P)
         try:
+            if before_prep is not None:
+                before_prep()
             uv_old, ea16, ea15 = self.prep_fwd(x, buffers, pl, norm_global, accumulate, want_edge_attr15)
             self.join()
             dec, sv_sim = self.simulator_fwd(P, x, ea16, pl)
