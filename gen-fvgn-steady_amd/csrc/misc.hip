@@ -345,6 +345,25 @@ extern "C" int gfv_adam_step_dev(float* p, const float* g, float* m, float* v, i
   return GFV_OK;
 }
 
+// the two halves of gfv_adam_step_dev as launches of their own: the tick depends on the step count and the hyper-parameters only, so
+// a caller may issue it early and on another stream (TrainStep: at the start of the backward, on the weight-gradient queue) and keep
+// ~6 us of single-thread double arithmetic off the end of the step
+extern "C" int gfv_adam_tick_dev(float* state, const float* hyper, void* stream) {
+  if (!state || !hyper) return GFV_ERR_ARG;
+  GFV_LAUNCH(adam_tick_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, state, hyper);
+  GFV_CHECK_LAUNCH();
+  return GFV_OK;
+}
+extern "C" int gfv_adam_update_dev(float* p, const float* g, float* m, float* v, int64_t n, const float* state, const float* hyper,
+                                   void* stream) {
+  GfvProfScope ps_(GFV_K_MISC, 0, 28.0 * (double)n, stream);
+  if (n <= 0) return GFV_OK;
+  if (!state || !hyper) return GFV_ERR_ARG;
+  GFV_LAUNCH(adam_kernel, dim3(cap_grid(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long)n, state, hyper);
+  GFV_CHECK_LAUNCH();
+  return GFV_OK;
+}
+
 extern "C" int gfv_train_loss(const float* losses, int32_t B, float w_cont, float w_mom, float w_press, float* loss,
                               float* gloss, void* stream) {
   if (B <= 0) return GFV_ERR_ARG;

@@ -261,18 +261,25 @@ class TrainStep:
                 want_outputs=self.want_outputs, want_edge_attr15=False, before_prep=restore)
             L.check(lib.gfv_train_loss_dev(losses.data_ptr(), self.plan.B, self.hyper.data_ptr(), self.loss.data_ptr(),
                                            self.gloss.data_ptr(), st), "train_loss")
+            # (GFV_EARLY_TICK=1: Adam's tick - step count + bias corrections, ~6 us of one thread's double arithmetic that needs no
+            # gradient - goes out now, on the weight-gradient queue, not at the end of the step.  Measured: the extra fork costs what
+            # the tick saved, 3.574 / 3.567 against 3.568 / 3.562 ms - profiles/r05_ab_step_start.txt; opt-in)
+            early_tick = with_adam and os.environ.get("GFV_EARLY_TICK", "0") == "1"
+            if early_tick:
+                with self.engine.fork():
+                    L.check(lib.gfv_adam_tick_dev(self.adam_state.data_ptr(), self.hyper.data_ptr(), L.stream_ptr()), "adam_tick")
             self.engine.backward(self.P_run, ctx, self.gloss, self.G_run, self.plan)
         if self.padded:
             cmdlist.call(_gather, self.G_run.flat, self._unpad_map, self.flat_g)
         self.losses, self.uvp_node, self.uvp_cell = losses, uvp_node, uvp_cell
         if with_adam:
-            self._adam()
+            self._adam(ticked=early_tick)
 
-    def _adam(self):
+    def _adam(self, ticked=False):
         lib = L.load()
-        L.check(lib.gfv_adam_step_dev(self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.flat_m.data_ptr(),
-                                      self.flat_v.data_ptr(), self.n_params, self.adam_state.data_ptr(),
-                                      self.hyper.data_ptr(), L.stream_ptr()), "adam_step")
+        fn = lib.gfv_adam_update_dev if ticked else lib.gfv_adam_step_dev
+        L.check(fn(self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.flat_m.data_ptr(), self.flat_v.data_ptr(), self.n_params,
+                   self.adam_state.data_ptr(), self.hyper.data_ptr(), L.stream_ptr()), "adam_step")
 
     # data-parallel exchange: the flat gradient is reduced in two buckets.  The upper one (last processor + decoder:
     # their backward runs first) goes out on a communication stream as soon as its last gradient kernel is launched and

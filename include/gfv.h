@@ -523,6 +523,12 @@ int gfv_edge_attr(const float* x, int32_t ldx, const float* pos, const int32_t* 
  *   hyper[8] = {lr, beta1, beta2, eps, grad_scale (1 / world size), 0, 0, 0} */
 int gfv_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, float* state, const float* hyper,
                       void* stream);
+/* its two halves as launches of their own: gfv_adam_tick_dev advances t and forms the bias corrections (it needs neither gradients nor
+ * parameters: a caller may issue it early, on another stream, as long as it is ordered in front of the update), gfv_adam_update_dev
+ * applies them.  tick + update == gfv_adam_step_dev. */
+int gfv_adam_tick_dev(float* state, const float* hyper, void* stream);
+int gfv_adam_update_dev(float* p, const float* g, float* m, float* v, int64_t n, const float* state, const float* hyper,
+                        void* stream);
 int gfv_train_loss(const float* losses, int32_t B, float w_cont, float w_mom, float w_press, float* loss, float* gloss,
                    void* stream);
 /* same, weights read from the device: hyper[5..7] = {w_cont, w_mom, w_press} of the buffer gfv_adam_step_dev takes */
