@@ -1,0 +1,311 @@
+// gfv-build-flags: -fno-slp-vectorize
+// Column-owner SMALL-TILE form of the Transolver block's row-local forward chain (round 5; contract: include/gfv.h, gfv_trans_mlp_fwd):
+//   fx1 = out_x W_out^T + b_out + fx_in;   z = LayerNorm(fx1; gamma, beta) W_pre^T + b_pre  [M, 256];   out = gelu(z) W_post^T + b_post + fx1
+// (GraphTransolver.py:93-95,163-169) for SHORT launches.  transmlp.hip runs the chain on 128-row blocks with every layer's image staged
+// in LDS: at 5 k rows that is 41 workgroups on 256 CUs, slower than the three single-layer launches it replaces (9 + 9 + 11 us on
+// lin1s.hip).  Here, as in cfwd.hip: one 32-row tile per workgroup, 8 waves, wave w owns output columns 16 w .. 16 w + 15 of the
+// 128-wide layers and 32 w .. 32 w + 31 of the 256-wide one; weight slices straight from L2 into registers a layer ahead;
+// activations cross waves as MFMA B fragments in LDS; 4 barriers.
+//   * LayerNorm sits in the MIDDLE of this chain: per-wave (mean, M2) pairs over 16 columns, Chan's combination across the eight waves
+//     (the statistics of cfwd.hip's final LayerNorm, layout-agnostic width included), then the normalised rows go on as fragments
+//     behind ONE power-of-two scale per launch taken from a bound - |LN| <= sqrt(127) max|gamma| + max|beta| - not from the rows
+//     (a row maximum would need a second exchange behind the statistics): two or three bits of the 22 on typical rows.
+//   * gelu(z) is split behind the fixed scale of every column-owner kernel (CT_SH; beyond 2^11 GFV_FLAG_CHAIN_RANGE is raised).
+#include <cstdlib>
+
+#include "tchain_kernel.h"
+#include "../../include/gfv.h"
+
+int* gfv_internal_status_ptr();
+
+namespace {
+
+constexpr float CT_SH = 16.0f;
+constexpr float CT_SH_INV = 1.0f / 16.0f;
+constexpr float CT_SH_LIMIT = 2048.0f;
+
+__device__ __forceinline__ void ct_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+struct CtLds {
+  static constexpr int B0 = 0;                       // out_x fragments: 2 groups x 4 k-groups x 2 KB
+  static constexpr int B1 = 16384;                   // LayerNorm output fragments
+  static constexpr int B2 = 32768;                   // gelu(z) fragments: 2 groups x 8 k-groups x 2 KB
+  static constexpr int SINV = 65536;                 // float [32]: 1 / row scale of the input rows
+  static constexpr int LNP = SINV + 128;             // float2 [32][8]: per-wave (mean, M2) of a row
+  static constexpr int BND = LNP + 32 * 8 * 8;       // float [8]: per-wave bound of |LayerNorm output|
+  static constexpr int TOTAL = BND + 32;
+};
+
+struct CtArgs {
+  const float* x; const float* res;
+  const void* imgA; const void* imgB; const void* imgC;
+  const float* bA; const float* bB; const float* bC;
+  const float* gamma; const float* beta; const float* wmax;
+  float* fx1; float* z; float* out;
+  int M, hidden;
+};
+
+template <int LOWP>
+__global__ __launch_bounds__(512, 2) void ctrans_fwd_kernel(const CtArgs A, int* status) {
+  constexpr bool BF = LOWP == 2;
+  constexpr int TG = 2;
+  __shared__ __attribute__((aligned(16))) char lds[CtLds::TOTAL];
+  char* b0 = lds + CtLds::B0;
+  char* b1 = lds + CtLds::B1;
+  char* b2 = lds + CtLds::B2;
+  float* sinv = reinterpret_cast<float*>(lds + CtLds::SINV);
+  float* lnp = reinterpret_cast<float*>(lds + CtLds::LNP);
+  float* bnd = reinterpret_cast<float*>(lds + CtLds::BND);
+
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
+  const int row0 = (int)blockIdx.x * 32;
+  if (row0 >= A.M) return;
+  const int ngt = min(TG, (A.M - row0 + 15) >> 4);
+  const int c0 = 16 * w + 4 * g;   // this lane's columns of a 128-wide layer: c0 .. c0 + 3
+  const float invw = 1.0f / gfv_pow2_scale(*A.wmax);
+
+  // ---- to_out's weight slice: in flight beside the row loads ----
+  gfv_f16x8 ah[4], al[4];
+  {
+    const gfv_f16x8* im = reinterpret_cast<const gfv_f16x8*>(A.imgA) + (size_t)w * 128 + lane;
+#pragma unroll
+    for (int T = 0; T < 4; ++T) {
+      ah[T] = im[T * 1024];
+      al[T] = LOWP ? ah[T] : im[T * 1024 + 64];
+    }
+  }
+  // ---- out_x rows -> row scale -> fragments (wave q loads group q) ----
+  if (w < TG) {
+    const int row = min(row0 + 16 * w + j, A.M - 1);
+    const float* p = A.x + (size_t)row * 128 + 4 * g;
+    float v[8][4];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const float4 t = ld4(p + 16 * u);
+      v[u][0] = t.x; v[u][1] = t.y; v[u][2] = t.z; v[u][3] = t.w;
+    }
+    float m0 = 0.f, m1 = 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      m0 = max3_abs(m0, v[u][0], v[u][1]);
+      m1 = max3_abs(m1, v[u][2], v[u][3]);
+    }
+    const float s = gfv_pow2_scale(row_max4(max3_abs(0.f, m0, m1)));
+    if (g == 0) sinv[w * 16 + j] = 1.0f / s;
+    gfv_uint4* dst = reinterpret_cast<gfv_uint4*>(b0 + (size_t)w * 4 * 2048) + lane;
+#pragma unroll
+    for (int T = 0; T < 4; ++T) {
+      float e[8];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { e[r] = v[2 * T][r] * s; e[4 + r] = v[2 * T + 1][r] * s; }
+      gfv_uint4 hi, lo;
+      gfv_split8_t<BF>(e, hi, lo);
+      dst[(2 * T) * 64] = hi;
+      if (!LOWP) dst[(2 * T + 1) * 64] = lo;
+    }
+  }
+  // this wave's bias / affine columns, the residual rows, and its bound of the LayerNorm output
+  const float4 bA = A.bA ? ld4(A.bA + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+  const float4 gam = ld4(A.gamma + c0), bet = ld4(A.beta + c0);
+  float4 rres[TG];
+#pragma unroll
+  for (int q = 0; q < TG; ++q) rres[q] = ld4(A.res + (size_t)min(row0 + 16 * q + j, A.M - 1) * 128 + c0);
+  {
+    // |LN[c]| <= sqrt(127) |gamma[c]| + |beta[c]|  (|xhat| <= sqrt(n - 1))
+    const float b4 = fmaxf(fmaxf(fabsf(gam.x) * 11.27f + fabsf(bet.x), fabsf(gam.y) * 11.27f + fabsf(bet.y)),
+                           fmaxf(fabsf(gam.z) * 11.27f + fabsf(bet.z), fabsf(gam.w) * 11.27f + fabsf(bet.w)));
+    const float bw = gfv_wave_max(b4);
+    if (lane == 0) bnd[w] = bw;
+  }
+  float mabs = 0.f;
+  ct_barrier();
+
+  // ---- to_out: b0 -> fx1 (saved, kept) ; LayerNorm statistics ----
+  floatx4 acc[TG];
+#pragma unroll
+  for (int q = 0; q < TG; ++q) acc[q] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int T = 0; T < 4; ++T)
+#pragma unroll
+    for (int q = 0; q < TG; ++q) {
+      const gfv_f16x8* f = reinterpret_cast<const gfv_f16x8*>(b0 + (size_t)(q * 4 + T) * 2048) + lane;
+      const gfv_f16x8 xh = f[0];
+      if (!LOWP) {
+        const gfv_f16x8 xl = f[64];
+        acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[T], xh, acc[q], 0, 0, 0);
+        acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[T], xl, acc[q], 0, 0, 0);
+      }
+      acc[q] = gfv_mma_hh<BF>(ah[T], xh, acc[q]);
+    }
+  // linear_pre's slice (two n-tiles of its 256 columns): requested behind to_out's products
+  gfv_f16x8 bh[2][4], bl[2][4];
+#pragma unroll
+  for (int n = 0; n < 2; ++n) {
+    const int t16 = 2 * w + n;   // n-tile of the 256-wide layer: pass t16 >> 3, tile t16 & 7
+    const gfv_f16x8* im = reinterpret_cast<const gfv_f16x8*>(A.imgB) + (size_t)((t16 >> 3) * 4 * 8 + (t16 & 7)) * 128 + lane;
+#pragma unroll
+    for (int T = 0; T < 4; ++T) {
+      bh[n][T] = im[T * 1024];
+      bl[n][T] = LOWP ? bh[n][T] : im[T * 1024 + 64];
+    }
+  }
+  float fx[TG][4];
+#pragma unroll
+  for (int q = 0; q < TG; ++q) {
+    const int row = row0 + 16 * q + j;
+    const bool live = q < ngt && row < A.M;
+    const float si = sinv[q * 16 + j];
+    fx[q][0] = (acc[q][0] * si) * invw + bA.x + rres[q].x; fx[q][1] = (acc[q][1] * si) * invw + bA.y + rres[q].y;
+    fx[q][2] = (acc[q][2] * si) * invw + bA.z + rres[q].z; fx[q][3] = (acc[q][3] * si) * invw + bA.w + rres[q].w;
+    if (live) st4(A.fx1 + (size_t)row * 128 + c0, fx[q]);
+    const float mw = row_sum((fx[q][0] + fx[q][1]) + (fx[q][2] + fx[q][3])) * (1.0f / 16.0f);   // this wave's 16 columns
+    const float d0 = fx[q][0] - mw, d1 = fx[q][1] - mw, d2 = fx[q][2] - mw, d3 = fx[q][3] - mw;
+    const float m2 = row_sum((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3));
+    if (g == 0) *reinterpret_cast<float2*>(lnp + ((q * 16 + j) * 8 + w) * 2) = make_float2(mw, m2);
+  }
+  ct_barrier();
+  // ---- LayerNorm ln_2 -> fragments of linear_pre's input ----
+  float sB;
+  {
+    const float4 ba = *reinterpret_cast<const float4*>(bnd), bb = *reinterpret_cast<const float4*>(bnd + 4);
+    sB = gfv_pow2_scale(fmaxf(fmaxf(fmaxf(ba.x, ba.y), fmaxf(ba.z, ba.w)), fmaxf(fmaxf(bb.x, bb.y), fmaxf(bb.z, bb.w))));
+    const int hcols = (A.hidden > 0 && A.hidden < 128) ? A.hidden : 128;
+    const float inv_h = 1.0f / (float)hcols, npad = (float)(128 - hcols);
+#pragma unroll
+    for (int q = 0; q < TG; ++q) {
+      const float4* pp = reinterpret_cast<const float4*>(lnp + (q * 16 + j) * 16);
+      const float4 p0 = pp[0], p1 = pp[1], p2 = pp[2], p3 = pp[3];   // (mean, M2) x 8 waves
+      const float m128 = (((p0.x + p0.z) + (p1.x + p1.z)) + ((p2.x + p2.z) + (p3.x + p3.z))) * 0.125f;
+      const float e0 = p0.x - m128, e1 = p0.z - m128, e2 = p1.x - m128, e3 = p1.z - m128, e4 = p2.x - m128, e5 = p2.z - m128,
+                  e6 = p3.x - m128, e7 = p3.z - m128;
+      const float m2a = (((p0.y + p0.w) + (p1.y + p1.w)) + ((p2.y + p2.w) + (p3.y + p3.w))) +
+                        16.0f * (((e0 * e0 + e1 * e1) + (e2 * e2 + e3 * e3)) + ((e4 * e4 + e5 * e5) + (e6 * e6 + e7 * e7)));
+      // (a narrower model: statistics over all 128 columns, whose padded ones are exactly zero, corrected - cfwd.hip)
+      const float mean = hcols == 128 ? m128 : (m128 * 128.0f) * inv_h;
+      const float dm = m128 - mean;
+      const float m2 = hcols == 128 ? m2a : (m2a + 128.0f * dm * dm) - npad * (mean * mean);
+      const float rstd = rsqrtf(m2 * inv_h + 1e-5f);
+      const float l0 = (fx[q][0] - mean) * rstd * gam.x + bet.x, l1 = (fx[q][1] - mean) * rstd * gam.y + bet.y;
+      const float l2 = (fx[q][2] - mean) * rstd * gam.z + bet.z, l3 = (fx[q][3] - mean) * rstd * gam.w + bet.w;
+      unsigned h0, h1, lo0, lo1;
+      gfv_split_pair_t<BF>(l0 * sB, l1 * sB, h0, lo0);
+      gfv_split_pair_t<BF>(l2 * sB, l3 * sB, h1, lo1);
+      char* dst = b1 + (size_t)(q * 4 + (w >> 1)) * 2048 + lane * 16 + (w & 1) * 8;   // half of k-group w >> 1
+      *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
+      if (!LOWP) *reinterpret_cast<uint2*>(dst + 1024) = make_uint2(lo0, lo1);
+    }
+  }
+  ct_barrier();
+  // ---- linear_pre: b1 -> z (saved); gelu(z) -> b2 (k-group w of linear_post's 256-deep input) ----
+  floatx4 zc[TG][2];
+#pragma unroll
+  for (int q = 0; q < TG; ++q)
+#pragma unroll
+    for (int n = 0; n < 2; ++n) zc[q][n] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int T = 0; T < 4; ++T)
+#pragma unroll
+    for (int q = 0; q < TG; ++q) {
+      const gfv_f16x8* f = reinterpret_cast<const gfv_f16x8*>(b1 + (size_t)(q * 4 + T) * 2048) + lane;
+      const gfv_f16x8 xh = f[0];
+      if (!LOWP) {
+        const gfv_f16x8 xl = f[64];
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+          zc[q][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[n][T], xh, zc[q][n], 0, 0, 0);
+          zc[q][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[n][T], xl, zc[q][n], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int n = 0; n < 2; ++n) zc[q][n] = gfv_mma_hh<BF>(bh[n][T], xh, zc[q][n]);
+    }
+  // linear_post's slice (256 deep: 8 k-groups): requested behind linear_pre's products
+  gfv_f16x8 ch[8], cl[8];
+  {
+    const gfv_f16x8* im = reinterpret_cast<const gfv_f16x8*>(A.imgC) + (size_t)w * 128 + lane;
+#pragma unroll
+    for (int T = 0; T < 8; ++T) {
+      ch[T] = im[T * 1024];
+      cl[T] = LOWP ? ch[T] : im[T * 1024 + 64];
+    }
+  }
+  {
+    const float isB = 1.0f / sB;
+    const int cz = 32 * w + 4 * g;   // this lane's columns of the 256-wide layer: cz .. cz + 3 and cz + 16 .. cz + 19
+    float4 bB[2];
+#pragma unroll
+    for (int n = 0; n < 2; ++n) bB[n] = A.bB ? ld4(A.bB + cz + 16 * n) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int q = 0; q < TG; ++q) {
+      const int row = row0 + 16 * q + j;
+      const bool live = q < ngt && row < A.M;
+      float e8[8];
+#pragma unroll
+      for (int n = 0; n < 2; ++n) {
+        float zz[4] = {(zc[q][n][0] * isB) * invw + bB[n].x, (zc[q][n][1] * isB) * invw + bB[n].y,
+                       (zc[q][n][2] * isB) * invw + bB[n].z, (zc[q][n][3] * isB) * invw + bB[n].w};
+        if (live) st4(A.z + (size_t)row * 256 + cz + 16 * n, zz);
+        const gfv_f2 g01 = gfv_gelu2(gfv_f2{zz[0], zz[1]}), g23 = gfv_gelu2(gfv_f2{zz[2], zz[3]});
+        mabs = fmaxf(mabs, live ? max3_abs(max3_abs(0.f, g01.x, g01.y), g23.x, g23.y) : 0.f);
+        e8[4 * n + 0] = g01.x * CT_SH; e8[4 * n + 1] = g01.y * CT_SH; e8[4 * n + 2] = g23.x * CT_SH; e8[4 * n + 3] = g23.y * CT_SH;
+      }
+      gfv_uint4 hi, lo;
+      gfv_split8_t<BF>(e8, hi, lo);
+      gfv_uint4* dst = reinterpret_cast<gfv_uint4*>(b2 + (size_t)(q * 8 + w) * 2048) + lane;
+      dst[0] = hi;
+      if (!LOWP) dst[64] = lo;
+    }
+  }
+  const float4 bC = A.bC ? ld4(A.bC + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+  ct_barrier();
+  // ---- linear_post + residual fx1 ----
+#pragma unroll
+  for (int q = 0; q < TG; ++q) acc[q] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int T = 0; T < 8; ++T)
+#pragma unroll
+    for (int q = 0; q < TG; ++q) {
+      const gfv_f16x8* f = reinterpret_cast<const gfv_f16x8*>(b2 + (size_t)(q * 8 + T) * 2048) + lane;
+      const gfv_f16x8 xh = f[0];
+      if (!LOWP) {
+        const gfv_f16x8 xl = f[64];
+        acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cl[T], xh, acc[q], 0, 0, 0);
+        acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ch[T], xl, acc[q], 0, 0, 0);
+      }
+      acc[q] = gfv_mma_hh<BF>(ch[T], xh, acc[q]);
+    }
+#pragma unroll
+  for (int q = 0; q < TG; ++q) {
+    const int row = row0 + 16 * q + j;
+    if (q < ngt && row < A.M) {
+      float o[4] = {(acc[q][0] * CT_SH_INV) * invw + bC.x + fx[q][0], (acc[q][1] * CT_SH_INV) * invw + bC.y + fx[q][1],
+                    (acc[q][2] * CT_SH_INV) * invw + bC.z + fx[q][2], (acc[q][3] * CT_SH_INV) * invw + bC.w + fx[q][3]};
+      st4(A.out + (size_t)row * 128 + c0, o);
+    }
+  }
+  if (mabs > CT_SH_LIMIT) atomicOr(status, 2);   // GFV_FLAG_CHAIN_RANGE
+}
+
+int ct_env(const char* n, int dflt) {
+  const char* e = getenv(n);
+  return e ? atoi(e) : dflt;
+}
+
+}  // namespace
+
+extern "C" int gfv_hidden_size(void);
+
+// 1: launched; 0: not this family's launch (too many rows, switched off).  The caller (transmlp.hip) has checked the arguments.
+// form: gfv_f16split_enabled() of the calling thread (1 / 2 / 3)
+int gfv_internal_ctrans_fwd_try(const gfv_trans_mlp_t* a, int form, hipStream_t stream) {
+  if (!ct_env("GFV_CTRANS", 1) || a->M > ct_env("GFV_CTRANS_MAX_M", 16384)) return 0;
+  CtArgs B{a->x, a->res, a->img_out, a->img_pre, a->img_post, a->b_out, a->b_pre, a->b_post, a->gamma, a->beta, a->wmax,
+           a->fx1, a->z, a->out, a->M, gfv_hidden_size()};
+  int* st = gfv_internal_status_ptr();
+  const dim3 grid((a->M + 31) / 32), blk(512);
+  if (form == 3) GFV_LAUNCH((ctrans_fwd_kernel<2>), grid, blk, 0, stream, B, st);
+  else if (form == 2) GFV_LAUNCH((ctrans_fwd_kernel<1>), grid, blk, 0, stream, B, st);
+  else GFV_LAUNCH((ctrans_fwd_kernel<0>), grid, blk, 0, stream, B, st);
+  return 1;
+}

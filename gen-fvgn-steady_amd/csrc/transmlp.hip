@@ -413,6 +413,7 @@ void tm_ln(float& inv_n, float& npad) {
 }  // namespace
 
 bool gfv_internal_wimg_form_ok(const float* wmax);   // wimg.hip
+int gfv_internal_ctrans_fwd_try(const gfv_trans_mlp_t* a, int form, hipStream_t stream);   // ctrans.hip: the small-tile form
 
 extern "C" int gfv_trans_mlp_fwd(const gfv_trans_mlp_t* a, void* stream) {
   if (!a || a->M < 0) return GFV_ERR_ARG;
@@ -431,6 +432,10 @@ extern "C" int gfv_trans_mlp_fwd(const gfv_trans_mlp_t* a, void* stream) {
   tm_ln(B.ln_inv_n, B.ln_npad);
   // three Linear layers' flops; rows read: out_x, fx_in, fx1 (re-read); written: fx1, z (256 wide), out
   GfvProfScope ps_(GFV_K_LIN1, 2.0 * a->M * (128.0 * 128 + 2 * 128.0 * 256), 4.0 * a->M * (3 * 128.0 + 128 + 256 + 128), stream);
+  if (gfv_internal_ctrans_fwd_try(a, form, (hipStream_t)stream)) {   // short launches: one 32-row tile per workgroup
+    GFV_CHECK_LAUNCH();
+    return GFV_OK;
+  }
   int* st = gfv_internal_status_ptr();
   const int nblk = (a->M + 127) / 128;
   const dim3 grid(nblk), blk(512);

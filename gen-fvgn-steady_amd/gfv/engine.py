@@ -152,6 +152,8 @@ class Engine:
         # (above the small-tile single-layer family's range: 3.60 - 3.62 against 3.64 ms on the 50 k-cell mesh, 22.06 against 22.17 at
         # 8 meshes per GPU; on the 5 k-cell cavity the three small-tile launches are as fast: profiles/r05_ab_transmlp.txt)
         self._trans_fuse_min = int(os.environ.get("GFV_TRANS_FUSE_MIN_M", "16385"))
+        # the FORWARD chain has a small-tile form as well (csrc/ctrans.hip, up to GFV_CTRANS_MAX_M rows): fused at every size
+        self._trans_fuse_fwd_small = os.environ.get("GFV_CTRANS", "1") != "0"
         # the end of the backward: how many of the trailing weight-gradient flushes run on the MAIN stream (GFV_TAIL_MAIN: 1 = the last
         # encoder's, 2 = both encoders', 3 = the first GnBlock's too) and how the first GnBlock's flush is split between the streams
         # (GFV_TAIL_SPLIT: 0 = not at all, 1 / 2 = its first / its other pieces on main).  Unset: by launch size - (3, 0) between
@@ -884,7 +886,7 @@ class Engine:
                                 4 if B == 1 else 0, st), "deslice")
         fx1, z, out = _empty(dev, N, 128), _empty(dev, N, 256), _empty(dev, N, 128)
         # to_out + residual, ln_2, linear_pre, GELU, linear_post + residual: nothing crosses rows - ONE launch (csrc/transmlp.hip)
-        if not (self._trans_fuse and N >= self._trans_fuse_min and ops.trans_mlp_fwd(
+        if not (self._trans_fuse and (N >= self._trans_fuse_min or self._trans_fuse_fwd_small) and ops.trans_mlp_fwd(
                 out_x, fx_in, P[f"{a}.to_out.0.weight"], P[f"{a}.to_out.0.bias"], P[f"{prefix}.ln_2.weight"], P[f"{prefix}.ln_2.bias"],
                 P[f"{prefix}.mlp.linear_pre.0.weight"], P[f"{prefix}.mlp.linear_pre.0.bias"], P[f"{prefix}.mlp.linear_post.weight"],
                 P[f"{prefix}.mlp.linear_post.bias"], fx1, z, out)):

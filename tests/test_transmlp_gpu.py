@@ -32,9 +32,12 @@ def _ref_fwd(P, x, res):
     return fx1, z, out
 
 
-@pytest.mark.parametrize("M", [3000, 129, 25479])
-def test_transolver_chain_forward_and_backward_in_one_launch_each(M):
+@pytest.mark.parametrize("M,small", [(3000, 1), (129, 1), (33, 1), (5184, 1), (3000, 0), (129, 0), (25479, 1)])
+def test_transolver_chain_forward_and_backward_in_one_launch_each(M, small, monkeypatch):
+    """small = 1: launches of up to 16 384 rows run the forward chain on its small-tile form (csrc/ctrans.hip); 0: the 128-row-block
+    kernel of transmlp.hip at every size (the library reads the switch per launch)."""
     from gfv import lib as L, ops
+    monkeypatch.setenv("GFV_CTRANS", str(small))
     dev = torch.device("cuda")
     P, x, res, g = _setup(M, M)
     d = lambda t: t.to(dev).contiguous()
