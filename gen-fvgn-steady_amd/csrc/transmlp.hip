@@ -413,7 +413,8 @@ void tm_ln(float& inv_n, float& npad) {
 }  // namespace
 
 bool gfv_internal_wimg_form_ok(const float* wmax);   // wimg.hip
-int gfv_internal_ctrans_fwd_try(const gfv_trans_mlp_t* a, int form, hipStream_t stream);   // ctrans.hip: the small-tile form
+int gfv_internal_ctrans_fwd_try(const gfv_trans_mlp_t* a, int form, hipStream_t stream);   // ctrans.hip: the small-tile forms
+int gfv_internal_ctrans_bwd_try(const gfv_trans_mlp_bwd_t* a, int form, hipStream_t stream);
 
 extern "C" int gfv_trans_mlp_fwd(const gfv_trans_mlp_t* a, void* stream) {
   if (!a || a->M < 0) return GFV_ERR_ARG;
@@ -470,6 +471,10 @@ extern "C" int gfv_trans_mlp_bwd(const gfv_trans_mlp_bwd_t* a, void* stream) {
   B.M = a->M; B.n_tiles = (a->M + 63) / 64;
   tm_ln(B.ln_inv_n, B.ln_npad);
   GfvProfScope ps_(GFV_K_LIN1, 2.0 * a->M * (128.0 * 128 + 2 * 128.0 * 256), 4.0 * a->M * (128.0 + 256 + 128 + 256 + 128 + 128 + 128), stream);
+  if (gfv_internal_ctrans_bwd_try(a, form, (hipStream_t)stream)) {   // short launches: one 32-row tile per workgroup, ln_partial per 32 rows
+    GFV_CHECK_LAUNCH();
+    return GFV_OK;
+  }
   int* st = gfv_internal_status_ptr();
   const int nblk = (a->M + 127) / 128;
   const dim3 grid(nblk), blk(512);

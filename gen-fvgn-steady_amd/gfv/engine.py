@@ -929,15 +929,17 @@ class Engine:
         g_sum = _empty(dev, N, 128) if g_add is not None else None
         gs = _empty(dev, 3, ops.gscale_ld(N))
         tiles = ops.rowtile_tiles(N)
-        part = _empty(dev, tiles, 2, 128)
+        part = _empty(dev, ops.ln_rows(N), 2, 128)
         g_fx1, g_out_x = _empty(dev, N, 128), _empty(dev, N, 128)
         gam2, bet2 = P[f"{prefix}.ln_2.weight"], P[f"{prefix}.ln_2.bias"]
-        # the three adjoint launches (GELU' epilogue, LayerNorm-backward epilogue, plain) as ONE (csrc/transmlp.hip)
-        fused = (self._trans_fuse and N >= self._trans_fuse_min and
+        # the three adjoint launches (GELU' epilogue, LayerNorm-backward epilogue, plain) as ONE (csrc/transmlp.hip; its small-tile
+        # form, csrc/ctrans.hip, up to GFV_CTRANS_MAX_M rows)
+        fused = (self._trans_fuse and (N >= self._trans_fuse_min or self._trans_fuse_fwd_small) and
                  ops.trans_mlp_bwd(g_out, g_add, g_sum, z, fx1, self._T(Wpost), self._T(Wpre), self._T(P[f"{a}.to_out.0.weight"]),
                                    gam2, g_z, g_fx1, g_out_x, part, gs[0]))
         if fused:
             have = True
+            tiles = lib.gfv_trans_mlp_ln_rows(N)   # (one ln_partial row per 64 rows, per 32 from the small-tile form)
         else:
             have = ops.rowtile_chain(N, [Seg(g_out)], [LayerSpec(self._T(Wpost), None, L.OP_MUL_DGELU, aux=z)],
                                      [(g_z, 256), (g_z.data_ptr() + 512, 256)], in_add=g_add, in_save=g_sum, gscale=gs)

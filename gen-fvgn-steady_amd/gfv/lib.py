@@ -195,6 +195,7 @@ _SIGNATURES = {
     "gfv_plan_sizes": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     "gfv_trans_mlp_fwd": (C.c_int, [C.POINTER(TransMlp), C.c_void_p]),
     "gfv_trans_mlp_bwd": (C.c_int, [C.POINTER(TransMlpBwd), C.c_void_p]),
+    "gfv_trans_mlp_ln_rows": (C.c_int, [C.c_int32]),
     "gfv_record_begin": (C.c_int, []),
     "gfv_record_count": (C.c_int, []),
     "gfv_record_end": (C.c_int64, []),

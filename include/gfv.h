@@ -633,8 +633,10 @@ int gfv_plan_sizes(const gfv_plan_t* plan, int64_t* sizes5);
  *   forward:   fx1 = out_x W_out^T + b_out + fx_in;   z = LayerNorm(fx1; gamma, beta) W_pre^T + b_pre   [M,256];
  *              out = gelu(z) W_post^T + b_post + fx1          (GraphTransolver.py:93-95,163-169)
  *   backward:  g = g_out (+ g_add) (-> g_sum);  g_z = (g W_post) * gelu'(z);  g_fx1 = LayerNorm-backward(g_z W_pre; fx1, gamma) + g;
- *              g_out_x = g_fx1 W_out;  ln_partial[tile, 0:128 | 128:256] = per-64-row-tile (dgamma, dbeta) sums (gfv_rowtile_tiles(M)
- *              rows; sum them with gfv_reduce_multi);  gscale[row / 16] = the 16-row-group scales of g (gfv_dw_tile_t.gscale).
+ *              g_out_x = g_fx1 W_out;  ln_partial[tile, 0:128 | 128:256] = per-tile (dgamma, dbeta) sums - gfv_trans_mlp_ln_rows(M)
+ *              rows (one per 64 rows; one per 32 where the small-tile form of csrc/ctrans.hip takes the launch: provide
+ *              gfv_rowtile_ln_rows(M)); sum them with gfv_reduce_multi;  gscale[row / 16] = the 16-row-group scales of g
+ *              (gfv_dw_tile_t.gscale).
  *   The backward takes the images of the TRANSPOSED weights: img_post_t of W_post^T [256,128], img_pre_t of W_pre^T [128,256],
  *   img_out_t of W_out^T [128,128].  The weight gradients stay with gfv_dw_multi (they read g / z, g_z / fx1, g_fx1 / out_x).
  * ---------------------------------------------------------------------------------------------------------- */
@@ -675,6 +677,7 @@ typedef struct {
 } gfv_trans_mlp_bwd_t;
 int gfv_trans_mlp_fwd(const gfv_trans_mlp_t* args, void* stream);
 int gfv_trans_mlp_bwd(const gfv_trans_mlp_bwd_t* args, void* stream);
+int gfv_trans_mlp_ln_rows(int32_t M);   /* rows of ln_partial a gfv_trans_mlp_bwd launch over M rows fills (the calling process's switches) */
 
 /* ------------------------------------------------------------------------------------------------------------
  * Native command list (round 5).  Between gfv_record_begin and gfv_record_end every kernel launch the CALLING THREAD issues

@@ -81,7 +81,9 @@ def test_transolver_chain_forward_and_backward_in_one_launch_each(M, small, monk
         god, gad = d(go), d(ga)
         gsum, gz, gfx1, gox = new(M, 128), new(M, 256), new(M, 128), new(M, 128)
         tiles = ops.rowtile_tiles(M)
-        part = new(tiles, 2, 128)
+        part = new(ops.ln_rows(M), 2, 128)
+        nfill = L.load().gfv_trans_mlp_ln_rows(M)   # one row per 64 rows; per 32 from the small-tile form
+        assert nfill == ((M + 31) // 32 if (small and M <= 16384) else tiles)
         gs = torch.zeros(3, ops.gscale_ld(M), device=dev)
         assert ops.trans_mlp_bwd(god, gad, gsum, zz, f1, Wpost_t, Wpre_t, Wout_t, Pd["gamma"], gz, gfx1, gox, part, gs[0])
         torch.cuda.synchronize()
@@ -89,6 +91,8 @@ def test_transolver_chain_forward_and_backward_in_one_launch_each(M, small, monk
         assert rel(gz, gz_ref) < TOL, rel(gz, gz_ref)
         assert rel(gfx1, gfx1_ref) < TOL, rel(gfx1, gfx1_ref)
         assert rel(gox, xg.grad) < TOL, rel(gox, xg.grad)
+        assert bool(torch.isnan(part[nfill:]).all()) and not bool(torch.isnan(part[:nfill]).any())
+        part = part[:nfill]
         dgb = part.double().sum(0).cpu()
         assert rel(dgb[0], Pg["gamma"].grad) < TOL and rel(dgb[1], Pg["beta"].grad) < TOL
         # the group scales of g: s * max|g| over 16 rows in [2^13, 2^14)
