@@ -154,6 +154,7 @@ class Engine:
         self._trans_fuse_min = int(os.environ.get("GFV_TRANS_FUSE_MIN_M", "16385"))
         # the FORWARD chain has a small-tile form as well (csrc/ctrans.hip, up to GFV_CTRANS_MAX_M rows): fused at every size
         self._trans_fuse_fwd_small = os.environ.get("GFV_CTRANS", "1") != "0"
+        self._slice_walk_max = int(os.environ.get("GFV_SLICE_WALK_MAX", "0"))
         # the end of the backward: how many of the trailing weight-gradient flushes run on the MAIN stream (GFV_TAIL_MAIN: 1 = the last
         # encoder's, 2 = both encoders', 3 = the first GnBlock's too) and how the first GnBlock's flush is split between the streams
         # (GFV_TAIL_SPLIT: 0 = not at all, 1 / 2 = its first / its other pieces on main).  Unset: by launch size - (3, 0) between
@@ -874,10 +875,10 @@ class Engine:
                                               st), "slice_softmax_fwd")
             L.check(lib.gfv_slice_token_partial(w.data_ptr(), fx_mid.data_ptr(), pl.chunk_beg.data_ptr(),
                                                 pl.chunk_end.data_ptr(), pl.n_chunks, partial.data_ptr(), st), "token_partial")
-        partial = self._graph_partials(partial, pl)
+        partial, gptr = self._graph_partials(partial, pl)
         token, norm = _empty(dev, B, 8, 32, 16), _empty(dev, B, 8, 32)
         attn, out_token = _empty(dev, B, 8, 32, 32), _empty(dev, B, 8, 32, 16)
-        L.check(lib.gfv_slice_attention_fwd(partial.data_ptr(), pl.gunit_ptr.data_ptr(), B, P[f"{a}.to_q.weight"].data_ptr(),
+        L.check(lib.gfv_slice_attention_fwd(partial.data_ptr(), gptr.data_ptr(), B, P[f"{a}.to_q.weight"].data_ptr(),
                                             P[f"{a}.to_k.weight"].data_ptr(), P[f"{a}.to_v.weight"].data_ptr(),
                                             token.data_ptr(), norm.data_ptr(), attn.data_ptr(), out_token.data_ptr(), st),
                 "slice_attention_fwd")
@@ -903,14 +904,17 @@ class Engine:
                   out_token=out_token, out_x=out_x, fx1=fx1, z=z)
         return out, sv
 
-    @staticmethod
-    def _graph_partials(partial, pl):
+    def _graph_partials(self, partial, pl):
         """[n_chunks, 256, 17] per-chunk slice tokens -> [B, 256, 17] per-graph sums (one wide launch; the attention
-        blocks - 8 per graph - then read one row instead of walking every chunk of their graph)."""
+        blocks - 8 per graph - then read one row instead of walking every chunk of their graph) and the chunk ranges to hand
+        the attention kernel.  Up to GFV_SLICE_WALK_MAX chunks per graph on average the attention blocks walk the chunks
+        themselves (same sums, same order per block: eight loads in flight) and the launch is saved."""
+        if pl.n_chunks <= self._slice_walk_max * pl.B:
+            return partial, pl.gchunk_ptr
         out = _empty(partial.device, pl.B, 256, 17)
         L.check(L.load().gfv_reduce_partials_seg(partial.data_ptr(), pl.gchunk_ptr.data_ptr(), pl.B, 256 * 17,
                                                  out.data_ptr(), L.stream_ptr()), "reduce_partials_seg")
-        return out
+        return out, pl.gunit_ptr
 
     def trans_bwd(self, P, sv, g_out, grads, pl, g_add=None):
         """g_add: optional addend of the incoming gradient (g_out + g_add is the gradient); the sum is formed in the
@@ -983,8 +987,8 @@ class Engine:
                                             pl.chunk_end.data_ptr(), pl.n_chunks, gpartial.data_ptr(), st), "token_partial")
         g_raw, g_norm = _empty(dev, B, 8, 32, 16), _empty(dev, B, 8, 32)
         dwp = _empty(dev, B * 8, 3, 16, 16)
-        gpartial = self._graph_partials(gpartial, pl)
-        L.check(lib.gfv_slice_attention_bwd(gpartial.data_ptr(), pl.gunit_ptr.data_ptr(), B,
+        gpartial, gptr = self._graph_partials(gpartial, pl)
+        L.check(lib.gfv_slice_attention_bwd(gpartial.data_ptr(), gptr.data_ptr(), B,
                                             P[f"{a}.to_q.weight"].data_ptr(), P[f"{a}.to_k.weight"].data_ptr(),
                                             P[f"{a}.to_v.weight"].data_ptr(), sv["token"].data_ptr(), sv["norm"].data_ptr(),
                                             sv["attn"].data_ptr(), g_raw.data_ptr(), g_norm.data_ptr(), dwp.data_ptr(), st),
