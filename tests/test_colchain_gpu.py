@@ -227,7 +227,7 @@ def test_engine_recompute_form_and_its_fallback(dev, mode):
     from gfv.engine import Engine, GradStore
     from gfv.ops import Seg
     g = torch.Generator().manual_seed(11)
-    M = 20000                                            # (>= GFV_COLCHAIN_BWD_MIN_M: the fused backward takes it)
+    M = 30000                                            # (> GFV_CBWD_MAX_M, >= GFV_COLCHAIN_BWD_MIN_M: the fused backward takes it)
     x = torch.randn(M, 128, generator=g)
     P = _params(g, 128)
     names = ["mlp.0.0.weight", "mlp.0.0.bias", "mlp.0.2.weight", "mlp.0.2.bias", "mlp.0.4.weight", "mlp.0.4.bias", "mlp.1.weight", "mlp.1.bias"]
