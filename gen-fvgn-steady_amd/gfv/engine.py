@@ -174,7 +174,7 @@ class Engine:
         self._fuse_dw_min = int(os.environ.get("GFV_COLCHAIN_BWD_MIN_M", "2048"))
         # up to this many rows the dX chain of an MLP runs on the column-owner small-tile backward (csrc/cbwd.hip) and its weight
         # gradients as one launch of the side queue; above it the persistent backward with fused weight gradients
-        self._cbwd_max = int(os.environ.get("GFV_CBWD_MAX_M", "24000")) if os.environ.get("GFV_CBWD", "1") != "0" else 0
+        self._cbwd_max = int(os.environ.get("GFV_CBWD_MAX_M", "25000")) if os.environ.get("GFV_CBWD", "1") != "0" else 0
         self._wi, self._wi_key, self._wmax, self._wi_abs = None, None, None, None
         self._pkey_cache = None
         self._zero_e = None
