@@ -26,7 +26,8 @@
 // rows), 12.0 against 22 (encoder); 25 k-row NodeBlock launches 30.9 us with 32-row tiles, 35.6 with 64-row tiles (84 KB of LDS:
 // one workgroup per CU) against 35 for the row-owner chain; 75 k-row EdgeBlock launches 78 - 83 us against 80.  So: 32-row tiles
 // up to GFV_CFWD_TG2_MAX_M = 40 000 rows, 64-row tiles up to GFV_CFWD_MAX_M = 100 000 rows (edge-level launches of 50 k rows:
-// 3.26 against 3.35 ms per step on a 25 k-cell mesh, of 75 k rows: 3.67 against 3.70 on the headline mesh; beyond that - 8
+// 3.26 against 3.35 ms per step on a 25 k-cell mesh, of 75 k rows: 3.67 against 3.70 on the headline mesh - and, re-measured with the
+// round's final kernels, 32-row tiles there too: see the launcher; beyond that - 8
 // meshes per GPU - the row-owner chain, whose 64 rows share one weight stream through LDS), the encoders' narrow inputs up to
 // GFV_CFWD_RAG_MAX_M = 16 384 rows (33 us against 30 at 25 k rows).
 #include <cstdlib>
@@ -402,10 +403,13 @@ void cf_launch(const gfv_rowtile_args_t& a, int tg, int lowp, hipStream_t stream
 // 1: launched; 0: not a launch of this family.  lowp: 0 three products, 1 / 2 the single-product forms.  dry != 0: only tell
 // whether the launch would be taken.  `args` carries `hidden` (the launcher of rowtile.hip fills it in).
 int gfv_internal_cfwd_try(const gfv_rowtile_args_t* a, int lowp, hipStream_t stream, int dry) {
-  static const int on = cf_env("GFV_CFWD", 1);
-  static const int max_m = cf_env("GFV_CFWD_MAX_M", 100000);
-  static const int tg2_max = cf_env("GFV_CFWD_TG2_MAX_M", 40000);
-  static const int rag_max = cf_env("GFV_CFWD_RAG_MAX_M", 16384);
+  // (read per launch - at record time under a command list -: the tests move the limits to reach both tile heights at any size)
+  const int on = cf_env("GFV_CFWD", 1);
+  const int max_m = cf_env("GFV_CFWD_MAX_M", 100000);
+  // 32-row tiles at every size the family takes: 64-row tiles (GFV_CFWD_TG2_MAX_M below the launch's rows) measured -1.8 % / -0.6 % /
+  // -0.6 % of the step WORSE at 45 k / 51 k / 75 k edge rows with the round's final kernels (profiles/r05_thresholds.txt)
+  const int tg2_max = cf_env("GFV_CFWD_TG2_MAX_M", 100000);
+  const int rag_max = cf_env("GFV_CFWD_RAG_MAX_M", 16384);
   if (!on || a->nlayers != 3 || a->M > max_m || a->M < 1 || (a->flags & (GFV_CHAIN_ROW_OWNER | GFV_CHAIN_COLUMN_OWNER))) return 0;
   // the decoder's shape: no LayerNorm, a last layer of <= 16 columns, nothing else around it
   const bool dec = a->fin_op == GFV_FIN_PLAIN && a->layer[2].N >= 1 && a->layer[2].N <= 16 && !a->res[0] && !a->out_nores && !a->fin_presave &&
