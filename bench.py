@@ -160,6 +160,58 @@ def cpu_baseline(graphs_cpu, budget_s, max_steps=6, min_steps=1):
     return float(np.median(times)), len(times)
 
 
+def drop_in_leg(device, graphs_cpu, ts_ms, steps, min_time=1.0):
+    """The path north_star names - the reference's driver UNCHANGED: the literal sequence of pre_train_Adam.py:158-191 /
+    solve_with_grad_GPU.py:133-181 (`optimizer.zero_grad(); out = model(...); loss = mean(log(...)); loss.backward();
+    optimizer.step()`) on a fresh `NNmodel` and the same batch, node state restored and norm flags re-armed every iteration as the
+    solve loop does.  Timed with stock `torch.optim.Adam` and with `gfv.optim.Adam` (one import changed), each with the recorded
+    launch lists (default) and with every launch issued eagerly (GFV_DROPIN_REPLAY=0: what rounds 1 - 5 shipped)."""
+    from FVMmodel.importer import NNmodel
+    from gfv.optim import Adam as GfvAdam
+    from gfv.params import default_params
+    out = {}
+    for name, opt_cls, replay in (("torch_adam", torch.optim.Adam, True), ("gfv_adam", GfvAdam, True),
+                                  ("torch_adam_eager", torch.optim.Adam, False)):
+        torch.manual_seed(0)
+        params = default_params(dataset_size=1)
+        model = NNmodel(params).to(device)
+        model._replay.enabled = replay
+        graphs = tuple(g.clone().to(device) for g in graphs_cpu)
+        gn = graphs[0]
+        backup = gn.x.clone()
+        opt = opt_cls(model.parameters(), lr=params.lr)
+
+        def it():
+            gn.x.copy_(backup)
+            gn.norm_uvp, gn.norm_global = params.norm_uvp, params.norm_global
+            opt.zero_grad()
+            lc, lx, ly, lp, un, uc = model(graph_node=graphs[0], graph_node_x=graphs[1], graph_edge=graphs[2],
+                                           graph_cell=graphs[3], graph_Index=graphs[4], is_training=True)
+            loss = torch.mean(torch.log(params.loss_press * lp + params.loss_cont * lc + params.loss_mom * lx + params.loss_mom * ly))
+            loss.backward()
+            opt.step()
+            return loss
+        for _ in range(8):
+            it()
+        torch.cuda.synchronize()
+        n, el = 0, 0.0
+        while el < min_time and n < 50 * steps:
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                loss = it()
+            torch.cuda.synchronize()
+            el += time.perf_counter() - t0
+            n += steps
+        out[name] = {"ms_per_step": round(1e3 * el / n, 4), "timed_steps": n, "final_loss": round(float(loss), 6),
+                     "replayed_forward_calls": model._replay.replays, "over_trainstep": round(1e3 * el / n / ts_ms, 3)}
+        del model, opt, graphs
+        torch.cuda.empty_cache()
+    out["note"] = ("the reference driver's own call sequence on FVMmodel.importer.NNmodel (autograd node, loss in torch ops, "
+                   "torch.optim.Adam over 159 tensors) against gfv.trainer.TrainStep's fused step (`ms_per_step` of this line, "
+                   "over_trainstep = the ratio); same mesh, same launch sequence inside the model.  Single process, no collectives")
+    return out
+
+
 def self_launch_command(gpus, argv, port=None):
     """The command `python bench.py --gpus N ...` runs when it is started WITHOUT a launcher: the driver's own multi-GPU line
     (one rank per GPU over RCCL, rendezvous on 127.0.0.1), with this invocation's arguments passed through unchanged."""
@@ -205,6 +257,8 @@ def main():
                     help="do not time the all-fp32-MFMA form as well (profiling runs: every executed step is then the same form)")
     ap.add_argument("--skip-copy-rate", action="store_true",
                     help="do not measure the device's copy rate (profiling runs: the 1 GiB copies would be counted as step traffic)")
+    ap.add_argument("--skip-drop-in", action="store_true",
+                    help="do not time the reference driver's call sequence on NNmodel (profiling runs)")
     ap.add_argument("--allow-shared-gpu", action="store_true",
                     help="self-test only: let several ranks share one GPU (the JSON then says so in distinct_gpus)")
     args = ap.parse_args()
@@ -350,6 +404,11 @@ def main():
             ts.step()
         with_ms = 1e3 * timed(cal_steps) / cal_steps
         exposed_us = round(1e3 * (with_ms - local_ms), 1)
+
+    # ---- the drop-in path: the reference driver's literal call sequence on the same batch, beside the fused TrainStep ----
+    drop_in = None
+    if rank == 0 and world == 1 and not args.skip_drop_in:
+        drop_in = drop_in_leg(device, graphs_cpu, ms_per_step, max(5, min(20, args.steps)))
 
     # ---- roofline leg: same step, eager, HIP events around every launch --------------------------------------------
     # every rank runs the instrumented steps (they contain the gradient all-reduce); rank 0 reports.  The timed region
@@ -571,6 +630,10 @@ def main():
                         "thread count) is the baseline"}
             torch.set_num_threads(ncores)
 
+    torch.cuda.synchronize()
+    sf = ctypes.c_int32(0)
+    lib.gfv_status_flags(ctypes.byref(sf))
+    status_flags = int(sf.value) | int(L.status_mirror()[0])
     if rank == 0:
         total_meshes = world * args.meshes_per_gpu
         value = total_meshes * timed_steps / elapsed
@@ -635,6 +698,8 @@ def main():
                                  "cmd_list": "command-list replay of the eager launch sequence (gfv/cmdlist.py)"}[used]
                               + (" with the weight gradients on a side stream" if ts.engine.overlap else "")),
             "cpu_baseline": cpu,
+            "drop_in": drop_in,
+            "status_flags": status_flags,   # device status word at the end of the run (0: no kernel left its fp16 window / range)
             "steps_executed": executed[0],   # every training step this process ran (all legs): profiles divide by it
         }
         if cpu:

@@ -14,6 +14,7 @@ import torch.nn as nn
 
 from FVMmodel.padding import check_hidden, pad_parameters
 from gfv import functions as GF
+from gfv import lib as L
 from gfv.plan import get_plan
 from utils.normalization import Normalizer
 from utils.utilities import NodeType  # noqa: F401  (re-exported like the reference)
@@ -45,6 +46,7 @@ class NNmodel(nn.Module):
         self.initialize_weights()
         self._engine = None
         self._names = None
+        self._replay = GF.ReplayCache()   # recorded forward / backward launch lists per (batch, parameter storage): gfv/functions.py
 
     # importer.py:42-52
     def initialize_weights(self):
@@ -70,11 +72,27 @@ class NNmodel(nn.Module):
         return self._engine
 
     def param_names_tensors(self):
-        names, tensors = [], []
-        for n, p in self.named_parameters():
-            names.append(n)
-            tensors.append(p)
-        return names, tensors
+        """(names, Parameter objects) in `named_parameters()` order; walked once and kept (159 entries: the walk costs ~0.1 ms per
+        call) until the module tree may have changed - `_apply` (.to / .cuda / .float), `load_state_dict`, `register_parameter`."""
+        if self._names is None:
+            names, tensors = [], []
+            for n, p in self.named_parameters():
+                names.append(n)
+                tensors.append(p)
+            self._names = (names, tensors)
+        return self._names
+
+    def _apply(self, fn, *args, **kwargs):
+        self._names = None
+        return super()._apply(fn, *args, **kwargs)
+
+    def load_state_dict(self, *args, **kwargs):
+        self._names = None
+        return super().load_state_dict(*args, **kwargs)
+
+    def register_parameter(self, name, param):
+        self.__dict__["_names"] = None
+        return super().register_parameter(name, param)
 
     def forward(self, graph_node, graph_node_x, graph_edge, graph_cell, graph_Index, is_training=True):
         if not is_training:
@@ -84,6 +102,9 @@ class NNmodel(nn.Module):
                              "please check the graph.norm_uvp")                            # importer.py:123-124
         x = graph_node.x
         GF.require_gpu(x)
+        # what the kernels of EARLIER calls raised in the device status word (a hidden activation outside the fixed-scale fp16 window,
+        # a weight-gradient operand beyond fp16): read from the pinned mirror the backward publishes into - no synchronisation
+        L.raise_on_status("NNmodel.forward")
         if not (x.is_contiguous() and x.dtype == torch.float32):
             x = x.contiguous().float()
             graph_node.x = x
@@ -94,7 +115,7 @@ class NNmodel(nn.Module):
         tensors = pad_parameters(names, tensors, self.hidden_size)   # (hidden_size 128: as they are)
         losses, uvp_node, uvp_cell, ea15 = GF.ModelFn.apply(
             self.engine(), plan, names, self.node_norm.buffers_dict(), x,
-            dict(norm_global=norm_global, accumulate=accumulate), *tensors)
+            dict(norm_global=norm_global, accumulate=accumulate), self._replay if self.hidden_size == 128 else None, *tensors)
         if accumulate:
             self.node_norm.note_accumulated()
         graph_node.norm_uvp = False

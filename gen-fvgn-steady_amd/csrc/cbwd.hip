@@ -375,6 +375,7 @@ int gfv_internal_cbwd_try(const gfv_rowtile_args_t* a, int lowp, hipStream_t str
   // the default leaves to the persistent backward)
   const int on = cw_env("GFV_CBWD", 1);
   const int max_m = cw_env("GFV_CBWD_MAX_M", 25000);
+  if (!gfv_internal_status_ptr()) return 0;   // (the kernels raise their range flag there)
   if (!on || a->M > max_m || a->M < 1 || (a->flags & (GFV_CHAIN_ROW_OWNER | GFV_CHAIN_COLUMN_OWNER))) return 0;
   const bool noout = a->nlayers == 2;
   if ((a->nlayers != 3 && !noout) || a->in_op != GFV_IN_LNBWD || a->fin_op != GFV_FIN_PLAIN || a->nseg != 1) return 0;

@@ -404,6 +404,7 @@ void cf_launch(const gfv_rowtile_args_t& a, int tg, int lowp, hipStream_t stream
 // whether the launch would be taken.  `args` carries `hidden` (the launcher of rowtile.hip fills it in).
 int gfv_internal_cfwd_try(const gfv_rowtile_args_t* a, int lowp, hipStream_t stream, int dry) {
   // (read per launch - at record time under a command list -: the tests move the limits to reach both tile heights at any size)
+  if (!gfv_internal_status_ptr()) return 0;   // (the kernels raise their range flag there)
   const int on = cf_env("GFV_CFWD", 1);
   const int max_m = cf_env("GFV_CFWD_MAX_M", 100000);
   // 32-row tiles at every size the family takes: 64-row tiles (GFV_CFWD_TG2_MAX_M below the launch's rows) measured -1.8 % / -0.6 % /

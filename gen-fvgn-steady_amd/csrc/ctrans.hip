@@ -685,7 +685,7 @@ extern "C" int gfv_trans_mlp_ln_rows(int32_t M) {
 }
 
 int gfv_internal_ctrans_bwd_try(const gfv_trans_mlp_bwd_t* a, int form, hipStream_t stream) {
-  if (!ct_env("GFV_CTRANS", 1) || a->M > ct_env("GFV_CTRANS_MAX_M", 16384)) return 0;
+  if (!ct_env("GFV_CTRANS", 1) || a->M > ct_env("GFV_CTRANS_MAX_M", 16384) || !gfv_internal_status_ptr()) return 0;
   CtBwdArgs B{a->g, a->g_add, a->g_sum, a->z, a->fx1, a->img_post_t, a->img_pre_t, a->img_out_t, a->gamma, a->wmax,
               a->g_z, a->g_fx1, a->g_out_x, a->ln_partial, a->gscale, a->M, gfv_hidden_size()};
   int* st = gfv_internal_status_ptr();
@@ -699,7 +699,7 @@ int gfv_internal_ctrans_bwd_try(const gfv_trans_mlp_bwd_t* a, int form, hipStrea
 // 1: launched; 0: not this family's launch (too many rows, switched off).  The caller (transmlp.hip) has checked the arguments.
 // form: gfv_f16split_enabled() of the calling thread (1 / 2 / 3)
 int gfv_internal_ctrans_fwd_try(const gfv_trans_mlp_t* a, int form, hipStream_t stream) {
-  if (!ct_env("GFV_CTRANS", 1) || a->M > ct_env("GFV_CTRANS_MAX_M", 16384)) return 0;
+  if (!ct_env("GFV_CTRANS", 1) || a->M > ct_env("GFV_CTRANS_MAX_M", 16384) || !gfv_internal_status_ptr()) return 0;
   CtArgs B{a->x, a->res, a->img_out, a->img_pre, a->img_post, a->b_out, a->b_pre, a->b_post, a->gamma, a->beta, a->wmax,
            a->fx1, a->z, a->out, a->M, gfv_hidden_size()};
   int* st = gfv_internal_status_ptr();

@@ -38,6 +38,43 @@ int* gfv_internal_status_ptr() {
   return p;
 }
 
+// Asynchronous mirror of the status word (include/gfv.h gfv_status_mirror): one pinned, device-mapped int32 per process.  Kernels
+// that end a step copy a non-zero status word into it (a plain system-scope store: the host only ever clears it after it has read a
+// non-zero value and cleared the device word, so nothing is lost to a race - a flag raised in between is published by the next step).
+namespace {
+int32_t* g_status_host = nullptr;       // host address
+int32_t* g_status_host_dev = nullptr;   // the same word as the device addresses it
+__global__ void status_publish_kernel(const int* __restrict__ dev_word, int* host_word) {
+  const int v = *reinterpret_cast<const volatile int*>(dev_word);
+  if (v) __hip_atomic_store(host_word, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+}  // namespace
+int32_t* gfv_internal_status_mirror() { return g_status_host_dev; }   // nullptr until a host asked for the mirror
+extern "C" int gfv_status_mirror(int32_t** host_word) {
+  if (!host_word) return GFV_ERR_ARG;
+  if (!g_status_host) {
+    void* h = nullptr;
+    void* d = nullptr;
+    if (hipHostMalloc(&h, sizeof(int32_t), hipHostMallocMapped) != hipSuccess) return GFV_ERR_LAUNCH;
+    *static_cast<int32_t*>(h) = 0;
+    if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) {
+      hipHostFree(h);
+      return GFV_ERR_LAUNCH;
+    }
+    g_status_host = static_cast<int32_t*>(h);
+    g_status_host_dev = static_cast<int32_t*>(d);
+  }
+  *host_word = g_status_host;
+  return GFV_OK;
+}
+extern "C" int gfv_status_publish(void* stream) {
+  int* dev = gfv_internal_status_ptr();
+  if (!dev || !g_status_host_dev) return GFV_ERR_ARG;   // (gfv_status_mirror first)
+  GFV_LAUNCH(status_publish_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (const int*)dev, (int*)g_status_host_dev);
+  GFV_CHECK_LAUNCH();
+  return GFV_OK;
+}
+
 namespace {
 
 constexpr int SUB = 32;   // rows per staged sub-tile

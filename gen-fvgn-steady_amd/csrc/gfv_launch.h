@@ -11,7 +11,8 @@
 
 struct GfvRecorder;
 GfvRecorder* gfv_rec_active();   // the list the calling thread records into, or nullptr (record.hip)
-void gfv_rec_push(GfvRecorder* r, void (*run)(const void* blob, hipStream_t st), const void* blob, size_t bytes, hipStream_t st);
+// `run` re-issues the command and returns what the runtime said: gfv_record_replay stops at the first failure (GFV_ERR_LAUNCH)
+void gfv_rec_push(GfvRecorder* r, hipError_t (*run)(const void* blob, hipStream_t st), const void* blob, size_t bytes, hipStream_t st);
 
 template <class... KArgs, class... Args>
 inline void gfv_launch(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t shmem, hipStream_t st, Args&&... args) {
@@ -25,13 +26,15 @@ inline void gfv_launch(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t s
     };
     static_assert(std::is_trivially_copyable<std::tuple<std::decay_t<KArgs>...>>::value || true, "kernel arguments are plain data");
     const Blob blob{kernel, grid, block, shmem, std::tuple<std::decay_t<KArgs>...>(args...)};
-    gfv_rec_push(r, [](const void* p, hipStream_t s) {
+    gfv_rec_push(r, [](const void* p, hipStream_t s) -> hipError_t {
       const Blob& B = *static_cast<const Blob*>(p);
       std::apply([&](const auto&... a) { hipLaunchKernelGGL(B.k, B.g, B.b, B.sh, s, a...); }, B.a);
+      return hipGetLastError();
     }, &blob, sizeof(Blob), st);
   }
 }
 #define GFV_LAUNCH(kernel, grid, block, shmem, stream, ...) gfv_launch(kernel, dim3(grid), dim3(block), (size_t)(shmem), stream, __VA_ARGS__)
 
 // hipMemsetAsync of a few bytes inside a recorded step (wimg.hip: the weight maximum's zero)
-void gfv_memset_rec(void* dst, int value, size_t bytes, hipStream_t st);
+// (returns the runtime's error of the eager call)
+hipError_t gfv_memset_rec(void* dst, int value, size_t bytes, hipStream_t st);

@@ -217,21 +217,33 @@ __global__ __launch_bounds__(256) void edge_attr_kernel(const float* __restrict_
 
 // Adam (torch.optim.Adam defaults, pre_train_Adam.py:115): the step counter and the hyper-parameters live in device
 // memory, so a captured hipGraph follows lr changes (lr_scheduler.step() every epoch in both reference drivers).
-// state = {t, lr / (1 - b1^t), sqrt(1 - b2^t), reserved}: the bias corrections are formed in double like torch's host
-// code (fp32 powf at t = 1 is 1.3e-5 away), once per step by the tick kernel.
-// hyper = {lr, beta1, beta2, eps, grad_scale, 0, 0, 0}
-__global__ void adam_tick_kernel(float* state, const float* __restrict__ hyper) {
-  const float t = state[0] + 1.0f;
-  const double bc1 = 1.0 - pow((double)hyper[1], (double)t), bc2 = 1.0 - pow((double)hyper[2], (double)t);
-  state[0] = t;
-  state[1] = (float)((double)hyper[0] / bc1);
-  state[2] = (float)sqrt(bc2);
+// state[8] = {t = completed steps, bc1_hi, bc1_lo, sqrt(1 - b2^(t+1)), arrival counter (int), 0, 0, 0}: the bias corrections OF
+// THE NEXT STEP, formed in double like torch's host code (fp32 powf at t = 1 is 1.3e-5 away); 1 - b1^(t+1) is kept as a
+// (hi, lo) float pair so that every thread forms lr / bc1 in double with the CURRENT lr (a step follows `ts.lr = ...`).
+// Round 6: ONE launch per step.  The tick used to be a launch of its own (4.8 us of launch floor for two pows of one thread;
+// folded into every workgroup it cost 53 us): now the workgroup that FINISHES LAST - every other one has read the state by then -
+// advances t, forms the next step's corrections and publishes the status word (include/gfv.h gfv_status_mirror).
+// hyper = {lr, beta1, beta2, eps, grad_scale, w_cont, w_mom, w_press}
+__device__ __forceinline__ void adam_corrections(float* state, const float* hyper, float t_done) {
+  const double tn = (double)t_done + 1.0;
+  const double bc1 = 1.0 - pow((double)hyper[1], tn), bc2 = 1.0 - pow((double)hyper[2], tn);
+  const float hi = (float)bc1;
+  state[0] = t_done;
+  state[1] = hi;
+  state[2] = (float)(bc1 - (double)hi);
+  state[3] = (float)sqrt(bc2);
+}
+__global__ void adam_state_init_kernel(float* state, const float* __restrict__ hyper, float t_done) {
+  adam_corrections(state, hyper, t_done);
+  reinterpret_cast<int*>(state)[4] = 0;
+  state[5] = state[6] = state[7] = 0.f;
 }
 
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                                                   float* __restrict__ v, long n, const float* __restrict__ state,
-                                                   const float* __restrict__ hyper) {
-  const float step_size = state[1], bc2_sqrt = state[2];
+                                                   float* __restrict__ v, long n, float* state,
+                                                   const float* __restrict__ hyper, const int* status_dev, int* status_host) {
+  const float step_size = (float)((double)hyper[0] / ((double)state[1] + (double)state[2])), bc2_sqrt = state[3];
+  const float t_done = state[0];
   const float b1 = hyper[1], b2 = hyper[2], eps = hyper[3], grad_scale = hyper[4];
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
     const float gi = g[i] * grad_scale;
@@ -240,6 +252,19 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     m[i] = mi; v[i] = vi;
     const float denom = sqrtf(vi) / bc2_sqrt + eps;
     p[i] = p[i] - step_size * (mi / denom);
+  }
+  __syncthreads();   // every thread of this workgroup has read the state
+  if (threadIdx.x == 0) {
+    int* counter = reinterpret_cast<int*>(state) + 4;
+    __threadfence();
+    if (atomicAdd(counter, 1) == (int)gridDim.x - 1) {
+      *counter = 0;
+      adam_corrections(state, hyper, t_done + 1.0f);
+      if (status_host) {
+        const int f = *reinterpret_cast<const volatile int*>(status_dev);
+        if (f) __hip_atomic_store(status_host, f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
   }
 }
 
@@ -334,32 +359,24 @@ extern "C" int gfv_edge_attr(const float* x, int32_t ldx, const float* pos, cons
   return GFV_OK;
 }
 
+int* gfv_internal_status_ptr();        // dw.hip
+int32_t* gfv_internal_status_mirror();   // dw.hip: nullptr until a host asked for the mirror
+
+extern "C" int gfv_adam_state_init(float* state, const float* hyper, float steps_done, void* stream) {
+  if (!state || !hyper || !(steps_done >= 0.f)) return GFV_ERR_ARG;
+  GFV_LAUNCH(adam_state_init_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, state, hyper, steps_done);
+  GFV_CHECK_LAUNCH();
+  return GFV_OK;
+}
+
 extern "C" int gfv_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, float* state, const float* hyper,
                                  void* stream) {
   GfvProfScope ps_(GFV_K_MISC, 0, 28.0 * (double)n, stream);   // p, g, m, v in; p, m, v out
   if (n <= 0) return GFV_OK;
   if (!state || !hyper) return GFV_ERR_ARG;
-  GFV_LAUNCH(adam_tick_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, state, hyper);
-  GFV_LAUNCH(adam_kernel, dim3(cap_grid(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long)n, state, hyper);
-  GFV_CHECK_LAUNCH();
-  return GFV_OK;
-}
-
-// the two halves of gfv_adam_step_dev as launches of their own: the tick depends on the step count and the hyper-parameters only, so
-// a caller may issue it early and on another stream (TrainStep: at the start of the backward, on the weight-gradient queue) and keep
-// ~6 us of single-thread double arithmetic off the end of the step
-extern "C" int gfv_adam_tick_dev(float* state, const float* hyper, void* stream) {
-  if (!state || !hyper) return GFV_ERR_ARG;
-  GFV_LAUNCH(adam_tick_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, state, hyper);
-  GFV_CHECK_LAUNCH();
-  return GFV_OK;
-}
-extern "C" int gfv_adam_update_dev(float* p, const float* g, float* m, float* v, int64_t n, const float* state, const float* hyper,
-                                   void* stream) {
-  GfvProfScope ps_(GFV_K_MISC, 0, 28.0 * (double)n, stream);
-  if (n <= 0) return GFV_OK;
-  if (!state || !hyper) return GFV_ERR_ARG;
-  GFV_LAUNCH(adam_kernel, dim3(cap_grid(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long)n, state, hyper);
+  int32_t* mirror = gfv_internal_status_mirror();
+  GFV_LAUNCH(adam_kernel, dim3(cap_grid(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long)n, state, hyper,
+             (const int*)gfv_internal_status_ptr(), (int*)mirror);
   GFV_CHECK_LAUNCH();
   return GFV_OK;
 }

@@ -11,6 +11,7 @@
 
 #include "../../include/gfv.h"
 #include "gfv_common.h"
+#include "gfv_launch.h"
 
 namespace {
 
@@ -183,6 +184,8 @@ extern "C" int gfv_plan_destroy(gfv_plan_t* plan) {
 }
 
 extern "C" int gfv_plan_create(const gfv_plan_desc_t* d, gfv_plan_t** out, void* stream_) {
+  // (once per batch, synchronising, launches of its own that a command list does not note: never inside a recorded step)
+  if (gfv_rec_active()) return GFV_ERR_ARG;
   if (d == nullptr || out == nullptr) return GFV_ERR_ARG;
   *out = nullptr;
   const int64_t N = d->n_nodes, E = d->n_faces, C = d->n_cells, Sg = d->n_incidences, Ex = d->n_stencil_pairs, Es = d->n_support_pairs;

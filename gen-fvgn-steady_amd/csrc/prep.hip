@@ -124,6 +124,8 @@ extern "C" size_t gfv_khop_workspace_ints(int32_t N, int32_t F) { return (size_t
 extern "C" int gfv_khop_count(const int64_t* face0, const int64_t* face1, int32_t F, int32_t N, int32_t k, int32_t* ws,
                               void* stream_) {
   if (N < 1 || F < 0 || k < 1 || !ws) return GFV_ERR_ARG;
+  // per-mesh preprocessing: its fills below are plain hipMemsetAsync calls a replay would not repeat - not part of a recorded step
+  if (gfv_rec_active()) return GFV_ERR_ARG;
   hipStream_t stream = (hipStream_t)stream_;
   int* deg = ws;                       // [N + 1] degree, then the CSR cursor
   int* rowptr = deg + (N + 1);         // [N + 1]

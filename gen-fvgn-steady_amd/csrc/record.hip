@@ -11,7 +11,7 @@
 
 struct GfvRecorder {
   struct Cmd {
-    void (*run)(const void*, hipStream_t);
+    hipError_t (*run)(const void*, hipStream_t);
     hipStream_t st;
     size_t off;
   };
@@ -25,54 +25,65 @@ std::mutex g_mu;
 std::unordered_map<int64_t, GfvRecorder*> g_lists;
 int64_t g_next = 1;
 
-// events for stream-to-stream edges: a wait refers to the event's record at the time of the call, so a small ring is enough
+// events for stream-to-stream edges: a wait refers to the event's record at the time of the call, so a small ring is enough.
+// One ring per DEVICE (an event belongs to the device that was current when it was created: a process that drives streams of
+// several devices gets a ring on each)
 constexpr int N_EVENTS = 64;
-hipEvent_t g_events[N_EVENTS];
-bool g_events_ready = false;
-int g_event_next = 0;
+constexpr int MAX_DEVICES = 16;
+struct EventRing {
+  hipEvent_t ev[N_EVENTS];
+  bool ready = false;
+  int next = 0;
+};
+EventRing g_rings[MAX_DEVICES];
 hipEvent_t next_event() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) return nullptr;
   std::lock_guard<std::mutex> lk(g_mu);
-  if (!g_events_ready) {
+  EventRing& r = g_rings[dev];
+  if (!r.ready) {
     for (int i = 0; i < N_EVENTS; ++i)
-      if (hipEventCreateWithFlags(&g_events[i], hipEventDisableTiming) != hipSuccess) return nullptr;
-    g_events_ready = true;
+      if (hipEventCreateWithFlags(&r.ev[i], hipEventDisableTiming) != hipSuccess) return nullptr;
+    r.ready = true;
   }
-  hipEvent_t e = g_events[g_event_next];
-  g_event_next = (g_event_next + 1) % N_EVENTS;
+  hipEvent_t e = r.ev[r.next];
+  r.next = (r.next + 1) % N_EVENTS;
   return e;
 }
 struct WaitBlob {
   hipStream_t waited;
 };
-void run_wait(const void* p, hipStream_t waiter) {
+hipError_t run_wait(const void* p, hipStream_t waiter) {
   const WaitBlob& B = *static_cast<const WaitBlob*>(p);
   hipEvent_t e = next_event();
-  if (!e) return;
-  hipEventRecord(e, B.waited);
-  hipStreamWaitEvent(waiter, e, 0);
+  if (!e) return hipErrorInvalidResourceHandle;   // (a dropped edge would be a data race, not an error: fail the replay)
+  hipError_t rc = hipEventRecord(e, B.waited);
+  if (rc != hipSuccess) return rc;
+  return hipStreamWaitEvent(waiter, e, 0);
 }
 struct MemsetBlob {
   void* dst;
   int value;
   size_t bytes;
 };
-void run_memset(const void* p, hipStream_t st) {
+hipError_t run_memset(const void* p, hipStream_t st) {
   const MemsetBlob& B = *static_cast<const MemsetBlob*>(p);
-  hipMemsetAsync(B.dst, B.value, B.bytes, st);
+  return hipMemsetAsync(B.dst, B.value, B.bytes, st);
 }
 }  // namespace
 
 GfvRecorder* gfv_rec_active() { return t_active; }
-void gfv_rec_push(GfvRecorder* r, void (*run)(const void*, hipStream_t), const void* blob, size_t bytes, hipStream_t st) {
+void gfv_rec_push(GfvRecorder* r, hipError_t (*run)(const void*, hipStream_t), const void* blob, size_t bytes, hipStream_t st) {
   const size_t off = (r->arena.size() + 15) & ~(size_t)15;
   r->arena.resize(off + bytes);
   memcpy(r->arena.data() + off, blob, bytes);
   r->cmds.push_back({run, st, off});
 }
-void gfv_memset_rec(void* dst, int value, size_t bytes, hipStream_t st) {
+hipError_t gfv_memset_rec(void* dst, int value, size_t bytes, hipStream_t st) {
   const MemsetBlob b{dst, value, bytes};
-  run_memset(&b, st);
+  const hipError_t rc = run_memset(&b, st);
   if (GfvRecorder* r = gfv_rec_active()) gfv_rec_push(r, run_memset, &b, sizeof(b), st);
+  return rc;
 }
 
 extern "C" int gfv_record_begin(void) {
@@ -107,8 +118,8 @@ extern "C" int gfv_record_replay(int64_t handle, int32_t first, int32_t last) {
   if (first < 0 || last > n || first > last) return GFV_ERR_ARG;
   if (t_active) return GFV_ERR_ARG;   // (a replay inside a recording would be recorded again)
   const char* base = r->arena.data();
-  for (int i = first; i < last; ++i) r->cmds[i].run(base + r->cmds[i].off, r->cmds[i].st);
-  GFV_CHECK_LAUNCH();
+  for (int i = first; i < last; ++i)
+    if (r->cmds[i].run(base + r->cmds[i].off, r->cmds[i].st) != hipSuccess) return GFV_ERR_LAUNCH;   // stop at the first failure
   return GFV_OK;
 }
 extern "C" int gfv_record_free(int64_t handle) {

@@ -107,7 +107,10 @@ static int cbwd_try(const gfv_rowtile_args_t* args, int lowp, hipStream_t stream
 }
 static int rowtile_chain_impl(const gfv_rowtile_args_t* args, void* stream) {
   if (!args || args->M < 0 || args->nlayers < 1 || args->nlayers > 3 || args->nseg < 1 || args->nseg > 3) return GFV_ERR_ARG;
-  if (args->M == 0) return GFV_OK;
+  if (args->M == 0) {
+    g_last_ln_rows = 0;   // (an empty batch fills no ln_partial row: a caller that sums gfv_rowtile_last_ln_rows() rows sums none)
+    return GFV_OK;
+  }
   for (int i = 0; i < args->nseg; ++i)
     if (args->seg[i].width < 1 || args->seg[i].width > 128) return GFV_ERR_ARG;
   for (int l = 0; l + 1 < args->nlayers; ++l)

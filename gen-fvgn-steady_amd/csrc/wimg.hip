@@ -124,7 +124,7 @@ extern "C" size_t gfv_weight_image_bytes(int32_t N, int32_t K) {
 extern "C" int gfv_weight_absmax(const gfv_wimg_desc_t* descs_dev, int32_t n_desc, float* wmax, void* stream) {
   GfvProfScope ps_(GFV_K_WIMG, 0, 4.0 * 1181539.0, stream);
   if (!descs_dev || !wmax || n_desc < 0) return GFV_ERR_ARG;
-  gfv_memset_rec(wmax, 0, sizeof(float), (hipStream_t)stream);   // (recordable: gfv_launch.h)
+  if (gfv_memset_rec(wmax, 0, sizeof(float), (hipStream_t)stream) != hipSuccess) return GFV_ERR_LAUNCH;   // (recordable: gfv_launch.h)
   if (n_desc == 0) return GFV_OK;
   GFV_LAUNCH(wabsmax_kernel, dim3(4, n_desc), dim3(256), 0, (hipStream_t)stream, descs_dev, wmax);
   GFV_CHECK_LAUNCH();

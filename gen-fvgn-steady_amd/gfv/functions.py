@@ -132,29 +132,146 @@ class IntegratorFn(torch.autograd.Function):
         return None, None, gdec, None
 
 
+# (storage address of the flat gradient tensor the last ModelFn.backward handed out, positions of the parameters that got no
+# gradient - their slots hold zeros): gfv.optim.Adam feeds that tensor to its fused launch as it is
+LAST_FLAT = None
+
+
+def _note_flat(flat, names, skip):
+    global LAST_FLAT
+    LAST_FLAT = (flat.untyped_storage().data_ptr(), frozenset(i for i, n in enumerate(names) if n in skip))
+
+
+class _Replay:
+    """One recorded (forward, backward) pair of command lists of NNmodel.forward for ONE batch, parameter set and flag
+    combination (gfv/cmdlist.py).  The lists hold raw pointers: `x` (the node-state tensor of the recorded call), the saved
+    activations `sv` and the outputs live in the forward list's private pool, the gradient rows in `grads` (allocated once,
+    outside the pools), the incoming loss gradient is copied into `gloss`."""
+
+    __slots__ = ("warm", "fwd", "bwd", "x", "outs", "sv", "sig", "gloss", "grads", "plan", "pending", "P")
+
+    def __init__(self):
+        self.warm, self.fwd, self.bwd, self.pending = 0, None, None, False
+        self.x = self.outs = self.sv = self.sig = self.gloss = self.grads = self.plan = self.P = None
+
+
+class ReplayCache:
+    """Per-model cache of recorded forward / backward lists (round 6: the drop-in path `loss.backward(); optimizer.step()` of
+    pre_train_Adam.py:158-191 / solve_with_grad_GPU.py:133-181 used to issue every launch eagerly from Python - 2.9 x the
+    command-list step on the 5 k-cell cavity).  A call replays when the batch's plan, the parameter storage, the product form
+    and the two norm flags are the ones of a recorded call; anything else runs eagerly, as before.  GFV_DROPIN_REPLAY=0 turns
+    it off."""
+
+    WARM = 2   # eager calls before recording: they settle the weight-image set and the engine's persistent workspaces
+
+    def __init__(self):
+        import os
+        self.enabled = os.environ.get("GFV_DROPIN_REPLAY", "1") != "0"
+        self.entries = {}
+        self.replays = 0   # (diagnostics: how many forward calls were replayed)
+
+    def lookup(self, engine, plan, key):
+        if not self.enabled or engine.hidden != 128 or engine.dist_world > 1 or engine.dist_force:
+            return None
+        ent = self.entries.get(key)
+        if ent is None:
+            if len(self.entries) >= 8:    # a training loop over many batches: keep the most recent few
+                self.entries.pop(next(iter(self.entries)))
+            ent = self.entries[key] = _Replay()
+            ent.plan = plan
+        return ent
+
+    def clear(self):
+        self.entries.clear()
+
+
 class ModelFn(torch.autograd.Function):
     """Whole NNmodel.forward (importer.py:156-240) as one autograd node."""
 
     @staticmethod
-    def forward(ctx, engine, plan, names, buffers, x, flags, *params):
+    def forward(ctx, engine, plan, names, buffers, x, flags, cache, *params):
         require_gpu(x)
+        from . import cmdlist
+        from . import lib as L
         P = dict(zip(names, (p.detach() for p in params)))
+        ent = None
+        if cache is not None and cmdlist.active() is None and not torch.cuda.is_current_stream_capturing():
+            key = (id(plan), flags["norm_global"], flags["accumulate"], L.load().gfv_f16split_enabled(),
+                   tuple(p.data_ptr() for p in params))
+            ent = cache.lookup(engine, plan, key)
+        run = lambda: engine.forward(P, buffers, x, plan, norm_global=flags["norm_global"], accumulate=flags["accumulate"])
         with engine.model_width():
-            losses, uvp_node, uvp_cell, ea15, sv = engine.forward(
-                P, buffers, x, plan, norm_global=flags["norm_global"], accumulate=flags["accumulate"])
-        ctx.engine, ctx.plan, ctx.names, ctx.sv, ctx.P = engine, plan, names, sv, P
+            if ent is None or ent.pending:
+                # (pending: the previous replayed forward's backward has not run - its saved rows must not be overwritten)
+                ent = None
+                losses, uvp_node, uvp_cell, ea15, sv = run()
+            elif ent.fwd is None:
+                if ent.warm < ReplayCache.WARM:
+                    ent.warm += 1
+                    ent = None
+                    losses, uvp_node, uvp_cell, ea15, sv = run()
+                else:
+                    with cmdlist.record() as cl:
+                        losses, uvp_node, uvp_cell, ea15, sv = run()
+                    ent.fwd, ent.x, ent.sv, ent.P = cl, x, sv, P
+                    ent.outs = (losses, uvp_node, uvp_cell, ea15)
+                    ent.sig = engine.capture_signature()
+            elif ent.sig != engine.capture_signature():
+                # the engine's weight-image set / descriptor tables changed under the lists: drop them, run eagerly
+                cache.entries = {k: v for k, v in cache.entries.items() if v is not ent}
+                ent = None
+                losses, uvp_node, uvp_cell, ea15, sv = run()
+            else:
+                foreign = x.data_ptr() != ent.x.data_ptr()
+                if foreign:                   # another tensor than the recorded one carries the node state: through the recorded
+                    ent.x.copy_(x)            # tensor and back (the reference normalises graph_node.x IN PLACE, importer.py:123-130)
+                ent.fwd.replay()
+                if foreign:
+                    x.copy_(ent.x)
+                losses, uvp_node, uvp_cell, ea15 = ent.outs
+                sv, P = ent.sv, ent.P
+                cache.replays += 1
+        if ent is not None:
+            # the lists' own output tensors are overwritten by the next replay: hand out copies (4 small launches)
+            losses, uvp_node, uvp_cell, ea15 = losses.clone(), uvp_node.clone(), uvp_cell.clone(), ea15.clone()
+            ent.pending = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        ctx.engine, ctx.plan, ctx.names, ctx.sv, ctx.P, ctx.ent = engine, plan, names, sv, P, ent
         ctx.mark_non_differentiable(uvp_node, uvp_cell, ea15)
         return losses, uvp_node, uvp_cell, ea15
 
     @staticmethod
     def backward(ctx, g_losses, _gn, _gc, _ge):
-        P = ctx.P
+        from . import cmdlist
+        from . import lib as L
+        P, ent = ctx.P, ctx.ent
         skip = unused_param_names(ctx.names)
-        grads = _alloc_grads(ctx.names, [P[n] for n in ctx.names], skip)
+        tail = (None, None, None, None, None, None, None)
+        if ent is None:
+            grads = _alloc_grads(ctx.names, [P[n] for n in ctx.names], skip)
+            with ctx.engine.model_width():
+                ctx.engine.backward(P, ctx.sv, g_losses.contiguous(), grads, ctx.plan)
+            L.status_publish()    # NNmodel.forward reads the mirror at its next call (no synchronisation)
+            _note_flat(grads.flat, ctx.names, skip)
+            return tail + tuple(grads.view(n) for n in ctx.names)
         with ctx.engine.model_width():
-            ctx.engine.backward(P, ctx.sv, g_losses.contiguous(), grads, ctx.plan)
-        return (None, None, None, None, None, None) + tuple(grads.view(n) for n in ctx.names)
+            if ent.bwd is None:
+                ent.gloss = g_losses.contiguous().clone()
+                ent.grads = _alloc_grads(ctx.names, [P[n] for n in ctx.names], skip)   # zeroed once; every step rewrites the same rows
+                with cmdlist.record() as cl:
+                    ctx.engine.backward(P, ent.sv, ent.gloss, ent.grads, ctx.plan)
+                    L.status_publish()
+                ent.bwd = cl
+            else:
+                ent.gloss.copy_(g_losses)
+                ent.bwd.replay()
+        ent.pending = False
+        # autograd keeps what it is handed as `.grad` (or adds it to one): a fresh flat copy per step - one launch - so that a
+        # later replay never rewrites a tensor the caller still holds; its views keep the flat layout gfv.optim.Adam recognises
+        flat = ent.grads.flat.clone()
+        G = ent.grads
+        _note_flat(flat, ctx.names, G.skip)
+        return tail + tuple(None if n in G.skip else flat[G.off[n]:G.off[n] + G.numel(n)].view(G.shape[n]) for n in ctx.names)
 
 
 __all__ = ["Engine", "get_plan", "GnBlockFn", "Mlp3Fn", "TransolverFn", "SimulatorFn", "IntegratorFn", "ModelFn",
-           "unused_param_names"]
+           "ReplayCache", "unused_param_names"]

@@ -51,7 +51,7 @@ class RowtileArgs(C.Structure):
     ]
 
 
-ABI_VERSION = 2   # GFV_ABI_VERSION of include/gfv.h this binding is written against
+ABI_VERSION = 3   # GFV_ABI_VERSION of include/gfv.h this binding is written against
 
 DW_FUSED_FLOATS = 2 * 128 * 128 + 4 * 128   # floats per workgroup block of a fused weight-gradient launch (include/gfv.h)
 DW_FUSED_FLOATS_IN = 3 * 128 * 128 + 5 * 128   # ... with the first Linear's weight gradient fused as well (dw_in)
@@ -101,6 +101,8 @@ _SIGNATURES = {
                                         C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_void_p]),
     "gfv_transpose_batch": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "gfv_status_flags": (C.c_int, [C.POINTER(C.c_int32)]),
+    "gfv_status_mirror": (C.c_int, [C.POINTER(C.POINTER(C.c_int32))]),
+    "gfv_status_publish": (C.c_int, [C.c_void_p]),
     "gfv_profile_enable": (C.c_int, [C.c_int]),
     "gfv_profile_collect": (C.c_int, [C.c_int, C.POINTER(C.c_double)]),
     "gfv_profile_reset": (C.c_int, []),
@@ -185,8 +187,7 @@ _SIGNATURES = {
     "gfv_node_prep": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
     "gfv_edge_attr": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "gfv_adam_step_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "gfv_adam_tick_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
-    "gfv_adam_update_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gfv_adam_state_init": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]),
     "gfv_train_loss_dev": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gfv_train_loss": (C.c_int, [C.c_void_p, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gfv_plan_create": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_void_p]),
@@ -267,6 +268,44 @@ def stream_wait(waiter, waited):
     """`waiter.wait_stream(waited)` through the library (include/gfv.h gfv_stream_wait): the same event record + stream wait,
     and part of a natively recorded step (gfv/cmdlist.py)."""
     check(load().gfv_stream_wait(C.c_void_p(waiter.cuda_stream), C.c_void_p(waited.cuda_stream)), "gfv_stream_wait")
+
+
+FLAG_NAMES = {1: "GFV_FLAG_DW_RANGE (a weight-gradient operand left the fp16 range)",
+              2: "GFV_FLAG_CHAIN_RANGE (a hidden activation left the fixed-scale fp16 window of the column-owner chain kernels)"}
+_status_word = None
+
+
+def status_mirror():
+    """The library's pinned, device-mapped copy of the status word (include/gfv.h gfv_status_mirror) as a ctypes int32
+    pointer; kernels that end a step publish into it, the host reads it without a synchronisation."""
+    global _status_word
+    if _status_word is None:
+        p = C.POINTER(C.c_int32)()
+        check(load(raw=True).gfv_status_mirror(C.byref(p)), "gfv_status_mirror")
+        _status_word = p
+    return _status_word
+
+
+def status_publish():
+    """Enqueue the publication of the status word on the current stream (callers without the fused Adam at their end)."""
+    status_mirror()
+    check(load().gfv_status_publish(stream_ptr()), "gfv_status_publish")
+
+
+def raise_on_status(where):
+    """Non-blocking check of what the kernels of EARLIER steps raised: a non-zero mirror is cleared (together with the device
+    word: that one read synchronises, on the error path only) and turned into a FloatingPointError naming the flags."""
+    w = status_mirror()
+    v = int(w[0])
+    if not v:
+        return
+    w[0] = 0
+    flags = C.c_int32(0)
+    load(raw=True).gfv_status_flags(C.byref(flags))   # clears the device word
+    v |= int(flags.value)
+    names = [n for bit, n in FLAG_NAMES.items() if v & bit] or [f"flags {v:#x}"]
+    raise FloatingPointError(f"libgfv status word raised before {where}: " + "; ".join(names) + ".  The split-fp16 products of that "
+                             "step lost fp32 accuracy (or overflowed): run with GFV_F16SPLIT=0 (fp32 MFMA) or rescale the model")
 
 
 def ptr(t):

@@ -61,9 +61,11 @@ class TrainStep:
         self.flat_v = torch.zeros(total, dtype=torch.float32, device=dev)
         # Adam step counter + derived bias corrections, and the hyper-parameters: device resident (include/gfv.h,
         # gfv_adam_step_dev), so a captured step follows `ts.lr = ...` (lr_scheduler.step() in the reference drivers)
-        self.adam_state = torch.zeros(4, dtype=torch.float32, device=dev)
+        # (adam_state[8] = {completed steps, the NEXT step's bias corrections, arrival counter}: include/gfv.h gfv_adam_step_dev)
+        self.adam_state = torch.zeros(8, dtype=torch.float32, device=dev)
         self.hyper = torch.zeros(8, dtype=torch.float32, device=dev)
         self._sync_hyper()
+        L.status_mirror()   # the fused Adam publishes the device status word from now on; step() reads it without a sync
         self.P = {}
         for n, t in zip(names, tensors):
             off, k = self.G.off[n], t.numel()
@@ -118,8 +120,16 @@ class TrainStep:
     def _sync_hyper(self):
         vals = (self._lr, self._betas[0], self._betas[1], self._eps, 1.0 / self.world_size, *self._lw)
         if vals != self._hyper_host:
+            betas_moved = self._hyper_host is None or vals[1:3] != self._hyper_host[1:3]
             self.hyper.copy_(torch.tensor(vals, dtype=torch.float32))
             self._hyper_host = vals
+            if betas_moved:
+                self._init_adam_state()
+
+    def _init_adam_state(self, steps_done=None):
+        """The device-side bias corrections of the next step, from the step count (a new object, a loaded checkpoint, new betas)."""
+        t = float(self.adam_state[0]) if steps_done is None else float(steps_done)
+        L.check(L.load().gfv_adam_state_init(self.adam_state.data_ptr(), self.hyper.data_ptr(), t, L.stream_ptr()), "adam_state_init")
 
     lr = property(lambda self: self._lr)
     betas = property(lambda self: self._betas)
@@ -190,13 +200,12 @@ class TrainStep:
             step = float(st["step"]) if step is None else step
             if float(st["step"]) != step:
                 raise ValueError("per-parameter step counts differ: not a state this fused Adam can resume")
-        self.adam_state.zero_()
-        self.adam_state[0] = 0.0 if step is None else step
         g = sd["param_groups"][0]
         self._lr, self._betas, self._eps = float(g["lr"]), (float(g["betas"][0]), float(g["betas"][1])), float(g["eps"])
         if "gfv_loss_weights" in sd:
             self._lw = tuple(float(x) for x in sd["gfv_loss_weights"])
         self._sync_hyper()
+        self._init_adam_state(0.0 if step is None else step)
 
     def named_state(self):
         """{name: (parameter, exp_avg, exp_avg_sq)} views of the flat buffers.  (The alignment padding between tensors is not
@@ -261,25 +270,19 @@ class TrainStep:
                 want_outputs=self.want_outputs, want_edge_attr15=False, before_prep=restore)
             L.check(lib.gfv_train_loss_dev(losses.data_ptr(), self.plan.B, self.hyper.data_ptr(), self.loss.data_ptr(),
                                            self.gloss.data_ptr(), st), "train_loss")
-            # (GFV_EARLY_TICK=1: Adam's tick - step count + bias corrections, ~6 us of one thread's double arithmetic that needs no
-            # gradient - goes out now, on the weight-gradient queue, not at the end of the step.  Measured: the extra fork costs what
-            # the tick saved, 3.574 / 3.567 against 3.568 / 3.562 ms - profiles/r05_ab_step_start.txt; opt-in)
-            early_tick = with_adam and os.environ.get("GFV_EARLY_TICK", "0") == "1"
-            if early_tick:
-                with self.engine.fork():
-                    L.check(lib.gfv_adam_tick_dev(self.adam_state.data_ptr(), self.hyper.data_ptr(), L.stream_ptr()), "adam_tick")
             self.engine.backward(self.P_run, ctx, self.gloss, self.G_run, self.plan)
         if self.padded:
             cmdlist.call(_gather, self.G_run.flat, self._unpad_map, self.flat_g)
         self.losses, self.uvp_node, self.uvp_cell = losses, uvp_node, uvp_cell
         if with_adam:
-            self._adam(ticked=early_tick)
+            self._adam()
 
-    def _adam(self, ticked=False):
-        lib = L.load()
-        fn = lib.gfv_adam_update_dev if ticked else lib.gfv_adam_step_dev
-        L.check(fn(self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.flat_m.data_ptr(), self.flat_v.data_ptr(), self.n_params,
-                   self.adam_state.data_ptr(), self.hyper.data_ptr(), L.stream_ptr()), "adam_step")
+    def _adam(self):
+        # ONE launch (round 6): its last workgroup advances the step count, forms the next step's bias corrections and publishes
+        # the device status word into the pinned mirror `step()` reads (include/gfv.h gfv_adam_step_dev, gfv_status_mirror)
+        L.check(L.load().gfv_adam_step_dev(self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.flat_m.data_ptr(),
+                                           self.flat_v.data_ptr(), self.n_params, self.adam_state.data_ptr(),
+                                           self.hyper.data_ptr(), L.stream_ptr()), "adam_step")
 
     # data-parallel exchange: the flat gradient is reduced in two buckets.  The upper one (last processor + decoder:
     # their backward runs first) goes out on a communication stream as soon as its last gradient kernel is launched and
@@ -360,6 +363,10 @@ class TrainStep:
         """One training iteration.  Returns the (device) scalar loss tensor of this rank's batch.
         `use_graph`: False = eager launches, True = hipGraph replay, "list" = command-list replay."""
         self._check_aliasing()
+        # what the kernels of the steps BEFORE the last one raised in the device status word (a hidden activation outside the
+        # fixed-scale fp16 window, a weight-gradient operand beyond fp16): read from the pinned mirror the fused Adam publishes
+        # into - no synchronisation; the step that overflowed has long finished when its successor is issued
+        L.raise_on_status("TrainStep.step")
         # caller-owned data the plan holds copies of (Dirichlet targets, node / face types, theta_PDE, sigma, uvp_dim, dt_graph):
         # an in-place edit between two steps reaches the plan's tensors here - copied in place, so the pointers a captured step
         # holds stay valid (the reference re-reads graph_node.y / graph_Index on every forward, importer.py:141-154,168).

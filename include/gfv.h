@@ -25,7 +25,15 @@ extern "C" {
 /* 2 (round 4): gfv_rowtile_args_t grew (rc_Wh, rc_bias; round 3 had already turned its former pad fields hidden / flags /
  * product_form into live inputs and appended fin_stats .. dw_in_ld without a bump), gfv_set_f16split became a process-wide
  * default with gfv_set_f16split_thread beside it.  A binding checks gfv_abi_version() AND gfv_struct_size() at load. */
-#define GFV_ABI_VERSION 2
+/* 3 (round 6): buffer-size contracts that moved in round 5 without a bump are now part of the version - (1) ln_partial of a
+ * GFV_IN_LNBWD / GFV_FIN_LNBWD launch and of gfv_trans_mlp_bwd must hold gfv_rowtile_ln_rows(M) = ceil(M / 32) rows (ABI 2 said
+ * gfv_rowtile_tiles(M) = ceil(M / 64): the small-tile backward families fill one row per 32 rows); (2) a fused dw_partial launch
+ * writes blocks 0 .. gfv_rowtile_dw_partials_m(M) - 1 ONLY (ABI 2 callers reduced gfv_rowtile_dw_partials() blocks: the blocks
+ * beyond that count are NOT written and hold whatever the buffer held); (3) the status word has an asynchronous mirror
+ * (gfv_status_mirror / gfv_status_publish) and gfv_adam_step_dev publishes it; Adam is one launch (state[8], gfv_adam_state_init;
+ * gfv_adam_tick_dev / gfv_adam_update_dev removed); (4) new entry points
+ * gfv_prep_stats / gfv_prep_apply, gfv_fvm_fwd_fused / gfv_fvm_bwd_fused, gfv_slice_token_attention_fwd / _bwd. */
+#define GFV_ABI_VERSION 3
 int gfv_abi_version(void);
 /* sizeof of the argument structs as the library was compiled (which: 0 gfv_seg_t, 1 gfv_layer_t, 2 gfv_rowtile_args_t,
  * 3 gfv_wimg_desc_t, 4 gfv_dw_tile_t, 5 gfv_reduce_piece_t, 6 gfv_plan_desc_t, 7 gfv_trans_mlp_t, 8 gfv_trans_mlp_bwd_t): lets a
@@ -180,6 +188,8 @@ typedef struct {
    * g3 / gz2) and the LayerNorm's (dgamma, dbeta).  With dw_partial set the launch accumulates them per workgroup - no float
    * atomics - and leaves  dw_partial[wg * dw_partial_stride + ...] = [dW3 (128 x 128, row n, column k) | db3 (128) | dW2 |
    * db2 | dgamma | dbeta]  (GFV_DW_FUSED_FLOATS floats) for wg < gfv_rowtile_dw_partials_m(M); sum them with gfv_reduce_multi.
+   * BLOCKS AT OR BEYOND gfv_rowtile_dw_partials_m(M) ARE NOT WRITTEN (ABI 3; until round 5 a launch zero-filled all
+   * gfv_rowtile_dw_partials() blocks): reduce exactly gfv_rowtile_dw_partials_m(M) of them.
    * layer[0].save / in_save / ln_partial may then be NULL (nothing else reads g3 / gz2). */
   float* dw_partial;
   int64_t dw_partial_stride;
@@ -328,6 +338,14 @@ enum { GFV_FLAG_DW_RANGE = 1,
        GFV_FLAG_CHAIN_RANGE = 2 };
 /* device status word: OR of GFV_FLAG_* raised by kernels since the last call; reads (synchronising) and clears it */
 int gfv_status_flags(int32_t* flags_out);
+/* The same word WITHOUT a synchronisation (round 6): *host_word = a pinned, device-mapped int32 the library owns (allocated at the
+ * first call, one per process).  gfv_status_publish enqueues a one-thread kernel on `stream` that copies a non-zero status word
+ * into it (the device word stays raised until gfv_status_flags clears it); gfv_adam_step_dev does the same from inside the Adam
+ * launch once the mirror exists.  A host loop reads *host_word after the NEXT step was issued (the previous step's
+ * kernels have long finished: no wait), and on a non-zero value calls gfv_status_flags (clears the device word), zeroes
+ * *host_word and raises.  gfv.trainer.TrainStep.step and FVMmodel.importer.NNmodel.forward do exactly that (FloatingPointError). */
+int gfv_status_mirror(int32_t** host_word);
+int gfv_status_publish(void* stream);
 int gfv_dw_slabs(int32_t M, int32_t ntiles, int32_t* rows_per_slab);
 size_t gfv_dw_multi_workspace_floats(int32_t M, int32_t ntiles, int64_t block_floats);
 int gfv_dw_multi(const gfv_dw_tile_t* tiles, int32_t ntiles, int32_t M, int64_t block_floats, float* workspace,
@@ -518,17 +536,17 @@ int gfv_edge_attr(const float* x, int32_t ldx, const float* pos, const int32_t* 
                   float* out15, int32_t E, void* stream);
 /* Fused Adam on the flat buffers (torch.optim.Adam defaults; pre_train_Adam.py:115,189-191).  Step counter and
  * hyper-parameters are DEVICE resident so that a captured hipGraph follows learning-rate changes:
- *   state[4] = {t, lr / (1 - beta1^t), sqrt(1 - beta2^t), reserved}  (t is advanced by the call; the bias corrections
- *              are formed in double, as torch's host code does)
- *   hyper[8] = {lr, beta1, beta2, eps, grad_scale (1 / world size), 0, 0, 0} */
+ *   state[8] = {t = completed steps, bc1_hi, bc1_lo, sqrt(1 - beta2^(t+1)), arrival counter (int32, 0 between launches), 0, 0, 0}
+ *              with bc1 = 1 - beta1^(t+1) as a (hi, lo) float pair: the bias corrections of the NEXT step, formed in double as
+ *              torch's host code does.  gfv_adam_state_init writes them for a given t (once, and again after a checkpoint
+ *              load or a change of the betas); every gfv_adam_step_dev launch then applies them with the lr of hyper[0] as it
+ *              is at that moment and - its last workgroup to finish - advances t and forms the following step's (ABI 3: ONE launch
+ *              per step; ABI 2 had state[4] and a tick launch in front, gfv_adam_tick_dev / gfv_adam_update_dev: removed)
+ *   hyper[8] = {lr, beta1, beta2, eps, grad_scale (1 / world size), w_cont, w_mom, w_press}
+ * The same launch publishes the status word once gfv_status_mirror has been called. */
+int gfv_adam_state_init(float* state, const float* hyper, float steps_done, void* stream);
 int gfv_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, float* state, const float* hyper,
                       void* stream);
-/* its two halves as launches of their own: gfv_adam_tick_dev advances t and forms the bias corrections (it needs neither gradients nor
- * parameters: a caller may issue it early, on another stream, as long as it is ordered in front of the update), gfv_adam_update_dev
- * applies them.  tick + update == gfv_adam_step_dev. */
-int gfv_adam_tick_dev(float* state, const float* hyper, void* stream);
-int gfv_adam_update_dev(float* p, const float* g, float* m, float* v, int64_t n, const float* state, const float* hyper,
-                        void* stream);
 int gfv_train_loss(const float* losses, int32_t B, float w_cont, float w_mom, float w_press, float* loss, float* gloss,
                    void* stream);
 /* same, weights read from the device: hyper[5..7] = {w_cont, w_mom, w_press} of the buffer gfv_adam_step_dev takes */
@@ -671,7 +689,7 @@ typedef struct {
   float* g_z;            /* [M,256] out */
   float* g_fx1;          /* [M,128] out */
   float* g_out_x;        /* [M,128] out */
-  float* ln_partial;     /* optional [gfv_rowtile_tiles(M), 256] */
+  float* ln_partial;     /* optional [gfv_rowtile_ln_rows(M), 256] (PROVIDE one row per 32 rows; gfv_trans_mlp_ln_rows(M) of them are filled) */
   float* gscale;         /* optional [ceil(M / 128) * 8] */
   int32_t M, reserved;
 } gfv_trans_mlp_bwd_t;

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(handle, name), f"{name} declared in include/gfv.h but not exported by libgfv.so"
     assert declared == set(lib.declared_symbols()), declared ^ set(lib.declared_symbols())
-    assert handle.gfv_abi_version() == 2
+    assert handle.gfv_abi_version() == 3
 
 
 def test_ctypes_structs_match_header_layout():
