@@ -668,6 +668,281 @@ __global__ __launch_bounds__(256) void node_bwd_kernel(const NodeBwdArgs A) {
 }
 
 
+// ==== round 6: fewer launches in the finite-volume section (each of these kernels lasted 3 - 10 us, most of it the ~4.5 us a
+// launch of any size costs: profiles/r05_latency_floor.txt) ==========================================================
+//
+// (1) forward tail = graph_loss + train_loss + cell_to_node in ONE launch of 1024-thread workgroups: workgroups [0, B) form the
+// residual norms of graph b exactly as graph_loss_kernel does; the one of them that finishes LAST also forms the training loss
+// and its gradient with train_loss_kernel's arithmetic (same strided partial sums, same fold); workgroups >= B smooth 1024
+// nodes each (cell_to_node_kernel's arithmetic).  The three have no data dependence on each other except losses -> train loss.
+__global__ __launch_bounds__(1024) void fvm_tail_kernel(const float* __restrict__ cres, const int* __restrict__ gcell_ptr,
+                                                       const float* __restrict__ theta, const float* __restrict__ sigma,
+                                                       float* __restrict__ sums, float* __restrict__ losses, int B,
+                                                       const float* __restrict__ hyper, float* __restrict__ loss,
+                                                       float* __restrict__ gloss, int* __restrict__ counter,
+                                                       const float* __restrict__ phic, const int* __restrict__ nrow,
+                                                       const int* __restrict__ ncell, const float* __restrict__ pos,
+                                                       const float* __restrict__ centroid, const int* __restrict__ node_type,
+                                                       const float* __restrict__ y, const int* __restrict__ nbatch,
+                                                       const float* __restrict__ uvp_dim, const float* __restrict__ phi, int smooth,
+                                                       float* __restrict__ out, int N) {
+  __shared__ float red[4][1024];
+  __shared__ int last;
+  const int tid = threadIdx.x;
+  if ((int)blockIdx.x >= B) {
+    const int i = ((int)blockIdx.x - B) * 1024 + tid;
+    if (i >= N) return;
+    float u, v, p;
+    if (smooth & 1) {
+      const float px = pos[2 * i], py = pos[2 * i + 1];
+      float su = 0.f, sv = 0.f, sp = 0.f, sw = 0.f;
+      for (int k = nrow[i]; k < nrow[i + 1]; ++k) {
+        const int c = ncell[k];
+        const float dx = px - centroid[2 * c], dy = py - centroid[2 * c + 1];
+        const float w = 1.0f / sqrtf(dx * dx + dy * dy);
+        su += phic[(size_t)c * 8] * w; sv += phic[(size_t)c * 8 + 1] * w; sp += phic[(size_t)c * 8 + 2] * w; sw += w;
+      }
+      u = su / sw; v = sv / sw; p = sp / sw;
+    } else {
+      u = phi[(size_t)i * 8]; v = phi[(size_t)i * 8 + 1]; p = phi[(size_t)i * 8 + 2];
+    }
+    if (smooth & 2) {
+      out[3 * i] = u; out[3 * i + 1] = v; out[3 * i + 2] = p;
+      return;
+    }
+    const int nt = node_type[i];
+    if (nt == NT_WALL || nt == NT_INFLOW || nt == NT_PRESS || nt == NT_INWALL) { u = y[2 * i]; v = y[2 * i + 1]; }
+    if (nt == NT_PRESS) p = 0.f;
+    const int b = nbatch[i];
+    out[3 * i] = u * uvp_dim[3 * b] * sigma[3 * b];
+    out[3 * i + 1] = v * uvp_dim[3 * b + 1] * sigma[3 * b + 1];
+    out[3 * i + 2] = p * uvp_dim[3 * b + 2] * sigma[3 * b + 2];
+    return;
+  }
+  const int b = blockIdx.x;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  const int c_end = gcell_ptr[b + 1];
+  int c = gcell_ptr[b] + tid;
+  for (; c + 7 * 1024 < c_end; c += 8 * 1024) {
+    float4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(cres + (size_t)(c + 1024 * u) * 4);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { s0 += v[u].x * v[u].x; s1 += v[u].y * v[u].y; s2 += v[u].z * v[u].z; s3 += v[u].w; }
+  }
+  for (; c < c_end; c += 1024) {
+    const float4 v = *reinterpret_cast<const float4*>(cres + (size_t)c * 4);
+    s0 += v.x * v.x; s1 += v.y * v.y; s2 += v.z * v.z; s3 += v.w;
+  }
+  red[0][tid] = s0; red[1][tid] = s1; red[2][tid] = s2; red[3][tid] = s3;
+  __syncthreads();
+  for (int o = 512; o >= 1; o >>= 1) {
+    if (tid < o) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) red[j][tid] += red[j][tid + o];
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    const float S0 = red[0][0], S1 = red[1][0], S2 = red[2][0], S3 = red[3][0];
+    sums[4 * b] = S0; sums[4 * b + 1] = S1; sums[4 * b + 2] = S2; sums[4 * b + 3] = S3;
+    losses[4 * b] = sqrtf(S0) * theta[(size_t)b * 9 + 1];
+    losses[4 * b + 1] = sqrtf(S1) * sigma[(size_t)b * 3];
+    losses[4 * b + 2] = sqrtf(S2) * sigma[(size_t)b * 3 + 1];
+    losses[4 * b + 3] = sqrtf(S3);
+    last = 0;
+    if (hyper) {
+      __threadfence();
+      last = atomicAdd(counter, 1) == B - 1;
+    }
+  }
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  // train_loss_kernel (csrc/misc.hip) by the first 64 threads of the workgroup that saw every graph's losses written
+  const float wc = hyper[5], wm = hyper[6], wp = hyper[7];
+  float s = 0.f;
+  if (tid < 64) {
+    for (int g = tid; g < B; g += 64) {
+      const float l0 = __hip_atomic_load(losses + 4 * g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const float l1 = __hip_atomic_load(losses + 4 * g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const float l2 = __hip_atomic_load(losses + 4 * g + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const float l3 = __hip_atomic_load(losses + 4 * g + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const float tot = wp * l3 + wc * l0 + wm * l1 + wm * l2;
+      s += logf(tot);
+      const float inv = 1.0f / (tot * (float)B);
+      gloss[4 * g] = wc * inv; gloss[4 * g + 1] = wm * inv; gloss[4 * g + 2] = wm * inv; gloss[4 * g + 3] = wp * inv;
+    }
+    red[0][tid] = s;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    float a = 0.f;
+    for (int i = 0; i < 64; ++i) a += red[0][i];
+    *loss = a / (float)B;
+    *counter = 0;
+  }
+}
+
+// (2) backward, conserved form: three launches instead of six.
+// gc of a cell = cell_bwd_kernel's expressions, formed where it is used instead of being written by a launch of its own
+__device__ __forceinline__ float4 fvm_gc(const float* __restrict__ cres, const float* __restrict__ sums, const float* __restrict__ gloss,
+                                         const float* __restrict__ theta, const float* __restrict__ sigma, int c, int b) {
+  const float4 r = *reinterpret_cast<const float4*>(cres + (size_t)c * 4);
+  const float S0 = sums[4 * b], S1 = sums[4 * b + 1], S2 = sums[4 * b + 2], S3 = sums[4 * b + 3];
+  const float g0 = S0 > 0.f ? gloss[4 * b] * theta[(size_t)b * 9 + 1] * r.x / sqrtf(S0) : 0.f;
+  const float g1 = S1 > 0.f ? gloss[4 * b + 1] * sigma[(size_t)b * 3] * r.y / sqrtf(S1) : 0.f;
+  const float g2 = S2 > 0.f ? gloss[4 * b + 2] * sigma[(size_t)b * 3 + 1] * r.z / sqrtf(S2) : 0.f;
+  const float g3 = S3 > 0.f ? gloss[4 * b + 3] / sqrtf(S3) : 0.f;
+  return make_float4(g0, g1, g2, g3);
+}
+
+// face_bwd_kernel (mode 0) with gc formed on the fly
+__global__ __launch_bounds__(256) void face_bwd2_kernel(const float* __restrict__ Ff, const float* __restrict__ cres,
+                                                        const float* __restrict__ sums, const float* __restrict__ gloss,
+                                                        const float* __restrict__ sigma, const int* __restrict__ frow,
+                                                        const int* __restrict__ fk, const int* __restrict__ kcell,
+                                                        const float* __restrict__ kS, const int* __restrict__ ftype,
+                                                        const int* __restrict__ cbatch, const float* __restrict__ theta,
+                                                        float* __restrict__ gFf, int E) {
+  const int f = blockIdx.x * 256 + threadIdx.x;
+  if (f >= E) return;
+  const float4* fp = reinterpret_cast<const float4*>(Ff + (size_t)f * 16);
+  const float4 f0 = fp[0], f1 = fp[1], f2 = fp[2];
+  const float p = f0.z, uh = f0.w, vh = f1.x;
+  const int ft = ftype[f];
+  float g[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) g[j] = 0.f;
+  for (int q = frow[f]; q < frow[f + 1]; ++q) {
+    const int k = fk[q];
+    const int c = kcell[k];
+    const int b = cbatch[c];
+    const float* th = theta + (size_t)b * 9;
+    const float th2 = th[2], th3 = th[3], th4 = th[4];
+    const float Sx = kS[2 * k], Sy = kS[2 * k + 1];
+    const float4 gcv = fvm_gc(cres, sums, gloss, theta, sigma, c, b);
+    const float gd = gcv.x, gx = gcv.y, gy = gcv.z;
+    g[0] += gd * Sx;
+    g[1] += gd * Sy;
+    const float uS = uh * Sx + vh * Sy, gU = gx * uh + gy * vh, gS = gx * Sx + gy * Sy;
+    g[3] += th2 * (gx * uS + gU * Sx);
+    g[4] += th2 * (gy * uS + gU * Sy);
+    g[2] += th3 * gS;
+    g[5 + 6] -= th4 * gx * Sx;
+    g[5 + 7] -= th4 * gx * Sy;
+    g[5 + 8] -= th4 * gy * Sx;
+    g[5 + 9] -= th4 * gy * Sy;
+    if (ft == NT_OUTFLOW) {
+      const float l0 = th4 * (f1.y * Sx + f1.z * Sy) - p * Sx;
+      const float l1 = th4 * (f1.w * Sx + f2.x * Sy) - p * Sy;
+      const float gl0 = gcv.w * l0, gl1 = gcv.w * l1;
+      g[5 + 0] += th4 * gl0 * Sx;
+      g[5 + 1] += th4 * gl0 * Sy;
+      g[5 + 2] += th4 * gl1 * Sx;
+      g[5 + 3] += th4 * gl1 * Sy;
+      g[2] -= gl0 * Sx + gl1 * Sy;
+    }
+  }
+  if (ft == NT_INFLOW || ft == NT_WALL) { g[0] = 0.f; g[1] = 0.f; g[3] = 0.f; g[4] = 0.f; }
+  float4* o = reinterpret_cast<float4*>(gFf + (size_t)f * 16);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) o[j] = make_float4(g[4 * j], g[4 * j + 1], g[4 * j + 2], g[4 * j + 3]);
+}
+
+// node_bwd_kernel (mode 0) + wlsq_bwd_solve_kernel: lane (node i, channel c), 8 lanes per node.  Channel c's share of the node
+// adjoint - g_phi[i,c] and g_grad[i,c,0:2] - is a sum over the node's faces and cells that involves channel c only, formed in
+// node_bwd_kernel's order; the lane then solves its own transposed system: g_grad never goes to memory.
+template <int M>
+__global__ __launch_bounds__(256) void node_bwd_solve_kernel(const NodeBwdArgs A, const float* __restrict__ cres,
+                                                             const float* __restrict__ sums, const float* __restrict__ gloss,
+                                                             const float* __restrict__ sigma, const float* __restrict__ An,
+                                                             const float* __restrict__ rn, float* __restrict__ grhs) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  const int i = t >> 3, c = t & 7;
+  if (i >= A.N) return;
+  lu_t b[M];
+#pragma unroll
+  for (int j = 0; j < M; ++j) b[j] = 0.0;
+  float gp = 0.f;
+  if (c < 5) {
+    const float px = A.pos[2 * i], py = A.pos[2 * i + 1];
+    float g0 = 0.f, g1 = 0.f;
+    for (int k = A.nfrow[i]; k < A.nfrow[i + 1]; ++k) {
+      const int f = A.nfcol2[k] >> 1;
+      const float rx = A.fpos[2 * f] - px, ry = A.fpos[2 * f + 1] - py;
+      const float* gf = A.gFf + (size_t)f * 16;
+      const float h = 0.5f * gf[c];
+      gp += h;
+      g0 += h * rx + 0.5f * gf[5 + 2 * c];
+      g1 += h * ry + 0.5f * gf[5 + 2 * c + 1];
+    }
+    if (c < 2) {
+      for (int k = A.nrow[i]; k < A.nrow[i + 1]; ++k) {
+        const int cc = A.ncell[k];
+        const int bb = A.cbatch[cc];
+        const float cnt = fmaxf((float)(A.crow[cc + 1] - A.crow[cc]), 1.f);
+        const float coef = A.theta[(size_t)bb * 9] * A.area[cc] / A.dt[bb] / cnt;
+        const float4 gcv = fvm_gc(cres, sums, gloss, A.theta, sigma, cc, bb);
+        const float gxy = (c == 0 ? gcv.y : gcv.z) * coef;
+        const float rx = A.centroid[2 * cc] - px, ry = A.centroid[2 * cc + 1] - py;
+        gp += gxy;
+        g0 += gxy * rx;
+        g1 += gxy * ry;
+      }
+    }
+    b[0] = (lu_t)g0;
+    b[1] = (lu_t)g1;
+    LU<M> m;
+    load_An(An, rn, i, m);
+    lu_factor(m);
+    lu_solve_t(m, b);
+#pragma unroll
+    for (int j = 0; j < M; ++j) b[j] = b[j] / (lu_t)rn[(size_t)i * M + j];
+  }
+  A.gphi[(size_t)i * 8 + c] = gp;
+#pragma unroll
+  for (int j = 0; j < M; ++j) grhs[((size_t)i * 8 + c) * M + j] = (float)b[j];
+}
+
+// wlsq_bwd_gather_kernel + phi_bwd_kernel: the eight lanes of node j finish g_phi[j, 0:5], lanes 0..2 turn it into the gradient
+// of the decoder output (g_phi is not written back)
+template <int M>
+__global__ __launch_bounds__(256) void wlsq_gather_phi_bwd_kernel(const float* __restrict__ grhs, const int* __restrict__ rowptr_o,
+                                                                  const int* __restrict__ inn, const float* __restrict__ Bo,
+                                                                  const float* __restrict__ sumB, const float* __restrict__ gphi,
+                                                                  const float* __restrict__ dec, const int* __restrict__ node_type,
+                                                                  float* __restrict__ gdec, int N, int mode) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  const int j = t >> 3, c = t & 7;
+  float v = 0.f;
+  if (j < N && c < 5) {
+    float s = 0.f;
+    const int beg = rowptr_o[j], end = rowptr_o[j + 1];
+    int k = beg;
+    for (; k + 4 <= end; k += 4) {
+      float tt[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) tt[u] = dotM<M>(Bo + (size_t)(k + u) * M, grhs + ((size_t)inn[k + u] * 8 + c) * M);
+      s += tt[0]; s += tt[1]; s += tt[2]; s += tt[3];
+    }
+    for (; k < end; ++k) s += dotM<M>(Bo + (size_t)k * M, grhs + ((size_t)inn[k] * 8 + c) * M);
+    s -= dotM<M>(sumB + (size_t)j * M, grhs + ((size_t)j * 8 + c) * M);
+    v = gphi[(size_t)j * 8 + c] + s;
+  }
+  // (every lane of the wave takes part in the shuffles; 8-lane groups are aligned inside the 64-lane wave)
+  const int lane = threadIdx.x & 63, base = lane & ~7;
+  const float v3 = __shfl(v, base + 3), v4 = __shfl(v, base + 4);
+  if (j >= N || c >= 3) return;
+  const float ch = (mode == 0) ? 0.f : (mode == 1 ? 1.f : 0.5f);
+  float g = c == 0 ? v + ch * v3 : (c == 1 ? v + ch * v4 : v);
+  const int nt = node_type[j];
+  if (c < 2 && (nt == NT_WALL || nt == NT_INFLOW || nt == NT_PRESS || nt == NT_INWALL)) g = 0.f;
+  if (c == 2 && nt == NT_PRESS) g = 0.f;
+  const float th = tanhf(dec[3 * j + c] / 10.f);
+  gdec[3 * j + c] = g * (1.f - th * th);
+}
+
 // ---- WLSQ moment matrices on the device (row f2; Load_mesh.py:247-272 calc_WLSQ_A_B_normal_matrix -> FVgrad.py:183-232
 // compute_normal_matrix -> FVorder.py:7-86 moments_order), float64 like the host preprocessing -------------------------
 // One thread per receiving node walks its directed stencil entries in CSR order (fixed order: deterministic):
@@ -964,3 +1239,36 @@ extern "C" int gfv_wlsq_moments(const double* pos, const int32_t* rowptr, const 
   GFV_CHECK_LAUNCH();
   return GFV_OK;
 }
+
+// ---- round 6: fused forward tail / three-launch backward (kernels above) ----------------------------------------------
+extern "C" int gfv_fvm_fwd_tail(const gfv_fvm_mesh_t* m, const float* cres, const float* phic, const float* phi, float* sums,
+                                float* losses, float* uvp_node, const float* hyper, float* loss, float* gloss, int32_t* counter,
+                                void* stream) {
+  if (!m || m->B <= 0 || !cres || !sums || !losses) return GFV_ERR_ARG;
+  if (hyper && (!loss || !gloss || !counter)) return GFV_ERR_ARG;
+  if (uvp_node && (!phic || !phi)) return GFV_ERR_ARG;
+  GfvProfScope ps_(GFV_K_FVM, 0, 16.0 * gfv_prof_size_Sigma() / 3.0 + (uvp_node ? 4.0 * gfv_prof_size_Sigma() + 68.0 * m->N : 0.0), stream);
+  const int nodes = uvp_node ? m->N : 0;
+  GFV_LAUNCH(fvm_tail_kernel, dim3(m->B + gfv_div_up(nodes, 1024)), dim3(1024), 0, (hipStream_t)stream, cres, m->gcell_ptr, m->theta,
+             m->sigma, sums, losses, m->B, hyper, loss, gloss, counter, phic, m->nrow, m->ncell, m->pos, m->centroid, m->node_type,
+             m->y, m->batch, m->uvp_dim, phi, m->smooth, uvp_node, nodes);
+  GFV_CHECK_LAUNCH();
+  return GFV_OK;
+}
+
+extern "C" int gfv_fvm_bwd_fused(const gfv_fvm_mesh_t* m, const float* cres, const float* sums, const float* gloss, const float* Ff,
+                                 const float* dec, float* gFf_ws, float* gphi_ws, float* grhs_ws, float* gdec, void* stream) {
+  if (!m || !cres || !sums || !gloss || !Ff || !dec || !gFf_ws || !gphi_ws || !grhs_ws || !gdec) return GFV_ERR_ARG;
+  const int N = m->N, E = m->E, terms = m->terms;
+  GfvProfScope ps_(GFV_K_FVM, 0, 40.0 * gfv_prof_size_Sigma() + 32.0 * m->C + 140.0 * E + 120.0 * N + (4.0 + 4.0 * terms) * gfv_prof_size_S()
+                                 + (64.0 + 4.0 * terms * terms + 4.0 * terms + 2 * 32.0 * terms + 32.0) * N + 60.0 * N, stream);
+  LAUNCH1D(face_bwd2_kernel, E, stream, Ff, cres, sums, gloss, m->sigma, m->frow, m->fk, m->kcell, m->kS, m->ftype, m->cbatch, m->theta,
+           gFf_ws, E);
+  NodeBwdArgs a{gFf_ws, nullptr, m->nfrow, m->nfcol2, m->nrow, m->ncell, m->pos, m->fpos, m->centroid, m->crow, m->area, m->cbatch, m->theta,
+                m->dt, gphi_ws, nullptr, N, 0, nullptr, nullptr};
+  WLSQ_DISPATCH(terms, LAUNCH1D(node_bwd_solve_kernel<MM>, (long)N * 8, stream, a, cres, sums, gloss, m->sigma, m->An, m->rn, grhs_ws));
+  WLSQ_DISPATCH(terms, LAUNCH1D(wlsq_gather_phi_bwd_kernel<MM>, (long)N * 8, stream, grhs_ws, m->xo_rowptr, m->xo_in, m->xo_B, m->sumB,
+                                gphi_ws, dec, m->node_type, gdec, N, m->mode));
+  return GFV_OK;
+}
+

@@ -215,6 +215,137 @@ __global__ __launch_bounds__(256) void edge_attr_kernel(const float* __restrict_
   }
 }
 
+// ---- round 6: the input preparation as TWO launches (was: state restore copy, graph_norm_partial, graph_norm_final,
+// normalizer_finalize, node_prep, edge_attr - six launches of 3 - 6 us each at the very start of the step) -----------------
+//
+// prep_stats_kernel: the per-graph statistics exactly as graph_norm_partial + graph_norm_final form them (NORM_NB workgroups per
+// graph, double partial sums, folded k = 0 .. NORM_NB-1 in order) - the fold is done by the workgroup of the graph that arrives
+// LAST (integer counter per graph; the order of the fold does not depend on who does it), and - `mean_std` given - that
+// workgroup of graph 0 also derives the Normalizer's (mean, std) from its running buffers (normalizer_finalize without
+// accumulation: an accumulating step updates the buffers first, gfv_normalizer_update).
+// With `x_raw` the launch also leaves a copy of the un-normalised rows (the drop-in path normalises graph_node.x IN PLACE,
+// importer.py:123-130, and the edge features need both end nodes' normalised rows: the second launch reads the raw copy).
+__global__ __launch_bounds__(256) void prep_stats_kernel(const float* __restrict__ x, int ldx, const int* __restrict__ gnode_ptr,
+                                                         double* __restrict__ ws, int* __restrict__ counters,
+                                                         float* __restrict__ stats, float* __restrict__ x_raw,
+                                                         const float* acc_count, const float* acc_sum, const float* acc_sq,
+                                                         float* __restrict__ mean_std) {
+  __shared__ double red[4][6];
+  __shared__ int last;
+  const int b = blockIdx.y, blk = blockIdx.x, tid = threadIdx.x;
+  const int beg = gnode_ptr[b], end = gnode_ptr[b + 1];
+  double s[3] = {0.0, 0.0, 0.0}, q[3] = {0.0, 0.0, 0.0};
+  for (int i = beg + blk * 256 + tid; i < end; i += NORM_NB * 256) {
+    const float* r = x + (size_t)i * ldx;
+    if (x_raw) {
+      float* o = x_raw + (size_t)i * 12;
+#pragma unroll
+      for (int c = 0; c < 12; ++c) o[c] = r[c];
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const double v = (double)r[c];
+      s[c] += v;
+      q[c] += v * v;
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+      s[c] += __shfl_xor(s[c], o);
+      q[c] += __shfl_xor(q[c], o);
+    }
+  }
+  if ((tid & 63) == 0) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { red[tid >> 6][c] = s[c]; red[tid >> 6][3 + c] = q[c]; }
+  }
+  __syncthreads();
+  if (tid < 6) ws[((size_t)b * NORM_NB + blk) * 6 + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+  __syncthreads();
+  if (tid == 0) {
+    __threadfence();
+    last = atomicAdd(counters + b, 1) == NORM_NB - 1;
+  }
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  if (tid < 3) {
+    const double cnt = fmax((double)(end - beg), 1.0);
+    double ss = 0.0, qq = 0.0;
+    for (int k = 0; k < NORM_NB; ++k) {
+      ss += __hip_atomic_load(ws + ((size_t)b * NORM_NB + k) * 6 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      qq += __hip_atomic_load(ws + ((size_t)b * NORM_NB + k) * 6 + 3 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    const double mean = ss / cnt, var = fmax(qq / cnt - mean * mean, 0.0);
+    stats[6 * b + tid] = (float)mean;
+    stats[6 * b + 3 + tid] = (float)sqrt(var);
+  }
+  if (tid == 0) counters[b] = 0;   // (reusable by the next launch)
+  if (b == 0 && mean_std && tid >= 64 && tid < 64 + 9) {
+    // normalizer_finalize_kernel with accumulate = 0 (normalization.py:72-85)
+    const int c = tid - 64;
+    const float safe = fmaxf(*acc_count, 1.0f);
+    const float mean = acc_sum[c] / safe;
+    float sd = sqrtf(acc_sq[c] / safe - mean * mean);
+    if (sd < 1e-8f || !(sd == sd)) sd = (sd == sd) ? 1.0f : sd;
+    mean_std[c] = mean;
+    mean_std[9 + c] = sd;
+  }
+}
+
+// prep_apply_kernel: node_prep + edge_attr in one launch.  Threads [0, N) normalise node i (raw row in, normalised row out,
+// uv_old), threads [N, N + E) form edge e's relative features from the RAW rows of its two end nodes, normalising them on the
+// way with the very expressions node_prep uses - the same fp32 operations on the same inputs, so the differences equal those
+// of the stored normalised rows bit for bit.  x_raw != x_out (the raw rows must survive the launch: TrainStep's persistent
+// backup, or the copy prep_stats left).
+__device__ __forceinline__ void prep_norm_row(const float* __restrict__ xr, int b, const float* __restrict__ stats,
+                                              const float* __restrict__ mean_std, int norm_global, float (&v)[12]) {
+#pragma unroll
+  for (int c = 0; c < 3; ++c) v[c] = (xr[c] - stats[6 * b + c]) / (stats[6 * b + 3 + c] + 1e-8f);
+#pragma unroll
+  for (int c = 0; c < 9; ++c) v[3 + c] = norm_global ? (xr[3 + c] - mean_std[c]) / mean_std[9 + c] : xr[3 + c];
+}
+__global__ __launch_bounds__(256) void prep_apply_kernel(const float* __restrict__ x_raw, float* __restrict__ x_out,
+                                                         const int* __restrict__ batch, const float* __restrict__ stats,
+                                                         const float* __restrict__ uvp_dim, const float* __restrict__ mean_std,
+                                                         int norm_global, float* __restrict__ uv_old, int N,
+                                                         const float* __restrict__ pos, const int* __restrict__ es,
+                                                         const int* __restrict__ er, float* __restrict__ out16,
+                                                         float* __restrict__ out15, int E) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t < N) {
+    const int b = batch[t];
+    const float* xr = x_raw + (size_t)t * 12;
+    uv_old[2 * t] = xr[0] / uvp_dim[3 * b];
+    uv_old[2 * t + 1] = xr[1] / uvp_dim[3 * b + 1];
+    float v[12];
+    prep_norm_row(xr, b, stats, mean_std, norm_global, v);
+    float4* o = reinterpret_cast<float4*>(x_out + (size_t)t * 12);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) o[j] = make_float4(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
+    return;
+  }
+  const int e = t - N;
+  if (e >= E) return;
+  const int s = es[e], r = er[e];
+  float a[12], c2[12], v[16];
+  prep_norm_row(x_raw + (size_t)s * 12, batch[s], stats, mean_std, norm_global, a);
+  prep_norm_row(x_raw + (size_t)r * 12, batch[r], stats, mean_std, norm_global, c2);
+#pragma unroll
+  for (int c = 0; c < 12; ++c) v[c] = a[c] - c2[c];
+  const float dx = pos[2 * s] - pos[2 * r], dy = pos[2 * s + 1] - pos[2 * r + 1];
+  v[12] = dx; v[13] = dy; v[14] = sqrtf(dx * dx + dy * dy); v[15] = 0.f;
+  float4* o = reinterpret_cast<float4*>(out16 + (size_t)e * 16);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) o[j] = make_float4(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
+  if (out15) {
+#pragma unroll
+    for (int c = 0; c < 15; ++c) out15[(size_t)e * 15 + c] = v[c];
+  }
+}
+
 // Adam (torch.optim.Adam defaults, pre_train_Adam.py:115): the step counter and the hyper-parameters live in device
 // memory, so a captured hipGraph follows lr changes (lr_scheduler.step() every epoch in both reference drivers).
 // state[8] = {t = completed steps, bc1_hi, bc1_lo, sqrt(1 - b2^(t+1)), arrival counter (int), 0, 0, 0}: the bias corrections OF
@@ -239,13 +370,14 @@ __global__ void adam_state_init_kernel(float* state, const float* __restrict__ h
   state[5] = state[6] = state[7] = 0.f;
 }
 
-__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+constexpr int ADAM_TPB = 512, ADAM_MAX_WGS = 512;   // (few workgroups: one same-address atomic each at the end)
+__global__ __launch_bounds__(ADAM_TPB) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, long n, float* state,
                                                    const float* __restrict__ hyper, const int* status_dev, int* status_host) {
   const float step_size = (float)((double)hyper[0] / ((double)state[1] + (double)state[2])), bc2_sqrt = state[3];
   const float t_done = state[0];
   const float b1 = hyper[1], b2 = hyper[2], eps = hyper[3], grad_scale = hyper[4];
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+  for (long i = (long)blockIdx.x * ADAM_TPB + threadIdx.x; i < n; i += (long)gridDim.x * ADAM_TPB) {
     const float gi = g[i] * grad_scale;
     const float mi = m[i] * b1 + (1.0f - b1) * gi;
     const float vi = v[i] * b2 + (1.0f - b2) * gi * gi;
@@ -253,11 +385,13 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     const float denom = sqrtf(vi) / bc2_sqrt + eps;
     p[i] = p[i] - step_size * (mi / denom);
   }
-  __syncthreads();   // every thread of this workgroup has read the state
+  __syncthreads();   // every thread of this workgroup has read the state (the values were consumed by the loop above)
   if (threadIdx.x == 0) {
     int* counter = reinterpret_cast<int*>(state) + 4;
-    __threadfence();
-    if (atomicAdd(counter, 1) == (int)gridDim.x - 1) {
+    // RELAXED, no fence: the last arriver needs no DATA of the others, only the fact that they are past their reads of `state`.
+    // (A release fence here writes back the L2's dirty lines - the 14 MB this launch has just written - once per workgroup: the
+    // first form of this kernel took 115 us instead of 8.)
+    if (__hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1) {
       *counter = 0;
       adam_corrections(state, hyper, t_done + 1.0f);
       if (status_host) {
@@ -359,6 +493,38 @@ extern "C" int gfv_edge_attr(const float* x, int32_t ldx, const float* pos, cons
   return GFV_OK;
 }
 
+extern "C" size_t gfv_prep_workspace_bytes(int32_t B) {
+  return (size_t)(B > 0 ? B : 0) * (NORM_NB * 6 * sizeof(double) + 2 * sizeof(double));   // partial sums + one counter per graph (padded)
+}
+extern "C" int gfv_prep_stats(const float* x, int32_t ldx, const int32_t* gnode_ptr, int32_t B, float* stats, void* workspace,
+                              float* x_raw, const float* acc_count, const float* acc_sum, const float* acc_sq, float* mean_std,
+                              void* stream) {
+  GfvProfScope ps_(GFV_K_MISC, 0, 0.0, stream);
+  if (B <= 0) return GFV_OK;
+  if (!x || !gnode_ptr || !stats || !workspace || (reinterpret_cast<size_t>(workspace) & 7) || ldx < 12) return GFV_ERR_ARG;
+  if (mean_std && (!acc_count || !acc_sum || !acc_sq)) return GFV_ERR_ARG;
+  double* ws = reinterpret_cast<double*>(workspace);
+  int* counters = reinterpret_cast<int*>(ws + (size_t)B * NORM_NB * 6);
+  GFV_LAUNCH(prep_stats_kernel, dim3(NORM_NB, B), dim3(256), 0, (hipStream_t)stream, x, ldx, gnode_ptr, ws, counters, stats, x_raw,
+             acc_count, acc_sum, acc_sq, mean_std);
+  GFV_CHECK_LAUNCH();
+  return GFV_OK;
+}
+extern "C" int gfv_prep_apply(const float* x_raw, float* x_out, const int32_t* batch, const float* stats, const float* uvp_dim,
+                              const float* mean_std, int32_t norm_global, float* uv_old, int32_t N, const float* pos,
+                              const int32_t* es, const int32_t* er, float* out16, float* out15, int32_t E, void* stream) {
+  GfvProfScope ps_(GFV_K_MISC, 0, (96.0 + 4.0 + 8.0) * N + (8.0 + 64.0 + (out15 ? 60.0 : 0.0)) * E, stream);
+  if (N <= 0) return GFV_OK;
+  if (!x_raw || !x_out || x_raw == x_out || (reinterpret_cast<size_t>(x_out) & 15) || !batch || !stats || !uvp_dim || !uv_old ||
+      (norm_global && !mean_std) || (E > 0 && (!pos || !es || !er || !out16)))
+    return GFV_ERR_ARG;
+  const long total = (long)N + (E > 0 ? E : 0);
+  GFV_LAUNCH(prep_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x_raw, x_out, batch, stats,
+             uvp_dim, mean_std, norm_global, uv_old, N, pos, es, er, out16, out15, E > 0 ? E : 0);
+  GFV_CHECK_LAUNCH();
+  return GFV_OK;
+}
+
 int* gfv_internal_status_ptr();        // dw.hip
 int32_t* gfv_internal_status_mirror();   // dw.hip: nullptr until a host asked for the mirror
 
@@ -375,7 +541,9 @@ extern "C" int gfv_adam_step_dev(float* p, const float* g, float* m, float* v, i
   if (n <= 0) return GFV_OK;
   if (!state || !hyper) return GFV_ERR_ARG;
   int32_t* mirror = gfv_internal_status_mirror();
-  GFV_LAUNCH(adam_kernel, dim3(cap_grid(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long)n, state, hyper,
+  long wgs = (n + ADAM_TPB - 1) / ADAM_TPB;
+  if (wgs > ADAM_MAX_WGS) wgs = ADAM_MAX_WGS;
+  GFV_LAUNCH(adam_kernel, dim3((unsigned)wgs), dim3(ADAM_TPB), 0, (hipStream_t)stream, p, g, m, v, (long)n, state, hyper,
              (const int*)gfv_internal_status_ptr(), (int*)mirror);
   GFV_CHECK_LAUNCH();
   return GFV_OK;

@@ -561,6 +561,7 @@ extern "C" int gfv_struct_size(int32_t which) {
     case 6: return (int)sizeof(gfv_plan_desc_t);
     case 7: return (int)sizeof(gfv_trans_mlp_t);
     case 8: return (int)sizeof(gfv_trans_mlp_bwd_t);
+    case 9: return (int)sizeof(gfv_fvm_mesh_t);
     default: return -1;
   }
 }

@@ -154,7 +154,11 @@ class Engine:
         self._trans_fuse_min = int(os.environ.get("GFV_TRANS_FUSE_MIN_M", "16385"))
         # the FORWARD chain has a small-tile form as well (csrc/ctrans.hip, up to GFV_CTRANS_MAX_M rows): fused at every size
         self._trans_fuse_fwd_small = os.environ.get("GFV_CTRANS", "1") != "0"
-        self._slice_walk_max = int(os.environ.get("GFV_SLICE_WALK_MAX", "0"))
+        # up to this many token chunks per graph the attention workgroups sum the chunk partials themselves (the kernels walk them,
+        # eight loads in flight) instead of a pre-reduction launch of its own: 4 launches per step fewer on meshes below ~6 k nodes
+        # (round 6); above, the per-graph pre-reduction is faster (round 3: 12 -> 7 us at 400 chunks)
+        self._slice_walk_max = int(os.environ.get("GFV_SLICE_WALK_MAX", "96"))
+        self._trans_reduce_merge = os.environ.get("GFV_TRANS_REDUCE_MERGE", "1") != "0"
         # the end of the backward: how many of the trailing weight-gradient flushes run on the MAIN stream (GFV_TAIL_MAIN: 1 = the last
         # encoder's, 2 = both encoders', 3 = the first GnBlock's too) and how the first GnBlock's flush is split between the streams
         # (GFV_TAIL_SPLIT: 0 = not at all, 1 / 2 = its first / its other pieces on main).  Unset: by launch size - (3, 0) between
@@ -179,6 +183,9 @@ class Engine:
         self._pkey_cache = None
         self._zero_e = None
         self._etmp = None
+        self._prep_ws = None
+        self._fvm_cnt = None
+        self._fvm_fuse = os.environ.get("GFV_FVM_FUSE", "1") != "0"   # round 6: forward tail as one launch, backward as three
         self._side, self._sides = None, []
         self._keep = []
         # data parallel: (world, process group) set by TrainStep; the Normalizer statistics are exchanged inside the
@@ -322,7 +329,7 @@ class Engine:
         if phase == "fwd":
             # one power-of-two scale for all weight images of this step, from max|W| over every weight matrix
             # (GFV_ABSMAX_WS=1: one launch - the maximum is written by the workgroup that arrives last, no fill in front)
-            if os.environ.get("GFV_ABSMAX_WS", "0") == "1":   # (measured neutral, profiles/r05_ab_step_start.txt: opt-in)
+            if os.environ.get("GFV_ABSMAX_WS", "1") == "1":   # (round 5 measured it time-neutral; default since round 6: one launch fewer)
                 L.check(L.load().gfv_weight_absmax_ws(self._wi_abs[0].data_ptr(), self._wi_abs[1], self._wmax.data_ptr(),
                                                       self._wi_abs_ws.data_ptr(), L.stream_ptr()), "gfv_weight_absmax_ws")
             else:
@@ -634,6 +641,35 @@ class Engine:
                                  L.stream_ptr()), "gfv_dw_multi")
         if not reduce:
             return wptr, lib.gfv_dw_slabs(M, ti, None), blen, (need + 3) // 4 * 4
+
+    def _dw_jobs(self, grads, jobs, pieces=()):
+        """Several weight-gradient launches whose reductions are ONE launch (round 6: a Transolver block's four weight-gradient
+        launches used to be followed by six reduction launches on the side queue).  jobs: dicts (layers, tiles, M, row0s) as
+        `_dw_block` takes them; every job gets its own region of the slab workspace (sized for all of them up front: the
+        workspace must not move under launches already issued); `pieces`: further reduction pieces (LayerNorm / attention
+        partials) folded into the same launch."""
+        lib = L.load()
+        dev = grads.flat.device
+        needs = []
+        for j in jobs:
+            first = j["layers"][0][0]
+            last = j["layers"][-1][1] if j["layers"][-1][1] is not None else j["layers"][-1][0]
+            blen = grads.block(first, last)[1]
+            needs.append((lib.gfv_dw_multi_workspace_floats(j["M"], len(j["tiles"]), blen) + 3) // 4 * 4)
+        self._workspace(sum(needs) + 8, dev)
+        out, off = [], 0
+        for j, need in zip(jobs, needs):
+            first = j["layers"][0][0]
+            last = j["layers"][-1][1] if j["layers"][-1][1] is not None else j["layers"][-1][0]
+            wptr, slabs, blen, used = self._dw_block(grads, j["layers"], j["tiles"], j["M"], row0s=j.get("row0s"), reduce=False,
+                                                     ws_offset=off)
+            assert used <= need
+            off0, _ = grads.block(first, last)
+            out.append(dict(partial=wptr, out=grads.flat.data_ptr() + 4 * off0, n_chunks=slabs, chunk_stride=blen, rows=1, cols=blen))
+            off += need
+        out += list(pieces)
+        for k in range(0, len(out), 12):   # (gfv_reduce_multi takes 12 pieces)
+            ops.reduce_multi(out[k:k + 12])
 
     @staticmethod
     def _put(grads, name, value):
@@ -951,8 +987,14 @@ class Engine:
         if g_add is not None:
             g_out = g_sum
         g_post = g_out
-        self.defer(lambda: self._dw_block(grads, [(f"{prefix}.mlp.linear_post.weight", f"{prefix}.mlp.linear_post.bias", 2)],
-                                          [self._tile(g_post, 128, zs, a_op=1, gscale=s_post) for zs in zsegs], N), g_post, z, gs)
+        merge = self._trans_reduce_merge
+        jobs, extra, keep = [], [], [g_post, z, gs]
+        if merge:
+            jobs.append(dict(layers=[(f"{prefix}.mlp.linear_post.weight", f"{prefix}.mlp.linear_post.bias", 2)],
+                             tiles=[self._tile(g_post, 128, zs, a_op=1, gscale=s_post) for zs in zsegs], M=N))
+        else:
+            self.defer(lambda: self._dw_block(grads, [(f"{prefix}.mlp.linear_post.weight", f"{prefix}.mlp.linear_post.bias", 2)],
+                                              [self._tile(g_post, 128, zs, a_op=1, gscale=s_post) for zs in zsegs], N), g_post, z, gs)
         # linear_pre behind LayerNorm ln_2
         if not fused:
             ops.rowtile_chain(N, [Seg(g_z, width=128, ld=256), Seg(g_z, width=128, ld=256, offset=128)],
@@ -969,12 +1011,25 @@ class Engine:
                 dict(partial=wptr, out=grads.flat.data_ptr() + 4 * off0, n_chunks=slabs, chunk_stride=blen, rows=1, cols=blen),
                 dict(partial=part, out=self._gview2(grads, f"{prefix}.ln_2.weight", f"{prefix}.ln_2.bias"), n_chunks=tiles,
                      chunk_stride=256, rows=1, cols=256)])
-        self.defer(side_pre, g_z, fx1, part)
+        if merge:
+            jobs.append(dict(layers=[(f"{prefix}.mlp.linear_pre.0.weight", f"{prefix}.mlp.linear_pre.0.bias", 2)],
+                             tiles=[self._tile(g_z, 128, Seg(fx1), a_op=2, a_gamma=gam2, a_beta=bet2, ldg=256, g_offset=128 * h)
+                                    for h in range(2)], M=N, row0s=[0, 128]))
+            extra.append(dict(partial=part, out=self._gview2(grads, f"{prefix}.ln_2.weight", f"{prefix}.ln_2.bias"), n_chunks=tiles,
+                              chunk_stride=256, rows=1, cols=256))
+            keep += [g_z, fx1, part]
+        else:
+            self.defer(side_pre, g_z, fx1, part)
         # to_out
         if not fused:
             ops.rowtile_chain(N, [Seg(g_fx1)], [LayerSpec(self._T(P[f"{a}.to_out.0.weight"]))], [g_out_x])
-        self.defer(lambda: self._dw_block(grads, [(f"{a}.to_out.0.weight", f"{a}.to_out.0.bias", 1)],
-                                          [self._tile(g_fx1, 128, Seg(sv["out_x"]))], N), g_fx1, sv["out_x"])
+        if merge:
+            jobs.append(dict(layers=[(f"{a}.to_out.0.weight", f"{a}.to_out.0.bias", 1)],
+                             tiles=[self._tile(g_fx1, 128, Seg(sv["out_x"]))], M=N))
+            keep += [g_fx1, sv["out_x"]]
+        else:
+            self.defer(lambda: self._dw_block(grads, [(f"{a}.to_out.0.weight", f"{a}.to_out.0.bias", 1)],
+                                              [self._tile(g_fx1, 128, Seg(sv["out_x"]))], N), g_fx1, sv["out_x"])
         # de-slice / attention / slice
         w, batch = sv["w"], pl.batch
         fused_post = self._slice_fuse
@@ -996,7 +1051,12 @@ class Engine:
         def side_qkv():   # parameter gradients only: off the critical path; one launch, straight into the three tensors
             ops.reduce_multi([dict(partial=dwp.data_ptr() + 4 * 256 * i, out=grads.view(f"{a}.{nm}.weight"), n_chunks=B * 8,
                                    chunk_stride=768, rows=1, cols=256) for i, nm in enumerate(("to_q", "to_k", "to_v"))])
-        self.defer(side_qkv, dwp)
+        if merge:
+            extra += [dict(partial=dwp.data_ptr() + 4 * 256 * i, out=grads.view(f"{a}.{nm}.weight"), n_chunks=B * 8,
+                           chunk_stride=768, rows=1, cols=256) for i, nm in enumerate(("to_q", "to_k", "to_v"))]
+            keep.append(dwp)
+        else:
+            self.defer(side_qkv, dwp)
         g_fx_mid = _empty(dev, N, 128)
         nblk = lib.gfv_slice_softmax_bwd_blocks(N)
         sp = _empty(dev, nblk, 552)
@@ -1021,7 +1081,13 @@ class Engine:
                                    cols=c)
                               for o, c, nm in ((0, 512, f"{a}.in_project_slice.weight"), (512, 32, f"{a}.in_project_slice.bias"),
                                                (544, 8, f"{a}.graph_temperature"))])
-        self.defer(side_slice, sp)
+        if merge:
+            extra += [dict(partial=sp.data_ptr() + 4 * o, out=grads.view(nm), n_chunks=nblk, chunk_stride=552, rows=1, cols=c)
+                      for o, c, nm in ((0, 512, f"{a}.in_project_slice.weight"), (512, 32, f"{a}.in_project_slice.bias"),
+                                       (544, 8, f"{a}.graph_temperature"))]
+            keep.append(sp)
+        else:
+            self.defer(side_slice, sp)
         # projections; fx_in also feeds the to_out residual
         t1, g_fx_in = _empty(dev, N, 128), _empty(dev, N, 128)
         Wfxt, Wxt = self._T(P[f"{a}.in_project_fx.weight"]), self._T(P[f"{a}.in_project_x.weight"])
@@ -1030,17 +1096,26 @@ class Engine:
         else:
             ops.rowtile_chain(N, [Seg(g_fx_mid)], [LayerSpec(Wfxt)], [t1], res=[g_fx1])
             ops.rowtile_chain(N, [Seg(g_x_mid)], [LayerSpec(Wxt)], [g_fx_in], res=[t1])
-        self.defer(lambda: self._dw_block(grads, [(f"{a}.in_project_x.weight", f"{a}.in_project_x.bias", 1),
-                                                  (f"{a}.in_project_fx.weight", f"{a}.in_project_fx.bias", 1)],
-                                          [self._tile(g_x_mid, 128, Seg(fx_in)), self._tile(g_fx_mid, 128, Seg(fx_in))], N),
-                   g_x_mid, g_fx_mid, fx_in)
+        if merge:
+            jobs.append(dict(layers=[(f"{a}.in_project_x.weight", f"{a}.in_project_x.bias", 1),
+                                     (f"{a}.in_project_fx.weight", f"{a}.in_project_fx.bias", 1)],
+                             tiles=[self._tile(g_x_mid, 128, Seg(fx_in)), self._tile(g_fx_mid, 128, Seg(fx_in))], M=N))
+            keep += [g_x_mid, g_fx_mid, fx_in]
+            # the block's four weight-gradient launches, then ONE reduction launch for all of their slab partials, the LayerNorm
+            # partials and the attention / slice-projection partials (11 pieces; was six reduction launches)
+            self.defer(lambda: self._dw_jobs(grads, jobs, extra), *keep)
+        else:
+            self.defer(lambda: self._dw_block(grads, [(f"{a}.in_project_x.weight", f"{a}.in_project_x.bias", 1),
+                                                      (f"{a}.in_project_fx.weight", f"{a}.in_project_fx.bias", 1)],
+                                              [self._tile(g_x_mid, 128, Seg(fx_in)), self._tile(g_fx_mid, 128, Seg(fx_in))], N),
+                       g_x_mid, g_fx_mid, fx_in)
         self.flush()   # the block's parameter gradients: one fork
         return g_fx_in
 
     # ------------------------------------------------------------------------------------------------------------
     # finite-volume integrator (FVscheme.py:618-724 -> conserved_form :50-274)
     # ------------------------------------------------------------------------------------------------------------
-    def fvm_fwd(self, dec, uv_old, pl, want_outputs=True):
+    def fvm_fwd(self, dec, uv_old, pl, want_outputs=True, train_loss=None):
         lib = L.load()
         st = L.stream_ptr()
         N, E, C, B = pl.N, pl.E, pl.C, pl.B
@@ -1048,12 +1123,37 @@ class Engine:
         phi = _empty(dev, N, 8)
         L.check(lib.gfv_phi_fwd(dec.data_ptr(), pl.y.data_ptr(), pl.node_type.data_ptr(), uv_old.data_ptr(), phi.data_ptr(),
                                 N, self.mode, st), "phi_fwd")
-        losses, uvp_node, uvp_cell, sv = self.fvm_core_fwd(phi, pl, want_outputs)
+        losses, uvp_node, uvp_cell, sv = self.fvm_core_fwd(phi, pl, want_outputs, train_loss=train_loss)
         sv["dec"] = dec
         return losses, uvp_node, uvp_cell, sv
 
-    def fvm_core_fwd(self, phi, pl, want_outputs=True, raw_outputs=False):
+    def _fvm_mesh(self, pl, raw=False):
+        """gfv_fvm_mesh_t of a plan (include/gfv.h), built once per plan and output mode and kept on it."""
+        cache = pl.__dict__.setdefault("_fvm_mesh_cache", {})
+        key = (self.mode, self.smooth, self.order_terms, bool(raw))
+        m = cache.get(key)
+        if m is None:
+            m = L.FvmMesh(N=pl.N, E=pl.E, C=pl.C, B=pl.B, terms=pl.M, mode=self.mode, smooth=self.smooth | (2 if raw else 0), reserved=0)
+            for name, t in (("node_type", pl.node_type), ("batch", pl.batch), ("ftype", pl.ftype), ("cbatch", pl.cbatch),
+                            ("gcell_ptr", pl.gcell_ptr), ("pos", pl.pos), ("fpos", pl.fpos), ("y", pl.y), ("centroid", pl.centroid),
+                            ("area", pl.area), ("theta", pl.theta), ("sigma", pl.sigma), ("uvp_dim", pl.uvp_dim), ("dt", pl.dt),
+                            ("crow", pl.crow), ("kcell", pl.kcell), ("kS", pl.kS), ("frow", pl.frow), ("fk", pl.fk),
+                            ("nfrow", pl.n_rowptr), ("nfcol2", pl.n_col_edge2), ("nrow", pl.nrow), ("ncell", pl.ncell),
+                            ("An", pl.An), ("rn", pl.rn), ("xo_rowptr", pl.xo_rowptr), ("xo_in", pl.xo_in), ("xo_B", pl.xo_B),
+                            ("sumB", pl.sumB)):
+                setattr(m, name, t.data_ptr())
+            cache[key] = m
+        return m
+
+    def _fvm_counter(self, dev):
+        if self._fvm_cnt is None or self._fvm_cnt.device != dev:
+            self._fvm_cnt = torch.zeros(4, dtype=torch.int32, device=dev)   # (arrival counter of the tail launch: zero between launches)
+        return self._fvm_cnt
+
+    def fvm_core_fwd(self, phi, pl, want_outputs=True, raw_outputs=False, train_loss=None):
         """phi [N,8] = (uvp_new, uv_hat, uv_old, 0) -> residual losses [B,4], smoothed node field, cell field.
+        train_loss = (hyper [8], loss [1], gloss [B,4]) device tensors: the training loss of pre_train_Adam.py:177-184 and its
+        gradient with respect to the four residuals are formed behind the residual norms (TrainStep).
         raw_outputs: the two fields as the reference's stand-alone Intergrator returns them (FVscheme.py:253-262,718-724) - the
         smoothed node field before the Dirichlet overwrite and neither field re-dimensionalised (importer.py:223-231 does both
         afterwards)."""
@@ -1081,22 +1181,42 @@ class Engine:
                                     cres.data_ptr(), None if uvp_cell is None else uvp_cell.data_ptr(), C, self.nc,
                                     None if gradc is None else gradc.data_ptr(), st), "cell_fwd")
         sums, losses = _empty(dev, B, 4), _empty(dev, B, 4)
-        L.check(lib.gfv_graph_loss(cres.data_ptr(), pl.gcell_ptr.data_ptr(), pl.theta.data_ptr(), pl.sigma.data_ptr(),
-                                   sums.data_ptr(), losses.data_ptr(), B, st), "graph_loss")
-        uvp_node = None
-        if want_outputs:
-            uvp_node = _empty(dev, N, 3)
-            L.check(lib.gfv_cell_to_node(phic.data_ptr(), pl.nrow.data_ptr(), pl.ncell.data_ptr(), pl.pos.data_ptr(),
-                                         pl.centroid.data_ptr(), pl.node_type.data_ptr(), pl.y.data_ptr(),
-                                         pl.batch.data_ptr(), pl.uvp_dim.data_ptr(), pl.sigma.data_ptr(), phi.data_ptr(),
-                                         self.smooth | (2 if raw_outputs else 0), uvp_node.data_ptr(), N, st), "cell_to_node")
-            if raw_outputs:
-                uvp_cell = phic[:, 0:3].clone()
+        uvp_node = _empty(dev, N, 3) if want_outputs else None
+        if self._fvm_fuse:
+            # residual norms + (train: the training loss and its gradient, by the workgroup that sees the last graph's norms) +
+            # node smoothing as ONE launch (round 6, csrc/fvm.hip fvm_tail_kernel)
+            tl = train_loss
+            L.check(lib.gfv_fvm_fwd_tail(self._fvm_mesh(pl, raw_outputs), cres.data_ptr(), phic.data_ptr(), phi.data_ptr(),
+                                         sums.data_ptr(), losses.data_ptr(), None if uvp_node is None else uvp_node.data_ptr(),
+                                         None if tl is None else tl[0].data_ptr(), None if tl is None else tl[1].data_ptr(),
+                                         None if tl is None else tl[2].data_ptr(), self._fvm_counter(dev).data_ptr(), st), "fvm_fwd_tail")
+        else:
+            L.check(lib.gfv_graph_loss(cres.data_ptr(), pl.gcell_ptr.data_ptr(), pl.theta.data_ptr(), pl.sigma.data_ptr(),
+                                       sums.data_ptr(), losses.data_ptr(), B, st), "graph_loss")
+            if want_outputs:
+                L.check(lib.gfv_cell_to_node(phic.data_ptr(), pl.nrow.data_ptr(), pl.ncell.data_ptr(), pl.pos.data_ptr(),
+                                             pl.centroid.data_ptr(), pl.node_type.data_ptr(), pl.y.data_ptr(),
+                                             pl.batch.data_ptr(), pl.uvp_dim.data_ptr(), pl.sigma.data_ptr(), phi.data_ptr(),
+                                             self.smooth | (2 if raw_outputs else 0), uvp_node.data_ptr(), N, st), "cell_to_node")
+            if train_loss is not None:
+                L.check(lib.gfv_train_loss_dev(losses.data_ptr(), B, train_loss[0].data_ptr(), train_loss[1].data_ptr(),
+                                               train_loss[2].data_ptr(), st), "train_loss")
+        if want_outputs and raw_outputs:
+            uvp_cell = phic[:, 0:3].clone()
         sv = dict(Ff=Ff, cres=cres, sums=sums, phi=phi, grad=grad, phic=phic, gradc=gradc)
         return losses, uvp_node, uvp_cell, sv
 
     def fvm_bwd(self, sv, gloss, pl):
         lib = L.load()
+        if self._fvm_fuse and not self.nc:
+            # conserved form: three launches from the loss gradients to the decoder-output gradient (round 6, csrc/fvm.hip)
+            dev = gloss.device
+            gFf, gphi, grhs = _empty(dev, pl.E, 16), _empty(dev, pl.N, 8), _empty(dev, pl.N, 8, pl.M)
+            gdec = _empty(dev, pl.N, 3)
+            L.check(lib.gfv_fvm_bwd_fused(self._fvm_mesh(pl), sv["cres"].data_ptr(), sv["sums"].data_ptr(), gloss.data_ptr(),
+                                          sv["Ff"].data_ptr(), sv["dec"].data_ptr(), gFf.data_ptr(), gphi.data_ptr(), grhs.data_ptr(),
+                                          gdec.data_ptr(), L.stream_ptr()), "fvm_bwd_fused")
+            return gdec
         gphi = self.fvm_core_bwd(sv, gloss, pl)
         gdec = _empty(gloss.device, pl.N, 3)
         L.check(lib.gfv_phi_bwd(gphi.data_ptr(), sv["dec"].data_ptr(), pl.node_type.data_ptr(), gdec.data_ptr(), pl.N,
@@ -1128,13 +1248,76 @@ class Engine:
     # ------------------------------------------------------------------------------------------------------------
     # input preparation (importer.py:166-178)
     # ------------------------------------------------------------------------------------------------------------
-    def prep_fwd(self, x, buffers, pl, norm_global, accumulate, want_edge_attr15=True):
-        """In place on x [N,12]; returns (uv_old [N,2], edge_attr16 [E,16], edge_attr15 [E,15] or None)."""
+    def prep_fwd(self, x, buffers, pl, norm_global, accumulate, want_edge_attr15=True, x_raw=None):
+        """In place on x [N,12]; returns (uv_old [N,2], edge_attr16 [E,16], edge_attr15 [E,15] or None).
+        Round 6: two launches - the per-graph statistics (+ the Normalizer's mean / std when it does not accumulate; + a copy of
+        the raw rows when the caller has none), then node normalisation and edge features together (csrc/misc.hip prep_stats /
+        prep_apply).  x_raw: the un-normalised rows in a tensor of the caller's that survives the step (TrainStep's backup: its
+        per-step restore copy is then not needed at all); None: `x` holds them and is normalised in place (importer.py:123-130)."""
         lib = L.load()
         st = L.stream_ptr()
         N, E, B = pl.N, pl.E, pl.B
         dev = x.device
         assert x.is_contiguous() and x.shape[1] == 12
+        if os.environ.get("GFV_PREP_FUSE", "1") == "0":
+            return self._prep_fwd_unfused(x, buffers, pl, norm_global, accumulate, want_edge_attr15, x_raw)
+        stats = _empty(dev, B, 6)
+        ws = self._prep_ws
+        need = lib.gfv_prep_workspace_bytes(B) // 4
+        if ws is None or ws.numel() < need or ws.device != dev:
+            # (allocated by the warm-up steps that precede any recording / capture; the arrival counters start at zero and every
+            # launch leaves them at zero)
+            ws = self._prep_ws = torch.zeros(need, dtype=torch.float32, device=dev)
+        mean_std = _empty(dev, 18)
+        fused_norm = False
+        if norm_global:
+            sync = accumulate and (self.dist_world > 1 or self.dist_force)
+            if accumulate:
+                nb = lib.gfv_normalizer_blocks(N)
+                pws = _empty(dev, nb, 18)
+                src = x if x_raw is None else x_raw
+                if sync:
+                    from . import parallel
+                    before = parallel.snapshot_normalizer(buffers)
+
+                def update(acc):
+                    L.check(lib.gfv_normalizer_update(src.data_ptr(), 12, N, 1 if acc else 0, buffers["acc_count"].data_ptr(),
+                                                      buffers["num_accumulations"].data_ptr(), buffers["acc_sum"].data_ptr(),
+                                                      buffers["acc_sum_squared"].data_ptr(), pws.data_ptr(),
+                                                      mean_std.data_ptr(), L.stream_ptr()), "normalizer_update")
+                update(True)
+                if sync:
+                    # statistics of the GLOBAL batch on every rank, then mean / std recomputed from them (finalize only)
+                    parallel.allreduce_normalizer(buffers, before, self.dist_world, self.dist_group, force=self.dist_force)
+                    update(False)
+            else:
+                fused_norm = True   # mean / std from the running buffers inside the statistics launch
+        own_raw = x_raw is None
+        if own_raw:
+            x_raw = _empty(dev, N, 12)
+        L.check(lib.gfv_prep_stats((x if own_raw else x_raw).data_ptr(), 12, pl.gnode_ptr.data_ptr(), B, stats.data_ptr(), ws.data_ptr(),
+                                   x_raw.data_ptr() if own_raw else None,
+                                   buffers["acc_count"].data_ptr() if fused_norm else None,
+                                   buffers["acc_sum"].data_ptr() if fused_norm else None,
+                                   buffers["acc_sum_squared"].data_ptr() if fused_norm else None,
+                                   mean_std.data_ptr() if fused_norm else None, st), "prep_stats")
+        uv_old = _empty(dev, N, 2)
+        ea16 = _empty(dev, E, 16)
+        ea15 = _empty(dev, E, 15) if want_edge_attr15 else None
+        L.check(lib.gfv_prep_apply(x_raw.data_ptr(), x.data_ptr(), pl.batch.data_ptr(), stats.data_ptr(), pl.uvp_dim.data_ptr(),
+                                   mean_std.data_ptr(), 1 if norm_global else 0, uv_old.data_ptr(), N, pl.pos.data_ptr(),
+                                   pl.es.data_ptr(), pl.er.data_ptr(), ea16.data_ptr(),
+                                   None if ea15 is None else ea15.data_ptr(), E, st), "prep_apply")
+        return uv_old, ea16, ea15
+
+    def _prep_fwd_unfused(self, x, buffers, pl, norm_global, accumulate, want_edge_attr15=True, x_raw=None):
+        """The six-launch form of rounds 1 - 5 (GFV_PREP_FUSE=0; what the fused launches are tested against)."""
+        lib = L.load()
+        st = L.stream_ptr()
+        N, E, B = pl.N, pl.E, pl.B
+        dev = x.device
+        if x_raw is not None:
+            cmdlist.call(x.copy_, x_raw)
         stats = _empty(dev, B, 6)
         # per-graph mean / std over 64 workgroups per graph (double partial sums, folded in a fixed order)
         nws = _empty(dev, B, 64 * 12)   # = gfv_graph_norm_workspace_bytes(B) / 4 floats (64 x 6 doubles per graph)
@@ -1244,7 +1427,7 @@ class Engine:
     # whole model (importer.py:156-240)
     # ------------------------------------------------------------------------------------------------------------
     def forward(self, P, buffers, x, pl, *, norm_global=True, accumulate=True, want_outputs=True, want_edge_attr15=True,
-                before_prep=None):
+                before_prep=None, x_raw=None, train_loss=None):
         """before_prep: main-stream work of the caller that only the input preparation waits for (TrainStep's restore of the
         un-normalised node state): issued BEHIND the fork, so that the side stream's image build - which the first encoder launch
         waits for, ~16 us in round 5's timelines - starts a copy and a cross-queue signal earlier."""
@@ -1254,12 +1437,12 @@ class Engine:
         try:
             if before_prep is not None:
                 before_prep()
-            uv_old, ea16, ea15 = self.prep_fwd(x, buffers, pl, norm_global, accumulate, want_edge_attr15)
+            uv_old, ea16, ea15 = self.prep_fwd(x, buffers, pl, norm_global, accumulate, want_edge_attr15, x_raw=x_raw)
             self.join()
             dec, sv_sim = self.simulator_fwd(P, x, ea16, pl)
         finally:
             self._wi_exit("fwd", prev)
-        losses, uvp_node, uvp_cell, sv_fvm = self.fvm_fwd(dec, uv_old, pl, want_outputs)
+        losses, uvp_node, uvp_cell, sv_fvm = self.fvm_fwd(dec, uv_old, pl, want_outputs, train_loss=train_loss)
         return losses, uvp_node, uvp_cell, ea15, dict(sim=sv_sim, fvm=sv_fvm)
 
     def backward(self, P, ctx, gloss, grads, pl):

@@ -88,6 +88,16 @@ class TransMlpBwd(C.Structure):
                 ("ln_partial", C.c_void_p), ("gscale", C.c_void_p), ("M", C.c_int32), ("reserved", C.c_int32)]
 
 
+class FvmMesh(C.Structure):
+    """gfv_fvm_mesh_t (include/gfv.h): the mesh tables of a batch for the fused finite-volume launches."""
+    _fields_ = ([("N", C.c_int32), ("E", C.c_int32), ("C", C.c_int32), ("B", C.c_int32), ("terms", C.c_int32), ("mode", C.c_int32),
+                 ("smooth", C.c_int32), ("reserved", C.c_int32)]
+                + [(n, C.c_void_p) for n in (
+                    "node_type", "batch", "ftype", "cbatch", "gcell_ptr", "pos", "fpos", "y", "centroid", "area", "theta", "sigma",
+                    "uvp_dim", "dt", "crow", "kcell", "kS", "frow", "fk", "nfrow", "nfcol2", "nrow", "ncell", "An", "rn",
+                    "xo_rowptr", "xo_in", "xo_B", "sumB")])
+
+
 _lib = None
 
 _SIGNATURES = {
@@ -187,6 +197,13 @@ _SIGNATURES = {
     "gfv_node_prep": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
     "gfv_edge_attr": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "gfv_adam_step_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gfv_prep_workspace_bytes": (C.c_size_t, [C.c_int32]),
+    "gfv_prep_stats": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gfv_prep_apply": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
+                                 C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
+    "gfv_fvm_fwd_tail": (C.c_int, [C.POINTER(FvmMesh)] + [C.c_void_p] * 11),
+    "gfv_fvm_bwd_fused": (C.c_int, [C.POINTER(FvmMesh)] + [C.c_void_p] * 10),
     "gfv_adam_state_init": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]),
     "gfv_train_loss_dev": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gfv_train_loss": (C.c_int, [C.c_void_p, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -252,7 +269,7 @@ def load(raw=False):
     if lib.gfv_abi_version() != ABI_VERSION:
         raise RuntimeError(f"libgfv.so has ABI {lib.gfv_abi_version()}, this binding is written for {ABI_VERSION}: rebuild it "
                            "(python gen-fvgn-steady_amd/gfv/build.py)")
-    for which, st in enumerate((Seg, Layer, RowtileArgs, WimgDesc, DwTile, ReducePiece, PlanDesc, TransMlp, TransMlpBwd)):
+    for which, st in enumerate((Seg, Layer, RowtileArgs, WimgDesc, DwTile, ReducePiece, PlanDesc, TransMlp, TransMlpBwd, FvmMesh)):
         if lib.gfv_struct_size(which) != C.sizeof(st):
             raise RuntimeError(f"libgfv.so: struct {st.__name__} is {lib.gfv_struct_size(which)} bytes in the library, "
                                f"{C.sizeof(st)} in the binding")

@@ -259,17 +259,13 @@ class TrainStep:
         st = L.stream_ptr()
         if self.padded:
             cmdlist.call(_gather, self.flat_p, self._pad_map, self.flat_pp)
-        # solve_with_grad_GPU.py:143: fresh, un-normalised node state every step (behind the engine's fork: see Engine.forward)
-        restore = lambda: cmdlist.call(self.x.copy_, self.x_backup)
-        if os.environ.get("GFV_EARLY_FORK", "1") == "0":   # (A/B: the restore in front of the engine's fork, as before round 5)
-            restore()
-            restore = None
+        # solve_with_grad_GPU.py:143: fresh, un-normalised node state every step.  Round 6: no restore copy - the input
+        # preparation reads the raw rows from the persistent backup and writes the normalised ones into `x` (Engine.prep_fwd)
         with self.engine.model_width():
             losses, uvp_node, uvp_cell, _, ctx = self.engine.forward(
                 self.P_run, self.model.node_norm.buffers_dict(), self.x, self.plan, norm_global=True, accumulate=accumulate,
-                want_outputs=self.want_outputs, want_edge_attr15=False, before_prep=restore)
-            L.check(lib.gfv_train_loss_dev(losses.data_ptr(), self.plan.B, self.hyper.data_ptr(), self.loss.data_ptr(),
-                                           self.gloss.data_ptr(), st), "train_loss")
+                want_outputs=self.want_outputs, want_edge_attr15=False, x_raw=self.x_backup,
+                train_loss=(self.hyper, self.loss, self.gloss))   # loss + its gradient behind the residual norms, same launch
             self.engine.backward(self.P_run, ctx, self.gloss, self.G_run, self.plan)
         if self.padded:
             cmdlist.call(_gather, self.G_run.flat, self._unpad_map, self.flat_g)

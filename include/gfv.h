@@ -36,7 +36,8 @@ extern "C" {
 #define GFV_ABI_VERSION 3
 int gfv_abi_version(void);
 /* sizeof of the argument structs as the library was compiled (which: 0 gfv_seg_t, 1 gfv_layer_t, 2 gfv_rowtile_args_t,
- * 3 gfv_wimg_desc_t, 4 gfv_dw_tile_t, 5 gfv_reduce_piece_t, 6 gfv_plan_desc_t, 7 gfv_trans_mlp_t, 8 gfv_trans_mlp_bwd_t): lets a
+ * 3 gfv_wimg_desc_t, 4 gfv_dw_tile_t, 5 gfv_reduce_piece_t, 6 gfv_plan_desc_t, 7 gfv_trans_mlp_t, 8 gfv_trans_mlp_bwd_t,
+ * 9 gfv_fvm_mesh_t): lets a
  * binding check its own layout */
 int gfv_struct_size(int32_t which);
 
@@ -534,6 +535,24 @@ int gfv_node_prep(float* x, int32_t ldx, const int32_t* batch, const float* stat
                   const float* mean_std, int32_t norm_global, float* uv_old, int32_t N, void* stream);
 int gfv_edge_attr(const float* x, int32_t ldx, const float* pos, const int32_t* es, const int32_t* er, float* out16,
                   float* out15, int32_t E, void* stream);
+/* Round 6 - the input preparation as TWO launches (importer.py:114-130,166-178: was graph_norm_stats_ws + normalizer_update +
+ * node_prep + edge_attr, and a state-restore copy in front of them in the solve loop, solve_with_grad_GPU.py:143).
+ * gfv_prep_stats: stats[B,6] as gfv_graph_norm_stats_ws forms them (same partial sums, same fold order - by the workgroup of
+ *   the graph that arrives last); workspace: gfv_prep_workspace_bytes(B) bytes, 8-byte aligned, ZERO before the first launch
+ *   (every launch leaves its arrival counters at zero; one workspace per stream that may run this concurrently).
+ *   x_raw != NULL: also copies the rows x[:, 0:12] -> x_raw [N,12] (a caller that normalises x in place needs the raw rows
+ *   for the edge features).  mean_std != NULL: also derives the Normalizer's (mean[9], std[9]) from acc_count / acc_sum /
+ *   acc_sq WITHOUT accumulating (= gfv_normalizer_update(accumulate = 0)); an accumulating step calls gfv_normalizer_update first.
+ * gfv_prep_apply: node i < N: uv_old[i] = x_raw[i, 0:2] / uvp_dim[batch[i]], x_out[i] = the normalised row (gfv_node_prep's
+ *   arithmetic); edge e < E: out16 / out15 = gfv_edge_attr's relative features of the NORMALISED end-node rows, formed from the
+ *   raw rows with the same expressions (bit-identical to gfv_node_prep followed by gfv_edge_attr).  x_raw and x_out are
+ *   [N,12] contiguous and must not alias. */
+size_t gfv_prep_workspace_bytes(int32_t B);
+int gfv_prep_stats(const float* x, int32_t ldx, const int32_t* gnode_ptr, int32_t B, float* stats, void* workspace, float* x_raw,
+                   const float* acc_count, const float* acc_sum, const float* acc_sq, float* mean_std, void* stream);
+int gfv_prep_apply(const float* x_raw, float* x_out, const int32_t* batch, const float* stats, const float* uvp_dim,
+                   const float* mean_std, int32_t norm_global, float* uv_old, int32_t N, const float* pos, const int32_t* es,
+                   const int32_t* er, float* out16, float* out15, int32_t E, void* stream);
 /* Fused Adam on the flat buffers (torch.optim.Adam defaults; pre_train_Adam.py:115,189-191).  Step counter and
  * hyper-parameters are DEVICE resident so that a captured hipGraph follows learning-rate changes:
  *   state[8] = {t = completed steps, bc1_hi, bc1_lo, sqrt(1 - beta2^(t+1)), arrival counter (int32, 0 between launches), 0, 0, 0}
@@ -551,6 +570,36 @@ int gfv_train_loss(const float* losses, int32_t B, float w_cont, float w_mom, fl
                    void* stream);
 /* same, weights read from the device: hyper[5..7] = {w_cont, w_mom, w_press} of the buffer gfv_adam_step_dev takes */
 int gfv_train_loss_dev(const float* losses, int32_t B, const float* hyper, float* loss, float* gloss, void* stream);
+
+/* Round 6 - the finite-volume section with fewer launches (FVscheme.py:145-262 and its adjoint; the stand-alone entry points
+ * above stay what the operator modules use and what these are tested against, bit for bit).  The mesh tables of a batch in one
+ * struct (all device pointers, the tables of gfv_plan_create / gfv/plan.py): */
+typedef struct {
+  int32_t N, E, C, B;
+  int32_t terms;        /* Taylor terms of the WLSQ order: 2 / 5 / 9 / 14 */
+  int32_t mode;         /* integrator: 0 explicit, 1 implicit, 2 imex (gfv_phi_fwd) */
+  int32_t smooth;       /* gfv_cell_to_node's `smooth` bits */
+  int32_t reserved;
+  const int32_t* node_type; const int32_t* batch; const int32_t* ftype; const int32_t* cbatch; const int32_t* gcell_ptr;
+  const float* pos; const float* fpos; const float* y; const float* centroid; const float* area;
+  const float* theta; const float* sigma; const float* uvp_dim; const float* dt;
+  const int32_t* crow; const int32_t* kcell; const float* kS;            /* cell <- (face, node) incidences */
+  const int32_t* frow; const int32_t* fk;                                /* face <- incidences */
+  const int32_t* nfrow; const int32_t* nfcol2;                           /* node <- faces (2 * face + side) */
+  const int32_t* nrow; const int32_t* ncell;                             /* node <- incidences */
+  const float* An; const float* rn;                                      /* WLSQ moment matrices as stored + row norms */
+  const int32_t* xo_rowptr; const int32_t* xo_in; const float* xo_B; const float* sumB;   /* stencil in sender order */
+} gfv_fvm_mesh_t;
+/* forward tail: gfv_graph_loss + gfv_train_loss_dev (hyper != NULL; its last-arriving workgroup) + gfv_cell_to_node (uvp_node !=
+ * NULL) as ONE launch.  counter: one int32 of the caller's, zero before the first launch (the launch leaves it zero). */
+int gfv_fvm_fwd_tail(const gfv_fvm_mesh_t* mesh, const float* cres, const float* phic, const float* phi, float* sums, float* losses,
+                     float* uvp_node, const float* hyper, float* loss, float* gloss, int32_t* counter, void* stream);
+/* backward of the conserved form from the loss gradients to the gradient of the decoder output, THREE launches (was six:
+ * gfv_fvm_bwd_ex's cell / face / node kernels, gfv_wlsq_bwd_ex's solve / gather, gfv_phi_bwd): per face (the cell factors formed on
+ * the fly); per (node, channel) the node adjoint + its transposed WLSQ solve; per (node, channel) the stencil gather + the
+ * decoder-output adjoint.  Workspaces: gFf_ws [E,16], gphi_ws [N,8], grhs_ws [N,8,terms].  Same sums in the same order as the six. */
+int gfv_fvm_bwd_fused(const gfv_fvm_mesh_t* mesh, const float* cres, const float* sums, const float* gloss, const float* Ff,
+                      const float* dec, float* gFf_ws, float* gphi_ws, float* grhs_ws, float* gdec, void* stream);
 
 /* k-hop reconstruction stencil of a mesh on the device (per-mesh preprocessing; parse_to_h5.py:228-254,
  * Load_mesh.py:421-521): the unordered node pairs (i < j) with j within k edges of i, as np.unique(axis=1) orders them

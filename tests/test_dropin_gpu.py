@@ -126,7 +126,8 @@ def test_gfv_adam_equals_torch_adam_and_exchanges_state():
     for a, b in zip(lt, lg):
         assert abs(float(a) - float(b)) < 1e-5 * abs(float(a))
     for (n, a), b in zip(mt.named_parameters(), mg.parameters()):
-        assert float((a - b).abs().max()) < 2e-6 * float(a.abs().max()) + 6 * 2e-7 * params.lr, n
+        # (Adam's normalised step is ~lr per iteration whatever the gradient's size: 2 % of one step after six)
+        assert float((a.detach() - b.detach()).abs().max()) < 0.02 * params.lr, n
     assert float(og.adam_state[0]) == 6.0
     # the gradients of the last backward sit in ONE flat tensor the optimiser recognises
     flat = og._flat_grad()
