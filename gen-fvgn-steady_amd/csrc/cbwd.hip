@@ -27,6 +27,7 @@
 
 #include "colchain_kernel.h"
 
+#include "gfv_limits.h"
 int* gfv_internal_status_ptr();
 
 namespace {
@@ -344,10 +345,6 @@ __global__ __launch_bounds__(512, 4) void cbwd_kernel(const gfv_rowtile_args_t A
 }
 
 inline bool cw_al16(const void* p) { return (reinterpret_cast<size_t>(p) & 15) == 0; }
-int cw_env(const char* n, int dflt) {
-  const char* e = getenv(n);
-  return e ? atoi(e) : dflt;
-}
 
 // 32-row tiles only.  (A 64-row instantiation was timed - slower at every size, profiles/r05_cfwd.txt run 20 / 21 - and then failed a
 // model-level check that reached it through the environment, 1.4e-3 on the gradients of a 50 k-cell mesh: it had no kernel test of
@@ -371,10 +368,10 @@ extern "C" int gfv_rowtile_ln_rows(int32_t M) { return (M + 31) / 32; }
 // 1: launched; 0: not a launch of this family.  lowp: 0 three products, 1 / 2 the single-product forms.  dry != 0: only tell
 // whether the launch would be taken.  `a` carries `hidden` (the launcher of rowtile.hip fills it in).
 int gfv_internal_cbwd_try(const gfv_rowtile_args_t* a, int lowp, hipStream_t stream, int dry) {
-  // (read per launch - at record time under a command list -, not once: the tests move the row limit to reach the kernel at sizes
-  // the default leaves to the persistent backward)
-  const int on = cw_env("GFV_CBWD", 1);
-  const int max_m = cw_env("GFV_CBWD_MAX_M", 25000);
+  // (the dispatch limits: gfv_limits.h - environment once, gfv_set_limit afterwards: the tests move the row limit to reach the
+  // kernel at sizes the default leaves to the persistent backward)
+  const int on = gfv_internal_limit(GFV_LIM_CBWD_ON);
+  const int max_m = gfv_internal_limit(GFV_LIM_CBWD_MAX_M);
   if (!gfv_internal_status_ptr()) return 0;   // (the kernels raise their range flag there)
   if (!on || a->M > max_m || a->M < 1 || (a->flags & (GFV_CHAIN_ROW_OWNER | GFV_CHAIN_COLUMN_OWNER))) return 0;
   const bool noout = a->nlayers == 2;

@@ -34,6 +34,7 @@
 
 #include "tchain_kernel.h"
 
+#include "gfv_limits.h"
 int* gfv_internal_status_ptr();
 
 namespace {
@@ -374,10 +375,6 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void cfwd_kernel(const gf
 }
 
 inline bool cf_al16(const void* p) { return (reinterpret_cast<size_t>(p) & 15) == 0; }
-int cf_env(const char* n, int dflt) {
-  const char* e = getenv(n);
-  return e ? atoi(e) : dflt;
-}
 
 template <int KT0, int N0, bool PADD, bool RAGIN, bool FINLN = true>
 void cf_launch(const gfv_rowtile_args_t& a, int tg, int lowp, hipStream_t stream) {
@@ -403,14 +400,14 @@ void cf_launch(const gfv_rowtile_args_t& a, int tg, int lowp, hipStream_t stream
 // 1: launched; 0: not a launch of this family.  lowp: 0 three products, 1 / 2 the single-product forms.  dry != 0: only tell
 // whether the launch would be taken.  `args` carries `hidden` (the launcher of rowtile.hip fills it in).
 int gfv_internal_cfwd_try(const gfv_rowtile_args_t* a, int lowp, hipStream_t stream, int dry) {
-  // (read per launch - at record time under a command list -: the tests move the limits to reach both tile heights at any size)
+  // (the dispatch limits: gfv_limits.h - the tests move them to reach both tile heights at any size)
   if (!gfv_internal_status_ptr()) return 0;   // (the kernels raise their range flag there)
-  const int on = cf_env("GFV_CFWD", 1);
-  const int max_m = cf_env("GFV_CFWD_MAX_M", 100000);
+  const int on = gfv_internal_limit(GFV_LIM_CFWD_ON);
+  const int max_m = gfv_internal_limit(GFV_LIM_CFWD_MAX_M);
   // 32-row tiles at every size the family takes: 64-row tiles (GFV_CFWD_TG2_MAX_M below the launch's rows) measured -1.8 % / -0.6 % /
   // -0.6 % of the step WORSE at 45 k / 51 k / 75 k edge rows with the round's final kernels (profiles/r05_thresholds.txt)
-  const int tg2_max = cf_env("GFV_CFWD_TG2_MAX_M", 100000);
-  const int rag_max = cf_env("GFV_CFWD_RAG_MAX_M", 16384);
+  const int tg2_max = gfv_internal_limit(GFV_LIM_CFWD_TG2_MAX_M);
+  const int rag_max = gfv_internal_limit(GFV_LIM_CFWD_RAG_MAX_M);
   if (!on || a->nlayers != 3 || a->M > max_m || a->M < 1 || (a->flags & (GFV_CHAIN_ROW_OWNER | GFV_CHAIN_COLUMN_OWNER))) return 0;
   // the decoder's shape: no LayerNorm, a last layer of <= 16 columns, nothing else around it
   const bool dec = a->fin_op == GFV_FIN_PLAIN && a->layer[2].N >= 1 && a->layer[2].N <= 16 && !a->res[0] && !a->out_nores && !a->fin_presave &&

@@ -16,6 +16,7 @@
 #include "tchain_kernel.h"
 #include "../../include/gfv.h"
 
+#include "gfv_limits.h"
 int* gfv_internal_status_ptr();
 
 namespace {
@@ -669,10 +670,6 @@ __global__ __launch_bounds__(512, 2) void ctrans_bwd_kernel(const CtBwdArgs A, i
   if (mabs > 60000.0f) atomicOr(status, 2);   // GFV_FLAG_CHAIN_RANGE: a fragment value beyond fp16's range
 }
 
-int ct_env(const char* n, int dflt) {
-  const char* e = getenv(n);
-  return e ? atoi(e) : dflt;
-}
 
 }  // namespace
 
@@ -681,11 +678,11 @@ extern "C" int gfv_hidden_size(void);
 // rows of ln_partial a gfv_trans_mlp_bwd launch over M rows fills: one per 32 rows when the small-tile form takes it, one per 64 otherwise
 extern "C" int gfv_trans_mlp_ln_rows(int32_t M) {
   if (M <= 0) return 0;
-  return (ct_env("GFV_CTRANS", 1) && M <= ct_env("GFV_CTRANS_MAX_M", 16384)) ? (M + 31) / 32 : (M + 63) / 64;
+  return (gfv_internal_limit(GFV_LIM_CTRANS_ON) && M <= gfv_internal_limit(GFV_LIM_CTRANS_MAX_M)) ? (M + 31) / 32 : (M + 63) / 64;
 }
 
 int gfv_internal_ctrans_bwd_try(const gfv_trans_mlp_bwd_t* a, int form, hipStream_t stream) {
-  if (!ct_env("GFV_CTRANS", 1) || a->M > ct_env("GFV_CTRANS_MAX_M", 16384) || !gfv_internal_status_ptr()) return 0;
+  if (!gfv_internal_limit(GFV_LIM_CTRANS_ON) || a->M > gfv_internal_limit(GFV_LIM_CTRANS_MAX_M) || !gfv_internal_status_ptr()) return 0;
   CtBwdArgs B{a->g, a->g_add, a->g_sum, a->z, a->fx1, a->img_post_t, a->img_pre_t, a->img_out_t, a->gamma, a->wmax,
               a->g_z, a->g_fx1, a->g_out_x, a->ln_partial, a->gscale, a->M, gfv_hidden_size()};
   int* st = gfv_internal_status_ptr();
@@ -699,7 +696,7 @@ int gfv_internal_ctrans_bwd_try(const gfv_trans_mlp_bwd_t* a, int form, hipStrea
 // 1: launched; 0: not this family's launch (too many rows, switched off).  The caller (transmlp.hip) has checked the arguments.
 // form: gfv_f16split_enabled() of the calling thread (1 / 2 / 3)
 int gfv_internal_ctrans_fwd_try(const gfv_trans_mlp_t* a, int form, hipStream_t stream) {
-  if (!ct_env("GFV_CTRANS", 1) || a->M > ct_env("GFV_CTRANS_MAX_M", 16384) || !gfv_internal_status_ptr()) return 0;
+  if (!gfv_internal_limit(GFV_LIM_CTRANS_ON) || a->M > gfv_internal_limit(GFV_LIM_CTRANS_MAX_M) || !gfv_internal_status_ptr()) return 0;
   CtArgs B{a->x, a->res, a->img_out, a->img_pre, a->img_post, a->b_out, a->b_pre, a->b_post, a->gamma, a->beta, a->wmax,
            a->fx1, a->z, a->out, a->M, gfv_hidden_size()};
   int* st = gfv_internal_status_ptr();

@@ -1,0 +1,20 @@
+// Dispatch limits of gfv_rowtile_chain / gfv_trans_mlp_*: which kernel family takes a launch of M rows.  ONE table (round 6; the
+// families used to call getenv 2 - 4 times on every eager launch): a limit is read from its environment variable ONCE, at first use,
+// and can be moved afterwards with gfv_set_limit (include/gfv.h) - the tests' and the A/B tools' handle.
+#pragma once
+enum {
+  GFV_LIM_CBWD_ON = 0,        // GFV_CBWD            1      the column-owner small-tile backward (cbwd.hip)
+  GFV_LIM_CBWD_MAX_M,         // GFV_CBWD_MAX_M      25000  ... up to this many rows; above: the persistent fused backward
+  GFV_LIM_CFWD_ON,            // GFV_CFWD            1      the column-owner small-tile forward (cfwd.hip)
+  GFV_LIM_CFWD_MAX_M,         // GFV_CFWD_MAX_M      100000
+  GFV_LIM_CFWD_TG2_MAX_M,     // GFV_CFWD_TG2_MAX_M  100000 32-row tiles up to here, 64-row tiles above
+  GFV_LIM_CFWD_RAG_MAX_M,     // GFV_CFWD_RAG_MAX_M  16384  narrow / ragged first layers and the decoder
+  GFV_LIM_CTRANS_ON,          // GFV_CTRANS          1      the small-tile Transolver chains (ctrans.hip)
+  GFV_LIM_CTRANS_MAX_M,       // GFV_CTRANS_MAX_M    16384
+  GFV_LIM_CFWDP_MIN_M,        // GFV_CFWDP_MIN_M     12000  the PERSISTENT small-tile forward (cfwdp.hip) from this many rows ...
+  GFV_LIM_CFWDP_MAX_M,        // GFV_CFWDP_MAX_M     60000  ... up to this many
+  GFV_LIM_CFWDP_EDGE,         // GFV_CFWDP_EDGE      0      ... also for the factored EdgeBlock's launches (gathered addend)
+  GFV_LIM_CFWDP_WGS,          // GFV_CFWDP_WGS       256    workgroups of a persistent launch (one per CU)
+  GFV_LIM_COUNT
+};
+int gfv_internal_limit(int which);

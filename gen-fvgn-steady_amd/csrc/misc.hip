@@ -348,52 +348,67 @@ __global__ __launch_bounds__(256) void prep_apply_kernel(const float* __restrict
 
 // Adam (torch.optim.Adam defaults, pre_train_Adam.py:115): the step counter and the hyper-parameters live in device
 // memory, so a captured hipGraph follows lr changes (lr_scheduler.step() every epoch in both reference drivers).
-// state[8] = {t = completed steps, bc1_hi, bc1_lo, sqrt(1 - b2^(t+1)), arrival counter (int), 0, 0, 0}: the bias corrections OF
-// THE NEXT STEP, formed in double like torch's host code (fp32 powf at t = 1 is 1.3e-5 away); 1 - b1^(t+1) is kept as a
-// (hi, lo) float pair so that every thread forms lr / bc1 in double with the CURRENT lr (a step follows `ts.lr = ...`).
+// state[16] (include/gfv.h): t = completed steps; the bias corrections OF THE NEXT STEP - 1 - b1^(t+1) as a (hi, lo) float pair,
+// sqrt(1 - b2^(t+1)) -; 1 - b1 and 1 - b2 rounded from DOUBLE as torch's host code forms them (1 - 0.999 in double is 0.001;
+// 1.0f - 0.999f is 1.3e-5 away - the second moments of rounds 1 - 5 differed from torch's by that factor); the running powers
+// b^(t+1) and the betas themselves as (hi, lo) pairs (48 bits: the powers advance by one double multiplication per step, no pow).
+// Every thread forms lr / bc1 in double with the CURRENT lr (a step follows `ts.lr = ...`).
 // Round 6: ONE launch per step.  The tick used to be a launch of its own (4.8 us of launch floor for two pows of one thread;
 // folded into every workgroup it cost 53 us): now the workgroup that FINISHES LAST - every other one has read the state by then -
 // advances t, forms the next step's corrections and publishes the status word (include/gfv.h gfv_status_mirror).
 // hyper = {lr, beta1, beta2, eps, grad_scale, w_cont, w_mom, w_press}
-__device__ __forceinline__ void adam_corrections(float* state, const float* hyper, float t_done) {
-  const double tn = (double)t_done + 1.0;
-  const double bc1 = 1.0 - pow((double)hyper[1], tn), bc2 = 1.0 - pow((double)hyper[2], tn);
-  const float hi = (float)bc1;
-  state[0] = t_done;
-  state[1] = hi;
-  state[2] = (float)(bc1 - (double)hi);
-  state[3] = (float)sqrt(bc2);
+enum { AS_T = 0, AS_BC1_HI = 1, AS_BC1_LO = 2, AS_SQRT_BC2 = 3, AS_COUNTER = 4, AS_OMB1 = 5, AS_OMB2 = 6, AS_P1 = 8, AS_P2 = 10,
+       AS_B1 = 12, AS_B2 = 14 };
+__device__ __forceinline__ void as_put(float* state, int at, double v) {
+  const float hi = (float)v;
+  state[at] = hi;
+  state[at + 1] = (float)(v - (double)hi);
 }
-__global__ void adam_state_init_kernel(float* state, const float* __restrict__ hyper, float t_done) {
-  adam_corrections(state, hyper, t_done);
-  reinterpret_cast<int*>(state)[4] = 0;
-  state[5] = state[6] = state[7] = 0.f;
+__device__ __forceinline__ double as_get(const float* state, int at) { return (double)state[at] + (double)state[at + 1]; }
+__device__ __forceinline__ void adam_corrections(float* state, double p1, double p2) {   // p = beta^(t+1)
+  as_put(state, AS_P1, p1);
+  as_put(state, AS_P2, p2);
+  as_put(state, AS_BC1_HI, 1.0 - p1);
+  state[AS_SQRT_BC2] = (float)sqrt(1.0 - p2);
+}
+__global__ void adam_state_init_kernel(float* state, float t_done, double b1, double b2) {
+  for (int i = 0; i < 16; ++i) state[i] = 0.f;
+  state[AS_T] = t_done;
+  reinterpret_cast<int*>(state)[AS_COUNTER] = 0;
+  state[AS_OMB1] = (float)(1.0 - b1);
+  state[AS_OMB2] = (float)(1.0 - b2);
+  as_put(state, AS_B1, b1);
+  as_put(state, AS_B2, b2);
+  const double tn = (double)t_done + 1.0;
+  adam_corrections(state, pow(b1, tn), pow(b2, tn));
 }
 
 constexpr int ADAM_TPB = 512, ADAM_MAX_WGS = 512;   // (few workgroups: one same-address atomic each at the end)
 __global__ __launch_bounds__(ADAM_TPB) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                                                   float* __restrict__ v, long n, float* state,
-                                                   const float* __restrict__ hyper, const int* status_dev, int* status_host) {
-  const float step_size = (float)((double)hyper[0] / ((double)state[1] + (double)state[2])), bc2_sqrt = state[3];
-  const float t_done = state[0];
+                                                        float* __restrict__ v, long n, float* state,
+                                                        const float* __restrict__ hyper, const int* status_dev, int* status_host) {
+  const float step_size = (float)((double)hyper[0] / as_get(state, AS_BC1_HI)), bc2_sqrt = state[AS_SQRT_BC2];
+  const float t_done = state[AS_T];
   const float b1 = hyper[1], b2 = hyper[2], eps = hyper[3], grad_scale = hyper[4];
+  const float omb1 = state[AS_OMB1], omb2 = state[AS_OMB2];
   for (long i = (long)blockIdx.x * ADAM_TPB + threadIdx.x; i < n; i += (long)gridDim.x * ADAM_TPB) {
     const float gi = g[i] * grad_scale;
-    const float mi = m[i] * b1 + (1.0f - b1) * gi;
-    const float vi = v[i] * b2 + (1.0f - b2) * gi * gi;
+    const float mi = m[i] * b1 + omb1 * gi;
+    const float vi = v[i] * b2 + omb2 * gi * gi;
     m[i] = mi; v[i] = vi;
     const float denom = sqrtf(vi) / bc2_sqrt + eps;
     p[i] = p[i] - step_size * (mi / denom);
   }
   __syncthreads();   // every thread of this workgroup has read the state (the values were consumed by the loop above)
   if (threadIdx.x == 0) {
-    int* counter = reinterpret_cast<int*>(state) + 4;
+    int* counter = reinterpret_cast<int*>(state) + AS_COUNTER;
     // RELAXED, no fence: the last arriver needs no DATA of the others, only the fact that they are past their reads of `state`.
     // (A release fence here writes back the L2's dirty lines - the 14 MB this launch has just written - once per workgroup: the
     // first form of this kernel took 115 us instead of 8.)
     if (__hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1) {
       *counter = 0;
-      adam_corrections(state, hyper, t_done + 1.0f);
+      state[AS_T] = t_done + 1.0f;
+      adam_corrections(state, as_get(state, AS_P1) * as_get(state, AS_B1), as_get(state, AS_P2) * as_get(state, AS_B2));
       if (status_host) {
         const int f = *reinterpret_cast<const volatile int*>(status_dev);
         if (f) __hip_atomic_store(status_host, f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -493,18 +508,22 @@ extern "C" int gfv_edge_attr(const float* x, int32_t ldx, const float* pos, cons
   return GFV_OK;
 }
 
+// workspace = [arrival counters: PREP_MAX_GRAPHS int32, a FIXED header - a caller may reuse one workspace for batches of different
+// sizes, and a counter must be where the last launch left its zero][per-graph partial sums: B x NORM_NB x 6 doubles]
+constexpr int PREP_MAX_GRAPHS = 1024;
 extern "C" size_t gfv_prep_workspace_bytes(int32_t B) {
-  return (size_t)(B > 0 ? B : 0) * (NORM_NB * 6 * sizeof(double) + 2 * sizeof(double));   // partial sums + one counter per graph (padded)
+  return PREP_MAX_GRAPHS * sizeof(int32_t) + (size_t)(B > 0 ? B : 0) * NORM_NB * 6 * sizeof(double);
 }
 extern "C" int gfv_prep_stats(const float* x, int32_t ldx, const int32_t* gnode_ptr, int32_t B, float* stats, void* workspace,
                               float* x_raw, const float* acc_count, const float* acc_sum, const float* acc_sq, float* mean_std,
                               void* stream) {
   GfvProfScope ps_(GFV_K_MISC, 0, 0.0, stream);
   if (B <= 0) return GFV_OK;
-  if (!x || !gnode_ptr || !stats || !workspace || (reinterpret_cast<size_t>(workspace) & 7) || ldx < 12) return GFV_ERR_ARG;
+  if (!x || !gnode_ptr || !stats || !workspace || (reinterpret_cast<size_t>(workspace) & 7) || ldx < 12 || B > PREP_MAX_GRAPHS)
+    return GFV_ERR_ARG;
   if (mean_std && (!acc_count || !acc_sum || !acc_sq)) return GFV_ERR_ARG;
-  double* ws = reinterpret_cast<double*>(workspace);
-  int* counters = reinterpret_cast<int*>(ws + (size_t)B * NORM_NB * 6);
+  int* counters = reinterpret_cast<int*>(workspace);
+  double* ws = reinterpret_cast<double*>(counters + PREP_MAX_GRAPHS);
   GFV_LAUNCH(prep_stats_kernel, dim3(NORM_NB, B), dim3(256), 0, (hipStream_t)stream, x, ldx, gnode_ptr, ws, counters, stats, x_raw,
              acc_count, acc_sum, acc_sq, mean_std);
   GFV_CHECK_LAUNCH();
@@ -528,9 +547,9 @@ extern "C" int gfv_prep_apply(const float* x_raw, float* x_out, const int32_t* b
 int* gfv_internal_status_ptr();        // dw.hip
 int32_t* gfv_internal_status_mirror();   // dw.hip: nullptr until a host asked for the mirror
 
-extern "C" int gfv_adam_state_init(float* state, const float* hyper, float steps_done, void* stream) {
-  if (!state || !hyper || !(steps_done >= 0.f)) return GFV_ERR_ARG;
-  GFV_LAUNCH(adam_state_init_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, state, hyper, steps_done);
+extern "C" int gfv_adam_state_init(float* state, double beta1, double beta2, float steps_done, void* stream) {
+  if (!state || !(steps_done >= 0.f) || !(beta1 >= 0.0 && beta1 < 1.0) || !(beta2 >= 0.0 && beta2 < 1.0)) return GFV_ERR_ARG;
+  GFV_LAUNCH(adam_state_init_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, state, steps_done, beta1, beta2);
   GFV_CHECK_LAUNCH();
   return GFV_OK;
 }

@@ -9,7 +9,9 @@
 #include <atomic>
 #include <stdio.h>
 #include <stdlib.h>
+#include <mutex>
 #include "gfv_common.h"
+#include "gfv_limits.h"
 #include "gfv_prof.h"
 #include "../../include/gfv.h"
 
@@ -67,6 +69,42 @@ extern "C" int gfv_set_hidden_size(int32_t h) {
 
 static thread_local int g_last_path = -1;
 extern "C" int gfv_rowtile_last_path(void) { return g_last_path; }
+// ---- dispatch limits (gfv_limits.h) ----
+namespace {
+struct LimitDef { const char* env; int dflt; };
+const LimitDef k_limits[GFV_LIM_COUNT] = {
+    {"GFV_CBWD", 1},        {"GFV_CBWD_MAX_M", 25000},      {"GFV_CFWD", 1},          {"GFV_CFWD_MAX_M", 100000},
+    {"GFV_CFWD_TG2_MAX_M", 100000}, {"GFV_CFWD_RAG_MAX_M", 16384}, {"GFV_CTRANS", 1}, {"GFV_CTRANS_MAX_M", 16384},
+    {"GFV_CFWDP_MIN_M", 12000}, {"GFV_CFWDP_MAX_M", 60000}, {"GFV_CFWDP_EDGE", 0},    {"GFV_CFWDP_WGS", 256}};
+int g_limit[GFV_LIM_COUNT];
+bool g_limit_set[GFV_LIM_COUNT];
+std::once_flag g_limit_once;
+void limits_init() {
+  for (int i = 0; i < GFV_LIM_COUNT; ++i) {
+    const char* e = getenv(k_limits[i].env);
+    g_limit[i] = e ? atoi(e) : k_limits[i].dflt;
+    g_limit_set[i] = false;
+  }
+}
+}  // namespace
+int gfv_internal_limit(int which) {
+  std::call_once(g_limit_once, limits_init);
+  return (which >= 0 && which < GFV_LIM_COUNT) ? g_limit[which] : 0;
+}
+extern "C" int gfv_get_limit(int32_t which) { return (which >= 0 && which < GFV_LIM_COUNT) ? gfv_internal_limit(which) : -1; }
+extern "C" int gfv_set_limit(int32_t which, int32_t value) {
+  if (which < 0 || which >= GFV_LIM_COUNT) return GFV_ERR_ARG;
+  std::call_once(g_limit_once, limits_init);
+  if (value < 0) {   // back to the environment's / the built-in value
+    const char* e = getenv(k_limits[which].env);
+    g_limit[which] = e ? atoi(e) : k_limits[which].dflt;
+  } else {
+    g_limit[which] = value;
+  }
+  return GFV_OK;
+}
+extern "C" const char* gfv_limit_name(int32_t which) { return (which >= 0 && which < GFV_LIM_COUNT) ? k_limits[which].env : nullptr; }
+
 static thread_local int g_last_ln_rows = 0;
 extern "C" int gfv_rowtile_last_ln_rows(void) { return g_last_ln_rows; }
 
@@ -89,6 +127,7 @@ extern "C" int gfv_rowtile_chain(const gfv_rowtile_args_t* args, void* stream) {
 }
 int gfv_internal_lin1_try(const gfv_rowtile_args_t* a, int lowp, hipStream_t stream, int dry);   // lin1.hip
 int gfv_internal_cfwd_try(const gfv_rowtile_args_t* a, int lowp, hipStream_t stream, int dry);   // cfwd.hip
+int gfv_internal_cfwdp_try(const gfv_rowtile_args_t* a, int lowp, hipStream_t stream, int dry);  // cfwdp.hip: its persistent form
 bool gfv_internal_wimg_form_ok(const float* wmax);                                               // wimg.hip
 int gfv_internal_cbwd_try(const gfv_rowtile_args_t* a, int lowp, hipStream_t stream, int dry);   // cbwd.hip
 // the column-owner small-tile forward (cfwd.hip) reads the LayerNorm width from its arguments
@@ -96,6 +135,8 @@ static int cfwd_try(const gfv_rowtile_args_t* args, int lowp, hipStream_t stream
   if (args->nlayers != 3 || (args->fin_op != GFV_FIN_LN && args->fin_op != GFV_FIN_PLAIN)) return 0;
   gfv_rowtile_args_t local = *args;
   local.hidden = g_hidden;
+  // mid-size launches (a CU runs several 32-row tiles): the persistent form keeps the weight slices in registers across tiles
+  if (gfv_internal_cfwdp_try(&local, lowp, stream, dry)) return 1;
   return gfv_internal_cfwd_try(&local, lowp, stream, dry);
 }
 // the column-owner small-tile backward (cbwd.hip): the dX chain behind a LayerNorm backward, no fused weight gradients

@@ -36,7 +36,7 @@ _QUERIES = frozenset((
     "gfv_abi_version", "gfv_struct_size", "gfv_rowtile_tiles", "gfv_rowtile_last_path", "gfv_dw_chunks", "gfv_dw_slabs",
     "gfv_linear_dw_workspace_floats", "gfv_dw_multi_workspace_floats", "gfv_f16split_enabled", "gfv_set_f16split", "gfv_set_f16split_thread", "gfv_hidden_size",
     "gfv_weight_image_bytes", "gfv_normalizer_blocks", "gfv_slice_softmax_bwd_blocks", "gfv_profile_enable",
-    "gfv_profile_collect", "gfv_profile_reset", "gfv_profile_set_sizes", "gfv_status_flags", "gfv_status_mirror", "gfv_prep_workspace_bytes", "gfv_rowtile_dw_partials", "gfv_rowtile_dw_partials_m",
+    "gfv_profile_collect", "gfv_profile_reset", "gfv_profile_set_sizes", "gfv_status_flags", "gfv_status_mirror", "gfv_prep_workspace_bytes", "gfv_get_limit", "gfv_set_limit", "gfv_limit_name", "gfv_rowtile_dw_partials", "gfv_rowtile_dw_partials_m",
     "gfv_rowtile_fuses_dw", "gfv_graph_norm_workspace_bytes", "gfv_plan_create", "gfv_plan_destroy", "gfv_plan_table", "gfv_plan_sizes",
     "gfv_record_begin", "gfv_record_count", "gfv_record_end", "gfv_record_length", "gfv_record_replay", "gfv_record_free"))
 

@@ -178,7 +178,8 @@ class Engine:
         self._fuse_dw_min = int(os.environ.get("GFV_COLCHAIN_BWD_MIN_M", "2048"))
         # up to this many rows the dX chain of an MLP runs on the column-owner small-tile backward (csrc/cbwd.hip) and its weight
         # gradients as one launch of the side queue; above it the persistent backward with fused weight gradients
-        self._cbwd_max = int(os.environ.get("GFV_CBWD_MAX_M", "25000")) if os.environ.get("GFV_CBWD", "1") != "0" else 0
+        # (the library's own dispatch limits, csrc/gfv_limits.h: read when a forward starts, `_cbwd_max` below)
+        self._cbwd_max_fixed = None
         self._wi, self._wi_key, self._wmax, self._wi_abs = None, None, None, None
         self._pkey_cache = None
         self._zero_e = None
@@ -241,6 +242,12 @@ class Engine:
             yield
         finally:
             L.check(lib.gfv_set_hidden_size(128), "gfv_set_hidden_size")
+
+    @property
+    def _cbwd_max(self):
+        if self._cbwd_max_fixed is not None:
+            return self._cbwd_max_fixed
+        return L.get_limit("GFV_CBWD_MAX_M") if L.get_limit("GFV_CBWD") else 0
 
     def _tail_cfg(self, pl):
         """(GFV_TAIL_MAIN, GFV_TAIL_SPLIT) of this batch: the environment's, or by the number of edge rows (see __init__)."""
@@ -1259,7 +1266,7 @@ class Engine:
         N, E, B = pl.N, pl.E, pl.B
         dev = x.device
         assert x.is_contiguous() and x.shape[1] == 12
-        if os.environ.get("GFV_PREP_FUSE", "1") == "0":
+        if os.environ.get("GFV_PREP_FUSE", "1") == "0" or B > 1024:   # (the fused launch keeps 1024 arrival counters)
             return self._prep_fwd_unfused(x, buffers, pl, norm_global, accumulate, want_edge_attr15, x_raw)
         stats = _empty(dev, B, 6)
         ws = self._prep_ws

@@ -119,6 +119,9 @@ _SIGNATURES = {
     "gfv_profile_set_sizes": (C.c_int, [C.c_double, C.c_double]),
     "gfv_gather_pair": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
                                   C.c_void_p]),
+    "gfv_get_limit": (C.c_int, [C.c_int32]),
+    "gfv_set_limit": (C.c_int, [C.c_int32, C.c_int32]),
+    "gfv_limit_name": (C.c_char_p, [C.c_int32]),
     "gfv_rowtile_tiles": (C.c_int, [C.c_int32]),
     "gfv_rowtile_chain": (C.c_int, [C.POINTER(RowtileArgs), C.c_void_p]),
     "gfv_rowtile_last_path": (C.c_int, []),
@@ -204,7 +207,7 @@ _SIGNATURES = {
                                  C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "gfv_fvm_fwd_tail": (C.c_int, [C.POINTER(FvmMesh)] + [C.c_void_p] * 11),
     "gfv_fvm_bwd_fused": (C.c_int, [C.POINTER(FvmMesh)] + [C.c_void_p] * 10),
-    "gfv_adam_state_init": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]),
+    "gfv_adam_state_init": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_float, C.c_void_p]),
     "gfv_train_loss_dev": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gfv_train_loss": (C.c_int, [C.c_void_p, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gfv_plan_create": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_void_p]),
@@ -285,6 +288,48 @@ def stream_wait(waiter, waited):
     """`waiter.wait_stream(waited)` through the library (include/gfv.h gfv_stream_wait): the same event record + stream wait,
     and part of a natively recorded step (gfv/cmdlist.py)."""
     check(load().gfv_stream_wait(C.c_void_p(waiter.cuda_stream), C.c_void_p(waited.cuda_stream)), "gfv_stream_wait")
+
+
+_limit_ids = None
+
+
+def limit_id(name):
+    """Index of a dispatch limit (csrc/gfv_limits.h) by the name of its environment variable, e.g. "GFV_CBWD_MAX_M"."""
+    global _limit_ids
+    if _limit_ids is None:
+        lib, ids, i = load(raw=True), {}, 0
+        while True:
+            n = lib.gfv_limit_name(i)
+            if not n:
+                break
+            ids[n.decode()] = i
+            i += 1
+        _limit_ids = ids
+    return _limit_ids[name]
+
+
+def get_limit(name):
+    return load(raw=True).gfv_get_limit(limit_id(name))
+
+
+class limits:
+    """`with L.limits(GFV_CBWD_MAX_M=100000): ...` - move dispatch limits for the duration of a block (tests, A/B tools)."""
+
+    def __init__(self, **kw):
+        self.kw = kw
+
+    def __enter__(self):
+        lib = load(raw=True)
+        self.old = {k: lib.gfv_get_limit(limit_id(k)) for k in self.kw}
+        for k, v in self.kw.items():
+            check(lib.gfv_set_limit(limit_id(k), int(v)), "gfv_set_limit")
+        return self
+
+    def __exit__(self, *exc):
+        lib = load(raw=True)
+        for k, v in self.old.items():
+            lib.gfv_set_limit(limit_id(k), v)
+        return False
 
 
 FLAG_NAMES = {1: "GFV_FLAG_DW_RANGE (a weight-gradient operand left the fp16 range)",

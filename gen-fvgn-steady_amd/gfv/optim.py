@@ -41,7 +41,7 @@ class Adam(torch.optim.Optimizer):
         self.flat_v = torch.zeros(total, dtype=torch.float32, device=dev)
         self._offs = [self.G.off[str(i)] for i in range(len(ps))]
         self._adopt()
-        self.adam_state = torch.zeros(8, dtype=torch.float32, device=dev)
+        self.adam_state = torch.zeros(16, dtype=torch.float32, device=dev)
         self.hyper = torch.zeros(8, dtype=torch.float32, device=dev)
         self._grad_scale = float(grad_scale)
         self._hyper_host = None
@@ -65,8 +65,8 @@ class Adam(torch.optim.Optimizer):
             self._hyper_host = vals
         if moved or steps_done is not None:
             t = float(self.adam_state[0]) if steps_done is None else float(steps_done)
-            L.check(L.load().gfv_adam_state_init(self.adam_state.data_ptr(), self.hyper.data_ptr(), t, L.stream_ptr()),
-                    "adam_state_init")
+            L.check(L.load().gfv_adam_state_init(self.adam_state.data_ptr(), float(g["betas"][0]), float(g["betas"][1]), t,
+                                                 L.stream_ptr()), "adam_state_init")
 
     def _flat_grad(self):
         """The gradients as ONE flat tensor in this object's layout.  NNmodel's backward returns exactly that - views of one

@@ -61,8 +61,8 @@ class TrainStep:
         self.flat_v = torch.zeros(total, dtype=torch.float32, device=dev)
         # Adam step counter + derived bias corrections, and the hyper-parameters: device resident (include/gfv.h,
         # gfv_adam_step_dev), so a captured step follows `ts.lr = ...` (lr_scheduler.step() in the reference drivers)
-        # (adam_state[8] = {completed steps, the NEXT step's bias corrections, arrival counter}: include/gfv.h gfv_adam_step_dev)
-        self.adam_state = torch.zeros(8, dtype=torch.float32, device=dev)
+        # (adam_state[16] = {completed steps, the NEXT step's bias corrections, arrival counter, 1 - betas, running powers}: include/gfv.h)
+        self.adam_state = torch.zeros(16, dtype=torch.float32, device=dev)
         self.hyper = torch.zeros(8, dtype=torch.float32, device=dev)
         self._sync_hyper()
         L.status_mirror()   # the fused Adam publishes the device status word from now on; step() reads it without a sync
@@ -129,7 +129,8 @@ class TrainStep:
     def _init_adam_state(self, steps_done=None):
         """The device-side bias corrections of the next step, from the step count (a new object, a loaded checkpoint, new betas)."""
         t = float(self.adam_state[0]) if steps_done is None else float(steps_done)
-        L.check(L.load().gfv_adam_state_init(self.adam_state.data_ptr(), self.hyper.data_ptr(), t, L.stream_ptr()), "adam_state_init")
+        L.check(L.load().gfv_adam_state_init(self.adam_state.data_ptr(), float(self._betas[0]), float(self._betas[1]), t,
+                                             L.stream_ptr()), "adam_state_init")
 
     lr = property(lambda self: self._lr)
     betas = property(lambda self: self._betas)

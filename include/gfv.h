@@ -30,7 +30,7 @@ extern "C" {
  * gfv_rowtile_tiles(M) = ceil(M / 64): the small-tile backward families fill one row per 32 rows); (2) a fused dw_partial launch
  * writes blocks 0 .. gfv_rowtile_dw_partials_m(M) - 1 ONLY (ABI 2 callers reduced gfv_rowtile_dw_partials() blocks: the blocks
  * beyond that count are NOT written and hold whatever the buffer held); (3) the status word has an asynchronous mirror
- * (gfv_status_mirror / gfv_status_publish) and gfv_adam_step_dev publishes it; Adam is one launch (state[8], gfv_adam_state_init;
+ * (gfv_status_mirror / gfv_status_publish) and gfv_adam_step_dev publishes it; Adam is one launch (state[16], gfv_adam_state_init;
  * gfv_adam_tick_dev / gfv_adam_update_dev removed); (4) new entry points
  * gfv_prep_stats / gfv_prep_apply, gfv_fvm_fwd_fused / gfv_fvm_bwd_fused, gfv_slice_token_attention_fwd / _bwd. */
 #define GFV_ABI_VERSION 3
@@ -221,6 +221,13 @@ int gfv_rowtile_tiles(int32_t M); /* number of 64-row tiles = rows of ln_partial
  * gfv_rowtile_tiles(M) otherwise.  The rows beyond that count are not written. */
 int gfv_rowtile_ln_rows(int32_t M);
 int gfv_rowtile_last_ln_rows(void);
+/* Dispatch limits (round 6): which kernel family takes a launch of M rows is decided by ONE table (csrc/gfv_limits.h lists the
+ * entries: GFV_CBWD_MAX_M, GFV_CFWD_TG2_MAX_M, GFV_CFWDP_MIN_M ...).  A limit takes the value of the environment variable of its
+ * name ONCE, at first use (or its built-in default); gfv_set_limit moves it afterwards (value < 0: back to environment / default) -
+ * process-wide, for tests and A/B tools.  gfv_limit_name(which) = the variable's name, NULL past the last entry. */
+int gfv_get_limit(int32_t which);
+int gfv_set_limit(int32_t which, int32_t value);
+const char* gfv_limit_name(int32_t which);
 int gfv_rowtile_chain(const gfv_rowtile_args_t* args, void* stream);
 /* which kernel the calling thread's last gfv_rowtile_chain launch took: 1 register-resident chain, 2 its ragged-shape
  * instantiation (0 was the generic LDS row-tile kernel, retired with ABI 2); + 4 when the products ran as split-fp16; + 8 when the column-owner persistent
@@ -538,8 +545,9 @@ int gfv_edge_attr(const float* x, int32_t ldx, const float* pos, const int32_t* 
 /* Round 6 - the input preparation as TWO launches (importer.py:114-130,166-178: was graph_norm_stats_ws + normalizer_update +
  * node_prep + edge_attr, and a state-restore copy in front of them in the solve loop, solve_with_grad_GPU.py:143).
  * gfv_prep_stats: stats[B,6] as gfv_graph_norm_stats_ws forms them (same partial sums, same fold order - by the workgroup of
- *   the graph that arrives last); workspace: gfv_prep_workspace_bytes(B) bytes, 8-byte aligned, ZERO before the first launch
- *   (every launch leaves its arrival counters at zero; one workspace per stream that may run this concurrently).
+ *   the graph that arrives last); workspace: gfv_prep_workspace_bytes(B) bytes, 8-byte aligned, its first 4096 bytes (the
+ *   arrival counters of up to 1024 graphs: B <= 1024) ZERO before the first launch - every launch leaves them at zero, so one
+ *   workspace serves batches of any size one after the other; one workspace per stream that may run this concurrently.
  *   x_raw != NULL: also copies the rows x[:, 0:12] -> x_raw [N,12] (a caller that normalises x in place needs the raw rows
  *   for the edge features).  mean_std != NULL: also derives the Normalizer's (mean[9], std[9]) from acc_count / acc_sum /
  *   acc_sq WITHOUT accumulating (= gfv_normalizer_update(accumulate = 0)); an accumulating step calls gfv_normalizer_update first.
@@ -555,15 +563,18 @@ int gfv_prep_apply(const float* x_raw, float* x_out, const int32_t* batch, const
                    const int32_t* er, float* out16, float* out15, int32_t E, void* stream);
 /* Fused Adam on the flat buffers (torch.optim.Adam defaults; pre_train_Adam.py:115,189-191).  Step counter and
  * hyper-parameters are DEVICE resident so that a captured hipGraph follows learning-rate changes:
- *   state[8] = {t = completed steps, bc1_hi, bc1_lo, sqrt(1 - beta2^(t+1)), arrival counter (int32, 0 between launches), 0, 0, 0}
- *              with bc1 = 1 - beta1^(t+1) as a (hi, lo) float pair: the bias corrections of the NEXT step, formed in double as
- *              torch's host code does.  gfv_adam_state_init writes them for a given t (once, and again after a checkpoint
- *              load or a change of the betas); every gfv_adam_step_dev launch then applies them with the lr of hyper[0] as it
- *              is at that moment and - its last workgroup to finish - advances t and forms the following step's (ABI 3: ONE launch
- *              per step; ABI 2 had state[4] and a tick launch in front, gfv_adam_tick_dev / gfv_adam_update_dev: removed)
- *   hyper[8] = {lr, beta1, beta2, eps, grad_scale (1 / world size), w_cont, w_mom, w_press}
+ *   state[16]: [0] t = completed steps; [1..2] 1 - beta1^(t+1) as a (hi, lo) float pair and [3] sqrt(1 - beta2^(t+1)): the bias
+ *              corrections of the NEXT step, formed in double as torch's host code does; [4] arrival counter (int32, 0 between
+ *              launches); [5] 1 - beta1, [6] 1 - beta2 rounded from double (torch: `value = 1 - beta2`); [8..11] the running
+ *              powers beta^(t+1) and [12..15] the betas as (hi, lo) pairs.  gfv_adam_state_init writes all of it for a given t and
+ *              the betas in DOUBLE (once, and again after a checkpoint load or a change of the betas); every gfv_adam_step_dev
+ *              launch then applies it with the lr of hyper[0] as it is at that moment and - its last workgroup to finish -
+ *              advances t and the powers by one multiplication (ABI 3: ONE launch per step; ABI 2 had state[4] and a tick
+ *              launch in front, gfv_adam_tick_dev / gfv_adam_update_dev: removed)
+ *   hyper[8] = {lr, beta1, beta2, eps, grad_scale (1 / world size), w_cont, w_mom, w_press}  (beta1 / beta2 here: the fp32 factors
+ *              of the moment decay, as torch's fp32 kernels take them)
  * The same launch publishes the status word once gfv_status_mirror has been called. */
-int gfv_adam_state_init(float* state, const float* hyper, float steps_done, void* stream);
+int gfv_adam_state_init(float* state, double beta1, double beta2, float steps_done, void* stream);
 int gfv_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, float* state, const float* hyper,
                       void* stream);
 int gfv_train_loss(const float* losses, int32_t B, float w_cont, float w_mom, float w_press, float* loss, float* gloss,

@@ -20,13 +20,13 @@ timeout 900 python3 $R/bench.py --meshes-per-gpu 8 --cpu-budget 0 --steps 10 --w
 timeout 900 python3 $R/bench.py --workload cavity --cells 5041 --cpu-budget 8 > $O/bench_cavity.json 2> $O/bench_cavity.err
 timeout 900 python3 $R/bench.py --workload poly --cpu-budget 8 > $O/bench_poly.json 2> $O/bench_poly.err
 # one form of the step only (command-list replay, split-fp16 products): what the in-step averages are taken from
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 $R/bench.py --cpu-budget 0 --graph list --skip-fp32-form --profile-steps 0 --skip-copy-rate > $O/prof.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 $R/bench.py --cpu-budget 0 --graph list --skip-fp32-form --profile-steps 0 --skip-copy-rate --skip-drop-in > $O/prof.log 2>&1
 find $O/prof -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats.csv \;
 rm -rf $O/prof
 python3 $R/profiles/instep_aggregate.py $O/kernel_stats.csv $O/kernel_stats_in_step.json $R/gen-fvgn-steady_amd/gfv/libgfv.so.srchash > $O/kernel_stats_in_step.txt
 # PMC passes: eager launches only, split-fp16 form only; the JSON line says how many steps ran (steps_executed)
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 900 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_$c -- python3 $R/bench.py --steps 5 --warmup 1 --graph off --min-time 0 --cpu-budget 0 --profile-steps 1 --skip-fp32-form --skip-copy-rate > $O/pmc_$c.log 2>&1
+  timeout 900 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_$c -- python3 $R/bench.py --steps 5 --warmup 1 --graph off --min-time 0 --cpu-budget 0 --profile-steps 1 --skip-fp32-form --skip-copy-rate --skip-drop-in > $O/pmc_$c.log 2>&1
 done
 NSTEPS=$(python3 -c "import json,sys; print([json.loads(l) for l in open('$O/pmc_FETCH_SIZE.log') if l.startswith('{')][-1]['steps_executed'])")
 python3 $R/profiles/pmc_aggregate.py $O $NSTEPS > $O/hbm_pmc.txt
@@ -34,7 +34,7 @@ rm -rf $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE
 # the same two passes with 8 meshes per GPU (BASELINE config 4's per-GPU load; the working set no longer fits the Infinity Cache)
 mkdir -p $O/b8
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 900 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/b8/pmc_$c -- python3 $R/bench.py --meshes-per-gpu 8 --steps 3 --warmup 1 --graph off --min-time 0 --cpu-budget 0 --profile-steps 1 --skip-fp32-form --skip-copy-rate > $O/b8/pmc_$c.log 2>&1
+  timeout 900 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/b8/pmc_$c -- python3 $R/bench.py --meshes-per-gpu 8 --steps 3 --warmup 1 --graph off --min-time 0 --cpu-budget 0 --profile-steps 1 --skip-fp32-form --skip-copy-rate --skip-drop-in > $O/b8/pmc_$c.log 2>&1
 done
 NSTEPS8=$(python3 -c "import json,sys; print([json.loads(l) for l in open('$O/b8/pmc_FETCH_SIZE.log') if l.startswith('{')][-1]['steps_executed'])")
 python3 $R/profiles/pmc_aggregate.py $O/b8 $NSTEPS8 > $O/hbm_pmc_b8.txt

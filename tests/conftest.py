@@ -44,3 +44,18 @@ def _clean_status_word(request):
         if L._status_word is not None:
             L._status_word[0] = 0
     yield
+
+
+@pytest.fixture
+def gfv_limits():
+    """`gfv_limits(GFV_CBWD_MAX_M=100000)`: move dispatch limits of the library (csrc/gfv_limits.h, gfv_set_limit) for one test."""
+    from gfv import lib as L
+    stack = []
+
+    def move(**kw):
+        ctx = L.limits(**kw)
+        ctx.__enter__()
+        stack.append(ctx)
+    yield move
+    for ctx in reversed(stack):
+        ctx.__exit__(None, None, None)

@@ -69,13 +69,13 @@ def _ln_sums(part, M):
 
 @pytest.mark.parametrize("M", [4000, 97, 1024, 33, 16384, 41003])
 @pytest.mark.parametrize("extras", [True, False])
-def test_small_tile_backward_edge_mlp(dev, M, extras, monkeypatch):
+def test_small_tile_backward_edge_mlp(dev, M, extras, gfv_limits):
     """EdgeBlock backward in its factored form: LayerNorm backward (+ the gathered and the plain addend of the incoming
-    gradient), the three transposed layers, residual.  (41 003 rows: beyond the default row limit of the family, which the
-    library reads per launch.)"""
+    gradient), the three transposed layers, residual.  (41 003 rows: beyond the default row limit of the family: moved for
+    the test, gfv_set_limit.)"""
     from gfv import lib as L, ops
     if M > 16384:
-        monkeypatch.setenv("GFV_CBWD_MAX_M", "100000")
+        gfv_limits(GFV_CBWD_MAX_M=100000)
     g = torch.Generator().manual_seed(M + 7 * extras)
     n_nodes = 300
     e = torch.randn(M, 128, generator=g)

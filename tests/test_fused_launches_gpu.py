@@ -96,9 +96,9 @@ def test_adam_launch_equals_torch_adam_bias_corrections():
     p0 = torch.randn(n, generator=g)
     p = p0.clone().cuda()
     m, v = torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
-    state = torch.zeros(8, device="cuda")
+    state = torch.zeros(16, device="cuda")
     hyper = torch.tensor([1e-3, 0.9, 0.999, 1e-8, 1.0, 0, 0, 0], device="cuda")
-    L.check(lib.gfv_adam_state_init(state.data_ptr(), hyper.data_ptr(), 0.0, L.stream_ptr()), "init")
+    L.check(lib.gfv_adam_state_init(state.data_ptr(), 0.9, 0.999, 0.0, L.stream_ptr()), "init")
     q = torch.nn.Parameter(p0.clone().cuda())
     opt = torch.optim.Adam([q], lr=1e-3)
     for step in range(40):
@@ -113,6 +113,7 @@ def test_adam_launch_equals_torch_adam_bias_corrections():
     torch.cuda.synchronize()
     assert float(state[0]) == 40.0 and int(state.view(torch.int32)[4]) == 0
     st = opt.state[q]
+    # (torch: exp_avg.lerp_(grad, 1 - beta1); exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1 - beta2) with 1 - beta in double)
     assert float((m - st["exp_avg"]).abs().max()) <= 2e-6 * float(st["exp_avg"].abs().max())
     assert float((v - st["exp_avg_sq"]).abs().max()) <= 2e-6 * float(st["exp_avg_sq"].abs().max())
     assert float((p - q.detach()).abs().max()) < 40 * 1e-3 * 2e-5

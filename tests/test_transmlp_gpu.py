@@ -33,11 +33,11 @@ def _ref_fwd(P, x, res):
 
 
 @pytest.mark.parametrize("M,small", [(3000, 1), (129, 1), (33, 1), (5184, 1), (3000, 0), (129, 0), (25479, 1)])
-def test_transolver_chain_forward_and_backward_in_one_launch_each(M, small, monkeypatch):
+def test_transolver_chain_forward_and_backward_in_one_launch_each(M, small, gfv_limits):
     """small = 1: launches of up to 16 384 rows run the forward chain on its small-tile form (csrc/ctrans.hip); 0: the 128-row-block
-    kernel of transmlp.hip at every size (the library reads the switch per launch)."""
+    kernel of transmlp.hip at every size (the switch is a dispatch limit: gfv_set_limit)."""
     from gfv import lib as L, ops
-    monkeypatch.setenv("GFV_CTRANS", str(small))
+    gfv_limits(GFV_CTRANS=small)
     dev = torch.device("cuda")
     P, x, res, g = _setup(M, M)
     d = lambda t: t.to(dev).contiguous()
