@@ -11,10 +11,6 @@ enum {
   GFV_LIM_CFWD_RAG_MAX_M,     // GFV_CFWD_RAG_MAX_M  16384  narrow / ragged first layers and the decoder
   GFV_LIM_CTRANS_ON,          // GFV_CTRANS          1      the small-tile Transolver chains (ctrans.hip)
   GFV_LIM_CTRANS_MAX_M,       // GFV_CTRANS_MAX_M    16384
-  GFV_LIM_CFWDP_MIN_M,        // GFV_CFWDP_MIN_M     12000  the PERSISTENT small-tile forward (cfwdp.hip) from this many rows ...
-  GFV_LIM_CFWDP_MAX_M,        // GFV_CFWDP_MAX_M     60000  ... up to this many
-  GFV_LIM_CFWDP_EDGE,         // GFV_CFWDP_EDGE      0      ... also for the factored EdgeBlock's launches (gathered addend)
-  GFV_LIM_CFWDP_WGS,          // GFV_CFWDP_WGS       256    workgroups of a persistent launch (one per CU)
   GFV_LIM_COUNT
 };
 int gfv_internal_limit(int which);

@@ -271,12 +271,18 @@ __global__ __launch_bounds__(256) void prep_stats_kernel(const float* __restrict
   __syncthreads();
   if (!last) return;
   __threadfence();
+  // the NORM_NB x 6 partial sums: ONE round trip (a thread each) into LDS, then folded k = 0 .. NORM_NB - 1 in order as
+  // graph_norm_final_kernel does (its 2 x 64 dependent loads per thread were most of that launch's 6 us)
+  __shared__ double fold[NORM_NB * 6];
+  for (int i = tid; i < NORM_NB * 6; i += 256)
+    fold[i] = __hip_atomic_load(ws + (size_t)b * NORM_NB * 6 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
   if (tid < 3) {
     const double cnt = fmax((double)(end - beg), 1.0);
     double ss = 0.0, qq = 0.0;
     for (int k = 0; k < NORM_NB; ++k) {
-      ss += __hip_atomic_load(ws + ((size_t)b * NORM_NB + k) * 6 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      qq += __hip_atomic_load(ws + ((size_t)b * NORM_NB + k) * 6 + 3 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      ss += fold[k * 6 + tid];
+      qq += fold[k * 6 + 3 + tid];
     }
     const double mean = ss / cnt, var = fmax(qq / cnt - mean * mean, 0.0);
     stats[6 * b + tid] = (float)mean;

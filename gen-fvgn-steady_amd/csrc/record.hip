@@ -1,4 +1,5 @@
 // Native command list (include/gfv.h gfv_record_*): the launches of one recorded step, replayed from C.  See gfv_launch.h.
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -144,3 +145,47 @@ extern "C" int gfv_stream_wait(void* waiter, void* waited) {
   if (GfvRecorder* r = gfv_rec_active()) gfv_rec_push(r, run_wait, &b, sizeof(b), (hipStream_t)waiter);
   return GFV_OK;
 }
+
+// Issue order of a recorded step (round 6).  A step is recorded in the order the host issued it: the main stream's launches with the
+// side stream's bursts (a block's weight-gradient launches and their reduction: 5 - 10 commands) in between.  On a small mesh the
+// main stream's kernels last 5 - 20 us and the host needs ~4 us per command, so while it issues a burst the main queue runs dry
+// (profiles/r06_timeline_cavity_unmerged.txt: holes of 30 - 110 us in front of the next block's first launch).  This pass moves every
+// run of side-stream commands (its leading "side waits for main" included) behind up to `k` of the main-stream launches that follow it,
+// but never across a command in which the main stream waits (a join), and only by a third of the distance to the next join (a burst
+// right in front of a join - the weight images at the start of a step - stays where it is).  Moving a burst later only ADDS ordering:
+// its wait then covers more of the main stream, and nothing on the main stream waits for it before the join.  Returns the number of
+// runs moved.
+extern "C" int gfv_record_delay_side(int64_t handle, void* main_stream, int32_t k) {
+  GfvRecorder* r = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_lists.find(handle);
+    if (it == g_lists.end()) return GFV_ERR_ARG;
+    r = it->second;
+  }
+  if (k <= 0) return 0;
+  const hipStream_t ms = (hipStream_t)main_stream;
+  auto& c = r->cmds;
+  const size_t n = c.size();
+  auto is_join = [&](size_t i) { return c[i].st == ms && c[i].run == run_wait; };
+  int moved_runs = 0;
+  size_t i = 0;
+  while (i < n) {
+    if (c[i].st == ms) { ++i; continue; }
+    size_t j = i;
+    while (j < n && c[j].st != ms) ++j;          // the run [i, j)
+    size_t d = 0, t = j;
+    while (t < n && !is_join(t)) { if (c[t].st == ms) ++d; ++t; }   // main-stream launches up to the next join
+    size_t want = d / 3 < (size_t)k ? d / 3 : (size_t)k;
+    t = j;
+    size_t got = 0;
+    while (t < n && got < want && c[t].st == ms && !is_join(t)) { ++t; ++got; }
+    if (got > 0) {
+      std::rotate(c.begin() + i, c.begin() + j, c.begin() + t);
+      ++moved_runs;
+    }
+    i = t > j ? t : j;
+  }
+  return moved_runs;
+}
+

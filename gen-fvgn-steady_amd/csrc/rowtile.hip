@@ -74,8 +74,7 @@ namespace {
 struct LimitDef { const char* env; int dflt; };
 const LimitDef k_limits[GFV_LIM_COUNT] = {
     {"GFV_CBWD", 1},        {"GFV_CBWD_MAX_M", 25000},      {"GFV_CFWD", 1},          {"GFV_CFWD_MAX_M", 100000},
-    {"GFV_CFWD_TG2_MAX_M", 100000}, {"GFV_CFWD_RAG_MAX_M", 16384}, {"GFV_CTRANS", 1}, {"GFV_CTRANS_MAX_M", 16384},
-    {"GFV_CFWDP_MIN_M", 12000}, {"GFV_CFWDP_MAX_M", 60000}, {"GFV_CFWDP_EDGE", 0},    {"GFV_CFWDP_WGS", 256}};
+    {"GFV_CFWD_TG2_MAX_M", 100000}, {"GFV_CFWD_RAG_MAX_M", 16384}, {"GFV_CTRANS", 1}, {"GFV_CTRANS_MAX_M", 16384}};
 int g_limit[GFV_LIM_COUNT];
 bool g_limit_set[GFV_LIM_COUNT];
 std::once_flag g_limit_once;
@@ -127,7 +126,6 @@ extern "C" int gfv_rowtile_chain(const gfv_rowtile_args_t* args, void* stream) {
 }
 int gfv_internal_lin1_try(const gfv_rowtile_args_t* a, int lowp, hipStream_t stream, int dry);   // lin1.hip
 int gfv_internal_cfwd_try(const gfv_rowtile_args_t* a, int lowp, hipStream_t stream, int dry);   // cfwd.hip
-int gfv_internal_cfwdp_try(const gfv_rowtile_args_t* a, int lowp, hipStream_t stream, int dry);  // cfwdp.hip: its persistent form
 bool gfv_internal_wimg_form_ok(const float* wmax);                                               // wimg.hip
 int gfv_internal_cbwd_try(const gfv_rowtile_args_t* a, int lowp, hipStream_t stream, int dry);   // cbwd.hip
 // the column-owner small-tile forward (cfwd.hip) reads the LayerNorm width from its arguments
@@ -135,8 +133,6 @@ static int cfwd_try(const gfv_rowtile_args_t* args, int lowp, hipStream_t stream
   if (args->nlayers != 3 || (args->fin_op != GFV_FIN_LN && args->fin_op != GFV_FIN_PLAIN)) return 0;
   gfv_rowtile_args_t local = *args;
   local.hidden = g_hidden;
-  // mid-size launches (a CU runs several 32-row tiles): the persistent form keeps the weight slices in registers across tiles
-  if (gfv_internal_cfwdp_try(&local, lowp, stream, dry)) return 1;
   return gfv_internal_cfwd_try(&local, lowp, stream, dry);
 }
 // the column-owner small-tile backward (cbwd.hip): the dX chain behind a LayerNorm backward, no fused weight gradients

@@ -38,7 +38,8 @@ _QUERIES = frozenset((
     "gfv_weight_image_bytes", "gfv_normalizer_blocks", "gfv_slice_softmax_bwd_blocks", "gfv_profile_enable",
     "gfv_profile_collect", "gfv_profile_reset", "gfv_profile_set_sizes", "gfv_status_flags", "gfv_status_mirror", "gfv_prep_workspace_bytes", "gfv_get_limit", "gfv_set_limit", "gfv_limit_name", "gfv_rowtile_dw_partials", "gfv_rowtile_dw_partials_m",
     "gfv_rowtile_fuses_dw", "gfv_graph_norm_workspace_bytes", "gfv_plan_create", "gfv_plan_destroy", "gfv_plan_table", "gfv_plan_sizes",
-    "gfv_record_begin", "gfv_record_count", "gfv_record_end", "gfv_record_length", "gfv_record_replay", "gfv_record_free"))
+    "gfv_record_begin", "gfv_record_count", "gfv_record_end", "gfv_record_length", "gfv_record_replay", "gfv_record_free",
+    "gfv_record_delay_side"))
 
 
 class CommandList:
@@ -218,6 +219,11 @@ class record:
             lib = L.load(raw=True)
             self.cl.n_native = max(lib.gfv_record_count(), 0)
             self.cl.native = int(lib.gfv_record_end())
+            # issue order: side-stream bursts behind a few of the main stream's launches (include/gfv.h gfv_record_delay_side) -
+            # only for lists without host-side commands in between (their positions count native launches)
+            delay = int(os.environ.get("GFV_SIDE_DELAY", "0"))
+            if delay > 0 and self.cl.native and not self.cl.cmds and not (exc and exc[0] is not None):
+                self.cl.delayed = lib.gfv_record_delay_side(self.cl.native, self.cl.main.cuda_stream, delay)
             if exc and exc[0] is not None and self.cl.native:
                 lib.gfv_record_free(self.cl.native)
                 self.cl.native = 0

@@ -155,9 +155,10 @@ class Engine:
         # the FORWARD chain has a small-tile form as well (csrc/ctrans.hip, up to GFV_CTRANS_MAX_M rows): fused at every size
         self._trans_fuse_fwd_small = os.environ.get("GFV_CTRANS", "1") != "0"
         # up to this many token chunks per graph the attention workgroups sum the chunk partials themselves (the kernels walk them,
-        # eight loads in flight) instead of a pre-reduction launch of its own: 4 launches per step fewer on meshes below ~6 k nodes
-        # (round 6); above, the per-graph pre-reduction is faster (round 3: 12 -> 7 us at 400 chunks)
-        self._slice_walk_max = int(os.environ.get("GFV_SLICE_WALK_MAX", "96"))
+        # eight loads in flight) instead of a pre-reduction launch of its own.  Measured in round 6 on the 5 k-cell cavity (81 chunks):
+        # the attention launch 6.7 -> 17.8 us forward, 11 -> 21 us backward, against 4.6 us for the pre-reduction launch it saves
+        # (profiles/r06_timeline_cavity_merged_first.txt): off
+        self._slice_walk_max = int(os.environ.get("GFV_SLICE_WALK_MAX", "0"))
         self._trans_reduce_merge = os.environ.get("GFV_TRANS_REDUCE_MERGE", "1") != "0"
         # the end of the backward: how many of the trailing weight-gradient flushes run on the MAIN stream (GFV_TAIL_MAIN: 1 = the last
         # encoder's, 2 = both encoders', 3 = the first GnBlock's too) and how the first GnBlock's flush is split between the streams
@@ -336,7 +337,10 @@ class Engine:
         if phase == "fwd":
             # one power-of-two scale for all weight images of this step, from max|W| over every weight matrix
             # (GFV_ABSMAX_WS=1: one launch - the maximum is written by the workgroup that arrives last, no fill in front)
-            if os.environ.get("GFV_ABSMAX_WS", "1") == "1":   # (round 5 measured it time-neutral; default since round 6: one launch fewer)
+            # (GFV_ABSMAX_WS=1: one launch, the maximum written by the workgroup that arrives last - 13.7 us against 4.7 + 5.7 for the
+            # fill + atomic form in the step's timeline, profiles/r06_timeline_cavity_merged_first.txt: a last-arriver costs more than
+            # the kernel boundary it saves.  Opt-in)
+            if os.environ.get("GFV_ABSMAX_WS", "0") == "1":
                 L.check(L.load().gfv_weight_absmax_ws(self._wi_abs[0].data_ptr(), self._wi_abs[1], self._wmax.data_ptr(),
                                                       self._wi_abs_ws.data_ptr(), L.stream_ptr()), "gfv_weight_absmax_ws")
             else:

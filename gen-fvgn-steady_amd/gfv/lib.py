@@ -224,6 +224,7 @@ _SIGNATURES = {
     "gfv_record_replay": (C.c_int, [C.c_int64, C.c_int32, C.c_int32]),
     "gfv_record_free": (C.c_int, [C.c_int64]),
     "gfv_stream_wait": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "gfv_record_delay_side": (C.c_int, [C.c_int64, C.c_void_p, C.c_int32]),
 }
 
 

@@ -776,6 +776,11 @@ int gfv_record_length(int64_t handle);
 int gfv_record_replay(int64_t handle, int32_t first, int32_t last);
 int gfv_record_free(int64_t handle);
 int gfv_stream_wait(void* waiter_stream, void* waited_stream);
+/* Reorders a recorded list (round 6): every run of commands of other streams than `main_stream` moves behind up to k of the main
+ * stream's launches that follow it - never across a command in which the main stream waits, and by at most a third of the distance
+ * to it.  A later position only adds ordering (the run's leading wait then covers more of the main stream).  For steps whose main
+ * stream runs dry while the host issues a side-stream burst (small meshes).  Returns the number of runs moved, or GFV_ERR_ARG. */
+int gfv_record_delay_side(int64_t handle, void* main_stream, int32_t k);
 
 #ifdef __cplusplus
 }

@@ -83,15 +83,12 @@ def _run(M, segs, Pd, wi, fam, *, res=None, padd=None, nores=False, stats=True, 
 
 
 # 32-row tiles on 8 waves (partial last tile; one tile; many) - the default at every size - and 64-row tiles on 4 waves (dispatch
-# limit GFV_CFWD_TG2_MAX_M: launches above it take the 64-row tiles); pers: the PERSISTENT form (csrc/cfwdp.hip: min(256, tiles)
-# workgroups keep their weight slices in registers and walk the tiles) at every size instead of from 12 000 rows
-@pytest.mark.parametrize("M,tall,pers", [(777, 0, 0), (32, 0, 0), (20001, 0, 0), (41003, 0, 0), (41003, 1, 0), (777, 1, 0), (97, 1, 0),
-                                         (777, 0, 1), (33, 0, 1), (8200, 0, 1), (20001, 0, 1), (41003, 0, 1)])
-def test_small_tile_forward_node_and_edge_shapes(M, tall, pers, gfv_limits):
+# limit GFV_CFWD_TG2_MAX_M: launches above it take the 64-row tiles)
+@pytest.mark.parametrize("M,tall", [(777, 0), (32, 0), (20001, 0), (41003, 0), (41003, 1), (777, 1), (97, 1)])
+def test_small_tile_forward_node_and_edge_shapes(M, tall, gfv_limits):
     from gfv import lib as L, ops
     if tall:
         gfv_limits(GFV_CFWD_TG2_MAX_M=0)
-    gfv_limits(GFV_CFWDP_MIN_M=1 if pers else 10 ** 9, GFV_CFWDP_MAX_M=10 ** 9, GFV_CFWDP_EDGE=pers)
     g = torch.Generator().manual_seed(M)
     d = lambda t: t.cuda().contiguous()
     # (1) NodeBlock: [nbm 64 | x 128], residual x, rows over three decades
@@ -247,42 +244,3 @@ def test_small_tile_forward_decoder_shape(M):
         assert rel(mine, ref) < TOL, (name, rel(mine, ref))
         assert rel(mine, other) < 4e-6, (name, rel(mine, other))
 
-
-@pytest.mark.parametrize("M", [33, 8200, 25479, 41003])
-def test_persistent_small_tile_forward_equals_the_per_tile_one_bit_for_bit(M, gfv_limits):
-    """csrc/cfwdp.hip against csrc/cfwd.hip on the three shapes both take (NodeBlock [64 | 128], factored EdgeBlock with the gathered
-    addend, plain 128): the same arithmetic per tile, so every output and saved tensor is IDENTICAL - whichever workgroup walks a
-    tile, however many tiles it walks (8 200 rows = 257 tiles on 256 workgroups: one workgroup takes two)."""
-    from gfv import lib as L, ops
-    g = torch.Generator().manual_seed(M)
-    d = lambda t: t.cuda().contiguous()
-    nbm = torch.randn(M, 64, generator=g)
-    x = torch.randn(M, 128, generator=g) * torch.logspace(-2, 1, M)[:, None]
-    N = max(8, M // 3)
-    pab = torch.randn(N, 256, generator=g)
-    si, ri = torch.randint(0, N, (M,), generator=g), torch.randint(0, N, (M,), generator=g)
-    res = {}
-    for pers in (0, 1):
-        with L.limits(GFV_CFWDP_MIN_M=1 if pers else 10 ** 9, GFV_CFWDP_MAX_M=10 ** 9, GFV_CFWDP_EDGE=pers):
-            out = []
-            gg = torch.Generator().manual_seed(5)
-            P = _params(gg, 192)
-            Pd = {k: d(v) for k, v in P.items()}
-            xd = d(x)
-            a, pa = _run(M, [ops.Seg(d(nbm)), ops.Seg(xd)], Pd, _wi([P["W1"], P["W2"], P["W3"]]), 0, res=xd)
-            out += [t for t in a.values() if t is not None]
-            Wfull = torch.randn(128, 384, generator=gg) * 0.06
-            P = _params(gg, 128)
-            P["W1"] = Wfull[:, 256:384].clone()
-            Pd = {k: d(v) for k, v in P.items()}
-            a, pb = _run(M, [ops.Seg(xd)], Pd, _wi([Wfull, P["W2"], P["W3"]]), 0, res=xd, padd=(d(pab), d(si.int()), d(ri.int())),
-                         nores=True, w1=d(Wfull)[:, 256:384])
-            out += [t for t in a.values() if t is not None]
-            P = _params(gg, 128)
-            Pd = {k: d(v) for k, v in P.items()}
-            a, pc = _run(M, [ops.Seg(xd)], Pd, _wi([P["W1"], P["W2"], P["W3"]]), 0, stats=False)
-            out += [t for t in a.values() if t is not None]
-            assert pa & 64 and pb & 64 and pc & 64
-            res[pers] = out
-    for i, (a, b) in enumerate(zip(res[0], res[1])):
-        assert torch.equal(a, b), (M, i, float((a - b).abs().max()))

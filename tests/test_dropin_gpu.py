@@ -145,8 +145,9 @@ def test_gfv_adam_equals_torch_adam_and_exchanges_state():
     m2.load_state_dict(mg.state_dict())
     o2 = Adam(m2.parameters(), lr=1.0)
     o2.load_state_dict(sd)
-    g2 = tuple(g.clone().to("cuda") for g in cases.make_graphs("cyl_cavity_b2"))
-    _driver_steps(mg, params, og, graphs, 2)
+    g1 = tuple(g.clone().to("cuda") for g in cases.make_graphs("cyl_cavity_b2"))   # (fresh batches for both: `graphs` holds the
+    g2 = tuple(g.clone().to("cuda") for g in cases.make_graphs("cyl_cavity_b2"))   # normalised node state of its last iteration)
+    _driver_steps(mg, params, og, g1, 2)
     _driver_steps(m2, params, o2, g2, 2)
     for a, b in zip(mg.parameters(), m2.parameters()):
         assert torch.equal(a, b)

@@ -142,3 +142,25 @@ def test_merged_reductions_and_walked_token_sums_agree_with_the_separate_launche
     for n, g in res[False][1].items():
         err = float((res[True][1][n] - g).abs().max())
         assert err <= 2e-6 * float(g.abs().max()) + 2e-7 * gscale, (n, err)
+
+
+def test_recorded_step_with_delayed_side_bursts_is_bit_identical(monkeypatch):
+    """gfv_record_delay_side: the recorded step with every side-stream burst issued behind up to six of the main stream's
+    following launches - a different ISSUE order of the same launches with the same dependencies: parameters, moments, losses and
+    fields after eight steps equal those of the list as recorded, bit for bit."""
+    from gfv.trainer import TrainStep
+    res = {}
+    for delay in (0, 6):
+        monkeypatch.setenv("GFV_SIDE_DELAY", str(delay))
+        model, params = _model()
+        graphs = tuple(g.clone().to("cuda") for g in cases.make_graphs("cyl_b3"))
+        ts = TrainStep(model, graphs, use_graph="list")
+        for _ in range(8):
+            ts.step()
+        torch.cuda.synchronize()
+        cl = ts._graphs[("list", False, False)][0] if ("list", False, False) in ts._graphs else next(iter(ts._graphs.values()))[0]
+        res[delay] = ([ts.loss.clone(), ts.losses.clone(), ts.uvp_node.clone(), ts.flat_p.clone(), ts.flat_m.clone(), ts.flat_v.clone()],
+                      getattr(cl, "delayed", 0))
+    assert res[6][1] > 0 and res[0][1] == 0      # the pass found runs to move
+    for a, b in zip(res[0][0], res[6][0]):
+        assert torch.equal(a, b)
