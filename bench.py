@@ -481,6 +481,10 @@ def main():
                              "fp32_equiv_tflops": round(tf, 3) if mfma_peak else None, "algorithmic_gbs": round(gbs, 1),
                              "frac_mfma": round(f_mfma, 4), "frac_hbm": round(f_hbm, 4),
                              "algorithmic_bytes_per_launch": round(by / n), "frac_isolated": round(ach / peak, 4)})
+            if copy_rate:
+                # against what THIS box's memory side delivers (a 1 GiB device-to-device copy in this run: 4.8 - 5.2 TB/s = 0.60 - 0.65 of
+                # the 8 TB/s spec on this pool): the fraction a bandwidth-bound kernel can be held to
+                roof_all[-1]["frac_of_copy_rate"] = round(gbs / copy_rate, 4)
             if kind == 3:   # gathers: priced by DISTINCT source rows; what L2 / Infinity Cache serve beside it
                 roof_all[-1]["l2_side_gbs"] = round(fl / (ms * 1e-3) / 1e9, 1)
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")

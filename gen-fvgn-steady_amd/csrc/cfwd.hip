@@ -20,16 +20,15 @@
 // 4 barriers per tile instead of 13; per wave 48 TG / 2 MFMAs per 128-deep layer.  Hidden activations are split behind the fixed
 // scale CF_SH (colchain_kernel.h CC_SH: GELU outputs in [2^-4, 2^11] keep fp32 accuracy; beyond 2^11 GFV_FLAG_CHAIN_RANGE is
 // raised), the layer INPUT rows behind their own power-of-two row scale as everywhere else.
-// Price: every tile pulls the three images (160 - 224 KB) from L2 into registers, and a CU fetches 25 - 35 B / clock from L2
-// (profiles/r05_launch_floor.txt): where a CU runs several tiles the weight stream is what the launch waits for.  Measured
-// (profiles/r05_cfwd.txt, in-step averages): 5 k-row launches 11.9 us against 25 (NodeBlock), 17.5 against 27 (EdgeBlock, 10 k
-// rows), 12.0 against 22 (encoder); 25 k-row NodeBlock launches 30.9 us with 32-row tiles, 35.6 with 64-row tiles (84 KB of LDS:
-// one workgroup per CU) against 35 for the row-owner chain; 75 k-row EdgeBlock launches 78 - 83 us against 80.  So: 32-row tiles
-// up to GFV_CFWD_TG2_MAX_M = 40 000 rows, 64-row tiles up to GFV_CFWD_MAX_M = 100 000 rows (edge-level launches of 50 k rows:
-// 3.26 against 3.35 ms per step on a 25 k-cell mesh, of 75 k rows: 3.67 against 3.70 on the headline mesh - and, re-measured with the
-// round's final kernels, 32-row tiles there too: see the launcher; beyond that - 8
-// meshes per GPU - the row-owner chain, whose 64 rows share one weight stream through LDS), the encoders' narrow inputs up to
-// GFV_CFWD_RAG_MAX_M = 16 384 rows (33 us against 30 at 25 k rows).
+// Price: every tile pulls the three images (160 - 224 KB) from L2 into registers.  Measured (profiles/r05_cfwd.txt, in-step
+// averages): 5 k-row launches 11.9 us against 25 (NodeBlock), 17.5 against 27 (EdgeBlock, 10 k rows), 12.0 against 22 (encoder);
+// 25 k-row NodeBlock launches 30.9 us against 35 for the row-owner chain; 75 k-row EdgeBlock launches 78 - 83 us against 80.
+// What bounds the mid-size launches is NOT that weight stream (round 6: a persistent form with the slices resident in registers
+// across tiles - profiles/tools/cfwdp - took 31.5 - 32.3 us where this kernel takes 29 - 30.6: the tile got 40 % shorter, and one
+// workgroup per CU instead of two doubled the rounds) but the latency of a tile's dependent chain times the number of rounds
+// (797 tiles on 2 x 256 slots).  32-row tiles on 8 waves at every size up to GFV_CFWD_MAX_M = 100 000 rows (beyond - 8 meshes per
+// GPU - the row-owner chain, whose 64 rows share one weight stream through LDS); the encoders' narrow inputs and the decoder up to
+// GFV_CFWD_RAG_MAX_M = 16 384 rows.  (A 64-row form on 4 waves existed through round 5: slower at every size, removed.)
 #include <cstdlib>
 
 #include "tchain_kernel.h"
@@ -377,22 +376,18 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void cfwd_kernel(const gf
 inline bool cf_al16(const void* p) { return (reinterpret_cast<size_t>(p) & 15) == 0; }
 
 template <int KT0, int N0, bool PADD, bool RAGIN, bool FINLN = true>
-void cf_launch(const gfv_rowtile_args_t& a, int tg, int lowp, hipStream_t stream) {
+void cf_launch(const gfv_rowtile_args_t& a, int lowp, hipStream_t stream) {
   int* st = gfv_internal_status_ptr();
+  // 32-row tiles on 8 waves of 16 columns at every size.  (The 64-row form - 4 waves of 32 columns, selectable by row count through
+  // round 5 - measured WORSE at every size it was tried at with the final kernels: -1.8 % / -0.6 % / -0.6 % of the step at 45 k / 51 k
+  // / 75 k edge rows, 35.6 against 30.9 us at 25 k node rows (profiles/r05_thresholds.txt, r05_cfwd.txt); its instantiations were
+  // removed in round 6.)
+  constexpr int tg = 2;
   const int tiles = (a.M + 16 * tg - 1) / (16 * tg);
-  // 32-row tiles on 8 waves of 16 columns, 64-row tiles on 4 waves of 32 columns (measured, profiles/r05_cfwd.txt: 8 waves on the
-  // small tiles 1.644 against 1.659 ms on the 5 k-cell mesh and 3.62 against 3.64 on the 50 k-cell one; 8 waves on the 64-row
-  // tiles of 50 k-row edge launches 3.30 against 3.26)
-  const dim3 grid(PADD ? gfv_xcd_grid(tiles) : tiles), blk(tg == 2 ? 512 : 256);
-#define CF_TG(LP)                                                                                              \
-  do {                                                                                                         \
-    if (tg == 2) GFV_LAUNCH((cfwd_kernel<KT0, N0, 2, PADD, LP, RAGIN, 8, FINLN>), grid, blk, 0, stream, a, st); \
-    else GFV_LAUNCH((cfwd_kernel<KT0, N0, 4, PADD, LP, RAGIN, 4, FINLN>), grid, blk, 0, stream, a, st);        \
-  } while (0)
-  if (lowp == 2) CF_TG(2);
-  else if (lowp) CF_TG(1);
-  else CF_TG(0);
-#undef CF_TG
+  const dim3 grid(PADD ? gfv_xcd_grid(tiles) : tiles), blk(512);
+  if (lowp == 2) GFV_LAUNCH((cfwd_kernel<KT0, N0, 2, PADD, 2, RAGIN, 8, FINLN>), grid, blk, 0, stream, a, st);
+  else if (lowp) GFV_LAUNCH((cfwd_kernel<KT0, N0, 2, PADD, 1, RAGIN, 8, FINLN>), grid, blk, 0, stream, a, st);
+  else GFV_LAUNCH((cfwd_kernel<KT0, N0, 2, PADD, 0, RAGIN, 8, FINLN>), grid, blk, 0, stream, a, st);
 }
 
 }  // namespace
@@ -404,9 +399,6 @@ int gfv_internal_cfwd_try(const gfv_rowtile_args_t* a, int lowp, hipStream_t str
   if (!gfv_internal_status_ptr()) return 0;   // (the kernels raise their range flag there)
   const int on = gfv_internal_limit(GFV_LIM_CFWD_ON);
   const int max_m = gfv_internal_limit(GFV_LIM_CFWD_MAX_M);
-  // 32-row tiles at every size the family takes: 64-row tiles (GFV_CFWD_TG2_MAX_M below the launch's rows) measured -1.8 % / -0.6 % /
-  // -0.6 % of the step WORSE at 45 k / 51 k / 75 k edge rows with the round's final kernels (profiles/r05_thresholds.txt)
-  const int tg2_max = gfv_internal_limit(GFV_LIM_CFWD_TG2_MAX_M);
   const int rag_max = gfv_internal_limit(GFV_LIM_CFWD_RAG_MAX_M);
   if (!on || a->nlayers != 3 || a->M > max_m || a->M < 1 || (a->flags & (GFV_CHAIN_ROW_OWNER | GFV_CHAIN_COLUMN_OWNER))) return 0;
   // the decoder's shape: no LayerNorm, a last layer of <= 16 columns, nothing else around it
@@ -432,7 +424,6 @@ int gfv_internal_cfwd_try(const gfv_rowtile_args_t* a, int lowp, hipStream_t str
   for (int i = 0; i < a->nseg; ++i)
     if (a->seg[i].idx || a->seg[i].csr_rowptr || a->seg[i].csr_scale || a->seg[i].save) return 0;
   const int K0 = a->layer[0].K;
-  const int tg = a->M <= tg2_max ? 2 : 4;
   int shape = -1;   // 0: [64 | 128] (NodeBlock), 1: [128] + gathered addend (factored EdgeBlock), 2: [128] plain, 3: one narrow ragged segment
   auto plain = [&](int i, int width) {
     const gfv_seg_t& s = a->seg[i];
@@ -452,10 +443,10 @@ int gfv_internal_cfwd_try(const gfv_rowtile_args_t* a, int lowp, hipStream_t str
   }
   if (shape < 0) return 0;
   if (dry) return 1;
-  if (shape == 0) cf_launch<6, 4, false, false>(*a, tg, lowp, stream);
-  else if (shape == 1) cf_launch<4, 8, true, false>(*a, tg, lowp, stream);
-  else if (shape == 2) cf_launch<4, 8, false, false>(*a, tg, lowp, stream);
-  else if (shape == 4) cf_launch<4, 8, false, false, false>(*a, tg, lowp, stream);
-  else cf_launch<1, 2, false, true>(*a, tg, lowp, stream);
+  if (shape == 0) cf_launch<6, 4, false, false>(*a, lowp, stream);
+  else if (shape == 1) cf_launch<4, 8, true, false>(*a, lowp, stream);
+  else if (shape == 2) cf_launch<4, 8, false, false>(*a, lowp, stream);
+  else if (shape == 4) cf_launch<4, 8, false, false, false>(*a, lowp, stream);
+  else cf_launch<1, 2, false, true>(*a, lowp, stream);
   return 1;
 }

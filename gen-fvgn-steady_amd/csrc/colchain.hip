@@ -33,11 +33,8 @@ static bool cc_bwd_ok(const gfv_rowtile_args_t* a) {
   static const int min_m = cc_env("GFV_COLCHAIN_BWD_MIN_M", 2048);
   if (a->flags & GFV_CHAIN_ROW_OWNER) return false;
   if (!(a->flags & GFV_CHAIN_COLUMN_OWNER) && (!on || a->M < min_m)) return false;
-  if (!a->dw_partial || a->dw_partial_stride < (a->dw_in ? GFV_DW_FUSED_FLOATS_IN : GFV_DW_FUSED_FLOATS) || !a->in_stats || !a->wmax) return false;
-  if (a->dw_in && (!al16(a->dw_in) || (a->dw_in_ld & 3) || a->dw_in_ld < 128)) return false;
-  // (the trailing first-layer weight gradient keeps one scale per tile of a workgroup in LDS: 256 tiles of 64 rows each)
-  if (a->dw_in && ((a->M + 63) / 64 + cc_cus() - 1) / cc_cus() + 1 > 256) return false;
-  if (a->dw_in && !a->layer[1].save) return false;   // (it reads the gz1 rows the tile loop stored)
+  if (!a->dw_partial || a->dw_partial_stride < GFV_DW_FUSED_FLOATS || !a->in_stats || !a->wmax) return false;
+  if (a->dw_in) return false;   // (the first Linear's weight gradient fused as well: removed in round 6, include/gfv.h)
   // (two layers: the input needs no gradient - the encoders; out[0] then receives gz1, the last layer's op is the second DGELU)
   const bool noout = a->nlayers == 2;
   // recompute form: the forward images of the second and third Linear are given, z2 (layer[0].aux) and y (in_aux) are not read
@@ -95,15 +92,13 @@ int gfv_internal_colchain_try(const gfv_rowtile_args_t* a, hipStream_t stream) {
 #define CB_K(...) GFV_LAUNCH((colchain_bwd_kernel<__VA_ARGS__>), grid, blk, 0, stream, *a, st)
 #define CB_LAUNCH(LOWP, RC)                                                                                                      \
   do {                                                                                                                           \
-    if (a->nlayers == 2) CB_K(LOWP, false, false, false, true, RC);                                                              \
-    else if (a->layer[2].N == 192 && a->gadd) CB_K(LOWP, true, false, true, false, RC);                                          \
-    else if (a->layer[2].N == 192) CB_K(LOWP, false, false, true, false, RC);                                                    \
-    else if (a->gadd && a->dw_in) CB_K(LOWP, true, true);                                                                        \
-    else if (a->gadd) CB_K(LOWP, true, false, false, false, RC);                                                                 \
-    else if (a->dw_in) CB_K(LOWP, false, true);                                                                                  \
-    else CB_K(LOWP, false, false, false, false, RC);                                                                             \
+    if (a->nlayers == 2) CB_K(LOWP, false, false, true, RC);                                                                     \
+    else if (a->layer[2].N == 192 && a->gadd) CB_K(LOWP, true, true, false, RC);                                                 \
+    else if (a->layer[2].N == 192) CB_K(LOWP, false, true, false, RC);                                                           \
+    else if (a->gadd) CB_K(LOWP, true, false, false, RC);                                                                        \
+    else CB_K(LOWP, false, false, false, RC);                                                                                    \
   } while (0)
-    const bool rc = a->rc_Wh[0] != nullptr;   // (cc_bwd_ok: never together with dw_in)
+    const bool rc = a->rc_Wh[0] != nullptr;
     // (product_form as gfv_internal_tchain_launch left it: 0 three products, 1 / 2 the single-product forms in fp16 / bf16)
     if (a->product_form == 2) { if (rc) CB_LAUNCH(2, true); else CB_LAUNCH(2, false); }
     else if (a->product_form != 0) { if (rc) CB_LAUNCH(1, true); else CB_LAUNCH(1, false); }

@@ -333,31 +333,24 @@ __device__ __forceinline__ void cb_load_gathers(const CbBufs& B, const CcCtx& c,
   }
 }
 
-// GADD: the gathered addend [gadd[s] | gadd[r]] of the incoming gradient exists; DW1: the forward's first Linear is 128 deep
-// and its input rows are given (dw_in): its weight gradient dW1 = gz1^T x is formed by this launch as well - in a TRAILING pass
-// of every workgroup over its own rows, behind the tile loop (round 5).  (Rounds 3 - 4 accumulated it tile by tile beside dW3 /
-// dW2: 36 more live registers in a kernel that sits at 253 of 256 - 18 to 43 spilled registers in every variant, 4.06 against
-// 3.82 ms per step.)  The trailing pass re-reads the gz1 rows this workgroup wrote (L2 / Infinity Cache) and the input rows,
-// splits both into fragments (two buffer pairs, alternating: one barrier per tile), and runs the weight-gradient phase on them
-// with the registers of the dW3 accumulators, which have left for the partial block by then: no live value is added to the
-// tile loop.  It replaces the one-tile weight-gradient launch over the E rows on the side queue (27 us alone, ~115 us beside a
-// persistent launch) at ~3 k cycles per tile here.
+// GADD: the gathered addend [gadd[s] | gadd[r]] of the incoming gradient exists.
+// (DW1 - the first Linear's weight gradient fused as well, per tile in rounds 3 - 4 (18 - 43 spilled registers), as a trailing pass
+// of every workgroup in round 5 (3 spills, parity-green, TIME-NEUTRAL: 3.71 - 3.76 against 3.72 - 3.74 ms, cavity +2.5 %:
+// profiles/r05_ab_dw1_trailing.txt) - was removed in round 6 with its six instantiations: that weight gradient stays a one-tile
+// launch of the side queue.)
 // OUT2: the last chain layer is 192 wide (NodeBlock: W1^T with the rows for x first, then the 64 for the neighbour mean,
 // blocks.py:54): waves 0..3 own a second n-tile and write out[1] ([M, 64], no residual)
 // NOOUT: the MLP's input needs no gradient (the encoders, EPD.py:92-119): a two-layer launch whose out[0] receives gz1 (what the
 // first Linear's weight-gradient launch reads); the third chain phase is only the weight gradient of the second Linear
 // RC: z2 and y3 are recomputed from z1 (rc_Wh / rc_bias: the forward's second and third Linear) instead of read
-template <int LOWP, bool GADD, bool DW1, bool OUT2 = false, bool NOOUT = false, bool RC = false>
+template <int LOWP, bool GADD, bool OUT2 = false, bool NOOUT = false, bool RC = false>
 __global__ __launch_bounds__(64 * CC_W, 2) void colchain_bwd_kernel(const gfv_rowtile_args_t A, int* status) {
-  static_assert(!(RC && DW1), "the fourth fragment buffer is either the first Linear's input rows or the recomputed a1");
   constexpr int TG = CB_TG;
-  constexpr int CB_TSC_MAX = 256;   // (DW1) tiles per workgroup whose gz1 scale is kept for the trailing pass (the launcher checks)
-  __shared__ __attribute__((aligned(16))) char lds[CbLds::TOTAL + ((DW1 || RC) ? CbLds::BUF : 0) + (DW1 ? 4 * CB_TSC_MAX : 0)];
+  __shared__ __attribute__((aligned(16))) char lds[CbLds::TOTAL + (RC ? CbLds::BUF : 0)];
   char* b0 = lds + CbLds::B0;
   char* b1 = lds + CbLds::B1;
   char* b2 = lds + CbLds::B2;
-  char* b3 = lds + CbLds::TOTAL;   // (DW1) the trailing pass's second fragment pair; (RC) a1 = gelu(z1)
-  float* tsc = reinterpret_cast<float*>(lds + CbLds::TOTAL + CbLds::BUF);   // (DW1) gz1 fragment scale of every tile of this workgroup
+  char* b3 = lds + CbLds::TOTAL;   // (RC) a1 = gelu(z1)
   float* part = reinterpret_cast<float*>(lds + CbLds::PART);
   float* smax = reinterpret_cast<float*>(lds + CbLds::SMAX);
 
@@ -390,7 +383,7 @@ __global__ __launch_bounds__(64 * CC_W, 2) void colchain_bwd_kernel(const gfv_ro
   B.out = cb_buf(NOOUT ? nullptr : A.out[0], rows128);
   const cb_rsrc out2 = cb_buf(OUT2 ? A.out[1] : nullptr, (size_t)A.M * 256);
 
-  // this wave's n-tile of the three transposed layers' images.  The weight-gradient accumulators take 72 (DW1: 108) registers
+  // this wave's n-tile of the three transposed layers' images.  The weight-gradient accumulators take 72 registers
   // for the whole launch, so the chain's weights are NOT resident here: every tile fetches each layer's slice (4 KB per wave,
   // L2 hits) one phase ahead of its use - 12 KB per wave and 64-row tile next to 230 KB of activation traffic - and the
   // LayerNorm-backward phase, where the register pressure peaks, holds none of them.
@@ -467,8 +460,7 @@ __global__ __launch_bounds__(64 * CC_W, 2) void colchain_bwd_kernel(const gfv_ro
   // 42.1 k -> 40.3 k cycles per tile (most of it in P1, whose epilogue is stores).
   const bool CB_LATE = c.w >= 4;
   CT_DECL
-  int tloc = 0;   // (DW1) this workgroup's tile counter
-  for (int t0 = g_beg; t0 < g_end; t0 += TG, ++tloc) {
+  for (int t0 = g_beg; t0 < g_end; t0 += TG) {
     c.row0 = 16 * t0;
     c.ngt = min(TG, g_end - t0);
     const int np = (c.ngt + 1) >> 1;
@@ -676,7 +668,6 @@ __global__ __launch_bounds__(64 * CC_W, 2) void colchain_bwd_kernel(const gfv_ro
     }
     sacc = s3;
     const float s2s = s3 * step1, s1s = s2s * step2;
-    if (DW1 && c.w == 0 && c.lane == 0) tsc[tloc] = s1s;   // the scale the trailing pass gives this tile's gz1 fragments
     // per-16-row scales of the rows this launch leaves for a weight-gradient launch of its own (gfv_rowtile_args_t.gscale):
     // the tile's fragment scales, a quarter of them (a slab scale s wants s max|v| <= 2^14, the fragments allow 2^16)
     if (A.gscale && c.w == 0 && c.lane < c.ngt) {
@@ -874,79 +865,6 @@ __global__ __launch_bounds__(64 * CC_W, 2) void colchain_bwd_kernel(const gfv_ro
       if (c.j == 0) {
         blk[2 * 16384 + 256 + c.col0 + r] = dg;
         blk[2 * 16384 + 384 + c.col0 + r] = db;
-      }
-    }
-  }
-  // ---- (DW1) trailing pass: dW1 = gz1^T x and db1 over this workgroup's rows ----
-  if constexpr (DW1) {
-    floatx4 (&d1)[8] = dw3;   // (the dW3 accumulators have left for the partial block)
-    floatx4 b1acc = floatx4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int kt = 0; kt < 8; ++kt) d1[kt] = floatx4{0.f, 0.f, 0.f, 0.f};
-    const cb_rsrc xin = cb_buf(A.dw_in, rows128);
-    float4 gq[TG], xq[TG];
-    float sacc1 = 0.f;
-    if (g_beg < g_end) {
-#pragma unroll
-      for (int q = 0; q < TG; ++q) {
-        const int off = cb_off(c, 16 * g_beg, q);
-        gq[q] = cb_ld4(B.save1, off);   // (this lane's own stores of the tile loop)
-        xq[q] = cb_ld4(xin, off);
-      }
-    }
-    cc_barrier();   // every wave is through the tile loop's last weight-gradient phase: the fragment buffers are free
-    int tl = 0;
-    for (int t0 = g_beg; t0 < g_end; t0 += TG, ++tl) {
-      const int row0 = 16 * t0, ngt = min(TG, g_end - t0), np = (ngt + 1) >> 1;
-      const float s1 = tsc[tl];
-      if (sacc1 != 0.f && sacc1 != s1) {
-        const float ratio = s1 / sacc1;
-#pragma unroll
-        for (int kt = 0; kt < 8; ++kt) d1[kt] *= ratio;
-        b1acc *= ratio;
-      }
-      sacc1 = s1;
-      char* gb = (tl & 1) ? b1 : b0;
-      char* ab = (tl & 1) ? b3 : b2;
-#pragma unroll
-      for (int q = 0; q < TG; ++q) {
-        const int row = row0 + 16 * q + c.j;
-        // rows past M / dead groups must not reach the sums over rows.  A SELECT, not a multiplication by 0: a dead lane's clamped
-        // load may land on a gz1 row another workgroup has not written yet (whatever the buffer held, NaN included)
-        const bool lv = q < ngt && row < c.M;
-        const float lf = lv ? 1.0f : 0.0f;
-        const float g4[4] = {lv ? gq[q].x : 0.f, lv ? gq[q].y : 0.f, lv ? gq[q].z : 0.f, lv ? gq[q].w : 0.f};
-        const float x4[4] = {xq[q].x, xq[q].y, xq[q].z, xq[q].w};
-        const float mx = max3_abs(max3_abs(0.f, x4[0], x4[1]), x4[2], x4[3]) * (60000.0f / CC_SH_LIMIT);
-        c.mabs = fmaxf(c.mabs, lf != 0.f ? mx : 0.f);
-        cc_put_frag<LOWP == 2>(gb, q, c, g4, s1);
-        cc_put_frag<LOWP == 2>(ab, q, c, x4, CC_SH);
-      }
-      // the next tile's rows: in flight through the barrier and this tile's products
-      const int nrow0 = t0 + TG < g_end ? 16 * (t0 + TG) : c.M;
-#pragma unroll
-      for (int q = 0; q < TG; ++q) {
-        const int off = cb_off(c, nrow0, q);
-        gq[q] = cb_ld4(B.save1, off);
-        xq[q] = cb_ld4(xin, off);
-      }
-      cc_barrier();
-      cb_dw_tile<LOWP>(gb, ab, np, c.w, c.lane, d1, b1acc);
-    }
-    if (A.dw_partial) {
-      float* blk = A.dw_partial + (size_t)blockIdx.x * A.dw_partial_stride;
-      const float is1 = sacc1 != 0.f ? 1.0f / sacc1 : 0.f;
-      const float u1 = is1 * CC_SH_INV;
-#pragma unroll
-      for (int kt = 0; kt < 8; ++kt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int n = 16 * cb_dw_ntile(c.w, kt) + 4 * c.g + r, k = 16 * cb_dw_ktile(c.w, kt) + c.j;
-          blk[2 * 16384 + 512 + n * 128 + k] = d1[kt][r] * u1;
-        }
-      if (c.j == 0) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) blk[3 * 16384 + 512 + 16 * cb_dw_btile(c.w) + 4 * c.g + r] = b1acc[r] * is1;
       }
     }
   }

@@ -7,7 +7,6 @@ enum {
   GFV_LIM_CBWD_MAX_M,         // GFV_CBWD_MAX_M      25000  ... up to this many rows; above: the persistent fused backward
   GFV_LIM_CFWD_ON,            // GFV_CFWD            1      the column-owner small-tile forward (cfwd.hip)
   GFV_LIM_CFWD_MAX_M,         // GFV_CFWD_MAX_M      100000
-  GFV_LIM_CFWD_TG2_MAX_M,     // GFV_CFWD_TG2_MAX_M  100000 32-row tiles up to here, 64-row tiles above
   GFV_LIM_CFWD_RAG_MAX_M,     // GFV_CFWD_RAG_MAX_M  16384  narrow / ragged first layers and the decoder
   GFV_LIM_CTRANS_ON,          // GFV_CTRANS          1      the small-tile Transolver chains (ctrans.hip)
   GFV_LIM_CTRANS_MAX_M,       // GFV_CTRANS_MAX_M    16384

@@ -74,7 +74,7 @@ namespace {
 struct LimitDef { const char* env; int dflt; };
 const LimitDef k_limits[GFV_LIM_COUNT] = {
     {"GFV_CBWD", 1},        {"GFV_CBWD_MAX_M", 25000},      {"GFV_CFWD", 1},          {"GFV_CFWD_MAX_M", 100000},
-    {"GFV_CFWD_TG2_MAX_M", 100000}, {"GFV_CFWD_RAG_MAX_M", 16384}, {"GFV_CTRANS", 1}, {"GFV_CTRANS_MAX_M", 16384}};
+    {"GFV_CFWD_RAG_MAX_M", 16384},  {"GFV_CTRANS", 1},         {"GFV_CTRANS_MAX_M", 16384}};
 int g_limit[GFV_LIM_COUNT];
 bool g_limit_set[GFV_LIM_COUNT];
 std::once_flag g_limit_once;
@@ -249,9 +249,9 @@ static int rowtile_chain_impl(const gfv_rowtile_args_t* args, void* stream) {
       // dX chain with fused weight gradients (column-owner backward family): + the two (three) weight-gradient GEMMs, the
       // forward's row statistics read, the first Linear's input rows read, the per-workgroup blocks written
       kind = GFV_K_COLCHAIN_BWD;
-      const int nfused = (args->dw_in ? 3 : 2) + (args->rc_Wh[0] ? 2 : 0);   // (+ the two recomputed forward layers)
+      const int nfused = 2 + (args->rc_Wh[0] ? 2 : 0);   // (+ the two recomputed forward layers)
       fl += nfused * 2.0 * args->M * 128.0 * 128.0;
-      by += 8.0 * args->M + (args->dw_in ? 4.0 * args->M * 128.0 : 0.0) + 4.0 * (double)gfv_rowtile_dw_partials_m(args->M) * (double)args->dw_partial_stride;
+      by += 8.0 * args->M + 4.0 * (double)gfv_rowtile_dw_partials_m(args->M) * (double)args->dw_partial_stride;
     }
     tok = gfv_prof_begin(kind, fl, by, (hipStream_t)stream);
   }

@@ -808,20 +808,14 @@ class Engine:
         lib = L.load()
         nwg = lib.gfv_rowtile_dw_partials_m(M)
         lean = sv["z2"] is None   # recompute form: the forward kept z1 only
-        # the first layer's gradient (the W1c block over the E rows) by the chain launch too: a trailing pass of every persistent
-        # workgroup over its own rows (round 5, csrc/colchain_kernel.h) instead of a one-tile weight-gradient launch on the side queue
-        # Measured (profiles/r05_ab_dw1_trailing.txt): 3 spilled registers instead of 18 - 43, parity-green - and time-neutral on the
-        # 50 k-cell mesh (3.71 - 3.76 against 3.72 - 3.74 ms), neutral at 8 meshes per GPU, 2.5 % slower on the 5 k-cell cavity (one
-        # tile per workgroup: the trailing pass is pure latency there): opt-in
-        fuse1 = os.environ.get("GFV_FUSE_DW1", "0") == "1" and not lean
-        FL = L.DW_FUSED_FLOATS_IN if fuse1 else L.DW_FUSED_FLOATS
+        FL = L.DW_FUSED_FLOATS
         dwp = _empty(dev, nwg, FL)
         gz1, g_e_in = _empty(dev, M, 128), _empty(dev, M, 128)
         layers = [LayerSpec(W3t, None, L.OP_MUL_DGELU, aux=sv["z2"]), LayerSpec(W2t, None, L.OP_MUL_DGELU, save=gz1, aux=sv["z1"]),
                   LayerSpec(W1ct)]
         gs = _empty(dev, 3, ops.gscale_ld(M))   # slot 2: the scales of gz1's rows for the first layer's weight-gradient launch
         kw = dict(res=[G], in_op=L.IN_LNBWD, in_gamma=P[names[6]], in_aux=sv["y3"], in_stats=sv["stats"], gadd=gadd[0], gadd_s=gadd[1],
-                  gadd_r=gadd[2], dw_partial=dwp, dw_in=e if fuse1 else None, gscale=gs,
+                  gadd_r=gadd[2], dw_partial=dwp, gscale=gs,
                   rc=(P[names[2]], P[names[3]], P[names[4]], P[names[5]]) if lean else None)
         if not ops.rowtile_chain(M, [Seg(G)], layers, [g_e_in], query_fused=True, **kw):
             return None
@@ -847,20 +841,15 @@ class Engine:
             pieces = [piece(16384 + 128, self._gview2(grads, names[2], names[3]), 1, 16384 + 128),   # dW2 | db2
                       piece(0, self._gview2(grads, names[4], names[5]), 1, 16384 + 128),             # dW3 | db3
                       piece(2 * 16384 + 256, self._gview2(grads, names[6], names[7]), 1, 256)]       # dgamma | dbeta
-            used = 0
-            if fuse1:
-                pieces += [piece(2 * 16384 + 512, gW1.data_ptr() + 4 * 256, 128, 128, 384),           # dW1c -> W1[:, 256:384]
-                           piece(3 * 16384 + 512, grads.view(names[1]), 1, 128)]                      # db1
-            else:
-                # the first layer's c block by the weight-gradient kernel (one tile over the E rows): slab partials laid out
-                # like a stand-in [W1c | b1] block
-                lay = [("W1c", "b1", 1)]
-                self._workspace(lib.gfv_dw_multi_workspace_floats(M, 1, tmpE.block("W1c", "b1")[1])
-                                + lib.gfv_dw_multi_workspace_floats(N, 2, tmpN.block("W1ab", "W1ab")[1]) + 8, dev)   # both regions, once
-                w1, slabs1, blen1, used = self._dw_block(tmpE, lay, [self._tile(gz1, 128, Seg(e), gscale=gs[2])], M, reduce=False)
-                ob1, lb1 = tmpE.block("b1", "b1")
-                pieces += [dict(partial=w1, out=gW1.data_ptr() + 4 * 256, n_chunks=slabs1, chunk_stride=blen1, rows=128, cols=128, ld_out=384),
-                           dict(partial=w1 + 4 * ob1, out=grads.view(names[1]), n_chunks=slabs1, chunk_stride=blen1, rows=1, cols=128)]
+            # the first layer's c block by the weight-gradient kernel (one tile over the E rows): slab partials laid out
+            # like a stand-in [W1c | b1] block
+            lay = [("W1c", "b1", 1)]
+            self._workspace(lib.gfv_dw_multi_workspace_floats(M, 1, tmpE.block("W1c", "b1")[1])
+                            + lib.gfv_dw_multi_workspace_floats(N, 2, tmpN.block("W1ab", "W1ab")[1]) + 8, dev)   # both regions, once
+            w1, slabs1, blen1, used = self._dw_block(tmpE, lay, [self._tile(gz1, 128, Seg(e), gscale=gs[2])], M, reduce=False)
+            ob1, lb1 = tmpE.block("b1", "b1")
+            pieces += [dict(partial=w1, out=gW1.data_ptr() + 4 * 256, n_chunks=slabs1, chunk_stride=blen1, rows=128, cols=128, ld_out=384),
+                       dict(partial=w1 + 4 * ob1, out=grads.view(names[1]), n_chunks=slabs1, chunk_stride=blen1, rows=1, cols=128)]
             w2, slabs2, blen2, _ = self._dw_block(tmpN, [("W1ab", None, 2)],
                                                   [self._tile(G_s, 128, Seg(nb)), self._tile(G_r, 128, Seg(nb))], N, reduce=False,
                                                   ws_offset=used)

@@ -54,7 +54,6 @@ class RowtileArgs(C.Structure):
 ABI_VERSION = 3   # GFV_ABI_VERSION of include/gfv.h this binding is written against
 
 DW_FUSED_FLOATS = 2 * 128 * 128 + 4 * 128   # floats per workgroup block of a fused weight-gradient launch (include/gfv.h)
-DW_FUSED_FLOATS_IN = 3 * 128 * 128 + 5 * 128   # ... with the first Linear's weight gradient fused as well (dw_in)
 
 
 class WimgDesc(C.Structure):

@@ -249,7 +249,7 @@ def rowtile_chain(M, segs, layers, outs, *, in_add=None, in_op=L.IN_NONE, in_gam
                   gadd=None, gadd_s=None, gadd_r=None, in_save=None, ln_partial=None, fin_op=L.FIN_PLAIN,
                   fin_gamma=None, fin_beta=None, fin_aux=None, fin_presave=None, res=None, out_nores=None,
                   padd=None, padd_s=None, padd_r=None, wimg=None, gscale=None, family=0, fin_stats=None, in_stats=None,
-                  dw_partial=None, dw_in=None, query_fused=False, rc=None):
+                  dw_partial=None, query_fused=False, rc=None):
     """Launch the fused row-tile GEMM chain.  outs / res: list (per 128-wide chunk of the last layer) of
     (tensor, ld) or tensors; see include/gfv.h for the semantics of every field.  gscale: [3, ld] buffer for the
     per-16-row scales of the gradient rows the launch leaves behind; returns True when the launch wrote it (split-fp16
@@ -318,8 +318,6 @@ def rowtile_chain(M, segs, layers, outs, *, in_add=None, in_op=L.IN_NONE, in_gam
     a.fin_stats, a.in_stats = _p(fin_stats), _p(in_stats)
     if dw_partial is not None:
         a.dw_partial, a.dw_partial_stride = dw_partial.data_ptr(), dw_partial.stride(0)
-        if dw_in is not None:
-            a.dw_in, a.dw_in_ld = dw_in.data_ptr(), dw_in.stride(0)
     if rc is not None:
         W2, b2, W3, b3 = rc
         h2, h3 = (wi.lookup(W2), wi.lookup(W3)) if wi is not None else (0, 0)

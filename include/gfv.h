@@ -194,10 +194,9 @@ typedef struct {
    * layer[0].save / in_save / ln_partial may then be NULL (nothing else reads g3 / gz2). */
   float* dw_partial;
   int64_t dw_partial_stride;
-  /* optional with dw_partial: the input rows [M, dw_in_ld] of the forward's FIRST Linear when it is 128 deep (a plain
-   * [M, 128] row block: the EdgeBlock's edge latents in the factored form).  The launch then fuses that weight gradient as
-   * well,  dW1 = gz1^T x  (gz1 = layer 1's product) and its bias gradient, appended to the block: [... | dW1 | db1]
-   * (GFV_DW_FUSED_FLOATS_IN floats). */
+  /* RESERVED (ABI 3): rounds 3 - 5 took the input rows of the forward's first Linear here and fused that weight gradient as well
+   * (GFV_DW_FUSED_FLOATS_IN floats per block) - time-neutral at its best (profiles/r05_ab_dw1_trailing.txt), removed with its
+   * kernel instantiations.  Must be NULL / 0: a launch with dw_in set does not run fused (gfv_rowtile_fuses_dw says 0). */
   const float* dw_in;
   int32_t dw_in_ld;
   int32_t reserved2_;
@@ -206,11 +205,11 @@ typedef struct {
    * (or NULL).  The launch then rebuilds z2 = W2 gelu(z1) + b2 and the LayerNorm input y = W3 gelu(z2) + b3 tile by tile from
    * z1 (layer[1].aux) on the matrix cores; layer[0].aux (z2) and in_aux (y) are NOT read and may be NULL - the forward launch
    * need not save them (gfv_layer_t.save of its second layer, fin_presave).  in_stats is still read (the rows' forward
-   * statistics).  Not together with dw_in. */
+   * statistics). */
   const void* rc_Wh[2];
   const float* rc_bias[2];
 } gfv_rowtile_args_t;
-enum { GFV_DW_FUSED_FLOATS = 2 * 128 * 128 + 4 * 128, GFV_DW_FUSED_FLOATS_IN = 3 * 128 * 128 + 5 * 128 };
+enum { GFV_DW_FUSED_FLOATS = 2 * 128 * 128 + 4 * 128 };
 int gfv_rowtile_dw_partials(void);                              /* the most workgroups (= partial blocks) a fused launch runs */
 int gfv_rowtile_dw_partials_m(int32_t M);                       /* ... a fused launch over M rows runs: blocks 0 .. this - 1 are written */
 int gfv_rowtile_fuses_dw(const gfv_rowtile_args_t* args);       /* 1: gfv_rowtile_chain would run this launch with fused weight gradients */

@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Where the host time of the drop-in training iteration goes (round 6): the reference driver's call sequence on NNmodel under
+cProfile, on the 5 k-cell cavity (where the iteration is host-bound) - `python profiles/tools/dropin_profile.py [cells] [gfv|torch]`."""
+import cProfile
+import os
+import pstats
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "gen-fvgn-steady_amd")]
+import torch
+
+import bench
+from FVMmodel.importer import NNmodel
+from gfv.optim import Adam as GfvAdam
+from gfv.params import default_params
+
+cells = int(sys.argv[1]) if len(sys.argv) > 1 else 5041
+which = sys.argv[2] if len(sys.argv) > 2 else "gfv"
+dev = torch.device("cuda", 0)
+graphs_cpu, sz = bench.build_workload("cavity" if cells < 20000 else "cylinder", cells, 1, 0, dev)
+params = default_params(dataset_size=1)
+model = NNmodel(params).to(dev)
+graphs = tuple(g.clone().to(dev) for g in graphs_cpu)
+gn = graphs[0]
+backup = gn.x.clone()
+opt = (GfvAdam if which == "gfv" else torch.optim.Adam)(model.parameters(), lr=params.lr)
+
+
+def it():
+    gn.x.copy_(backup)
+    gn.norm_uvp, gn.norm_global = params.norm_uvp, params.norm_global
+    opt.zero_grad()
+    lc, lx, ly, lp, un, uc = model(*graphs)
+    loss = torch.mean(torch.log(params.loss_press * lp + params.loss_cont * lc + params.loss_mom * lx + params.loss_mom * ly))
+    loss.backward()
+    opt.step()
+
+
+for _ in range(10):
+    it()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(200):
+    it()
+torch.cuda.synchronize()
+print(f"{cells} cells, {which} Adam: {1e3 * (time.perf_counter() - t0) / 200:.3f} ms per iteration (un-profiled)")
+# host time only: the same loop WITHOUT waiting for the device at the end of each iteration
+pr = cProfile.Profile()
+pr.enable()
+for _ in range(200):
+    it()
+pr.disable()
+torch.cuda.synchronize()
+st = pstats.Stats(pr)
+st.sort_stats("cumulative").print_stats(28)
+st.sort_stats("tottime").print_stats(18)

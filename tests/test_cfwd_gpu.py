@@ -82,13 +82,10 @@ def _run(M, segs, Pd, wi, fam, *, res=None, padd=None, nores=False, stats=True, 
     return dict(z1=z1, z2=z2, y3=y3, out=out, stats=st, nores=onr), path
 
 
-# 32-row tiles on 8 waves (partial last tile; one tile; many) - the default at every size - and 64-row tiles on 4 waves (dispatch
-# limit GFV_CFWD_TG2_MAX_M: launches above it take the 64-row tiles)
-@pytest.mark.parametrize("M,tall", [(777, 0), (32, 0), (20001, 0), (41003, 0), (41003, 1), (777, 1), (97, 1)])
-def test_small_tile_forward_node_and_edge_shapes(M, tall, gfv_limits):
+# 32-row tiles on 8 waves: a partial last tile, one tile, many
+@pytest.mark.parametrize("M", [777, 32, 97, 20001, 41003])
+def test_small_tile_forward_node_and_edge_shapes(M):
     from gfv import lib as L, ops
-    if tall:
-        gfv_limits(GFV_CFWD_TG2_MAX_M=0)
     g = torch.Generator().manual_seed(M)
     d = lambda t: t.cuda().contiguous()
     # (1) NodeBlock: [nbm 64 | x 128], residual x, rows over three decades

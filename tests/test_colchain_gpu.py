@@ -51,8 +51,8 @@ def _images(dev, Ws):
 
 @pytest.mark.parametrize("M", [4000, 97, 1024])
 @pytest.mark.parametrize("extras", [True, False])
-@pytest.mark.parametrize("dw1", [True, False, "rc"])
-def test_column_owner_backward_with_fused_weight_gradients(dev, M, extras, dw1):
+@pytest.mark.parametrize("form", ["read", "rc"])
+def test_column_owner_backward_with_fused_weight_gradients(dev, M, extras, form):
     """EdgeBlock backward in its factored form: LayerNorm backward, the three transposed layers, residual; with the weight
     gradients of the third and second Linear, their bias gradients and (dgamma, dbeta) accumulated by the same launch
     (include/gfv.h, gfv_rowtile_args_t.dw_partial) - every piece against float64 autograd."""
@@ -85,12 +85,9 @@ def test_column_owner_backward_with_fused_weight_gradients(dev, M, extras, dw1):
     gz1 = torch.full((M, 128), float("nan"), device=dev)
     ge = torch.full((M, 128), float("nan"), device=dev)
     nwg = L.load().gfv_rowtile_dw_partials_m(M)
-    part = torch.full((nwg, L.DW_FUSED_FLOATS_IN if dw1 else L.DW_FUSED_FLOATS), float("nan"), device=dev)
+    part = torch.full((nwg, L.DW_FUSED_FLOATS), float("nan"), device=dev)
     kw = dict(gadd=d(gagg), gadd_s=d(s.int()), gadd_r=d(r.int()), in_add=d(gadd2)) if extras else {}
-    rc = dw1 == "rc"     # recompute form: neither z2 nor the LayerNorm input is handed over
-    dw1 = dw1 is True
-    if dw1:
-        kw["dw_in"] = d(e)
+    rc = form == "rc"     # recompute form: neither z2 nor the LayerNorm input is handed over
     if rc:
         kw["rc"] = (Pd["W2"], Pd["b2"], Pd["W3"], Pd["b3"])
         z2d = y3d = None
@@ -110,8 +107,6 @@ def test_column_owner_backward_with_fused_weight_gradients(dev, M, extras, dw1):
     dW2, db2 = tot[16512:16512 + 16384].view(128, 128), tot[16512 + 16384:16512 + 16384 + 128]
     dgam, dbet = tot[2 * 16384 + 256:2 * 16384 + 384], tot[2 * 16384 + 384:2 * 16384 + 512]
     pieces = [(dW3, "W3"), (db3, "b3"), (dW2, "W2"), (db2, "b2"), (dgam, "gamma"), (dbet, "beta")]
-    if dw1:
-        pieces += [(tot[2 * 16384 + 512:3 * 16384 + 512].view(128, 128), "W1"), (tot[3 * 16384 + 512:], "b1")]
     for mine, name in pieces:
         assert rel(mine, Pg[name].grad) < TOL, (name, rel(mine, Pg[name].grad))
     # gz1 feeds the separate first-layer weight gradient and the node-level scatter
