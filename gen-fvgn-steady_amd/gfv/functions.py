@@ -148,11 +148,11 @@ class _Replay:
     activations `sv` and the outputs live in the forward list's private pool, the gradient rows in `grads` (allocated once,
     outside the pools), the incoming loss gradient is copied into `gloss`."""
 
-    __slots__ = ("warm", "fwd", "bwd", "x", "outs", "sv", "sig", "gloss", "grads", "plan", "pending", "P")
+    __slots__ = ("warm", "fwd", "bwd", "x", "outs", "sv", "sig", "gloss", "grads", "plan", "pending", "P", "split_sizes", "split_how")
 
     def __init__(self):
         self.warm, self.fwd, self.bwd, self.pending = 0, None, None, False
-        self.x = self.outs = self.sv = self.sig = self.gloss = self.grads = self.plan = self.P = None
+        self.x = self.outs = self.sv = self.sig = self.gloss = self.grads = self.plan = self.P = self.split_sizes = self.split_how = None
 
 
 class ReplayCache:
@@ -193,13 +193,17 @@ class ModelFn(torch.autograd.Function):
         require_gpu(x)
         from . import cmdlist
         from . import lib as L
-        P = dict(zip(names, (p.detach() for p in params)))
+        P = None   # name -> detached parameter: built only where launches are issued from Python (159 detach calls: ~65 us)
         ent = None
         if cache is not None and cmdlist.active() is None and not torch.cuda.is_current_stream_capturing():
             key = (id(plan), flags["norm_global"], flags["accumulate"], L.load().gfv_f16split_enabled(),
                    tuple(p.data_ptr() for p in params))
             ent = cache.lookup(engine, plan, key)
-        run = lambda: engine.forward(P, buffers, x, plan, norm_global=flags["norm_global"], accumulate=flags["accumulate"])
+
+        def run():
+            nonlocal P
+            P = dict(zip(names, (p.detach() for p in params)))
+            return engine.forward(P, buffers, x, plan, norm_global=flags["norm_global"], accumulate=flags["accumulate"])
         with engine.model_width():
             if ent is None or ent.pending:
                 # (pending: the previous replayed forward's backward has not run - its saved rows must not be overwritten)
@@ -234,7 +238,7 @@ class ModelFn(torch.autograd.Function):
         if ent is not None:
             # the lists' own output tensors are overwritten by the next replay: hand out copies (4 small launches)
             losses, uvp_node, uvp_cell, ea15 = losses.clone(), uvp_node.clone(), uvp_cell.clone(), ea15.clone()
-            ent.pending = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+            ent.pending = any(ctx.needs_input_grad)   # a backward will read the saved rows: no replay into them until it has run
         ctx.engine, ctx.plan, ctx.names, ctx.sv, ctx.P, ctx.ent = engine, plan, names, sv, P, ent
         ctx.mark_non_differentiable(uvp_node, uvp_cell, ea15)
         return losses, uvp_node, uvp_cell, ea15
@@ -256,7 +260,14 @@ class ModelFn(torch.autograd.Function):
         with ctx.engine.model_width():
             if ent.bwd is None:
                 ent.gloss = g_losses.contiguous().clone()
-                ent.grads = _alloc_grads(ctx.names, [P[n] for n in ctx.names], skip)   # zeroed once; every step rewrites the same rows
+                ent.grads = G0 = _alloc_grads(ctx.names, [P[n] for n in ctx.names], skip)   # zeroed once; every step rewrites the same rows
+                pad = lambda k: (k + 3) // 4 * 4
+                ent.split_sizes = [pad(G0.numel(n)) for n in ctx.names]
+                assert sum(ent.split_sizes) == G0.flat.numel()
+                # per tensor: None = no gradient; True = the chunk as it is (1-D, unpadded); else (numel, shape)
+                ent.split_how = [None if n in G0.skip else
+                                 (True if (len(G0.shape[n]) == 1 and pad(G0.numel(n)) == G0.numel(n)) else (G0.numel(n), G0.shape[n]))
+                                 for n in ctx.names]
                 with cmdlist.record() as cl:
                     ctx.engine.backward(P, ent.sv, ent.gloss, ent.grads, ctx.plan)
                     L.status_publish()
@@ -270,7 +281,11 @@ class ModelFn(torch.autograd.Function):
         flat = ent.grads.flat.clone()
         G = ent.grads
         _note_flat(flat, ctx.names, G.skip)
-        return tail + tuple(None if n in G.skip else flat[G.off[n]:G.off[n] + G.numel(n)].view(G.shape[n]) for n in ctx.names)
+        # the 159 views: ONE split at the (16-byte aligned) offsets, then a reshape only where the tensor is not 1-D / not padded
+        # (slicing + viewing every tensor from Python was ~0.4 ms of a 2.6 ms iteration on the 5 k-cell cavity,
+        # profiles/r06_dropin_host_profile.txt)
+        return tail + tuple(None if how is None else (c if how is True else c[:how[0]].view(how[1]))
+                            for c, how in zip(flat.split_with_sizes(ent.split_sizes), ent.split_how))
 
 
 __all__ = ["Engine", "get_plan", "GnBlockFn", "Mlp3Fn", "TransolverFn", "SimulatorFn", "IntegratorFn", "ModelFn",

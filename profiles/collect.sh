@@ -24,6 +24,10 @@ timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- p
 find $O/prof -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats.csv \;
 rm -rf $O/prof
 python3 $R/profiles/instep_aggregate.py $O/kernel_stats.csv $O/kernel_stats_in_step.json $R/gen-fvgn-steady_amd/gfv/libgfv.so.srchash > $O/kernel_stats_in_step.txt
+# round 6: the same at BASELINE config 4's per-GPU load (8 meshes per GPU): kernel statistics of the two-queue step
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof8 -- python3 $R/bench.py --meshes-per-gpu 8 --steps 10 --warmup 4 --cpu-budget 0 --graph list --skip-fp32-form --profile-steps 0 --skip-copy-rate --skip-drop-in > $O/prof_b8.log 2>&1
+find $O/prof8 -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats_b8.csv \;
+rm -rf $O/prof8
 # PMC passes: eager launches only, split-fp16 form only; the JSON line says how many steps ran (steps_executed)
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 900 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_$c -- python3 $R/bench.py --steps 5 --warmup 1 --graph off --min-time 0 --cpu-budget 0 --profile-steps 1 --skip-fp32-form --skip-copy-rate --skip-drop-in > $O/pmc_$c.log 2>&1
@@ -45,6 +49,9 @@ bash $R/profiles/tools/latency_floor.sh ${tag}_lf > /dev/null 2>&1
 cp $R/gpurun_out/${tag}_lf/latency_floor.txt $O/latency_floor.txt
 TL_TAG=${tag}_tl bash $R/profiles/tools/timeline.sh > $O/timeline.txt 2>&1
 ABFLAGS="--workload cavity --cells 5041" TL_TAG=${tag}_tlc bash $R/profiles/tools/timeline.sh > $O/timeline_cavity.txt 2>&1
+ABFLAGS="--meshes-per-gpu 8 --steps 10 --warmup 4 --min-time 1.5" TL_TAG=${tag}_tl8 bash $R/profiles/tools/timeline.sh > $O/timeline_b8.txt 2>&1
+# round 6: where the host time of the drop-in iteration goes (cProfile of the reference driver's call sequence, 5 k-cell cavity)
+timeout 600 python3 $R/profiles/tools/dropin_profile.py 5041 gfv > $O/dropin_host_profile.txt 2>&1
 tail -3 $O/pytest.log
 head -c 400 $O/bench.json; echo
 tail -4 $O/hbm_pmc.txt

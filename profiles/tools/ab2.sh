@@ -8,9 +8,9 @@ cd /tmp && export TMPDIR=/tmp
 for rep in 1 2 3; do
   for v in base $name; do
     if [ $v = base ]; then
-      env GFV_LIB=$R/gen-fvgn-steady_amd/gfv/libgfv.so timeout 300 python3 $R/bench.py --cpu-budget 0 --min-time 1.5 --graph list --skip-fp32-form > $O/${v}_$rep.json 2> $O/${v}_$rep.err
+      env GFV_LIB=$R/gen-fvgn-steady_amd/gfv/libgfv.so timeout 300 python3 $R/bench.py --cpu-budget 0 --min-time 1.5 --graph list --skip-fp32-form --skip-drop-in > $O/${v}_$rep.json 2> $O/${v}_$rep.err
     else
-      env GFV_LIB=$R/gen-fvgn-steady_amd/gfv/libgfv_$v.so "$@" timeout 300 python3 $R/bench.py --cpu-budget 0 --min-time 1.5 --graph list --skip-fp32-form > $O/${v}_$rep.json 2> $O/${v}_$rep.err
+      env GFV_LIB=$R/gen-fvgn-steady_amd/gfv/libgfv_$v.so "$@" timeout 300 python3 $R/bench.py --cpu-budget 0 --min-time 1.5 --graph list --skip-fp32-form --skip-drop-in > $O/${v}_$rep.json 2> $O/${v}_$rep.err
     fi
     python3 -c "
 import json

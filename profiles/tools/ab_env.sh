@@ -10,7 +10,7 @@ for rep in 1 2; do
     envs=""
     [ "$v" != base ] && envs=$(echo $v | tr ',' ' ')
     tag=$(echo $v | tr -c 'A-Za-z0-9=_' '_')
-    env $envs timeout 300 python3 $R/bench.py --cpu-budget 0 --min-time 1.5 --graph list --skip-fp32-form > $O/${tag}_$rep.json 2> $O/${tag}_$rep.err
+    env $envs timeout 300 python3 $R/bench.py --cpu-budget 0 --min-time 1.5 --graph list --skip-fp32-form --skip-drop-in > $O/${tag}_$rep.json 2> $O/${tag}_$rep.err
     python3 -c "
 import json
 d=json.load(open('$O/${tag}_$rep.json'))

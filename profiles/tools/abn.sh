@@ -9,7 +9,7 @@ for rep in 1 2 3; do
   for v in base "$@"; do
     lib=$R/gen-fvgn-steady_amd/gfv/libgfv.so
     [ $v != base ] && lib=$R/gen-fvgn-steady_amd/gfv/libgfv_$v.so
-    env GFV_LIB=$lib timeout 300 python3 $R/bench.py --cpu-budget 0 --min-time 1.5 --graph list --skip-fp32-form > $O/${v}_$rep.json 2> $O/${v}_$rep.err
+    env GFV_LIB=$lib timeout 300 python3 $R/bench.py --cpu-budget 0 --min-time 1.5 --graph list --skip-fp32-form --skip-drop-in > $O/${v}_$rep.json 2> $O/${v}_$rep.err
     python3 -c "
 import json
 d=json.load(open('$O/${v}_$rep.json'))

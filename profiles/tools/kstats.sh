@@ -8,7 +8,7 @@ for v in "$@"; do
   export GFV_LIB=$lib
   O=$R/gpurun_out/kstats_$v
   rm -rf $O; mkdir -p $O
-  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 $R/bench.py --cpu-budget 0 --min-time 0.5 --graph list --skip-fp32-form --profile-steps 1 > $O/bench.json 2> $O/err.txt
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 $R/bench.py --cpu-budget 0 --min-time 0.5 --graph list --skip-fp32-form --skip-drop-in --profile-steps 1 > $O/bench.json 2> $O/err.txt
   f=$(find $O -name "*kernel_stats.csv" | head -1)
   echo "== $v"; python3 - "$f" <<'PY'
 import csv,sys

@@ -9,7 +9,7 @@ for cfg in "$@"; do
   O=$R/gpurun_out/kstats_env_$i
   rm -rf $O; mkdir -p $O
   export $cfg
-  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 $R/bench.py --cpu-budget 0 --min-time 0.5 --graph list --skip-fp32-form --profile-steps 0 $KSTATS_FLAGS > $O/bench.json 2> $O/err.txt
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 $R/bench.py --cpu-budget 0 --min-time 0.5 --graph list --skip-fp32-form --skip-drop-in --profile-steps 0 $KSTATS_FLAGS > $O/bench.json 2> $O/err.txt
   for kv in $cfg; do unset ${kv%%=*}; done
   f=$(find $O -name "*kernel_stats.csv" | head -1)
   echo "== $cfg   $(python3 -c "import json,sys; print(json.loads(open('$O/bench.json').read().strip().splitlines()[-1])['ms_per_step'])" 2>/dev/null) ms/step"

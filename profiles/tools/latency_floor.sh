@@ -11,7 +11,7 @@ cd /tmp && export TMPDIR=/tmp
 export GFV_OVERLAP=0
 for kv in $LF_ENV; do export $kv; done
 for cells in ${LF_CELLS:-1024 5041 25281 75076}; do
-  timeout 600 rocprofv3 --kernel-trace --output-format csv -d $O/prof_$cells -- python3 $R/bench.py --workload cavity --cells $cells --cpu-budget 0 --min-time 0.25 --steps 20 --graph list --skip-fp32-form --profile-steps 0 --skip-copy-rate > $O/bench_$cells.json 2> $O/err_$cells.txt
+  timeout 600 rocprofv3 --kernel-trace --output-format csv -d $O/prof_$cells -- python3 $R/bench.py --workload cavity --cells $cells --cpu-budget 0 --min-time 0.25 --steps 20 --graph list --skip-fp32-form --skip-drop-in --profile-steps 0 --skip-copy-rate > $O/bench_$cells.json 2> $O/err_$cells.txt
   f=$(find $O/prof_$cells -name "*kernel_trace.csv" | head -1)
   python3 $R/profiles/tools/latency_floor.py --reduce "$f" $O/trace_$cells.json
   rm -rf $O/prof_$cells

@@ -8,7 +8,7 @@ mkdir -p $O
 for kv in "$@"; do export $kv; done
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 900 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_$c -- python3 $R/bench.py --steps 5 --warmup 1 --graph off --min-time 0 --cpu-budget 0 --profile-steps 1 --skip-fp32-form --skip-copy-rate $PMCFLAGS > $O/pmc_$c.log 2>&1
+  timeout 900 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_$c -- python3 $R/bench.py --steps 5 --warmup 1 --graph off --min-time 0 --cpu-budget 0 --profile-steps 1 --skip-fp32-form --skip-drop-in --skip-copy-rate $PMCFLAGS > $O/pmc_$c.log 2>&1
 done
 NSTEPS=$(python3 -c "import json,sys; print([json.loads(l) for l in open('$O/pmc_FETCH_SIZE.log') if l.startswith('{')][-1]['steps_executed'])")
 python3 $R/profiles/pmc_aggregate.py $O $NSTEPS > $O/hbm_pmc.txt

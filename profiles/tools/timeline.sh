@@ -5,7 +5,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/${TL_TAG:-timeline}
 rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --output-format csv -d $O/prof -- python3 $R/bench.py --cpu-budget 0 --min-time 0.3 --graph list --skip-fp32-form --profile-steps 0 --skip-copy-rate $ABFLAGS > $O/bench.json 2> $O/err.txt
+timeout 600 rocprofv3 --kernel-trace --output-format csv -d $O/prof -- python3 $R/bench.py --cpu-budget 0 --min-time 0.3 --graph list --skip-fp32-form --profile-steps 0 --skip-copy-rate --skip-drop-in $ABFLAGS > $O/bench.json 2> $O/err.txt
 f=$(find $O/prof -name "*kernel_trace.csv" | head -1)
 python3 - "$f" <<'PY'
 import csv,sys,collections
@@ -13,7 +13,7 @@ rows=list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r:int(r["Start_Timestamp"]))
 # steps are delimited by adam_kernel; take the last 40 complete steps
 idx=[i for i,r in enumerate(rows) if "adam_kernel" in r["Kernel_Name"]]
-idx=idx[-70:-20]
+idx=idx[-70:-20] if len(idx)>90 else idx[2:-2]   # (long steps - 8 meshes per GPU - run fewer of them)
 agg=collections.defaultdict(lambda:[0.0,0.0,0]); steps=0; span=0.0
 gapsum=collections.defaultdict(float)
 for a,b in zip(idx[:-1],idx[1:]):
@@ -31,7 +31,7 @@ for a,b in zip(idx[:-1],idx[1:]):
 print("steps",steps,"span/step ms",span/steps/1e6)
 for q,(busy,gaps,n) in agg.items(): print("queue",q,"kernels/step %.1f busy %.3f ms gaps %.3f ms" % (n/steps,busy/steps/1e6,gaps/steps/1e6))
 # one step: list main-queue gaps > 3 us with neighbours
-a,b=idx[-22],idx[-21]
+a,b=idx[len(idx)//2],idx[len(idx)//2+1]
 seg=rows[a+1:b+1]
 mainq=max(agg,key=lambda q:agg[q][0])
 rs=[r for r in seg if r["Queue_Id"]==mainq]; rs.sort(key=lambda r:int(r["Start_Timestamp"]))
@@ -45,7 +45,8 @@ import csv,sys
 rows=list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r:int(r["Start_Timestamp"]))
 idx=[i for i,r in enumerate(rows) if "adam_kernel" in r["Kernel_Name"]]
-a,b=idx[-22],idx[-21]
+idx=idx[-70:-20] if len(idx)>90 else idx[2:-2]
+a,b=idx[len(idx)//2],idx[len(idx)//2+1]
 seg=rows[a+1:b+1]
 t0=int(seg[0]["Start_Timestamp"])
 qs=sorted({r["Queue_Id"] for r in seg})

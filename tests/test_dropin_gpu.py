@@ -76,32 +76,44 @@ def test_replayed_drop_in_steps_equal_eager_ones(fresh_x):
 
 
 def test_second_forward_before_the_backward_does_not_touch_the_saved_rows():
-    """forward, forward, backward-of-the-first: the second call must not replay into the rows the first one's backward reads (it
-    runs eagerly); gradients equal those of forward, backward."""
+    """forward(x1), forward(x2), backward-of-the-first: the second call must not replay into the rows the first one's backward
+    reads (it runs eagerly); the gradients are those of forward(x1), backward alone - and differ from forward(x2)'s."""
     model, params = _model()
     graphs = tuple(g.clone().to("cuda") for g in cases.make_graphs("cavity_mixed_b1"))
     opt = torch.optim.SGD(model.parameters(), lr=0.0)
-    _driver_steps(model, params, opt, graphs, 4)      # warm-up + recording + one replay
     gn = graphs[0]
-    backup = gn.x.clone()
+    raw = gn.x.clone()
+    _driver_steps(model, params, opt, graphs, 4)      # warm-up + recording + one replay
+    other = raw.clone()
+    other[:, 0:3] = other[:, 0:3].flip(0) * 1.7 + 0.3   # another node state on the same mesh
 
-    def fwd():
-        gn.x.copy_(backup)   # (the normalised state: per-graph standardisation is idempotent, as in the reference's solve loop)
+    def fwd(state):
+        gn.x.copy_(state)
         gn.norm_uvp, gn.norm_global = True, True
         o = model(*graphs)
         return torch.mean(torch.log(o[3] + 6e4 * o[0] + 5e4 * o[1] + 5e4 * o[2]))
+
+    def grads_of(state):
+        opt.zero_grad()
+        fwd(state).backward()
+        return [None if p.grad is None else p.grad.clone() for p in model.parameters()]
+    want, want_other = grads_of(raw), grads_of(other)
+    assert any(w is not None and not torch.equal(w, v) for w, v in zip(want, want_other))
+    before = model._replay.replays
     opt.zero_grad()
-    fwd().backward()
-    want = [None if p.grad is None else p.grad.clone() for p in model.parameters()]
-    opt.zero_grad()
-    first = fwd()
-    second = fwd()        # pending backward of `first`: eager
+    first = fwd(raw)        # replayed
+    second = fwd(other)     # the first call's backward is pending: issued eagerly, the saved rows stay the first call's
+    assert model._replay.replays == before + 1
     first.backward()
     for p, w in zip(model.parameters(), want):
         assert (p.grad is None) == (w is None)
         if w is not None:
             assert torch.equal(p.grad, w)
-    assert torch.equal(first.detach(), second.detach())
+    opt.zero_grad()
+    second.backward()
+    for p, w in zip(model.parameters(), want_other):
+        if w is not None:
+            assert torch.equal(p.grad, w)
 
 
 def test_gfv_adam_equals_torch_adam_and_exchanges_state():
