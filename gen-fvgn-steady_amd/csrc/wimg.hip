@@ -45,51 +45,6 @@ __global__ __launch_bounds__(256) void wabsmax_kernel(const gfv_wimg_desc_t* __r
   }
 }
 
-// The same maximum without a memset in front and without atomics on the result (round 5: the fill + this launch + the image launch are
-// the chain the first encoder launch of a step waits for): every workgroup leaves its maximum in ws[1 + workgroup], the one that
-// arrives LAST (ws[0]: an unsigned counter it sets back to 0) folds them and WRITES *wmax.  ws: 1 + 4 n_desc words, zero before the
-// first call.
-__global__ __launch_bounds__(256) void wabsmax_ws_kernel(const gfv_wimg_desc_t* __restrict__ descs, float* __restrict__ wmax,
-                                                         float* __restrict__ ws) {
-  const gfv_wimg_desc_t d = descs[blockIdx.y];
-  float m = 0.f;
-  if (d.ldw == d.K && ((d.N * d.K) & 3) == 0 && (reinterpret_cast<size_t>(d.W) & 15) == 0) {
-    const int total4 = (d.N * d.K) >> 2;
-    const float4* w4 = reinterpret_cast<const float4*>(d.W);
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < total4; i += gridDim.x * 256) {
-      const float4 v = w4[i];
-      m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
-    }
-  } else {
-    for (int n = blockIdx.x * 4 + (threadIdx.x >> 6); n < d.N; n += gridDim.x * 4)
-      for (int k = threadIdx.x & 63; k < d.K; k += 64) m = fmaxf(m, fabsf(d.W[(size_t)n * d.ldw + k]));
-  }
-  m = gfv_wave_max(m);
-  __shared__ float wm[4];
-  __shared__ int last;
-  if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
-  __syncthreads();
-  const unsigned nwg = gridDim.x * gridDim.y, wg = blockIdx.y * gridDim.x + blockIdx.x;
-  if (threadIdx.x == 0) {
-    ws[1 + wg] = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
-    __threadfence();
-    last = atomicAdd(reinterpret_cast<unsigned*>(ws), 1u) == nwg - 1;
-  }
-  __syncthreads();
-  if (!last) return;
-  __threadfence();
-  float t = 0.f;
-  for (unsigned i = threadIdx.x; i < nwg; i += 256) t = fmaxf(t, __hip_atomic_load(ws + 1 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-  t = gfv_wave_max(t);
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = t;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    *wmax = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
-    *reinterpret_cast<unsigned*>(ws) = 0u;
-  }
-}
-
 // one thread = one (pass, T, nt, lane) fragment, both parts (bf: the bf16 single-product form - the high part in bf16, no low part)
 __global__ __launch_bounds__(256) void wimg_kernel(const gfv_wimg_desc_t* __restrict__ descs, const float* __restrict__ wmax, int bf) {
   const gfv_wimg_desc_t d = descs[blockIdx.y];
@@ -127,15 +82,6 @@ extern "C" int gfv_weight_absmax(const gfv_wimg_desc_t* descs_dev, int32_t n_des
   if (gfv_memset_rec(wmax, 0, sizeof(float), (hipStream_t)stream) != hipSuccess) return GFV_ERR_LAUNCH;   // (recordable: gfv_launch.h)
   if (n_desc == 0) return GFV_OK;
   GFV_LAUNCH(wabsmax_kernel, dim3(4, n_desc), dim3(256), 0, (hipStream_t)stream, descs_dev, wmax);
-  GFV_CHECK_LAUNCH();
-  return GFV_OK;
-}
-
-extern "C" int gfv_weight_absmax_ws_floats(int32_t n_desc) { return 1 + 4 * (n_desc > 0 ? n_desc : 0); }
-extern "C" int gfv_weight_absmax_ws(const gfv_wimg_desc_t* descs_dev, int32_t n_desc, float* wmax, float* ws, void* stream) {
-  GfvProfScope ps_(GFV_K_WIMG, 0, 4.0 * 1181539.0, stream);
-  if (!descs_dev || !wmax || !ws || n_desc < 1) return GFV_ERR_ARG;
-  GFV_LAUNCH(wabsmax_ws_kernel, dim3(4, n_desc), dim3(256), 0, (hipStream_t)stream, descs_dev, wmax, ws);
   GFV_CHECK_LAUNCH();
   return GFV_OK;
 }

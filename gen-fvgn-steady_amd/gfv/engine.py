@@ -153,12 +153,7 @@ class Engine:
         # 8 meshes per GPU; on the 5 k-cell cavity the three small-tile launches are as fast: profiles/r05_ab_transmlp.txt)
         self._trans_fuse_min = int(os.environ.get("GFV_TRANS_FUSE_MIN_M", "16385"))
         # the FORWARD chain has a small-tile form as well (csrc/ctrans.hip, up to GFV_CTRANS_MAX_M rows): fused at every size
-        self._trans_fuse_fwd_small = os.environ.get("GFV_CTRANS", "1") != "0"
-        # up to this many token chunks per graph the attention workgroups sum the chunk partials themselves (the kernels walk them,
-        # eight loads in flight) instead of a pre-reduction launch of its own.  Measured in round 6 on the 5 k-cell cavity (81 chunks):
-        # the attention launch 6.7 -> 17.8 us forward, 11 -> 21 us backward, against 4.6 us for the pre-reduction launch it saves
-        # (profiles/r06_timeline_cavity_merged_first.txt): off
-        self._slice_walk_max = int(os.environ.get("GFV_SLICE_WALK_MAX", "0"))
+        self._trans_fuse_fwd_small = bool(L.get_limit("GFV_CTRANS")) if torch.cuda.is_available() else True
         self._trans_reduce_merge = os.environ.get("GFV_TRANS_REDUCE_MERGE", "1") != "0"
         # the end of the backward: how many of the trailing weight-gradient flushes run on the MAIN stream (GFV_TAIL_MAIN: 1 = the last
         # encoder's, 2 = both encoders', 3 = the first GnBlock's too) and how the first GnBlock's flush is split between the streams
@@ -169,9 +164,7 @@ class Engine:
         # against 2.005 the other way round (latency-bound and bandwidth-bound ends) - interleaved on one box
         self._tail_env = ("GFV_TAIL_MAIN" in os.environ) or ("GFV_TAIL_SPLIT" in os.environ)
         self._tail_main = int(os.environ.get("GFV_TAIL_MAIN", "2"))
-        self._split_all = int(os.environ.get("GFV_SPLIT_ALL", "0"))     # (experiment) the same split for every GnBlock's flush
         self._tail_split = int(os.environ.get("GFV_TAIL_SPLIT", "1"))   # last GnBlock's flush: 1 / 2 = its first / its other pieces on main
-        self._enc_order = int(os.environ.get("GFV_ENC_ORDER", "1"))
         self._fuse_noout = os.environ.get("GFV_FUSE_NOOUT", "1") != "0"   # ... also where the input needs no gradient (encoders)
         # (round 5: 2 048 instead of 16 384 rows - on a 5 k-cell mesh the persistent backward with one tile per workgroup takes
         # 26 - 31 us per launch where the row-owner dX chain took 33 - 41 and left three weight-gradient tiles to the side queue:
@@ -210,7 +203,7 @@ class Engine:
             if not e.overlap:
                 return self
             if e._side is None:
-                e._side = pick_concurrent_stream(int(os.environ.get("GFV_SIDE_PRIO", "0")))
+                e._side = pick_concurrent_stream()
                 # ONE side queue: the weight-gradient launches share one slab workspace and the stand-in gradient blocks, so
                 # two side queues would race on them (the several-queues experiment of round 2 is gone with its knob)
                 e._sides = [e._side]
@@ -325,27 +318,20 @@ class Engine:
         key = self._pkey(P, fresh=(phase == "fwd"))
         if self._wi_key != key:
             dev = next(iter(P.values())).device
-            self._retired.append((self._wi, self._wmax, self._wi_abs, getattr(self, "_wi_abs_ws", None)))
+            self._retired.append((self._wi, self._wmax, self._wi_abs))
             self._wmax = torch.zeros((1,), dtype=torch.float32, device=dev)
             self._wi = {ph: ops.WeightImages(dev, self._wmax) for ph in ("fwd", "bwd")}
             self._wi["fwd"].add_static(P.values())
             mats = [t for t in P.values() if t.dim() == 2 and t.stride(1) == 1]
             self._wi_abs = ops.WeightImages._upload([((t.data_ptr(), t.stride(0), t.shape[0], t.shape[1]), t) for t in mats], dev)
-            self._wi_abs_ws = torch.zeros((L.load().gfv_weight_absmax_ws_floats(self._wi_abs[1]),), dtype=torch.float32, device=dev)
             self._wi_key = key
         wi = self._wi[phase]
         if phase == "fwd":
-            # one power-of-two scale for all weight images of this step, from max|W| over every weight matrix
-            # (GFV_ABSMAX_WS=1: one launch - the maximum is written by the workgroup that arrives last, no fill in front)
-            # (GFV_ABSMAX_WS=1: one launch, the maximum written by the workgroup that arrives last - 13.7 us against 4.7 + 5.7 for the
-            # fill + atomic form in the step's timeline, profiles/r06_timeline_cavity_merged_first.txt: a last-arriver costs more than
-            # the kernel boundary it saves.  Opt-in)
-            if os.environ.get("GFV_ABSMAX_WS", "0") == "1":
-                L.check(L.load().gfv_weight_absmax_ws(self._wi_abs[0].data_ptr(), self._wi_abs[1], self._wmax.data_ptr(),
-                                                      self._wi_abs_ws.data_ptr(), L.stream_ptr()), "gfv_weight_absmax_ws")
-            else:
-                L.check(L.load().gfv_weight_absmax(self._wi_abs[0].data_ptr(), self._wi_abs[1], self._wmax.data_ptr(),
-                                                   L.stream_ptr()), "gfv_weight_absmax")
+            # one power-of-two scale for all weight images of this step, from max|W| over every weight matrix: a 4-byte fill + integer
+            # atomicMax on the bit pattern (order independent).  (A one-launch form - the maximum written by the workgroup that
+            # arrives last - was measured twice, neutral in round 5, 13.7 us against 4.7 + 5.7 in round 6's timeline: removed.)
+            L.check(L.load().gfv_weight_absmax(self._wi_abs[0].data_ptr(), self._wi_abs[1], self._wmax.data_ptr(),
+                                               L.stream_ptr()), "gfv_weight_absmax")
         elif not wi.static and self._wt:
             wi.add_static(self._wt.values())
             if self.recompute:
@@ -878,7 +864,7 @@ class Engine:
         # the block's weight gradients: one fork (the last block's may go to the main stream: GFV_TAIL_MAIN >= 3)
         last = self._defer_mode and getattr(self, "_last_gn", False)
         tail_main, tail_split = self._tail_cfg(pl)
-        self.flush(on_main=last and tail_main >= 3, split=tail_split if last else (self._split_all if self._defer_mode else 0))
+        self.flush(on_main=last and tail_main >= 3, split=tail_split if last else 0)
         return g_x_in, g_e_in
 
     # ------------------------------------------------------------------------------------------------------------
@@ -943,10 +929,8 @@ class Engine:
     def _graph_partials(self, partial, pl):
         """[n_chunks, 256, 17] per-chunk slice tokens -> [B, 256, 17] per-graph sums (one wide launch; the attention
         blocks - 8 per graph - then read one row instead of walking every chunk of their graph) and the chunk ranges to hand
-        the attention kernel.  Up to GFV_SLICE_WALK_MAX chunks per graph on average the attention blocks walk the chunks
-        themselves (same sums, same order per block: eight loads in flight) and the launch is saved."""
-        if pl.n_chunks <= self._slice_walk_max * pl.B:
-            return partial, pl.gchunk_ptr
+        the attention kernel.  (Letting the attention blocks walk the chunks themselves on small meshes saves the launch and costs
+        more than it: 6.7 -> 17.8 us forward, 11 -> 21 us backward at 81 chunks, profiles/r06_timeline_cavity_merged_first.txt.)"""
         out = _empty(partial.device, pl.B, 256, 17)
         L.check(L.load().gfv_reduce_partials_seg(partial.data_ptr(), pl.gchunk_ptr.data_ptr(), pl.B, 256 * 17,
                                                  out.data_ptr(), L.stream_ptr()), "reduce_partials_seg")
@@ -1413,14 +1397,9 @@ class Engine:
         # (the two encoders end the backward; running the big one - edge encoder, 75 k rows - first so that its weight
         # gradient overlaps the node encoder's chain was measured: 4.892 against 4.877 ms / step in this order)
         tail = self._tail_cfg(pl)[0] if self._defer_mode else 0   # how many of the trailing flushes run on the main stream
-        if self._enc_order == 0:
-            self.mlp3_bwd(P, sv["sv_nenc"], g_x, grads, g_add=pending)
-            self.flush(on_main=tail >= 2)
-            self.mlp3_bwd(P, sv["sv_eenc"], g_e, grads)
-        else:
-            self.mlp3_bwd(P, sv["sv_eenc"], g_e, grads)
-            self.flush(on_main=tail >= 2)
-            self.mlp3_bwd(P, sv["sv_nenc"], g_x, grads, g_add=pending)
+        self.mlp3_bwd(P, sv["sv_eenc"], g_e, grads)
+        self.flush(on_main=tail >= 2)
+        self.mlp3_bwd(P, sv["sv_nenc"], g_x, grads, g_add=pending)
         self.flush(on_main=tail >= 1)
 
     # ------------------------------------------------------------------------------------------------------------

@@ -135,6 +135,10 @@ class IntegratorFn(torch.autograd.Function):
 # (storage address of the flat gradient tensor the last ModelFn.backward handed out, positions of the parameters that got no
 # gradient - their slots hold zeros): gfv.optim.Adam feeds that tensor to its fused launch as it is
 LAST_FLAT = None
+# (GFV_DROPIN_TIMING=1: host seconds spent in the sections of the replayed autograd node, summed - profiles/tools/dropin_profile.py)
+TIMING = None
+if __import__("os").environ.get("GFV_DROPIN_TIMING") == "1":
+    TIMING = {"fwd_calls": 0, "fwd_total": 0.0, "fwd_replay": 0.0, "bwd_calls": 0, "bwd_total": 0.0, "bwd_replay": 0.0, "bwd_views": 0.0}
 
 
 def _note_flat(flat, names, skip):
@@ -193,6 +197,7 @@ class ModelFn(torch.autograd.Function):
         require_gpu(x)
         from . import cmdlist
         from . import lib as L
+        t_in = __import__("time").perf_counter() if TIMING is not None else 0.0
         P = None   # name -> detached parameter: built only where launches are issued from Python (159 detach calls: ~65 us)
         ent = None
         if cache is not None and cmdlist.active() is None and not torch.cuda.is_current_stream_capturing():
@@ -229,7 +234,10 @@ class ModelFn(torch.autograd.Function):
                 foreign = x.data_ptr() != ent.x.data_ptr()
                 if foreign:                   # another tensor than the recorded one carries the node state: through the recorded
                     ent.x.copy_(x)            # tensor and back (the reference normalises graph_node.x IN PLACE, importer.py:123-130)
+                t_r = __import__("time").perf_counter() if TIMING is not None else 0.0
                 ent.fwd.replay()
+                if TIMING is not None:
+                    TIMING["fwd_replay"] += __import__("time").perf_counter() - t_r
                 if foreign:
                     x.copy_(ent.x)
                 losses, uvp_node, uvp_cell, ea15 = ent.outs
@@ -241,12 +249,16 @@ class ModelFn(torch.autograd.Function):
             ent.pending = any(ctx.needs_input_grad)   # a backward will read the saved rows: no replay into them until it has run
         ctx.engine, ctx.plan, ctx.names, ctx.sv, ctx.P, ctx.ent = engine, plan, names, sv, P, ent
         ctx.mark_non_differentiable(uvp_node, uvp_cell, ea15)
+        if TIMING is not None:
+            TIMING["fwd_calls"] += 1
+            TIMING["fwd_total"] += __import__("time").perf_counter() - t_in
         return losses, uvp_node, uvp_cell, ea15
 
     @staticmethod
     def backward(ctx, g_losses, _gn, _gc, _ge):
         from . import cmdlist
         from . import lib as L
+        t_in = __import__("time").perf_counter() if TIMING is not None else 0.0
         P, ent = ctx.P, ctx.ent
         skip = unused_param_names(ctx.names)
         tail = (None, None, None, None, None, None, None)
@@ -274,8 +286,12 @@ class ModelFn(torch.autograd.Function):
                 ent.bwd = cl
             else:
                 ent.gloss.copy_(g_losses)
+                t_r = __import__("time").perf_counter() if TIMING is not None else 0.0
                 ent.bwd.replay()
+                if TIMING is not None:
+                    TIMING["bwd_replay"] += __import__("time").perf_counter() - t_r
         ent.pending = False
+        t_v = __import__("time").perf_counter() if TIMING is not None else 0.0
         # autograd keeps what it is handed as `.grad` (or adds it to one): a fresh flat copy per step - one launch - so that a
         # later replay never rewrites a tensor the caller still holds; its views keep the flat layout gfv.optim.Adam recognises
         flat = ent.grads.flat.clone()
@@ -284,8 +300,14 @@ class ModelFn(torch.autograd.Function):
         # the 159 views: ONE split at the (16-byte aligned) offsets, then a reshape only where the tensor is not 1-D / not padded
         # (slicing + viewing every tensor from Python was ~0.4 ms of a 2.6 ms iteration on the 5 k-cell cavity,
         # profiles/r06_dropin_host_profile.txt)
-        return tail + tuple(None if how is None else (c if how is True else c[:how[0]].view(how[1]))
-                            for c, how in zip(flat.split_with_sizes(ent.split_sizes), ent.split_how))
+        out = tail + tuple(None if how is None else (c if how is True else c[:how[0]].view(how[1]))
+                           for c, how in zip(flat.split_with_sizes(ent.split_sizes), ent.split_how))
+        if TIMING is not None:
+            now = __import__("time").perf_counter()
+            TIMING["bwd_calls"] += 1
+            TIMING["bwd_views"] += now - t_v
+            TIMING["bwd_total"] += now - t_in
+        return out
 
 
 __all__ = ["Engine", "get_plan", "GnBlockFn", "Mlp3Fn", "TransolverFn", "SimulatorFn", "IntegratorFn", "ModelFn",

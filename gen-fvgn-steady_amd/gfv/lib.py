@@ -152,8 +152,6 @@ _SIGNATURES = {
     "gfv_set_hidden_size": (C.c_int, [C.c_int32]),
     "gfv_weight_image_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
     "gfv_weight_absmax": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
-    "gfv_weight_absmax_ws_floats": (C.c_int, [C.c_int32]),
-    "gfv_weight_absmax_ws": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gfv_weight_images": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p]),
     "gfv_weight_images_form": (C.c_int, [C.c_void_p]),
     "gfv_reduce_partials_2d": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),

@@ -280,11 +280,6 @@ int gfv_set_f16split_thread(int32_t on);
 int gfv_hidden_size(void);
 int gfv_set_hidden_size(int32_t h);
 int gfv_weight_absmax(const gfv_wimg_desc_t* descs_dev, int32_t n_desc, float* wmax, void* stream);
-/* the same value with one launch instead of a fill + a launch (it is WRITTEN by the workgroup that finishes last, not accumulated):
- * ws = gfv_weight_absmax_ws_floats(n_desc) words of the caller's, zero before the first call (the launch leaves them reusable), one
- * workspace per stream that may run this concurrently; n_desc >= 1 */
-int gfv_weight_absmax_ws_floats(int32_t n_desc);
-int gfv_weight_absmax_ws(const gfv_wimg_desc_t* descs_dev, int32_t n_desc, float* wmax, float* ws, void* stream);
 /* build every image; max_frags = max over descs of gfv_weight_image_bytes / 32 */
 int gfv_weight_images(const gfv_wimg_desc_t* descs_dev, int32_t n_desc, int64_t max_frags, const float* wmax,
                       void* stream);

@@ -3,6 +3,7 @@
 cProfile, on the 5 k-cell cavity (where the iteration is host-bound) - `python profiles/tools/dropin_profile.py [cells] [gfv|torch]`."""
 import cProfile
 import os
+os.environ.setdefault("GFV_DROPIN_TIMING", "1")
 import pstats
 import sys
 import time
@@ -46,6 +47,42 @@ for _ in range(200):
     it()
 torch.cuda.synchronize()
 print(f"{cells} cells, {which} Adam: {1e3 * (time.perf_counter() - t0) / 200:.3f} ms per iteration (un-profiled)")
+from gfv import functions as GF
+if GF.TIMING:
+    T = GF.TIMING
+    n = max(T["bwd_calls"], 1)
+    print("autograd node, host ms per call: forward %.3f (list replay %.3f) | backward %.3f (list replay %.3f, gradient views %.3f)"
+          % (1e3 * T["fwd_total"] / max(T["fwd_calls"], 1), 1e3 * T["fwd_replay"] / max(T["fwd_calls"], 1), 1e3 * T["bwd_total"] / n,
+             1e3 * T["bwd_replay"] / n, 1e3 * T["bwd_views"] / n))
+# sections of the iteration, host wall time with a device synchronisation behind each (so that a section's launches are charged to it)
+import collections
+sec = collections.OrderedDict()
+
+
+def timed_it():
+    def mark(name, t0):
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        sec[name] = sec.get(name, 0.0) + (t1 - t0)
+        return t1
+    t = time.perf_counter()
+    gn.x.copy_(backup)
+    gn.norm_uvp, gn.norm_global = params.norm_uvp, params.norm_global
+    opt.zero_grad()
+    t = mark("restore + zero_grad", t)
+    lc, lx, ly, lp, un, uc = model(*graphs)
+    t = mark("model(...)", t)
+    loss = torch.mean(torch.log(params.loss_press * lp + params.loss_cont * lc + params.loss_mom * lx + params.loss_mom * ly))
+    t = mark("loss", t)
+    loss.backward()
+    t = mark("loss.backward()", t)
+    opt.step()
+    t = mark("optimizer.step()", t)
+
+
+for _ in range(100):
+    timed_it()
+print("sections, ms per iteration WITH a device synchronisation behind each: " + ", ".join(f"{k} {1e3 * v / 100:.3f}" for k, v in sec.items()))
 # host time only: the same loop WITHOUT waiting for the device at the end of each iteration
 pr = cProfile.Profile()
 pr.enable()

@@ -87,7 +87,12 @@ def test_second_forward_before_the_backward_does_not_touch_the_saved_rows():
     other = raw.clone()
     other[:, 0:3] = other[:, 0:3].flip(0) * 1.7 + 0.3   # another node state on the same mesh
 
-    def fwd(state):
+    xa = gn.x   # the tensor the recorded lists know
+
+    def fwd(state, tensor=None):
+        # (a second forward must carry its node state in ANOTHER tensor: the first call's backward reads the normalised rows of
+        # its own - overwriting them in place in between is an error in the reference as well, autograd's version check)
+        gn.x = xa if tensor is None else tensor
         gn.x.copy_(state)
         gn.norm_uvp, gn.norm_global = True, True
         o = model(*graphs)
@@ -101,8 +106,8 @@ def test_second_forward_before_the_backward_does_not_touch_the_saved_rows():
     assert any(w is not None and not torch.equal(w, v) for w, v in zip(want, want_other))
     before = model._replay.replays
     opt.zero_grad()
-    first = fwd(raw)        # replayed
-    second = fwd(other)     # the first call's backward is pending: issued eagerly, the saved rows stay the first call's
+    first = fwd(raw)                                  # replayed
+    second = fwd(other, torch.empty_like(raw))        # the first call's backward is pending: issued eagerly, nothing of the lists is touched
     assert model._replay.replays == before + 1
     first.backward()
     for p, w in zip(model.parameters(), want):

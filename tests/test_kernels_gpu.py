@@ -583,10 +583,9 @@ def test_rowtile_unsupported_shape_is_an_error_and_launches_nothing(dev, chain_m
     assert bool((out == 7.0).all()) and bool((out2 == 7.0).all()) and bool((part == 0).all())
 
 
-def test_weight_absmax_in_one_launch(dev):
-    """gfv_weight_absmax_ws: max |W| over a set of weight blocks (whole matrices and a column block of a wider one), written by
-    the workgroup that arrives last - equal to gfv_weight_absmax (a fill + atomic maxima) and to torch, call after call on the
-    same workspace."""
+def test_weight_absmax_over_blocks_and_column_blocks(dev):
+    """gfv_weight_absmax: max |W| over a set of weight blocks (whole matrices and a column block of a wider one) - a 4-byte fill +
+    integer atomic maxima on the bit pattern: equal to torch, call after call."""
     from gfv import lib as L, ops
     lib = L.load()
     g = torch.Generator(device="cpu").manual_seed(21)
@@ -596,13 +595,9 @@ def test_weight_absmax_in_one_launch(dev):
     blocks.append((mats[1][:, 128:256].data_ptr(), 384, 128, 128))        # a column block of the wide matrix
     desc, nd = ops.WeightImages._upload([(b, torch.empty(lib.gfv_weight_image_bytes(b[2], b[3]), dtype=torch.uint8, device=dev))
                                          for b in blocks], dev)
-    ws = torch.zeros(lib.gfv_weight_absmax_ws_floats(nd), device=dev)
     for rep in range(3):
         want = max(float(mats[0].abs().max()), float(mats[2].abs().max()), float(mats[3].abs().max()), float(mats[1][:, 128:256].abs().max()))
-        out = torch.full((1,), float("nan"), device=dev)
-        L.check(lib.gfv_weight_absmax_ws(desc.data_ptr(), nd, out.data_ptr(), ws.data_ptr(), L.stream_ptr()), "absmax_ws")
         ref = torch.full((1,), float("nan"), device=dev)
         L.check(lib.gfv_weight_absmax(desc.data_ptr(), nd, ref.data_ptr(), L.stream_ptr()), "absmax")
-        assert float(out) == want == float(ref), (rep, float(out), want, float(ref))
+        assert want == float(ref), (rep, want, float(ref))
         mats[3].mul_(3.0)                                                  # the next call sees other values
-    assert int(ws[:1].view(torch.int32)) == 0
