@@ -1,6 +1,7 @@
-"""The one-pass Transolver adjoint behind the attention (gfv_slice_post_bwd, csrc/slice.hip) against the four launches it
-replaces - gfv_slice_gw, gfv_deslice, gfv_slice_gw (accumulate), gfv_slice_softmax_bwd: the same terms in the same order,
-so every output agrees to rounding - and, through them, against a float64 restatement of GraphTransolver.py:64-92's adjoint."""
+"""The Transolver slice kernels (csrc/slice.hip) against FLOAT64 restatements of GraphTransolver.py:64-92 (1e-5): the one-pass
+adjoint behind the attention (gfv_slice_post_bwd) - also against the four launches it replaces (gfv_slice_gw, gfv_deslice,
+gfv_slice_gw accumulate, gfv_slice_softmax_bwd: the same terms in the same order, equal to rounding) -, the fused softmax +
+token sums, the matrix-core token sums and de-slice.  (Every assertion that carries parity here is the float64 one.)"""
 import pytest
 import torch
 
@@ -20,7 +21,7 @@ def _case(N, sizes, seed):
 
 
 @pytest.mark.parametrize("N,sizes", [(5000, [1700, 2100, 1200]), (77, [77]), (1000, [3, 500, 497]), (32, [32])])
-def test_one_pass_slice_adjoint_equals_the_four_launches(N, sizes):
+def test_one_pass_slice_adjoint_against_float64_and_the_four_launches(N, sizes):
     from gfv import lib as L
     lib = L.load()
     st = L.stream_ptr()
@@ -65,7 +66,7 @@ def test_one_pass_slice_adjoint_equals_the_four_launches(N, sizes):
 
 
 @pytest.mark.parametrize("N,sizes", [(5000, [1700, 2100, 1200]), (77, [77]), (1000, [3, 500, 497])])
-def test_matrix_core_token_and_deslice_kernels_equal_the_scalar_ones(N, sizes, monkeypatch):
+def test_matrix_core_token_and_deslice_kernels_against_float64(N, sizes):
     """gfv_slice_softmax_token (softmax + per-chunk token sums in one pass), the matrix-core form of gfv_slice_token_partial
     and of gfv_deslice against float64 statements of GraphTransolver.py:64-73,90-92."""
     from gfv import lib as L
