@@ -42,11 +42,14 @@ def it():
 for _ in range(10):
     it()
 torch.cuda.synchronize()
-t0 = time.perf_counter()
-for _ in range(200):
-    it()
-torch.cuda.synchronize()
-print(f"{cells} cells, {which} Adam: {1e3 * (time.perf_counter() - t0) / 200:.3f} ms per iteration (un-profiled)")
+for per_sync in (200, 20, 5, 20, 200):   # iterations between two device synchronisations
+    t0 = time.perf_counter()
+    for k in range(200):
+        it()
+        if (k + 1) % per_sync == 0:
+            torch.cuda.synchronize()
+    torch.cuda.synchronize()
+    print(f"{cells} cells, {which} Adam: {1e3 * (time.perf_counter() - t0) / 200:.3f} ms per iteration (un-profiled, a device synchronisation every {per_sync} iterations)")
 from gfv import functions as GF
 if GF.TIMING:
     T = GF.TIMING
