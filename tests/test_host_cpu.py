@@ -261,3 +261,24 @@ def test_bench_starts_its_own_ranks_when_called_without_a_launcher(monkeypatch):
     with pytest.raises(SystemExit) as ex:
         bench.main()
     assert not seen and "MI355X" in str(ex.value.code)
+
+
+def test_host_thread_placement_helper(tmp_path):
+    """gfv.host: CPU-list parsing, the L3 group of a CPU, pin / restore round trip (a no-op where the process already sits on one
+    L3 - this container -, never an error)."""
+    import os
+    from gfv import host
+    assert host._parse_cpu_list("0-3,8,10-11\n") == {0, 1, 2, 3, 8, 10, 11}
+    assert host._parse_cpu_list("") == set()
+    if not hasattr(os, "sched_getaffinity"):
+        return
+    before = os.sched_getaffinity(0)
+    grp = host.l3_group(min(before))
+    assert grp == set() or min(before) in grp
+    prev = host.pin_to_l3()
+    now = os.sched_getaffinity(0)
+    assert now <= before and len(now) >= 1
+    if prev is not None:
+        assert prev == before and now == (host.l3_group(os.sched_getcpu()) & before or now)
+    host.restore(prev)
+    assert os.sched_getaffinity(0) == before
