@@ -179,7 +179,8 @@ class ReplayCache:
             return None
         ent = self.entries.get(key)
         if ent is None:
-            if len(self.entries) >= 8:    # a training loop over many batches: keep the most recent few
+            if len(self.entries) >= 4:    # a training loop over many batches: keep the most recent few (a recorded entry holds
+                                          # its activations' pool: ~1 GB per 50 k-cell mesh)
                 self.entries.pop(next(iter(self.entries)))
             ent = self.entries[key] = _Replay()
             ent.plan = plan
