@@ -10,6 +10,10 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "gen-fvgn-steady_amd")]
+from gfv import host
+
+if os.environ.get("GFV_PROFILE_PIN", "1") == "1":   # the loop's two host threads on one L3, as bench.py runs it (gfv/host.py)
+    host.pin_to_l3()
 import torch
 
 import bench
@@ -49,7 +53,8 @@ for per_sync in (200, 20, 5, 20, 200):   # iterations between two device synchro
         if (k + 1) % per_sync == 0:
             torch.cuda.synchronize()
     torch.cuda.synchronize()
-    print(f"{cells} cells, {which} Adam: {1e3 * (time.perf_counter() - t0) / 200:.3f} ms per iteration (un-profiled, a device synchronisation every {per_sync} iterations)")
+    print(f"{cells} cells, {which} Adam, host threads on {len(os.sched_getaffinity(0))} CPUs: {1e3 * (time.perf_counter() - t0) / 200:.3f} ms per iteration "
+          f"(un-profiled, a device synchronisation every {per_sync} iterations)")
 from gfv import functions as GF
 if GF.TIMING:
     T = GF.TIMING
