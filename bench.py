@@ -273,7 +273,9 @@ def main():
     # host threads of the loop (this one, PyTorch's autograd thread, RCCL's proxies) on the CPUs of ONE L3: the host-bound legs (drop-in
     # on small meshes) run 20 - 30 % faster than with the threads placed freely over the box's 256 CPUs (gfv/host.py)
     from gfv import host as gfv_host
-    pinned_prev = None if args.no_pin_host else gfv_host.pin_to_l3()
+    # (several ranks on one node: rank r takes the r-th L3 group of the host, so no two ranks share one)
+    pinned_prev = None if args.no_pin_host else gfv_host.pin_to_l3(
+        rank=int(os.environ.get("LOCAL_RANK", "0")) if int(os.environ.get("WORLD_SIZE", "1")) > 1 else None)
     pinned_cpus = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

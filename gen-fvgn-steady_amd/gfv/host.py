@@ -40,13 +40,34 @@ def l3_group(cpu):
     return set()
 
 
-def pin_to_l3(cpu=None):
+def l3_groups(allowed=None):
+    """The distinct L3 groups among the allowed CPUs, in CPU order."""
+    allowed = set(os.sched_getaffinity(0)) if allowed is None else set(allowed)
+    groups, seen = [], set()
+    for c in sorted(allowed):
+        if c in seen:
+            continue
+        g = (l3_group(c) & allowed) or {c}
+        seen |= g
+        groups.append(g)
+    return groups
+
+
+def pin_to_l3(cpu=None, rank=None):
     """Confine the calling thread (and the threads it will create) to the CPUs sharing the L3 of `cpu` (default: the CPU it is
-    running on).  Returns the previous affinity set (hand it to `restore`), or None when nothing was changed."""
+    running on).  `rank` (one process per GPU on one node): the rank-th L3 group of the host instead, so that the ranks of a job
+    never share one.  Returns the previous affinity set (hand it to `restore`), or None when nothing was changed."""
     if not hasattr(os, "sched_setaffinity"):
         return None
     try:
         prev = os.sched_getaffinity(0)
+        if rank is not None:
+            groups = l3_groups(prev)
+            if len(groups) < 2:
+                return None
+            group = groups[int(rank) % len(groups)]
+            os.sched_setaffinity(0, group)
+            return prev
         cpu = os.sched_getcpu() if cpu is None and hasattr(os, "sched_getcpu") else (cpu if cpu is not None else min(prev))
         group = l3_group(cpu) & prev
         if len(group) < 2 or group == prev:

@@ -282,3 +282,10 @@ def test_host_thread_placement_helper(tmp_path):
         assert prev == before and now == (host.l3_group(os.sched_getcpu()) & before or now)
     host.restore(prev)
     assert os.sched_getaffinity(0) == before
+    groups = host.l3_groups(before)
+    assert set().union(*groups) == set(before) and sum(len(g) for g in groups) == len(before)   # a partition of the allowed CPUs
+    prev = host.pin_to_l3(rank=3)
+    if prev is not None:
+        assert os.sched_getaffinity(0) == groups[3 % len(groups)]
+    host.restore(prev)
+    assert os.sched_getaffinity(0) == before
