@@ -202,7 +202,7 @@ def drop_in_leg(device, graphs_cpu, ts_ms, steps, min_time=1.0):
             torch.cuda.synchronize()
             el += time.perf_counter() - t0
             n += steps
-        out[name] = {"ms_per_step": round(1e3 * el / n, 4), "timed_steps": n, "final_loss": round(float(loss), 6),
+        out[name] = {"ms_per_step": round(1e3 * el / n, 4), "timed_steps": n, "final_loss": round(float(loss.detach()), 6),
                      "replayed_forward_calls": model._replay.replays, "over_trainstep": round(1e3 * el / n / ts_ms, 3)}
         del model, opt, graphs
         torch.cuda.empty_cache()
