@@ -27,8 +27,10 @@
 // across tiles - profiles/tools/cfwdp - took 31.5 - 32.3 us where this kernel takes 29 - 30.6: the tile got 40 % shorter, and one
 // workgroup per CU instead of two doubled the rounds) but the latency of a tile's dependent chain times the number of rounds
 // (797 tiles on 2 x 256 slots).  32-row tiles on 8 waves at every size up to GFV_CFWD_MAX_M = 100 000 rows (beyond - 8 meshes per
-// GPU - the row-owner chain, whose 64 rows share one weight stream through LDS); the encoders' narrow inputs and the decoder up to
-// GFV_CFWD_RAG_MAX_M = 16 384 rows.  (A 64-row form on 4 waves existed through round 5: slower at every size, removed.)
+// GPU - the row-owner chain, whose 64 rows share one weight stream through LDS), the encoders' narrow inputs and the decoder
+// included (through round 5 those stopped at 16 384 rows; over eight mesh sizes from 8 k to 40 k nodes the step is 0.4 - 1.2 %
+// faster with them here at every size, profiles/r06_dispatch_sweep.txt).  (A 64-row form on 4 waves existed through round 5:
+// slower at every size, removed.)
 #include <cstdlib>
 
 #include "tchain_kernel.h"
@@ -399,7 +401,6 @@ int gfv_internal_cfwd_try(const gfv_rowtile_args_t* a, int lowp, hipStream_t str
   if (!gfv_internal_status_ptr()) return 0;   // (the kernels raise their range flag there)
   const int on = gfv_internal_limit(GFV_LIM_CFWD_ON);
   const int max_m = gfv_internal_limit(GFV_LIM_CFWD_MAX_M);
-  const int rag_max = gfv_internal_limit(GFV_LIM_CFWD_RAG_MAX_M);
   if (!on || a->nlayers != 3 || a->M > max_m || a->M < 1 || (a->flags & (GFV_CHAIN_ROW_OWNER | GFV_CHAIN_COLUMN_OWNER))) return 0;
   // the decoder's shape: no LayerNorm, a last layer of <= 16 columns, nothing else around it
   const bool dec = a->fin_op == GFV_FIN_PLAIN && a->layer[2].N >= 1 && a->layer[2].N <= 16 && !a->res[0] && !a->out_nores && !a->fin_presave &&
@@ -435,10 +436,10 @@ int gfv_internal_cfwd_try(const gfv_rowtile_args_t* a, int lowp, hipStream_t str
   } else if (a->nseg == 2 && K0 == 192 && plain(0, 64) && plain(1, 128)) {
     shape = 0;
   } else if (dec) {
-    if (plain(0, 128) && a->M <= rag_max) shape = 4;
+    if (plain(0, 128)) shape = 4;
   } else if (a->nseg == 1 && K0 == 128 && plain(0, 128)) {
     shape = 2;
-  } else if (a->nseg == 1 && K0 <= 32 && a->seg[0].width == K0 && a->M <= rag_max) {
+  } else if (a->nseg == 1 && K0 <= 32 && a->seg[0].width == K0) {
     shape = 3;
   }
   if (shape < 0) return 0;

@@ -16,6 +16,7 @@
 #include <cstdlib>
 
 #include "tchain_kernel.h"
+#include "gfv_limits.h"
 
 int* gfv_internal_status_ptr();
 extern "C" int gfv_hidden_size(void);
@@ -413,17 +414,13 @@ __global__ __launch_bounds__(256, 2) void lin1s_kernel(const Lin1sArgs A, int* s
 }
 
 inline bool l1s_al16(const void* p) { return (reinterpret_cast<size_t>(p) & 15) == 0; }
-int l1s_env(const char* n, int dflt) {
-  const char* e = getenv(n);
-  return e ? atoi(e) : dflt;
-}
 
 }  // namespace
 
 // 1: launched; 0: not a launch of this family (lin1.hip asks here first).  Same contract as gfv_internal_lin1_try.
 int gfv_internal_lin1s_try(const gfv_rowtile_args_t* a, int lowp, hipStream_t stream, int dry) {
-  static const int on = l1s_env("GFV_LIN1S", 1);
-  static const int max_m = l1s_env("GFV_LIN1S_MAX_M", 16384);
+  const int on = gfv_internal_limit(GFV_LIM_LIN1S_ON);
+  const int max_m = gfv_internal_limit(GFV_LIM_LIN1S_MAX_M);
   if (!on || a->nlayers != 1 || a->M > max_m || a->M < 1 || (a->flags & (GFV_CHAIN_ROW_OWNER | GFV_CHAIN_COLUMN_OWNER))) return 0;
   const gfv_layer_t& L = a->layer[0];
   if (!L.Wh || !a->wmax || L.save || L.bias2 && !l1s_al16(L.bias2)) return 0;

@@ -74,7 +74,8 @@ namespace {
 struct LimitDef { const char* env; int dflt; };
 const LimitDef k_limits[GFV_LIM_COUNT] = {
     {"GFV_CBWD", 1},        {"GFV_CBWD_MAX_M", 25000},      {"GFV_CFWD", 1},          {"GFV_CFWD_MAX_M", 100000},
-    {"GFV_CFWD_RAG_MAX_M", 16384},  {"GFV_CTRANS", 1},         {"GFV_CTRANS_MAX_M", 16384}};
+    {"GFV_CTRANS", 1},         {"GFV_CTRANS_MAX_M", 16384},
+    {"GFV_LIN1S", 1},       {"GFV_LIN1S_MAX_M", 16384}};
 int g_limit[GFV_LIM_COUNT];
 bool g_limit_set[GFV_LIM_COUNT];
 std::once_flag g_limit_once;

@@ -157,8 +157,8 @@ class Engine:
         self._trans_reduce_merge = os.environ.get("GFV_TRANS_REDUCE_MERGE", "1") != "0"
         # the end of the backward: how many of the trailing weight-gradient flushes run on the MAIN stream (GFV_TAIL_MAIN: 1 = the last
         # encoder's, 2 = both encoders', 3 = the first GnBlock's too) and how the first GnBlock's flush is split between the streams
-        # (GFV_TAIL_SPLIT: 0 = not at all, 1 / 2 = its first / its other pieces on main).  Unset: by launch size - (3, 0) between
-        # 30 k and 300 k edge rows, (2, 1) outside.  Measured with the round-4 kernels (the encoders' narrow weight gradients now
+        # (GFV_TAIL_SPLIT: 0 = not at all, 1 / 2 = its first / its other pieces on main).  Unset: by launch size (`_tail_cfg`: (2, 0)
+        # below 32 k edge rows, (2, 2) up to 150 k, (2, 1) above; through round 5 (3, 0) between 30 k and 300 k, (2, 1) outside).  Measured with the round-4 kernels (the encoders' narrow weight gradients now
         # take 12 - 36 us instead of 27 - 66, which left the side queue as the tail): one 50 k-cell mesh 3.704 against 3.731 ms,
         # the reference's 15 k-cell polygon mesh 3.239 against 3.280; 8 meshes 21.92 against 21.84 and the 5 k-cell cavity 2.022
         # against 2.005 the other way round (latency-bound and bandwidth-bound ends) - interleaved on one box
@@ -247,7 +247,12 @@ class Engine:
         """(GFV_TAIL_MAIN, GFV_TAIL_SPLIT) of this batch: the environment's, or by the number of edge rows (see __init__)."""
         if self._tail_env:
             return self._tail_main, self._tail_split
-        return (3, 0) if 30000 <= pl.E < 300000 else (2, 1)
+        # round 6, over thirteen meshes from 2 k to 180 k edge rows with the final kernels (profiles/r06_tail_sweep.txt): the rule of
+        # round 5 - (3, 0) between 30 k and 300 k edge rows - was the slowest or second slowest pair at every size
+        # ((3, k) with k > 0 issues the same launches as (2, k): a split flush ignores `on_main`)
+        if pl.E < 32000:
+            return 2, 0
+        return (2, 2) if pl.E < 150000 else (2, 1)
 
     def defer(self, fn, *keep):
         """Parameter-gradient work (nothing downstream of the backward chain reads it): queued and launched on the side
