@@ -9,6 +9,14 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(autouse=True)
+def _families_on(gfv_limits):
+    """These are the tests OF the small-tile families: they take their launches whatever GFV_CBWD / GFV_CFWD / GFV_CTRANS /
+    GFV_LIN1S say in the environment (the suite is also run with them switched off: the model-level tests then cover the
+    large-launch kernels at every size)."""
+    gfv_limits(GFV_CBWD=1, GFV_CFWD=1, GFV_CTRANS=1, GFV_LIN1S=1)
+
 TOL = 1e-5
 PATH = 5 + 128
 

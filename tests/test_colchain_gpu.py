@@ -237,6 +237,7 @@ def test_engine_recompute_form_and_its_fallback(dev, mode):
     res = {}
     for form in ("read", mode):
         eng = Engine()
+        eng.fuse_dw = True                               # (the recompute form IS the fused backward: GFV_FUSE_DW=0 must not reach this test)
         eng.recompute = form != "read"
         xd, god = x.to(dev), go.to(dev)
         grads = GradStore(names, [Pd[n].shape for n in names], dev)

@@ -108,7 +108,7 @@ def test_second_forward_before_the_backward_does_not_touch_the_saved_rows():
     opt.zero_grad()
     first = fwd(raw)                                  # replayed
     second = fwd(other, torch.empty_like(raw))        # the first call's backward is pending: issued eagerly, nothing of the lists is touched
-    assert model._replay.replays == before + 1
+    assert model._replay.replays == before + (1 if model._replay.enabled else 0)   # (GFV_DROPIN_REPLAY=0: both eager)
     first.backward()
     for p, w in zip(model.parameters(), want):
         assert (p.grad is None) == (w is None)
@@ -153,9 +153,11 @@ def test_gfv_adam_equals_torch_adam_and_exchanges_state():
     sd = og.state_dict()
     st = ot.state_dict()
     assert set(sd["param_groups"][0]) >= {"lr", "betas", "eps", "params"} and len(sd["param_groups"][0]["params"]) == len(st["param_groups"][0]["params"])
+    m_scale = max(float(s["exp_avg"].abs().max()) for s in st["state"].values())
     for i, s in st["state"].items():
-        # (six chaotic Adam steps apart: the moments agree as well as the gradients of the two runs do)
-        assert float((sd["state"][i]["exp_avg"] - s["exp_avg"].cpu()).abs().max()) < 2e-3 * float(s["exp_avg"].abs().max()) + 1e-12
+        # (six chaotic Adam steps apart: the moments agree as well as the gradients of the two runs do; tensors whose gradient is
+        # rounding noise of the whole computation - 1e-10 here - are held to 1e-6 of the largest moment)
+        assert float((sd["state"][i]["exp_avg"] - s["exp_avg"].cpu()).abs().max()) < 2e-3 * float(s["exp_avg"].abs().max()) + 1e-6 * m_scale
         assert float(sd["state"][i]["step"]) == float(s["step"]) == 6.0
     # resume: a new optimiser loaded from it continues exactly like the original
     m2, _ = _model()
@@ -282,11 +284,15 @@ def test_record_api_replays_ranges_and_stream_edges():
     assert lib.gfv_record_begin() == 0
     assert lib.gfv_record_replay(h, 0, cnt) != 0   # inside a recording
     # gfv.cmdlist on a thread whose library-level recording is already open: begin fails, nothing is left half-entered
-    with pytest.raises(RuntimeError):
-        with cmdlist.record():
-            pass
-    assert cmdlist.active() is None
-    lib.gfv_record_free(lib.gfv_record_end())
+    # (GFV_CMDLIST_NATIVE=0 keeps its list in Python and never opens a library-level recording: nothing to collide with)
+    try:
+        if cmdlist.NATIVE:
+            with pytest.raises(RuntimeError):
+                with cmdlist.record():
+                    pass
+        assert cmdlist.active() is None
+    finally:
+        lib.gfv_record_free(lib.gfv_record_end())
     with cmdlist.record() as cl:
         body()
     torch.cuda.synchronize()

@@ -4,6 +4,8 @@ order, so everything is compared bit for bit - through the drop-in model (forwar
 and through the fused TrainStep (losses, fields, parameters, Adam moments after several steps), on meshes with several graphs,
 mixed cell types and an OUTFLOW boundary.  The stand-alone kernels being compared against are the ones the operator tests hold to
 the oracle (tests/test_operators_gpu.py, tests/test_model_gpu.py)."""
+import os
+
 import pytest
 import torch
 
@@ -157,6 +159,11 @@ def test_recorded_step_with_delayed_side_bursts_is_bit_identical(monkeypatch):
         cl = ts._graphs[("list", False, False)][0] if ("list", False, False) in ts._graphs else next(iter(ts._graphs.values()))[0]
         res[delay] = ([ts.loss.clone(), ts.losses.clone(), ts.uvp_node.clone(), ts.flat_p.clone(), ts.flat_m.clone(), ts.flat_v.clone()],
                       getattr(cl, "delayed", 0))
-    assert res[6][1] > 0 and res[0][1] == 0      # the pass found runs to move
+    from gfv import cmdlist
+    # (the Python-level list of GFV_CMDLIST_NATIVE=0 has no such pass, GFV_OVERLAP=0 no side stream, and with the launch merges
+    # of round 6 switched off the bursts sit directly in front of joins: the two runs are then the same list)
+    eng = model.engine()
+    if cmdlist.NATIVE and eng.overlap and eng._fvm_fuse and eng._trans_reduce_merge and os.environ.get("GFV_PREP_FUSE", "1") != "0":
+        assert res[6][1] > 0 and res[0][1] == 0      # the pass found runs to move
     for a, b in zip(res[0][0], res[6][0]):
         assert torch.equal(a, b)

@@ -352,13 +352,14 @@ def test_rowtile_transolver_linears(dev):
     assert rel(dWp, Wp6.grad) < TOL and rel(dbp, bp6.grad) < TOL
 
 
-def test_rowtile_stacked_layers(dev, chain_mode):
+def test_rowtile_stacked_layers(dev, chain_mode, gfv_limits):
     """Virtual layers stacked from two weight blocks, which exist as split-fp16 images only (the blocks' images back to
     back).  Rows: two Linear layers applied to the same input in one launch (`LayerSpec(stack=, bias2=)`: the node-level
     products W1a x, W1b x of the factored EdgeBlock; in_project_fx / in_project_x of the Transolver block) - one launch per
     block when the image is missing.  Columns: the sum of two Linear layers applied to two input segments
     (`stack_cols`: the adjoint of the in_project pair)."""
     from gfv import lib as L, ops
+    gfv_limits(GFV_LIN1S=1)   # (the launch-path assertion below names the small-tile single-layer family)
     g = torch.Generator().manual_seed(5)
     M = 900
     d = lambda t: t.to(dev).contiguous()
