@@ -273,11 +273,18 @@ def main():
     # host threads of the loop (this one, PyTorch's autograd thread, RCCL's proxies) on the CPUs of ONE L3: the host-bound legs (drop-in
     # on small meshes) run 20 - 30 % faster than with the threads placed freely over the box's 256 CPUs (gfv/host.py)
     from gfv import host as gfv_host
-    # (several ranks on one node: rank r takes the r-th L3 group of the host, so no two ranks share one)
-    pinned_prev = None if args.no_pin_host else gfv_host.pin_to_l3(
-        rank=int(os.environ.get("LOCAL_RANK", "0")) if int(os.environ.get("WORLD_SIZE", "1")) > 1 else None)
-    pinned_cpus = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None
+    # (several ranks on one node: every rank takes an L3 group of its own - on its GPU's NUMA node where sysfs tells it, else the
+    # rank-th group of the host - so no two ranks share one; device PROPERTIES only are queried for that, no context is created)
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.no_pin_host:
+        pinned_prev = None
+    elif world > 1:
+        lr = int(os.environ.get("LOCAL_RANK", "0"))
+        nd = torch.cuda.device_count()
+        pinned_prev = gfv_host.pin_to_l3(rank=lr, gpu_nodes=gfv_host.gpu_numa_nodes(), device=lr % nd if nd > 0 else None)
+    else:
+        pinned_prev = gfv_host.pin_to_l3()
+    pinned_cpus = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and args.gpus != world:

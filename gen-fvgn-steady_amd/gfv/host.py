@@ -53,19 +53,70 @@ def l3_groups(allowed=None):
     return groups
 
 
-def pin_to_l3(cpu=None, rank=None):
+def numa_cpus(node):
+    """The logical CPUs of NUMA node `node` (empty set: not known)."""
+    try:
+        with open(f"/sys/devices/system/node/node{int(node)}/cpulist") as f:
+            return _parse_cpu_list(f.read())
+    except (OSError, ValueError):
+        return set()
+
+
+def gpu_numa_nodes():
+    """NUMA node of every visible GPU, by device index (-1: not known), from the PCI address the runtime reports and sysfs.
+    Queries device properties only - no context is created on the other devices.  [] when it cannot be told."""
+    try:
+        import torch
+        out = []
+        for i in range(torch.cuda.device_count()):
+            p = torch.cuda.get_device_properties(i)
+            addr = "%04x:%02x:%02x.0" % (getattr(p, "pci_domain_id", 0), p.pci_bus_id, p.pci_device_id)
+            try:
+                with open(f"/sys/bus/pci/devices/{addr}/numa_node") as f:
+                    out.append(int(f.read().strip()))
+            except (OSError, ValueError):
+                out.append(-1)
+        return out
+    except Exception:
+        return []
+
+
+def rank_l3_group(rank, allowed=None, gpu_nodes=None, device=None):
+    """The L3 group for local rank `rank` of a one-process-per-GPU job: by default the rank-th group of the host; when the NUMA
+    nodes of the GPUs are known (`gpu_nodes[device]`), a group on the GPU's OWN node - the k-th one for the k-th GPU of that node -
+    so that the launch path of a GPU on the second socket does not cross the socket link.  None: fewer than two groups."""
+    groups = l3_groups(allowed)
+    if len(groups) < 2:
+        return None
+    fallback = groups[int(rank) % len(groups)]
+    try:
+        if not gpu_nodes or device is None or not (0 <= device < len(gpu_nodes)) or gpu_nodes[device] < 0:
+            return fallback
+        node = gpu_nodes[device]
+        cpus = numa_cpus(node)
+        local = [g for g in groups if g <= cpus]
+        if not local:
+            return fallback
+        k = sum(1 for j in range(device) if gpu_nodes[j] == node)   # this GPU's position among the GPUs of its node
+        k += int(rank) // len(gpu_nodes)                             # (more ranks than GPUs - a self-test: the next group)
+        return local[k % len(local)]
+    except Exception:
+        return fallback
+
+
+def pin_to_l3(cpu=None, rank=None, gpu_nodes=None, device=None):
     """Confine the calling thread (and the threads it will create) to the CPUs sharing the L3 of `cpu` (default: the CPU it is
-    running on).  `rank` (one process per GPU on one node): the rank-th L3 group of the host instead, so that the ranks of a job
-    never share one.  Returns the previous affinity set (hand it to `restore`), or None when nothing was changed."""
+    running on).  `rank` (one process per GPU on one node): an L3 group of its own instead (`rank_l3_group`: the rank-th of the
+    host, or - `gpu_nodes` / `device` given - one on the GPU's NUMA node), so that the ranks of a job never share one.  Returns
+    the previous affinity set (hand it to `restore`), or None when nothing was changed."""
     if not hasattr(os, "sched_setaffinity"):
         return None
     try:
         prev = os.sched_getaffinity(0)
         if rank is not None:
-            groups = l3_groups(prev)
-            if len(groups) < 2:
+            group = rank_l3_group(rank, prev, gpu_nodes, device)
+            if not group:
                 return None
-            group = groups[int(rank) % len(groups)]
             os.sched_setaffinity(0, group)
             return prev
         cpu = os.sched_getcpu() if cpu is None and hasattr(os, "sched_getcpu") else (cpu if cpu is not None else min(prev))

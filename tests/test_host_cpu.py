@@ -289,3 +289,27 @@ def test_host_thread_placement_helper(tmp_path):
         assert os.sched_getaffinity(0) == groups[3 % len(groups)]
     host.restore(prev)
     assert os.sched_getaffinity(0) == before
+
+
+def test_rank_placement_follows_the_gpus_numa_node(monkeypatch):
+    """gfv.host.rank_l3_group on a made-up two-socket host (2 NUMA nodes x 4 L3 groups of 4 CPUs, GPUs 0 - 3 on node 0 and 4 - 7 on
+    node 1): every rank gets a group of its own on its GPU's node; unknown topology falls back to the rank-th group."""
+    from gfv import host
+    cpus = set(range(32))
+    monkeypatch.setattr(host, "l3_group", lambda c: set(range(4 * (c // 4), 4 * (c // 4) + 4)))
+    monkeypatch.setattr(host, "numa_cpus", lambda n: set(range(16 * n, 16 * n + 16)) if n in (0, 1) else set())
+    nodes = [0, 0, 0, 0, 1, 1, 1, 1]
+    got = [host.rank_l3_group(r, cpus, nodes, r) for r in range(8)]
+    assert len({frozenset(g) for g in got}) == 8                       # no two ranks share a group
+    for r, g in enumerate(got):
+        assert g <= host.numa_cpus(nodes[r])                            # ... and each sits on its GPU's node
+    # GPUs interleaved over the nodes: the k-th GPU of a node takes that node's k-th group
+    inter = [0, 1, 0, 1, 0, 1, 0, 1]
+    got = [host.rank_l3_group(r, cpus, inter, r) for r in range(8)]
+    assert len({frozenset(g) for g in got}) == 8 and all(g <= host.numa_cpus(inter[r]) for r, g in enumerate(got))
+    # nothing known about the GPUs (or about this one): the rank-th group of the host
+    groups = host.l3_groups(cpus)
+    assert host.rank_l3_group(5, cpus, [], 5) == groups[5] and host.rank_l3_group(5, cpus, [-1] * 8, 5) == groups[5]
+    assert host.rank_l3_group(9, cpus, None, None) == groups[9 % 8]
+    # a node whose CPUs are not among the allowed ones: fallback again
+    assert host.rank_l3_group(2, set(range(16)), [3] * 8, 2) == host.l3_groups(set(range(16)))[2]
