@@ -12,11 +12,24 @@
 
 namespace {
 
-template <int LPR>
+// LN (round 6; LPR = 16 only): the source rows are the 64-column HALVES of 128-wide pre-LayerNorm rows y (half-row c = row c >> 1,
+// columns 64 (c & 1) ..), and what is summed is LayerNorm(y) = (y - mean) * rstd * gamma + beta with the row statistics the
+// producing chain launch left behind (gfv_rowtile_args_t.fin_stats) - the expression, and so every bit, of that launch's own
+// LayerNorm output.  The EdgeBlock forward then need not write its output a second time without the residual (blocks.py:35-42
+// aggregates the MLP's output, the block returns e + output): 512 B per edge row less on a launch that runs at the rate of
+// its bytes.
+struct SegLn {
+  const float* stats;   // [rows of y][2] = (mean, 1 / std)
+  const float* gamma;   // [128]
+  const float* beta;    // [128]
+};
+
+template <int LPR, bool LN = false>
 __global__ __launch_bounds__(256) void seg_gather_sum_vec(const float* __restrict__ src, const int* __restrict__ rowptr,
                                                           const int* __restrict__ col, const float* __restrict__ scale,
                                                           const float* __restrict__ src_scale,
-                                                          float* __restrict__ out, int n_rows, int accumulate) {
+                                                          float* __restrict__ out, int n_rows, int accumulate, const SegLn ln) {
+  static_assert(!LN || LPR == 16, "LayerNorm on load: halves of 128-wide rows");
   constexpr int F = LPR * 4;
   constexpr int ROWS_PER_BLOCK = 256 / LPR;
   const int sub = threadIdx.x / LPR;
@@ -29,8 +42,26 @@ __global__ __launch_bounds__(256) void seg_gather_sum_vec(const float* __restric
     // the column indices of up to 8 entries come back in ONE round trip (clamped reads past the row end are cheap 4-B
     // loads that are never used); the gathers then go out in groups of four (tail: up to three at once).  Accumulation
     // pattern unchanged: full groups of four -> a0..a3, a tail of < 4 entries -> a0.
+    float4 lg0, lg1, lb0, lb1;   // (selected per half-row with ?: - indexing an array by cc & 1 would put it in scratch)
+    if constexpr (LN) {
+      lg0 = *reinterpret_cast<const float4*>(ln.gamma + 4 * l);
+      lg1 = *reinterpret_cast<const float4*>(ln.gamma + 64 + 4 * l);
+      lb0 = *reinterpret_cast<const float4*>(ln.beta + 4 * l);
+      lb1 = *reinterpret_cast<const float4*>(ln.beta + 64 + 4 * l);
+    }
     auto gat = [&](int cc) {
       float4 v = *reinterpret_cast<const float4*>(src + (size_t)cc * F + 4 * l);
+      if constexpr (LN) {
+        const float2 ms = *reinterpret_cast<const float2*>(ln.stats + 2 * (size_t)(cc >> 1));
+        const bool hi = (cc & 1) != 0;
+        const float4 ga = make_float4(hi ? lg1.x : lg0.x, hi ? lg1.y : lg0.y, hi ? lg1.z : lg0.z, hi ? lg1.w : lg0.w);
+        const float4 be = make_float4(hi ? lb1.x : lb0.x, hi ? lb1.y : lb0.y, hi ? lb1.z : lb0.z, hi ? lb1.w : lb0.w);
+        v.x = (v.x - ms.x) * ms.y * ga.x + be.x;
+        v.y = (v.y - ms.x) * ms.y * ga.y + be.y;
+        v.z = (v.z - ms.x) * ms.y * ga.z + be.z;
+        v.w = (v.w - ms.x) * ms.y * ga.w + be.w;
+        return v;
+      }
       if (src_scale) {
         const float sc = src_scale[cc];
         v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
@@ -408,7 +439,7 @@ extern "C" int gfv_seg_gather_sum_ex(const float* src, const int32_t* rowptr, co
   // bytes = 0.63 - 0.66 of 8 TB/s at 8 meshes per GPU on three of its four launch shapes: profiles/r04_seg_pmc_b8.txt.)
 #define LAUNCH_VEC(LPR)                                                                                       \
   GFV_LAUNCH((seg_gather_sum_vec<LPR>), dim3(gfv_xcd_grid(grid_for(n_rows, 256 / LPR))), dim3(256), 0, st, src, \
-                     rowptr, col, scale, src_scale, out, n_rows, accumulate)
+                     rowptr, col, scale, src_scale, out, n_rows, accumulate, SegLn{})
   switch (F) {
     case 4: LAUNCH_VEC(1); break;
     case 8: LAUNCH_VEC(2); break;
@@ -422,6 +453,28 @@ extern "C" int gfv_seg_gather_sum_ex(const float* src, const int32_t* rowptr, co
                          col, scale, src_scale, out, n_rows, F, accumulate);
   }
 #undef LAUNCH_VEC
+  gfv_prof_end(tok, st);
+  GFV_CHECK_LAUNCH();
+  return GFV_OK;
+}
+
+extern "C" int gfv_seg_gather_sum_ln(const float* y, const float* stats, const float* gamma, const float* beta, const int32_t* rowptr,
+                                     const int32_t* col, float* out, int32_t n_rows, int64_t nnz_hint, int64_t n_src_hint,
+                                     void* stream) {
+  if (n_rows < 0 || !y || !stats || !gamma || !beta || !rowptr || !col || !out) return GFV_ERR_ARG;
+  if (((reinterpret_cast<size_t>(y) | reinterpret_cast<size_t>(gamma) | reinterpret_cast<size_t>(beta) | reinterpret_cast<size_t>(out)) & 15) ||
+      (reinterpret_cast<size_t>(stats) & 7))
+    return GFV_ERR_ARG;
+  if (n_rows == 0) return GFV_OK;
+  hipStream_t st = (hipStream_t)stream;
+  void* tok = nullptr;
+  if (gfv_prof_enabled() && nnz_hint >= 0) {   // priced as the plain 64-wide gather (+ 8 B of statistics per source row)
+    const double rsrc = (n_src_hint >= 0 && n_src_hint < nnz_hint) ? (double)n_src_hint : (double)nnz_hint;
+    const double by = 4.0 * rsrc * 64 + 4.0 * rsrc + 4.0 * (double)nnz_hint + 4.0 * (double)n_rows * 64 + 4.0 * (double)n_rows;
+    tok = gfv_prof_begin(GFV_K_SEG, 4.0 * (double)nnz_hint * 64, by, st);
+  }
+  GFV_LAUNCH((seg_gather_sum_vec<16, true>), dim3(gfv_xcd_grid(grid_for(n_rows, 16))), dim3(256), 0, st, y, rowptr, col,
+             (const float*)nullptr, (const float*)nullptr, out, n_rows, 0, SegLn{stats, gamma, beta});
   gfv_prof_end(tok, st);
   GFV_CHECK_LAUNCH();
   return GFV_OK;

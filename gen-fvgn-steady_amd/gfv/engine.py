@@ -181,6 +181,11 @@ class Engine:
         self._prep_ws = None
         self._fvm_cnt = None
         self._fvm_fuse = os.environ.get("GFV_FVM_FUSE", "1") != "0"   # round 6: forward tail as one launch, backward as three
+        # round 6: the EdgeBlock forward does not write its LayerNorm output a second time without the residual (512 B per edge row
+        # on a launch that runs at the rate of its bytes) - the node aggregation applies the LayerNorm to the saved pre-LayerNorm rows
+        # on the way in (gfv_seg_gather_sum_ln: the launch's own expression and statistics, bit-identical sums).  Interleaved on one
+        # box: 3.59 -> 3.52 ms per step at 50 k cells, 22.6 -> 22.2 ms per step of 8 meshes
+        self._agg_ln = os.environ.get("GFV_AGG_LN", "1") != "0"
         self._side, self._sides = None, []
         self._keep = []
         # data parallel: (world, process group) set by TrainStep; the Normalizer statistics are exchanged inside the
@@ -430,9 +435,11 @@ class Engine:
                 f"{lin}.4.bias"] + ([f"{prefix}.1.weight", f"{prefix}.1.bias"] if ln else [])
 
     def mlp3_fwd(self, P, prefix, M, segs, *, ln=True, res=None, in_add=None, want_nores=False, keep=True, w1=None,
-                 padd=None, saved_segs=None):
+                 padd=None, saved_segs=None, nores_from_saved=False):
         """w1: column block of the first weight that multiplies `segs` (default: all of it); padd = (t [*,256], s, r):
-        gathered addend t[s[m], :128] + t[r[m], 128:] to the first pre-activation (factored EdgeBlock)."""
+        gathered addend t[s[m], :128] + t[r[m], 128:] to the first pre-activation (factored EdgeBlock).
+        nores_from_saved: the caller can form the output without the residual from what the launch saves anyway (pre-LayerNorm
+        rows + row statistics): where both exist the second output is not written and None is returned for it."""
         names = self._mlp_names(prefix, ln)
         W1, b1, W2, b2, W3, b3 = (P[n] for n in names[:6])
         if w1 is not None:
@@ -451,6 +458,8 @@ class Engine:
         z2 = _empty(dev, M, 128) if (keep and not lean) else None
         y3 = _empty(dev, M, 128) if (keep and ln and not lean) else None
         out = _empty(dev, M, nout)
+        if want_nores and nores_from_saved and y3 is not None and stats is not None and nout == 128:
+            want_nores = False
         nores = _empty(dev, M, 128) if want_nores else None
         ops.rowtile_chain(
             M, segs,
@@ -698,13 +707,18 @@ class Engine:
                 ops.rowtile_chain(N, [Seg(nb)], [LayerSpec(W1[:, 0:128], stack=W1[:, 128:256])],
                                   [(pab, 256), (pab.data_ptr() + 512, 256)])
             e_out, e_new, sv_e = self.mlp3_fwd(P, f"{prefix}.eb_module.net", E, [Seg(e)], res=e, want_nores=True,
-                                               w1=W1[:, 256:384], padd=(pab, pl.es, pl.er))
+                                               w1=W1[:, 256:384], padd=(pab, pl.es, pl.er), nores_from_saved=self._agg_ln)
             sv_e["nb"] = nb
         else:
             nb = ops.seg_gather_sum(x, pl.n_rowptr, pl.n_col_node, N)
             e_out, e_new, sv_e = self.mlp3_fwd(P, f"{prefix}.eb_module.net", E, [Seg(nb, pl.es), Seg(nb, pl.er), Seg(e)],
-                                               res=e, want_nores=True)
-        agg = ops.seg_gather_sum(e_new.view(2 * E, 64), pl.n_rowptr, pl.n_col_edge2, N)
+                                               res=e, want_nores=True, nores_from_saved=self._agg_ln)
+        if e_new is None:
+            # (the aggregation of blocks.py:35-42 over LayerNorm(y3), formed on the way in from the rows and statistics the launch saved)
+            ln_names = self._mlp_names(f"{prefix}.eb_module.net", True)
+            agg = ops.seg_gather_sum_ln(sv_e["y3"], sv_e["stats"], P[ln_names[6]], P[ln_names[7]], pl.n_rowptr, pl.n_col_edge2, N)
+        else:
+            agg = ops.seg_gather_sum(e_new.view(2 * E, 64), pl.n_rowptr, pl.n_col_edge2, N)
         if fuse and (self._fuse_mask & 2):
             # nbm = mean over the neighbours of the aggregates (blocks.py:44-51), in the node MLP's prologue; the launch
             # leaves the assembled rows ([N,128] buffer, columns 0:64) for the weight gradient of the first layer

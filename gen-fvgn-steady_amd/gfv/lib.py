@@ -108,6 +108,8 @@ _SIGNATURES = {
                                          C.c_int32, C.c_int32, C.c_int64, C.c_void_p]),
     "gfv_seg_gather_sum_ex": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                         C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_void_p]),
+    "gfv_seg_gather_sum_ln": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                        C.c_int64, C.c_int64, C.c_void_p]),
     "gfv_transpose_batch": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "gfv_status_flags": (C.c_int, [C.POINTER(C.c_int32)]),
     "gfv_status_mirror": (C.c_int, [C.POINTER(C.POINTER(C.c_int32))]),

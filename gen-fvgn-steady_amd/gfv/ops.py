@@ -29,6 +29,19 @@ def seg_gather_sum(src, rowptr, col, n_rows, scale=None, src_scale=None, out=Non
     return out
 
 
+def seg_gather_sum_ln(y, stats, gamma, beta, rowptr, col, n_rows, out=None):
+    """out[r] = sum_{k in row r} LayerNorm(y)[half-row col[k]]  (y [E,128] pre-LayerNorm rows + their saved (mean, 1 / std); a
+    half-row c is columns 64 (c & 1) .. of row c >> 1): include/gfv.h gfv_seg_gather_sum_ln."""
+    lib = L.load()
+    assert y.dim() == 2 and y.shape[1] == 128 and y.is_contiguous() and stats.shape == (y.shape[0], 2) and stats.is_contiguous()
+    if out is None:
+        out = torch.empty((n_rows, 64), dtype=torch.float32, device=y.device)
+    rc = lib.gfv_seg_gather_sum_ln(_p(L.f32c(y)), _p(L.f32c(stats)), _p(L.f32c(gamma)), _p(L.f32c(beta)), _p(L.i32c(rowptr)),
+                                   _p(L.i32c(col)), _p(out), n_rows, col.shape[0], 2 * y.shape[0], L.stream_ptr())
+    L.check(rc, "gfv_seg_gather_sum_ln")
+    return out
+
+
 def gather_pair(a, s, r, base=None, out=None):
     lib = L.load()
     F = a.shape[-1]

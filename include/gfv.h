@@ -62,6 +62,16 @@ int gfv_seg_gather_sum_ex(const float* src, const int32_t* rowptr, const int32_t
                           const float* src_scale, float* out, int32_t n_rows, int32_t F, int32_t accumulate,
                           int64_t nnz_hint, int64_t n_src_hint, void* stream);
 
+/* Round 6.  The same reduce over the 64-column HALVES of 128-wide rows (half-row c = row c >> 1, columns 64 (c & 1) ...: the view
+ * blocks.py:35-42 scatters to the two end nodes of an edge), with LayerNorm applied on the way in:
+ *   out[r, :] = sum_k LN(y)[half-row col[k]],   LN(y)[e, c] = (y[e, c] - mean_e) * rstd_e * gamma[c] + beta[c],
+ * y [*,128] = the pre-LayerNorm rows a chain launch saved (gfv_rowtile_args_t.fin_presave), stats [*,2] = its (mean, 1 / std)
+ * (fin_stats).  The expression is the chain launch's own, so the sums equal - bit for bit - those over its LayerNorm output,
+ * which the EdgeBlock forward then need not write a second time without the residual (512 B per edge row).  out [n_rows, 64];
+ * y, gamma, beta, out 16-byte aligned.  The two hints: as gfv_seg_gather_sum_ex (profiler only). */
+int gfv_seg_gather_sum_ln(const float* y, const float* stats, const float* gamma, const float* beta, const int32_t* rowptr,
+                          const int32_t* col, float* out, int32_t n_rows, int64_t nnz_hint, int64_t n_src_hint, void* stream);
+
 /* out[e, 0:F] = a[s[e], :], out[e, F:2F] = a[r[e], :]  (+ base[e,:] if base != NULL).  Adjoint of the
  * chunked edge->node scatter at blocks.py:34-42. */
 int gfv_gather_pair(const float* a, const int32_t* s, const int32_t* r, const float* base, float* out,

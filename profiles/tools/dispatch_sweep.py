@@ -45,7 +45,7 @@ ENGINE_SETTINGS = [   # (label, {engine attribute: value}) - the host-side switc
     ("tail=(3,0)", dict(_tail_env=True, _tail_main=3, _tail_split=0)), ("tail=(3,1)", dict(_tail_env=True, _tail_main=3, _tail_split=1)),
     ("tail=(3,2)", dict(_tail_env=True, _tail_main=3, _tail_split=2)),
     ("factor=0", dict(factor=False)), ("fvm_fuse=0", dict(_fvm_fuse=False)), ("reduce_merge=0", dict(_trans_reduce_merge=False)),
-    ("slice_fuse=0", dict(_slice_fuse=False)), ("trans_fuse=0", dict(_trans_fuse=False)), ("overlap=0", dict(overlap=False)),
+    ("agg_ln=0", dict(_agg_ln=False)), ("slice_fuse=0", dict(_slice_fuse=False)), ("trans_fuse=0", dict(_trans_fuse=False)), ("overlap=0", dict(overlap=False)),
     ("default", {}),
 ]
 

@@ -167,3 +167,64 @@ def test_recorded_step_with_delayed_side_bursts_is_bit_identical(monkeypatch):
         assert res[6][1] > 0 and res[0][1] == 0      # the pass found runs to move
     for a, b in zip(res[0][0], res[6][0]):
         assert torch.equal(a, b)
+
+
+def test_layernorm_on_load_aggregation_kernel_is_bit_identical_to_gathering_the_layernorm_output():
+    """gfv_seg_gather_sum_ln against gfv_seg_gather_sum over the LayerNorm output formed by the same fp32 expression
+    ((y - mean) * rstd * gamma + beta, one rounding per operation): rows with 0 .. 11 entries, both halves, the same CSR order."""
+    from gfv import ops
+    g = torch.Generator().manual_seed(21)
+    E, N = 5003, 1777
+    y = (torch.randn(E, 128, generator=g) * 3.0 + 0.5).cuda()
+    gamma, beta = (1.0 + 0.3 * torch.randn(128, generator=g)).cuda(), (0.2 * torch.randn(128, generator=g)).cuda()
+    mean = y.mean(1)
+    rstd = torch.rsqrt(y.var(1, unbiased=False) + 1e-5)
+    stats = torch.stack((mean, rstd), 1).contiguous()
+    ln = (y - mean[:, None]) * rstd[:, None] * gamma[None, :] + beta[None, :]
+    counts = torch.randint(0, 12, (N,), generator=g)
+    counts[5] = 0
+    rowptr = torch.zeros(N + 1, dtype=torch.int32)
+    rowptr[1:] = counts.cumsum(0).to(torch.int32)
+    col = torch.randint(0, 2 * E, (int(rowptr[-1]),), generator=g).to(torch.int32)
+    want = ops.seg_gather_sum(ln.view(2 * E, 64), rowptr.cuda(), col.cuda(), N)
+    got = ops.seg_gather_sum_ln(y, stats, gamma, beta, rowptr.cuda(), col.cuda(), N)
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
+    ref = torch.zeros(N, 64, dtype=torch.float64)
+    lnd = ln.double().cpu().view(2 * E, 64)
+    for r in range(N):
+        for k in range(int(rowptr[r]), int(rowptr[r + 1])):
+            ref[r] += lnd[int(col[k])]
+    assert float((got.double().cpu() - ref).abs().max()) < 1e-5 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("family", ["small-tile", "row-owner"])
+@pytest.mark.parametrize("case", ["cyl_cavity_b2", "cavity_mixed_b1"])
+def test_aggregation_from_the_saved_rows_is_bit_identical(case, family, gfv_limits, monkeypatch):
+    """Engine._agg_ln (GFV_AGG_LN): the EdgeBlock forward without its second, residual-free output - the node aggregation forms
+    LayerNorm(y3) on the way in - against the forward that writes it: outputs, side effects and every gradient bit for bit, with the
+    EdgeBlock MLP on the column-owner small-tile forward and on the row-owner chain (what 8 meshes per GPU run)."""
+    from gfv import ops
+    if family == "row-owner":
+        gfv_limits(GFV_CFWD=0)
+    calls = {True: 0, False: 0}
+    plain = ops.seg_gather_sum_ln
+    res = {}
+    for on in (True, False):
+        def counted(*a, _on=on, **kw):
+            calls[_on] += 1
+            return plain(*a, **kw)
+        monkeypatch.setattr(ops, "seg_gather_sum_ln", counted)
+        model, params = _model()
+        model._replay.enabled = False
+        model.engine()._agg_ln = on
+        graphs = tuple(g.clone().to("cuda") for g in cases.make_graphs(case))
+        graphs[0].norm_uvp, graphs[0].norm_global = True, True
+        o = model(*graphs)
+        torch.mean(torch.log(o[3] + 6e4 * o[0] + 5e4 * o[1] + 5e4 * o[2])).backward()
+        torch.cuda.synchronize()
+        res[on] = [t.detach().clone() for t in o] + [graphs[0].x.clone()] + [p.grad.clone() for p in model.parameters() if p.grad is not None]
+    assert calls == {True: 6, False: 0}, calls     # one aggregation per GnBlock
+    assert len(res[True]) == len(res[False])
+    for i, (a, b) in enumerate(zip(res[True], res[False])):
+        assert torch.equal(a, b), (i, float((a - b).abs().max()))
