@@ -205,8 +205,9 @@ def test_aggregation_from_the_saved_rows_is_bit_identical(case, family, gfv_limi
     LayerNorm(y3) on the way in - against the forward that writes it: outputs, side effects and every gradient bit for bit, with the
     EdgeBlock MLP on the column-owner small-tile forward and on the row-owner chain (what 8 meshes per GPU run)."""
     from gfv import ops
-    if family == "row-owner":
-        gfv_limits(GFV_CFWD=0)
+    # (the families this test is about, whatever the environment says: the row statistics the aggregation reads are saved for the
+    # small-tile backward of launches this short)
+    gfv_limits(GFV_CBWD=1, GFV_CFWD=0 if family == "row-owner" else 1)
     calls = {True: 0, False: 0}
     plain = ops.seg_gather_sum_ln
     res = {}

@@ -488,7 +488,10 @@ def test_data_parallel_trainstep_two_ranks(mode):
     m = re.search(r"DPRESULT same=(\d) param_err=(\S+) norm_err=(\S+)", r.stdout)
     assert r.returncode == 0 and m, r.stdout[-1500:] + r.stderr[-1500:]
     assert m.group(1) == "1", "ranks diverged"
-    assert float(m.group(2)) < 2e-5 and float(m.group(3)) < 1e-6, m.group(0)
+    # (the workers inherit the product form: under the single-product forms - GFV_F16SPLIT=2 / 3 - the single process on the
+    # two-mesh batch and the two ranks agree to that form's accuracy, measured 6e-5)
+    tol = 2e-5 if os.environ.get("GFV_F16SPLIT", "1") in ("0", "1") else 5e-4
+    assert float(m.group(2)) < tol and float(m.group(3)) < 1e-6, m.group(0)
 
 
 def test_command_list_recording_refuses_stray_torch_ops():
