@@ -26,7 +26,7 @@
 // What bounds the mid-size launches is NOT that weight stream (round 6: a persistent form with the slices resident in registers
 // across tiles - profiles/tools/cfwdp - took 31.5 - 32.3 us where this kernel takes 29 - 30.6: the tile got 40 % shorter, and one
 // workgroup per CU instead of two doubled the rounds) but the latency of a tile's dependent chain times the number of rounds
-// (797 tiles on 2 x 256 slots).  32-row tiles on 8 waves at every size up to GFV_CFWD_MAX_M = 200 000 rows (beyond - 8 meshes per
+// (797 tiles on 2 x 256 slots).  32-row tiles on 8 waves at every size up to GFV_CFWD_MAX_M = 250 000 rows (beyond - the edge-level launches of 8 meshes per
 // GPU - the row-owner chain, whose 64 rows share one weight stream through LDS), the encoders' narrow inputs and the decoder
 // included (through round 5 those stopped at 16 384 rows; over eight mesh sizes from 8 k to 40 k nodes the step is 0.4 - 1.2 %
 // faster with them here at every size, profiles/r06_dispatch_sweep.txt).  (A 64-row form on 4 waves existed through round 5:

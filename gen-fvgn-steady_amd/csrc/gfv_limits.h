@@ -6,7 +6,7 @@ enum {
   GFV_LIM_CBWD_ON = 0,        // GFV_CBWD            1      the column-owner small-tile backward (cbwd.hip)
   GFV_LIM_CBWD_MAX_M,         // GFV_CBWD_MAX_M      25000  ... up to this many rows; above: the persistent fused backward
   GFV_LIM_CFWD_ON,            // GFV_CFWD            1      the column-owner small-tile forward (cfwd.hip)
-  GFV_LIM_CFWD_MAX_M,         // GFV_CFWD_MAX_M      200000 (every shape: GnBlock MLPs, the encoders' narrow first layers, the decoder)
+  GFV_LIM_CFWD_MAX_M,         // GFV_CFWD_MAX_M      250000 (every shape: GnBlock MLPs, the encoders' narrow first layers, the decoder)
   GFV_LIM_CTRANS_ON,          // GFV_CTRANS          1      the small-tile Transolver chains (ctrans.hip)
   GFV_LIM_CTRANS_MAX_M,       // GFV_CTRANS_MAX_M    16384
   GFV_LIM_LIN1S_ON,           // GFV_LIN1S           1      the small-tile single-layer launches (lin1s.hip)

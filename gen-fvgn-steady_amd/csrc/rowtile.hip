@@ -73,7 +73,7 @@ extern "C" int gfv_rowtile_last_path(void) { return g_last_path; }
 namespace {
 struct LimitDef { const char* env; int dflt; };
 const LimitDef k_limits[GFV_LIM_COUNT] = {
-    {"GFV_CBWD", 1},        {"GFV_CBWD_MAX_M", 25000},      {"GFV_CFWD", 1},          {"GFV_CFWD_MAX_M", 200000},
+    {"GFV_CBWD", 1},        {"GFV_CBWD_MAX_M", 25000},      {"GFV_CFWD", 1},          {"GFV_CFWD_MAX_M", 250000},
     {"GFV_CTRANS", 1},         {"GFV_CTRANS_MAX_M", 16384},
     {"GFV_LIN1S", 1},       {"GFV_LIN1S_MAX_M", 16384}};
 int g_limit[GFV_LIM_COUNT];

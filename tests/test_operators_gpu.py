@@ -481,11 +481,16 @@ def test_data_parallel_trainstep_two_ranks(mode):
     import subprocess
     import sys
     worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "dp_gpu_worker.py")
-    port = 29600 + (os.getpid() % 300)
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                        "--master-addr", "127.0.0.1", "--master-port", str(port), worker],
-                       capture_output=True, text=True, timeout=600, env=dict(os.environ, MASTER_ADDR="127.0.0.1", GFV_TEST_MODE=mode))
-    m = re.search(r"DPRESULT same=(\d) param_err=(\S+) norm_err=(\S+)", r.stdout)
+    # (a port of its own per parametrisation; ONE more attempt on another port when the launcher produced no result line at all - a
+    # rendezvous that did not come up is the test bed's problem; a result line with wrong values is never retried)
+    for attempt in range(2):
+        port = 29600 + (os.getpid() % 300) + (0 if mode == "eager" else 311) + 523 * attempt
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                            "--master-addr", "127.0.0.1", "--master-port", str(port), worker],
+                           capture_output=True, text=True, timeout=600, env=dict(os.environ, MASTER_ADDR="127.0.0.1", GFV_TEST_MODE=mode))
+        m = re.search(r"DPRESULT same=(\d) param_err=(\S+) norm_err=(\S+)", r.stdout)
+        if m:
+            break
     assert r.returncode == 0 and m, r.stdout[-1500:] + r.stderr[-1500:]
     assert m.group(1) == "1", "ranks diverged"
     # (the workers inherit the product form: under the single-product forms - GFV_F16SPLIT=2 / 3 - the single process on the
