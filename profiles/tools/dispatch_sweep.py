@@ -46,6 +46,7 @@ ENGINE_SETTINGS = [   # (label, {engine attribute: value}) - the host-side switc
     ("tail=(3,2)", dict(_tail_env=True, _tail_main=3, _tail_split=2)),
     ("factor=0", dict(factor=False)), ("fvm_fuse=0", dict(_fvm_fuse=False)), ("reduce_merge=0", dict(_trans_reduce_merge=False)),
     ("agg_ln=0", dict(_agg_ln=False)), ("slice_fuse=0", dict(_slice_fuse=False)), ("trans_fuse=0", dict(_trans_fuse=False)), ("overlap=0", dict(overlap=False)),
+    ("defer=0", dict(_defer_mode=False)), ("fuse_dw_min=0", dict(_fuse_dw_min=0)), ("fuse_dw_min=8192", dict(_fuse_dw_min=8192)),
     ("default", {}),
 ]
 
@@ -90,12 +91,29 @@ def main():
     ap.add_argument("--families", default="cbwd,ctrans,lin1s,cfwd")
     ap.add_argument("--engine", action="store_true", help="sweep the host-side switches of gfv/engine.py instead of the limits")
     ap.add_argument("--workload", default="cylinder")
+    ap.add_argument("--cbwd-node", action="store_true",
+                    help="the NODE-level 3-layer backward alone: persistent fused backward (limit 0) | small-tile cbwd for the node rows "
+                         "only (limit N + 1) | for node and edge rows (limit 2^30)")
     ap.add_argument("--tail", action="store_true", help="only the (GFV_TAIL_MAIN, GFV_TAIL_SPLIT) pairs, as one table over the sizes")
     args = ap.parse_args()
     import bench
     from gfv import host
     host.pin_to_l3()
     fams = args.families.split(",")
+    if args.cbwd_node:
+        print("# ms per fused training step; GFV_CBWD_MAX_M = 0 (persistent backward at both levels) | N + 1 (cbwd for the node-level "
+              "MLPs only) | 2^30 (cbwd at both levels); 'shipped' = 25 000")
+        print("%8s %7s %7s %9s %9s %9s %9s" % ("cells", "N", "E", "shipped", "none", "node", "both"), flush=True)
+        for cells in [int(c) for c in args.cells.split(",")]:
+            graphs_cpu, sz = bench.build_workload(args.workload, cells, 1, 0, torch.device("cuda"))
+            graphs = tuple(g.clone().to("cuda") for g in graphs_cpu)
+            row = [time_setting(graphs, lim, None, False, args.steps)[0]
+                   for lim in ({}, dict(GFV_CBWD_MAX_M=0), dict(GFV_CBWD_MAX_M=sz["N"] + 1), dict(GFV_CBWD_MAX_M=BIG))]
+            print("%8d %7d %7d " % (sz["C"], sz["N"], sz["E"]) + " ".join("%9.4f" % v for v in row), flush=True)
+            del graphs, graphs_cpu
+            gc.collect()
+            torch.cuda.empty_cache()
+        return
     if args.tail:
         pairs = [(2, 0), (2, 1), (2, 2), (3, 0), (3, 1), (3, 2), (1, 0)]
         print("# ms per fused training step, (GFV_TAIL_MAIN, GFV_TAIL_SPLIT) forced; 'rule' = gfv/engine.py _tail_cfg as shipped")
